@@ -1,0 +1,97 @@
+"""ctypes binding of libdas_hip.so (the C ABI declared in include/das_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or does not export
+every symbol the header declares, importing the ops fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdas_hip.so')
+
+DAS_OK, DAS_ERR_ARG, DAS_ERR_LAUNCH = 0, 1, 2
+DAS_F32, DAS_BF16 = 0, 1
+DAS_MAX_LEVELS = 5
+
+vp, i32, f32, i64 = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+
+class DasConvDesc(C.Structure):
+    _fields_ = [('dtype', i32), ('out_dtype', i32),
+                ('B', i32), ('H', i32), ('W', i32), ('Cin', i32), ('x_pix_stride', i32),
+                ('Ho', i32), ('Wo', i32), ('Cout', i32), ('y_pix_stride', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
+                ('relu_in', i32), ('relu', i32),
+                ('scale', vp), ('shift', vp), ('residual', vp), ('res_pix_stride', i32), ('stats', vp)]
+
+
+class DasHeadAssembleDesc(C.Structure):
+    _fields_ = [('J', i32), ('root_idx', i32), ('raw_ps', i32), ('off_c', i32), ('depth_c', i32), ('uvd_c', i32),
+                ('sigma_c', i32), ('scale_off', f32), ('scale_depth', f32), ('scale_uv', f32), ('scale_d', f32)]
+
+
+class DasDecodeDesc(C.Structure):
+    _fields_ = [('B', i32), ('J', i32), ('num_levels', i32),
+                ('H', i32 * DAS_MAX_LEVELS), ('W', i32 * DAS_MAX_LEVELS), ('stride', i32 * DAS_MAX_LEVELS),
+                ('cls', vp * DAS_MAX_LEVELS), ('ctr', vp * DAS_MAX_LEVELS), ('pose', vp * DAS_MAX_LEVELS),
+                ('cls_ps', i32 * DAS_MAX_LEVELS), ('ctr_ps', i32 * DAS_MAX_LEVELS), ('pose_ps', i32 * DAS_MAX_LEVELS),
+                ('nms_pre', i32), ('nms_post', i32), ('score_thr', f32), ('nms_thr', f32), ('scale_factor', vp)]
+
+
+# name -> (restype, argtypes); must list every function include/das_hip.h declares
+SIGNATURES = {
+    'das_abi_version': (i32, []),
+    'das_target_arch': (C.c_char_p, []),
+    'das_conv2d_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), vp]),
+    'das_pack_nchw_to_nhwc': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'das_unpack_nhwc_to_nchw': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'das_maxpool3x3s2': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'das_upsample_bilinear_ac': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'das_add_upsample_nearest': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'das_add3': (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
+    'das_bn_train_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp]),
+    'das_groupnorm_nhwc': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
+    'das_deform_im2col3x3': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'das_offset_sample': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'das_sigmoid_blend': (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
+    'das_head_assemble': (i32, [vp, vp, vp, i64, C.POINTER(DasHeadAssembleDesc), vp]),
+    'das_head_finalize': (i32, [vp, vp, i64, i32, i32, i32, f32, f32, f32, i32, vp]),
+    'das_decode_cap': (i32, [C.POINTER(DasDecodeDesc)]),
+    'das_decode_ws_bytes': (i64, [i32, i32, i32]),
+    'das_decode': (i32, [C.POINTER(DasDecodeDesc), vp, vp, vp, vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class DasHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdas_hip.so and bind every declared entry point. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DasHipError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C das_amd/csrc`. das_amd has no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DasHipError(f'libdas_hip.so does not export {name}') from e
+        fn.restype, fn.argtypes = res, args
+    if lib.das_abi_version() != 1:
+        raise DasHipError('libdas_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != DAS_OK:
+        raise DasHipError(f'{what} failed: ' + {DAS_ERR_ARG: 'DAS_ERR_ARG (unsupported shape/dtype/alignment)',
+                                                  DAS_ERR_LAUNCH: 'DAS_ERR_LAUNCH (HIP launch error)'}.get(
+                                                      status, str(status)))

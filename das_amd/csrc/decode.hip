@@ -1,0 +1,217 @@
+// Fused per-image decode: sigmoid scores -> threshold -> per-level top-k -> gather + affine
+// -> stable descending sort -> greedy OKS-NMS -> first nms_post survivors.
+// (das_head.py:690-796 `_get_poses_single`, pose_nms.py:51-126.) One 1024-thread workgroup per
+// image; candidate keys live in LDS (128 KiB). Integer/ordering work is exact:
+// key = (score bits << 32) | ~flat_index, so "higher score first, then lower flat index".
+// Thresholding before the per-level top-k is equivalent to the reference's order (top-k first,
+// threshold after concat) because the threshold is applied to the same score.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 1024;
+constexpr int LDS_KEYS = 16384;  // max locations of one level (128 KiB of u64 keys)
+
+__host__ __device__ inline long long ws_bytes_per_image(int cap, int J) {
+  long long per = (long long)cap * 8 + (long long)cap * J * 4 * 3 + (long long)cap * 4 + (long long)cap * 12 + cap;
+  return (per + 255) / 256 * 256;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ void bitonic_sort_desc(unsigned long long* keys, int P) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < P; i += TPB) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], b = keys[ixj];
+          const bool desc = ((i & k) == 0);
+          if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __restrict__ out_scores,
+                                                     float* __restrict__ out_poses, float* __restrict__ out_centers,
+                                                     int* __restrict__ out_index, int* __restrict__ out_count,
+                                                     char* __restrict__ ws, int cap) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+  __shared__ int s_n, s_sel, s_kept;
+  const int b = blockIdx.x, tid = threadIdx.x, J = d.J;
+  // per-image workspace: merged keys [cap] u64, kx/ky [cap*J] f32, area [cap] f32, center [cap*3], z [cap*J],
+  // suppressed [cap] u8, keep [nms_post] int
+  char* w = ws + (size_t)b * ws_bytes_per_image(cap, J);
+  unsigned long long* mkeys = reinterpret_cast<unsigned long long*>(w);
+  float* kx = reinterpret_cast<float*>(mkeys + cap);
+  float* ky = kx + (size_t)cap * J;
+  float* kz = ky + (size_t)cap * J;
+  float* area = kz + (size_t)cap * J;
+  float* cen = area + cap;
+  unsigned char* sup = reinterpret_cast<unsigned char*>(cen + (size_t)cap * 3);
+
+  int total = 0, point_base = 0;
+  for (int l = 0; l < d.num_levels; ++l) {
+    const int npts = d.H[l] * d.W[l];
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const float* cls = d.cls[l] + (size_t)b * npts * d.cls_ps[l];
+    const float* ctr = d.ctr[l] + (size_t)b * npts * d.ctr_ps[l];
+    for (int i = tid; i < npts; i += TPB) {
+      const float s = sigmoidf_(cls[(size_t)i * d.cls_ps[l]]) * sigmoidf_(ctr[(size_t)i * d.ctr_ps[l]]);
+      if (s > d.score_thr) {
+        const int pos = atomicAdd(&s_n, 1);
+        keys[pos] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(~(unsigned)(point_base + i));
+      }
+    }
+    __syncthreads();
+    int n = s_n;
+    if (d.nms_pre > 0 && npts > d.nms_pre && n > d.nms_pre) {
+      int P = 1;
+      while (P < n) P <<= 1;
+      for (int i = n + tid; i < P; i += TPB) keys[i] = 0ull;
+      __syncthreads();
+      bitonic_sort_desc(keys, P);
+      n = d.nms_pre;
+    }
+    for (int i = tid; i < n; i += TPB) mkeys[total + i] = keys[i];
+    total += n;
+    point_base += npts;
+    __syncthreads();
+  }
+
+  // ---- global order: score desc, flat index asc
+  int P = 1;
+  while (P < total) P <<= 1;
+  for (int i = tid; i < P; i += TPB) keys[i] = i < total ? mkeys[i] : 0ull;
+  __syncthreads();
+  if (total > 1) bitonic_sort_desc(keys, P);
+
+  // ---- gather + affine per candidate (das_head.py:725-743)
+  const float sx = d.scale_factor[b * 2], sy = d.scale_factor[b * 2 + 1];
+  const float zs = sqrtf(sx * sy);
+  for (int c = tid; c < total; c += TPB) {
+    const unsigned flat = ~(unsigned)(keys[c] & 0xffffffffull);
+    int l = 0, base = 0;
+    while (l + 1 < d.num_levels && (int)flat >= base + d.H[l] * d.W[l]) { base += d.H[l] * d.W[l]; ++l; }
+    const int loc = (int)flat - base, Wl = d.W[l];
+    const int st = d.stride[l];
+    const float ptx = (float)((loc % Wl) * st + st / 2), pty = (float)((loc / Wl) * st + st / 2);
+    const float* pp = d.pose[l] + ((size_t)b * d.H[l] * Wl + loc) * d.pose_ps[l];
+    const float depth = pp[2] * zs;
+    cen[c * 3 + 0] = (ptx - pp[0]) / sx;
+    cen[c * 3 + 1] = (pty - pp[1]) / sy;
+    cen[c * 3 + 2] = depth;
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int j = 0; j < J; ++j) {
+      const float x = (pp[3 + 3 * j] + ptx) / sx, y = (pp[4 + 3 * j] + pty) / sy;
+      kx[(size_t)c * J + j] = x;
+      ky[(size_t)c * J + j] = y;
+      kz[(size_t)c * J + j] = pp[5 + 3 * j] + depth;
+      mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
+      mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+    }
+    area[c] = (mxx - mnx) * (mxy - mny);
+    sup[c] = 0;
+  }
+  if (tid == 0) s_kept = 0;
+  __syncthreads();
+
+  // ---- greedy OKS-NMS (pose_nms.py:92-126), f64 arithmetic as numpy does, f32 compare
+  const float thr32 = d.nms_thr;
+  int cur = 0;
+  while (true) {
+    if (tid == 0) {
+      int s = cur;
+      while (s < total && sup[s]) ++s;
+      s_sel = (s < total && s_kept < d.nms_post) ? s : -1;
+      if (s_sel >= 0) out_index[(size_t)b * d.nms_post + s_kept] = s_sel;  // slot id, remapped below
+      if (s_sel >= 0) ++s_kept;
+    }
+    __syncthreads();
+    const int sel = s_sel;
+    if (sel < 0) break;
+    const float ag = area[sel];
+    for (int c = sel + 1 + tid; c < total; c += TPB) {
+      if (sup[c]) continue;
+      const double denom = (double)((ag + area[c]) / 2.f) + 2.220446049250313e-16;
+      double acc = 0.0;
+      for (int j = 0; j < J; ++j) {
+        const float dx = kx[(size_t)c * J + j] - kx[(size_t)sel * J + j];
+        const float dy = ky[(size_t)c * J + j] - ky[(size_t)sel * J + j];
+        double var = 0.0256;  // (0.08*2)^2
+        if (J == 17) {
+          const double sg[17] = {.026, .025, .025, .035, .035, .079, .079, .072, .072, .062, .062, .107, .107, .087,
+                                 .087, .089, .089};
+          var = (sg[j] * 2) * (sg[j] * 2);
+        }
+        const double e = (double)(dx * dx + dy * dy) / var / denom / 2.0;
+        acc += exp(-e);
+      }
+      const float iou = (float)(acc / (double)J);
+      if (!(iou <= thr32)) sup[c] = 1;
+    }
+    cur = sel + 1;
+    __syncthreads();
+  }
+
+  // ---- emit survivors in kept order
+  const int K = s_kept;
+  if (tid == 0) out_count[b] = K;
+  for (int i = tid; i < K * (J + 1); i += TPB) {
+    const int k = i / (J + 1), j = i % (J + 1);
+    const int slot = out_index[(size_t)b * d.nms_post + k];
+    if (j == J) {
+      out_scores[(size_t)b * d.nms_post + k] = __uint_as_float((unsigned)(keys[slot] >> 32));
+      out_centers[((size_t)b * d.nms_post + k) * 3 + 0] = cen[slot * 3 + 0];
+      out_centers[((size_t)b * d.nms_post + k) * 3 + 1] = cen[slot * 3 + 1];
+      out_centers[((size_t)b * d.nms_post + k) * 3 + 2] = cen[slot * 3 + 2];
+    } else {
+      float* o = out_poses + (((size_t)b * d.nms_post + k) * J + j) * 3;
+      o[0] = kx[(size_t)slot * J + j];
+      o[1] = ky[(size_t)slot * J + j];
+      o[2] = kz[(size_t)slot * J + j];
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += TPB) {
+    const int slot = out_index[(size_t)b * d.nms_post + k];
+    out_index[(size_t)b * d.nms_post + k] = (int)~(unsigned)(keys[slot] & 0xffffffffull);
+  }
+}
+}  // namespace
+
+extern "C" long long das_decode_ws_bytes(int B, int cap, int J) { return ws_bytes_per_image(cap, J) * B; }
+
+extern "C" int das_decode_cap(const DasDecodeDesc* d) {
+  int cap = 0;
+  for (int l = 0; l < d->num_levels; ++l) {
+    const int n = d->H[l] * d->W[l];
+    cap += (d->nms_pre > 0 && n > d->nms_pre) ? d->nms_pre : n;
+  }
+  return cap;
+}
+
+extern "C" int das_decode(const DasDecodeDesc* d, float* out_scores, float* out_poses, float* out_centers,
+                          int* out_index, int* out_count, void* ws, void* stream) {
+  if (!d || !out_scores || !out_poses || !out_centers || !out_index || !out_count || !ws) return DAS_ERR_ARG;
+  if (d->B < 1 || d->J < 1 || d->num_levels < 1 || d->num_levels > DAS_MAX_LEVELS || d->nms_post < 1) return DAS_ERR_ARG;
+  for (int l = 0; l < d->num_levels; ++l)
+    if (d->H[l] * d->W[l] > LDS_KEYS || !d->cls[l] || !d->ctr[l] || !d->pose[l]) return DAS_ERR_ARG;
+  const int cap = das_decode_cap(d);
+  if (cap > LDS_KEYS) return DAS_ERR_ARG;
+  const int lds = LDS_KEYS * 8;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(decode_kernel, dim3(d->B), dim3(TPB), lds, (hipStream_t)stream, *d, out_scores, out_poses,
+                     out_centers, out_index, out_count, (char*)ws, cap);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}

@@ -1,0 +1,234 @@
+// HBM-bound NHWC helper kernels: layout pack/unpack, max-pool, bilinear / nearest upsampling,
+// adds. One 16-byte channel vector per thread (8 bf16 / 4 f32), grid-stride, fully coalesced.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid_for(long long n) {
+  long long b = (n + TPB - 1) / TPB;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int H, int W, int Cpad) {
+  const long long npix = (long long)B * H * W;
+  const long long total = npix * Cpad;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int c = (int)(i % Cpad);
+    const long long pix = i / Cpad;
+    float v = 0.f;
+    if (c < C) {
+      const long long b = pix / ((long long)H * W), hw = pix - b * H * W;
+      v = x[(b * C + c) * H * W + hw];
+    }
+    Elem<T>::store(y + i, v);
+  }
+}
+
+template <typename T>
+__global__ void unpack_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W, int ps,
+                              int c0) {
+  const long long HW = (long long)H * W, total = (long long)B * C * HW;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const long long hw = i % HW, bc = i / HW;
+    const int c = (int)(bc % C);
+    const long long b = bc / C;
+    y[i] = Elem<T>::load(x + (b * HW + hw) * ps + c0 + c);
+  }
+}
+
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  const long long total = (long long)B * Ho * Wo * VC;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int v = (int)(i % VC);
+    long long pix = i / VC;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const long long b = pix / Ho;
+    float m[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int hi = ho * 2 - 1 + dy;
+      if (hi < 0 || hi >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int wi = wo * 2 - 1 + dx;
+        if (wi < 0 || wi >= W) continue;
+        float f[EPV];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + ((b * H + hi) * W + wi) * C + v * EPV), f);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) m[j] = fmaxf(m[j], f[j]);
+      }
+    }
+    *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(m);
+  }
+}
+
+// torch upsample_bilinear2d, align_corners=True (area_pixel_compute_scale: (in-1)/(out-1) in f32)
+template <typename T>
+__global__ void bilinear_ac_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho,
+                                   int Wo, float sh, float sw) {
+#pragma clang fp contract(off)
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  const long long total = (long long)B * Ho * Wo * VC;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int v = (int)(i % VC);
+    long long pix = i / VC;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const long long b = pix / Ho;
+    const float h1r = sh * ho, w1r = sw * wo;
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = (h1 < H - 1) ? 1 : 0, w1p = (w1 < W - 1) ? 1 : 0;
+    const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
+    const T* base = x + ((b * H + h1) * W + w1) * C + v * EPV;
+    float a[EPV], bb[EPV], c[EPV], d[EPV], o[EPV];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base), a);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + (long long)w1p * C), bb);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + (long long)h1p * W * C), c);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + ((long long)h1p * W + w1p) * C), d);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) o[j] = h0l * (w0l * a[j] + w1l * bb[j]) + h1l * (w0l * c[j] + w1l * d[j]);
+    *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(o);
+  }
+}
+
+// y = a + nearest(b): torch nearest index = min(floor(dst * (in/out)), in-1) with f32 scale
+template <typename T>
+__global__ void add_nearest_kernel(const T* __restrict__ a, const T* __restrict__ bsrc, T* __restrict__ y, int B,
+                                   int H, int W, int C, int Hb, int Wb, float sh, float sw) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  const long long total = (long long)B * H * W * VC;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int v = (int)(i % VC);
+    long long pix = i / VC;
+    const int w = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const long long b = pix / H;
+    const int hs = min((int)floorf(h * sh), Hb - 1), ws = min((int)floorf(w * sw), Wb - 1);
+    float fa[EPV], fb[EPV];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(a + i * EPV), fa);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(bsrc + ((b * Hb + hs) * Wb + ws) * C + v * EPV), fb);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) fa[j] += fb[j];
+    *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(fa);
+  }
+}
+
+template <typename T>
+__global__ void add3_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                            T* __restrict__ y, long long nvec, int relu) {
+  constexpr int EPV = Elem<T>::EPV;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (long long)gridDim.x * TPB) {
+    float fa[EPV], fb[EPV];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(a + i * EPV), fa);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(b + i * EPV), fb);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) fa[j] += fb[j];
+    if (c) {
+      // bf16 storage: the reference rounds (a+b) before adding c; keep that order
+      uint4 t = Elem<T>::pack(fa);
+      Elem<T>::unpack(t, fa);
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(c + i * EPV), fb);
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) fa[j] += fb[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) fa[j] = fmaxf(fa[j], 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(fa);
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                 \
+  if ((dtype) == DAS_BF16) { using T = bf16_t; CALL; } \
+  else if ((dtype) == DAS_F32) { using T = float; CALL; } \
+  else return DAS_ERR_ARG;
+
+extern "C" int das_pack_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C, int H, int W, int Cpad,
+                                     void* stream) {
+  if (!x || !y || Cpad < C) return DAS_ERR_ARG;
+  const long long total = (long long)B * H * W * Cpad;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, x,
+                                       (T*)y, B, C, H, W, Cpad));
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_unpack_nhwc_to_nchw(const void* x, float* y, int dtype, int B, int C, int H, int W, int pix_stride,
+                                       int c0, void* stream) {
+  if (!x || !y || c0 + C > pix_stride) return DAS_ERR_ARG;
+  const long long total = (long long)B * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(unpack_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
+                                       (const T*)x, y, B, C, H, W, pix_stride, c0));
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream) {
+  if (!x || !y || C % 8) return DAS_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  DISPATCH_T(dtype, {
+    const long long total = (long long)B * Ho * Wo * (C / Elem<T>::EPV);
+    hipLaunchKernelGGL(maxpool_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const T*)x,
+                       (T*)y, B, H, W, C, Ho, Wo);
+  });
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_upsample_bilinear_ac(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho,
+                                        int Wo, void* stream) {
+  if (!x || !y || C % 8) return DAS_ERR_ARG;
+  const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  DISPATCH_T(dtype, {
+    const long long total = (long long)B * Ho * Wo * (C / Elem<T>::EPV);
+    hipLaunchKernelGGL(bilinear_ac_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const T*)x,
+                       (T*)y, B, H, W, C, Ho, Wo, sh, sw);
+  });
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_add_upsample_nearest(const void* a, const void* b, void* y, int dtype, int B, int H, int W, int C,
+                                        int Hb, int Wb, void* stream) {
+  if (!a || !b || !y || C % 8) return DAS_ERR_ARG;
+  const float sh = (float)Hb / (float)H, sw = (float)Wb / (float)W;
+  DISPATCH_T(dtype, {
+    const long long total = (long long)B * H * W * (C / Elem<T>::EPV);
+    hipLaunchKernelGGL(add_nearest_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const T*)a,
+                       (const T*)b, (T*)y, B, H, W, C, Hb, Wb, sh, sw);
+  });
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_add3(const void* a, const void* b, const void* c, void* y, int dtype, long long n, int relu,
+                        void* stream) {
+  if (!a || !b || !y || n % 8) return DAS_ERR_ARG;
+  DISPATCH_T(dtype, {
+    const long long nvec = n / Elem<T>::EPV;
+    hipLaunchKernelGGL(add3_kernel<T>, dim3(grid_for(nvec)), dim3(TPB), 0, (hipStream_t)stream, (const T*)a,
+                       (const T*)b, (const T*)c, (T*)y, nvec, relu);
+  });
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_abi_version(void) { return 1; }
+extern "C" const char* das_target_arch(void) { return "gfx950"; }

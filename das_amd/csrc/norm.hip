@@ -1,0 +1,174 @@
+// Normalisation kernels over NHWC: train-mode BatchNorm finalize/apply and GroupNorm(+ReLU).
+// All HBM-bound; statistics in f32.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+inline int grid_for(long long n) {
+  long long b = (n + TPB - 1) / TPB;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, long long count, int C, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* save_mean,
+                                   float* save_invstd) {
+#pragma clang fp contract(off)
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  const float n = (float)count;
+  const float mean = stats[c] / n;
+  float var = stats[C + c] / n - mean * mean;
+  var = fmaxf(var, 0.f);
+  save_mean[c] = mean;
+  save_invstd[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = count > 1 ? var * (n / (n - 1.f)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long long count, int C,
+                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const T* __restrict__ res, int relu) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  const long long total = count * VC;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int c0 = (int)(i % VC) * EPV;
+    float f[EPV];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + i * EPV), f);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) f[j] = (f[j] - mean[c0 + j]) * invstd[c0 + j] * gamma[c0 + j] + beta[c0 + j];
+    if (res) {
+      float r[EPV];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(res + i * EPV), r);
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) f[j] += r[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) f[j] = fmaxf(f[j], 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(f);
+  }
+}
+
+// ---- GroupNorm: pass 1 = per-(image, group) sum / sumsq; pass 2 = normalise (+ReLU)
+template <typename T>
+__global__ void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int ps, int G, int pix_per_block,
+                                float* __restrict__ stats) {
+  constexpr int EPV = Elem<T>::EPV;
+  extern __shared__ float sred[];  // [2*C]
+  const int b = blockIdx.y;
+  const int VC = C / EPV;
+  for (int i = threadIdx.x; i < 2 * C; i += TPB) sred[i] = 0.f;
+  __syncthreads();
+  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = TPB / VC;
+  float s[EPV], q[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  if (pl < PL) {
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, HW);
+    for (int p = p0 + pl; p < p1; p += PL) {
+      float f[EPV];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + ((long long)b * HW + p) * ps + v * EPV), f);
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      atomicAdd(&sred[v * EPV + j], s[j]);
+      atomicAdd(&sred[C + v * EPV + j], q[j]);
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += TPB) {
+    float a = 0.f, c = 0.f;
+    for (int j = 0; j < cpg; ++j) { a += sred[g * cpg + j]; c += sred[C + g * cpg + j]; }
+    atomicAdd(&stats[((long long)b * G + g) * 2], a);
+    atomicAdd(&stats[((long long)b * G + g) * 2 + 1], c);
+  }
+}
+
+template <typename T>
+__global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int C, int ps, int G,
+                                const float* __restrict__ stats, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int relu, long long total) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV, cpg = C / G;
+  const float inv_n = 1.f / ((float)HW * (float)cpg);
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int v = (int)(i % VC);
+    const long long pix = i / VC;
+    const long long b = pix / HW;
+    float f[EPV];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + pix * ps + v * EPV), f);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const int c = v * EPV + j, g = c / cpg;
+      const float mean = stats[(b * G + g) * 2] * inv_n;
+      const float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+      const float o = (f[j] - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
+      f[j] = relu ? fmaxf(o, 0.f) : o;
+    }
+    *reinterpret_cast<uint4*>(y + pix * ps + v * EPV) = Elem<T>::pack(f);
+  }
+}
+}  // namespace
+
+extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
+                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  float momentum, float eps, const void* residual, int relu, float* save_mean,
+                                  float* save_invstd, void* stream) {
+  if (!x || !y || !stats || !gamma || !beta || !save_mean || !save_invstd || C % 8 || count <= 0) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, s, stats, count, C, running_mean,
+                     running_var, momentum, eps, save_mean, save_invstd);
+  if (dtype == DAS_BF16) {
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(count * (C / 8))), dim3(TPB), 0, s, (const bf16_t*)x,
+                       (bf16_t*)y, count, C, save_mean, save_invstd, gamma, beta, (const bf16_t*)residual, relu);
+  } else if (dtype == DAS_F32) {
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(count * (C / 4))), dim3(TPB), 0, s, (const float*)x,
+                       (float*)y, count, C, save_mean, save_invstd, gamma, beta, (const float*)residual, relu);
+  } else {
+    return DAS_ERR_ARG;
+  }
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, int B, int HW, int C, int pix_stride, int G,
+                                  const float* gamma, const float* beta, float eps, int relu, float* stats_ws,
+                                  void* stream) {
+  if (!x || !y || !gamma || !beta || !stats_ws || C % 8 || C % G || pix_stride % 8 || C > 2048) return DAS_ERR_ARG;
+  const int epv = dtype == DAS_BF16 ? 8 : 4;
+  if ((C / epv) > TPB) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * B * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  // enough blocks to fill the chip, at least 64 pixels per block
+  int chunks = (256 * 4 + B - 1) / B;
+  int ppb = (HW + chunks - 1) / chunks;
+  if (ppb < 64) ppb = 64;
+  chunks = (HW + ppb - 1) / ppb;
+  const long long total = (long long)B * HW * (C / epv);
+  if (dtype == DAS_BF16) {
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(chunks, B), dim3(TPB), 2 * C * sizeof(float), s, (const bf16_t*)x,
+                       HW, C, pix_stride, G, ppb, stats_ws);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, s, (const bf16_t*)x, (bf16_t*)y,
+                       HW, C, pix_stride, G, stats_ws, gamma, beta, eps, relu, total);
+  } else if (dtype == DAS_F32) {
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(chunks, B), dim3(TPB), 2 * C * sizeof(float), s, (const float*)x,
+                       HW, C, pix_stride, G, ppb, stats_ws);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, s, (const float*)x, (float*)y, HW,
+                       C, pix_stride, G, stats_ws, gamma, beta, eps, relu, total);
+  } else {
+    return DAS_ERR_ARG;
+  }
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}

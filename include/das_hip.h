@@ -1,0 +1,168 @@
+/*
+ * das_hip.h — C ABI of libdas_hip.so, the MI355X (gfx950) device library behind the DAS
+ * hot path (MSPN2 backbone -> FPN -> DASHead -> decode).
+ *
+ * The reference (wangzt-halo/das, a mmdet3d fork) has no native code on this path: every
+ * device op it runs is a torch/ATen or mmcv-full CUDA op reached through Python. The entry
+ * points below are therefore the ops those call sites bind, restated for NHWC tensors:
+ * plain device pointers, sizes, a hipStream_t passed as void*, int status codes. No torch
+ * types cross this boundary. All tensors are NHWC ("channels last"), row = one pixel,
+ * `*_pix_stride` = elements between consecutive pixels (>= channel count; lets an op read
+ * or write a channel slice of a wider tensor). dtype codes: DAS_F32 / DAS_BF16 storage,
+ * arithmetic always accumulates in f32.
+ *
+ * Every function is asynchronous on `stream`, never allocates, never synchronises, and
+ * returns DAS_OK or a DAS_ERR_* code (argument errors are detected before any launch).
+ */
+#ifndef DAS_HIP_H
+#define DAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAS_OK 0
+#define DAS_ERR_ARG 1      /* unsupported shape / alignment / dtype combination */
+#define DAS_ERR_LAUNCH 2   /* hipGetLastError() != hipSuccess after the launch */
+
+#define DAS_F32 0
+#define DAS_BF16 1
+
+/* Library/ABI version and the code object's target, for the loader's sanity check. */
+int das_abi_version(void);
+const char* das_target_arch(void);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA, fused epilogue.
+ * Replaces: every torch `nn.Conv2d` / mmcv `ConvModule` conv on the path
+ *   (mspn_mmpose.py:81-105,254,327-379,546; anchor_free_mono3d_pose_head.py:116-165;
+ *    das_head.py:112-161; recursive_update.py:171-180,243) together with the eval-mode
+ *   BatchNorm affine, bias add, ReLU and residual add that follow them
+ *   (mspn_mmpose.py:126-157,381-404).
+ *   y = act( (conv(act_in(x), w)) * scale[c] + shift[c] + residual )
+ * x: (B,H,W,Cin) dtype, Cin % 8 == 0.  w: (Cout,KH,KW,Cin) dtype, K-contiguous.
+ * y: (B,Ho,Wo,Cout) out_dtype. Cout % 8 == 0 (pad weights with zero rows).
+ * scale/shift: f32[Cout] or NULL. residual: same dtype/shape as y or NULL (needs
+ * out_dtype == dtype). stats: f32[2*Cout] accumulators (sum, sum of squares of the values
+ * *as stored in y before residual/relu*), or NULL — used for train-mode BatchNorm.
+ */
+typedef struct {
+  int dtype, out_dtype;
+  int B, H, W, Cin, x_pix_stride;
+  int Ho, Wo, Cout, y_pix_stride;
+  int KH, KW, stride, pad;
+  int relu_in, relu;
+  const float* scale;
+  const float* shift;
+  const void* residual;
+  int res_pix_stride;
+  float* stats;
+} DasConvDesc;
+int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream);
+
+/* Pack an NCHW f32 image batch into NHWC `dtype` with channels zero-padded to Cpad.
+ * Replaces the implicit layout of `img` entering MSPN2.forward (mspn_mmpose.py:657-662). */
+int das_pack_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C, int H, int W, int Cpad, void* stream);
+/* NHWC `dtype` (channel slice [c0, c0+C) of rows with pix_stride) -> dense NCHW f32. */
+int das_unpack_nhwc_to_nchw(const void* x, float* y, int dtype, int B, int C, int H, int W, int pix_stride,
+                            int c0, void* stream);
+
+/* 3x3 stride-2 pad-1 max pooling (mspn_mmpose.py:553 `MaxPool2d`). */
+int das_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream);
+
+/* Bilinear upsampling, align_corners=True, to (Ho,Wo) (mspn_mmpose.py:385-389). */
+int das_upsample_bilinear_ac(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho, int Wo,
+                             void* stream);
+
+/* y = a + nearest_upsample(b -> (H,W)); FPN top-down path (mmdet FPN.forward). */
+int das_add_upsample_nearest(const void* a, const void* b, void* y, int dtype, int B, int H, int W, int C,
+                             int Hb, int Wb, void* stream);
+
+/* y = a + b (+ c); c may be NULL (mspn_mmpose.py:284-285 cross-stage skip adds). n elements. */
+int das_add3(const void* a, const void* b, const void* c, void* y, int dtype, long long n, int relu, void* stream);
+
+/* Train-mode BatchNorm finalize (torch BatchNorm2d in training mode, mspn_mmpose.py:74-79):
+ * from `stats` = [sum(C), sumsq(C)] over `count` pixels compute mean / biased var,
+ * y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta + residual ), and update running stats
+ * (momentum, unbiased var). save_mean/save_invstd: f32[C] outputs for backward. */
+int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
+                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float momentum, float eps, const void* residual, int relu, float* save_mean,
+                       float* save_invstd, void* stream);
+
+/* GroupNorm (+ReLU) over NHWC (torch GroupNorm, das_head.py:54, recursive_update.py:178,244).
+ * stats workspace: f32[B*G*2], zeroed by the call. */
+int das_groupnorm_nhwc(const void* x, void* y, int dtype, int B, int HW, int C, int pix_stride, int G,
+                       const float* gamma, const float* beta, float eps, int relu, float* stats_ws,
+                       void* stream);
+
+/* DCNv2 deformable im2col (mmcv ModulatedDeformConv2dPack.forward -> modulated_deform_conv2d,
+ * das_head.py:107-108, anchor_free_mono3d_pose_head.py:111-112,131-132, recursive_update.py:177-178).
+ * x: (B,H,W,C) dtype with x_pix_stride. om: (B,H,W,om_pix_stride) f32, channels [0,18) = (dy,dx)
+ * per tap k, [18,27) = mask logits (sigmoid applied here). col: (B*H*W, 9*C) dtype, tap-major,
+ * so that DCN == das_conv2d_nhwc(1x1, Cin = 9*C) on col. 3x3, stride 1, pad 1, dilation 1. */
+int das_deform_im2col3x3(const void* x, const float* om, void* col, int dtype, int B, int H, int W, int C,
+                         int x_pix_stride, int om_pix_stride, void* stream);
+
+/* Recursive-update offset re-sampling (recursive_update.py:9-82 offset_sample/_core), fused.
+ * uvd (B,H,W,uvd_ps) f32 [J*3], samp_off (…,so_ps) f32 [J*heads*2], conf (…,conf_ps) f32 [J*3]
+ * -> out (B,H,W,out_ps) f32 [J*3]. */
+int das_offset_sample(const float* uvd, const float* samp_off, const float* conf, float* out, int B, int H,
+                      int W, int J, int heads, int uvd_ps, int so_ps, int conf_ps, int out_ps, void* stream);
+
+/* off = (1-sigmoid(w))*off + sigmoid(w)*nxt  (recursive_update.py:193-195), per pixel over C
+ * channels, all f32 with their own pixel strides. */
+int das_sigmoid_blend(const float* off, const float* w, const float* nxt, float* out, long long npix, int C,
+                      int off_ps, int w_ps, int nxt_ps, int out_ps, void* stream);
+
+/* DASHead.forward_single tail (das_head.py:237-262): per-level Scale, root-joint pinning and,
+ * in eval mode, depth/stride/z_norm rescale. raw: (npix, raw_ps) f32 with channel slices
+ * off@off_c(2), depth@depth_c(1), uvd@uvd_c(3J), sigma@sigma_c(3J).
+ * pose_pred: (npix, 3+6J) f32 = [off(2), depth, uvd(3J), sigma(3J)]; uvd_out: (npix,3J) f32 =
+ * scaled+pinned initial uvd (input of the recursive-update branch). */
+typedef struct {
+  int J, root_idx, raw_ps, off_c, depth_c, uvd_c, sigma_c;
+  float scale_off, scale_depth, scale_uv, scale_d;
+} DasHeadAssembleDesc;
+int das_head_assemble(const float* raw, float* pose_pred, float* uvd_out, long long npix,
+                      const DasHeadAssembleDesc* d, void* stream);
+/* Eval-mode overwrite (das_head.py:254-262): uvd := ref_uvd (root z = 0), u,v *= stride,
+ * dz *= z_norm, depth /= depth_factor. In train mode only pins ref root z (das_head.py:254). */
+int das_head_finalize(float* pose_pred, float* ref_uvd, long long npix, int J, int root_idx, int ref_ps,
+                      float stride, float z_norm, float depth_factor, int eval_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Decode (das_head.py:690-796 `_get_poses_single`, pose_nms.py:51-126 oks_iou / oks_nms), fused:
+ * per image  score = sigmoid(cls)*sigmoid(ctr) -> keep score > score_thr -> per level keep the
+ * nms_pre best when the level has more than nms_pre locations -> center = (point - offset)/scale,
+ * joints = (uvd + root)/scale, depth *= sqrt(sx*sy) -> order by (score desc, flat location index
+ * asc) -> greedy OKS-NMS keeping oks <= nms_thr (f64 arithmetic, f32 compare, as numpy does) ->
+ * first nms_post survivors. Inputs are the eval-mode head outputs, f32, NHWC per level:
+ * cls/ctr (B,H,W,*_ps) logits in channel 0, pose (B,H,W,pose_ps) = [off2, depth, uvd 3J, ...].
+ * Outputs (kept order, row b*nms_post + k): scores, poses (J,3), centers (3), index = flat
+ * location index over levels fine->coarse; out_count[b] = number kept.
+ */
+#define DAS_MAX_LEVELS 5
+typedef struct {
+  int B, J, num_levels;
+  int H[DAS_MAX_LEVELS], W[DAS_MAX_LEVELS], stride[DAS_MAX_LEVELS];
+  const float* cls[DAS_MAX_LEVELS];
+  const float* ctr[DAS_MAX_LEVELS];
+  const float* pose[DAS_MAX_LEVELS];
+  int cls_ps[DAS_MAX_LEVELS], ctr_ps[DAS_MAX_LEVELS], pose_ps[DAS_MAX_LEVELS];
+  int nms_pre, nms_post;
+  float score_thr, nms_thr;
+  const float* scale_factor; /* device f32[B*2]: (sx, sy) per image */
+} DasDecodeDesc;
+/* candidate capacity per image = sum over levels of min(H*W, nms_pre) */
+int das_decode_cap(const DasDecodeDesc* d);
+long long das_decode_ws_bytes(int B, int cap, int J);
+int das_decode(const DasDecodeDesc* d, float* out_scores, float* out_poses, float* out_centers, int* out_index,
+               int* out_count, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAS_HIP_H */

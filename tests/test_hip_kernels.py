@@ -1,0 +1,296 @@
+"""Kernel-level parity: every C-ABI entry point of libdas_hip.so against the CPU oracle /
+plain torch fp32 on the same seeded inputs. GPU only (`-m gpu`)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def ops():
+    from das_amd import ops as o
+    return o
+
+
+def nhwc(t, dtype=torch.float32):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(t, dtype):
+    return t.to(dtype).float()
+
+
+def tol(dtype):
+    return dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1.6e-2)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 9, 11, 16, 24, 3, 1, 1),
+    (1, 16, 20, 32, 136, 3, 1, 1),
+    (2, 17, 13, 64, 64, 1, 1, 0),
+    (2, 17, 13, 64, 256, 1, 2, 0),
+    (1, 20, 24, 8, 64, 7, 2, 3),      # stem-like, Cin not a multiple of BK
+    (3, 8, 13, 256, 256, 3, 1, 1),    # head shape at the coarsest level
+    (2, 12, 12, 48, 8, 3, 2, 1),      # tiny Cout (BN=32 path), stride-2 3x3
+    (1, 33, 47, 128, 192, 3, 2, 1),
+    (1, 5, 7, 24, 40, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_plain(case, dtype):
+    B, H, W, Cin, Cout, k, s, p = case
+    x = cases.randn(1, B, Cin, H, W)
+    w = cases.randn(2, Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    ref = F.conv2d(rnd(x, dtype), rnd(w, dtype), None, s, p)
+    o = ops()
+    y = o.conv2d(nhwc(x, dtype), o.pack_weight(w.to(DEV), dtype), k, k, s, p)
+    assert y.dtype == dtype
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_epilogue_scale_shift_residual_relu_stats(dtype):
+    B, H, W, Cin, Cout = 2, 14, 18, 64, 200
+    x, w = cases.randn(3, B, Cin, H, W), cases.randn(4, Cout, Cin, 3, 3) / 24
+    scale, shift = cases.randn(5, Cout).abs() + 0.5, cases.randn(6, Cout)
+    res = cases.randn(7, B, Cout, H, W)
+    o = ops()
+    conv = F.conv2d(rnd(x, dtype), rnd(w, dtype), None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None]
+    conv_q = rnd(conv, dtype)
+    ref = F.relu(conv_q + rnd(res, dtype))
+    stats = torch.zeros(2 * Cout, device=DEV)
+    y = o.conv2d(nhwc(x, dtype), o.pack_weight(w.to(DEV), dtype), 3, 3, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV),
+                 residual=nhwc(res, dtype), relu=True, stats=stats)
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **tol(dtype))
+    n = B * H * W
+    s_ref = torch.cat([conv_q.sum((0, 2, 3)), (conv_q ** 2).sum((0, 2, 3))])
+    np.testing.assert_allclose(stats.cpu().numpy() / n, s_ref.numpy() / n, rtol=3e-3 if dtype != torch.float32 else 1e-4,
+                               atol=3e-3 if dtype != torch.float32 else 1e-4)
+
+
+def test_conv_relu_in_slices_and_f32_out():
+    """bf16 in, f32 out (head predictors), reading a channel slice and writing into a slice."""
+    o = ops()
+    B, H, W = 2, 6, 9
+    big = cases.randn(8, B, 96, H, W)
+    w = cases.randn(9, 16, 32, 1, 1) / 6
+    xb = nhwc(big, torch.bfloat16)
+    out = torch.zeros(B, H, W, 40, device=DEV)
+    o.conv2d(xb[..., 32:64], o.pack_weight(w.to(DEV), torch.bfloat16), 1, 1, relu_in=True, out_dtype=torch.float32,
+             out=out[..., 8:24])
+    ref = F.conv2d(F.relu(rnd(big[:, 32:64], torch.bfloat16)), rnd(w, torch.bfloat16))
+    np.testing.assert_allclose(nchw(out[..., 8:24]).numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    assert float(out[..., :8].abs().max()) == 0 and float(out[..., 24:].abs().max()) == 0
+
+
+def test_conv_rejects_bad_args():
+    from das_amd import _lib
+    o = ops()
+    x = torch.zeros(1, 4, 4, 12, device=DEV)  # Cin % 8 != 0
+    w = torch.zeros(8, 1, 1, 12, device=DEV)
+    with pytest.raises(_lib.DasHipError):
+        o.conv2d(x, w, 1, 1)
+    with pytest.raises(_lib.DasHipError):
+        o.conv2d(torch.zeros(1, 4, 4, 8), torch.zeros(8, 1, 1, 8), 1, 1)  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pack_pool_upsample_add(dtype):
+    o = ops()
+    img = cases.randn(10, 2, 3, 19, 23)
+    x = o.pack_image(img.to(DEV), dtype, 8)
+    assert x.shape == (2, 19, 23, 8)
+    np.testing.assert_array_equal(nchw(x)[:, :3].numpy(), rnd(img, dtype).numpy())
+    assert float(x[..., 3:].float().abs().max()) == 0
+    np.testing.assert_array_equal(o.to_nchw_f32(x, 1, 2).cpu().numpy(), rnd(img, dtype)[:, 1:3].numpy())
+
+    a = cases.randn(11, 2, 16, 13, 17)
+    np.testing.assert_array_equal(nchw(o.maxpool3x3s2(nhwc(a, dtype))).numpy(),
+                                  F.max_pool2d(rnd(a, dtype), 3, 2, 1).numpy())
+    up = o.upsample_bilinear_ac(nhwc(a, dtype), 26, 33)
+    ref = F.interpolate(rnd(a, dtype), size=(26, 33), mode='bilinear', align_corners=True)
+    np.testing.assert_allclose(nchw(up).numpy(), ref.numpy(), **(dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32
+                                                                  else dict(rtol=8e-3, atol=8e-3)))
+    b = cases.randn(12, 2, 16, 7, 9)
+    y = o.add_upsample_nearest(nhwc(a, dtype), nhwc(b, dtype))
+    ref = rnd(rnd(a, dtype) + F.interpolate(rnd(b, dtype), size=(13, 17), mode='nearest'), dtype)
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=0, atol=0)
+    c = cases.randn(13, 2, 16, 13, 17)
+    y = o.add3(nhwc(a, dtype), nhwc(c, dtype), nhwc(a * 0.5, dtype), relu=True)
+    ref = F.relu(rnd(rnd(rnd(a, dtype) + rnd(c, dtype), dtype) + rnd(a * 0.5, dtype), dtype))
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bn_train_apply(dtype):
+    o = ops()
+    B, H, W, Cin, Cout = 3, 10, 12, 32, 64
+    x, w = cases.randn(14, B, Cin, H, W), cases.randn(15, Cout, Cin, 1, 1) / 5
+    gamma, beta = cases.randn(16, Cout).abs() + 0.5, cases.randn(17, Cout)
+    rm, rv = cases.randn(18, Cout) * 0.1, cases.randn(19, Cout).abs() + 0.5
+    res = cases.randn(20, B, Cout, H, W)
+    conv = rnd(F.conv2d(rnd(x, dtype), rnd(w, dtype)), dtype)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.relu(rnd(F.batch_norm(conv, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5), dtype) + rnd(res, dtype))
+    stats = torch.zeros(2 * Cout, device=DEV)
+    raw = o.conv2d(nhwc(x, dtype), o.pack_weight(w.to(DEV), dtype), 1, 1, stats=stats)
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    y, mean, invstd = o.bn_train_apply(raw, stats, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, residual=nhwc(res, dtype),
+                                       relu=True)
+    t = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **t)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rm_ref.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rv_ref.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(mean.cpu().numpy(), conv.mean((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,G', [(256, 32), (64, 32), (32, 32), (768, 96)])
+def test_groupnorm(dtype, C, G):
+    o = ops()
+    x = cases.randn(21, 2, C, 9, 13) * 2 + 0.5
+    gamma, beta = cases.randn(22, C), cases.randn(23, C)
+    ref = F.relu(F.group_norm(rnd(x, dtype), G, gamma, beta, 1e-5))
+    xd = nhwc(x, dtype)
+    y = o.groupnorm(xd, gamma.to(DEV), beta.to(DEV), G, relu=True, out=torch.empty_like(xd))
+    t = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1.6e-2)
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **t)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dcnv2_im2col_plus_gemm(dtype):
+    from oracle.nn_ops import modulated_deform_conv2d
+    o = ops()
+    B, C, O, H, W = 2, 32, 40, 11, 14
+    x, w, bias = cases.randn(24, B, C, H, W), cases.randn(25, O, C, 3, 3) / 17, cases.randn(26, O)
+    om = cases.randn(27, B, 27, H, W)
+    om[:, :18] *= 2.0
+    ref = modulated_deform_conv2d(rnd(x, dtype), om[:, :18], torch.sigmoid(om[:, 18:]), rnd(w, dtype), bias)
+    omd = torch.zeros(B, H, W, 32, device=DEV)
+    omd[..., :27] = om.permute(0, 2, 3, 1).to(DEV)
+    col = o.deform_im2col3x3(nhwc(x, dtype), omd)
+    wp = o.pack_weight(w.to(DEV), dtype).reshape(O, 1, 1, 9 * C)
+    y = o.conv2d(col, wp, 1, 1, shift=bias.to(DEV))
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **(dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32
+                                                                  else dict(rtol=3e-2, atol=3e-2)))
+
+
+def test_offset_sample_matches_oracle(golden_dir):
+    import os
+    from oracle.head import offset_sample
+    o = ops()
+    B, Jn, heads, h, w = 2, 3, 4, 10, 14
+    uvd, so, conf = cases.randn(31, B, Jn * 3, h, w) * 2, cases.randn(32, B, Jn * heads * 2, h, w) * 1.5, \
+        cases.randn(33, B, Jn * 3, h, w)
+    y = o.offset_sample(nhwc(uvd), nhwc(so), nhwc(conf), Jn)
+    z = np.load(os.path.join(golden_dir, 'offset_sample.npz'))
+    np.testing.assert_allclose(nchw(y).numpy(), z['out'], rtol=1e-4, atol=1e-5)  # reference fixture
+    np.testing.assert_allclose(nchw(y).numpy(), offset_sample(uvd, so, conf, Jn, heads).numpy(), rtol=1e-4, atol=1e-5)
+    # J = 15 at a full-size level, offsets large enough to leave the map
+    B, Jn, h, w = 1, 15, 32, 52
+    uvd, so, conf = cases.randn(34, B, Jn * 3, h, w) * 20, cases.randn(35, B, Jn * 8, h, w) * 6, cases.randn(36, B, Jn * 3, h, w)
+    y = o.offset_sample(nhwc(uvd), nhwc(so), nhwc(conf), Jn)
+    # values reach |80| with pixel-to-pixel slopes of ~30: f32 coordinate rounding alone moves samples by ~1e-4
+    np.testing.assert_allclose(nchw(y).numpy(), offset_sample(uvd, so, conf, Jn, 4).numpy(), rtol=1e-4, atol=2e-3)
+
+
+def test_blend_assemble_finalize():
+    o = ops()
+    J, root = 5, 2
+    B, H, W = 2, 4, 6
+    off, wl, nxt = cases.randn(37, B, 3 * J, H, W), cases.randn(38, B, 3 * J, H, W), cases.randn(39, B, 3 * J, H, W)
+    y = o.sigmoid_blend(nhwc(off), nhwc(wl), nhwc(nxt))
+    g = torch.sigmoid(wl)
+    np.testing.assert_allclose(nchw(y).numpy(), ((1 - g) * off + g * nxt).numpy(), rtol=1e-5, atol=1e-6)
+
+    raw = cases.randn(40, B, 16 + 3 * J + 1 + 3 * J + 5, H, W)
+    uvd_c, sigma_c = 16, 16 + 3 * J + 1
+    sc = (1.1, 0.9, 1.2, 0.8)
+    pose, uvd = o.head_assemble(nhwc(raw), J, root, 8, 12, uvd_c, sigma_c, sc)
+    r_uvd = raw[:, uvd_c:uvd_c + 3 * J].clone().reshape(B, J, 3, H, W)
+    r_uvd[:, :, :2] *= sc[2]
+    r_uvd[:, :, 2] *= sc[3]
+    r_uvd[:, root, 2] = 0
+    r_sig = raw[:, sigma_c:sigma_c + 3 * J].clone().reshape(B, J, 3, H, W)
+    r_sig[:, root, 2] = 1
+    ref = torch.cat([raw[:, 8:10] * sc[0], raw[:, 12:13] * sc[1], r_uvd.reshape(B, -1, H, W), r_sig.reshape(B, -1, H, W)], 1)
+    np.testing.assert_allclose(nchw(pose).numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(nchw(uvd).numpy(), r_uvd.reshape(B, -1, H, W).numpy(), rtol=1e-6, atol=1e-7)
+
+    refd = cases.randn(41, B, 3 * J, H, W)
+    rd = nhwc(refd)
+    o.head_finalize(pose, rd, J, root, 16.0, 50.0, 20.0, eval_mode=True)
+    e = refd.clone().reshape(B, J, 3, H, W)
+    e[:, root, 2] = 0
+    np.testing.assert_array_equal(nchw(rd).numpy(), e.reshape(B, -1, H, W).numpy())
+    e[:, :, :2] *= 16.0
+    e[:, :, 2] *= 50.0
+    ref2 = ref.clone()
+    ref2[:, 3:3 + 3 * J] = e.reshape(B, -1, H, W)
+    ref2[:, 2] = ref[:, 2] / 20.0
+    np.testing.assert_allclose(nchw(pose).numpy(), ref2.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def _decode_hip(cls, pose, ctr, sf, J, strides, cfg):
+    o = ops()
+    out = o.decode([nhwc(c) for c in cls], [nhwc(c) for c in ctr], [nhwc(p) for p in pose], strides,
+                   torch.tensor(sf, dtype=torch.float32, device=DEV), J, cfg['nms_pre'], cfg['nms_post'],
+                   cfg['score_thr'], cfg['nms_thr'])
+    return {k: v.cpu() for k, v in out.items()}
+
+
+def _check_decode_vs_oracle(cls, pose, ctr, sfs, J, strides, cfg, golden=None):
+    from oracle import decode as od
+    metas = [dict(scale_factor=np.array([s[0], s[1], s[0], s[1]], dtype=np.float32), filename='x') for s in sfs]
+    ref = od.get_poses(cls, pose, ctr, metas, J, strides, cfg, return_index=True)
+    out = _decode_hip(cls, pose, ctr, sfs, J, strides, cfg)
+    for b, r in enumerate(ref):
+        K = int(out['count'][b])
+        assert K == r['poses'].shape[0]
+        # bit-exact kept indices, in order
+        np.testing.assert_array_equal(out['index'][b, :K].numpy(), r['index'].numpy())
+        np.testing.assert_allclose(out['poses'][b, :K].numpy(), r['poses'].numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out['centers'][b, :K].numpy(), r['centers'].numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out['scores'][b, :K].numpy(), np.array(r['scores'], dtype=np.float32), rtol=1e-5)
+        if golden is not None:
+            np.testing.assert_allclose(out['poses'][b, :K].numpy(), golden[f'poses{b}'], rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(out['scores'][b, :K].numpy(), golden[f'scores{b}'], rtol=1e-5)
+    return out
+
+
+def test_decode_full_size_vs_oracle_and_reference_fixture(golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, 'decode_full.npz'))
+    cls, pose, ctr = cases.full_decode_inputs()
+    out = _check_decode_vs_oracle(cls, pose, ctr, [(1.3, 1.3), (1.0, 1.0)], cases.FULL_J, cases.FULL_STRIDES,
+                                  cases.FULL_TEST_CFG, golden=z)
+    assert int(out['count'].min()) > 20
+
+
+def test_decode_topk_truncation_and_empty():
+    # many candidates above threshold on level 0 -> the nms_pre truncation path is exercised
+    cls, pose, ctr = cases.full_decode_inputs(seed=77, B=1, bias=1.0)
+    cfg = dict(cases.FULL_TEST_CFG, nms_pre=300, nms_thr=0.3)
+    _check_decode_vs_oracle(cls, pose, ctr, [(1.0, 1.0)], cases.FULL_J, cases.FULL_STRIDES, cfg)
+    cls, pose, ctr = cases.full_decode_inputs(seed=78, B=2, bias=-20.0)
+    out = _decode_hip(cls, pose, ctr, [(1.0, 1.0)] * 2, cases.FULL_J, cases.FULL_STRIDES, cases.FULL_TEST_CFG)
+    assert out['count'].tolist() == [0, 0]
+
+
+def test_decode_mupots_topology():
+    """config 5 geometry: J=21, 768x1024 input -> levels 96x128 ... 12x16 (16320 locations)."""
+    sizes = [(96, 128), (48, 64), (24, 32), (12, 16)]
+    cls, pose, ctr = cases.full_decode_inputs(seed=5, B=1, Jn=21, sizes=sizes, bias=-4.5)
+    _check_decode_vs_oracle(cls, pose, ctr, [(0.8, 0.8)], 21, cases.FULL_STRIDES, cases.FULL_TEST_CFG)
