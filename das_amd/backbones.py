@@ -1,0 +1,208 @@
+"""MSPN2 backbone (reference: mmdet3d/models/backbones/mspn_mmpose.py).
+
+Same constructor arguments, module tree and state-dict keys as the reference class
+(`top.top.0.{conv,bn}`, `multi_stage_mspn.{s}.downsample.layer{L}.{b}.{conv1,bn1,...}`,
+`multi_stage_mspn.{s}.upsample.up{u}.{in_skip,up_conv,out_skip1,out_skip2,cross_conv}.{conv,bn}`);
+every layer runs as an NHWC HIP kernel. Reference quirks kept on purpose:
+  * blocks >= 1 of every layer ignore `norm_cfg` and use plain BN (mspn_mmpose.py:273-274);
+  * `ResNetTop` always emits 64 channels and `cross_conv` always emits 64 (`:456,:615`);
+  * `frozen_stages` / `norm_eval` are accepted and ignored (`:600`, `_frozen_stage` never called).
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .nn import ConvModule, as_nhwc, conv_bn, to_nchw_view
+from .registry import BACKBONES
+
+
+class Bottleneck(nn.Module):
+    """ResNet bottleneck, 'pytorch' style (stride on the 3x3), expansion 4 (mspn_mmpose.py:17-157,196-210)."""
+    expansion = 4
+
+    def __init__(self, in_channels, out_channels, stride=1, downsample=None, norm_cfg=dict(type='BN')):
+        super().__init__()
+        mid = out_channels
+        out = out_channels * self.expansion
+        self.conv1 = nn.Conv2d(in_channels, mid, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid)
+        self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(mid)
+        self.conv3 = nn.Conv2d(mid, out, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(out)
+        for bn in (self.bn1, self.bn2, self.bn3):
+            bn._das_sync = norm_cfg.get('type') == 'SyncBN'
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = conv_bn(x, self.conv1, self.bn1, relu=True)
+        out = conv_bn(out, self.conv2, self.bn2, relu=True)
+        identity = x if self.downsample is None else self.downsample(x)
+        # relu(bn3(conv3(out)) + identity): residual add and ReLU ride in the conv/BN epilogue
+        return conv_bn(out, self.conv3, self.bn3, relu=True, residual=identity)
+
+
+class DownsampleModule(nn.Module):
+    def __init__(self, num_blocks, num_units=4, has_skip=False, norm_cfg=dict(type='BN'), in_channels=64):
+        super().__init__()
+        assert len(num_blocks) == num_units
+        self.has_skip, self.num_units, self.norm_cfg = has_skip, num_units, copy.deepcopy(norm_cfg)
+        self.in_channels = in_channels
+        self.layer1 = self._make_layer(in_channels, num_blocks[0])
+        for i in range(1, num_units):
+            self.add_module(f'layer{i + 1}', self._make_layer(in_channels * 2 ** i, num_blocks[i], stride=2))
+
+    def _make_layer(self, out_channels, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.in_channels != out_channels * Bottleneck.expansion:
+            downsample = ConvModule(self.in_channels, out_channels * Bottleneck.expansion, 1, stride=stride, padding=0,
+                                    norm_cfg=self.norm_cfg, act_cfg=None)
+        units = [Bottleneck(self.in_channels, out_channels, stride=stride, downsample=downsample,
+                            norm_cfg=self.norm_cfg)]
+        self.in_channels = out_channels * Bottleneck.expansion
+        for _ in range(1, blocks):
+            units.append(Bottleneck(self.in_channels, out_channels))  # default BN: reference quirk
+        return nn.Sequential(*units)
+
+    def forward(self, x, skip1, skip2):
+        out = []
+        for i in range(self.num_units):
+            x = getattr(self, f'layer{i + 1}')(x)
+            if self.has_skip:
+                x = ops.add3(x, skip1[i], skip2[i])
+            out.append(x)
+        out.reverse()
+        return tuple(out)
+
+
+class UpsampleUnit(nn.Module):
+    def __init__(self, ind, num_units, in_channels, unit_channels=256, gen_skip=False, gen_cross_conv=False,
+                 norm_cfg=dict(type='BN'), out_channels=64):
+        super().__init__()
+        self.ind, self.num_units = ind, num_units
+        self.in_skip = ConvModule(in_channels, unit_channels, 1, norm_cfg=norm_cfg, act_cfg=None)
+        if ind > 0:
+            self.up_conv = ConvModule(unit_channels, unit_channels, 1, norm_cfg=norm_cfg, act_cfg=None)
+        self.gen_skip = gen_skip
+        if gen_skip:
+            self.out_skip1 = ConvModule(in_channels, in_channels, 1, norm_cfg=norm_cfg)
+            self.out_skip2 = ConvModule(unit_channels, in_channels, 1, norm_cfg=norm_cfg)
+        self.gen_cross_conv = gen_cross_conv
+        if ind == num_units - 1 and gen_cross_conv:
+            self.cross_conv = ConvModule(unit_channels, out_channels, 1, norm_cfg=norm_cfg)
+
+    def forward(self, x, up_x):
+        if self.ind > 0:
+            lat = self.in_skip(x)
+            up = ops.upsample_bilinear_ac(up_x, x.shape[1], x.shape[2])
+            # relu(in_skip(x) + up_conv(up)): add + ReLU fused into up_conv's epilogue
+            out = conv_bn(up, self.up_conv.conv, self.up_conv.bn, relu=True, residual=lat)
+        else:
+            out = conv_bn(x, self.in_skip.conv, self.in_skip.bn, relu=True)
+        skip1 = skip2 = cross = None
+        if self.gen_skip:
+            skip1 = self.out_skip1(x)
+            skip2 = self.out_skip2(out)
+        if self.ind == self.num_units - 1 and self.gen_cross_conv:
+            cross = self.cross_conv(out)
+        return out, skip1, skip2, cross
+
+
+class UpsampleModule(nn.Module):
+    def __init__(self, unit_channels=256, num_units=4, gen_skip=False, gen_cross_conv=False, norm_cfg=dict(type='BN'),
+                 out_channels=64):
+        super().__init__()
+        self.in_channels = [Bottleneck.expansion * out_channels * 2 ** i for i in range(num_units)][::-1]
+        self.num_units = num_units
+        for i in range(num_units):
+            self.add_module(f'up{i + 1}', UpsampleUnit(i, num_units, self.in_channels[i], unit_channels, gen_skip,
+                                                        gen_cross_conv, norm_cfg=norm_cfg, out_channels=64))
+
+    def forward(self, x):
+        out, skip1, skip2, cross = [], [], [], None
+        for i in range(self.num_units):
+            o, s1, s2, c = getattr(self, f'up{i + 1}')(x[i], out[i - 1] if i > 0 else None)
+            out.append(o)
+            skip1.append(s1)
+            skip2.append(s2)
+            if c is not None:
+                cross = c
+        skip1.reverse()
+        skip2.reverse()
+        return out, skip1, skip2, cross
+
+
+class SingleStageNetwork(nn.Module):
+    def __init__(self, has_skip=False, gen_skip=False, gen_cross_conv=False, unit_channels=256, num_units=4,
+                 num_blocks=(2, 2, 2, 2), norm_cfg=dict(type='BN'), in_channels=64):
+        super().__init__()
+        self.downsample = DownsampleModule(list(num_blocks), num_units, has_skip, norm_cfg, in_channels)
+        self.upsample = UpsampleModule(unit_channels, num_units, gen_skip, gen_cross_conv, norm_cfg, in_channels)
+
+    def forward(self, x, skip1, skip2):
+        mid = self.downsample(x, skip1, skip2)
+        return self.upsample(mid)
+
+
+class ResNetTop(nn.Module):
+    def __init__(self, norm_cfg=dict(type='BN'), channels=64):
+        super().__init__()
+        # index 1 (MaxPool2d) has no parameters; kept so that keys read top.top.0.*
+        self.top = nn.Sequential(ConvModule(3, channels, 7, stride=2, padding=3, norm_cfg=norm_cfg),
+                                 nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
+
+    def forward(self, x):
+        return ops.maxpool3x3s2(self.top[0](x))
+
+
+@BACKBONES.register_module()
+class MSPN2(nn.Module):
+    """forward(img NCHW float) -> list of the last stage's 4 maps, strides 4/8/16/32, 256 ch,
+    as NCHW-shaped channels-last views (mspn_mmpose.py:657-667)."""
+
+    def __init__(self, unit_channels=256, num_stages=4, num_units=4, num_blocks=[2, 2, 2, 2], norm_cfg=dict(type='BN'),
+                 res_top_channels=64, frozen_stages=-1, norm_eval=False, pretrained=None, compute_dtype='bf16'):
+        super().__init__()
+        norm_cfg = copy.deepcopy(norm_cfg)
+        num_blocks = copy.deepcopy(num_blocks)
+        assert num_stages > 0 and num_units > 1 and num_units == len(num_blocks)
+        self.unit_channels, self.num_stages, self.num_units = unit_channels, num_stages, num_units
+        self.num_blocks, self.norm_cfg = num_blocks, norm_cfg
+        self.top = ResNetTop(norm_cfg=norm_cfg)
+        self.multi_stage_mspn = nn.ModuleList()
+        for i in range(num_stages):
+            last = i == num_stages - 1
+            self.multi_stage_mspn.append(SingleStageNetwork(i > 0, not last, not last, unit_channels, num_units,
+                                                            num_blocks, norm_cfg, res_top_channels))
+        self.pretrained = pretrained
+        self.compute_dtype = torch.bfloat16 if compute_dtype in ('bf16', torch.bfloat16) else torch.float32
+
+    def forward(self, x):
+        x = as_nhwc(x, self.compute_dtype)
+        x = self.top(x)
+        skip1 = skip2 = None
+        out = None
+        for stage in self.multi_stage_mspn:
+            out, skip1, skip2, x = stage(x, skip1, skip2)
+        return [to_nchw_view(o) for o in out[::-1]]
+
+    def init_weights(self, pretrained=None):
+        """kaiming for convs, BN weight 1 (mspn_mmpose.py:682-692); checkpoint loading strips
+        the `backbone.` prefix (`:672-680`). Unlike the reference, pretrained=None is accepted."""
+        pretrained = pretrained or self.pretrained
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if isinstance(pretrained, str):
+            import os
+            if not os.path.isfile(pretrained):
+                raise FileNotFoundError(f'pretrained backbone checkpoint {pretrained} not found')
+            sd = torch.load(pretrained, map_location='cpu')
+            sd = sd.get('state_dict', sd)
+            sd = {k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')} or sd
+            self.load_state_dict(sd, strict=False)

@@ -1,0 +1,106 @@
+"""DAS detector (reference: mmdet3d/models/detectors/das.py:5-39 on top of mmdet's
+SingleStageDetector / BaseDetector protocol): backbone -> neck -> bbox_head, `forward_train`
+returning the loss dict, `simple_test` returning per-image pose dicts, `train_step` /
+`forward(return_loss=...)` as the runner calls them (tools/train.py, mmdet3d/apis/test.py:39)."""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+@DETECTORS.register_module()
+class DAS(nn.Module):
+    def __init__(self, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None):
+        super().__init__()
+        backbone = dict(backbone)
+        if pretrained is not None:
+            backbone['pretrained'] = pretrained
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck) if neck is not None else None
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.CLASSES = ('person',)
+
+    @property
+    def with_neck(self):
+        return self.neck is not None
+
+    def init_weights(self):
+        self.backbone.init_weights()
+        if self.with_neck:
+            self.neck.init_weights()
+        self.bbox_head.init_weights()
+
+    def set_compute_dtype(self, dtype):
+        """bf16 (default, the benchmarked precision) or f32 (exact-f32 MFMA path, parity runs)."""
+        self.backbone.compute_dtype = dtype
+        return self
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_poses_3d, gt_labels_3d, centers2d, depths,
+                      gt_bboxes_ignore=None):
+        x = self.extract_feat(img)
+        return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_poses_3d, gt_labels_3d, centers2d,
+                                            depths, gt_bboxes_ignore)
+
+    def simple_test(self, img, img_metas, rescale=False, **kwargs):
+        x = self.extract_feat(img)
+        outs = self.bbox_head(x)
+        return self.bbox_head.get_poses(*outs, img_metas, rescale=rescale)
+
+    def aug_test(self, imgs, img_metas, rescale=False):
+        raise NotImplementedError
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """mmdet BaseDetector.forward_test: lists with one entry per test-time augmentation."""
+        if not isinstance(imgs, (list, tuple)):
+            imgs, img_metas = [imgs], [img_metas]
+        if len(imgs) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        if len(imgs) == 1:
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        return self.aug_test(imgs, img_metas, **kwargs)
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        with torch.no_grad():
+            return self.forward_test(img, img_metas, **kwargs)
+
+    @staticmethod
+    def _parse_losses(losses):
+        """Sum of every entry whose key contains 'loss'; log vars averaged over ranks."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        for name, value in log_vars.items():
+            if dist.is_available() and dist.is_initialized():
+                value = value.data.clone()
+                dist.all_reduce(value.div_(dist.get_world_size()))
+            log_vars[name] = value.item()
+        return loss, log_vars
+
+    def train_step(self, data, optimizer=None):
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+    def val_step(self, data, optimizer=None):
+        return self.train_step(data, optimizer)

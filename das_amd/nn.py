@@ -1,0 +1,240 @@
+"""Layer containers and fused-op helpers shared by the backbone, neck and head.
+
+Parameters live in ordinary `nn.Conv2d` / `nn.BatchNorm2d` / `nn.GroupNorm` modules (OIHW, f32)
+so that state-dict keys and shapes equal the reference's checkpoints
+(`backbone.top.top.0.conv.weight`, `...bn.running_mean`, `bbox_head.cls_convs.1.conv.conv_offset.weight`
+...). Those modules are never *called*: the forward path packs their parameters once into the
+NHWC/K-contiguous layout the HIP kernels want (cache keyed on parameter version) and launches
+libdas_hip.so through `das_amd.ops`.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+# ------------------------------------------------------------------ layout helpers
+def as_nhwc(t, dtype):
+    """Accept an NCHW-shaped tensor (dense NCHW, or a channels-last view produced by `to_nchw_view`)
+    and return an NHWC (B,H,W,C) tensor of `dtype` without copying when possible."""
+    assert t.dim() == 4
+    v = t.permute(0, 2, 3, 1)
+    if v.is_contiguous() and t.dtype == dtype and t.shape[1] % 8 == 0:
+        return v
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return ops.pack_image(t, dtype, (t.shape[1] + 7) // 8 * 8)
+    return ops.pack_image(t.float().contiguous(), dtype, (t.shape[1] + 7) // 8 * 8)
+
+
+def to_nchw_view(x):
+    """NHWC (B,H,W,C) -> logical NCHW view (channels-last strides), no copy."""
+    return x.permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------ parameter packing cache
+def _versions(*ts):
+    return tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+
+
+class _Cache:
+    """Per-module cache of packed tensors, invalidated when any source tensor changes."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, sources, make):
+        ver = _versions(*sources)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            val = make()
+        self.store[key] = (ver, val)
+        return val
+
+
+def _cache_of(mod):
+    c = mod.__dict__.get('_das_cache')
+    if c is None:
+        c = _Cache()
+        mod.__dict__['_das_cache'] = c
+    return c
+
+
+def packed_weight(conv, dtype, cin_pad=None):
+    return _cache_of(conv).get(('w', dtype, cin_pad), (conv.weight,),
+                               lambda: ops.pack_weight(conv.weight, dtype, cin_pad=cin_pad))
+
+
+def _pad8(v, n, fill=0.0):
+    out = torch.full(((n + 7) // 8 * 8,), fill, dtype=torch.float32, device=v.device)
+    out[:n] = v.detach().float()
+    return out
+
+
+def bn_eval_affine(conv, bn):
+    """BatchNorm in eval mode is y = x*scale + shift with running stats (+ optional conv bias)."""
+    def make():
+        scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+        shift = bn.bias.float() - bn.running_mean.float() * scale
+        if conv.bias is not None:
+            shift = shift + conv.bias.float() * scale
+        n = scale.numel()
+        return _pad8(scale, n, 1.0), _pad8(shift, n)
+    return _cache_of(bn).get(('affine', id(conv)), (bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.bias), make)
+
+
+def bias_shift(conv):
+    if conv.bias is None:
+        return None
+    return _cache_of(conv).get(('bias',), (conv.bias,), lambda: _pad8(conv.bias, conv.bias.numel()))
+
+
+# ------------------------------------------------------------------ fused units
+def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False):
+    """ConvModule(conv, BN[, ReLU]) (+ residual add before the ReLU) on an NHWC tensor.
+
+    eval: one kernel (BN folded into the conv epilogue). train: conv with fused per-channel
+    sum / sum-of-squares, then the BN apply kernel (batch statistics, running-stat update).
+    """
+    w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    if not bn.training:
+        scale, shift = bn_eval_affine(conv, bn)
+        return ops.conv2d(x, w, k, k, s, p, scale=scale, shift=shift, residual=residual, relu=relu, relu_in=relu_in)
+    assert conv.bias is None
+    cout = w.shape[0]
+    stats = torch.zeros(2 * cout, dtype=torch.float32, device=x.device)
+    raw = ops.conv2d(x, w, k, k, s, p, relu_in=relu_in, stats=stats)
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    y, mean, invstd = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
+                                         residual=residual, relu=relu)
+    bn.num_batches_tracked += 1
+    return y
+
+
+def conv_plain(x, conv, relu=False, out_dtype=None, out=None):
+    """nn.Conv2d with bias, no norm (the 1x1 predictors)."""
+    w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    return ops.conv2d(x, w, k, k, s, p, shift=bias_shift(conv), relu=relu, out_dtype=out_dtype, out=out)
+
+
+def dcn_v2(x, dcn):
+    """ModulatedDeformConv2dPack.forward: offset/mask conv (f32 out) -> deformable im2col -> GEMM."""
+    C = x.shape[-1]
+    w_off = _cache_of(dcn.conv_offset).get(('w', x.dtype), (dcn.conv_offset.weight,),
+                                           lambda: ops.pack_weight(dcn.conv_offset.weight, x.dtype, cout_pad=32))
+    b_off = _cache_of(dcn.conv_offset).get(('b',), (dcn.conv_offset.bias,), lambda: _pad8(dcn.conv_offset.bias, 27))
+    om = ops.conv2d(x, w_off, 3, 3, 1, 1, shift=b_off, out_dtype=torch.float32)
+    col = ops.deform_im2col3x3(x, om)
+    w = _cache_of(dcn).get(('w', x.dtype), (dcn.weight,),
+                           lambda: ops.pack_weight(dcn.weight, x.dtype).reshape(dcn.weight.shape[0], 1, 1, 9 * C))
+    shift = None
+    if dcn.bias is not None:
+        shift = _cache_of(dcn).get(('b',), (dcn.bias,), lambda: _pad8(dcn.bias, dcn.bias.numel()))
+    return ops.conv2d(col, w, 1, 1, shift=shift)
+
+
+def group_norm_relu(x, gn, relu=True):
+    return ops.groupnorm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=relu)
+
+
+# ------------------------------------------------------------------ parameter containers
+class ModulatedDeformConv2dPack(nn.Module):
+    """Parameter container with mmcv's DCNv2 key names: weight, bias, conv_offset.{weight,bias}."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True):
+        super().__init__()
+        assert kernel_size == 3 and stride == 1 and padding == 1, 'the DAS path only uses 3x3/s1/p1 DCNv2'
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = (3, 3), (1, 1), (1, 1)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.conv_offset = nn.Conv2d(in_channels, 27, 3, 1, 1, bias=True)
+        self.init_weights()
+
+    def init_weights(self):
+        stdv = 1.0 / math.sqrt(self.in_channels * 9)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+
+def build_norm(cfg, num_features):
+    """(name, module) like mmcv build_norm_layer: BN/SyncBN -> 'bn', GN -> 'gn'."""
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    requires_grad = cfg.pop('requires_grad', True)
+    if t in ('BN', 'SyncBN', 'BN2d'):
+        # SyncBN's cross-rank statistics exchange is handled by the DDP wrapper
+        name, layer = 'bn', nn.BatchNorm2d(num_features, **cfg)
+        layer._das_sync = (t == 'SyncBN')
+    elif t == 'GN':
+        name, layer = 'gn', nn.GroupNorm(num_channels=num_features, **cfg)
+    else:
+        raise KeyError(f'unsupported norm type {t}')
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return name, layer
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> ReLU container with mmcv's attribute names (`conv`, `bn`/`gn`, `activate`).
+
+    `bias='auto'` means bias iff there is no norm. `conv_cfg=dict(type='DCNv2')` selects the
+    deformable conv. forward() takes and returns NHWC tensors.
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias='auto', conv_cfg=None,
+                 norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True):
+        super().__init__()
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.is_dcn = conv_cfg is not None and conv_cfg.get('type') == 'DCNv2'
+        if self.is_dcn:
+            self.conv = ModulatedDeformConv2dPack(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
+        else:
+            self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
+        self.norm_name = None
+        if self.with_norm:
+            self.norm_name, norm = build_norm(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            self.activate = nn.ReLU(inplace=inplace)
+        self.init_weights()
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name) if self.norm_name else None
+
+    def init_weights(self):
+        if not self.is_dcn:
+            nn.init.kaiming_normal_(self.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+            if self.conv.bias is not None:
+                nn.init.constant_(self.conv.bias, 0)
+        if self.with_norm:
+            nn.init.constant_(self.norm.weight, 1)
+            nn.init.constant_(self.norm.bias, 0)
+
+    def forward(self, x, residual=None, relu_in=False):
+        relu = self.with_activation
+        if self.norm_name == 'bn':
+            return conv_bn(x, self.conv, self.norm, relu=relu, residual=residual, relu_in=relu_in)
+        assert residual is None and not relu_in
+        if self.norm_name == 'gn':
+            y = dcn_v2(x, self.conv) if self.is_dcn else conv_plain(x, self.conv)
+            return group_norm_relu(y, self.norm, relu=relu)
+        return dcn_v2(x, self.conv) if self.is_dcn else conv_plain(x, self.conv, relu=relu)
+
+
+class Scale(nn.Module):
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))

@@ -12,6 +12,10 @@ from . import _lib
 
 _DT = {torch.float32: _lib.DAS_F32, torch.bfloat16: _lib.DAS_BF16}
 
+# bench.py sets this to a list to time every conv launch with HIP events recorded on the launch
+# stream: entries are (kernel family tag, algorithmic FLOPs, start event, end event).
+PROFILE = None
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -29,7 +33,7 @@ def _need_gpu(*ts):
 
 def _ps(t):
     """pixel stride (elements) of an NHWC tensor or a channel-slice view of one"""
-    assert t.stride(-1) == 1, 'channel dim must be contiguous'
+    assert t.shape[-1] == 1 or t.stride(-1) == 1, 'channel dim must be contiguous'
     ps = t.stride(-2)
     if t.dim() == 4:
         assert t.stride(1) == ps * t.shape[2] and t.stride(0) == ps * t.shape[1] * t.shape[2], 'rows must be dense'
@@ -72,7 +76,15 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         stats=stats.data_ptr() if stats is not None else None)
     if residual is not None:
         assert residual.shape == out.shape and residual.dtype == out.dtype
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.das_conv2d_nhwc(_ptr(x), _ptr(w), _ptr(out), C.byref(d), _stream()), 'das_conv2d_nhwc')
+    if PROFILE is not None:
+        e1.record()
+        bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+        tag = f'conv_igemm<{str(x.dtype)[6:]},{str(out_dtype)[6:]},BN{bn}>'
+        PROFILE.append((tag, 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, e0, e1))
     return out
 
 

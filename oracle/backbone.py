@@ -93,7 +93,8 @@ def fpn_forward(sd, feats, prefix='', start_level=1, num_outs=4, train=False):
     """mmdet FPN with add_extra_convs='on_output', relu_before_extra_convs=True, BN, no act.
 
     laterals 1x1+BN on levels start_level..; top-down `+= nearest_up(size=finer)`;
-    3x3+BN per level; extra levels = 3x3 stride-2 +BN on relu(previous output).
+    3x3+BN per level; the first extra level = 3x3 stride-2 +BN on the last output (no ReLU),
+    further extra levels on relu(previous extra output) — mmdet 2.14.0 `FPN.forward` part 2.
     """
     p = prefix
     n = len(feats) - start_level
@@ -102,5 +103,6 @@ def fpn_forward(sd, feats, prefix='', start_level=1, num_outs=4, train=False):
         lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[-2:], mode='nearest')
     outs = [conv_bn(sd, f'{p}fpn_convs.{i}', lats[i], 1, 1, False, train) for i in range(n)]
     for i in range(n, num_outs):
-        outs.append(conv_bn(sd, f'{p}fpn_convs.{i}', F.relu(outs[-1]), 2, 1, False, train))
+        src = outs[-1] if i == n else F.relu(outs[-1])
+        outs.append(conv_bn(sd, f'{p}fpn_convs.{i}', src, 2, 1, False, train))
     return outs

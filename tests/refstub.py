@@ -311,6 +311,7 @@ class RefFPN(nn.Module):
         for i in range(n - 1, 0, -1):
             lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode='nearest')
         outs = [self.fpn_convs[i](lats[i]) for i in range(n)]
-        for i in range(n, self.num_outs):
+        outs.append(self.fpn_convs[n](outs[-1]))  # first extra level: no ReLU (mmdet 2.14.0)
+        for i in range(n + 1, self.num_outs):
             outs.append(self.fpn_convs[i](F.relu(outs[-1])))
         return tuple(outs)
