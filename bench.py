@@ -175,7 +175,7 @@ def main():
         step()
     torch.cuda.synchronize()
     fam = {}
-    for tag, flops, e0, e1 in ops.PROFILE:
+    for tag, flops, e0, e1, _shape in ops.PROFILE:
         f = fam.setdefault(tag, [0.0, 0.0, 0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3

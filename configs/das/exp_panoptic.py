@@ -1,0 +1,48 @@
+# DAS on CMU Panoptic: 2-stage MSPN-50, J=15, root joint 2, SyncBN, fp16->bf16 mixed precision.
+_base_ = [
+    '../_base_/datasets/panoptic_monocular.py', '../_base_/models/das.py',
+    '../_base_/schedules/mmdet_schedule_1x.py', '../_base_/default_runtime.py'
+]
+fpn_channels = 256
+num_joints = 15
+model = dict(
+    pretrained='weights/2xmspn50_coco_256x192-c8765a5c_20201123.pth',
+    backbone=dict(
+        _delete_=True,
+        type='MSPN2',
+        unit_channels=256,
+        num_stages=2,
+        num_units=4,
+        num_blocks=[3, 4, 6, 3],
+        norm_cfg=dict(type='SyncBN'),
+        frozen_stages=1,
+        norm_eval=False),
+    neck=dict(
+        type='FPN',
+        in_channels=[256, 256, 256, 256],
+        out_channels=fpn_channels,
+        norm_cfg=dict(type='SyncBN'),
+        num_outs=4),
+    bbox_head=dict(
+        type='DASHead',
+        in_channels=fpn_channels,
+        feat_channels=fpn_channels,
+        regress_ranges=((-1, 80), (80, 160), (160, 320), (320, 1e8)),
+        strides=[8, 16, 32, 64],
+        num_joints=num_joints,
+        depth_factor=20,
+        z_norm=50,
+        root_idx=2,
+        recursive_update=dict(num_joints=num_joints)),
+    train_cfg=dict(code_weight=[1.0, 1.0, 1] + [2] * num_joints * 6),
+    test_cfg=dict(nms_across_levels=False, nms_pre=1000, nms_post=100, nms_thr=0.9, score_thr=0.07))
+
+optimizer = dict(lr=2e-3, paramwise_cfg=dict(bias_lr_mult=2., bias_decay_mult=0.))
+optimizer_config = dict(_delete_=True, grad_clip=dict(max_norm=35, norm_type=2))
+runner = dict(type='EpochBasedRunner', max_iters=None, max_epochs=22)
+lr_config = dict(policy='step', warmup='linear', warmup_iters=250, warmup_ratio=1.0 / 3, step=[16, 20])
+log_config = dict(interval=50)
+checkpoint_config = dict(interval=1, max_keep_ckpts=20)
+evaluation = dict(interval=1)
+find_unused_parameters = True
+fp16 = dict(loss_scale=dict(init_scale=512))  # honoured as bf16 autocast-free mixed precision: no loss scaling needed

@@ -1,0 +1,63 @@
+"""Synthetic multi-person pose data with the statistics BASELINE.md section 2 prescribes.
+
+GT row layout follows the reference datasets (mmdet3d/datasets/cmupanoptic_mono_dataset.py:218-222):
+`gt_poses_3d (G, 3+4J) = [cx, cy, depth, J x (u, v, dz), J x vis]`, `centers2d (G,2)`, `depths (G,)`,
+`gt_labels_3d (G,)`; images are already normalised (`img ~ N(0,1)`), `scale_factor = (1,1,1,1)`.
+Real-data loaders / CPU augmentation are out of scope."""
+import numpy as np
+import torch
+
+
+class SyntheticPoseDataset:
+    CLASSES = ('person',)
+
+    def __init__(self, num_joints=15, img_shape=(512, 832), length=1024, seed=0, root_idx=2, test_mode=False,
+                 max_persons=6, **kwargs):
+        self.J, self.img_shape, self.length, self.seed = num_joints, tuple(img_shape), length, seed
+        self.root_idx, self.test_mode, self.max_persons = root_idx, test_mode, max_persons
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        rs = np.random.RandomState((self.seed * 7919 + idx) % (2 ** 31))
+        H, W = self.img_shape
+        J = self.J
+        img = torch.from_numpy(rs.standard_normal((3, H, W)).astype(np.float32))
+        G = int(rs.randint(1, self.max_persons + 1))
+        c = np.stack([rs.uniform(40, W - 40, G), rs.uniform(40, H - 40, G)], 1)
+        depth = rs.uniform(0.2, 0.7, G)
+        uv = c[:, None] + rs.normal(0, 60.0, (G, J, 2))
+        dz = rs.normal(0, 20.0, (G, J, 1))
+        dz[:, self.root_idx] = 0
+        dz[rs.uniform(0, 1, G) < 0.1] = 0  # 10% of persons carry 2-D annotation only
+        vis = np.ones((G, J), dtype=np.float32)
+        poses = np.concatenate([c, depth[:, None], np.concatenate([uv, dz], -1).reshape(G, 3 * J), vis], 1)
+        meta = dict(filename=f'synthetic_{self.seed}_{idx}', scale_factor=np.ones(4, dtype=np.float32),
+                    img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3), flip=False)
+        return dict(img=img, img_metas=meta, gt_bboxes=torch.zeros(G, 4), gt_labels=torch.zeros(G, dtype=torch.long),
+                    gt_poses_3d=torch.from_numpy(poses.astype(np.float32)),
+                    gt_labels_3d=torch.zeros(G, dtype=torch.long),
+                    centers2d=torch.from_numpy(c.astype(np.float32)), depths=torch.from_numpy(depth.astype(np.float32)))
+
+
+def collate(samples, device=None):
+    """Batch a list of samples the way mmcv's collate + scatter would hand them to `model(**data)`."""
+    def dev(t):
+        return t.to(device, non_blocking=True) if device is not None else t
+    out = dict(img=dev(torch.stack([s['img'] for s in samples])), img_metas=[s['img_metas'] for s in samples])
+    for k in ('gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths'):
+        out[k] = [dev(s[k]) for s in samples]
+    return out
+
+
+DATASETS = {'SyntheticPoseDataset': SyntheticPoseDataset}
+
+
+def build_dataset(cfg):
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    if t not in DATASETS:
+        raise KeyError(f'dataset type {t} is outside this repo\'s scope (real-data loaders: SURVEY.md section 8f); '
+                       f'available: {sorted(DATASETS)}')
+    return DATASETS[t](**cfg)

@@ -84,7 +84,7 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         e1.record()
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
         tag = f'conv_igemm<{str(x.dtype)[6:]},{str(out_dtype)[6:]},BN{bn}>'
-        PROFILE.append((tag, 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, e0, e1))
+        PROFILE.append((tag, 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, e0, e1, (B, H, W, Cin, Cout, KH, stride, _ps(x))))
     return out
 
 
