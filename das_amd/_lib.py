@@ -22,12 +22,18 @@ class DasConvDesc(C.Structure):
                 ('Ho', i32), ('Wo', i32), ('Cout', i32), ('y_pix_stride', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('relu_in', i32), ('relu', i32),
-                ('scale', vp), ('shift', vp), ('residual', vp), ('res_pix_stride', i32), ('stats', vp)]
+                ('scale', vp), ('shift', vp), ('residual', vp), ('res_pix_stride', i32), ('stats', vp),
+                ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5)]
 
 
-class DasHeadAssembleDesc(C.Structure):
+class DasLevels(C.Structure):
+    _fields_ = [('num_levels', i32), ('B', i32), ('H', i32 * 5), ('W', i32 * 5)]
+
+
+class DasHeadDesc(C.Structure):
     _fields_ = [('J', i32), ('root_idx', i32), ('raw_ps', i32), ('off_c', i32), ('depth_c', i32), ('uvd_c', i32),
-                ('sigma_c', i32), ('scale_off', f32), ('scale_depth', f32), ('scale_uv', f32), ('scale_d', f32)]
+                ('sigma_c', i32), ('scale', (f32 * 4) * 5), ('level_stride', f32 * 5), ('z_norm', f32),
+                ('depth_factor', f32)]
 
 
 class DasDecodeDesc(C.Structure):
@@ -50,12 +56,12 @@ SIGNATURES = {
     'das_add_upsample_nearest': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_add3': (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
     'das_bn_train_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp]),
-    'das_groupnorm_nhwc': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, f32, i32, vp, vp]),
-    'das_deform_im2col3x3': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
-    'das_offset_sample': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'das_groupnorm_nhwc': (i32, [vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp, vp]),
+    'das_deform_im2col3x3': (i32, [vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp]),
+    'das_offset_sample': (i32, [vp, vp, vp, vp, C.POINTER(DasLevels), i32, i32, i32, i32, i32, i32, vp]),
     'das_sigmoid_blend': (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
-    'das_head_assemble': (i32, [vp, vp, vp, i64, C.POINTER(DasHeadAssembleDesc), vp]),
-    'das_head_finalize': (i32, [vp, vp, i64, i32, i32, i32, f32, f32, f32, i32, vp]),
+    'das_head_assemble': (i32, [vp, vp, vp, C.POINTER(DasLevels), C.POINTER(DasHeadDesc), vp]),
+    'das_head_finalize': (i32, [vp, vp, C.POINTER(DasLevels), C.POINTER(DasHeadDesc), i32, i32, vp]),
     'das_decode_cap': (i32, [C.POINTER(DasDecodeDesc)]),
     'das_decode_ws_bytes': (i64, [i32, i32, i32]),
     'das_decode': (i32, [C.POINTER(DasDecodeDesc), vp, vp, vp, vp, vp, vp, vp]),

@@ -77,3 +77,39 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 }
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- ragged multi-level rows (DasLevels): row m -> level, image, (h, w), plane origin
+struct LvGeom {
+  int l, b, h, w, H, W;
+  long long plane0;  // first row of this (level, image) plane
+};
+__host__ __device__ inline long long lv_total_rows(const DasLevels& lv) {
+  long long n = 0;
+  for (int l = 0; l < lv.num_levels; ++l) n += (long long)lv.B * lv.H[l] * lv.W[l];
+  return n;
+}
+__device__ __forceinline__ LvGeom lv_geom(const DasLevels& lv, long long m) {
+  LvGeom g;
+  long long start = 0;
+  int l = 0;
+  for (; l + 1 < lv.num_levels; ++l) {
+    const long long n = (long long)lv.B * lv.H[l] * lv.W[l];
+    if (m < start + n) break;
+    start += n;
+  }
+  g.l = l; g.H = lv.H[l]; g.W = lv.W[l];
+  const long long local = m - start;
+  const int hw = g.H * g.W;
+  g.b = (int)(local / hw);
+  const int rem = (int)(local - (long long)g.b * hw);
+  g.h = rem / g.W;
+  g.w = rem - g.h * g.W;
+  g.plane0 = start + (long long)g.b * hw;
+  return g;
+}
+static inline bool lv_valid(const DasLevels* lv) {
+  if (!lv || lv->num_levels < 1 || lv->num_levels > 5 || lv->B < 1) return false;
+  for (int l = 0; l < lv->num_levels; ++l)
+    if (lv->H[l] < 1 || lv->W[l] < 1) return false;
+  return true;
+}

@@ -1,0 +1,205 @@
+// Shared pieces of the implicit-GEMM convolution kernels: parameter block, MFMA wrappers and
+// the fused epilogue (scale/shift -> LDS-staged C tile -> residual / ReLU / BN statistics ->
+// 16-byte coalesced NHWC stores).
+#pragma once
+#include "common.h"
+
+namespace dasconv {
+
+constexpr int BM = 128;
+constexpr int MAXLV = DAS_MAX_LEVELS;
+
+struct ConvP {
+  const char* x;
+  const char* w;
+  char* y;
+  const float* scale;
+  const float* shift;
+  const char* res;
+  float* stats;
+  int H, W, Cin, xps;
+  int Ho, Wo, Cout, yps;
+  int KH, KW, stride, pad;
+  int relu_in, relu, rps;
+  int M, K, HoWo, ntiles, nblocks;
+  // ragged multi-level input (stride 1, "same" padding): rows of level l start at lvStart[l]
+  int nlev, B;
+  int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 relu_vec(uint4 v);
+template <>
+__device__ __forceinline__ uint4 relu_vec<float>(uint4 v) {
+  v.x = (v.x >> 31) ? 0u : v.x; v.y = (v.y >> 31) ? 0u : v.y;
+  v.z = (v.z >> 31) ? 0u : v.z; v.w = (v.w >> 31) ? 0u : v.w;
+  return v;
+}
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t u) {
+  uint32_t lo = (u & 0x8000u) ? 0u : (u & 0xffffu);
+  uint32_t hi = (u & 0x80000000u) ? 0u : (u & 0xffff0000u);
+  return lo | hi;
+}
+template <>
+__device__ __forceinline__ uint4 relu_vec<bf16_t>(uint4 v) {
+  return make_uint4(relu_bf16x2(v.x), relu_bf16x2(v.y), relu_bf16x2(v.z), relu_bf16x2(v.w));
+}
+
+// One 16-byte fragment pair -> accumulate. bf16: one 16x16x32 MFMA; f32: four exact-f32 16x16x4 MFMAs
+// (lane l holds k-group l>>4 of both operands, so the 4 dwords are 4 consistent k slices).
+template <typename T>
+__device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4_t& c);
+template <>
+__device__ __forceinline__ void mma<bf16_t>(const uint4& a, const uint4& b, f32x4_t& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0,
+                                              0, 0);
+}
+template <>
+__device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4_t& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+}
+
+template <int BN>
+struct Tiling {
+  static constexpr int TM = (BN == 128) ? 4 : 2;   // 16-row pixel tiles per wave
+  static constexpr int TN = (BN >= 64) ? 4 : 2;    // 16-row channel tiles per wave
+  static __device__ __forceinline__ int wave_m0(int wave) { return (BN == 128) ? (wave & 1) * 64 : wave * 32; }
+  static __device__ __forceinline__ int wave_n0(int wave) { return (BN == 128) ? (wave >> 1) * 64 : 0; }
+};
+
+template <typename OT, int BN>
+constexpr size_t epilogue_smem_bytes() {
+  size_t ctile = (size_t)BM * (BN * sizeof(OT) + 16);
+  size_t red = 2 * (size_t)(256 / (BN * sizeof(OT) / 16)) * BN * 4;
+  return ctile > red ? ctile : red;
+}
+
+// acc[a][b][j]: channel n0 + wave_n0 + a*16 + (lane>>4)*4 + j, pixel m0 + wave_m0 + b*16 + (lane&15).
+// Must be entered after a barrier that ends all LDS reads of the main loop.
+template <typename OT, int BN>
+__device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[Tiling<BN>::TN][Tiling<BN>::TM], const ConvP& p,
+                                              char* smem, int m0, int n0) {
+  constexpr int TM = Tiling<BN>::TM, TN = Tiling<BN>::TN;
+  constexpr int EPVO = 16 / (int)sizeof(OT);
+  constexpr int CS = BN * (int)sizeof(OT) + 16;  // padded C-tile row stride in bytes
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m0 = Tiling<BN>::wave_m0(wave), wave_n0 = Tiling<BN>::wave_n0(wave);
+  const int ch4 = (lane >> 4) * 4;
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+    const int nl = wave_n0 + a * 16 + ch4;
+    const int n = n0 + nl;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.Cout) {
+      if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + n); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
+      if (p.shift) { const float4 t = *reinterpret_cast<const float4*>(p.shift + n); sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w; }
+    }
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const int ml = wave_m0 + b * 16 + (lane & 15);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] * sc[j] + sh[j];
+      char* dst = smem + ml * CS + nl * (int)sizeof(OT);
+      if (sizeof(OT) == 2) {
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  __syncthreads();
+
+  constexpr int VR = BN * (int)sizeof(OT) / 16;  // 16-B vectors per C row
+  constexpr int RP = 256 / VR;                   // rows per pass
+  const int vec = tid % VR, r0 = tid / VR;
+  const int n = n0 + vec * EPVO;
+  float ssum[EPVO], ssq[EPVO];
+#pragma unroll
+  for (int j = 0; j < EPVO; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  OT* yg = reinterpret_cast<OT*>(p.y);
+  const OT* rg = reinterpret_cast<const OT*>(p.res);
+  if (n < p.Cout) {
+#pragma unroll 2
+    for (int ml = r0; ml < BM; ml += RP) {
+      const int m = m0 + ml;
+      if (m >= p.M) break;
+      const uint4 raw = *reinterpret_cast<const uint4*>(smem + ml * CS + vec * 16);
+      float f[EPVO];
+      Elem<OT>::unpack(raw, f);
+      if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < EPVO; ++j) { ssum[j] += f[j]; ssq[j] += f[j] * f[j]; }
+      }
+      if (rg) {
+        float r[EPVO];
+        Elem<OT>::unpack(*reinterpret_cast<const uint4*>(rg + (long long)m * p.rps + n), r);
+#pragma unroll
+        for (int j = 0; j < EPVO; ++j) f[j] += r[j];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < EPVO; ++j) f[j] = fmaxf(f[j], 0.f);
+      }
+      *reinterpret_cast<uint4*>(yg + (long long)m * p.yps + n) = (rg || p.relu) ? Elem<OT>::pack(f) : raw;
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [2][RP][BN]
+#pragma unroll
+    for (int j = 0; j < EPVO; ++j) {
+      red[r0 * BN + vec * EPVO + j] = ssum[j];
+      red[(RP + r0) * BN + vec * EPVO + j] = ssq[j];
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid % BN;
+      if (n0 + c < p.Cout) {
+        float s = 0.f;
+        for (int r = 0; r < RP; ++r) s += red[(which * RP + r) * BN + c];
+        atomicAdd(p.stats + which * p.Cout + n0 + c, s);
+      }
+    }
+  }
+}
+
+// Decode output row m into (image-plane origin offset in pixels, top-left input coords, plane size).
+struct RowGeom {
+  long long pix0;  // first pixel row of this image plane in x
+  int hi0, wi0, H, W;
+};
+__device__ __forceinline__ RowGeom row_geom(const ConvP& p, int m) {
+  RowGeom g;
+  if (m >= p.M) {
+    g.pix0 = 0; g.hi0 = -(1 << 28); g.wi0 = 0; g.H = 0; g.W = 0;
+    return g;
+  }
+  if (p.nlev <= 1) {
+    const int b = m / p.HoWo, rem = m - b * p.HoWo;
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    g.pix0 = (long long)b * p.H * p.W;
+    g.hi0 = ho * p.stride - p.pad;
+    g.wi0 = wo * p.stride - p.pad;
+    g.H = p.H; g.W = p.W;
+    return g;
+  }
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < MAXLV; ++i)
+    if (i < p.nlev && m >= p.lvStart[i]) l = i;
+  const int Hl = p.lvH[l], Wl = p.lvW[l], hw = Hl * Wl;
+  const int local = m - p.lvStart[l];
+  const int b = local / hw, rem = local - b * hw;
+  const int ho = rem / Wl, wo = rem - ho * Wl;
+  g.pix0 = (long long)p.lvStart[l] + (long long)b * hw;
+  g.hi0 = ho - p.pad;
+  g.wi0 = wo - p.pad;
+  g.H = Hl; g.W = Wl;
+  return g;
+}
+
+}  // namespace dasconv

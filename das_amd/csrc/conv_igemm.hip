@@ -2,78 +2,39 @@
 //
 // GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin (tap-major, channel-minor,
 // which is exactly the memory order of both the NHWC input row and the packed weights).
-// Tile 128(M) x BN(N) x BK(K) per 256-thread workgroup (4 waves); BK = 64 bytes of K per row
-// (32 bf16 / 16 f32). The weight tile feeds the MFMA "A" operand and the pixel tile the "B"
-// operand, so every lane ends up with 4 consecutive output channels of one pixel.
-//   bf16: v_mfma_f32_16x16x32_bf16        f32: 4 x v_mfma_f32_16x16x4_f32 (exact f32)
-// LDS rows are 64 B, 16-B slots XOR-swizzled so ds_read_b128 fragment reads are conflict
-// free under gfx950's non-contiguous b128 lane groups.
-// Global->register prefetch of tile k+1 overlaps the MFMAs of tile k; one barrier per K step.
-// Epilogue: per-channel scale/shift in registers -> stage the C tile in LDS -> 16-byte
-// coalesced NHWC stores with optional residual add, ReLU and per-channel sum / sum-of-squares
-// (train-mode BatchNorm statistics) reduced per block and accumulated with f32 atomics.
-#include "common.h"
+// Tile 128(M) x BN(N) per 256-thread workgroup (4 waves). The weight tile feeds the MFMA "A"
+// operand and the pixel tile the "B" operand, so every lane ends up with 4 consecutive output
+// channels of one pixel.   bf16: v_mfma_f32_16x16x32_bf16   f32: 4 x v_mfma_f32_16x16x4_f32 (exact)
+//
+// Two main loops share the epilogue in conv_common.h:
+//  * conv_glds_kernel  (fast path, Cin % BK == 0): 128 bytes of K per row per step (64 bf16 / 32 f32),
+//    both tiles DMA'd global->LDS with global_load_lds_dwordx4 (no VGPR staging), double-buffered,
+//    one vmcnt(0)+barrier per step. LDS image is lane-linear, so the bank swizzle is applied to the
+//    per-lane SOURCE address and to the fragment read (slot ^= (row>>1)&7); padding taps and tile
+//    tails read a 16-byte zero page instead of branching.
+//  * conv_reg_kernel   (generic path: the 7x7 stem with Cin=8, tiny test widths): 64 bytes of K per
+//    step staged through registers, slot ^= (-(row>>2))&3.
+// Both swizzles make ds_read_b128 conflict-free under gfx950's non-contiguous b128 lane groups.
+// A "ragged multi-level" mode (nlev > 1) lets one launch cover all FPN levels of the shared-weight
+// head convs: rows of level l start at lvStart[l] and carry their own (H, W).
+#include <algorithm>
+
+#include "conv_common.h"
+
+using namespace dasconv;
+
+__device__ uint4 g_das_zero_page[8];  // 128 B of zeros: source of every out-of-bounds DMA
 
 namespace {
 
-struct ConvP {
-  const char* x;
-  const char* w;
-  char* y;
-  const float* scale;
-  const float* shift;
-  const char* res;
-  float* stats;
-  int H, W, Cin, xps;
-  int Ho, Wo, Cout, yps;
-  int KH, KW, stride, pad;
-  int relu_in, relu, rps;
-  int M, K, HoWo, ntiles, nblocks;
-};
-
-constexpr int BM = 128;
-
-__device__ __forceinline__ int lds_slot(int row, int kg) { return row * 64 + ((kg ^ ((-(row >> 2)) & 3)) << 4); }
-
-template <typename T>
-__device__ __forceinline__ uint4 relu_vec(uint4 v);
-template <>
-__device__ __forceinline__ uint4 relu_vec<float>(uint4 v) {
-  v.x = (v.x >> 31) ? 0u : v.x; v.y = (v.y >> 31) ? 0u : v.y;
-  v.z = (v.z >> 31) ? 0u : v.z; v.w = (v.w >> 31) ? 0u : v.w;
-  return v;
-}
-__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t u) {
-  uint32_t lo = (u & 0x8000u) ? 0u : (u & 0xffffu);
-  uint32_t hi = (u & 0x80000000u) ? 0u : (u & 0xffff0000u);
-  return lo | hi;
-}
-template <>
-__device__ __forceinline__ uint4 relu_vec<bf16_t>(uint4 v) {
-  return make_uint4(relu_bf16x2(v.x), relu_bf16x2(v.y), relu_bf16x2(v.z), relu_bf16x2(v.w));
-}
-
-template <typename T>
-__device__ __forceinline__ void mma(const uint4& a, const uint4& b, f32x4_t& c);
-template <>
-__device__ __forceinline__ void mma<bf16_t>(const uint4& a, const uint4& b, f32x4_t& c) {
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0,
-                                              0, 0);
-}
-template <>
-__device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4_t& c) {
-  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-}
+// =============================================================== generic register-staged kernel
+__device__ __forceinline__ int slot64(int row, int kg) { return row * 64 + ((kg ^ ((-(row >> 2)) & 3)) << 4); }
 
 template <typename T, typename OT, int BN, bool ALIGNED>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+__global__ __launch_bounds__(256) void conv_reg_kernel(ConvP p) {
   constexpr int EPV = Elem<T>::EPV;
   constexpr int BK = 4 * EPV;
-  constexpr int TM = (BN == 128) ? 4 : 2;
-  constexpr int TN = (BN >= 64) ? 4 : 2;
+  constexpr int TM = Tiling<BN>::TM, TN = Tiling<BN>::TN;
   constexpr int WROWS = (BN >= 64) ? BN / 64 : 1;  // weight rows staged per thread
   constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,35 +44,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
   const int n0 = (logical % p.ntiles) * BN;
   const int m0 = (logical / p.ntiles) * BM;
-  const int wave_m0 = (BN == 128) ? (wave & 1) * 64 : wave * 32;
-  const int wave_n0 = (BN == 128) ? (wave >> 1) * 64 : 0;
+  const int wave_m0 = Tiling<BN>::wave_m0(wave), wave_n0 = Tiling<BN>::wave_n0(wave);
 
-  // ---- per-thread staging coordinates: 2 pixel rows + WROWS weight rows, one 16-B k-group
   const int srow = tid >> 2, kg = tid & 3;
-  int hi0[2], wi0[2];
-  long long xoff[2];
+  RowGeom rg[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + srow + 64 * i;
-    if (m < p.M) {
-      const int b = m / p.HoWo, rem = m - b * p.HoWo;
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      hi0[i] = ho * p.stride - p.pad;
-      wi0[i] = wo * p.stride - p.pad;
-      xoff[i] = (long long)b * p.H * p.W * p.xps;
-    } else {
-      hi0[i] = -(1 << 28);
-      wi0[i] = 0;
-      xoff[i] = 0;
-    }
-  }
+  for (int i = 0; i < 2; ++i) rg[i] = row_geom(p, m0 + srow + 64 * i);
   const bool w_active = (BN >= 64) || (tid < 128);
   const T* xg = reinterpret_cast<const T*>(p.x);
   const T* wg = reinterpret_cast<const T*>(p.w);
 
   uint4 ra[2], rw[WROWS];
-  // incremental (kh, kw, ci) of the tile being fetched, used when Cin % BK == 0
-  int f_kh = 0, f_kw = 0, f_ci = 0;
+  int f_kh = 0, f_kw = 0, f_ci = 0;  // incremental tap state when Cin % BK == 0
 
   auto fetch = [&](int kt) {
     const int k0 = kt * BK + kg * EPV;
@@ -128,10 +72,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int hi = hi0[i] + kh, wi = wi0[i] + kw;
+      const int hi = rg[i].hi0 + kh, wi = rg[i].wi0 + kw;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (kok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
-        v = *reinterpret_cast<const uint4*>(xg + xoff[i] + ((long long)hi * p.W + wi) * p.xps + ci);
+      if (kok && hi >= 0 && hi < rg[i].H && wi >= 0 && wi < rg[i].W) {
+        v = *reinterpret_cast<const uint4*>(xg + (rg[i].pix0 + (long long)hi * rg[i].W + wi) * p.xps + ci);
         if (p.relu_in) v = relu_vec<T>(v);
       }
       ra[i] = v;
@@ -155,10 +99,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     char* sA = smem + buf * A_BYTES;
     char* sW = smem + 2 * A_BYTES + buf * W_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(sA + lds_slot(srow + 64 * i, kg)) = ra[i];
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(sA + slot64(srow + 64 * i, kg)) = ra[i];
     if (w_active) {
 #pragma unroll
-      for (int i = 0; i < WROWS; ++i) *reinterpret_cast<uint4*>(sW + lds_slot(srow + 64 * i, kg)) = rw[i];
+      for (int i = 0; i < WROWS; ++i) *reinterpret_cast<uint4*>(sW + slot64(srow + 64 * i, kg)) = rw[i];
     }
   };
 
@@ -180,9 +124,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const char* sW = smem + 2 * A_BYTES + buf * W_BYTES;
     uint4 fb[TM], fa[TN];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) fb[t] = *reinterpret_cast<const uint4*>(sA + lds_slot(wave_m0 + t * 16 + frow, fkg));
+    for (int t = 0; t < TM; ++t) fb[t] = *reinterpret_cast<const uint4*>(sA + slot64(wave_m0 + t * 16 + frow, fkg));
 #pragma unroll
-    for (int t = 0; t < TN; ++t) fa[t] = *reinterpret_cast<const uint4*>(sW + lds_slot(wave_n0 + t * 16 + frow, fkg));
+    for (int t = 0; t < TN; ++t) fa[t] = *reinterpret_cast<const uint4*>(sW + slot64(wave_n0 + t * 16 + frow, fkg));
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -190,128 +134,153 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     if (kt + 1 < nk) stash(buf ^ 1);
     __syncthreads();
   }
+  conv_epilogue<OT, BN>(acc, p, smem, m0, n0);
+}
 
-  // ---------------------------------------------------------------- epilogue
-  constexpr int EPVO = 16 / (int)sizeof(OT);
-  constexpr int CS = BN * (int)sizeof(OT) + 16;  // padded C-tile row stride in bytes
-  const int ch4 = (lane >> 4) * 4;
-#pragma unroll
-  for (int a = 0; a < TN; ++a) {
-    const int nl = wave_n0 + a * 16 + ch4;
-    const int n = n0 + nl;
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n < p.Cout) {
-      if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + n); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
-      if (p.shift) { const float4 t = *reinterpret_cast<const float4*>(p.shift + n); sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w; }
-    }
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-      const int ml = wave_m0 + b * 16 + (lane & 15);
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j] * sc[j] + sh[j];
-      char* dst = smem + ml * CS + nl * (int)sizeof(OT);
-      if (sizeof(OT) == 2) {
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-      } else {
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
-  __syncthreads();
+// =============================================================== global_load_lds fast path
+__device__ __forceinline__ int slot128(int row, int kg) { return row * 128 + ((kg ^ ((row >> 1) & 7)) << 4); }
 
-  constexpr int VR = BN * (int)sizeof(OT) / 16;  // 16-B vectors per C row
-  constexpr int RP = 256 / VR;                   // rows per pass
-  const int vec = tid % VR, r0 = tid / VR;
-  const int n = n0 + vec * EPVO;
-  float ssum[EPVO], ssq[EPVO];
-#pragma unroll
-  for (int j = 0; j < EPVO; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-  OT* yg = reinterpret_cast<OT*>(p.y);
-  const OT* rg = reinterpret_cast<const OT*>(p.res);
-  if (n < p.Cout) {
-#pragma unroll 2
-    for (int ml = r0; ml < BM; ml += RP) {
-      const int m = m0 + ml;
-      if (m >= p.M) break;
-      const uint4 raw = *reinterpret_cast<const uint4*>(smem + ml * CS + vec * 16);
-      float f[EPVO];
-      Elem<OT>::unpack(raw, f);
-      if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < EPVO; ++j) { ssum[j] += f[j]; ssq[j] += f[j] * f[j]; }
-      }
-      if (rg) {
-        float r[EPVO];
-        Elem<OT>::unpack(*reinterpret_cast<const uint4*>(rg + (long long)m * p.rps + n), r);
-#pragma unroll
-        for (int j = 0; j < EPVO; ++j) f[j] += r[j];
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int j = 0; j < EPVO; ++j) f[j] = fmaxf(f[j], 0.f);
-      }
-      *reinterpret_cast<uint4*>(yg + (long long)m * p.yps + n) = (rg || p.relu) ? Elem<OT>::pack(f) : raw;
-    }
-  }
-  if (p.stats) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [2][RP][BN]
-#pragma unroll
-    for (int j = 0; j < EPVO; ++j) {
-      red[r0 * BN + vec * EPVO + j] = ssum[j];
-      red[(RP + r0) * BN + vec * EPVO + j] = ssq[j];
-    }
-    __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, c = tid % BN;
-      if (n0 + c < p.Cout) {
-        float s = 0.f;
-        for (int r = 0; r < RP; ++r) s += red[(which * RP + r) * BN + c];
-        atomicAdd(p.stats + which * p.Cout + n0 + c, s);
-      }
-    }
-  }
+__device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 template <typename T, typename OT, int BN>
-size_t smem_bytes() {
-  size_t stage = 2 * (size_t)(BM + BN) * 64;
-  size_t ctile = (size_t)BM * (BN * sizeof(OT) + 16);
-  size_t red = 2 * (size_t)(256 / (BN * sizeof(OT) / 16)) * BN * 4;
-  size_t m = stage > ctile ? stage : ctile;
-  return m > red ? m : red;
+__global__ __launch_bounds__(256) void conv_glds_kernel(ConvP p) {
+  constexpr int EPV = Elem<T>::EPV;
+  constexpr int BK = 8 * EPV;  // 128 bytes of K per row
+  constexpr int TM = Tiling<BN>::TM, TN = Tiling<BN>::TN;
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
+  constexpr int A_INSTR = 4;        // 1 KiB (8 rows) per wave-instruction, 16 KiB pixel tile / 4 waves
+  constexpr int W_INSTR = BN / 32;  // weight tile chunks per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int logical = xcd_remap(blockIdx.x, p.nblocks);
+  const int n0 = (logical % p.ntiles) * BN;
+  const int m0 = (logical / p.ntiles) * BM;
+  const int wave_m0 = Tiling<BN>::wave_m0(wave), wave_n0 = Tiling<BN>::wave_n0(wave);
+
+  // ---- DMA coordinates: chunk c covers LDS rows c*8..c*8+7; lane -> (row, physical slot)
+  const int lrow = lane >> 3, pslot = lane & 7;
+  const T* xg = reinterpret_cast<const T*>(p.x);
+  const T* wg = reinterpret_cast<const T*>(p.w);
+  const T* zero = reinterpret_cast<const T*>(g_das_zero_page);
+  RowGeom rg[A_INSTR];
+  int akg[A_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int row = (wave * A_INSTR + j) * 8 + lrow;
+    rg[j] = row_geom(p, m0 + row);
+    akg[j] = (pslot ^ ((row >> 1) & 7)) * EPV;  // logical k offset (elements) this lane fetches
+  }
+  const T* wrow[W_INSTR];
+#pragma unroll
+  for (int j = 0; j < W_INSTR; ++j) {
+    const int row = (wave * W_INSTR + j) * 8 + lrow;
+    const int n = n0 + row;
+    wrow[j] = (n < p.Cout) ? wg + (long long)n * p.K + (pslot ^ ((row >> 1) & 7)) * EPV : nullptr;
+  }
+
+  // per-row base pointer of tap (0,0), channel group akg: the tap offset is added per step and the
+  // pointer is only dereferenced when the tap is in bounds (else the zero page is selected)
+  const T* abase[A_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j)
+    abase[j] = xg + (rg[j].pix0 + (long long)rg[j].hi0 * rg[j].W + rg[j].wi0) * p.xps + akg[j];
+
+  int f_kh = 0, f_kw = 0, f_ci = 0;
+  auto issue = [&](int kt, int buf) {
+    char* sA = smem + buf * BUF;
+    char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      const int hi = rg[j].hi0 + f_kh, wi = rg[j].wi0 + f_kw;
+      const bool ok = (unsigned)hi < (unsigned)rg[j].H && (unsigned)wi < (unsigned)rg[j].W;
+      const T* cand = abase[j] + (long long)(f_kh * rg[j].W + f_kw) * p.xps + f_ci;
+      dma16(ok ? cand : zero, sA + (wave * A_INSTR + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) {
+      const T* cand = wrow[j] + (long long)kt * BK;
+      dma16(wrow[j] ? cand : zero, sW + (wave * W_INSTR + j) * 1024);
+    }
+    f_ci += BK;
+    if (f_ci >= p.Cin) {
+      f_ci = 0;
+      if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+    }
+  };
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  issue(0, 0);
+  __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
+  const int frow = lane & 15, fkg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const char* sA = smem + buf * BUF;
+    const char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint4 fb[TM], fa[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        fb[i] = *reinterpret_cast<const uint4*>(sA + slot128(wave_m0 + i * 16 + frow, t * 4 + fkg));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fa[i] = *reinterpret_cast<const uint4*>(sW + slot128(wave_n0 + i * 16 + frow, t * 4 + fkg));
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) mma<T>(fa[a], fb[b], acc[a][b]);
+    }
+    __syncthreads();  // prefetch landed (vmcnt 0) and every wave is done reading `buf`
+  }
+  conv_epilogue<OT, BN>(acc, p, smem, m0, n0);
 }
 
+// =============================================================== launch
 template <typename T, typename OT, int BN>
-int launch(const ConvP& p0, bool aligned, hipStream_t s) {
+int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   ConvP p = p0;
   p.ntiles = (p.Cout + BN - 1) / BN;
   const int mtiles = (p.M + BM - 1) / BM;
   p.nblocks = p.ntiles * mtiles;
-  const size_t sm = smem_bytes<T, OT, BN>();
+  const size_t epi = epilogue_smem_bytes<OT, BN>();
+  const size_t sm_reg = std::max<size_t>(2 * (size_t)(BM + BN) * 64, epi);
+  const size_t sm_glds = std::max<size_t>(2 * (size_t)(BM + BN) * 128, epi);
   static bool attr_set = false;  // one flag per instantiation; > 64 KiB dynamic LDS needs the opt-in
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BN, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OT, BN, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
+    (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
+    (void)hipFuncSetAttribute((const void*)conv_glds_kernel<T, OT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_glds);
     attr_set = true;
   }
-  if (aligned) {
-    hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BN, true>), dim3(p.nblocks), dim3(256), sm, s, p);
+  if (glds) {
+    hipLaunchKernelGGL((conv_glds_kernel<T, OT, BN>), dim3(p.nblocks), dim3(256), sm_glds, s, p);
+  } else if (aligned) {
+    hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, true>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
   } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<T, OT, BN, false>), dim3(p.nblocks), dim3(256), sm, s, p);
+    hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, false>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
   }
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }
 
 template <typename T, typename OT>
-int launch_bn(const ConvP& p, bool aligned, hipStream_t s) {
-  if (p.Cout > 64) return launch<T, OT, 128>(p, aligned, s);
-  if (p.Cout > 32) return launch<T, OT, 64>(p, aligned, s);
-  return launch<T, OT, 32>(p, aligned, s);
+int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
+  if (p.Cout > 64) return launch<T, OT, 128>(p, glds, aligned, s);
+  if (p.Cout > 32) return launch<T, OT, 64>(p, glds, aligned, s);
+  return launch<T, OT, 32>(p, glds, aligned, s);
 }
 
 }  // namespace
@@ -323,9 +292,22 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   if (d->residual && (d->out_dtype != d->dtype || d->res_pix_stride % 8)) return DAS_ERR_ARG;
   if (d->dtype == DAS_F32 && d->out_dtype != DAS_F32) return DAS_ERR_ARG;
   if (d->KH < 1 || d->KW < 1 || d->stride < 1 || d->B < 1) return DAS_ERR_ARG;
-  const long long M = (long long)d->B * d->Ho * d->Wo;
-  if (M <= 0 || M > 0x7fffffffLL) return DAS_ERR_ARG;
   ConvP p;
+  long long M = (long long)d->B * d->Ho * d->Wo;
+  p.nlev = d->num_levels;
+  p.B = d->B;
+  if (p.nlev > 1) {
+    // ragged multi-level rows: stride 1, "same" padding, output geometry == input geometry
+    if (p.nlev > MAXLV || d->stride != 1 || d->KH != d->KW || d->pad != d->KH / 2) return DAS_ERR_ARG;
+    M = 0;
+    for (int l = 0; l < p.nlev; ++l) {
+      if (d->lvl_H[l] < 1 || d->lvl_W[l] < 1) return DAS_ERR_ARG;
+      p.lvH[l] = d->lvl_H[l]; p.lvW[l] = d->lvl_W[l]; p.lvStart[l] = (int)M;
+      M += (long long)d->B * d->lvl_H[l] * d->lvl_W[l];
+    }
+  }
+  for (int l = (p.nlev > 1 ? p.nlev : 0); l < MAXLV; ++l) { p.lvH[l] = 0; p.lvW[l] = 0; p.lvStart[l] = 0x7fffffff; }
+  if (M <= 0 || M > 0x7fffffffLL) return DAS_ERR_ARG;
   p.x = (const char*)x; p.w = (const char*)w; p.y = (char*)y;
   p.scale = d->scale; p.shift = d->shift; p.res = (const char*)d->residual; p.stats = d->stats;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.xps = d->x_pix_stride;
@@ -336,10 +318,10 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   p.ntiles = p.nblocks = 0;
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == DAS_BF16) {
-    const bool aligned = (d->Cin % 32) == 0;
-    if (d->out_dtype == DAS_BF16) return launch_bn<bf16_t, bf16_t>(p, aligned, s);
-    return launch_bn<bf16_t, float>(p, aligned, s);
+    const bool glds = (d->Cin % 64) == 0 && !d->relu_in, aligned = (d->Cin % 32) == 0;
+    if (d->out_dtype == DAS_BF16) return launch_bn<bf16_t, bf16_t>(p, glds, aligned, s);
+    return launch_bn<bf16_t, float>(p, glds, aligned, s);
   }
-  if (d->dtype == DAS_F32) return launch_bn<float, float>(p, (d->Cin % 16) == 0, s);
+  if (d->dtype == DAS_F32) return launch_bn<float, float>(p, (d->Cin % 32) == 0 && !d->relu_in, (d->Cin % 16) == 0, s);
   return DAS_ERR_ARG;
 }

@@ -1,6 +1,7 @@
 // DASHead-specific kernels: DCNv2 deformable im2col, the fused recursive-update offset
 // re-sampling, the sigmoid-gated blend and the per-level assemble / finalize of pose_pred.
-// All HBM / latency bound gather work in f32 arithmetic.
+// All HBM / latency bound gather work in f32 arithmetic. Every kernel works on "ragged" rows
+// (DasLevels): one launch covers all FPN levels.
 #include "common.h"
 
 namespace {
@@ -13,8 +14,8 @@ inline int grid_for(long long n) {
 // ------------------------------------------------------------------ DCNv2 im2col (3x3, s1, p1)
 // One thread = one (pixel, tap, 16-B channel vector). col row = [tap][C].
 template <typename T>
-__global__ void deform_im2col_kernel(const T* __restrict__ x, const float* __restrict__ om, T* __restrict__ col, int B,
-                                     int H, int W, int C, int xps, int omps, long long total) {
+__global__ void deform_im2col_kernel(const T* __restrict__ x, const float* __restrict__ om, T* __restrict__ col,
+                                     DasLevels lv, int C, int xps, int omps, long long total) {
 #pragma clang fp contract(off)
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV;
@@ -23,15 +24,13 @@ __global__ void deform_im2col_kernel(const T* __restrict__ x, const float* __res
     long long r = i / VC;
     const int k = (int)(r % 9);
     const long long m = r / 9;
-    const int wo = (int)(m % W);
-    const long long t = m / W;
-    const int ho = (int)(t % H);
-    const long long b = t / H;
+    const LvGeom g = lv_geom(lv, m);
+    const int H = g.H, W = g.W;
     const float* o = om + m * omps;
     const float dy = o[2 * k], dx = o[2 * k + 1];
     const float mask = 1.f / (1.f + expf(-o[18 + k]));
-    const float py = (float)(ho - 1 + k / 3) + dy;
-    const float px = (float)(wo - 1 + k % 3) + dx;
+    const float py = (float)(g.h - 1 + k / 3) + dy;
+    const float px = (float)(g.w - 1 + k % 3) + dx;
     float out[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) out[j] = 0.f;
@@ -39,7 +38,7 @@ __global__ void deform_im2col_kernel(const T* __restrict__ x, const float* __res
       const float fy = floorf(py), fx = floorf(px);
       const int y0 = (int)fy, x0 = (int)fx;
       const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
-      const T* base = x + (b * H * W) * (long long)xps + v * EPV;
+      const T* base = x + g.plane0 * (long long)xps + v * EPV;
       const float wts[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -97,22 +96,20 @@ __device__ __forceinline__ void sample_nhwc(const float* __restrict__ img, int H
   }
 }
 
-// One thread = one (image, pixel, joint). heads is fixed at 4 (2*heads = 8 sampling sites).
+// One thread = one (pixel, joint). heads is fixed at 4 (2*heads = 8 sampling sites).
 __global__ void offset_sample_kernel(const float* __restrict__ uvd, const float* __restrict__ so,
-                                     const float* __restrict__ conf, float* __restrict__ out, int B, int H, int W,
-                                     int J, int uvd_ps, int so_ps, int conf_ps, int out_ps, long long total) {
+                                     const float* __restrict__ conf, float* __restrict__ out, DasLevels lv, int J,
+                                     int uvd_ps, int so_ps, int conf_ps, int out_ps, long long total) {
 #pragma clang fp contract(off)
   constexpr int HEADS = 4, S = 2 * HEADS;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const int j = (int)(i % J);
     const long long pix = i / J;
-    const int px = (int)(pix % W);
-    const long long t = pix / W;
-    const int py = (int)(t % H);
-    const long long b = t / H;
-    const float* uvd_b = uvd + b * H * W * (long long)uvd_ps;
-    const float* so_b = so + b * H * W * (long long)so_ps;
-    const float* conf_b = conf + b * H * W * (long long)conf_ps;
+    const LvGeom g = lv_geom(lv, pix);
+    const int H = g.H, W = g.W, px = g.w, py = g.h;
+    const float* uvd_b = uvd + g.plane0 * (long long)uvd_ps;
+    const float* so_b = so + g.plane0 * (long long)so_ps;
+    const float* conf_b = conf + g.plane0 * (long long)conf_ps;
     const float fw = (float)W, fh = (float)H;
     const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
     const float* u = uvd_b + ((long long)py * W + px) * uvd_ps + j * 3;
@@ -171,22 +168,34 @@ __global__ void sigmoid_blend_kernel(const float* __restrict__ off, const float*
   }
 }
 
+__device__ __forceinline__ int level_of(const DasLevels& lv, long long m) {
+  long long start = 0;
+  int l = 0;
+  for (; l + 1 < lv.num_levels; ++l) {
+    const long long n = (long long)lv.B * lv.H[l] * lv.W[l];
+    if (m < start + n) break;
+    start += n;
+  }
+  return l;
+}
+
 __global__ void head_assemble_kernel(const float* __restrict__ raw, float* __restrict__ pose, float* __restrict__ uvd,
-                                     long long npix, DasHeadAssembleDesc d) {
+                                     long long npix, DasLevels lv, DasHeadDesc d) {
   const int J3 = 3 * d.J, D = 3 + 6 * d.J;
   const long long total = npix * D;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const int c = (int)(i % D);
     const long long p = i / D;
+    const float* sc = d.scale[level_of(lv, p)];
     const float* r = raw + p * d.raw_ps;
     float v;
     if (c < 2) {
-      v = r[d.off_c + c] * d.scale_off;
+      v = r[d.off_c + c] * sc[0];
     } else if (c == 2) {
-      v = r[d.depth_c] * d.scale_depth;
+      v = r[d.depth_c] * sc[1];
     } else if (c < 3 + J3) {
       const int k = c - 3, comp = k % 3;
-      v = r[d.uvd_c + k] * (comp == 2 ? d.scale_d : d.scale_uv);
+      v = r[d.uvd_c + k] * (comp == 2 ? sc[3] : sc[2]);
       if (k == d.root_idx * 3 + 2) v = 0.f;
       uvd[p * J3 + k] = v;
     } else {
@@ -198,41 +207,40 @@ __global__ void head_assemble_kernel(const float* __restrict__ raw, float* __res
   }
 }
 
-__global__ void head_finalize_kernel(float* __restrict__ pose, float* __restrict__ ref, long long npix, int J,
-                                     int root_idx, int ref_ps, float stride, float z_norm, float depth_factor,
-                                     int eval_mode) {
+__global__ void head_finalize_kernel(float* __restrict__ pose, float* __restrict__ ref, long long npix, DasLevels lv,
+                                     DasHeadDesc d, int ref_ps, int eval_mode) {
 #pragma clang fp contract(off)
-  const int J3 = 3 * J, D = 3 + 6 * J;
+  const int J3 = 3 * d.J, D = 3 + 6 * d.J;
   const long long total = npix * (J3 + 1);
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const int k = (int)(i % (J3 + 1));
     const long long p = i / (J3 + 1);
     if (k == J3) {
-      if (eval_mode) pose[p * D + 2] = pose[p * D + 2] / depth_factor;
+      if (eval_mode) pose[p * D + 2] = pose[p * D + 2] / d.depth_factor;
       continue;
     }
     float v = ref[p * ref_ps + k];
-    if (k == root_idx * 3 + 2) {
+    if (k == d.root_idx * 3 + 2) {
       v = 0.f;
       ref[p * ref_ps + k] = 0.f;
     }
-    if (eval_mode) pose[p * D + 3 + k] = v * ((k % 3) == 2 ? z_norm : stride);
+    if (eval_mode) pose[p * D + 3 + k] = v * ((k % 3) == 2 ? d.z_norm : d.level_stride[level_of(lv, p)]);
   }
 }
 }  // namespace
 
-extern "C" int das_deform_im2col3x3(const void* x, const float* om, void* col, int dtype, int B, int H, int W, int C,
+extern "C" int das_deform_im2col3x3(const void* x, const float* om, void* col, int dtype, const DasLevels* lv, int C,
                                     int x_pix_stride, int om_pix_stride, void* stream) {
-  if (!x || !om || !col || C % 8 || x_pix_stride % 8 || om_pix_stride < 27) return DAS_ERR_ARG;
-  const long long npix = (long long)B * H * W;
+  if (!x || !om || !col || !lv_valid(lv) || C % 8 || x_pix_stride % 8 || om_pix_stride < 27) return DAS_ERR_ARG;
+  const long long npix = lv_total_rows(*lv);
   if (dtype == DAS_BF16) {
     const long long total = npix * 9 * (C / 8);
     hipLaunchKernelGGL(deform_im2col_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, om, (bf16_t*)col, B, H, W, C, x_pix_stride, om_pix_stride, total);
+                       (const bf16_t*)x, om, (bf16_t*)col, *lv, C, x_pix_stride, om_pix_stride, total);
   } else if (dtype == DAS_F32) {
     const long long total = npix * 9 * (C / 4);
     hipLaunchKernelGGL(deform_im2col_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
-                       (const float*)x, om, (float*)col, B, H, W, C, x_pix_stride, om_pix_stride, total);
+                       (const float*)x, om, (float*)col, *lv, C, x_pix_stride, om_pix_stride, total);
   } else {
     return DAS_ERR_ARG;
   }
@@ -240,14 +248,14 @@ extern "C" int das_deform_im2col3x3(const void* x, const float* om, void* col, i
   return DAS_OK;
 }
 
-extern "C" int das_offset_sample(const float* uvd, const float* samp_off, const float* conf, float* out, int B, int H,
-                                 int W, int J, int heads, int uvd_ps, int so_ps, int conf_ps, int out_ps,
+extern "C" int das_offset_sample(const float* uvd, const float* samp_off, const float* conf, float* out,
+                                 const DasLevels* lv, int J, int heads, int uvd_ps, int so_ps, int conf_ps, int out_ps,
                                  void* stream) {
-  if (!uvd || !samp_off || !conf || !out || heads != 4 || J < 1) return DAS_ERR_ARG;
+  if (!uvd || !samp_off || !conf || !out || !lv_valid(lv) || heads != 4 || J < 1) return DAS_ERR_ARG;
   if (uvd_ps < 3 * J || conf_ps < 3 * J || out_ps < 3 * J || so_ps < 8 * J) return DAS_ERR_ARG;
-  const long long total = (long long)B * H * W * J;
+  const long long total = lv_total_rows(*lv) * J;
   hipLaunchKernelGGL(offset_sample_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, uvd, samp_off,
-                     conf, out, B, H, W, J, uvd_ps, so_ps, conf_ps, out_ps, total);
+                     conf, out, *lv, J, uvd_ps, so_ps, conf_ps, out_ps, total);
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }
@@ -261,22 +269,24 @@ extern "C" int das_sigmoid_blend(const float* off, const float* w, const float* 
   return DAS_OK;
 }
 
-extern "C" int das_head_assemble(const float* raw, float* pose_pred, float* uvd_out, long long npix,
-                                 const DasHeadAssembleDesc* d, void* stream) {
-  if (!raw || !pose_pred || !uvd_out || !d || npix <= 0 || d->J < 1 || d->root_idx < 0 || d->root_idx >= d->J)
-    return DAS_ERR_ARG;
+static bool head_desc_ok(const DasHeadDesc* d) { return d && d->J >= 1 && d->root_idx >= 0 && d->root_idx < d->J; }
+
+extern "C" int das_head_assemble(const float* raw, float* pose_pred, float* uvd_out, const DasLevels* lv,
+                                 const DasHeadDesc* d, void* stream) {
+  if (!raw || !pose_pred || !uvd_out || !lv_valid(lv) || !head_desc_ok(d)) return DAS_ERR_ARG;
+  const long long npix = lv_total_rows(*lv);
   hipLaunchKernelGGL(head_assemble_kernel, dim3(grid_for(npix * (3 + 6 * d->J))), dim3(TPB), 0, (hipStream_t)stream,
-                     raw, pose_pred, uvd_out, npix, *d);
+                     raw, pose_pred, uvd_out, npix, *lv, *d);
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }
 
-extern "C" int das_head_finalize(float* pose_pred, float* ref_uvd, long long npix, int J, int root_idx, int ref_ps,
-                                 float stride, float z_norm, float depth_factor, int eval_mode, void* stream) {
-  if (!pose_pred || !ref_uvd || npix <= 0 || J < 1 || root_idx < 0 || root_idx >= J || ref_ps < 3 * J)
-    return DAS_ERR_ARG;
-  hipLaunchKernelGGL(head_finalize_kernel, dim3(grid_for(npix * (3 * J + 1))), dim3(TPB), 0, (hipStream_t)stream,
-                     pose_pred, ref_uvd, npix, J, root_idx, ref_ps, stride, z_norm, depth_factor, eval_mode);
+extern "C" int das_head_finalize(float* pose_pred, float* ref_uvd, const DasLevels* lv, const DasHeadDesc* d,
+                                 int ref_ps, int eval_mode, void* stream) {
+  if (!pose_pred || !ref_uvd || !lv_valid(lv) || !head_desc_ok(d) || ref_ps < 3 * d->J) return DAS_ERR_ARG;
+  const long long npix = lv_total_rows(*lv);
+  hipLaunchKernelGGL(head_finalize_kernel, dim3(grid_for(npix * (3 * d->J + 1))), dim3(TPB), 0, (hipStream_t)stream,
+                     pose_pred, ref_uvd, npix, *lv, *d, ref_ps, eval_mode);
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }

@@ -1,5 +1,7 @@
 // Normalisation kernels over NHWC: train-mode BatchNorm finalize/apply and GroupNorm(+ReLU).
 // All HBM-bound; statistics in f32.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -56,13 +58,18 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
   }
 }
 
-// ---- GroupNorm: pass 1 = per-(image, group) sum / sumsq; pass 2 = normalise (+ReLU)
+// ---- GroupNorm: pass 1 = per-(level, image, group) sum / sumsq; pass 2 = normalise (+ReLU)
 template <typename T>
-__global__ void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int ps, int G, int pix_per_block,
+__global__ void gn_stats_kernel(const T* __restrict__ x, DasLevels lv, int C, int ps, int G, int pix_per_block,
                                 float* __restrict__ stats) {
   constexpr int EPV = Elem<T>::EPV;
   extern __shared__ float sred[];  // [2*C]
-  const int b = blockIdx.y;
+  const int seg = blockIdx.y, l = seg / lv.B, b = seg % lv.B;
+  const int HW = lv.H[l] * lv.W[l];
+  const int p0 = blockIdx.x * pix_per_block;
+  if (p0 >= HW) return;  // block-uniform
+  long long row0 = (long long)b * HW;
+  for (int i = 0; i < l; ++i) row0 += (long long)lv.B * lv.H[i] * lv.W[i];
   const int VC = C / EPV;
   for (int i = threadIdx.x; i < 2 * C; i += TPB) sred[i] = 0.f;
   __syncthreads();
@@ -71,11 +78,10 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int ps, 
 #pragma unroll
   for (int j = 0; j < EPV; ++j) { s[j] = 0.f; q[j] = 0.f; }
   if (pl < PL) {
-    const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(p0 + pix_per_block, HW);
     for (int p = p0 + pl; p < p1; p += PL) {
       float f[EPV];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + ((long long)b * HW + p) * ps + v * EPV), f);
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (row0 + p) * ps + v * EPV), f);
 #pragma unroll
       for (int j = 0; j < EPV; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
     }
@@ -90,29 +96,30 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int ps, 
   for (int g = threadIdx.x; g < G; g += TPB) {
     float a = 0.f, c = 0.f;
     for (int j = 0; j < cpg; ++j) { a += sred[g * cpg + j]; c += sred[C + g * cpg + j]; }
-    atomicAdd(&stats[((long long)b * G + g) * 2], a);
-    atomicAdd(&stats[((long long)b * G + g) * 2 + 1], c);
+    atomicAdd(&stats[((long long)seg * G + g) * 2], a);
+    atomicAdd(&stats[((long long)seg * G + g) * 2 + 1], c);
   }
 }
 
 template <typename T>
-__global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int HW, int C, int ps, int G,
+__global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, DasLevels lv, int C, int ps, int G,
                                 const float* __restrict__ stats, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int relu, long long total) {
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV, cpg = C / G;
-  const float inv_n = 1.f / ((float)HW * (float)cpg);
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const int v = (int)(i % VC);
     const long long pix = i / VC;
-    const long long b = pix / HW;
+    const LvGeom g = lv_geom(lv, pix);
+    const long long seg = (long long)g.l * lv.B + g.b;
+    const float inv_n = 1.f / ((float)(g.H * g.W) * (float)cpg);
     float f[EPV];
     Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + pix * ps + v * EPV), f);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-      const int c = v * EPV + j, g = c / cpg;
-      const float mean = stats[(b * G + g) * 2] * inv_n;
-      const float var = fmaxf(stats[(b * G + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+      const int c = v * EPV + j, gi = c / cpg;
+      const float mean = stats[(seg * G + gi) * 2] * inv_n;
+      const float var = fmaxf(stats[(seg * G + gi) * 2 + 1] * inv_n - mean * mean, 0.f);
       const float o = (f[j] - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
       f[j] = relu ? fmaxf(o, 0.f) : o;
     }
@@ -142,30 +149,34 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
   return DAS_OK;
 }
 
-extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, int B, int HW, int C, int pix_stride, int G,
-                                  const float* gamma, const float* beta, float eps, int relu, float* stats_ws,
+extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLevels* lv, int C, int pix_stride,
+                                  int G, const float* gamma, const float* beta, float eps, int relu, float* stats_ws,
                                   void* stream) {
-  if (!x || !y || !gamma || !beta || !stats_ws || C % 8 || C % G || pix_stride % 8 || C > 2048) return DAS_ERR_ARG;
+  if (!x || !y || !gamma || !beta || !stats_ws || !lv_valid(lv) || C % 8 || C % G || pix_stride % 8 || C > 2048)
+    return DAS_ERR_ARG;
   const int epv = dtype == DAS_BF16 ? 8 : 4;
   if ((C / epv) > TPB) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * B * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  const int nseg = lv->num_levels * lv->B;
+  if (hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  int maxhw = 0;
+  for (int l = 0; l < lv->num_levels; ++l) maxhw = std::max(maxhw, lv->H[l] * lv->W[l]);
   // enough blocks to fill the chip, at least 64 pixels per block
-  int chunks = (256 * 4 + B - 1) / B;
-  int ppb = (HW + chunks - 1) / chunks;
+  int chunks = (256 * 4 + lv->B - 1) / lv->B;
+  int ppb = (maxhw + chunks - 1) / chunks;
   if (ppb < 64) ppb = 64;
-  chunks = (HW + ppb - 1) / ppb;
-  const long long total = (long long)B * HW * (C / epv);
+  chunks = (maxhw + ppb - 1) / ppb;
+  const long long total = lv_total_rows(*lv) * (C / epv);
   if (dtype == DAS_BF16) {
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(chunks, B), dim3(TPB), 2 * C * sizeof(float), s, (const bf16_t*)x,
-                       HW, C, pix_stride, G, ppb, stats_ws);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(chunks, nseg), dim3(TPB), 2 * C * sizeof(float), s,
+                       (const bf16_t*)x, *lv, C, pix_stride, G, ppb, stats_ws);
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, s, (const bf16_t*)x, (bf16_t*)y,
-                       HW, C, pix_stride, G, stats_ws, gamma, beta, eps, relu, total);
+                       *lv, C, pix_stride, G, stats_ws, gamma, beta, eps, relu, total);
   } else if (dtype == DAS_F32) {
-    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(chunks, B), dim3(TPB), 2 * C * sizeof(float), s, (const float*)x,
-                       HW, C, pix_stride, G, ppb, stats_ws);
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, s, (const float*)x, (float*)y, HW,
-                       C, pix_stride, G, stats_ws, gamma, beta, eps, relu, total);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(chunks, nseg), dim3(TPB), 2 * C * sizeof(float), s,
+                       (const float*)x, *lv, C, pix_stride, G, ppb, stats_ws);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, s, (const float*)x, (float*)y,
+                       *lv, C, pix_stride, G, stats_ws, gamma, beta, eps, relu, total);
   } else {
     return DAS_ERR_ARG;
   }

@@ -92,6 +92,10 @@ def bias_shift(conv):
     return _cache_of(conv).get(('bias',), (conv.bias,), lambda: _pad8(conv.bias, conv.bias.numel()))
 
 
+def _channels(x):
+    return x.C if isinstance(x, ops.Ragged) else x.shape[-1]
+
+
 # ------------------------------------------------------------------ fused units
 def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False):
     """ConvModule(conv, BN[, ReLU]) (+ residual add before the ReLU) on an NHWC tensor.
@@ -117,14 +121,14 @@ def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False):
 
 def conv_plain(x, conv, relu=False, out_dtype=None, out=None):
     """nn.Conv2d with bias, no norm (the 1x1 predictors)."""
-    w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+    w = packed_weight(conv, x.dtype, cin_pad=_channels(x))
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     return ops.conv2d(x, w, k, k, s, p, shift=bias_shift(conv), relu=relu, out_dtype=out_dtype, out=out)
 
 
 def dcn_v2(x, dcn):
     """ModulatedDeformConv2dPack.forward: offset/mask conv (f32 out) -> deformable im2col -> GEMM."""
-    C = x.shape[-1]
+    C = _channels(x)
     w_off = _cache_of(dcn.conv_offset).get(('w', x.dtype), (dcn.conv_offset.weight,),
                                            lambda: ops.pack_weight(dcn.conv_offset.weight, x.dtype, cout_pad=32))
     b_off = _cache_of(dcn.conv_offset).get(('b',), (dcn.conv_offset.bias,), lambda: _pad8(dcn.conv_offset.bias, 27))

@@ -2,7 +2,8 @@
 
 PyTorch is plumbing here: it owns device memory and the stream; every op below hands raw
 device pointers + sizes to a HIP kernel. Activations are NHWC tensors of shape (B, H, W, C),
-bf16 or f32. Ops raise (never fall back) when a tensor is not on a GPU.
+bf16 or f32, or `Ragged` row sets (all FPN levels back to back, the head's native layout).
+Ops raise (never fall back) when a tensor is not on a GPU.
 """
 import ctypes as C
 
@@ -13,7 +14,7 @@ from . import _lib
 _DT = {torch.float32: _lib.DAS_F32, torch.bfloat16: _lib.DAS_BF16}
 
 # bench.py sets this to a list to time every conv launch with HIP events recorded on the launch
-# stream: entries are (kernel family tag, algorithmic FLOPs, start event, end event).
+# stream: entries are (kernel family tag, algorithmic FLOPs, start event, end event, shape).
 PROFILE = None
 
 
@@ -27,17 +28,90 @@ def _ptr(t):
 
 def _need_gpu(*ts):
     for t in ts:
+        if isinstance(t, Ragged):
+            t = t.data
         if t is not None and not t.is_cuda:
             raise _lib.DasHipError('das_amd ops run on the GPU only (no CPU fallback); got a CPU tensor')
 
 
+class Ragged:
+    """Pixel rows of several FPN levels back to back: `data` is (rows, C) (possibly a channel-slice
+    view), level l owns B*H_l*W_l consecutive rows in (b, h, w) order."""
+
+    def __init__(self, data, B, sizes):
+        assert data.dim() == 2
+        self.data, self.B, self.sizes = data, B, [tuple(s) for s in sizes]
+        self.starts = [0]
+        for h, w in self.sizes:
+            self.starts.append(self.starts[-1] + B * h * w)
+        assert data.shape[0] == self.starts[-1], (data.shape, self.starts)
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def C(self):
+        return self.data.shape[1]
+
+    @property
+    def rows(self):
+        return self.data.shape[0]
+
+    def like(self, data):
+        return Ragged(data, self.B, self.sizes)
+
+    def new(self, C_, dtype=None):
+        return self.like(torch.empty(self.rows, C_, dtype=dtype or self.dtype, device=self.device))
+
+    def cslice(self, c0, c1):
+        return self.like(self.data[:, c0:c1])
+
+    def level(self, l):
+        h, w = self.sizes[l]
+        return self.data[self.starts[l]:self.starts[l + 1]].unflatten(0, (self.B, h, w))
+
+    @staticmethod
+    def from_levels(tensors):
+        """list of NHWC (B,H,W,C) tensors -> Ragged (one concatenation copy)."""
+        B = tensors[0].shape[0]
+        return Ragged(torch.cat([t.reshape(-1, t.shape[-1]) for t in tensors], 0), B, [t.shape[1:3] for t in tensors])
+
+
 def _ps(t):
-    """pixel stride (elements) of an NHWC tensor or a channel-slice view of one"""
+    """pixel stride (elements) of an NHWC tensor / Ragged / channel-slice view"""
+    if isinstance(t, Ragged):
+        t = t.data
     assert t.shape[-1] == 1 or t.stride(-1) == 1, 'channel dim must be contiguous'
     ps = t.stride(-2)
     if t.dim() == 4:
         assert t.stride(1) == ps * t.shape[2] and t.stride(0) == ps * t.shape[1] * t.shape[2], 'rows must be dense'
     return ps
+
+
+def _levels(x):
+    lv = _lib.DasLevels()
+    if isinstance(x, Ragged):
+        lv.num_levels, lv.B = len(x.sizes), x.B
+        for l, (h, w) in enumerate(x.sizes):
+            lv.H[l], lv.W[l] = h, w
+    else:
+        lv.num_levels, lv.B, lv.H[0], lv.W[0] = 1, x.shape[0], x.shape[1], x.shape[2]
+    return lv
+
+
+def _data(x):
+    return x.data if isinstance(x, Ragged) else x
+
+
+def _empty_like_rows(x, C_, dtype):
+    if isinstance(x, Ragged):
+        return x.new(C_, dtype)
+    return torch.empty(*x.shape[:-1], C_, dtype=dtype, device=x.device)
 
 
 def pack_weight(w, dtype, cin_pad=None, cout_pad=None):
@@ -52,39 +126,56 @@ def pack_weight(w, dtype, cin_pad=None, cout_pad=None):
 
 def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, relu_in=False,
            out_dtype=None, stats=None, out=None):
-    """x (B,H,W,Cin[view]) ; w packed (Cout,KH,KW,Cin). Returns y (B,Ho,Wo,Cout)."""
+    """x (B,H,W,Cin[view]) or Ragged; w packed (Cout,KH,KW,Cin). Returns y (B,Ho,Wo,Cout) / Ragged."""
     _need_gpu(x, w)
     lib = _lib.load()
-    B, H, W, Cin = x.shape
+    ragged = isinstance(x, Ragged)
+    xd = _data(x)
+    Cin = xd.shape[-1]
     Cout = w.shape[0]
     assert w.shape[1:] == (KH, KW, Cin), (w.shape, (KH, KW, Cin))
-    assert w.dtype == x.dtype and w.is_contiguous()
-    Ho = (H + 2 * pad - KH) // stride + 1
-    Wo = (W + 2 * pad - KW) // stride + 1
-    out_dtype = out_dtype or x.dtype
-    if out is None:
-        out = torch.empty(B, Ho, Wo, Cout, dtype=out_dtype, device=x.device)
-    assert out.shape == (B, Ho, Wo, Cout) and out.dtype == out_dtype
+    assert w.dtype == xd.dtype and w.is_contiguous()
+    out_dtype = out_dtype or xd.dtype
+    if ragged:
+        assert stride == 1 and pad == KH // 2 and KH == KW
+        B, (H, W) = x.B, x.sizes[0]
+        Ho, Wo = H, W
+        if out is None:
+            out = x.new(Cout, out_dtype)
+        assert isinstance(out, Ragged) and out.data.shape == (x.rows, Cout) and out.dtype == out_dtype
+        rows = x.rows
+    else:
+        B, H, W, _ = x.shape
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        if out is None:
+            out = torch.empty(B, Ho, Wo, Cout, dtype=out_dtype, device=x.device)
+        assert out.shape == (B, Ho, Wo, Cout) and out.dtype == out_dtype
+        rows = B * Ho * Wo
+    od, rd = _data(out), _data(residual) if residual is not None else None
     for t in (scale, shift):
         assert t is None or (t.dtype == torch.float32 and t.numel() == Cout and t.is_contiguous())
     d = _lib.DasConvDesc(
-        dtype=_DT[x.dtype], out_dtype=_DT[out_dtype], B=B, H=H, W=W, Cin=Cin, x_pix_stride=_ps(x), Ho=Ho, Wo=Wo,
+        dtype=_DT[xd.dtype], out_dtype=_DT[out_dtype], B=B, H=H, W=W, Cin=Cin, x_pix_stride=_ps(x), Ho=Ho, Wo=Wo,
         Cout=Cout, y_pix_stride=_ps(out), KH=KH, KW=KW, stride=stride, pad=pad, relu_in=int(relu_in), relu=int(relu),
         scale=scale.data_ptr() if scale is not None else None, shift=shift.data_ptr() if shift is not None else None,
-        residual=residual.data_ptr() if residual is not None else None,
-        res_pix_stride=_ps(residual) if residual is not None else 0,
-        stats=stats.data_ptr() if stats is not None else None)
-    if residual is not None:
-        assert residual.shape == out.shape and residual.dtype == out.dtype
+        residual=rd.data_ptr() if rd is not None else None, res_pix_stride=_ps(residual) if rd is not None else 0,
+        stats=stats.data_ptr() if stats is not None else None, num_levels=len(x.sizes) if ragged else 0)
+    if ragged:
+        for l, (h, w_) in enumerate(x.sizes):
+            d.lvl_H[l], d.lvl_W[l] = h, w_
+    if rd is not None:
+        assert rd.shape == od.shape and rd.dtype == od.dtype
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.das_conv2d_nhwc(_ptr(x), _ptr(w), _ptr(out), C.byref(d), _stream()), 'das_conv2d_nhwc')
+    _lib.check(lib.das_conv2d_nhwc(_ptr(xd), _ptr(w), _ptr(od), C.byref(d), _stream()), 'das_conv2d_nhwc')
     if PROFILE is not None:
         e1.record()
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
-        tag = f'conv_igemm<{str(x.dtype)[6:]},{str(out_dtype)[6:]},BN{bn}>'
-        PROFILE.append((tag, 2.0 * B * Ho * Wo * Cout * KH * KW * Cin, e0, e1, (B, H, W, Cin, Cout, KH, stride, _ps(x))))
+        tag = f'conv_igemm<{str(xd.dtype)[6:]},{str(out_dtype)[6:]},BN{bn}>'
+        PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1,
+                        (B, H, W, Cin, Cout, KH, stride, len(x.sizes) if ragged else 1)))
     return out
 
 
@@ -140,12 +231,14 @@ def add_upsample_nearest(a, b):
 
 
 def add3(a, b, c=None, relu=False):
+    """Elementwise a + b (+ c) on dense tensors (or dense Ragged rows)."""
     _need_gpu(a, b, c)
-    assert a.is_contiguous() and b.is_contiguous() and (c is None or c.is_contiguous())
-    y = torch.empty_like(a)
-    _lib.check(_lib.load().das_add3(_ptr(a), _ptr(b), _ptr(c), _ptr(y), _DT[a.dtype], a.numel(), int(relu), _stream()),
-               'das_add3')
-    return y
+    ad, bd, cd = _data(a), _data(b), _data(c) if c is not None else None
+    assert ad.is_contiguous() and bd.is_contiguous() and (cd is None or cd.is_contiguous())
+    yd = torch.empty_like(ad)
+    _lib.check(_lib.load().das_add3(_ptr(ad), _ptr(bd), _ptr(cd), _ptr(yd), _DT[ad.dtype], ad.numel(), int(relu),
+                                    _stream()), 'das_add3')
+    return a.like(yd) if isinstance(a, Ragged) else yd
 
 
 def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None,
@@ -166,68 +259,84 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
 
 
 def groupnorm(x, gamma, beta, G, eps=1e-5, relu=True, out=None):
-    """In/out NHWC (may be channel-slice views with a pixel stride)."""
+    """In/out NHWC or Ragged (may be channel-slice views with a pixel stride); default in place."""
     _need_gpu(x)
-    B, H, W, Cc = x.shape
     out = x if out is None else out
-    ws = torch.empty(B * G * 2, dtype=torch.float32, device=x.device)
+    xd, od = _data(x), _data(out)
+    lv = _levels(x)
+    ws = torch.empty(lv.num_levels * lv.B * G * 2, dtype=torch.float32, device=xd.device)
     assert _ps(out) == _ps(x)
-    _lib.check(_lib.load().das_groupnorm_nhwc(_ptr(x), _ptr(out), _DT[x.dtype], B, H * W, Cc, _ps(x), G, _ptr(gamma),
-                                              _ptr(beta), eps, int(relu), _ptr(ws), _stream()), 'das_groupnorm_nhwc')
+    _lib.check(_lib.load().das_groupnorm_nhwc(_ptr(xd), _ptr(od), _DT[xd.dtype], C.byref(lv), xd.shape[-1], _ps(x), G,
+                                              _ptr(gamma), _ptr(beta), eps, int(relu), _ptr(ws), _stream()),
+               'das_groupnorm_nhwc')
     return out
 
 
 def deform_im2col3x3(x, om):
-    """x (B,H,W,C[view]); om (B,H,W,>=27) f32 -> col (B,H,W,9*C)."""
+    """x rows x C (NHWC / Ragged, may be a slice view); om rows x >=27 f32 -> col rows x 9C."""
     _need_gpu(x, om)
-    B, H, W, Cc = x.shape
-    assert om.dtype == torch.float32
-    col = torch.empty(B, H, W, 9 * Cc, dtype=x.dtype, device=x.device)
-    _lib.check(_lib.load().das_deform_im2col3x3(_ptr(x), _ptr(om), _ptr(col), _DT[x.dtype], B, H, W, Cc, _ps(x),
-                                                _ps(om), _stream()), 'das_deform_im2col3x3')
+    xd, omd = _data(x), _data(om)
+    Cc = xd.shape[-1]
+    assert omd.dtype == torch.float32
+    col = _empty_like_rows(x, 9 * Cc, xd.dtype)
+    lv = _levels(x)
+    _lib.check(_lib.load().das_deform_im2col3x3(_ptr(xd), _ptr(omd), _ptr(_data(col)), _DT[xd.dtype], C.byref(lv), Cc,
+                                                _ps(x), _ps(om), _stream()), 'das_deform_im2col3x3')
     return col
 
 
 def offset_sample(uvd, samp_off, conf, J, heads=4):
     _need_gpu(uvd, samp_off, conf)
-    B, H, W, _ = uvd.shape
-    out = torch.empty(B, H, W, 3 * J, dtype=torch.float32, device=uvd.device)
-    _lib.check(_lib.load().das_offset_sample(_ptr(uvd), _ptr(samp_off), _ptr(conf), _ptr(out), B, H, W, J, heads,
-                                             _ps(uvd), _ps(samp_off), _ps(conf), _ps(out), _stream()),
-               'das_offset_sample')
+    out = _empty_like_rows(uvd, 3 * J, torch.float32)
+    lv = _levels(uvd)
+    _lib.check(_lib.load().das_offset_sample(_ptr(_data(uvd)), _ptr(_data(samp_off)), _ptr(_data(conf)),
+                                             _ptr(_data(out)), C.byref(lv), J, heads, _ps(uvd), _ps(samp_off),
+                                             _ps(conf), _ps(out), _stream()), 'das_offset_sample')
     return out
 
 
 def sigmoid_blend(off, w, nxt):
     _need_gpu(off, w, nxt)
-    Cc = off.shape[-1]
-    out = torch.empty(*off.shape[:-1], Cc, dtype=torch.float32, device=off.device)
-    npix = off.numel() // Cc if off.is_contiguous() else off.shape[0] * off.shape[1] * off.shape[2]
-    _lib.check(_lib.load().das_sigmoid_blend(_ptr(off), _ptr(w), _ptr(nxt), _ptr(out), npix, Cc, _ps(off), _ps(w),
-                                             _ps(nxt), _ps(out), _stream()), 'das_sigmoid_blend')
+    od = _data(off)
+    Cc = od.shape[-1]
+    out = _empty_like_rows(off, Cc, torch.float32)
+    npix = 1
+    for s in od.shape[:-1]:
+        npix *= s
+    _lib.check(_lib.load().das_sigmoid_blend(_ptr(od), _ptr(_data(w)), _ptr(_data(nxt)), _ptr(_data(out)), npix, Cc,
+                                             _ps(off), _ps(w), _ps(nxt), _ps(out), _stream()), 'das_sigmoid_blend')
     return out
 
 
-def head_assemble(raw, J, root_idx, off_c, depth_c, uvd_c, sigma_c, scales):
-    """raw (B,H,W,raw_ps) f32 -> pose_pred (B,H,W,3+6J), uvd (B,H,W,3J)."""
+def head_desc(J, root_idx, raw_ps, off_c, depth_c, uvd_c, sigma_c, scales, strides, z_norm, depth_factor):
+    """scales: per level [offset, depth, uv, d]; strides: per level head stride."""
+    d = _lib.DasHeadDesc(J=J, root_idx=root_idx, raw_ps=raw_ps, off_c=off_c, depth_c=depth_c, uvd_c=uvd_c,
+                         sigma_c=sigma_c, z_norm=float(z_norm), depth_factor=float(depth_factor))
+    for l, sc in enumerate(scales):
+        for k in range(4):
+            d.scale[l][k] = float(sc[k])
+    for l, s in enumerate(strides):
+        d.level_stride[l] = float(s)
+    return d
+
+
+def head_assemble(raw, desc):
+    """raw rows x raw_ps f32 -> pose_pred rows x (3+6J), uvd rows x 3J."""
     _need_gpu(raw)
-    B, H, W, _ = raw.shape
-    pose = torch.empty(B, H, W, 3 + 6 * J, dtype=torch.float32, device=raw.device)
-    uvd = torch.empty(B, H, W, 3 * J, dtype=torch.float32, device=raw.device)
-    d = _lib.DasHeadAssembleDesc(J=J, root_idx=root_idx, raw_ps=_ps(raw), off_c=off_c, depth_c=depth_c, uvd_c=uvd_c,
-                                 sigma_c=sigma_c, scale_off=scales[0], scale_depth=scales[1], scale_uv=scales[2],
-                                 scale_d=scales[3])
-    _lib.check(_lib.load().das_head_assemble(_ptr(raw), _ptr(pose), _ptr(uvd), B * H * W, C.byref(d), _stream()),
-               'das_head_assemble')
+    J = desc.J
+    pose = _empty_like_rows(raw, 3 + 6 * J, torch.float32)
+    uvd = _empty_like_rows(raw, 3 * J, torch.float32)
+    lv = _levels(raw)
+    _lib.check(_lib.load().das_head_assemble(_ptr(_data(raw)), _ptr(_data(pose)), _ptr(_data(uvd)), C.byref(lv),
+                                             C.byref(desc), _stream()), 'das_head_assemble')
     return pose, uvd
 
 
-def head_finalize(pose, ref, J, root_idx, stride, z_norm, depth_factor, eval_mode):
+def head_finalize(pose, ref, desc, eval_mode):
     _need_gpu(pose, ref)
-    npix = pose.numel() // pose.shape[-1]
-    _lib.check(_lib.load().das_head_finalize(_ptr(pose), _ptr(ref), npix, J, root_idx, _ps(ref), float(stride),
-                                             float(z_norm), float(depth_factor), int(eval_mode), _stream()),
-               'das_head_finalize')
+    lv = _levels(pose)
+    _lib.check(_lib.load().das_head_finalize(_ptr(_data(pose)), _ptr(_data(ref)), C.byref(lv), C.byref(desc), _ps(ref),
+                                             int(eval_mode), _stream()), 'das_head_finalize')
     return pose, ref
 
 

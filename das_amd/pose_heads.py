@@ -28,6 +28,11 @@ def _p8(n):
     return (n + 7) // 8 * 8
 
 
+def _cs(t, c0, c1):
+    """channel slice of an NHWC tensor or a Ragged row set (a view)"""
+    return t.cslice(c0, c1) if isinstance(t, ops.Ragged) else t[..., c0:c1]
+
+
 # ---------------------------------------------------------------------------- RealNVP (train only)
 def _mlp(d, tanh):
     layers = [nn.Linear(d, 64), nn.LeakyReLU(), nn.Linear(64, 64), nn.LeakyReLU(), nn.Linear(64, d)]
@@ -92,10 +97,10 @@ class NextLevelOffset(nn.Module):
         feat = ops.add3(feat, self.update_feat_conv(feat))
         w, b, offs = self._fused_heads(feat.dtype)
         out = ops.conv2d(feat, w, 1, 1, shift=b, out_dtype=torch.float32)
-        so = out[..., offs[0]:offs[0] + J * self.num_heads * 2]
-        conf = out[..., offs[1]:offs[1] + J * self.dim]
-        wgt = out[..., offs[2]:offs[2] + J * self.dim]
-        nxt = out[..., offs[3]:offs[3] + J * self.dim]
+        so = _cs(out, offs[0], offs[0] + J * self.num_heads * 2)
+        conf = _cs(out, offs[1], offs[1] + J * self.dim)
+        wgt = _cs(out, offs[2], offs[2] + J * self.dim)
+        nxt = _cs(out, offs[3], offs[3] + J * self.dim)
         offset = ops.sigmoid_blend(offset, wgt, nxt)
         return feat, offset, so, conf
 
@@ -274,19 +279,19 @@ class DASHead(nn.Module):
                 x = m(x)
         return x
 
-    def forward_single(self, x, lvl):
-        """x: NHWC (B,h,w,C). Returns NHWC f32: cls (B,h,w,1) view, pose_pred (B,h,w,3+6J),
-        centerness (B,h,w,1) view[, ref_uvd (B,h,w,3J)]."""
+    def forward_rows(self, x, level_ids):
+        """x: `ops.Ragged` rows of the FPN levels `level_ids` (all levels in one launch per layer; the
+        head's weights are shared across levels, das_head.py:176-178). Returns Ragged f32:
+        cls (rows,1 view), pose_pred (rows,3+6J), centerness (rows,1 view)[, ref_uvd (rows,3J)]."""
         J, L = self.num_joints, self.raw_layout()
-        B, h, w, _ = x.shape
         cls_feat = self._run(self.cls_convs, x)
         reg_feat = self._run(self.reg_convs, x)
         pose_feat = self._run(self.pose_convs, x)
-        raw = torch.empty(B, h, w, L['total'], dtype=torch.float32, device=x.device)
+        raw = x.new(L['total'], torch.float32)
 
         def predict(feat, prevs, pred, c0):
             n = _p8(pred.weight.shape[0])
-            conv_plain(self._run(prevs, feat), pred, out_dtype=torch.float32, out=raw[..., c0:c0 + n])
+            conv_plain(self._run(prevs, feat), pred, out_dtype=torch.float32, out=_cs(raw, c0, c0 + n))
         predict(cls_feat, self.conv_cls_prev, self.conv_cls, L['cls'])
         predict(reg_feat, self.conv_centerness_prev, self.conv_centerness, L['ctr'])
         predict(reg_feat, self.conv_reg_prevs[0], self.conv_regs[0], L['off'])
@@ -294,15 +299,22 @@ class DASHead(nn.Module):
         predict(pose_feat, self.conv_pose_prevs[0], self.conv_poses[0], L['uvd'])
         predict(pose_feat, self.conv_pose_prevs[1], self.conv_poses[1], L['sigma'])
 
-        sc = self._scale_values()[lvl]
-        pose_pred, uvd0 = ops.head_assemble(raw, J, self.root_idx, L['off'], L['depth'], L['uvd'], L['sigma'], sc)
+        sc = self._scale_values()
+        desc = ops.head_desc(J, self.root_idx, L['total'], L['off'], L['depth'], L['uvd'], L['sigma'],
+                             [sc[l] for l in level_ids], [self.strides[l] for l in level_ids], self.z_norm,
+                             self.depth_factor)
+        pose_pred, uvd0 = ops.head_assemble(raw, desc)
         ref = self.recursive_update_branch(pose_feat, uvd0)
-        ops.head_finalize(pose_pred, ref, J, self.root_idx, self.strides[lvl], self.z_norm, self.depth_factor,
-                          eval_mode=not self.training)
-        cls, ctr = raw[..., L['cls']:L['cls'] + 1], raw[..., L['ctr']:L['ctr'] + 1]
+        ops.head_finalize(pose_pred, ref, desc, eval_mode=not self.training)
+        cls, ctr = _cs(raw, L['cls'], L['cls'] + 1), _cs(raw, L['ctr'], L['ctr'] + 1)
         if self.training:
             return cls, pose_pred, ctr, ref
         return cls, pose_pred, ctr
+
+    def forward_single(self, x, lvl):
+        """One level, NHWC in / NHWC out (reference signature `forward_single`, das_head.py:232-267)."""
+        r = ops.Ragged(x.reshape(-1, x.shape[-1]), x.shape[0], [x.shape[1:3]])
+        return tuple(t.level(0) for t in self.forward_rows(r, [lvl]))
 
     def _scale_values(self):
         """Per-level Scale parameters as python floats (one small D2H copy, cached per version)."""
@@ -317,11 +329,10 @@ class DASHead(nn.Module):
         """feats: tuple of NCHW-shaped tensors (one per level). Returns the reference's tuple of
         per-output lists, each tensor an NCHW-shaped view of NHWC f32 storage."""
         assert len(feats) == len(self.strides)
-        outs = []
-        for lvl, f in enumerate(feats):
-            dtype = self.compute_dtype or f.dtype
-            outs.append([to_nchw_view(t) for t in self.forward_single(as_nhwc(f, dtype), lvl)])
-        return tuple(list(t) for t in zip(*outs))
+        dtype = self.compute_dtype or feats[0].dtype
+        x = ops.Ragged.from_levels([as_nhwc(f, dtype) for f in feats])
+        outs = self.forward_rows(x, list(range(len(feats))))
+        return tuple([to_nchw_view(t.level(l)) for l in range(len(feats))] for t in outs)
 
     # ------------------------------------------------------------------ decode
     def get_points(self, featmap_sizes, dtype, device, flatten=False):

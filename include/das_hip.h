@@ -59,6 +59,12 @@ typedef struct {
   const void* residual;
   int res_pix_stride;
   float* stats;
+  /* Ragged multi-level mode (num_levels > 1): x and y hold the rows of all FPN levels back to back,
+   * level l = B*lvl_H[l]*lvl_W[l] pixel rows in (b,h,w) order; requires stride 1 and pad = KH/2.
+   * One launch then covers every level of the shared-weight head convs (das_head.py:176-178
+   * `multi_apply(self.forward_single, feats, ...)`). num_levels <= 1: plain (B,H,W,C) tensor. */
+  int num_levels;
+  int lvl_H[5], lvl_W[5];
 } DasConvDesc;
 int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream);
 
@@ -92,25 +98,34 @@ int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C
                        float momentum, float eps, const void* residual, int relu, float* save_mean,
                        float* save_invstd, void* stream);
 
-/* GroupNorm (+ReLU) over NHWC (torch GroupNorm, das_head.py:54, recursive_update.py:178,244).
- * stats workspace: f32[B*G*2], zeroed by the call. */
-int das_groupnorm_nhwc(const void* x, void* y, int dtype, int B, int HW, int C, int pix_stride, int G,
+/* Ragged multi-level pixel rows. The DASHead shares its weights across FPN levels
+ * (das_head.py:176-178 `multi_apply(self.forward_single, feats, ...)`), so the head ops below take
+ * the rows of ALL levels back to back: level l contributes B*H[l]*W[l] rows in (b,h,w) order. A plain
+ * (B,H,W,C) tensor is the special case num_levels = 1. */
+typedef struct {
+  int num_levels, B;
+  int H[5], W[5];
+} DasLevels;
+
+/* GroupNorm (+ReLU) over NHWC rows (torch GroupNorm, das_head.py:54, recursive_update.py:178,244);
+ * statistics per (level, image, group). stats workspace: f32[num_levels*B*G*2], zeroed by the call. */
+int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLevels* lv, int C, int pix_stride, int G,
                        const float* gamma, const float* beta, float eps, int relu, float* stats_ws,
                        void* stream);
 
 /* DCNv2 deformable im2col (mmcv ModulatedDeformConv2dPack.forward -> modulated_deform_conv2d,
  * das_head.py:107-108, anchor_free_mono3d_pose_head.py:111-112,131-132, recursive_update.py:177-178).
- * x: (B,H,W,C) dtype with x_pix_stride. om: (B,H,W,om_pix_stride) f32, channels [0,18) = (dy,dx)
- * per tap k, [18,27) = mask logits (sigmoid applied here). col: (B*H*W, 9*C) dtype, tap-major,
+ * x: rows x C dtype with x_pix_stride. om: rows x om_pix_stride f32, channels [0,18) = (dy,dx)
+ * per tap k, [18,27) = mask logits (sigmoid applied here). col: (rows, 9*C) dtype, tap-major,
  * so that DCN == das_conv2d_nhwc(1x1, Cin = 9*C) on col. 3x3, stride 1, pad 1, dilation 1. */
-int das_deform_im2col3x3(const void* x, const float* om, void* col, int dtype, int B, int H, int W, int C,
+int das_deform_im2col3x3(const void* x, const float* om, void* col, int dtype, const DasLevels* lv, int C,
                          int x_pix_stride, int om_pix_stride, void* stream);
 
 /* Recursive-update offset re-sampling (recursive_update.py:9-82 offset_sample/_core), fused.
- * uvd (B,H,W,uvd_ps) f32 [J*3], samp_off (…,so_ps) f32 [J*heads*2], conf (…,conf_ps) f32 [J*3]
- * -> out (B,H,W,out_ps) f32 [J*3]. */
-int das_offset_sample(const float* uvd, const float* samp_off, const float* conf, float* out, int B, int H,
-                      int W, int J, int heads, int uvd_ps, int so_ps, int conf_ps, int out_ps, void* stream);
+ * uvd (rows,uvd_ps) f32 [J*3], samp_off (rows,so_ps) f32 [J*heads*2], conf (rows,conf_ps) f32 [J*3]
+ * -> out (rows,out_ps) f32 [J*3]. */
+int das_offset_sample(const float* uvd, const float* samp_off, const float* conf, float* out, const DasLevels* lv,
+                      int J, int heads, int uvd_ps, int so_ps, int conf_ps, int out_ps, void* stream);
 
 /* off = (1-sigmoid(w))*off + sigmoid(w)*nxt  (recursive_update.py:193-195), per pixel over C
  * channels, all f32 with their own pixel strides. */
@@ -118,20 +133,23 @@ int das_sigmoid_blend(const float* off, const float* w, const float* nxt, float*
                       int off_ps, int w_ps, int nxt_ps, int out_ps, void* stream);
 
 /* DASHead.forward_single tail (das_head.py:237-262): per-level Scale, root-joint pinning and,
- * in eval mode, depth/stride/z_norm rescale. raw: (npix, raw_ps) f32 with channel slices
+ * in eval mode, depth/stride/z_norm rescale. raw: (rows, raw_ps) f32 with channel slices
  * off@off_c(2), depth@depth_c(1), uvd@uvd_c(3J), sigma@sigma_c(3J).
- * pose_pred: (npix, 3+6J) f32 = [off(2), depth, uvd(3J), sigma(3J)]; uvd_out: (npix,3J) f32 =
- * scaled+pinned initial uvd (input of the recursive-update branch). */
+ * pose_pred: (rows, 3+6J) f32 = [off(2), depth, uvd(3J), sigma(3J)]; uvd_out: (rows,3J) f32 =
+ * scaled+pinned initial uvd (input of the recursive-update branch). scale[l] = the level's four
+ * `Scale` values (offset, depth, uv, d); level_stride[l] = head stride of level l. */
 typedef struct {
   int J, root_idx, raw_ps, off_c, depth_c, uvd_c, sigma_c;
-  float scale_off, scale_depth, scale_uv, scale_d;
-} DasHeadAssembleDesc;
-int das_head_assemble(const float* raw, float* pose_pred, float* uvd_out, long long npix,
-                      const DasHeadAssembleDesc* d, void* stream);
+  float scale[5][4];
+  float level_stride[5];
+  float z_norm, depth_factor;
+} DasHeadDesc;
+int das_head_assemble(const float* raw, float* pose_pred, float* uvd_out, const DasLevels* lv,
+                      const DasHeadDesc* d, void* stream);
 /* Eval-mode overwrite (das_head.py:254-262): uvd := ref_uvd (root z = 0), u,v *= stride,
  * dz *= z_norm, depth /= depth_factor. In train mode only pins ref root z (das_head.py:254). */
-int das_head_finalize(float* pose_pred, float* ref_uvd, long long npix, int J, int root_idx, int ref_ps,
-                      float stride, float z_norm, float depth_factor, int eval_mode, void* stream);
+int das_head_finalize(float* pose_pred, float* ref_uvd, const DasLevels* lv, const DasHeadDesc* d, int ref_ps,
+                      int eval_mode, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Decode (das_head.py:690-796 `_get_poses_single`, pose_nms.py:51-126 oks_iou / oks_nms), fused:

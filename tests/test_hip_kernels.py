@@ -218,7 +218,9 @@ def test_blend_assemble_finalize():
     raw = cases.randn(40, B, 16 + 3 * J + 1 + 3 * J + 5, H, W)
     uvd_c, sigma_c = 16, 16 + 3 * J + 1
     sc = (1.1, 0.9, 1.2, 0.8)
-    pose, uvd = o.head_assemble(nhwc(raw), J, root, 8, 12, uvd_c, sigma_c, sc)
+    rawd = nhwc(raw)
+    desc = o.head_desc(J, root, rawd.shape[-1], 8, 12, uvd_c, sigma_c, [sc], [16.0], 50.0, 20.0)
+    pose, uvd = o.head_assemble(rawd, desc)
     r_uvd = raw[:, uvd_c:uvd_c + 3 * J].clone().reshape(B, J, 3, H, W)
     r_uvd[:, :, :2] *= sc[2]
     r_uvd[:, :, 2] *= sc[3]
@@ -231,7 +233,7 @@ def test_blend_assemble_finalize():
 
     refd = cases.randn(41, B, 3 * J, H, W)
     rd = nhwc(refd)
-    o.head_finalize(pose, rd, J, root, 16.0, 50.0, 20.0, eval_mode=True)
+    o.head_finalize(pose, rd, desc, eval_mode=True)
     e = refd.clone().reshape(B, J, 3, H, W)
     e[:, root, 2] = 0
     np.testing.assert_array_equal(nchw(rd).numpy(), e.reshape(B, -1, H, W).numpy())
@@ -294,3 +296,39 @@ def test_decode_mupots_topology():
     sizes = [(96, 128), (48, 64), (24, 32), (12, 16)]
     cls, pose, ctr = cases.full_decode_inputs(seed=5, B=1, Jn=21, sizes=sizes, bias=-4.5)
     _check_decode_vs_oracle(cls, pose, ctr, [(0.8, 0.8)], 21, cases.FULL_STRIDES, cases.FULL_TEST_CFG)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_ragged_multilevel_conv_gn_dcn_match_per_level(dtype):
+    """One launch over the rows of all levels == the same op applied level by level."""
+    o = ops()
+    B, C, O = 2, 64, 72
+    sizes = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    lv = [nhwc(cases.randn(50 + i, B, C, h, w), dtype) for i, (h, w) in enumerate(sizes)]
+    r = o.Ragged.from_levels(lv)
+    w3 = o.pack_weight((cases.randn(60, O, C, 3, 3) / 24).to(DEV), dtype)
+    bias = cases.randn(61, O).to(DEV)
+    y = o.conv2d(r, w3, 3, 3, 1, 1, shift=bias, relu=True)
+    for l, x in enumerate(lv):
+        ref = o.conv2d(x, w3, 3, 3, 1, 1, shift=bias, relu=True)
+        np.testing.assert_array_equal(y.level(l).float().cpu().numpy(), ref.float().cpu().numpy())
+    # GroupNorm statistics are per (level, image)
+    gamma, beta = cases.randn(62, O).to(DEV), cases.randn(63, O).to(DEV)
+    g = o.groupnorm(y.like(y.data.clone()), gamma, beta, 9, relu=True)
+    for l in range(len(sizes)):
+        ref = o.groupnorm(y.level(l).clone(), gamma, beta, 9, relu=True)
+        np.testing.assert_allclose(g.level(l).float().cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # deformable im2col + offset_sample geometry per row
+    om = o.Ragged.from_levels([nhwc(cases.randn(70 + i, B, 32, h, w) * 1.5) for i, (h, w) in enumerate(sizes)])
+    col = o.deform_im2col3x3(r, om)
+    for l, x in enumerate(lv):
+        ref = o.deform_im2col3x3(x, om.level(l).contiguous())
+        np.testing.assert_array_equal(col.level(l).float().cpu().numpy(), ref.float().cpu().numpy())
+    J = 3
+    uvd = o.Ragged.from_levels([nhwc(cases.randn(80 + i, B, 3 * J, h, w) * 2) for i, (h, w) in enumerate(sizes)])
+    so = o.Ragged.from_levels([nhwc(cases.randn(90 + i, B, 8 * J, h, w)) for i, (h, w) in enumerate(sizes)])
+    cf = o.Ragged.from_levels([nhwc(cases.randn(95 + i, B, 3 * J, h, w)) for i, (h, w) in enumerate(sizes)])
+    out = o.offset_sample(uvd, so, cf, J)
+    for l in range(len(sizes)):
+        ref = o.offset_sample(uvd.level(l).contiguous(), so.level(l).contiguous(), cf.level(l).contiguous(), J)
+        np.testing.assert_array_equal(out.level(l).cpu().numpy(), ref.cpu().numpy())
