@@ -173,7 +173,9 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
     if PROFILE is not None:
         e1.record()
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
-        tag = f'conv_igemm<{str(xd.dtype)[6:]},{str(out_dtype)[6:]},BN{bn}>'
+        short = {torch.bfloat16: 'bf16', torch.float32: 'float'}
+        glds = Cin % (64 if xd.dtype == torch.bfloat16 else 32) == 0 and not relu_in
+        tag = f'{"conv_glds_kernel" if glds else "conv_reg_kernel"}<{short[xd.dtype]}, {short[out_dtype]}, {bn}>'
         PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1,
                         (B, H, W, Cin, Cout, KH, stride, len(x.sizes) if ragged else 1)))
     return out
