@@ -23,7 +23,7 @@ class DasConvDesc(C.Structure):
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('relu_in', i32), ('relu', i32),
                 ('scale', vp), ('shift', vp), ('residual', vp), ('res_pix_stride', i32), ('stats', vp),
-                ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5)]
+                ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5), ('in_up', i32)]
 
 
 class DasLevels(C.Structure):
@@ -49,6 +49,9 @@ SIGNATURES = {
     'das_abi_version': (i32, []),
     'das_target_arch': (C.c_char_p, []),
     'das_conv2d_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), vp]),
+    'das_conv2d_wgrad_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), vp]),
+    'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
+    'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     'das_pack_nchw_to_nhwc': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'das_unpack_nhwc_to_nchw': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_maxpool3x3s2': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

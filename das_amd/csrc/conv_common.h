@@ -21,6 +21,8 @@ struct ConvP {
   int Ho, Wo, Cout, yps;
   int KH, KW, stride, pad;
   int relu_in, relu, rps;
+  int up_sh;  // log2 of the input zero-upsampling factor (dgrad of a strided conv): tap coordinate t
+              // reads x[t >> up_sh] when t is a multiple of 1 << up_sh, else contributes zero
   int M, K, HoWo, ntiles, nblocks;
   // ragged multi-level input (stride 1, "same" padding): rows of level l start at lvStart[l]
   int nlev, B;

@@ -72,9 +72,11 @@ __global__ __launch_bounds__(256) void conv_reg_kernel(ConvP p) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int hi = rg[i].hi0 + kh, wi = rg[i].wi0 + kw;
+      const int th = rg[i].hi0 + kh, tw = rg[i].wi0 + kw;
+      const int hi = th >> p.up_sh, wi = tw >> p.up_sh;
+      const bool on_grid = (((th | tw) & ((1 << p.up_sh) - 1)) == 0);
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (kok && hi >= 0 && hi < rg[i].H && wi >= 0 && wi < rg[i].W) {
+      if (kok && on_grid && th >= 0 && hi < rg[i].H && tw >= 0 && wi < rg[i].W) {
         v = *reinterpret_cast<const uint4*>(xg + (rg[i].pix0 + (long long)hi * rg[i].W + wi) * p.xps + ci);
         if (p.relu_in) v = relu_vec<T>(v);
       }
@@ -197,9 +199,17 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvP p) {
     char* sW = sA + A_BYTES;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-      const int hi = rg[j].hi0 + f_kh, wi = rg[j].wi0 + f_kw;
-      const bool ok = (unsigned)hi < (unsigned)rg[j].H && (unsigned)wi < (unsigned)rg[j].W;
-      const T* cand = abase[j] + (long long)(f_kh * rg[j].W + f_kw) * p.xps + f_ci;
+      const int th = rg[j].hi0 + f_kh, tw = rg[j].wi0 + f_kw;
+      const T* cand;
+      bool ok;
+      if (p.up_sh == 0) {
+        ok = (unsigned)th < (unsigned)rg[j].H && (unsigned)tw < (unsigned)rg[j].W;
+        cand = abase[j] + (long long)(f_kh * rg[j].W + f_kw) * p.xps + f_ci;
+      } else {  // dgrad of a strided conv: only taps landing on the stride grid read dY
+        const int hi = th >> p.up_sh, wi = tw >> p.up_sh;
+        ok = (((th | tw) & ((1 << p.up_sh) - 1)) == 0) && th >= 0 && tw >= 0 && hi < rg[j].H && wi < rg[j].W;
+        cand = xg + (rg[j].pix0 + (long long)hi * rg[j].W + wi) * p.xps + f_ci + akg[j];
+      }
       dma16(ok ? cand : zero, sA + (wave * A_INSTR + j) * 1024);
     }
 #pragma unroll
@@ -314,6 +324,9 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.yps = d->y_pix_stride;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.relu_in = d->relu_in; p.relu = d->relu; p.rps = d->res_pix_stride;
+  if (d->in_up != 0 && d->in_up != 1 && d->in_up != 2) return DAS_ERR_ARG;
+  if (d->in_up == 2 && (d->stride != 1 || p.nlev > 1)) return DAS_ERR_ARG;
+  p.up_sh = d->in_up == 2 ? 1 : 0;
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0;
   hipStream_t s = (hipStream_t)stream;

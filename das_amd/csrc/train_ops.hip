@@ -1,0 +1,374 @@
+// Backward kernels of the conv / norm units (training path).
+//   conv data-gradient  : das_conv2d_nhwc itself on flipped/transposed weights (+ in_up for strides)
+//   conv weight-gradient: conv_wgrad_kernel below — GEMM dW[o][k] = sum_m dY[m][o] * Xcol[m][k] whose
+//                         reduction runs over pixel rows, i.e. over the slow axis of both NHWC operands.
+//                         bf16: tiles are DMA'd row-major into LDS and transposed for free by
+//                         ds_read_b64_tr_b16 while building the MFMA fragments; f32: 16x16x4 MFMA whose
+//                         fragments are single dwords, so no transpose is needed.
+//   BatchNorm (train) backward, GroupNorm backward, column sums (bias gradients).
+#include <algorithm>
+
+#include "conv_common.h"
+
+using namespace dasconv;
+
+__device__ uint4 g_das_zero_page_train[8];  // this translation unit's zero page (no -fgpu-rdc)
+
+namespace {
+constexpr int TPB = 256;
+inline int grid_for(long long n, int cap = 8192) {
+  long long b = (n + TPB - 1) / TPB;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+__device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ weight gradient
+template <typename T>
+struct WG;
+template <>
+struct WG<bf16_t> {
+  static constexpr int ROWB = 256;  // 128 channels x 2 B
+  static __device__ __forceinline__ int swz(int slot, int row) { return slot ^ ((row & 7) << 1); }
+};
+template <>
+struct WG<float> {
+  static constexpr int ROWB = 512;
+  static __device__ __forceinline__ int swz(int slot, int row) { return slot; }
+};
+
+// p.x = forward input X, p.res = dY (pixel stride p.rps), p.y = dW f32 [Cout][K] (pre-zeroed).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_block) {
+  constexpr int EPV = Elem<T>::EPV;
+  constexpr int ROWB = WG<T>::ROWB, SLOTS = ROWB / 16;
+  constexpr int BKM = 32;                      // pixel rows per step
+  constexpr int TILE = BKM * ROWB;             // bytes per operand tile
+  constexpr int RPI = 1024 / ROWB;             // rows per wave-instruction
+  constexpr int IPW = BKM / RPI / 4;           // DMA instructions per wave per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = (p.K + 127) / 128;
+  const int o0 = (blockIdx.x / ntiles) * 128, n0 = (blockIdx.x % ntiles) * 128;
+  const int wave_o0 = (wave >> 1) * 64, wave_n0 = (wave & 1) * 64;
+  const long long m_begin = (long long)blockIdx.y * steps_per_block * BKM;
+
+  const T* xg = reinterpret_cast<const T*>(p.x);
+  const T* dyg = reinterpret_cast<const T*>(p.res);
+  const T* zero = reinterpret_cast<const T*>(g_das_zero_page_train);
+
+  // per (lane, instruction) constants: tile row, dY channel, X column -> (tap, ci)
+  int rrow[IPW], och[IPW], xkh[IPW], xkw[IPW], xci[IPW];
+  bool ook[IPW], nok[IPW];
+#pragma unroll
+  for (int j = 0; j < IPW; ++j) {
+    const int row = (wave * IPW + j) * RPI + lane / SLOTS;
+    const int logical = WG<T>::swz(lane % SLOTS, row);
+    rrow[j] = row;
+    och[j] = o0 + logical * EPV;
+    ook[j] = och[j] < p.Cout;
+    const int n = n0 + logical * EPV;
+    nok[j] = n < p.K;
+    const int tap = n / p.Cin;
+    xci[j] = n - tap * p.Cin;
+    xkh[j] = tap / p.KW;
+    xkw[j] = tap - xkh[j] * p.KW;
+  }
+
+  auto issue = [&](int step, int buf) {
+    char* sD = smem + buf * 2 * TILE;
+    char* sX = sD + TILE;
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const long long m = m_begin + (long long)step * BKM + rrow[j];
+      const bool mok = m < p.M;
+      const T* sd = (mok && ook[j]) ? dyg + m * p.rps + och[j] : zero;
+      dma16(sd, sD + (wave * IPW + j) * 1024);
+      const T* sx = zero;
+      if (mok && nok[j]) {
+        const RowGeom g = row_geom(p, (int)m);
+        const int hi = g.hi0 + xkh[j], wi = g.wi0 + xkw[j];
+        if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+          sx = xg + (g.pix0 + (long long)hi * g.W + wi) * p.xps + xci[j];
+      }
+      dma16(sx, sX + (wave * IPW + j) * 1024);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const long long m_left = (long long)p.M - m_begin;
+  const int nsteps = (int)std::min<long long>(steps_per_block, (m_left + BKM - 1) / BKM);
+  if (nsteps <= 0) return;
+  issue(0, 0);
+  __syncthreads();
+  const int g4 = lane >> 4, q = lane & 15;
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) issue(s + 1, buf ^ 1);
+    const char* sD = smem + buf * 2 * TILE;
+    const char* sX = sD + TILE;
+    if constexpr (sizeof(T) == 2) {
+      uint4 fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v4i16_t lo[2], hi[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = h * 16 + g4 * 4 + (q >> 2);
+          const int sub = q & 3;
+          const int ca = wave_o0 + t * 16, cb = wave_n0 + t * 16;
+          const int sa = WG<T>::swz((ca >> 3) + (sub >> 1), row), sb = WG<T>::swz((cb >> 3) + (sub >> 1), row);
+          lo[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4i16_t*)(sD + row * ROWB + sa * 16 + (sub & 1) * 8));
+          hi[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4i16_t*)(sX + row * ROWB + sb * 16 + (sub & 1) * 8));
+        }
+        fa[t] = make_uint4(__builtin_bit_cast(uint2, lo[0]).x, __builtin_bit_cast(uint2, lo[0]).y,
+                           __builtin_bit_cast(uint2, lo[1]).x, __builtin_bit_cast(uint2, lo[1]).y);
+        fb[t] = make_uint4(__builtin_bit_cast(uint2, hi[0]).x, __builtin_bit_cast(uint2, hi[0]).y,
+                           __builtin_bit_cast(uint2, hi[1]).x, __builtin_bit_cast(uint2, hi[1]).y);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                              __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BKM / 4; ++kk) {
+        float fa[4], fb[4];
+        const int row = kk * 4 + g4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          fa[t] = *reinterpret_cast<const float*>(sD + row * ROWB + (wave_o0 + t * 16 + q) * 4);
+          fb[t] = *reinterpret_cast<const float*>(sX + row * ROWB + (wave_n0 + t * 16 + q) * 4);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  float* dw = reinterpret_cast<float*>(p.y);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int n = n0 + wave_n0 + b * 16 + q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = o0 + wave_o0 + a * 16 + g4 * 4 + j;
+        if (o < p.Cout && n < p.K) atomicAdd(dw + (long long)o * p.K + n, acc[a][b][j]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------ column sums (bias gradient)
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, long long rows, int C, int ps, float* __restrict__ out) {
+  constexpr int EPV = Elem<T>::EPV;
+  extern __shared__ float sred[];
+  const int VC = C / EPV;
+  for (int i = threadIdx.x; i < C; i += TPB) sred[i] = 0.f;
+  __syncthreads();
+  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = TPB / VC;
+  if (pl < PL) {
+    float s[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) s[j] = 0.f;
+    for (long long r = (long long)blockIdx.x * PL + pl; r < rows; r += (long long)gridDim.x * PL) {
+      float f[EPV];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + r * ps + v * EPV), f);
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) s[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) atomicAdd(&sred[v * EPV + j], s[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += TPB) atomicAdd(out + i, sred[i]);
+}
+
+// ------------------------------------------------------------------ BatchNorm (train) backward
+// pass 1: s1[c] = sum dZ, s2[c] = sum dZ * xhat with dZ = dY * (y > 0 if relu)
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ raw,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd, long long rows,
+                                     int C, int relu, float* __restrict__ sums) {
+  constexpr int EPV = Elem<T>::EPV;
+  extern __shared__ float sred[];  // [2C]
+  const int VC = C / EPV;
+  for (int i = threadIdx.x; i < 2 * C; i += TPB) sred[i] = 0.f;
+  __syncthreads();
+  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = TPB / VC;
+  if (pl < PL) {
+    float s1[EPV], s2[EPV], mu[EPV], is[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[v * EPV + j]; is[j] = invstd[v * EPV + j]; }
+    for (long long r = (long long)blockIdx.x * PL + pl; r < rows; r += (long long)gridDim.x * PL) {
+      float g[EPV], x[EPV];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + r * C + v * EPV), g);
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(raw + r * C + v * EPV), x);
+      if (relu) {
+        float o[EPV];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + r * C + v * EPV), o);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) { s1[j] += g[j]; s2[j] += g[j] * (x[j] - mu[j]) * is[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      atomicAdd(&sred[v * EPV + j], s1[j]);
+      atomicAdd(&sred[C + v * EPV + j], s2[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(sums + i, sred[i]);
+}
+
+// pass 2: dRaw = gamma*invstd*(dZ - s1/N - xhat*s2/N); optionally dRes = dZ
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ raw,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ sums, long long rows,
+                                    int C, int relu, T* __restrict__ draw, T* __restrict__ dres) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  const long long total = rows * VC;
+  const float inv_n = 1.f / (float)rows;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int c0 = (int)(i % VC) * EPV;
+    float g[EPV], x[EPV], o[EPV];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + i * EPV), g);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(raw + i * EPV), x);
+    if (relu) {
+      float yy[EPV];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + i * EPV), yy);
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+    }
+    if (dres) *reinterpret_cast<uint4*>(dres + i * EPV) = Elem<T>::pack(g);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const int c = c0 + j;
+      const float xhat = (x[j] - mean[c]) * invstd[c];
+      o[j] = gamma[c] * invstd[c] * (g[j] - sums[c] * inv_n - xhat * sums[C + c] * inv_n);
+    }
+    *reinterpret_cast<uint4*>(draw + i * EPV) = Elem<T>::pack(o);
+  }
+}
+}  // namespace
+
+extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, void* stream) {
+  if (!x || !dy || !dw || !d) return DAS_ERR_ARG;
+  if (d->Cin % 8 || d->Cout % 8 || d->x_pix_stride % 8 || d->y_pix_stride % 8) return DAS_ERR_ARG;
+  if (d->KH < 1 || d->KW < 1 || d->stride < 1 || d->B < 1 || d->in_up > 1) return DAS_ERR_ARG;
+  ConvP p;
+  long long M = (long long)d->B * d->Ho * d->Wo;
+  p.nlev = d->num_levels;
+  p.B = d->B;
+  if (p.nlev > 1) {
+    if (p.nlev > MAXLV || d->stride != 1 || d->KH != d->KW || d->pad != d->KH / 2) return DAS_ERR_ARG;
+    M = 0;
+    for (int l = 0; l < p.nlev; ++l) {
+      p.lvH[l] = d->lvl_H[l]; p.lvW[l] = d->lvl_W[l]; p.lvStart[l] = (int)M;
+      M += (long long)d->B * d->lvl_H[l] * d->lvl_W[l];
+    }
+  }
+  for (int l = (p.nlev > 1 ? p.nlev : 0); l < MAXLV; ++l) { p.lvH[l] = 0; p.lvW[l] = 0; p.lvStart[l] = 0x7fffffff; }
+  if (M <= 0 || M > 0x7fffffffLL) return DAS_ERR_ARG;
+  p.x = (const char*)x; p.w = nullptr; p.y = (char*)dw; p.res = (const char*)dy;
+  p.scale = p.shift = nullptr; p.stats = nullptr;
+  p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.xps = d->x_pix_stride;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.yps = 0; p.rps = d->y_pix_stride;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+  p.relu_in = p.relu = 0; p.up_sh = 0;
+  p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
+  p.ntiles = p.nblocks = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * p.K, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  const int tiles = ((d->Cout + 127) / 128) * ((p.K + 127) / 128);
+  const long long total_steps = (M + 31) / 32;
+  // aim for ~4 workgroups per CU, at least 8 steps per workgroup
+  long long splits = std::max<long long>(1, (256 * 4 + tiles - 1) / tiles);
+  long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
+  splits = (total_steps + spb - 1) / spb;
+  if (d->dtype == DAS_BF16) {
+    const size_t sm = 2 * 2 * 32 * 256;
+    hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3(tiles, (unsigned)splits), dim3(256), sm, s, p, (int)spb);
+  } else if (d->dtype == DAS_F32) {
+    const size_t sm = 2 * 2 * 32 * 512;
+    hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(tiles, (unsigned)splits), dim3(256), sm, s, p, (int)spb);
+  } else {
+    return DAS_ERR_ARG;
+  }
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream) {
+  if (!x || !out || rows <= 0 || C % 8 || pix_stride % 8 || C > 2048) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, rows / 64));
+  if (dtype == DAS_BF16) {
+    if (C / 8 > TPB) return DAS_ERR_ARG;
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(TPB), C * sizeof(float), s, (const bf16_t*)x, rows, C,
+                       pix_stride, out);
+  } else if (dtype == DAS_F32) {
+    if (C / 4 > TPB) return DAS_ERR_ARG;
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(TPB), C * sizeof(float), s, (const float*)x, rows, C,
+                       pix_stride, out);
+  } else {
+    return DAS_ERR_ARG;
+  }
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
+                                     const float* mean, const float* invstd, const float* gamma, int relu,
+                                     void* draw, void* dres, float* sums, void* stream) {
+  if (!dy || !raw || !mean || !invstd || !gamma || !draw || !sums || rows <= 0 || C % 8 || C > 2048) return DAS_ERR_ARG;
+  if (relu && !y) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, rows / 64));
+  if (dtype == DAS_BF16) {
+    if (C / 8 > TPB) return DAS_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(TPB), 2 * C * sizeof(float), s,
+                       (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)raw, mean, invstd, rows, C, relu, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(rows * (C / 8))), dim3(TPB), 0, s, (const bf16_t*)dy,
+                       (const bf16_t*)y, (const bf16_t*)raw, mean, invstd, gamma, sums, rows, C, relu, (bf16_t*)draw,
+                       (bf16_t*)dres);
+  } else if (dtype == DAS_F32) {
+    if (C / 4 > TPB) return DAS_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(TPB), 2 * C * sizeof(float), s, (const float*)dy,
+                       (const float*)y, (const float*)raw, mean, invstd, rows, C, relu, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(rows * (C / 4))), dim3(TPB), 0, s, (const float*)dy,
+                       (const float*)y, (const float*)raw, mean, invstd, gamma, sums, rows, C, relu, (float*)draw,
+                       (float*)dres);
+  } else {
+    return DAS_ERR_ARG;
+  }
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}

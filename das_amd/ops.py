@@ -124,9 +124,78 @@ def pack_weight(w, dtype, cin_pad=None, cout_pad=None):
     return p
 
 
+def pack_weight_dgrad(w, dtype):
+    """OIHW f32 parameter -> data-gradient weights (Cin_pad, KH, KW, Cout_pad): taps flipped, I/O swapped."""
+    O, I, KH, KW = w.shape
+    p = torch.zeros((I + 7) // 8 * 8, KH, KW, (O + 7) // 8 * 8, dtype=dtype, device=w.device)
+    p[:I, :, :, :O] = w.detach().flip(2, 3).permute(1, 2, 3, 0).to(dtype)
+    return p
+
+
+def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw):
+    """dX of conv(x, w, stride, pad): a stride-1 conv of the (zero-upsampled) dY with flipped weights."""
+    if isinstance(dy, Ragged):
+        return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad)
+    return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, in_up=stride, out_hw=in_hw)
+
+
+def conv2d_wgrad(x, dy, KH, KW, stride, pad):
+    """dW (Cout, KH, KW, Cin) f32 of conv(x, w, stride, pad) given dy; x/dy NHWC or Ragged."""
+    _need_gpu(x, dy)
+    xd, dyd = _data(x), _data(dy)
+    Cin, Cout = xd.shape[-1], dyd.shape[-1]
+    ragged = isinstance(x, Ragged)
+    if ragged:
+        B, (H, W) = x.B, x.sizes[0]
+        Ho, Wo = H, W
+    else:
+        B, H, W, _ = x.shape
+        Ho, Wo = dy.shape[1], dy.shape[2]
+    dw = torch.empty(Cout, KH, KW, Cin, dtype=torch.float32, device=xd.device)
+    d = _lib.DasConvDesc(dtype=_DT[xd.dtype], out_dtype=_lib.DAS_F32, B=B, H=H, W=W, Cin=Cin, x_pix_stride=_ps(x),
+                         Ho=Ho, Wo=Wo, Cout=Cout, y_pix_stride=_ps(dy), KH=KH, KW=KW, stride=stride, pad=pad,
+                         num_levels=len(x.sizes) if ragged else 0)
+    if ragged:
+        for l, (h, w_) in enumerate(x.sizes):
+            d.lvl_H[l], d.lvl_W[l] = h, w_
+    assert dyd.dtype == xd.dtype
+    _lib.check(_lib.load().das_conv2d_wgrad_nhwc(_ptr(xd), _ptr(dyd), _ptr(dw), C.byref(d), _stream()),
+               'das_conv2d_wgrad_nhwc')
+    return dw
+
+
+def colsum(x):
+    """f32[C] column sums over all rows of an NHWC tensor / Ragged (bias gradient)."""
+    _need_gpu(x)
+    xd = _data(x)
+    Cc = xd.shape[-1]
+    rows = 1
+    for s in xd.shape[:-1]:
+        rows *= s
+    out = torch.empty(Cc, dtype=torch.float32, device=xd.device)
+    _lib.check(_lib.load().das_colsum(_ptr(xd), _DT[xd.dtype], rows, Cc, _ps(x), _ptr(out), _stream()), 'das_colsum')
+    return out
+
+
+def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres):
+    """Returns d_raw, d_residual (or None), dgamma, dbeta."""
+    _need_gpu(dy, raw)
+    assert dy.is_contiguous() and raw.is_contiguous() and (y is None or y.is_contiguous())
+    Cc = raw.shape[-1]
+    rows = raw.numel() // Cc
+    draw = torch.empty_like(raw)
+    dres = torch.empty_like(raw) if want_dres else None
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=raw.device)
+    _lib.check(_lib.load().das_bn_train_backward(_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean),
+                                                 _ptr(invstd), _ptr(gamma), int(relu), _ptr(draw), _ptr(dres),
+                                                 _ptr(sums), _stream()), 'das_bn_train_backward')
+    return draw, dres, sums[Cc:], sums[:Cc]
+
+
 def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, relu_in=False,
-           out_dtype=None, stats=None, out=None):
-    """x (B,H,W,Cin[view]) or Ragged; w packed (Cout,KH,KW,Cin). Returns y (B,Ho,Wo,Cout) / Ragged."""
+           out_dtype=None, stats=None, out=None, in_up=1, out_hw=None):
+    """x (B,H,W,Cin[view]) or Ragged; w packed (Cout,KH,KW,Cin). Returns y (B,Ho,Wo,Cout) / Ragged.
+    in_up / out_hw: data-gradient mode (x zero-upsampled by in_up, explicit output size)."""
     _need_gpu(x, w)
     lib = _lib.load()
     ragged = isinstance(x, Ragged)
@@ -146,8 +215,11 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         rows = x.rows
     else:
         B, H, W, _ = x.shape
-        Ho = (H + 2 * pad - KH) // stride + 1
-        Wo = (W + 2 * pad - KW) // stride + 1
+        if out_hw is not None:
+            Ho, Wo = out_hw
+        else:
+            Ho = (H + 2 * pad - KH) // stride + 1
+            Wo = (W + 2 * pad - KW) // stride + 1
         if out is None:
             out = torch.empty(B, Ho, Wo, Cout, dtype=out_dtype, device=x.device)
         assert out.shape == (B, Ho, Wo, Cout) and out.dtype == out_dtype
@@ -160,7 +232,8 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         Cout=Cout, y_pix_stride=_ps(out), KH=KH, KW=KW, stride=stride, pad=pad, relu_in=int(relu_in), relu=int(relu),
         scale=scale.data_ptr() if scale is not None else None, shift=shift.data_ptr() if shift is not None else None,
         residual=rd.data_ptr() if rd is not None else None, res_pix_stride=_ps(residual) if rd is not None else 0,
-        stats=stats.data_ptr() if stats is not None else None, num_levels=len(x.sizes) if ragged else 0)
+        stats=stats.data_ptr() if stats is not None else None, num_levels=len(x.sizes) if ragged else 0,
+        in_up=in_up)
     if ragged:
         for l, (h, w_) in enumerate(x.sizes):
             d.lvl_H[l], d.lvl_W[l] = h, w_

@@ -65,8 +65,32 @@ typedef struct {
    * `multi_apply(self.forward_single, feats, ...)`). num_levels <= 1: plain (B,H,W,C) tensor. */
   int num_levels;
   int lvl_H[5], lvl_W[5];
+  /* Input zero-upsampling factor, 1 or 2 (0 = 1). With in_up = s the kernel reads x as if s-1 zeros were
+   * inserted between its pixels: the data-gradient of a stride-s conv is
+   * das_conv2d_nhwc(x = dY, w = flipped/transposed weights, stride 1, pad = KH-1-pad, in_up = s,
+   * Ho/Wo = the forward input size). */
+  int in_up;
 } DasConvDesc;
 int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Training path: gradients of the conv / norm units (torch autograd of the ops above;
+ * Fp16OptimizerHook -> loss.backward() in the reference's runner).
+ *
+ * Data gradient of a conv = das_conv2d_nhwc on (dY, flipped + transposed weights, in_up = stride).
+ * Weight gradient: dw f32[Cout][KH][KW][Cin] (zeroed by the call) = sum over output pixels of
+ * dY[m][o] * X[m @ tap][ci]; `d` describes the FORWARD conv (x geometry, Ho/Wo, stride, pad,
+ * y_pix_stride = pixel stride of dy, ragged levels allowed).
+ */
+int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, void* stream);
+/* out f32[C] (zeroed by the call) = column sums of x (rows, C) — bias gradients. */
+int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream);
+/* Train-mode BatchNorm (+ReLU, + residual) backward. dZ = dY * (y > 0) when relu; sums f32[2C] (zeroed by
+ * the call) receive [sum dZ, sum dZ*xhat] = [dbeta, dgamma]; draw = gamma*invstd*(dZ - s1/N - xhat*s2/N);
+ * dres (optional) = dZ, the gradient of the residual input. raw = pre-norm conv output saved by forward. */
+int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
+                          const float* mean, const float* invstd, const float* gamma, int relu, void* draw,
+                          void* dres, float* sums, void* stream);
 
 /* Pack an NCHW f32 image batch into NHWC `dtype` with channels zero-padded to Cpad.
  * Replaces the implicit layout of `img` entering MSPN2.forward (mspn_mmpose.py:657-662). */
