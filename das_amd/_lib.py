@@ -52,6 +52,11 @@ SIGNATURES = {
     'das_conv2d_wgrad_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), vp]),
     'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
     'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    'das_groupnorm_backward': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp,
+                                     vp, vp, vp]),
+    'das_maxpool3x3s2_backward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'das_upsample_bilinear_ac_backward': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'das_upsample_nearest_backward': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_pack_nchw_to_nhwc': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'das_unpack_nhwc_to_nchw': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_maxpool3x3s2': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

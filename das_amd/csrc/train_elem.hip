@@ -1,0 +1,313 @@
+// Backward of the HBM-bound NHWC helpers: GroupNorm(+ReLU), 3x3/s2 max-pool, bilinear
+// (align_corners=True) upsampling, nearest upsample-add. All in "gather" form (each thread owns one
+// 16-byte channel vector of the gradient it produces), so results are deterministic and need no atomics
+// except the per-channel / per-group statistic reductions.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+inline int grid_for(long long n, int cap = 8192) {
+  long long b = (n + TPB - 1) / TPB;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ------------------------------------------------------------------ GroupNorm backward
+// pass 1: per channel a[c] = sum dZ, b[c] = sum dZ*xhat over the block's pixels of one (level,image)
+// segment; dgamma/dbeta get them directly, the group sums s1 = sum gamma*a, s2 = sum gamma*b per segment.
+template <typename T>
+__global__ void gn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                                     DasLevels lv, int C, int ps, int G, int pix_per_block,
+                                     const float* __restrict__ fstats, const float* __restrict__ gamma, float eps,
+                                     int relu, float* __restrict__ gsums, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  constexpr int EPV = Elem<T>::EPV;
+  extern __shared__ float sred[];  // [2C]
+  const int seg = blockIdx.y, l = seg / lv.B, b = seg % lv.B;
+  const int HW = lv.H[l] * lv.W[l];
+  const int p0 = blockIdx.x * pix_per_block;
+  if (p0 >= HW) return;
+  long long row0 = (long long)b * HW;
+  for (int i = 0; i < l; ++i) row0 += (long long)lv.B * lv.H[i] * lv.W[i];
+  const int VC = C / EPV, cpg = C / G;
+  const float inv_n = 1.f / ((float)HW * (float)cpg);
+  for (int i = threadIdx.x; i < 2 * C; i += TPB) sred[i] = 0.f;
+  __syncthreads();
+  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = TPB / VC;
+  if (pl < PL) {
+    float a[EPV], bb[EPV], mu[EPV], rs[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const int g = (v * EPV + j) / cpg;
+      const float m = fstats[((long long)seg * G + g) * 2] * inv_n;
+      const float var = fmaxf(fstats[((long long)seg * G + g) * 2 + 1] * inv_n - m * m, 0.f);
+      mu[j] = m; rs[j] = rsqrtf(var + eps); a[j] = 0.f; bb[j] = 0.f;
+    }
+    const int p1 = min(p0 + pix_per_block, HW);
+    for (int p = p0 + pl; p < p1; p += PL) {
+      float g[EPV], xx[EPV];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + (row0 + p) * ps + v * EPV), g);
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (row0 + p) * ps + v * EPV), xx);
+      if (relu) {
+        float o[EPV];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + (row0 + p) * ps + v * EPV), o);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) { a[j] += g[j]; bb[j] += g[j] * (xx[j] - mu[j]) * rs[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      atomicAdd(&sred[v * EPV + j], a[j]);
+      atomicAdd(&sred[C + v * EPV + j], bb[j]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    atomicAdd(dbeta + c, sred[c]);
+    atomicAdd(dgamma + c, sred[C + c]);
+  }
+  for (int g = threadIdx.x; g < G; g += TPB) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < cpg; ++j) { s1 += gamma[g * cpg + j] * sred[g * cpg + j]; s2 += gamma[g * cpg + j] * sred[C + g * cpg + j]; }
+    atomicAdd(&gsums[((long long)seg * G + g) * 2], s1);
+    atomicAdd(&gsums[((long long)seg * G + g) * 2 + 1], s2);
+  }
+}
+
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                                    T* __restrict__ dx, DasLevels lv, int C, int ps, int G,
+                                    const float* __restrict__ fstats, const float* __restrict__ gsums,
+                                    const float* __restrict__ gamma, float eps, int relu, long long total) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV, cpg = C / G;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int v = (int)(i % VC);
+    const long long pix = i / VC;
+    const LvGeom gm = lv_geom(lv, pix);
+    const long long seg = (long long)gm.l * lv.B + gm.b;
+    const float inv_n = 1.f / ((float)(gm.H * gm.W) * (float)cpg);
+    float g[EPV], xx[EPV], o[EPV];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + pix * ps + v * EPV), g);
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + pix * ps + v * EPV), xx);
+    if (relu) {
+      float yy[EPV];
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + pix * ps + v * EPV), yy);
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const int c = v * EPV + j, gi = c / cpg;
+      const float m = fstats[(seg * G + gi) * 2] * inv_n;
+      const float var = fmaxf(fstats[(seg * G + gi) * 2 + 1] * inv_n - m * m, 0.f);
+      const float rs = rsqrtf(var + eps);
+      const float xhat = (xx[j] - m) * rs;
+      o[j] = rs * (g[j] * gamma[c] - gsums[(seg * G + gi) * 2] * inv_n - xhat * gsums[(seg * G + gi) * 2 + 1] * inv_n);
+    }
+    *reinterpret_cast<uint4*>(dx + pix * ps + v * EPV) = Elem<T>::pack(o);
+  }
+}
+
+// ------------------------------------------------------------------ max-pool 3x3/s2/p1 backward
+// torch routes the gradient to the FIRST maximum in (kh, kw) scan order (ties are common after ReLU).
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int B, int H,
+                                   int W, int C, int Ho, int Wo, long long total) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int v = (int)(i % VC);
+    long long pix = i / VC;
+    const int wi = (int)(pix % W);
+    pix /= W;
+    const int hi = (int)(pix % H);
+    const long long b = pix / H;
+    float me[EPV], acc[EPV];
+    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + i * EPV), me);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+    for (int ho = max(0, hi / 2); ho <= min(Ho - 1, (hi + 1) / 2); ++ho) {
+      for (int wo = max(0, wi / 2); wo <= min(Wo - 1, (wi + 1) / 2); ++wo) {
+        const int myk = (hi - (ho * 2 - 1)) * 3 + (wi - (wo * 2 - 1));
+        bool win[EPV];
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) win[j] = true;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int yy = ho * 2 - 1 + k / 3, xx = wo * 2 - 1 + k % 3;
+          if (k == myk || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+          float f[EPV];
+          Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + ((b * H + yy) * W + xx) * C + v * EPV), f);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) win[j] = win[j] && (k < myk ? me[j] > f[j] : me[j] >= f[j]);
+        }
+        float g[EPV];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + ((b * Ho + ho) * Wo + wo) * C + v * EPV), g);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc[j] += win[j] ? g[j] : 0.f;
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + i * EPV) = Elem<T>::pack(acc);
+  }
+}
+
+// ------------------------------------------------------------------ bilinear (align_corners) backward
+__device__ __forceinline__ float bil_w(int dst, int src, int n_src, float scale) {
+#pragma clang fp contract(off)
+  const float r = scale * dst;
+  const int i0 = (int)r;
+  const int ip = (i0 < n_src - 1) ? 1 : 0;
+  const float l1 = r - i0;
+  float w = 0.f;
+  if (i0 == src) w += 1.f - l1;
+  if (i0 + ip == src) w += ip ? l1 : l1;  // when ip == 0 both taps hit i0: total weight (1-l1)+l1
+  return w;
+}
+
+template <typename T>
+__global__ void bilinear_ac_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C,
+                                       int Ho, int Wo, float sh, float sw, long long total) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int v = (int)(i % VC);
+    long long pix = i / VC;
+    const int w = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const long long b = pix / H;
+    float acc[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+    const int ho_lo = sh > 0.f ? max(0, (int)floorf((h - 1) / sh) - 1) : 0;
+    const int ho_hi = sh > 0.f ? min(Ho - 1, (int)ceilf((h + 1) / sh) + 1) : Ho - 1;
+    const int wo_lo = sw > 0.f ? max(0, (int)floorf((w - 1) / sw) - 1) : 0;
+    const int wo_hi = sw > 0.f ? min(Wo - 1, (int)ceilf((w + 1) / sw) + 1) : Wo - 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      const float wh = bil_w(ho, h, H, sh);
+      if (wh == 0.f) continue;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const float ww = bil_w(wo, w, W, sw);
+        if (ww == 0.f) continue;
+        float g[EPV];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + ((b * Ho + ho) * Wo + wo) * C + v * EPV), g);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc[j] += wh * ww * g[j];
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + i * EPV) = Elem<T>::pack(acc);
+  }
+}
+
+// ------------------------------------------------------------------ nearest upsample backward
+// db[hs,ws] = sum of dy[h,w] over the fine pixels whose nearest source is (hs,ws)
+template <typename T>
+__global__ void nearest_bwd_kernel(const T* __restrict__ dy, T* __restrict__ db, int B, int H, int W, int C, int Hb,
+                                   int Wb, float sh, float sw, long long total) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int v = (int)(i % VC);
+    long long pix = i / VC;
+    const int ws = (int)(pix % Wb);
+    pix /= Wb;
+    const int hs = (int)(pix % Hb);
+    const long long b = pix / Hb;
+    float acc[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+    const int h_lo = max(0, (int)floorf(hs / sh) - 1), h_hi = min(H - 1, (int)ceilf((hs + 1) / sh) + 1);
+    const int w_lo = max(0, (int)floorf(ws / sw) - 1), w_hi = min(W - 1, (int)ceilf((ws + 1) / sw) + 1);
+    for (int h = h_lo; h <= h_hi; ++h) {
+      if (min((int)floorf(h * sh), Hb - 1) != hs) continue;
+      for (int w = w_lo; w <= w_hi; ++w) {
+        if (min((int)floorf(w * sw), Wb - 1) != ws) continue;
+        float g[EPV];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + ((b * H + h) * W + w) * C + v * EPV), g);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) acc[j] += g[j];
+      }
+    }
+    *reinterpret_cast<uint4*>(db + i * EPV) = Elem<T>::pack(acc);
+  }
+}
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                 \
+  if ((dtype) == DAS_BF16) { using T = bf16_t; CALL; } \
+  else if ((dtype) == DAS_F32) { using T = float; CALL; } \
+  else return DAS_ERR_ARG;
+
+extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void* x, void* dx, int dtype,
+                                      const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
+                                      const float* gamma, float eps, int relu, float* gsums_ws, float* dgamma,
+                                      float* dbeta, void* stream) {
+  if (!dy || !x || !dx || !fwd_stats || !gamma || !gsums_ws || !dgamma || !dbeta || !lv_valid(lv)) return DAS_ERR_ARG;
+  if (C % 8 || C % G || pix_stride % 8 || C > 2048 || (relu && !y)) return DAS_ERR_ARG;
+  const int epv = dtype == DAS_BF16 ? 8 : 4;
+  if ((C / epv) > TPB) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int nseg = lv->num_levels * lv->B;
+  if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (hipMemsetAsync(dbeta, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  int maxhw = 0;
+  for (int l = 0; l < lv->num_levels; ++l) maxhw = std::max(maxhw, lv->H[l] * lv->W[l]);
+  int chunks = (256 * 4 + lv->B - 1) / lv->B;
+  int ppb = std::max(64, (maxhw + chunks - 1) / chunks);
+  chunks = (maxhw + ppb - 1) / ppb;
+  const long long total = lv_total_rows(*lv) * (C / epv);
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3(chunks, nseg), dim3(TPB), 2 * C * sizeof(float), s, (const T*)dy,
+                       (const T*)y, (const T*)x, *lv, C, pix_stride, G, ppb, fwd_stats, gamma, eps, relu, gsums_ws,
+                       dgamma, dbeta);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
+                       (const T*)x, (T*)dx, *lv, C, pix_stride, G, fwd_stats, gsums_ws, gamma, eps, relu, total);
+  });
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W,
+                                         int C, void* stream) {
+  if (!x || !dy || !dx || C % 8) return DAS_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  DISPATCH_T(dtype, {
+    const long long total = (long long)B * H * W * (C / Elem<T>::EPV);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total, 65536)), dim3(TPB), 0, (hipStream_t)stream,
+                       (const T*)x, (const T*)dy, (T*)dx, B, H, W, C, Ho, Wo, total);
+  });
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_upsample_bilinear_ac_backward(const void* dy, void* dx, int dtype, int B, int H, int W, int C,
+                                                 int Ho, int Wo, void* stream) {
+  if (!dy || !dx || C % 8) return DAS_ERR_ARG;
+  const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  DISPATCH_T(dtype, {
+    const long long total = (long long)B * H * W * (C / Elem<T>::EPV);
+    hipLaunchKernelGGL(bilinear_ac_bwd_kernel<T>, dim3(grid_for(total, 65536)), dim3(TPB), 0, (hipStream_t)stream,
+                       (const T*)dy, (T*)dx, B, H, W, C, Ho, Wo, sh, sw, total);
+  });
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_upsample_nearest_backward(const void* dy, void* db, int dtype, int B, int H, int W, int C, int Hb,
+                                             int Wb, void* stream) {
+  if (!dy || !db || C % 8) return DAS_ERR_ARG;
+  const float sh = (float)Hb / (float)H, sw = (float)Wb / (float)W;
+  DISPATCH_T(dtype, {
+    const long long total = (long long)B * Hb * Wb * (C / Elem<T>::EPV);
+    hipLaunchKernelGGL(nearest_bwd_kernel<T>, dim3(grid_for(total, 65536)), dim3(TPB), 0, (hipStream_t)stream,
+                       (const T*)dy, (T*)db, B, H, W, C, Hb, Wb, sh, sw, total);
+  });
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}

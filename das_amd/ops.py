@@ -333,7 +333,56 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     return y, mean, invstd
 
 
-def groupnorm(x, gamma, beta, G, eps=1e-5, relu=True, out=None):
+def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True):
+    """Returns dx (same container as x), dgamma, dbeta."""
+    _need_gpu(dy, x)
+    xd, dyd = _data(x), _data(dy)
+    yd = _data(y) if y is not None else None
+    lv = _levels(x)
+    Cc = xd.shape[-1]
+    dx = _empty_like_rows(x, Cc, xd.dtype)
+    assert _ps(dy) == _ps(x) == _ps(dx) and (yd is None or _ps(y) == _ps(x)), 'operands must share the pixel stride'
+    gs = torch.empty(lv.num_levels * lv.B * G * 2, dtype=torch.float32, device=xd.device)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=xd.device)
+    dbeta = torch.empty_like(dgamma)
+    _lib.check(_lib.load().das_groupnorm_backward(_ptr(dyd), _ptr(yd), _ptr(xd), _ptr(_data(dx)), _DT[xd.dtype],
+                                                  C.byref(lv), Cc, _ps(x), G, _ptr(fwd_stats), _ptr(gamma), eps,
+                                                  int(relu), _ptr(gs), _ptr(dgamma), _ptr(dbeta), _stream()),
+               'das_groupnorm_backward')
+    return dx, dgamma, dbeta
+
+
+def maxpool3x3s2_backward(x, dy):
+    _need_gpu(x, dy)
+    B, H, W, Cc = x.shape
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().das_maxpool3x3s2_backward(_ptr(x), _ptr(dy), _ptr(dx), _DT[x.dtype], B, H, W, Cc, _stream()),
+               'das_maxpool3x3s2_backward')
+    return dx
+
+
+def upsample_bilinear_ac_backward(dy, H, W):
+    _need_gpu(dy)
+    B, Ho, Wo, Cc = dy.shape
+    assert dy.is_contiguous()
+    dx = torch.empty(B, H, W, Cc, dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().das_upsample_bilinear_ac_backward(_ptr(dy), _ptr(dx), _DT[dy.dtype], B, H, W, Cc, Ho, Wo,
+                                                             _stream()), 'das_upsample_bilinear_ac_backward')
+    return dx
+
+
+def upsample_nearest_backward(dy, Hb, Wb):
+    _need_gpu(dy)
+    B, H, W, Cc = dy.shape
+    assert dy.is_contiguous()
+    db = torch.empty(B, Hb, Wb, Cc, dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().das_upsample_nearest_backward(_ptr(dy), _ptr(db), _DT[dy.dtype], B, H, W, Cc, Hb, Wb,
+                                                         _stream()), 'das_upsample_nearest_backward')
+    return db
+
+
+def groupnorm(x, gamma, beta, G, eps=1e-5, relu=True, out=None, return_stats=False):
     """In/out NHWC or Ragged (may be channel-slice views with a pixel stride); default in place."""
     _need_gpu(x)
     out = x if out is None else out
@@ -344,7 +393,7 @@ def groupnorm(x, gamma, beta, G, eps=1e-5, relu=True, out=None):
     _lib.check(_lib.load().das_groupnorm_nhwc(_ptr(xd), _ptr(od), _DT[xd.dtype], C.byref(lv), xd.shape[-1], _ps(x), G,
                                               _ptr(gamma), _ptr(beta), eps, int(relu), _ptr(ws), _stream()),
                'das_groupnorm_nhwc')
-    return out
+    return (out, ws) if return_stats else out
 
 
 def deform_im2col3x3(x, om):

@@ -30,6 +30,12 @@ extern "C" {
 #define DAS_F32 0
 #define DAS_BF16 1
 
+/* Ragged multi-level pixel rows (used by the head ops and their gradients). */
+typedef struct {
+  int num_levels, B;
+  int H[5], W[5];
+} DasLevels;
+
 /* Library/ABI version and the code object's target, for the loader's sanity check. */
 int das_abi_version(void);
 const char* das_target_arch(void);
@@ -92,6 +98,21 @@ int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dt
                           const float* mean, const float* invstd, const float* gamma, int relu, void* draw,
                           void* dres, float* sums, void* stream);
 
+/* GroupNorm(+ReLU) backward over ragged rows. x = pre-norm input saved by forward, y = forward output
+ * (ReLU mask), fwd_stats = the forward's stats workspace (sum, sumsq per level/image/group).
+ * gsums_ws f32[num_levels*B*G*2], dgamma/dbeta f32[C]: all zeroed by the call. */
+int das_groupnorm_backward(const void* dy, const void* y, const void* x, void* dx, int dtype, const DasLevels* lv,
+                           int C, int pix_stride, int G, const float* fwd_stats, const float* gamma, float eps,
+                           int relu, float* gsums_ws, float* dgamma, float* dbeta, void* stream);
+/* Backward of das_maxpool3x3s2 (gradient goes to the first maximum in scan order, as torch does),
+ * das_upsample_bilinear_ac and the upsampled operand of das_add_upsample_nearest. */
+int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W, int C,
+                              void* stream);
+int das_upsample_bilinear_ac_backward(const void* dy, void* dx, int dtype, int B, int H, int W, int C, int Ho, int Wo,
+                                      void* stream);
+int das_upsample_nearest_backward(const void* dy, void* db, int dtype, int B, int H, int W, int C, int Hb, int Wb,
+                                  void* stream);
+
 /* Pack an NCHW f32 image batch into NHWC `dtype` with channels zero-padded to Cpad.
  * Replaces the implicit layout of `img` entering MSPN2.forward (mspn_mmpose.py:657-662). */
 int das_pack_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C, int H, int W, int Cpad, void* stream);
@@ -126,10 +147,7 @@ int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C
  * (das_head.py:176-178 `multi_apply(self.forward_single, feats, ...)`), so the head ops below take
  * the rows of ALL levels back to back: level l contributes B*H[l]*W[l] rows in (b,h,w) order. A plain
  * (B,H,W,C) tensor is the special case num_levels = 1. */
-typedef struct {
-  int num_levels, B;
-  int H[5], W[5];
-} DasLevels;
+/* (typedef DasLevels: see the top of this header) */
 
 /* GroupNorm (+ReLU) over NHWC rows (torch GroupNorm, das_head.py:54, recursive_update.py:178,244);
  * statistics per (level, image, group). stats workspace: f32[num_levels*B*G*2], zeroed by the call. */
