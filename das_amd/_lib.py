@@ -70,6 +70,11 @@ SIGNATURES = {
     'das_sigmoid_blend': (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     'das_head_assemble': (i32, [vp, vp, vp, C.POINTER(DasLevels), C.POINTER(DasHeadDesc), vp]),
     'das_head_finalize': (i32, [vp, vp, C.POINTER(DasLevels), C.POINTER(DasHeadDesc), i32, i32, vp]),
+    'das_deform_im2col3x3_backward': (i32, [vp, vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, i32, vp]),
+    'das_offset_sample_backward': (i32, [vp, vp, vp, vp, vp, vp, vp, C.POINTER(DasLevels), i32, i32, i32, i32, i32,
+                                         i32, vp]),
+    'das_sigmoid_blend_backward': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    'das_head_assemble_backward': (i32, [vp, vp, vp, vp, vp, C.POINTER(DasLevels), C.POINTER(DasHeadDesc), vp]),
     'das_decode_cap': (i32, [C.POINTER(DasDecodeDesc)]),
     'das_decode_ws_bytes': (i64, [i32, i32, i32]),
     'das_decode': (i32, [C.POINTER(DasDecodeDesc), vp, vp, vp, vp, vp, vp, vp]),

@@ -1,0 +1,292 @@
+"""torch.autograd.Function wrappers: autograd sequences the backward pass (plumbing), every forward
+and backward body is a HIP kernel from libdas_hip.so. Activations are NHWC tensors or the 2-D `data`
+of an `ops.Ragged`; geometry travels as plain python arguments."""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import Ragged
+
+
+def _wrap(t, geom):
+    """geom = None (4-D NHWC tensor) or (B, sizes) for Ragged rows"""
+    return t if geom is None else Ragged(t, geom[0], geom[1])
+
+
+def _geom(x):
+    return (x.B, x.sizes) if isinstance(x, Ragged) else None
+
+
+def _d(x):
+    return x.data if isinstance(x, Ragged) else x
+
+
+def _dw_to_oihw(dw, weight):
+    O, I = weight.shape[0], weight.shape[1]
+    return dw[:O, :, :, :I].permute(0, 3, 1, 2)
+
+
+class ConvBNTrainFn(Function):
+    """conv (no bias) -> train-mode BatchNorm (+ residual) (+ ReLU). mspn_mmpose.py:126-157,381-404."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, conv, bn, relu):
+        from .nn import packed_weight
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+        stats = torch.zeros(2 * w.shape[0], dtype=torch.float32, device=x.device)
+        raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,
+                                             residual=residual, relu=relu)
+        bn.num_batches_tracked += 1
+        ctx.save_for_backward(x, raw, y, mean, invstd, gamma, weight)
+        ctx.cfg = (k, s, p, relu, residual is not None, conv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .nn import packed_weight_dgrad
+        x, raw, y, mean, invstd, gamma, weight = ctx.saved_tensors
+        k, s, p, relu, has_res, conv = ctx.cfg
+        dy = dy.contiguous()
+        draw, dres, dgamma, dbeta = ops.bn_train_backward(dy, y if relu else None, raw, mean, invstd, gamma, relu,
+                                                          has_res)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad(draw, packed_weight_dgrad(conv, x.dtype), k, k, s, p, (x.shape[1], x.shape[2]))
+            if dx.shape[-1] != x.shape[-1]:
+                dx = dx[..., :x.shape[-1]]
+        dw = _dw_to_oihw(ops.conv2d_wgrad(x, draw, k, k, s, p), weight)
+        return dx, dw, dgamma, dbeta, dres, None, None, None
+
+
+class ConvFn(Function):
+    """conv + bias (shift) [+ ReLU], output dtype T or f32; NHWC or ragged rows.
+    `w_packed`/`shift` are prepared by the caller (fused heads concatenate several nn.Conv2d)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv_like, geom, relu, out_dtype, out):
+        from .nn import bias_shift, packed_weight
+        k, s, p = conv_like.kernel_size[0], conv_like.stride[0], conv_like.padding[0]
+        xin = _wrap(x, geom)
+        w = packed_weight(conv_like, x.dtype, cin_pad=x.shape[-1])
+        y = ops.conv2d(xin, w, k, k, s, p, shift=bias_shift(conv_like), relu=relu, out_dtype=out_dtype,
+                       out=_wrap(out, geom) if out is not None else None)
+        yd = _d(y)
+        ctx.save_for_backward(x, weight, yd if relu else None)
+        ctx.cfg = (k, s, p, relu, geom, conv_like, bias is not None)
+        if out is not None:
+            ctx.mark_dirty(out)
+        return yd
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .nn import packed_weight_dgrad
+        x, weight, y = ctx.saved_tensors
+        k, s, p, relu, geom, conv, has_bias = ctx.cfg
+        if relu:
+            dy = dy * (y > 0).to(dy.dtype)  # only the stem-free plain convs with ReLU (none on the DAS path)
+        dz = dy if dy.dtype == x.dtype else dy.to(x.dtype)
+        if not (dz.stride(-1) == 1 and (dz.dim() != 2 or dz.stride(0) % 8 == 0)):
+            dz = dz.contiguous()
+        if dz.dim() == 4 and not dz.is_contiguous():
+            dz = dz.contiguous()
+        dzr, xr = _wrap(dz, geom), _wrap(x, geom)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            hw = None if geom is not None else (x.shape[1], x.shape[2])
+            dx = _d(ops.conv2d_dgrad(dzr, packed_weight_dgrad(conv, x.dtype), k, k, s, p, hw))
+            if dx.shape[-1] != x.shape[-1]:
+                dx = dx[..., :x.shape[-1]]
+        dwp = ops.conv2d_wgrad(xr, dzr, k, k, s, p)
+        dw = _dw_to_oihw(dwp, weight) if weight.dim() == 4 and weight.shape[2:] == (k, k) else None
+        db = ops.colsum(dzr)[:weight.shape[0]] if has_bias else None
+        return dx, dw, db, None, None, None, None, None
+
+
+class GroupNormReLUFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, geom, G, eps, relu):
+        xin = _wrap(x, geom)
+        out = xin.new(x.shape[-1]) if geom is not None else torch.empty_like(x)
+        y, st = ops.groupnorm(xin, gamma, beta, G, eps, relu=relu, out=out, return_stats=True)
+        yd = _d(y)
+        ctx.save_for_backward(x, yd, st, gamma)
+        ctx.cfg = (geom, G, eps, relu)
+        return yd
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, st, gamma = ctx.saved_tensors
+        geom, G, eps, relu = ctx.cfg
+        dy = dy.contiguous()
+        dx, dgamma, dbeta = ops.groupnorm_backward(_wrap(dy, geom), _wrap(y, geom), _wrap(x, geom), st, gamma, G, eps,
+                                                   relu)
+        return _d(dx), dgamma, dbeta, None, None, None, None
+
+
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.maxpool3x3s2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool3x3s2_backward(x, dy.contiguous())
+
+
+class BilinearUpFn(Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        ctx.hw = (x.shape[1], x.shape[2])
+        return ops.upsample_bilinear_ac(x, Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample_bilinear_ac_backward(dy.contiguous(), *ctx.hw), None, None
+
+
+class AddNearestFn(Function):
+    """a + nearest_upsample(b)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.hw = (b.shape[1], b.shape[2])
+        return ops.add_upsample_nearest(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return dy, ops.upsample_nearest_backward(dy, *ctx.hw)
+
+
+class Add3Fn(Function):
+    """a + b (+ c): the gradient is the identity on every operand"""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        ctx.n = 3 if c is not None else 2
+        return ops.add3(a, b, c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy, (dy if ctx.n == 3 else None)
+
+
+class DeformIm2colFn(Function):
+    """DCNv2 sampling: x rows (T), om rows f32 [dy,dx per tap | mask logits] -> col rows x 9C (T)."""
+
+    @staticmethod
+    def forward(ctx, x, om, geom):
+        col = ops.deform_im2col3x3(_wrap(x, geom), _wrap(om, geom))
+        ctx.save_for_backward(x, om)
+        ctx.geom = geom
+        return _d(col)
+
+    @staticmethod
+    def backward(ctx, dcol):
+        x, om = ctx.saved_tensors
+        geom = ctx.geom
+        dx, dom = ops.deform_im2col3x3_backward(_wrap(x, geom), _wrap(om, geom), _wrap(dcol.contiguous(), geom))
+        return _d(dx).to(x.dtype), _d(dom), None
+
+
+class DcnGemmFn(Function):
+    """The GEMM half of DCNv2: y = col (rows, 9C) x W^T + bias, W = dcn.weight (O, C, 3, 3)."""
+
+    @staticmethod
+    def forward(ctx, col, weight, bias, dcn, geom):
+        from .nn import _cache_of, _pad8
+        O, Cc = weight.shape[0], weight.shape[1]
+        w = _cache_of(dcn).get(('w', col.dtype), (weight,),
+                               lambda: ops.pack_weight(weight, col.dtype).reshape(-1, 1, 1, 9 * col.shape[-1] // 9))
+        shift = None
+        if bias is not None:
+            shift = _cache_of(dcn).get(('b',), (bias,), lambda: _pad8(bias, bias.numel()))
+        y = ops.conv2d(_wrap(col, geom), w, 1, 1, shift=shift)
+        ctx.save_for_backward(col, weight)
+        ctx.cfg = (dcn, geom, bias is not None)
+        return _d(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .nn import _cache_of
+        col, weight = ctx.saved_tensors
+        dcn, geom, has_bias = ctx.cfg
+        O, Cc = weight.shape[0], weight.shape[1]
+        dy = dy.contiguous()
+        dyr = _wrap(dy, geom)
+
+        def make_wt():  # (9C_pad.., 1, 1, O_pad) = transpose of the packed GEMM weight
+            wp = ops.pack_weight(weight, col.dtype).reshape(-1, 9 * col.shape[-1] // 9)
+            return wp.t().contiguous().reshape(wp.shape[1], 1, 1, wp.shape[0])
+        wt = _cache_of(dcn).get(('wt', col.dtype), (weight,), make_wt)
+        dcol = _d(ops.conv2d(dyr, wt, 1, 1))
+        dwp = ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0)          # (O_pad, 1, 1, 9*Cin_pad)
+        cpad = col.shape[-1] // 9
+        dw = dwp.reshape(dwp.shape[0], 3, 3, cpad)[:O, :, :, :Cc].permute(0, 3, 1, 2)
+        db = ops.colsum(dyr)[:O] if has_bias else None
+        return dcol, dw, db, None, None
+
+
+class OffsetSampleFn(Function):
+    @staticmethod
+    def forward(ctx, uvd, so, conf, geom, J, heads):
+        out = ops.offset_sample(_wrap(uvd, geom), _wrap(so, geom), _wrap(conf, geom), J, heads)
+        ctx.save_for_backward(uvd, so, conf)
+        ctx.cfg = (geom, J, heads)
+        return _d(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        uvd, so, conf = ctx.saved_tensors
+        geom, J, heads = ctx.cfg
+        d_uvd, d_so, d_conf = ops.offset_sample_backward(_wrap(uvd, geom), _wrap(so, geom), _wrap(conf, geom),
+                                                         _wrap(g.contiguous(), geom), J, heads)
+        return _d(d_uvd), _d(d_so), _d(d_conf), None, None, None
+
+
+class SigmoidBlendFn(Function):
+    @staticmethod
+    def forward(ctx, off, w, nxt, geom):
+        out = ops.sigmoid_blend(_wrap(off, geom), _wrap(w, geom), _wrap(nxt, geom))
+        ctx.save_for_backward(off, w, nxt)
+        ctx.geom = geom
+        return _d(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        off, w, nxt = ctx.saved_tensors
+        geom = ctx.geom
+        d_off, d_w, d_nxt = ops.sigmoid_blend_backward(_wrap(off, geom), _wrap(w, geom), _wrap(nxt, geom),
+                                                       _wrap(g.contiguous(), geom))
+        return d_off, d_w, d_nxt, None
+
+
+class HeadAssembleFn(Function):
+    """raw (rows, raw_ps) f32 + the per-level Scale parameters (L,4) -> pose_pred, initial uvd."""
+
+    @staticmethod
+    def forward(ctx, raw, scales, geom, desc, level_ids):
+        pose, uvd = ops.head_assemble(_wrap(raw, geom), desc)
+        ctx.save_for_backward(raw)
+        ctx.cfg = (geom, desc, level_ids, scales.shape)
+        return _d(pose), _d(uvd)
+
+    @staticmethod
+    def backward(ctx, d_pose, d_uvd):
+        (raw,) = ctx.saved_tensors
+        geom, desc, level_ids, sshape = ctx.cfg
+        d_raw, d_scale = ops.head_assemble_backward(_wrap(raw, geom), _wrap(d_pose.contiguous(), geom),
+                                                    _wrap(d_uvd.contiguous(), geom), desc)
+        ds = torch.zeros(sshape, dtype=torch.float32, device=raw.device)
+        for i, l in enumerate(level_ids):
+            ds[l] = d_scale[i]
+        return d_raw, ds, None, None, None
+
+
+def grad_mode(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -13,6 +13,7 @@ import copy
 import torch
 import torch.nn as nn
 
+from . import nn as nnops
 from . import ops
 from .nn import ConvModule, as_nhwc, conv_bn, to_nchw_view
 from .registry import BACKBONES
@@ -71,7 +72,7 @@ class DownsampleModule(nn.Module):
         for i in range(self.num_units):
             x = getattr(self, f'layer{i + 1}')(x)
             if self.has_skip:
-                x = ops.add3(x, skip1[i], skip2[i])
+                x = nnops.add3(x, skip1[i], skip2[i])
             out.append(x)
         out.reverse()
         return tuple(out)
@@ -96,7 +97,7 @@ class UpsampleUnit(nn.Module):
     def forward(self, x, up_x):
         if self.ind > 0:
             lat = self.in_skip(x)
-            up = ops.upsample_bilinear_ac(up_x, x.shape[1], x.shape[2])
+            up = nnops.upsample_bilinear(up_x, x.shape[1], x.shape[2])
             # relu(in_skip(x) + up_conv(up)): add + ReLU fused into up_conv's epilogue
             out = conv_bn(up, self.up_conv.conv, self.up_conv.bn, relu=True, residual=lat)
         else:
@@ -154,7 +155,7 @@ class ResNetTop(nn.Module):
                                  nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
 
     def forward(self, x):
-        return ops.maxpool3x3s2(self.top[0](x))
+        return nnops.max_pool(self.top[0](x))
 
 
 @BACKBONES.register_module()

@@ -187,8 +187,9 @@ __global__ void colsum_kernel(const T* __restrict__ x, long long rows, int C, in
   const int VC = C / EPV;
   for (int i = threadIdx.x; i < C; i += TPB) sred[i] = 0.f;
   __syncthreads();
-  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = TPB / VC;
-  if (pl < PL) {
+  const int VCB = min(VC, TPB);  // channel vectors handled side by side (wider rows loop over v)
+  const int pl = threadIdx.x / VCB, PL = TPB / VCB;
+  for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
     float s[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) s[j] = 0.f;
@@ -216,8 +217,9 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
   const int VC = C / EPV;
   for (int i = threadIdx.x; i < 2 * C; i += TPB) sred[i] = 0.f;
   __syncthreads();
-  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = TPB / VC;
-  if (pl < PL) {
+  const int VCB = min(VC, TPB);
+  const int pl = threadIdx.x / VCB, PL = TPB / VCB;
+  for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
     float s1[EPV], s2[EPV], mu[EPV], is[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[v * EPV + j]; is[j] = invstd[v * EPV + j]; }
@@ -330,11 +332,9 @@ extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int p
   if (hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, rows / 64));
   if (dtype == DAS_BF16) {
-    if (C / 8 > TPB) return DAS_ERR_ARG;
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(TPB), C * sizeof(float), s, (const bf16_t*)x, rows, C,
                        pix_stride, out);
   } else if (dtype == DAS_F32) {
-    if (C / 4 > TPB) return DAS_ERR_ARG;
     hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(TPB), C * sizeof(float), s, (const float*)x, rows, C,
                        pix_stride, out);
   } else {
@@ -353,14 +353,12 @@ extern "C" int das_bn_train_backward(const void* dy, const void* y, const void* 
   if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, rows / 64));
   if (dtype == DAS_BF16) {
-    if (C / 8 > TPB) return DAS_ERR_ARG;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(TPB), 2 * C * sizeof(float), s,
                        (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)raw, mean, invstd, rows, C, relu, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(rows * (C / 8))), dim3(TPB), 0, s, (const bf16_t*)dy,
                        (const bf16_t*)y, (const bf16_t*)raw, mean, invstd, gamma, sums, rows, C, relu, (bf16_t*)draw,
                        (bf16_t*)dres);
   } else if (dtype == DAS_F32) {
-    if (C / 4 > TPB) return DAS_ERR_ARG;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(TPB), 2 * C * sizeof(float), s, (const float*)dy,
                        (const float*)y, (const float*)raw, mean, invstd, rows, C, relu, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(rows * (C / 4))), dim3(TPB), 0, s, (const float*)dy,

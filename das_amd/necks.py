@@ -7,7 +7,7 @@ State-dict keys: `lateral_convs.{i}.{conv,bn}`, `fpn_convs.{i}.{conv,bn}`."""
 import torch.nn as nn
 
 from . import ops
-from .nn import ConvModule, as_nhwc, to_nchw_view
+from .nn import ConvModule, add_nearest, as_nhwc, to_nchw_view
 from .registry import NECKS
 
 
@@ -59,7 +59,7 @@ class FPN(nn.Module):
         lats = [l(feats[i + self.start_level]) for i, l in enumerate(self.lateral_convs)]
         n = len(lats)
         for i in range(n - 1, 0, -1):
-            lats[i - 1] = ops.add_upsample_nearest(lats[i - 1], lats[i])
+            lats[i - 1] = add_nearest(lats[i - 1], lats[i])
         outs = [self.fpn_convs[i](lats[i]) for i in range(n)]
         if self.num_outs > len(outs):
             if self.add_extra_convs == 'on_input':

@@ -68,6 +68,10 @@ def packed_weight(conv, dtype, cin_pad=None):
                                lambda: ops.pack_weight(conv.weight, dtype, cin_pad=cin_pad))
 
 
+def packed_weight_dgrad(conv, dtype):
+    return _cache_of(conv).get(('wd', dtype), (conv.weight,), lambda: ops.pack_weight_dgrad(conv.weight, dtype))
+
+
 def _pad8(v, n, fill=0.0):
     out = torch.full(((n + 7) // 8 * 8,), fill, dtype=torch.float32, device=v.device)
     out[:n] = v.detach().float()
@@ -109,6 +113,10 @@ def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False):
         scale, shift = bn_eval_affine(conv, bn)
         return ops.conv2d(x, w, k, k, s, p, scale=scale, shift=shift, residual=residual, relu=relu, relu_in=relu_in)
     assert conv.bias is None
+    from . import autograd as ag
+    if ag.grad_mode(x, conv.weight, bn.weight, residual):
+        assert not relu_in
+        return ag.ConvBNTrainFn.apply(x, conv.weight, bn.weight, bn.bias, residual, conv, bn, relu)
     cout = w.shape[0]
     stats = torch.zeros(2 * cout, dtype=torch.float32, device=x.device)
     raw = ops.conv2d(x, w, k, k, s, p, relu_in=relu_in, stats=stats)
@@ -121,18 +129,29 @@ def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False):
 
 def conv_plain(x, conv, relu=False, out_dtype=None, out=None):
     """nn.Conv2d with bias, no norm (the 1x1 predictors)."""
+    from . import autograd as ag
+    if ag.grad_mode(_tensor(x), conv.weight, conv.bias):
+        assert out is None, 'writing into a slice is an inference-only shortcut'
+        y = ag.ConvFn.apply(_tensor(x), conv.weight, conv.bias, conv, ag._geom(x), relu, out_dtype, None)
+        return ag._wrap(y, ag._geom(x))
     w = packed_weight(conv, x.dtype, cin_pad=_channels(x))
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     return ops.conv2d(x, w, k, k, s, p, shift=bias_shift(conv), relu=relu, out_dtype=out_dtype, out=out)
 
 
+def _tensor(x):
+    return x.data if isinstance(x, ops.Ragged) else x
+
+
 def dcn_v2(x, dcn):
     """ModulatedDeformConv2dPack.forward: offset/mask conv (f32 out) -> deformable im2col -> GEMM."""
     C = _channels(x)
-    w_off = _cache_of(dcn.conv_offset).get(('w', x.dtype), (dcn.conv_offset.weight,),
-                                           lambda: ops.pack_weight(dcn.conv_offset.weight, x.dtype, cout_pad=32))
-    b_off = _cache_of(dcn.conv_offset).get(('b',), (dcn.conv_offset.bias,), lambda: _pad8(dcn.conv_offset.bias, 27))
-    om = ops.conv2d(x, w_off, 3, 3, 1, 1, shift=b_off, out_dtype=torch.float32)
+    from . import autograd as ag
+    om = conv_plain(x, dcn.conv_offset, out_dtype=torch.float32)  # 27 -> 32 padded channels
+    if ag.grad_mode(_tensor(x), dcn.weight, _tensor(om)):
+        g = ag._geom(x)
+        col = ag.DeformIm2colFn.apply(_tensor(x), _tensor(om), g)
+        return ag._wrap(ag.DcnGemmFn.apply(col, dcn.weight, dcn.bias, dcn, g), g)
     col = ops.deform_im2col3x3(x, om)
     w = _cache_of(dcn).get(('w', x.dtype), (dcn.weight,),
                            lambda: ops.pack_weight(dcn.weight, x.dtype).reshape(dcn.weight.shape[0], 1, 1, 9 * C))
@@ -143,7 +162,34 @@ def dcn_v2(x, dcn):
 
 
 def group_norm_relu(x, gn, relu=True):
+    from . import autograd as ag
+    if ag.grad_mode(_tensor(x), gn.weight):
+        g = ag._geom(x)
+        return ag._wrap(ag.GroupNormReLUFn.apply(_tensor(x), gn.weight, gn.bias, g, gn.num_groups, gn.eps, relu), g)
     return ops.groupnorm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=relu)
+
+
+def max_pool(x):
+    from . import autograd as ag
+    return ag.MaxPoolFn.apply(x) if ag.grad_mode(x) else ops.maxpool3x3s2(x)
+
+
+def upsample_bilinear(x, Ho, Wo):
+    from . import autograd as ag
+    return ag.BilinearUpFn.apply(x, Ho, Wo) if ag.grad_mode(x) else ops.upsample_bilinear_ac(x, Ho, Wo)
+
+
+def add_nearest(a, b):
+    from . import autograd as ag
+    return ag.AddNearestFn.apply(a, b) if ag.grad_mode(a, b) else ops.add_upsample_nearest(a, b)
+
+
+def add3(a, b, c=None):
+    from . import autograd as ag
+    ta, tb, tc = _tensor(a), _tensor(b), _tensor(c) if c is not None else None
+    if ag.grad_mode(ta, tb, tc):
+        return ag._wrap(ag.Add3Fn.apply(ta, tb, tc), ag._geom(a))
+    return ops.add3(a, b, c)
 
 
 # ------------------------------------------------------------------ parameter containers

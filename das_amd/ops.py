@@ -464,6 +464,66 @@ def head_finalize(pose, ref, desc, eval_mode):
     return pose, ref
 
 
+def deform_im2col3x3_backward(x, om, dcol):
+    """Returns dx (rows, C) f32 and dom (rows, om channels) f32 (same containers as x / om)."""
+    _need_gpu(x, om, dcol)
+    xd, omd, dcd = _data(x), _data(om), _data(dcol)
+    Cc = xd.shape[-1]
+    dx = _empty_like_rows(x, Cc, torch.float32)
+    dom = _empty_like_rows(om, omd.shape[-1], torch.float32)
+    _data(dx).zero_()
+    _data(dom).zero_()
+    lv = _levels(x)
+    assert dcd.is_contiguous() and dcd.dtype == xd.dtype
+    _lib.check(_lib.load().das_deform_im2col3x3_backward(_ptr(xd), _ptr(omd), _ptr(dcd), _ptr(_data(dx)),
+                                                         _ptr(_data(dom)), _DT[xd.dtype], C.byref(lv), Cc, _ps(x),
+                                                         _ps(om), _ps(dom), _stream()), 'das_deform_im2col3x3_backward')
+    return dx, dom
+
+
+def offset_sample_backward(uvd, samp_off, conf, gout, J, heads=4):
+    _need_gpu(uvd, samp_off, conf, gout)
+    d_uvd = _empty_like_rows(uvd, 3 * J, torch.float32)
+    d_so = _empty_like_rows(uvd, 8 * J, torch.float32)
+    d_conf = _empty_like_rows(uvd, 3 * J, torch.float32)
+    for t in (d_uvd, d_so, d_conf):
+        _data(t).zero_()
+    lv = _levels(uvd)
+    _lib.check(_lib.load().das_offset_sample_backward(_ptr(_data(uvd)), _ptr(_data(samp_off)), _ptr(_data(conf)),
+                                                      _ptr(_data(gout)), _ptr(_data(d_uvd)), _ptr(_data(d_so)),
+                                                      _ptr(_data(d_conf)), C.byref(lv), J, heads, _ps(uvd),
+                                                      _ps(samp_off), _ps(conf), _ps(gout), _stream()),
+               'das_offset_sample_backward')
+    return d_uvd, d_so, d_conf
+
+
+def sigmoid_blend_backward(off, w, nxt, gout):
+    _need_gpu(off, w, nxt, gout)
+    od, gd = _data(off), _data(gout)
+    Cc = od.shape[-1]
+    assert gd.is_contiguous()
+    d_off, d_w, d_nxt = (torch.empty_like(gd) for _ in range(3))
+    npix = gd.numel() // Cc
+    _lib.check(_lib.load().das_sigmoid_blend_backward(_ptr(od), _ptr(_data(w)), _ptr(_data(nxt)), _ptr(gd), _ptr(d_off),
+                                                      _ptr(d_w), _ptr(d_nxt), npix, Cc, _ps(off), _ps(w), _ps(nxt),
+                                                      _stream()), 'das_sigmoid_blend_backward')
+    return d_off, d_w, d_nxt
+
+
+def head_assemble_backward(raw, d_pose, d_uvd, desc):
+    """Returns d_raw (same shape as raw, zero outside the off/depth/uvd/sigma slices) and d_scale (5,4)."""
+    _need_gpu(raw, d_pose, d_uvd)
+    rd = _data(raw)
+    d_raw = torch.zeros_like(rd)
+    assert rd.is_contiguous() and _data(d_pose).is_contiguous() and _data(d_uvd).is_contiguous()
+    d_scale = torch.empty(5, 4, dtype=torch.float32, device=rd.device)
+    lv = _levels(raw)
+    _lib.check(_lib.load().das_head_assemble_backward(_ptr(rd), _ptr(_data(d_pose)), _ptr(_data(d_uvd)), _ptr(d_raw),
+                                                      _ptr(d_scale), C.byref(lv), C.byref(desc), _stream()),
+               'das_head_assemble_backward')
+    return d_raw, d_scale
+
+
 def decode(cls_list, ctr_list, pose_list, strides, scale_factors, J, nms_pre, nms_post, score_thr, nms_thr):
     """Eval-mode head outputs per level, NHWC f32: cls/ctr (B,H,W,c>=1) logits in channel 0,
     pose (B,H,W,>=3+3J). scale_factors: (B,2) f32 device tensor. Returns dict of device tensors:

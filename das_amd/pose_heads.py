@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .nn import ConvModule, Scale, _cache_of, _pad8, as_nhwc, conv_plain, to_nchw_view
+from .nn import ConvModule, Scale, _cache_of, _pad8, add3, as_nhwc, conv_plain, to_nchw_view
 from .registry import HEADS, build_loss
 
 INF = 1e8
@@ -94,7 +94,18 @@ class NextLevelOffset(nn.Module):
     def forward(self, feat, offset):
         """feat (B,h,w,C) T; offset (B,h,w,3J) f32 -> feat', blended offset, samp_off view, conf view."""
         J = self.num_joints
-        feat = ops.add3(feat, self.update_feat_conv(feat))
+        feat = add3(feat, self.update_feat_conv(feat))
+        from . import autograd as ag
+        if ag.grad_mode(feat.data if isinstance(feat, ops.Ragged) else feat, self.sampling_offset.weight):
+            # training: four separate GEMMs so that autograd sees the four parameter sets
+            g = ag._geom(feat)
+            f32 = torch.float32
+            so = _cs(conv_plain(feat, self.sampling_offset, out_dtype=f32), 0, J * self.num_heads * 2)
+            conf = _cs(conv_plain(feat, self.sampling_conf, out_dtype=f32), 0, J * self.dim)
+            wgt = _cs(conv_plain(feat, self.update_weight, out_dtype=f32), 0, J * self.dim)
+            nxt = _cs(conv_plain(feat, self.update_offset_value, out_dtype=f32), 0, J * self.dim)
+            offset = ag._wrap(ag.SigmoidBlendFn.apply(ag._d(offset), ag._d(wgt), ag._d(nxt), g), g)
+            return feat, offset, so, conf
         w, b, offs = self._fused_heads(feat.dtype)
         out = ops.conv2d(feat, w, 1, 1, shift=b, out_dtype=torch.float32)
         so = _cs(out, offs[0], offs[0] + J * self.num_heads * 2)
@@ -114,6 +125,11 @@ class RecursiveUpdateLayer(nn.Module):
 
     def forward(self, feat, prev_offset):
         feat, off, so, conf = self.next_level_offset(feat, prev_offset)
+        from . import autograd as ag
+        if ag.grad_mode(ag._d(off), ag._d(so), ag._d(conf)):
+            g = ag._geom(off)
+            out = ag.OffsetSampleFn.apply(ag._d(off), ag._d(so), ag._d(conf), g, self.num_joints, self.num_heads)
+            return feat, ag._wrap(out, g)
         return feat, ops.offset_sample(off, so, conf, self.num_joints, self.num_heads)
 
 
@@ -287,11 +303,17 @@ class DASHead(nn.Module):
         cls_feat = self._run(self.cls_convs, x)
         reg_feat = self._run(self.reg_convs, x)
         pose_feat = self._run(self.pose_convs, x)
-        raw = x.new(L['total'], torch.float32)
+        from . import autograd as ag
+        train_graph = ag.grad_mode(x.data, self.conv_cls.weight)
+        raw = None if train_graph else x.new(L['total'], torch.float32)
+        parts = []
 
         def predict(feat, prevs, pred, c0):
             n = _p8(pred.weight.shape[0])
-            conv_plain(self._run(prevs, feat), pred, out_dtype=torch.float32, out=_cs(raw, c0, c0 + n))
+            if train_graph:  # slices are concatenated (in the raw_layout order) so autograd sees each predictor
+                parts.append(conv_plain(self._run(prevs, feat), pred, out_dtype=torch.float32).data)
+            else:
+                conv_plain(self._run(prevs, feat), pred, out_dtype=torch.float32, out=_cs(raw, c0, c0 + n))
         predict(cls_feat, self.conv_cls_prev, self.conv_cls, L['cls'])
         predict(reg_feat, self.conv_centerness_prev, self.conv_centerness, L['ctr'])
         predict(reg_feat, self.conv_reg_prevs[0], self.conv_regs[0], L['off'])
@@ -303,9 +325,20 @@ class DASHead(nn.Module):
         desc = ops.head_desc(J, self.root_idx, L['total'], L['off'], L['depth'], L['uvd'], L['sigma'],
                              [sc[l] for l in level_ids], [self.strides[l] for l in level_ids], self.z_norm,
                              self.depth_factor)
-        pose_pred, uvd0 = ops.head_assemble(raw, desc)
-        ref = self.recursive_update_branch(pose_feat, uvd0)
-        ops.head_finalize(pose_pred, ref, desc, eval_mode=not self.training)
+        if train_graph:
+            raw = x.like(torch.cat(parts, 1))
+            scales = torch.stack([torch.stack([s.scale for s in lv]) for lv in self.scales])
+            pose_d, uvd_d = ag.HeadAssembleFn.apply(raw.data, scales, ag._geom(raw), desc, tuple(level_ids))
+            pose_pred, uvd0 = x.like(pose_d), x.like(uvd_d)
+            ref = self.recursive_update_branch(pose_feat, uvd0)
+            zmask = torch.ones(3 * J, dtype=torch.float32, device=ref.device)
+            zmask[self.root_idx * 3 + 2] = 0
+            ref = ref.like(ref.data * zmask)  # ref_uvd[:, root z] = 0 (das_head.py:254)
+            assert self.training, 'gradients through the eval-mode rescale are not part of the DAS path'
+        else:
+            pose_pred, uvd0 = ops.head_assemble(raw, desc)
+            ref = self.recursive_update_branch(pose_feat, uvd0)
+            ops.head_finalize(pose_pred, ref, desc, eval_mode=not self.training)
         cls, ctr = _cs(raw, L['cls'], L['cls'] + 1), _cs(raw, L['ctr'], L['ctr'] + 1)
         if self.training:
             return cls, pose_pred, ctr, ref

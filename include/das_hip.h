@@ -193,6 +193,22 @@ int das_head_assemble(const float* raw, float* pose_pred, float* uvd_out, const 
 int das_head_finalize(float* pose_pred, float* ref_uvd, const DasLevels* lv, const DasHeadDesc* d, int ref_ps,
                       int eval_mode, void* stream);
 
+/* Gradients of the head ops above. Scatter-type gradients accumulate into caller-zeroed f32 buffers:
+ * dx (rows, C) dense f32, dom (rows, dom_pix_stride) f32 in the om channel order, d_uvd (rows,3J),
+ * d_samp_off (rows,8J), d_conf (rows,3J) dense f32. d_raw must be zero-filled by the caller; d_scale
+ * f32[5][4] is zeroed by the call. */
+int das_deform_im2col3x3_backward(const void* x, const float* om, const void* dcol, float* dx, float* dom, int dtype,
+                                  const DasLevels* lv, int C, int x_pix_stride, int om_pix_stride,
+                                  int dom_pix_stride, void* stream);
+int das_offset_sample_backward(const float* uvd, const float* samp_off, const float* conf, const float* grad_out,
+                               float* d_uvd, float* d_samp_off, float* d_conf, const DasLevels* lv, int J, int heads,
+                               int uvd_ps, int so_ps, int conf_ps, int gout_ps, void* stream);
+int das_sigmoid_blend_backward(const float* off, const float* w, const float* nxt, const float* grad_out, float* d_off,
+                               float* d_w, float* d_nxt, long long npix, int C, int off_ps, int w_ps, int nxt_ps,
+                               void* stream);
+int das_head_assemble_backward(const float* raw, const float* d_pose, const float* d_uvd, float* d_raw,
+                               float* d_scale, const DasLevels* lv, const DasHeadDesc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Decode (das_head.py:690-796 `_get_poses_single`, pose_nms.py:51-126 oks_iou / oks_nms), fused:
  * per image  score = sigmoid(cls)*sigmoid(ctr) -> keep score > score_thr -> per level keep the

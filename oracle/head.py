@@ -47,7 +47,10 @@ def offset_sample(uvd, samp_off, conf, J, heads, dim=3):
     # stage 1: the 4 head offsets seen from the current target location
     tgt = ((pts + off_uv) / norm).permute(0, 2, 3, 1)
     so = samp_off.reshape(B * J, heads * 2, h, w)
-    from_tgt = F.grid_sample(so.float(), 2 * tgt - 1, mode='bilinear', padding_mode='zeros', align_corners=False)
+    # the reference casts to float (recursive_update.py:25,56) to leave fp16; f64 stays f64 here so that
+    # the oracle can also serve as a high-precision gradient reference
+    up = (lambda t: t) if uvd.dtype == torch.float64 else (lambda t: t.float())
+    from_tgt = F.grid_sample(up(so), 2 * tgt - 1, mode='bilinear', padding_mode='zeros', align_corners=False)
     from_tgt = from_tgt.view(B * J, heads, 2, h, w) + off_uv[:, None]
     from_src = so.view(B * J, heads, 2, h, w)
     s = torch.cat([from_tgt, from_src], 1).reshape(B * J * 2 * heads, 2, h, w)
@@ -55,7 +58,7 @@ def offset_sample(uvd, samp_off, conf, J, heads, dim=3):
     # stage 2: sample [offset(dim), conf(dim)] at each of the 2*heads locations
     H2 = 2 * heads
     feat = torch.cat([u.repeat_interleave(H2, 0), conf.reshape(B * J, dim, h, w).repeat_interleave(H2, 0)], 1)
-    samp = F.grid_sample(feat.float(), 2 * loc - 1, mode='bilinear', padding_mode='zeros', align_corners=False)
+    samp = F.grid_sample(up(feat), 2 * loc - 1, mode='bilinear', padding_mode='zeros', align_corners=False)
     s_off, s_conf = samp[:, :dim], samp[:, dim:]
     diff = torch.cat([s, s.new_zeros(s.size(0), 1, h, w)], 1) if dim == 3 else s
     s_off = (s_off + diff).reshape(B * J, H2, dim, h, w)

@@ -1,0 +1,172 @@
+"""Training-path parity on the GPU: forward + backward of the das_amd modules (HIP kernels under
+torch.autograd) against the CPU oracle differentiated by torch autograd, same seeded weights/inputs.
+
+Yardstick. Gradients of these randomly initialised train-mode-BN / GroupNorm networks are
+ill-conditioned in f32: the oracle evaluated in f32 and in f64 already disagree by ~1e-2 on many
+parameters (single ReLU flips near zero move whole sub-graphs). So the HIP f32 path is compared with
+the oracle in **f64**, and has to be as close to it as the oracle's own f32 evaluation is (same
+median / 90th-percentile error band). The kernel-level backward tests (test_hip_backward*.py) pin
+each kernel to 1e-4..1e-5 individually.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def sd_of(z, seed):
+    shapes = [[int(i) for i in row if i >= 0] for row in z['sd_shapes']]
+    return cases.sd_from_manifest(z['sd_keys'], shapes, z['sd_dtypes'], seed)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def grad_sd(sd, dt=torch.float32):
+    out = {}
+    for k, v in sd.items():
+        if v.is_floating_point():
+            v = v.to(dt).clone()
+            if 'running' not in k and not k.endswith('.mask'):
+                v.requires_grad_(True)
+        else:
+            v = v.clone()
+        out[k] = v
+    return out
+
+
+def band_check(e_hip, e_o32, what):
+    """HIP-vs-f64 errors must sit in the same band as oracle-f32-vs-f64 errors."""
+    e_hip, e_o32 = np.sort(np.array(e_hip)), np.sort(np.array(e_o32))
+    med = lambda e: e[len(e) // 2]
+    p90 = lambda e: e[int(len(e) * 0.9)]
+    assert med(e_hip) < max(3 * med(e_o32), 2e-4), (what, 'median', med(e_hip), med(e_o32))
+    assert p90(e_hip) < max(3 * p90(e_o32), 1e-3), (what, 'p90', p90(e_hip), p90(e_o32))
+    assert e_hip[-1] < max(6 * e_o32[-1], 2e-2), (what, 'max', e_hip[-1], e_o32[-1])
+
+
+def param_errors(module, o64, o32, skip=()):
+    e_hip, e_o32 = [], []
+    for k, p in module.named_parameters():
+        if any(s in k for s in skip) or o64[k].grad is None:
+            continue
+        assert p.grad is not None, f'{k}: no gradient from the HIP path'
+        ref = o64[k].grad.numpy()
+        e_hip.append(rel(p.grad.double().cpu().numpy(), ref))
+        e_o32.append(rel(o32[k].grad.double().numpy(), ref))
+    return e_hip, e_o32
+
+
+def test_mspn2_train_backward_vs_oracle(golden_dir):
+    import das_amd
+    from oracle import backbone as ob
+    z = load(golden_dir, 'mspn_s2_train')
+    sd = sd_of(z, 1)
+    m = das_amd.MSPN2(unit_channels=16, num_stages=2, num_blocks=[1, 1, 1, 1], compute_dtype='f32')
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    x = cases.randn(7, 2, 3, 64, 96)
+    gs = [cases.randn(80 + i, 2, 16, 16 >> i, 24 >> i) for i in range(4)]
+    outs = m(x.to(DEV))
+    for i, o in enumerate(outs):  # forward still equals the reference fixture
+        assert rel(o.detach().float().cpu().numpy(), z[f'out{i}']) < 1e-4
+    sum((o.float() * g.to(DEV)).sum() for o, g in zip(outs, gs)).backward()
+    refs = {}
+    for dt in (torch.float64, torch.float32):
+        osd = grad_sd(sd, dt)
+        oo = ob.mspn2_forward(osd, x.to(dt), 2, (1, 1, 1, 1), train=True)
+        sum((o * g.to(dt)).sum() for o, g in zip(oo, gs)).backward()
+        refs[dt] = osd
+    e_hip, e_o32 = param_errors(m, refs[torch.float64], refs[torch.float32])
+    assert len(e_hip) > 100
+    band_check(e_hip, e_o32, 'mspn2 params')
+
+
+def test_fpn_backward_f32_vs_oracle():
+    import das_amd
+    from oracle import backbone as ob
+    f = das_amd.FPN([16] * 4, 24, 4, start_level=1, add_extra_convs='on_output', relu_before_extra_convs=True,
+                    norm_cfg=dict(type='BN'))
+    sd = {k: v.clone() for k, v in cases.det_fill(f.state_dict(), 2).items()}
+    f.to(DEV).train()
+    feats = [cases.randn(i, 2, 16, 32 >> i, 48 >> i) for i in range(4)]
+    gs = [cases.randn(90 + i, 2, 24, 16 >> i, 24 >> i) for i in range(4)]
+    fin = [t.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True) for t in feats]
+    outs = f([t.permute(0, 3, 1, 2) for t in fin])
+    sum((o.float() * g.to(DEV)).sum() for o, g in zip(outs, gs)).backward()
+    osd = grad_sd(sd)
+    fo = [t.clone().requires_grad_(True) for t in feats]
+    oo = ob.fpn_forward(osd, fo, train=True)
+    sum((o * g).sum() for o, g in zip(oo, gs)).backward()
+    for k, p in f.named_parameters():  # shallow and ReLU-free: well conditioned, tight tolerance
+        assert rel(p.grad.cpu().numpy(), osd[k].grad.numpy()) < 2e-3, k
+    for a, b in zip(fin[1:], fo[1:]):
+        assert rel(a.grad.permute(0, 3, 1, 2).cpu().numpy(), b.grad.numpy()) < 2e-3
+    assert fin[0].grad is None  # start_level=1: the stride-4 map is unused
+
+
+def build_head():
+    import das_amd
+    c = cases.HEAD_CFG
+    J, C = c['num_joints'], c['feat_channels']
+    return das_amd.DASHead(
+        num_classes=1, in_channels=C, feat_channels=C, stacked_convs=2, strides=c['strides'],
+        regress_ranges=c['regress_ranges'], num_joints=J, depth_factor=c['depth_factor'], z_norm=c['z_norm'],
+        root_idx=c['root_idx'], cls_branch=(C,), reg_branch=((C,),) * 4, centerness_branch=(64,),
+        centerness_on_reg=True, conv_bias=True, dcn_on_last_conv=True,
+        recursive_update=dict(prev_loss=True, num_heads=c['num_heads'], in_channels=C, feat_channels=C,
+                              num_layers=c['num_layers'], dim=3, num_joints=J),
+        train_cfg=dict(code_weight=c['code_weight']), test_cfg=cases.TEST_CFG, compute_dtype=torch.float32)
+
+
+def test_dashead_forward_graph_backward_vs_oracle(golden_dir):
+    """All head kernels' backward (towers, DCNv2, GN, predictors, Scale, recursive update) under a fixed
+    linear functional of the four train-mode outputs."""
+    from oracle import head as oh
+    z = load(golden_dir, 'head_train')
+    sd = sd_of(z, 3)
+    head = build_head()
+    head.load_state_dict(sd)
+    head.to(DEV).train()
+    feats = cases.head_feats()
+    fin = [t.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True) for t in feats]
+    outs = head([t.permute(0, 3, 1, 2) for t in fin])
+    names = ('cls', 'pose', 'ctr', 'ref')
+    gs = {}
+    tot = 0
+    for ni, (name, lst) in enumerate(zip(names, outs)):
+        for i, t in enumerate(lst):
+            assert rel(t.detach().float().cpu().numpy(), z[f'{name}{i}']) < 2e-4, (name, i)
+            gs[(name, i)] = cases.randn(300 + 10 * ni + i, *t.shape)
+            tot = tot + (t.float() * gs[(name, i)].to(DEV)).sum()
+    tot.backward()
+
+    refs, fgr = {}, {}
+    for dt in (torch.float64, torch.float32):
+        osd = grad_sd(sd, dt)
+        fo = [t.to(dt).clone().requires_grad_(True) for t in feats]
+        oo = oh.head_forward(osd, fo, cases.HEAD_CFG, '', True)
+        tot = 0
+        for name, lst in zip(names, oo):
+            for i, t in enumerate(lst):
+                tot = tot + (t * gs[(name, i)].to(dt)).sum()
+        tot.backward()
+        refs[dt], fgr[dt] = osd, fo
+    e_hip, e_o32 = param_errors(head, refs[torch.float64], refs[torch.float32], skip=('flow',))
+    assert len(e_hip) > 80
+    for a, b64, b32 in zip(fin, fgr[torch.float64], fgr[torch.float32]):
+        e_hip.append(rel(a.grad.permute(0, 3, 1, 2).double().cpu().numpy(), b64.grad.numpy()))
+        e_o32.append(rel(b32.grad.double().numpy(), b64.grad.numpy()))
+    band_check(e_hip, e_o32, 'head params + feats')
