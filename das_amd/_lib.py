@@ -36,6 +36,11 @@ class DasHeadDesc(C.Structure):
                 ('depth_factor', f32)]
 
 
+class DasTargetDesc(C.Structure):
+    _fields_ = [('J', i32), ('background', i32), ('stride', i32 * 5), ('range_lo', f32 * 5), ('range_hi', f32 * 5),
+                ('radius', f32), ('alpha', f32)]
+
+
 class DasDecodeDesc(C.Structure):
     _fields_ = [('B', i32), ('J', i32), ('num_levels', i32),
                 ('H', i32 * DAS_MAX_LEVELS), ('W', i32 * DAS_MAX_LEVELS), ('stride', i32 * DAS_MAX_LEVELS),
@@ -75,6 +80,12 @@ SIGNATURES = {
                                          i32, vp]),
     'das_sigmoid_blend_backward': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     'das_head_assemble_backward': (i32, [vp, vp, vp, vp, vp, C.POINTER(DasLevels), C.POINTER(DasHeadDesc), vp]),
+    'das_assign_targets': (i32, [C.POINTER(DasLevels), C.POINTER(DasTargetDesc), vp, vp, vp, vp, vp, vp]),
+    'das_sigmoid_focal_loss': (i32, [vp, i32, vp, i64, f32, f32, vp, vp, vp]),
+    'das_smooth_l1_loss': (i32, [vp, vp, i64, f32, vp, vp, vp]),
+    'das_bce_logits_loss': (i32, [vp, vp, i64, vp, vp, vp]),
+    'das_grad_sumsq': (i32, [vp, i64, vp, i32, vp]),
+    'das_sgd_momentum_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]),
     'das_decode_cap': (i32, [C.POINTER(DasDecodeDesc)]),
     'das_decode_ws_bytes': (i64, [i32, i32, i32]),
     'das_decode': (i32, [C.POINTER(DasDecodeDesc), vp, vp, vp, vp, vp, vp, vp]),

@@ -40,6 +40,7 @@ class ConvBNTrainFn(Function):
         y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,
                                              residual=residual, relu=relu)
         bn.num_batches_tracked += 1
+        bn.__dict__.pop('_das_cache', None)  # running stats changed under the cache's feet (raw-pointer update)
         ctx.save_for_backward(x, raw, y, mean, invstd, gamma, weight)
         ctx.cfg = (k, s, p, relu, residual is not None, conv)
         return y

@@ -1,0 +1,222 @@
+// Dense-head training kernels: point-to-person target assignment, sigmoid focal loss, SmoothL1 / BCE on
+// the positives, and the optimizer side (global grad norm, fused SGD-momentum with clipping).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+inline int grid_for(long long n, int cap = 4096) {
+  long long b = (n + TPB - 1) / TPB;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < TPB / 64; ++i) t += sh[i];
+  __syncthreads();
+  return t;  // valid on thread 0
+}
+
+// ------------------------------------------------------------------ target assignment
+// das_head.py:551-651 `_get_target_single` for every location of every level and image in one launch.
+// One thread per row (level-major, image, h, w). gt: rows [cx, cy, depth, J x (u,v,dz), J x vis].
+__global__ void assign_targets_kernel(DasLevels lv, DasTargetDesc d, const float* __restrict__ gt,
+                                      const int* __restrict__ gt_start, int* __restrict__ labels,
+                                      float* __restrict__ targets, float* __restrict__ ctr_t, long long rows) {
+#pragma clang fp contract(off)
+  const int J = d.J, D = 3 + 4 * J;
+  for (long long m = (long long)blockIdx.x * TPB + threadIdx.x; m < rows; m += (long long)gridDim.x * TPB) {
+    const LvGeom g = lv_geom(lv, m);
+    const int s = d.stride[g.l];
+    const float px = (float)(g.w * s + s / 2), py = (float)(g.h * s + s / 2);
+    const float rad = (float)s * d.radius;
+    const float lo = d.range_lo[g.l], hi = d.range_hi[g.l];
+    float best = 1e8f;
+    int best_i = -1;
+    for (int i = gt_start[g.b]; i < gt_start[g.b + 1]; ++i) {
+      const float* p = gt + (long long)i * D;
+      const float cx = p[0], cy = p[1];
+      float reach = 0.f;  // max over joints of |joint - centre| * vis
+      for (int j = 0; j < J; ++j) {
+        const float du = p[3 + 3 * j] - cx, dv = p[4 + 3 * j] - cy;
+        reach = fmaxf(reach, sqrtf(du * du + dv * dv) * p[3 + 3 * J + j]);
+      }
+      const float l = px - (cx - rad), r = (cx + rad) - px, t = py - (cy - rad), b = (cy + rad) - py;
+      const bool inside = fminf(fminf(l, t), fminf(r, b)) > 0.f;
+      const bool in_range = reach >= lo && reach <= hi;
+      const float dx = px - cx, dy = py - cy;
+      float dist = sqrtf(dx * dx + dy * dy);
+      if (!(inside && in_range)) dist = 1e8f;
+      if (best_i < 0 || dist < best) { best = dist; best_i = i; }
+    }
+    float* o = targets + m * D;
+    if (best_i < 0) {  // no GT in this image
+      labels[m] = d.background;
+      for (int k = 0; k < D; ++k) o[k] = 0.f;
+      ctr_t[m] = 0.f;
+      continue;
+    }
+    const float* p = gt + (long long)best_i * D;
+    labels[m] = best == 1e8f ? d.background : 0;
+    const float dx = px - p[0], dy = py - p[1];
+    o[0] = dx / (float)s;  // root offsets are stored stride-normalised (das_head.py:547)
+    o[1] = dy / (float)s;
+    o[2] = p[2];
+    for (int j = 0; j < J; ++j) {
+      o[3 + 3 * j] = p[3 + 3 * j] - p[0];
+      o[4 + 3 * j] = p[4 + 3 * j] - p[1];
+      o[5 + 3 * j] = p[5 + 3 * j];
+      o[3 + 3 * J + j] = p[3 + 3 * J + j];
+    }
+    ctr_t[m] = expf(-d.alpha * (sqrtf(dx * dx + dy * dy) / (1.414f * rad)));
+  }
+}
+
+// ------------------------------------------------------------------ sigmoid focal loss (num_classes = 1)
+// loss_i = BCE(x_i, t_i) * (alpha t + (1-alpha)(1-t)) * pt^gamma, t = (label == 0); writes dloss/dx per
+// row and accumulates the sum.
+__global__ void focal_kernel(const float* __restrict__ logit, int ps, const int* __restrict__ labels, long long rows,
+                             float gamma, float alpha, float* __restrict__ grad, float* __restrict__ sum) {
+  __shared__ float sh[TPB / 64];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < rows; i += (long long)gridDim.x * TPB) {
+    const float x = logit[i * ps];
+    const float t = labels[i] == 0 ? 1.f : 0.f;
+    const float p = 1.f / (1.f + expf(-x));
+    const float pt = (1.f - p) * t + p * (1.f - t);
+    const float aw = alpha * t + (1.f - alpha) * (1.f - t);
+    const float fw = aw * powf(pt, gamma);
+    const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    acc += bce * fw;
+    const float dpt = p * (1.f - p) * (1.f - 2.f * t);
+    const float dfw = aw * gamma * powf(pt, gamma - 1.f) * dpt;
+    grad[i] = dfw * bce + fw * (p - t);
+  }
+  const float tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(sum, tot);
+}
+
+// SmoothL1 (beta) and BCE-with-logits over n elements; per-element gradient + sum
+__global__ void smooth_l1_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, long long n, float beta,
+                                 float* __restrict__ grad, float* __restrict__ sum) {
+  __shared__ float sh[TPB / 64];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    const float e = pred[i] - tgt[i], a = fabsf(e);
+    acc += a < beta ? 0.5f * a * a / beta : a - 0.5f * beta;
+    grad[i] = a < beta ? e / beta : (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+  }
+  const float tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(sum, tot);
+}
+__global__ void bce_logits_kernel(const float* __restrict__ x, const float* __restrict__ t, long long n,
+                                  float* __restrict__ grad, float* __restrict__ sum) {
+  __shared__ float sh[TPB / 64];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    const float v = x[i], tt = t[i];
+    acc += fmaxf(v, 0.f) - v * tt + log1pf(expf(-fabsf(v)));
+    grad[i] = 1.f / (1.f + expf(-v)) - tt;
+  }
+  const float tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(sum, tot);
+}
+
+// ------------------------------------------------------------------ optimizer
+__global__ void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+  __shared__ float sh[TPB / 64];
+  float acc = 0.f;
+  const long long nv = n / 4;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < nv; i += (long long)gridDim.x * TPB) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[nv * 4 + threadIdx.x]; acc += v * v; }
+  const float tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(out, tot);
+}
+
+// torch.optim.SGD (momentum, no dampening/nesterov) with the clip coefficient folded in:
+//   g' = g * min(1, max_norm / (sqrt(sumsq) + 1e-6)) * grad_scale ; d = g' + wd*p ; buf = mom*buf + d ; p -= lr*buf
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n,
+                           float lr, float momentum, float wd, float grad_scale, float max_norm,
+                           const float* __restrict__ sumsq, int first_step) {
+  float coef = grad_scale;
+  if (max_norm > 0.f && sumsq) {
+    const float norm = sqrtf(*sumsq) * grad_scale;
+    coef *= fminf(1.f, max_norm / (norm + 1e-6f));
+  }
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    const float d = g[i] * coef + wd * p[i];
+    const float b = first_step ? d : momentum * buf[i] + d;
+    buf[i] = b;
+    p[i] -= lr * b;
+  }
+}
+}  // namespace
+
+extern "C" int das_assign_targets(const DasLevels* lv, const DasTargetDesc* d, const float* gt, const int* gt_start,
+                                  int* labels, float* targets, float* centerness, void* stream) {
+  if (!lv_valid(lv) || !d || !gt_start || !labels || !targets || !centerness || d->J < 1) return DAS_ERR_ARG;
+  const long long rows = lv_total_rows(*lv);
+  hipLaunchKernelGGL(assign_targets_kernel, dim3(grid_for(rows)), dim3(TPB), 0, (hipStream_t)stream, *lv, *d, gt,
+                     gt_start, labels, targets, centerness, rows);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_sigmoid_focal_loss(const float* logits, int pix_stride, const int* labels, long long rows,
+                                      float gamma, float alpha, float* grad, float* loss_sum, void* stream) {
+  if (!logits || !labels || !grad || !loss_sum || rows <= 0) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return DAS_ERR_LAUNCH;
+  hipLaunchKernelGGL(focal_kernel, dim3(grid_for(rows, 1024)), dim3(TPB), 0, s, logits, pix_stride, labels, rows, gamma,
+                     alpha, grad, loss_sum);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_smooth_l1_loss(const float* pred, const float* target, long long n, float beta, float* grad,
+                                  float* loss_sum, void* stream) {
+  if (!pred || !target || !grad || !loss_sum || n <= 0 || beta <= 0.f) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return DAS_ERR_LAUNCH;
+  hipLaunchKernelGGL(smooth_l1_kernel, dim3(grid_for(n, 256)), dim3(TPB), 0, s, pred, target, n, beta, grad, loss_sum);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_bce_logits_loss(const float* logits, const float* target, long long n, float* grad, float* loss_sum,
+                                   void* stream) {
+  if (!logits || !target || !grad || !loss_sum || n <= 0) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return DAS_ERR_LAUNCH;
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(grid_for(n, 256)), dim3(TPB), 0, s, logits, target, n, grad, loss_sum);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_grad_sumsq(const float* g, long long n, float* out, int zero_first, void* stream) {
+  if (!g || !out || n <= 0) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (zero_first && hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return DAS_ERR_LAUNCH;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 2048)), dim3(TPB), 0, s, g, n, out);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_sgd_momentum_step(float* p, const float* g, float* buf, long long n, float lr, float momentum,
+                                     float weight_decay, float grad_scale, float max_norm, const float* grad_sumsq,
+                                     int first_step, void* stream) {
+  if (!p || !g || !buf || n <= 0) return DAS_ERR_ARG;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 8192)), dim3(TPB), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum,
+                     weight_decay, grad_scale, max_norm, grad_sumsq, first_step);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}

@@ -34,8 +34,17 @@ def to_nchw_view(x):
 
 
 # ------------------------------------------------------------------ parameter packing cache
+# The fused optimizer updates parameters through raw pointers (no autograd version bump), so it
+# advances this counter instead; it is part of every cache key.
+PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    PARAM_EPOCH[0] += 1
+
+
 def _versions(*ts):
-    return tuple((t.data_ptr(), t._version) for t in ts if t is not None)
+    return (PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in ts if t is not None)
 
 
 class _Cache:
@@ -124,6 +133,7 @@ def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False):
     y, mean, invstd = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
                                          residual=residual, relu=relu)
     bn.num_batches_tracked += 1
+    bn.__dict__.pop('_das_cache', None)  # running stats were updated through raw pointers
     return y
 
 

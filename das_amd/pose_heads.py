@@ -407,9 +407,14 @@ class DASHead(nn.Module):
     # ------------------------------------------------------------------ train
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_poses_3d=None, gt_labels_3d=None,
                       centers2d=None, depths=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
-        outs = self(x)
-        return self.loss(*outs, gt_bboxes, gt_labels, gt_poses_3d, gt_labels_3d, centers2d, depths, img_metas,
-                         gt_bboxes_ignore=gt_bboxes_ignore)
+        # same as `self.loss(*self(x), ...)` (base_mono3d_dense_pose_head.py:21-38) but the outputs stay in
+        # the ragged all-levels layout, which is already the loss's flatten-and-concat order
+        from .losses import das_head_loss_rows
+        assert len(x) == len(self.strides)
+        dtype = self.compute_dtype or x[0].dtype
+        rows = ops.Ragged.from_levels([as_nhwc(f, dtype) for f in x])
+        cls, pose, ctr, ref = self.forward_rows(rows, list(range(len(x))))
+        return das_head_loss_rows(self, cls, pose, ctr, ref, gt_poses_3d)
 
     def loss(self, cls_scores, pose_preds, centernesses, aux_pose_preds, gt_bboxes, gt_labels, gt_poses_3d,
              gt_labels_3d, centers2d, depths, img_metas, gt_bboxes_ignore=None):

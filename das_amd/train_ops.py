@@ -1,0 +1,99 @@
+"""ctypes wrappers of the loss / target / optimizer entry points (train_loss.hip)."""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .ops import Ragged, _levels, _need_gpu, _ptr, _stream
+
+
+def assign_targets(geom_like, strides, regress_ranges, gt_rows, gt_start, J, radius=1.5, alpha=2.5, background=1):
+    """geom_like: a Ragged giving (B, level sizes). gt_rows (sum G, 3+4J) f32, gt_start (B+1,) int32, both on
+    the GPU. Returns labels int32 (rows,), targets f32 (rows, 3+4J), centerness f32 (rows,)."""
+    _need_gpu(gt_rows, gt_start)
+    lv = _levels(geom_like)
+    d = _lib.DasTargetDesc(J=J, background=background, radius=radius, alpha=alpha)
+    for l, (s, r) in enumerate(zip(strides, regress_ranges)):
+        d.stride[l], d.range_lo[l], d.range_hi[l] = int(s), float(r[0]), float(r[1])
+    rows, dev = geom_like.rows, geom_like.device
+    labels = torch.empty(rows, dtype=torch.int32, device=dev)
+    targets = torch.empty(rows, 3 + 4 * J, dtype=torch.float32, device=dev)
+    ctr = torch.empty(rows, dtype=torch.float32, device=dev)
+    assert gt_rows.dtype == torch.float32 and gt_start.dtype == torch.int32 and gt_start.numel() == geom_like.B + 1
+    assert gt_rows.numel() == 0 or (gt_rows.is_contiguous() and gt_rows.shape[1] == 3 + 4 * J)
+    _lib.check(_lib.load().das_assign_targets(C.byref(lv), C.byref(d), _ptr(gt_rows), _ptr(gt_start), _ptr(labels),
+                                              _ptr(targets), _ptr(ctr), _stream()), 'das_assign_targets')
+    return labels, targets, ctr
+
+
+class FocalLossSumFn(Function):
+    """sum_i focal(logit_i, label_i); logits (rows, 1) view with any row stride."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, gamma, alpha):
+        _need_gpu(logits, labels)
+        rows = logits.shape[0]
+        grad = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        assert logits.dtype == torch.float32 and labels.dtype == torch.int32
+        _lib.check(_lib.load().das_sigmoid_focal_loss(_ptr(logits), logits.stride(0), _ptr(labels), rows, gamma, alpha,
+                                                      _ptr(grad), _ptr(out), _stream()), 'das_sigmoid_focal_loss')
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g).unsqueeze(1), None, None, None
+
+
+class SmoothL1SumFn(Function):
+    @staticmethod
+    def forward(ctx, pred, target, beta):
+        pred, target = pred.contiguous(), target.contiguous()
+        grad = torch.empty_like(pred)
+        out = torch.empty(1, dtype=torch.float32, device=pred.device)
+        _lib.check(_lib.load().das_smooth_l1_loss(_ptr(pred), _ptr(target), pred.numel(), beta, _ptr(grad), _ptr(out),
+                                                  _stream()), 'das_smooth_l1_loss')
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+class BCELogitsSumFn(Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits, target = logits.contiguous(), target.contiguous()
+        grad = torch.empty_like(logits)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        _lib.check(_lib.load().das_bce_logits_loss(_ptr(logits), _ptr(target), logits.numel(), _ptr(grad), _ptr(out),
+                                                   _stream()), 'das_bce_logits_loss')
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def grad_sumsq(flat_grad, out=None, zero_first=True):
+    _need_gpu(flat_grad)
+    out = out if out is not None else torch.empty(1, dtype=torch.float32, device=flat_grad.device)
+    _lib.check(_lib.load().das_grad_sumsq(_ptr(flat_grad), flat_grad.numel(), _ptr(out), int(zero_first), _stream()),
+               'das_grad_sumsq')
+    return out
+
+
+def sgd_momentum_step(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0, max_norm=0.0, grad_sumsq_t=None,
+                      first_step=False):
+    _need_gpu(p, g, buf)
+    assert p.dtype == g.dtype == buf.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous()
+    _lib.check(_lib.load().das_sgd_momentum_step(_ptr(p), _ptr(g), _ptr(buf), p.numel(), lr, momentum, weight_decay,
+                                                 grad_scale, max_norm, _ptr(grad_sumsq_t), int(first_step), _stream()),
+               'das_sgd_momentum_step')

@@ -210,6 +210,42 @@ int das_head_assemble_backward(const float* raw, const float* d_pose, const floa
                                float* d_scale, const DasLevels* lv, const DasHeadDesc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Dense-head losses and the optimizer side of the train step.
+ *
+ * das_assign_targets: DASHead._get_target_single (das_head.py:551-651) + the stride normalisation of
+ * get_targets (:547) for every row (level-major, image, h, w) in one launch. gt: f32 rows
+ * [cx, cy, depth, J x (u,v,dz), J x vis] of all images back to back, gt_start int32[B+1] = first row of
+ * each image. Outputs: labels int32 (0 = person, `background` otherwise), targets f32 (rows, 3+4J) =
+ * [dx/stride, dy/stride, depth, J x (du,dv,dz), J x vis] of the chosen person, centerness f32.
+ */
+typedef struct {
+  int J, background;
+  int stride[5];
+  float range_lo[5], range_hi[5];
+  float radius, alpha;
+} DasTargetDesc;
+int das_assign_targets(const DasLevels* lv, const DasTargetDesc* d, const float* gt, const int* gt_start, int* labels,
+                       float* targets, float* centerness, void* stream);
+/* mmdet FocalLoss(use_sigmoid) / mmcv sigmoid_focal_loss for one class (das_head.py:341-344): per-row
+ * gradient + sum of the per-row loss (loss_sum zeroed by the call). logits: row i at logits[i*pix_stride]. */
+int das_sigmoid_focal_loss(const float* logits, int pix_stride, const int* labels, long long rows, float gamma,
+                           float alpha, float* grad, float* loss_sum, void* stream);
+/* mmdet SmoothL1Loss (das_head.py:375-379) and CrossEntropyLoss(use_sigmoid) (:470): elementwise gradient
+ * and loss sum over n dense f32 elements (loss_sum zeroed by the call). */
+int das_smooth_l1_loss(const float* pred, const float* target, long long n, float beta, float* grad, float* loss_sum,
+                       void* stream);
+int das_bce_logits_loss(const float* logits, const float* target, long long n, float* grad, float* loss_sum,
+                        void* stream);
+/* out (+)= sum g^2 over a flat f32 gradient buffer (global-norm clipping, exp_panoptic.py:204-205). */
+int das_grad_sumsq(const float* g, long long n, float* out, int zero_first, void* stream);
+/* torch.optim.SGD step (momentum, weight decay) on flat f32 buffers with the clip coefficient
+ * min(1, max_norm/(sqrt(*grad_sumsq)*grad_scale + 1e-6)) and grad_scale folded in; max_norm <= 0 disables
+ * clipping. first_step != 0 initialises the momentum buffer with the gradient (as torch does). */
+int das_sgd_momentum_step(float* p, const float* g, float* buf, long long n, float lr, float momentum,
+                          float weight_decay, float grad_scale, float max_norm, const float* grad_sumsq,
+                          int first_step, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Decode (das_head.py:690-796 `_get_poses_single`, pose_nms.py:51-126 oks_iou / oks_nms), fused:
  * per image  score = sigmoid(cls)*sigmoid(ctr) -> keep score > score_thr -> per level keep the
  * nms_pre best when the level has more than nms_pre locations -> center = (point - offset)/scale,
