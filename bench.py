@@ -1,13 +1,16 @@
 """bench.py — DAS hot-path throughput on MI355X.
 
-Default workload = BASELINE.json configs[1]: MSPN-50 1-stage + FPN + DASHead (J=15, exp_panoptic
-topology), bf16, batch 8 x 3 x 512 x 832 synthetic frames per GPU, forward + decode, inputs
-resident in HBM. One "step" = one pass of the hot path over one batch. N>1: one process per
-GPU (torchrun), independent batches per rank (weak scaling, no data-path collective).
+Workloads (BASELINE.json `configs`):
+  --workload train (default)  configs[2]/[3]: MSPN-50 4-stage + FPN + DASHead (J=15), bf16 activations with
+                              f32 master weights, batch 16 x 3x512x832 synthetic frames + GT per GPU, one FULL
+                              train step = forward + 4 losses + backward + gradient all-reduce (N>1) + clip + SGD.
+  --workload infer            configs[1]: MSPN-50 1-stage, batch 8, forward + decode.
+Inputs are resident in HBM when the timed region starts. N>1: one process per GPU (torchrun), independent
+per-rank batches (weak scaling); training exchanges gradients with RCCL all-reduce, inference has no collective.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     — dominant kernel family (bf16 implicit-GEMM conv), algorithmic FLOPs / HIP-event time
-  cpu_baseline — the CPU oracle (oracle/, "port") timed on this host on a bounded sample
+  roofline     — dominant kernel family, algorithmic FLOPs / HIP-event time measured on the launch stream
+  cpu_baseline — the CPU oracle (oracle/, "port") timed on this host on a bounded sample (N=1 only)
 """
 import argparse
 import json
@@ -24,7 +27,10 @@ if ROOT not in sys.path:
 
 H, W, J = 512, 832, 15
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
-FWD_GFLOP_PER_IMG = 227.0   # 1-stage J=15, conv MACs x2
+PEAK_F32_TFLOPS = 157.3
+# conv MACs x 2 per image at 512x832, J=15
+FWD_GFLOP = {1: 227.0, 2: 326.9, 3: 426.8, 4: 526.7}
+TRAIN_GFLOP = {k: 3 * v for k, v in FWD_GFLOP.items()}
 
 
 def model_cfg(num_stages=1, dtype='bf16'):
@@ -45,10 +51,10 @@ def model_cfg(num_stages=1, dtype='bf16'):
         test_cfg=dict(nms_across_levels=False, nms_pre=1000, nms_post=100, nms_thr=0.9, score_thr=0.07))
 
 
-def build_model(dev, seed=0, dtype='bf16'):
+def build_model(dev, seed=0, dtype='bf16', num_stages=1, train=False):
     import das_amd
     torch.manual_seed(seed)
-    model = das_amd.build_model(model_cfg(1, dtype))
+    model = das_amd.build_model(model_cfg(num_stages, dtype))
     model.init_weights()
     # random-init heads predict ~zero offsets; give the sampling / regression convs some spread so that
     # the deformable and resampling kernels see non-trivial coordinates, as a trained net would
@@ -56,7 +62,7 @@ def build_model(dev, seed=0, dtype='bf16'):
         for n, p in model.bbox_head.named_parameters():
             if 'conv_offset.weight' in n or 'sampling_offset.weight' in n or 'conv_poses.0.weight' in n:
                 p.normal_(0, 0.02)
-    return model.to(dev).eval()
+    return model.to(dev).train(train)
 
 
 def calibrate_scores(model, img, metas, target=150):
@@ -73,30 +79,47 @@ def calibrate_scores(model, img, metas, target=150):
         model.bbox_head.conv_cls.bias.add_(0.5 * (lo + hi))
 
 
-def cpu_baseline(budget_s=20.0):
-    """CPU oracle (port of the reference algorithm) forward + decode at 512x832, all host cores."""
-    from oracle import backbone as ob, decode as od, head as oh
+def cpu_baseline(workload, budget_s=20.0):
+    """CPU oracle (port of the reference algorithm) at 512x832 on a bounded sample.
+    infer: 1-stage forward + decode of one image; train: 4-stage forward + losses + backward of one image."""
+    from oracle import backbone as ob, decode as od, head as oh, loss as ol
     import das_amd
+    from das_amd.datasets import SyntheticPoseDataset
     torch.manual_seed(0)
     # 256 logical CPUs are visible on the GPU box but the job's share is far smaller: 256 torch
     # threads ran 100x slower than 8 (oversubscription). Use a fixed, stated thread count.
     cores = min(8, len(os.sched_getaffinity(0)))
     torch.set_num_threads(cores)
-    model = das_amd.build_model(model_cfg(1, 'f32'))
+    stages = 4 if workload == 'train' else 1
+    model = das_amd.build_model(model_cfg(stages, 'f32'))
     model.init_weights()
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     sd['bbox_head.conv_cls.bias'] += 3.0
+    if workload == 'train':
+        sd = {k: (v.requires_grad_(True) if v.is_floating_point() and 'running' not in k and not k.endswith('.mask')
+                  else v) for k, v in sd.items()}
     bsd = {k[9:]: v for k, v in sd.items() if k.startswith('backbone.')}
     nsd = {k[5:]: v for k, v in sd.items() if k.startswith('neck.')}
     hsd = {k[10:]: v for k, v in sd.items() if k.startswith('bbox_head.')}
     hcfg = dict(num_joints=J, root_idx=2, depth_factor=20, z_norm=50, strides=[8, 16, 32, 64], stacked_convs=2,
-                num_heads=4, num_layers=1)
+                num_heads=4, num_layers=1, regress_ranges=((-1, 80), (80, 160), (160, 320), (320, 1e8)),
+                code_weight=[1.0, 1.0, 1] + [2] * J * 6, prev_loss=True)
     tcfg = model_cfg()['test_cfg']
-    B = 1
-    img = torch.randn(B, 3, H, W)
-    metas = [dict(scale_factor=np.ones(4, dtype=np.float32), filename='')] * B
+    s = SyntheticPoseDataset(num_joints=J, img_shape=(H, W), length=4, seed=0)[0]
+    img = s['img'][None]
+    metas = [dict(scale_factor=np.ones(4, dtype=np.float32), filename='')]
+    gts = dict(gt_labels_3d=[s['gt_labels_3d']], gt_poses_3d=[s['gt_poses_3d']], centers2d=[s['centers2d']],
+               depths=[s['depths']])
 
     def step():
+        if workload == 'train':
+            for v in sd.values():
+                if v.is_floating_point() and v.grad is not None:
+                    v.grad = None
+            feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img, stages, (3, 4, 6, 3), train=True), train=True)
+            outs = oh.head_forward(hsd, feats, hcfg, '', True)
+            sum(ol.head_loss(hsd, '', *outs, gts, hcfg).values()).backward()
+            return None
         with torch.no_grad():
             feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img, 1, (3, 4, 6, 3)))
             c, p, k = oh.head_forward(hsd, feats, hcfg, '', False)
@@ -113,20 +136,54 @@ def cpu_baseline(budget_s=20.0):
     dt = time.perf_counter() - t0
     if n == 0:
         n, dt = 1, warm
-    return dict(value=round(n * B / dt, 4), unit='img/s', cores=cores, kind='port',
-                sample=f'{n} x (1 x 3 x {H} x {W}) forward+decode, CPU oracle fp32, torch {torch.__version__} '
+    what = ('4-stage forward + 4 losses + backward (no optimizer step)' if workload == 'train'
+            else '1-stage forward + decode')
+    return dict(value=round(n / dt, 4), unit='img/s', cores=cores, kind='port',
+                sample=f'{n} x (1 x 3 x {H} x {W}) {what}, CPU oracle fp32, torch {torch.__version__} '
                        f'{cores} threads, 1 warm-up')
+
+
+def roofline_from_profile(ops, run_step, dtype, reps=2):
+    """HIP events around every conv-family launch (forward, data-grad, weight-grad), on the launch stream."""
+    ops.PROFILE = []
+    for _ in range(reps):
+        run_step()
+    torch.cuda.synchronize()
+    fam = {}
+    for tag, flops, e0, e1, _shape in ops.PROFILE:
+        f = fam.setdefault(tag, [0.0, 0.0, 0])
+        f[0] += flops
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 1
+    ops.PROFILE = None
+    if not fam:
+        return None
+    peak = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
+    tag, (fl, sec, cnt) = max(fam.items(), key=lambda kv: kv[1][1])
+    ach = fl / sec / 1e12
+    return dict(bound='mfma', kernel=tag, achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+                traffic=None, launches_per_step=cnt // reps, avg_launch_us=round(sec / cnt * 1e6, 2),
+                family_ms_per_step=round(sec / reps * 1e3, 3),
+                all_families={k: dict(tflops=round(v[0] / v[1] / 1e12, 2), ms_per_step=round(v[1] / reps * 1e3, 3),
+                                      launches=v[2] // reps) for k, v in fam.items()})
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--workload', default='train', choices=['train', 'infer'])
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (train 16, infer 8)')
+    ap.add_argument('--stages', type=int, default=None, help='MSPN stages (train 4, infer 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     args = ap.parse_args()
+    train = args.workload == 'train'
+    batch = args.batch or (16 if train else 8)
+    stages = args.stages or (4 if train else 1)
+    steps = args.steps or (10 if train else 20)
+    warmup = args.warmup if args.warmup is not None else (3 if train else 5)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -140,14 +197,27 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from das_amd import ops
-    model = build_model(dev, seed=0, dtype=args.dtype)
-    g = torch.Generator(device='cpu').manual_seed(rank)
-    img = torch.randn(args.batch, 3, H, W, generator=g).to(dev)
-    metas = [dict(scale_factor=np.ones(4, dtype=np.float32), filename='')] * args.batch
-    calibrate_scores(model, img, metas)
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    model = build_model(dev, seed=0, dtype=args.dtype, num_stages=stages, train=train)
+    ds = SyntheticPoseDataset(num_joints=J, img_shape=(H, W), length=batch * world, seed=0)
+    data = collate([ds[rank * batch + i] for i in range(batch)], device=dev)
+    metas = data['img_metas']
+    extra = {}
+    if train:
+        from das_amd.optim import FlatSGD, step_lr, train_iteration
+        opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0,
+                      max_grad_norm=35.0)
+        it = [0]
 
-    def step():
-        return model(img, metas, return_loss=False, rescale=True)
+        def step():
+            out = train_iteration(model, opt, data, step_lr(2e-3, 0, it[0]))
+            it[0] += 1
+            return out
+    else:
+        calibrate_scores(model, data['img'], metas)
+
+        def step():
+            return model(data['img'], metas, return_loss=False, rescale=True)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -155,11 +225,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         res = step()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         res = step()
     sync_all()
     dt = time.perf_counter() - t0
@@ -167,47 +237,34 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    poses = sum(len(r['scores']) for r in res)
+    if train:
+        extra['last_losses'] = {k: round(float(v), 4) for k, v in res['log_vars'].items()}
+        extra['peak_mem_gb'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+    else:
+        extra['poses_per_step_rank0'] = sum(len(r['scores']) for r in res)
 
-    # ---- roofline of the dominant kernel family: HIP events around every conv launch, on the launch stream
-    ops.PROFILE = []
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    fam = {}
-    for tag, flops, e0, e1, _shape in ops.PROFILE:
-        f = fam.setdefault(tag, [0.0, 0.0, 0])
-        f[0] += flops
-        f[1] += e0.elapsed_time(e1) * 1e-3
-        f[2] += 1
-    ops.PROFILE = None
-    roof = None
-    if fam:
-        tag, (fl, sec, cnt) = max(fam.items(), key=lambda kv: kv[1][1])
-        ach = fl / sec / 1e12
-        roof = dict(bound='mfma', kernel=tag, achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS if args.dtype == 'bf16' else 157.3,
-                    unit='TFLOP/s', frac=round(ach / (PEAK_BF16_TFLOPS if args.dtype == 'bf16' else 157.3), 4),
-                    traffic=None, launches_per_step=cnt // 3, avg_launch_us=round(sec / cnt * 1e6, 2),
-                    family_ms_per_step=round(sec / 3 * 1e3, 3),
-                    all_families={k: dict(tflops=round(v[0] / v[1] / 1e12, 2), ms_per_step=round(v[1] / 3 * 1e3, 3),
-                                          launches=v[2] // 3) for k, v in fam.items()})
+    roof = roofline_from_profile(ops, step, args.dtype)
 
     if rank == 0:
-        total_imgs = args.batch * world * args.steps
+        total_imgs = batch * world * steps
+        gflop = (TRAIN_GFLOP if train else FWD_GFLOP)[stages]
+        wl = (f'BASELINE configs[2]/[3]: MSPN-50 {stages}-stage + FPN(4 lvls) + DASHead J=15, batch {batch} x 3x{H}x{W} '
+              f'per GPU, full train step (forward, 4 losses, backward, all-reduce, clip, SGD)' if train else
+              f'BASELINE configs[1]: MSPN-50 {stages}-stage + FPN(4 lvls) + DASHead J=15, batch {batch} x 3x{H}x{W} '
+              f'per GPU, forward + decode (inference)')
         out = {
-            'metric': 'imgs/sec', 'value': round(total_imgs / dt, 3), 'unit': 'img/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: MSPN-50 1-stage + FPN(4 lvls) + DASHead J=15, '
-                                   f'batch {args.batch} x 3x{H}x{W} per GPU, forward + decode (inference)',
-                       'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'parallelism': f'dp{world}',
-                       'algorithmic_gflop_per_img': FWD_GFLOP_PER_IMG},
-            'poses_per_step_rank0': poses,
-            'model_tflops': round(total_imgs * FWD_GFLOP_PER_IMG / dt / 1e3, 2),
+            'metric': 'imgs/sec train' if train else 'imgs/sec forward+decode', 'value': round(total_imgs / dt, 3),
+            'unit': 'img/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': wl, 'per_gpu_batch': batch, 'global_batch': batch * world,
+                       'parallelism': f'dp{world}', 'mspn_stages': stages, 'algorithmic_gflop_per_img': gflop},
+            'model_tflops': round(total_imgs * gflop / dt / 1e3, 2),
             'roofline': roof,
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -14,16 +14,18 @@ inline int grid_for(long long n, int cap = 16384) {
 // ------------------------------------------------------------------ DCNv2 col2im
 // One thread = one (pixel, tap, channel vector): dx += mask*w_corner*dcol (f32 atomics),
 // d_om[dy,dx,mask logit] += sum over the vector's channels.
+// One WAVE = one (pixel, tap); lane = channel (64 at a time). The four corner scatters of a wave are
+// 256-byte contiguous f32 atomic bursts (two cache lines each) instead of 32-byte-strided ones, and the
+// offset / mask gradients are a wave reduction written once, without atomics.
 template <typename T>
 __global__ void deform_col2im_kernel(const T* __restrict__ x, const float* __restrict__ om, const T* __restrict__ dcol,
                                      float* __restrict__ dx, float* __restrict__ dom, DasLevels lv, int C, int xps,
-                                     int omps, int domps, long long total) {
+                                     int omps, int domps, long long npairs) {
 #pragma clang fp contract(off)
-  constexpr int EPV = Elem<T>::EPV;
-  const int VC = C / EPV;
-  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    const int v = (int)(i % VC);
-    long long r = i / VC;
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * TPB + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * TPB) >> 6;
+  for (long long r = wave0; r < npairs; r += nwaves) {
     const int k = (int)(r % 9);
     const long long m = r / 9;
     const LvGeom g = lv_geom(lv, m);
@@ -33,9 +35,8 @@ __global__ void deform_col2im_kernel(const T* __restrict__ x, const float* __res
     const float mask = 1.f / (1.f + expf(-o[18 + k]));
     const float py = (float)(g.h - 1 + k / 3) + ody;
     const float px = (float)(g.w - 1 + k % 3) + odx;
-    if (!(py > -1.f && px > -1.f && py < (float)H && px < (float)W)) continue;
-    float gc[EPV];
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(dcol + (m * 9 + k) * C + v * EPV), gc);
+    float* d = dom + m * domps;
+    if (!(py > -1.f && px > -1.f && py < (float)H && px < (float)W)) continue;  // wave-uniform
     const float fy = floorf(py), fx = floorf(px);
     const int y0 = (int)fy, x0 = (int)fx;
     const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
@@ -43,27 +44,31 @@ __global__ void deform_col2im_kernel(const T* __restrict__ x, const float* __res
     const float wy[4] = {-hx, -lx, hx, lx};   // d(weight)/d(py)
     const float wx[4] = {-hy, hy, -ly, ly};   // d(weight)/d(px)
     float val = 0.f, gpy = 0.f, gpx = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int ch = c0 + lane;
+      if (ch >= C) break;
+      const float gc = Elem<T>::load(dcol + (m * 9 + k) * C + ch);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
-      if (yy < 0 || yy > H - 1 || xx < 0 || xx > W - 1) continue;
-      const long long pix = g.plane0 + (long long)yy * W + xx;
-      float f[EPV];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + pix * xps + v * EPV), f);
-      float dot = 0.f;
-#pragma unroll
-      for (int j = 0; j < EPV; ++j) {
-        dot += gc[j] * f[j];
-        atomicAdd(dx + pix * C + v * EPV + j, gc[j] * mask * wts[c]);
+      for (int c = 0; c < 4; ++c) {
+        const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
+        if (yy < 0 || yy > H - 1 || xx < 0 || xx > W - 1) continue;  // wave-uniform
+        const long long pix = g.plane0 + (long long)yy * W + xx;
+        const float f = Elem<T>::load(x + pix * xps + ch);
+        const float dot = gc * f;
+        atomicAdd(dx + pix * C + ch, gc * mask * wts[c]);
+        val += wts[c] * dot;
+        gpy += wy[c] * dot;
+        gpx += wx[c] * dot;
       }
-      val += wts[c] * dot;
-      gpy += wy[c] * dot;
-      gpx += wx[c] * dot;
     }
-    float* d = dom + m * domps;
-    atomicAdd(d + 2 * k, gpy * mask);
-    atomicAdd(d + 2 * k + 1, gpx * mask);
-    atomicAdd(d + 18 + k, val * mask * (1.f - mask));
+    val = wave_sum(val);
+    gpy = wave_sum(gpy);
+    gpx = wave_sum(gpx);
+    if (lane == 0) {
+      d[2 * k] = gpy * mask;
+      d[2 * k + 1] = gpx * mask;
+      d[18 + k] = val * mask * (1.f - mask);
+    }
   }
 }
 
@@ -286,17 +291,16 @@ extern "C" int das_deform_im2col3x3_backward(const void* x, const float* om, con
   if (!x || !om || !dcol || !dx || !dom || !lv_valid(lv) || C % 8 || x_pix_stride % 8 || om_pix_stride < 27 ||
       dom_pix_stride < 27)
     return DAS_ERR_ARG;
-  const long long npix = lv_total_rows(*lv);
+  const long long npairs = lv_total_rows(*lv) * 9;  // one wave per (pixel, tap)
+  const int blocks = grid_for(npairs * 64, 32768);
   if (dtype == DAS_BF16) {
-    const long long total = npix * 9 * (C / 8);
-    hipLaunchKernelGGL(deform_col2im_kernel<bf16_t>, dim3(grid_for(total, 65536)), dim3(TPB), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(deform_col2im_kernel<bf16_t>, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream,
                        (const bf16_t*)x, om, (const bf16_t*)dcol, dx, dom, *lv, C, x_pix_stride, om_pix_stride,
-                       dom_pix_stride, total);
+                       dom_pix_stride, npairs);
   } else if (dtype == DAS_F32) {
-    const long long total = npix * 9 * (C / 4);
-    hipLaunchKernelGGL(deform_col2im_kernel<float>, dim3(grid_for(total, 65536)), dim3(TPB), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(deform_col2im_kernel<float>, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream,
                        (const float*)x, om, (const float*)dcol, dx, dom, *lv, C, x_pix_stride, om_pix_stride,
-                       dom_pix_stride, total);
+                       dom_pix_stride, npairs);
   } else {
     return DAS_ERR_ARG;
   }

@@ -159,8 +159,16 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad):
         for l, (h, w_) in enumerate(x.sizes):
             d.lvl_H[l], d.lvl_W[l] = h, w_
     assert dyd.dtype == xd.dtype
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.load().das_conv2d_wgrad_nhwc(_ptr(xd), _ptr(dyd), _ptr(dw), C.byref(d), _stream()),
                'das_conv2d_wgrad_nhwc')
+    if PROFILE is not None:
+        e1.record()
+        rows = x.rows if ragged else B * Ho * Wo
+        tag = f'conv_wgrad_kernel<{"bf16" if xd.dtype == torch.bfloat16 else "float"}>'
+        PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1, (B, H, W, Cin, Cout, KH, stride, 0)))
     return dw
 
 

@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Training entry point with the reference's command line (tools/train.py:25-91):
+  python tools/train.py CONFIG [--work-dir D] [--resume-from CKPT] [--no-validate] [--gpus N | --gpu-ids ...]
+                        [--seed S] [--deterministic] [--cfg-options k=v ...]
+                        [--launcher {none,pytorch,slurm,mpi}] [--local_rank N] [--autoscale-lr]
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N tools/train.py CFG --launcher pytorch`),
+gradients all-reduced over RCCL. Data comes from cfg.data.train (SyntheticPoseDataset in this repo)."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import das_amd  # noqa: E402
+from das_amd.config import parse_cfg_options  # noqa: E402
+from das_amd.datasets import build_dataset, collate  # noqa: E402
+from das_amd.optim import build_optimizer, step_lr, train_iteration  # noqa: E402
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description='DAS (MI355X) train a detector')
+    p.add_argument('config')
+    p.add_argument('--work-dir')
+    p.add_argument('--resume-from')
+    p.add_argument('--no-validate', action='store_true')
+    g = p.add_mutually_exclusive_group()
+    g.add_argument('--gpus', type=int)
+    g.add_argument('--gpu-ids', type=int, nargs='+')
+    p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--deterministic', action='store_true')
+    p.add_argument('--cfg-options', nargs='+')
+    p.add_argument('--launcher', choices=['none', 'pytorch', 'slurm', 'mpi'], default='none')
+    p.add_argument('--local_rank', type=int, default=0)
+    p.add_argument('--autoscale-lr', action='store_true')
+    p.add_argument('--max-iters', type=int, default=None, help='stop after this many iterations (smoke runs)')
+    return p.parse_args()
+
+
+def main():
+    args = parse_args()
+    cfg = das_amd.Config.fromfile(args.config)
+    if args.cfg_options:
+        cfg.merge_from_dict(parse_cfg_options(args.cfg_options))
+    work_dir = args.work_dir or cfg.get('work_dir') or os.path.join('./work_dirs', os.path.splitext(
+        os.path.basename(args.config))[0])
+    distributed = args.launcher != 'none'
+    local_rank = int(os.environ.get('LOCAL_RANK', args.local_rank))
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group(cfg.get('dist_params', {}).get('backend', 'nccl'))
+    rank = torch.distributed.get_rank() if distributed else 0
+    world = torch.distributed.get_world_size() if distributed else 1
+    torch.manual_seed(args.seed)  # set_random_seed (tools/train.py:172-177)
+    if rank == 0:
+        os.makedirs(work_dir, exist_ok=True)
+
+    pretrained = cfg.model.get('pretrained')
+    if pretrained and not os.path.isfile(pretrained):
+        if rank == 0:
+            print(f'pretrained weights {pretrained} not found: training from random init')
+        cfg.model.pretrained = None
+    model = das_amd.build_model(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    model.init_weights()
+    model.cuda().train()
+    dataset = build_dataset(cfg.data.train)
+    model.CLASSES = dataset.CLASSES
+
+    if args.autoscale_lr:
+        cfg.optimizer['lr'] = cfg.optimizer['lr'] * world / 8
+    opt = build_optimizer(model, cfg)
+    start_epoch = 0
+    if args.resume_from:
+        ck = torch.load(args.resume_from, map_location='cpu')
+        model.load_state_dict(ck['state_dict'])
+        start_epoch = ck.get('meta', {}).get('epoch', 0)
+
+    spg = cfg.data.get('samples_per_gpu', 4)
+    lrc = cfg.get('lr_config', {})
+    max_epochs = cfg.get('runner', {}).get('max_epochs', 12)
+    log_every = cfg.get('log_config', {}).get('interval', 50)
+    it = 0
+    for epoch in range(start_epoch, max_epochs):
+        order = torch.randperm(len(dataset), generator=torch.Generator().manual_seed(args.seed + epoch)).tolist()
+        order = order[rank::world]
+        t0 = time.time()
+        for b in range(0, len(order) - spg + 1, spg):
+            data = collate([dataset[i] for i in order[b:b + spg]], device='cuda')
+            lr = step_lr(opt.base_lr, epoch, it, steps=lrc.get('step', (16, 20)), warmup_iters=lrc.get('warmup_iters', 0),
+                         warmup_ratio=lrc.get('warmup_ratio', 1.0))
+            out = train_iteration(model, opt, data, lr)
+            it += 1
+            if rank == 0 and it % log_every == 0:
+                lv = ', '.join(f'{k}: {v:.4f}' for k, v in out['log_vars'].items())
+                print(f'Epoch [{epoch + 1}][{b // spg + 1}/{len(order) // spg}] lr: {lr:.3e}, '
+                      f'{(time.time() - t0) / (b // spg + 1):.3f} s/it, {lv}', flush=True)
+            if args.max_iters and it >= args.max_iters:
+                break
+        if rank == 0:  # CheckpointHook(interval=1): state_dict + meta (tools/train.py:200-210)
+            torch.save(dict(state_dict=model.state_dict(),
+                            meta=dict(epoch=epoch + 1, iter=it, config=cfg.text, CLASSES=model.CLASSES,
+                                      das_amd_version=das_amd.__version__)),
+                       os.path.join(work_dir, f'epoch_{epoch + 1}.pth'))
+        if args.max_iters and it >= args.max_iters:
+            break
+    if distributed:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
