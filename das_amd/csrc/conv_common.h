@@ -64,31 +64,37 @@ __device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4
   c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
 }
 
-template <int BN>
+// BMT = pixel rows per workgroup tile: 128 (4 waves) or 256 (8 waves, BN = 128 only: the weight tile is
+// then shared by twice as many pixel rows, which is what relieves the L2 -> LDS path on the big layers).
+template <int BN, int BMT = 128>
 struct Tiling {
+  static constexpr int NT = BMT * 2;               // threads per workgroup
   static constexpr int TM = (BN == 128) ? 4 : 2;   // 16-row pixel tiles per wave
   static constexpr int TN = (BN >= 64) ? 4 : 2;    // 16-row channel tiles per wave
-  static __device__ __forceinline__ int wave_m0(int wave) { return (BN == 128) ? (wave & 1) * 64 : wave * 32; }
-  static __device__ __forceinline__ int wave_n0(int wave) { return (BN == 128) ? (wave >> 1) * 64 : 0; }
+  static __device__ __forceinline__ int wave_m0(int wave) {
+    return BMT == 256 ? (wave & 3) * 64 : ((BN == 128) ? (wave & 1) * 64 : wave * 32);
+  }
+  static __device__ __forceinline__ int wave_n0(int wave) {
+    return BMT == 256 ? (wave >> 2) * 64 : ((BN == 128) ? (wave >> 1) * 64 : 0);
+  }
 };
 
-template <typename OT, int BN>
+template <typename OT, int BN, int BMT = 128>
 constexpr size_t epilogue_smem_bytes() {
-  size_t ctile = (size_t)BM * (BN * sizeof(OT) + 16);
-  size_t red = 2 * (size_t)(256 / (BN * sizeof(OT) / 16)) * BN * 4;
+  size_t ctile = (size_t)BMT * (BN * sizeof(OT) + 16);
+  size_t red = 2 * (size_t)(2 * BMT / (BN * sizeof(OT) / 16)) * BN * 4;
   return ctile > red ? ctile : red;
 }
 
 // acc[a][b][j]: channel n0 + wave_n0 + a*16 + (lane>>4)*4 + j, pixel m0 + wave_m0 + b*16 + (lane&15).
 // Must be entered after a barrier that ends all LDS reads of the main loop.
-template <typename OT, int BN>
-__device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[Tiling<BN>::TN][Tiling<BN>::TM], const ConvP& p,
-                                              char* smem, int m0, int n0) {
-  constexpr int TM = Tiling<BN>::TM, TN = Tiling<BN>::TN;
+template <typename OT, int BN, int BMT = 128, typename Acc>
+__device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* smem, int m0, int n0) {
+  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN, NT = Tiling<BN, BMT>::NT;
   constexpr int EPVO = 16 / (int)sizeof(OT);
   constexpr int CS = BN * (int)sizeof(OT) + 16;  // padded C-tile row stride in bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_m0 = Tiling<BN>::wave_m0(wave), wave_n0 = Tiling<BN>::wave_n0(wave);
+  const int wave_m0 = Tiling<BN, BMT>::wave_m0(wave), wave_n0 = Tiling<BN, BMT>::wave_n0(wave);
   const int ch4 = (lane >> 4) * 4;
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
@@ -116,7 +122,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[Tiling<BN>::TN][Til
   __syncthreads();
 
   constexpr int VR = BN * (int)sizeof(OT) / 16;  // 16-B vectors per C row
-  constexpr int RP = 256 / VR;                   // rows per pass
+  constexpr int RP = NT / VR;                    // rows per pass
   const int vec = tid % VR, r0 = tid / VR;
   const int n = n0 + vec * EPVO;
   float ssum[EPVO], ssq[EPVO];
@@ -126,7 +132,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[Tiling<BN>::TN][Til
   const OT* rg = reinterpret_cast<const OT*>(p.res);
   if (n < p.Cout) {
 #pragma unroll 2
-    for (int ml = r0; ml < BM; ml += RP) {
+    for (int ml = r0; ml < BMT; ml += RP) {
       const int m = m0 + ml;
       if (m >= p.M) break;
       const uint4 raw = *reinterpret_cast<const uint4*>(smem + ml * CS + vec * 16);

@@ -147,14 +147,25 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, typename OT, int BN>
-__global__ __launch_bounds__(256) void conv_glds_kernel(ConvP p) {
+// Same DMA issued from inline asm: hipcc does not track it, so it inserts no `s_waitcnt vmcnt(0)` in front
+// of the next ds_read (it does for the builtin: an LDS-DMA is a pending LDS write to its alias analysis).
+// The caller owns the vmcnt accounting. M0 = LDS destination of lane 0; restored afterwards.
+__device__ __forceinline__ void dma16_asm(const void* src, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(lds_byte_addr)
+               : "memory");
+}
+
+template <typename T, typename OT, int BN, int BMT>
+__global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
   constexpr int EPV = Elem<T>::EPV;
   constexpr int BK = 8 * EPV;  // 128 bytes of K per row
-  constexpr int TM = Tiling<BN>::TM, TN = Tiling<BN>::TN;
-  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
+  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN;
+  constexpr int A_BYTES = BMT * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
   constexpr int A_INSTR = 4;        // 1 KiB (8 rows) per wave-instruction, 16 KiB pixel tile / 4 waves
-  constexpr int W_INSTR = BN / 32;  // weight tile chunks per wave
+  constexpr int W_INSTR = (BN / 8) / (BMT / 32);  // weight tile chunks per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -162,8 +173,8 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
   const int n0 = (logical % p.ntiles) * BN;
-  const int m0 = (logical / p.ntiles) * BM;
-  const int wave_m0 = Tiling<BN>::wave_m0(wave), wave_n0 = Tiling<BN>::wave_n0(wave);
+  const int m0 = (logical / p.ntiles) * BMT;
+  const int wave_m0 = Tiling<BN, BMT>::wave_m0(wave), wave_n0 = Tiling<BN, BMT>::wave_n0(wave);
 
   // ---- DMA coordinates: chunk c covers LDS rows c*8..c*8+7; lane -> (row, physical slot)
   const int lrow = lane >> 3, pslot = lane & 7;
@@ -255,7 +266,114 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvP p) {
     }
     __syncthreads();  // prefetch landed (vmcnt 0) and every wave is done reading `buf`
   }
-  conv_epilogue<OT, BN>(acc, p, smem, m0, n0);
+  conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
+}
+
+// =============================================================== 3-stage pipeline, 256 x 128 tile, 8 waves
+// One workgroup per CU (144 KiB of LDS): occupancy cannot hide DMA latency any more, so the loads run two
+// K-steps ahead of the MFMAs: per step  s_waitcnt vmcnt(one tile's DMAs still in flight) -> s_barrier ->
+// issue tile k+2 into the buffer freed by step k-1 -> MFMAs on tile k. Counted vmcnt + raw s_barrier
+// (a __syncthreads() would drain the DMA queue, cdna guide section 5).
+template <typename T, typename OT>
+__global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
+  constexpr int BN = 128, BMT = 256, NBUF = 3;
+  constexpr int EPV = Elem<T>::EPV;
+  constexpr int BK = 8 * EPV;
+  constexpr int TM = 4, TN = 4;
+  constexpr int A_BYTES = BMT * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
+  constexpr int A_INSTR = 4, W_INSTR = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int logical = xcd_remap(blockIdx.x, p.nblocks);
+  const int n0 = (logical % p.ntiles) * BN;
+  const int m0 = (logical / p.ntiles) * BMT;
+  const int wave_m0 = (wave & 3) * 64, wave_n0 = (wave >> 2) * 64;
+
+  const int lrow = lane >> 3, pslot = lane & 7;
+  const T* xg = reinterpret_cast<const T*>(p.x);
+  const T* wg = reinterpret_cast<const T*>(p.w);
+  const T* zero = reinterpret_cast<const T*>(g_das_zero_page);
+  RowGeom rg[A_INSTR];
+  const T* abase[A_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int row = (wave * A_INSTR + j) * 8 + lrow;
+    rg[j] = row_geom(p, m0 + row);
+    const int akg = (pslot ^ ((row >> 1) & 7)) * EPV;
+    abase[j] = xg + (rg[j].pix0 + (long long)rg[j].hi0 * rg[j].W + rg[j].wi0) * p.xps + akg;
+  }
+  const T* wrow[W_INSTR];
+#pragma unroll
+  for (int j = 0; j < W_INSTR; ++j) {
+    const int row = (wave * W_INSTR + j) * 8 + lrow;
+    const int n = n0 + row;
+    wrow[j] = (n < p.Cout) ? wg + (long long)n * p.K + (pslot ^ ((row >> 1) & 7)) * EPV : nullptr;
+  }
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  int f_kh = 0, f_kw = 0, f_ci = 0;
+  auto issue = [&](int kt, int buf) {
+    const unsigned sA = lds0 + buf * BUF, sW = sA + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      const int th = rg[j].hi0 + f_kh, tw = rg[j].wi0 + f_kw;
+      const bool ok = (unsigned)th < (unsigned)rg[j].H && (unsigned)tw < (unsigned)rg[j].W;
+      const T* cand = abase[j] + (long long)(f_kh * rg[j].W + f_kw) * p.xps + f_ci;
+      dma16_asm(ok ? cand : zero, sA + (wave * A_INSTR + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) {
+      const T* cand = wrow[j] + (long long)kt * BK;
+      dma16_asm(wrow[j] ? cand : zero, sW + (wave * W_INSTR + j) * 1024);
+    }
+    f_ci += BK;
+    if (f_ci >= p.Cin) {
+      f_ci = 0;
+      if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+    }
+  };
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  const int frow = lane & 15, fkg = lane >> 4;
+  int buf = 0, nbuf = 2;  // buffer of tile kt, buffer tile kt+2 goes to
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile kt landed; tile kt+1 (6 DMAs per wave) may fly
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(kt + 2, nbuf);
+    const char* sA = smem + buf * BUF;
+    const char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint4 fb[TM], fa[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fb[i] = *reinterpret_cast<const uint4*>(sA + slot128(wave_m0 + i * 16 + frow, t * 4 + fkg));
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fa[i] = *reinterpret_cast<const uint4*>(sW + slot128(wave_n0 + i * 16 + frow, t * 4 + fkg));
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) mma<T>(fa[a], fb[b], acc[a][b]);
+    }
+    buf = buf == NBUF - 1 ? 0 : buf + 1;
+    nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
+  }
+  __syncthreads();  // all LDS reads done before the C tile reuses the buffers
+  conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
 }
 
 // =============================================================== launch
@@ -263,20 +381,27 @@ template <typename T, typename OT, int BN>
 int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   ConvP p = p0;
   p.ntiles = (p.Cout + BN - 1) / BN;
-  const int mtiles = (p.M + BM - 1) / BM;
+  // 256-row tiles (8 waves, weight tile shared by twice the pixels) once they still fill the chip twice over
+  const bool big = glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((p.M + 255) / 256) * p.ntiles >= 384;
+  const int bm = big ? 256 : BM;
+  const int mtiles = (p.M + bm - 1) / bm;
   p.nblocks = p.ntiles * mtiles;
-  const size_t epi = epilogue_smem_bytes<OT, BN>();
-  const size_t sm_reg = std::max<size_t>(2 * (size_t)(BM + BN) * 64, epi);
-  const size_t sm_glds = std::max<size_t>(2 * (size_t)(BM + BN) * 128, epi);
+  const size_t sm_reg = std::max<size_t>(2 * (size_t)(BM + BN) * 64, epilogue_smem_bytes<OT, BN>());
+  const size_t sm_glds = std::max<size_t>(2 * (size_t)(BM + BN) * 128, epilogue_smem_bytes<OT, BN>());
+  constexpr int BIG = (BN == 128) ? 256 : 128;  // only instantiated for BN = 128
+  const size_t sm_big = std::max<size_t>(3 * (size_t)(BIG + BN) * 128, epilogue_smem_bytes<OT, BN, BIG>());
   static bool attr_set = false;  // one flag per instantiation; > 64 KiB dynamic LDS needs the opt-in
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
     (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
-    (void)hipFuncSetAttribute((const void*)conv_glds_kernel<T, OT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_glds);
+    (void)hipFuncSetAttribute((const void*)conv_glds_kernel<T, OT, BN, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_glds);
+    if (BN == 128) (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
     attr_set = true;
   }
-  if (glds) {
-    hipLaunchKernelGGL((conv_glds_kernel<T, OT, BN>), dim3(p.nblocks), dim3(256), sm_glds, s, p);
+  if (big) {
+    hipLaunchKernelGGL((conv_glds3_kernel<T, OT>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+  } else if (glds) {
+    hipLaunchKernelGGL((conv_glds_kernel<T, OT, BN, 128>), dim3(p.nblocks), dim3(256), sm_glds, s, p);
   } else if (aligned) {
     hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, true>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
   } else {
