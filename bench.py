@@ -111,6 +111,19 @@ def cpu_baseline(workload, budget_s=20.0):
     gts = dict(gt_labels_3d=[s['gt_labels_3d']], gt_poses_3d=[s['gt_poses_3d']], centers2d=[s['centers2d']],
                depths=[s['depths']])
 
+    if workload != 'train':  # same candidate load as the GPU run: ~150 locations above score_thr per image
+        with torch.no_grad():
+            feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img, 1, (3, 4, 6, 3)))
+            c, p, k = oh.head_forward(hsd, feats, hcfg, '', False)
+            cc = torch.cat([t.reshape(1, -1) for t in c], 1)
+            kk = torch.cat([t.reshape(1, -1) for t in k], 1)
+            lo, hi = -20.0, 20.0
+            for _ in range(40):
+                mid = 0.5 * (lo + hi)
+                n = ((torch.sigmoid(cc + mid) * torch.sigmoid(kk)) > 0.07).float().sum().item()
+                lo, hi = (mid, hi) if n < 150 else (lo, mid)
+            hsd['conv_cls.bias'] += 0.5 * (lo + hi)
+
     def step():
         if workload == 'train':
             for v in sd.values():

@@ -42,12 +42,56 @@ struct WG<float> {
   static __device__ __forceinline__ int swz(int slot, int row) { return slot; }
 };
 
+// Walks an output-pixel row index forward without divisions (the pixel-row reduction advances every lane's
+// row by a constant each step); falls back to a full decode only when a ragged level boundary is crossed.
+struct RowWalk {
+  int b, h, w;   // image, output row, output column inside the current level
+  RowGeom g;     // input-space geometry of the current row
+  int Ho, Wo;    // output plane size of the current level
+  long long m;
+};
+__device__ __forceinline__ void walk_refresh(const ConvP& p, RowWalk& r) {
+  r.g = row_geom(p, (int)min(r.m, (long long)p.M));
+  if (r.m >= p.M) return;
+  if (p.nlev <= 1) {
+    const int mm = (int)r.m;
+    r.b = mm / p.HoWo;
+    const int rem = mm - r.b * p.HoWo;
+    r.h = rem / p.Wo; r.w = rem - r.h * p.Wo; r.Ho = p.Ho; r.Wo = p.Wo;
+  } else {
+    r.Ho = r.g.H; r.Wo = r.g.W;
+    r.h = r.g.hi0 + p.pad; r.w = r.g.wi0 + p.pad;
+    int l = 0;
+    for (int i = 1; i < MAXLV; ++i)
+      if (i < p.nlev && r.m >= p.lvStart[i]) l = i;
+    r.b = (int)((r.m - p.lvStart[l]) / (r.Ho * r.Wo));
+  }
+}
+__device__ __forceinline__ void walk_advance(const ConvP& p, RowWalk& r, int n) {
+  r.m += n;
+  if (r.m >= p.M) { r.g.hi0 = -(1 << 28); return; }
+  r.w += n;
+  while (r.w >= r.Wo) { r.w -= r.Wo; ++r.h; }
+  bool crossed = false;
+  while (r.h >= r.Ho) { r.h -= r.Ho; ++r.b; crossed = true; }
+  if (crossed && (p.nlev > 1 && r.b >= p.B)) { walk_refresh(p, r); return; }   // next ragged level
+  if (crossed) r.g.pix0 = (p.nlev <= 1) ? (long long)r.b * p.H * p.W : r.g.pix0;  // (ragged: fixed below)
+  if (p.nlev <= 1) {
+    r.g.hi0 = r.h * p.stride - p.pad;
+    r.g.wi0 = r.w * p.stride - p.pad;
+  } else {
+    if (crossed) { walk_refresh(p, r); return; }  // new image inside a level: recompute the plane origin
+    r.g.hi0 = r.h - p.pad;
+    r.g.wi0 = r.w - p.pad;
+  }
+}
+
 // p.x = forward input X, p.res = dY (pixel stride p.rps), p.y = dW f32 [Cout][K] (pre-zeroed).
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_block) {
   constexpr int EPV = Elem<T>::EPV;
   constexpr int ROWB = WG<T>::ROWB, SLOTS = ROWB / 16;
-  constexpr int BKM = 32;                      // pixel rows per step
+  constexpr int BKM = (sizeof(T) == 2) ? 64 : 32;  // pixel rows per step
   constexpr int TILE = BKM * ROWB;             // bytes per operand tile
   constexpr int RPI = 1024 / ROWB;             // rows per wave-instruction
   constexpr int IPW = BKM / RPI / 4;           // DMA instructions per wave per tile
@@ -64,14 +108,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_
   const T* dyg = reinterpret_cast<const T*>(p.res);
   const T* zero = reinterpret_cast<const T*>(g_das_zero_page_train);
 
-  // per (lane, instruction) constants: tile row, dY channel, X column -> (tap, ci)
-  int rrow[IPW], och[IPW], xkh[IPW], xkw[IPW], xci[IPW];
+  // per (lane, instruction) constants: dY channel, X column -> (tap, ci); plus the row walker
+  int och[IPW], xkh[IPW], xkw[IPW], xci[IPW];
   bool ook[IPW], nok[IPW];
+  RowWalk rw[IPW];
 #pragma unroll
   for (int j = 0; j < IPW; ++j) {
     const int row = (wave * IPW + j) * RPI + lane / SLOTS;
     const int logical = WG<T>::swz(lane % SLOTS, row);
-    rrow[j] = row;
     och[j] = o0 + logical * EPV;
     ook[j] = och[j] < p.Cout;
     const int n = n0 + logical * EPV;
@@ -80,25 +124,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_
     xci[j] = n - tap * p.Cin;
     xkh[j] = tap / p.KW;
     xkw[j] = tap - xkh[j] * p.KW;
+    rw[j].m = m_begin + row;
+    walk_refresh(p, rw[j]);
   }
 
-  auto issue = [&](int step, int buf) {
+  auto issue = [&](int buf) {  // DMA the tiles of the walkers' current rows, then advance them one step
     char* sD = smem + buf * 2 * TILE;
     char* sX = sD + TILE;
 #pragma unroll
     for (int j = 0; j < IPW; ++j) {
-      const long long m = m_begin + (long long)step * BKM + rrow[j];
-      const bool mok = m < p.M;
-      const T* sd = (mok && ook[j]) ? dyg + m * p.rps + och[j] : zero;
+      const bool mok = rw[j].m < p.M;
+      const T* sd = (mok && ook[j]) ? dyg + rw[j].m * p.rps + och[j] : zero;
       dma16(sd, sD + (wave * IPW + j) * 1024);
-      const T* sx = zero;
-      if (mok && nok[j]) {
-        const RowGeom g = row_geom(p, (int)m);
-        const int hi = g.hi0 + xkh[j], wi = g.wi0 + xkw[j];
-        if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
-          sx = xg + (g.pix0 + (long long)hi * g.W + wi) * p.xps + xci[j];
-      }
+      const RowGeom& g = rw[j].g;
+      const int hi = g.hi0 + xkh[j], wi = g.wi0 + xkw[j];
+      const bool ok = mok && nok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+      const T* sx = ok ? xg + (g.pix0 + (long long)hi * g.W + wi) * p.xps + xci[j] : zero;
       dma16(sx, sX + (wave * IPW + j) * 1024);
+      walk_advance(p, rw[j], BKM);
     }
   };
 
@@ -111,41 +154,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_
   const long long m_left = (long long)p.M - m_begin;
   const int nsteps = (int)std::min<long long>(steps_per_block, (m_left + BKM - 1) / BKM);
   if (nsteps <= 0) return;
-  issue(0, 0);
+  issue(0);
   __syncthreads();
   const int g4 = lane >> 4, q = lane & 15;
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nsteps) issue(s + 1, buf ^ 1);
+    if (s + 1 < nsteps) issue(buf ^ 1);
     const char* sD = smem + buf * 2 * TILE;
     const char* sX = sD + TILE;
     if constexpr (sizeof(T) == 2) {
-      uint4 fa[4], fb[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        v4i16_t lo[2], hi[2];
+      for (int half = 0; half < BKM / 32; ++half) {
+        uint4 fa[4], fb[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int row = h * 16 + g4 * 4 + (q >> 2);
-          const int sub = q & 3;
-          const int ca = wave_o0 + t * 16, cb = wave_n0 + t * 16;
-          const int sa = WG<T>::swz((ca >> 3) + (sub >> 1), row), sb = WG<T>::swz((cb >> 3) + (sub >> 1), row);
-          lo[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) v4i16_t*)(sD + row * ROWB + sa * 16 + (sub & 1) * 8));
-          hi[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) v4i16_t*)(sX + row * ROWB + sb * 16 + (sub & 1) * 8));
+        for (int t = 0; t < 4; ++t) {
+          v4i16_t lo[2], hi[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int row = half * 32 + h * 16 + g4 * 4 + (q >> 2);
+            const int sub = q & 3;
+            const int ca = wave_o0 + t * 16, cb = wave_n0 + t * 16;
+            const int sa = WG<T>::swz((ca >> 3) + (sub >> 1), row), sb = WG<T>::swz((cb >> 3) + (sub >> 1), row);
+            lo[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) v4i16_t*)(sD + row * ROWB + sa * 16 + (sub & 1) * 8));
+            hi[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) v4i16_t*)(sX + row * ROWB + sb * 16 + (sub & 1) * 8));
+          }
+          fa[t] = make_uint4(__builtin_bit_cast(uint2, lo[0]).x, __builtin_bit_cast(uint2, lo[0]).y,
+                             __builtin_bit_cast(uint2, lo[1]).x, __builtin_bit_cast(uint2, lo[1]).y);
+          fb[t] = make_uint4(__builtin_bit_cast(uint2, hi[0]).x, __builtin_bit_cast(uint2, hi[0]).y,
+                             __builtin_bit_cast(uint2, hi[1]).x, __builtin_bit_cast(uint2, hi[1]).y);
         }
-        fa[t] = make_uint4(__builtin_bit_cast(uint2, lo[0]).x, __builtin_bit_cast(uint2, lo[0]).y,
-                           __builtin_bit_cast(uint2, lo[1]).x, __builtin_bit_cast(uint2, lo[1]).y);
-        fb[t] = make_uint4(__builtin_bit_cast(uint2, hi[0]).x, __builtin_bit_cast(uint2, hi[0]).y,
-                           __builtin_bit_cast(uint2, hi[1]).x, __builtin_bit_cast(uint2, hi[1]).y);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                                __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
       }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
-                                                              __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
     } else {
 #pragma unroll
       for (int kk = 0; kk < BKM / 4; ++kk) {
@@ -308,13 +354,14 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * p.K, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int tiles = ((d->Cout + 127) / 128) * ((p.K + 127) / 128);
-  const long long total_steps = (M + 31) / 32;
+  const int bkm = d->dtype == DAS_BF16 ? 64 : 32;
+  const long long total_steps = (M + bkm - 1) / bkm;
   // aim for ~4 workgroups per CU, at least 8 steps per workgroup
   long long splits = std::max<long long>(1, (256 * 4 + tiles - 1) / tiles);
   long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
   splits = (total_steps + spb - 1) / spb;
   if (d->dtype == DAS_BF16) {
-    const size_t sm = 2 * 2 * 32 * 256;
+    const size_t sm = 2 * 2 * 64 * 256;
     hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3(tiles, (unsigned)splits), dim3(256), sm, s, p, (int)spb);
   } else if (d->dtype == DAS_F32) {
     const size_t sm = 2 * 2 * 32 * 512;

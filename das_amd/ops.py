@@ -256,7 +256,14 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
         short = {torch.bfloat16: 'bf16', torch.float32: 'float'}
         glds = Cin % (64 if xd.dtype == torch.bfloat16 else 32) == 0 and not relu_in
-        tag = f'{"conv_glds_kernel" if glds else "conv_reg_kernel"}<{short[xd.dtype]}, {short[out_dtype]}, {bn}>'
+        # mirrors the dispatch in conv_igemm.hip::launch so that tags equal the rocprof kernel names
+        big = (glds and bn == 128 and out_dtype == torch.bfloat16 and in_up == 1 and
+               ((rows + 255) // 256) * ((Cout + 127) // 128) >= 384)
+        if big:
+            tag = f'conv_glds3_kernel<{short[xd.dtype]}, {short[out_dtype]}>'
+        else:
+            tag = f'{"conv_glds_kernel" if glds else "conv_reg_kernel"}<{short[xd.dtype]}, {short[out_dtype]}, {bn}' + \
+                  (', 128>' if glds else '>')
         PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1,
                         (B, H, W, Cin, Cout, KH, stride, len(x.sizes) if ragged else 1)))
     return out
