@@ -26,6 +26,10 @@ class DasConvDesc(C.Structure):
                 ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5), ('in_up', i32)]
 
 
+class DasPackEntry(C.Structure):
+    _fields_ = [('off', i64), ('O', i32), ('I', i32), ('KH', i32), ('KW', i32), ('tile_start', i32)]
+
+
 class DasLevels(C.Structure):
     _fields_ = [('num_levels', i32), ('B', i32), ('H', i32 * 5), ('W', i32 * 5)]
 
@@ -54,9 +58,10 @@ SIGNATURES = {
     'das_abi_version': (i32, []),
     'das_target_arch': (C.c_char_p, []),
     'das_conv2d_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), vp]),
-    'das_conv2d_wgrad_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), vp]),
+    'das_conv2d_wgrad_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), i32, vp]),
+    'das_pack_conv_weights': (i32, [vp, vp, vp, i32, vp, i32, i32, vp]),
     'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
-    'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
     'das_groupnorm_backward': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp,
                                      vp, vp, vp]),
     'das_maxpool3x3s2_backward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -26,6 +26,24 @@ def _dw_to_oihw(dw, weight):
     return dw[:O, :, :, :I].permute(0, 3, 1, 2)
 
 
+def _wgrad(x, dy, weight, k, s, p):
+    """Weight gradient of conv(x, weight). With the flat optimizer the kernel adds straight into the flat
+    gradient buffer (same (Cout,KH,KW,Cin) layout) and autograd gets None; otherwise an OIHW view is returned."""
+    sl = getattr(weight, '_das_slot', None)
+    cin, cout = _d(x).shape[-1], _d(dy).shape[-1]
+    if sl is not None and sl.direct(cin, cout) and sl.cl_shape[1] == k:
+        ops.conv2d_wgrad(x, dy, k, k, s, p, out=sl.grad_cl, accumulate=True)
+        sl.fired()
+        return None
+    return _dw_to_oihw(ops.conv2d_wgrad(x, dy, k, k, s, p), weight)
+
+
+def _param_acc(param):
+    """Flat-gradient slice of a 1-D parameter (or None without the flat optimizer)."""
+    sl = getattr(param, '_das_slot', None)
+    return None if sl is None or param.grad is None else (sl, param.grad)
+
+
 class ConvBNTrainFn(Function):
     """conv (no bias) -> train-mode BatchNorm (+ residual) (+ ReLU). mspn_mmpose.py:126-157,381-404."""
 
@@ -41,24 +59,33 @@ class ConvBNTrainFn(Function):
                                              residual=residual, relu=relu)
         bn.num_batches_tracked += 1
         bn.__dict__.pop('_das_cache', None)  # running stats changed under the cache's feet (raw-pointer update)
-        ctx.save_for_backward(x, raw, y, mean, invstd, gamma, weight)
-        ctx.cfg = (k, s, p, relu, residual is not None, conv)
+        ctx.save_for_backward(x, raw, y if residual is not None else None, mean, invstd, gamma, weight, beta)
+        ctx.cfg = (k, s, p, relu, residual is not None, conv, bn)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from .nn import packed_weight_dgrad
-        x, raw, y, mean, invstd, gamma, weight = ctx.saved_tensors
-        k, s, p, relu, has_res, conv = ctx.cfg
+        x, raw, y, mean, invstd, gamma, weight, beta = ctx.saved_tensors
+        k, s, p, relu, has_res, conv, bn = ctx.cfg
         dy = dy.contiguous()
-        draw, dres, dgamma, dbeta = ops.bn_train_backward(dy, y if relu else None, raw, mean, invstd, gamma, relu,
-                                                          has_res)
+        ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
+        direct = ga is not None and ba is not None
+        # without a residual the ReLU mask is recomputed from raw: y is not read at all
+        draw, dres, dgamma, dbeta = ops.bn_train_backward(dy, y if (relu and has_res) else None, raw, mean, invstd, gamma,
+                                                          relu, has_res, beta=beta,
+                                                          dgamma_acc=ga[1] if direct else None,
+                                                          dbeta_acc=ba[1] if direct else None)
+        if direct:
+            dgamma = dbeta = None
+            ga[0].fired()
+            ba[0].fired()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_dgrad(draw, packed_weight_dgrad(conv, x.dtype), k, k, s, p, (x.shape[1], x.shape[2]))
             if dx.shape[-1] != x.shape[-1]:
                 dx = dx[..., :x.shape[-1]]
-        dw = _dw_to_oihw(ops.conv2d_wgrad(x, draw, k, k, s, p), weight)
+        dw = _wgrad(x, draw, conv.weight, k, s, p) if ctx.needs_input_grad[1] else None
         return dx, dw, dgamma, dbeta, dres, None, None, None
 
 
@@ -100,8 +127,8 @@ class ConvFn(Function):
             dx = _d(ops.conv2d_dgrad(dzr, packed_weight_dgrad(conv, x.dtype), k, k, s, p, hw))
             if dx.shape[-1] != x.shape[-1]:
                 dx = dx[..., :x.shape[-1]]
-        dwp = ops.conv2d_wgrad(xr, dzr, k, k, s, p)
-        dw = _dw_to_oihw(dwp, weight) if weight.dim() == 4 and weight.shape[2:] == (k, k) else None
+        wp = conv.weight if getattr(conv, 'weight', None) is not None and conv.weight.shape == weight.shape else weight
+        dw = _wgrad(xr, dzr, wp, k, s, p) if ctx.needs_input_grad[1] else None
         db = ops.colsum(dzr)[:weight.shape[0]] if has_bias else None
         return dx, dw, db, None, None, None, None, None
 
@@ -226,9 +253,16 @@ class DcnGemmFn(Function):
             return wp.t().contiguous().reshape(wp.shape[1], 1, 1, wp.shape[0])
         wt = _cache_of(dcn).get(('wt', col.dtype), (weight,), make_wt)
         dcol = _d(ops.conv2d(dyr, wt, 1, 1))
-        dwp = ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0)          # (O_pad, 1, 1, 9*Cin_pad)
+        sl = getattr(dcn.weight, '_das_slot', None)
         cpad = col.shape[-1] // 9
-        dw = dwp.reshape(dwp.shape[0], 3, 3, cpad)[:O, :, :, :Cc].permute(0, 3, 1, 2)
+        if sl is not None and sl.direct(cpad, dy.shape[-1]):
+            # (O,3,3,C) channels-last storage == the (O,1,1,9C) GEMM weight: add straight into the flat gradient
+            ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0, out=sl.grad_cl, accumulate=True)
+            sl.fired()
+            dw = None
+        else:
+            dwp = ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0)          # (O_pad, 1, 1, 9*Cin_pad)
+            dw = dwp.reshape(dwp.shape[0], 3, 3, cpad)[:O, :, :, :Cc].permute(0, 3, 1, 2)
         db = ops.colsum(dyr)[:O] if has_bias else None
         return dcol, dw, db, None, None
 

@@ -62,6 +62,12 @@ struct Elem<bf16_t> {
   static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// Train-mode BatchNorm affine, written once so that forward and the backward's recomputed ReLU mask
+// round identically.
+__device__ __forceinline__ float bn_affine(float x, float mean, float invstd, float gamma, float beta) {
+  return __fmaf_rn((x - mean) * invstd, gamma, beta);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -30,7 +30,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, long long co
   }
 }
 
-template <typename T>
+// One 16-byte channel vector per thread and iteration. The grid stride is a multiple of the channel-vector
+// count whenever that count is a power of two (every BN on the path), so a thread keeps its channels for the
+// whole loop and the per-channel constants live in registers (FIXED); two iterations are kept in flight.
+template <typename T, bool FIXED>
 __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long long count, int C,
                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -38,15 +41,20 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV;
   const long long total = count * VC;
-  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    const int c0 = (int)(i % VC) * EPV;
-    float f[EPV];
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + i * EPV), f);
+  const long long stride = (long long)gridDim.x * TPB;
+  float mu[EPV], is[EPV], ga[EPV], be[EPV];
+  auto load_consts = [&](int c0) {
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) f[j] = (f[j] - mean[c0 + j]) * invstd[c0 + j] * gamma[c0 + j] + beta[c0 + j];
+    for (int j = 0; j < EPV; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }
+  };
+  auto finish = [&](long long i, const uint4& raw, const uint4& rv) {
+    float f[EPV];
+    Elem<T>::unpack(raw, f);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) f[j] = bn_affine(f[j], mu[j], is[j], ga[j], be[j]);
     if (res) {
       float r[EPV];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(res + i * EPV), r);
+      Elem<T>::unpack(rv, r);
 #pragma unroll
       for (int j = 0; j < EPV; ++j) f[j] += r[j];
     }
@@ -55,6 +63,28 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
       for (int j = 0; j < EPV; ++j) f[j] = fmaxf(f[j], 0.f);
     }
     *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(f);
+  };
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (FIXED) {
+    if (i < total) load_consts((int)(i % VC) * EPV);
+    for (; i + stride < total; i += 2 * stride) {
+      const uint4 a0 = *reinterpret_cast<const uint4*>(x + i * EPV);
+      const uint4 a1 = *reinterpret_cast<const uint4*>(x + (i + stride) * EPV);
+      uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+      if (res) {
+        r0 = *reinterpret_cast<const uint4*>(res + i * EPV);
+        r1 = *reinterpret_cast<const uint4*>(res + (i + stride) * EPV);
+      }
+      finish(i, a0, r0);
+      finish(i + stride, a1, r1);
+    }
+  }
+  for (; i < total; i += stride) {
+    if (!FIXED) load_consts((int)(i % VC) * EPV);
+    const uint4 a0 = *reinterpret_cast<const uint4*>(x + i * EPV);
+    uint4 r0 = make_uint4(0, 0, 0, 0);
+    if (res) r0 = *reinterpret_cast<const uint4*>(res + i * EPV);
+    finish(i, a0, r0);
   }
 }
 
@@ -136,15 +166,19 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, s, stats, count, C, running_mean,
                      running_var, momentum, eps, save_mean, save_invstd);
+  if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
+  const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
+  const int grid = grid_for(count * vc);
+  const bool fixed = ((long long)grid * TPB) % vc == 0;
+#define DAS_BN_APPLY(T, F)                                                                                      \
+  hipLaunchKernelGGL((bn_apply_kernel<T, F>), dim3(grid), dim3(TPB), 0, s, (const T*)x, (T*)y, count, C, save_mean, \
+                     save_invstd, gamma, beta, (const T*)residual, relu)
   if (dtype == DAS_BF16) {
-    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(count * (C / 8))), dim3(TPB), 0, s, (const bf16_t*)x,
-                       (bf16_t*)y, count, C, save_mean, save_invstd, gamma, beta, (const bf16_t*)residual, relu);
-  } else if (dtype == DAS_F32) {
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(count * (C / 4))), dim3(TPB), 0, s, (const float*)x,
-                       (float*)y, count, C, save_mean, save_invstd, gamma, beta, (const float*)residual, relu);
+    if (fixed) DAS_BN_APPLY(bf16_t, true); else DAS_BN_APPLY(bf16_t, false);
   } else {
-    return DAS_ERR_ARG;
+    if (fixed) DAS_BN_APPLY(float, true); else DAS_BN_APPLY(float, false);
   }
+#undef DAS_BN_APPLY
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }

@@ -86,7 +86,7 @@ __device__ __forceinline__ void walk_advance(const ConvP& p, RowWalk& r, int n) 
   }
 }
 
-// p.x = forward input X, p.res = dY (pixel stride p.rps), p.y = dW f32 [Cout][K] (pre-zeroed).
+// p.x = forward input X, p.res = dY (pixel stride p.rps), p.y = dW f32 [Cout][K] (atomically added to).
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_block) {
   constexpr int EPV = Elem<T>::EPV;
@@ -253,34 +253,66 @@ __global__ void colsum_kernel(const T* __restrict__ x, long long rows, int C, in
 }
 
 // ------------------------------------------------------------------ BatchNorm (train) backward
-// pass 1: s1[c] = sum dZ, s2[c] = sum dZ * xhat with dZ = dY * (y > 0 if relu)
-template <typename T>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ raw,
-                                     const float* __restrict__ mean, const float* __restrict__ invstd, long long rows,
-                                     int C, int relu, float* __restrict__ sums) {
+// MASK: 0 = no ReLU, 1 = ReLU mask from the saved output y (needed when a residual was added before the
+// ReLU), 2 = ReLU mask recomputed from raw (y > 0 <=> bn_affine(raw) > 0): one tensor read less per pass.
+template <typename T, int MASK>
+__device__ __forceinline__ void bn_masked_grad(float* g, const float* x, const uint4& yv, const float* mu,
+                                               const float* is, const float* ga, const float* be) {
   constexpr int EPV = Elem<T>::EPV;
+  if (MASK == 1) {
+    float o[EPV];
+    Elem<T>::unpack(yv, o);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+  } else if (MASK == 2) {
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) g[j] = bn_affine(x[j], mu[j], is[j], ga[j], be[j]) > 0.f ? g[j] : 0.f;
+  }
+}
+
+// pass 1: s1[c] = sum dZ, s2[c] = sum dZ * xhat with dZ = dY * mask. Four rows in flight per thread.
+template <typename T, int MASK>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ raw,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, long long rows,
+                                     int C, float* __restrict__ sums) {
+  constexpr int EPV = Elem<T>::EPV;
+  constexpr int U = 4;
   extern __shared__ float sred[];  // [2C]
   const int VC = C / EPV;
   for (int i = threadIdx.x; i < 2 * C; i += TPB) sred[i] = 0.f;
   __syncthreads();
   const int VCB = min(VC, TPB);
   const int pl = threadIdx.x / VCB, PL = TPB / VCB;
+  const long long rstride = (long long)gridDim.x * PL;
   for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
-    float s1[EPV], s2[EPV], mu[EPV], is[EPV];
+    float s1[EPV], s2[EPV], mu[EPV], is[EPV], ga[EPV], be[EPV];
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[v * EPV + j]; is[j] = invstd[v * EPV + j]; }
-    for (long long r = (long long)blockIdx.x * PL + pl; r < rows; r += (long long)gridDim.x * PL) {
-      float g[EPV], x[EPV];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + r * C + v * EPV), g);
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(raw + r * C + v * EPV), x);
-      if (relu) {
-        float o[EPV];
-        Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + r * C + v * EPV), o);
+    for (int j = 0; j < EPV; ++j) {
+      s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[v * EPV + j]; is[j] = invstd[v * EPV + j];
+      ga[j] = MASK == 2 ? gamma[v * EPV + j] : 0.f; be[j] = MASK == 2 ? beta[v * EPV + j] : 0.f;
+    }
+    for (long long r = (long long)blockIdx.x * PL + pl; r < rows; r += rstride * U) {
+      uint4 gv[U], xv[U], yv[U];
 #pragma unroll
-        for (int j = 0; j < EPV; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+      for (int u = 0; u < U; ++u) {
+        const long long ru = r + u * rstride;
+        gv[u] = xv[u] = yv[u] = make_uint4(0, 0, 0, 0);
+        if (ru < rows) {
+          gv[u] = *reinterpret_cast<const uint4*>(dy + ru * C + v * EPV);
+          xv[u] = *reinterpret_cast<const uint4*>(raw + ru * C + v * EPV);
+          if (MASK == 1) yv[u] = *reinterpret_cast<const uint4*>(y + ru * C + v * EPV);
+        }
       }
 #pragma unroll
-      for (int j = 0; j < EPV; ++j) { s1[j] += g[j]; s2[j] += g[j] * (x[j] - mu[j]) * is[j]; }
+      for (int u = 0; u < U; ++u) {  // rows past the end carry dY = 0 and add nothing
+        float g[EPV], x[EPV];
+        Elem<T>::unpack(gv[u], g);
+        Elem<T>::unpack(xv[u], x);
+        bn_masked_grad<T, MASK>(g, x, yv[u], mu, is, ga, be);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { s1[j] += g[j]; s2[j] += g[j] * (x[j] - mu[j]) * is[j]; }
+      }
     }
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
@@ -292,40 +324,89 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
   for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(sums + i, sred[i]);
 }
 
-// pass 2: dRaw = gamma*invstd*(dZ - s1/N - xhat*s2/N); optionally dRes = dZ
-template <typename T>
+// pass 2: dRaw = gamma*invstd*(dZ - s1/N - xhat*s2/N); optionally dRes = dZ. Block 0 also adds the two
+// sums into the parameter-gradient accumulators (dbeta += s1, dgamma += s2) when they are given.
+template <typename T, int MASK, bool FIXED>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ raw,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ sums, long long rows,
-                                    int C, int relu, T* __restrict__ draw, T* __restrict__ dres) {
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ sums, long long rows, int C, T* __restrict__ draw,
+                                    T* __restrict__ dres, float* __restrict__ dgamma_acc,
+                                    float* __restrict__ dbeta_acc) {
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV;
   const long long total = rows * VC;
   const float inv_n = 1.f / (float)rows;
-  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    const int c0 = (int)(i % VC) * EPV;
-    float g[EPV], x[EPV], o[EPV];
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + i * EPV), g);
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(raw + i * EPV), x);
-    if (relu) {
-      float yy[EPV];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + i * EPV), yy);
-#pragma unroll
-      for (int j = 0; j < EPV; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
-    }
-    if (dres) *reinterpret_cast<uint4*>(dres + i * EPV) = Elem<T>::pack(g);
+  const long long stride = (long long)gridDim.x * TPB;
+  if (blockIdx.x == 0 && dgamma_acc) {
+    for (int c = threadIdx.x; c < C; c += TPB) { dbeta_acc[c] += sums[c]; dgamma_acc[c] += sums[C + c]; }
+  }
+  float mu[EPV], is[EPV], ga[EPV], be[EPV], k1[EPV], k2[EPV], k3[EPV];
+  auto load_consts = [&](int c0) {
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       const int c = c0 + j;
-      const float xhat = (x[j] - mean[c]) * invstd[c];
-      o[j] = gamma[c] * invstd[c] * (g[j] - sums[c] * inv_n - xhat * sums[C + c] * inv_n);
+      mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = MASK == 2 ? beta[c] : 0.f;
+      k1[j] = ga[j] * is[j]; k2[j] = sums[c] * inv_n; k3[j] = sums[C + c] * inv_n * is[j];
     }
+  };
+  auto finish = [&](long long i, const uint4& gv, const uint4& xv, const uint4& yv) {
+    float g[EPV], x[EPV], o[EPV];
+    Elem<T>::unpack(gv, g);
+    Elem<T>::unpack(xv, x);
+    bn_masked_grad<T, MASK>(g, x, yv, mu, is, ga, be);
+    if (dres) *reinterpret_cast<uint4*>(dres + i * EPV) = Elem<T>::pack(g);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) o[j] = k1[j] * (g[j] - k2[j] - (x[j] - mu[j]) * k3[j]);
     *reinterpret_cast<uint4*>(draw + i * EPV) = Elem<T>::pack(o);
+  };
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  if (FIXED) {
+    if (i < total) load_consts((int)(i % VC) * EPV);
+    for (; i + stride < total; i += 2 * stride) {
+      const long long i1 = i + stride;
+      const uint4 g0 = *reinterpret_cast<const uint4*>(dy + i * EPV), g1 = *reinterpret_cast<const uint4*>(dy + i1 * EPV);
+      const uint4 x0 = *reinterpret_cast<const uint4*>(raw + i * EPV), x1 = *reinterpret_cast<const uint4*>(raw + i1 * EPV);
+      uint4 y0 = z4, y1 = z4;
+      if (MASK == 1) { y0 = *reinterpret_cast<const uint4*>(y + i * EPV); y1 = *reinterpret_cast<const uint4*>(y + i1 * EPV); }
+      finish(i, g0, x0, y0);
+      finish(i1, g1, x1, y1);
+    }
+  }
+  for (; i < total; i += stride) {
+    if (!FIXED) load_consts((int)(i % VC) * EPV);
+    const uint4 g0 = *reinterpret_cast<const uint4*>(dy + i * EPV);
+    const uint4 x0 = *reinterpret_cast<const uint4*>(raw + i * EPV);
+    uint4 y0 = z4;
+    if (MASK == 1) y0 = *reinterpret_cast<const uint4*>(y + i * EPV);
+    finish(i, g0, x0, y0);
+  }
+}
+
+template <typename T, int MASK>
+void launch_bn_backward(const void* dy, const void* y, const void* raw, long long rows, int C, const float* mean,
+                        const float* invstd, const float* gamma, const float* beta, void* draw, void* dres,
+                        float* sums, float* dgamma_acc, float* dbeta_acc, hipStream_t s) {
+  const int vc = C / Elem<T>::EPV;
+  const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, rows / 64));
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3(blocks), dim3(TPB), 2 * C * sizeof(float), s, (const T*)dy,
+                     (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
+  const int grid = grid_for(rows * vc);
+  if (((long long)grid * TPB) % vc == 0) {
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, true>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
+                       (const T*)raw, mean, invstd, gamma, beta, sums, rows, C, (T*)draw, (T*)dres, dgamma_acc,
+                       dbeta_acc);
+  } else {
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, false>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
+                       (const T*)raw, mean, invstd, gamma, beta, sums, rows, C, (T*)draw, (T*)dres, dgamma_acc,
+                       dbeta_acc);
   }
 }
 }  // namespace
 
-extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, void* stream) {
+extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate,
+                                     void* stream) {
   if (!x || !dy || !dw || !d) return DAS_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->x_pix_stride % 8 || d->y_pix_stride % 8) return DAS_ERR_ARG;
   if (d->KH < 1 || d->KW < 1 || d->stride < 1 || d->B < 1 || d->in_up > 1) return DAS_ERR_ARG;
@@ -352,7 +433,7 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * p.K, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * p.K, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int tiles = ((d->Cout + 127) / 128) * ((p.K + 127) / 128);
   const int bkm = d->dtype == DAS_BF16 ? 64 : 32;
   const long long total_steps = (M + bkm - 1) / bkm;
@@ -392,28 +473,24 @@ extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int p
 }
 
 extern "C" int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
-                                     const float* mean, const float* invstd, const float* gamma, int relu,
-                                     void* draw, void* dres, float* sums, void* stream) {
+                                     const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     int relu, void* draw, void* dres, float* sums, float* dgamma_acc,
+                                     float* dbeta_acc, void* stream) {
   if (!dy || !raw || !mean || !invstd || !gamma || !draw || !sums || rows <= 0 || C % 8 || C > 2048) return DAS_ERR_ARG;
-  if (relu && !y) return DAS_ERR_ARG;
+  if (relu && !y && !beta) return DAS_ERR_ARG;
+  if ((dgamma_acc == nullptr) != (dbeta_acc == nullptr)) return DAS_ERR_ARG;
+  if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
-  const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, rows / 64));
+  const int mask = !relu ? 0 : (y ? 1 : 2);
+#define DAS_BN_BWD(T, MASK)                                                                                       \
+  launch_bn_backward<T, MASK>(dy, y, raw, rows, C, mean, invstd, gamma, beta, draw, dres, sums, dgamma_acc, dbeta_acc, s)
   if (dtype == DAS_BF16) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(TPB), 2 * C * sizeof(float), s,
-                       (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)raw, mean, invstd, rows, C, relu, sums);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(rows * (C / 8))), dim3(TPB), 0, s, (const bf16_t*)dy,
-                       (const bf16_t*)y, (const bf16_t*)raw, mean, invstd, gamma, sums, rows, C, relu, (bf16_t*)draw,
-                       (bf16_t*)dres);
-  } else if (dtype == DAS_F32) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(TPB), 2 * C * sizeof(float), s, (const float*)dy,
-                       (const float*)y, (const float*)raw, mean, invstd, rows, C, relu, sums);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(rows * (C / 4))), dim3(TPB), 0, s, (const float*)dy,
-                       (const float*)y, (const float*)raw, mean, invstd, gamma, sums, rows, C, relu, (float*)draw,
-                       (float*)dres);
+    if (mask == 0) DAS_BN_BWD(bf16_t, 0); else if (mask == 1) DAS_BN_BWD(bf16_t, 1); else DAS_BN_BWD(bf16_t, 2);
   } else {
-    return DAS_ERR_ARG;
+    if (mask == 0) DAS_BN_BWD(float, 0); else if (mask == 1) DAS_BN_BWD(float, 1); else DAS_BN_BWD(float, 2);
   }
+#undef DAS_BN_BWD
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }

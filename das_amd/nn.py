@@ -72,12 +72,27 @@ def _cache_of(mod):
     return c
 
 
+def _slot_of(weight, cin=None):
+    """The optimizer's record of a conv weight if its flat storage is directly usable as a kernel operand
+    (channels multiples of 8, no input-channel padding needed)."""
+    sl = getattr(weight, '_das_slot', None)
+    if sl is None or not sl.packable or (cin is not None and cin != sl.cl_shape[3]):
+        return None
+    return sl
+
+
 def packed_weight(conv, dtype, cin_pad=None):
+    sl = _slot_of(conv.weight, cin_pad)
+    if sl is not None:
+        return sl.packed(dtype)  # view of the optimizer's once-per-step packed buffer
     return _cache_of(conv).get(('w', dtype, cin_pad), (conv.weight,),
                                lambda: ops.pack_weight(conv.weight, dtype, cin_pad=cin_pad))
 
 
 def packed_weight_dgrad(conv, dtype):
+    sl = _slot_of(conv.weight)
+    if sl is not None:
+        return sl.packed(dtype, dgrad=True)
     return _cache_of(conv).get(('wd', dtype), (conv.weight,), lambda: ops.pack_weight_dgrad(conv.weight, dtype))
 
 

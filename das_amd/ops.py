@@ -132,6 +132,14 @@ def pack_weight_dgrad(w, dtype):
     return p
 
 
+def pack_conv_weights(flat_src, fwd_dst, dgrad_dst, table_dev, n_entries, total_tiles):
+    """One launch packing every conv weight listed in the device table (see das_pack_conv_weights)."""
+    _need_gpu(flat_src, dgrad_dst)
+    _lib.check(_lib.load().das_pack_conv_weights(_ptr(flat_src), _ptr(fwd_dst), _ptr(dgrad_dst), _DT[dgrad_dst.dtype],
+                                                 _ptr(table_dev), n_entries, total_tiles, _stream()),
+               'das_pack_conv_weights')
+
+
 def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw):
     """dX of conv(x, w, stride, pad): a stride-1 conv of the (zero-upsampled) dY with flipped weights."""
     if isinstance(dy, Ragged):
@@ -139,8 +147,9 @@ def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw):
     return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, in_up=stride, out_hw=in_hw)
 
 
-def conv2d_wgrad(x, dy, KH, KW, stride, pad):
-    """dW (Cout, KH, KW, Cin) f32 of conv(x, w, stride, pad) given dy; x/dy NHWC or Ragged."""
+def conv2d_wgrad(x, dy, KH, KW, stride, pad, out=None, accumulate=False):
+    """dW (Cout, KH, KW, Cin) f32 of conv(x, w, stride, pad) given dy; x/dy NHWC or Ragged.
+    out + accumulate: add into an existing buffer of that layout (the optimizer's flat gradient)."""
     _need_gpu(x, dy)
     xd, dyd = _data(x), _data(dy)
     Cin, Cout = xd.shape[-1], dyd.shape[-1]
@@ -151,7 +160,12 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad):
     else:
         B, H, W, _ = x.shape
         Ho, Wo = dy.shape[1], dy.shape[2]
-    dw = torch.empty(Cout, KH, KW, Cin, dtype=torch.float32, device=xd.device)
+    if out is None:
+        assert not accumulate
+        dw = torch.empty(Cout, KH, KW, Cin, dtype=torch.float32, device=xd.device)
+    else:
+        dw = out
+        assert dw.numel() == Cout * KH * KW * Cin and dw.dtype == torch.float32 and dw.is_contiguous()
     d = _lib.DasConvDesc(dtype=_DT[xd.dtype], out_dtype=_lib.DAS_F32, B=B, H=H, W=W, Cin=Cin, x_pix_stride=_ps(x),
                          Ho=Ho, Wo=Wo, Cout=Cout, y_pix_stride=_ps(dy), KH=KH, KW=KW, stride=stride, pad=pad,
                          num_levels=len(x.sizes) if ragged else 0)
@@ -162,7 +176,7 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.load().das_conv2d_wgrad_nhwc(_ptr(xd), _ptr(dyd), _ptr(dw), C.byref(d), _stream()),
+    _lib.check(_lib.load().das_conv2d_wgrad_nhwc(_ptr(xd), _ptr(dyd), _ptr(dw), C.byref(d), int(accumulate), _stream()),
                'das_conv2d_wgrad_nhwc')
     if PROFILE is not None:
         e1.record()
@@ -185,8 +199,10 @@ def colsum(x):
     return out
 
 
-def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres):
-    """Returns d_raw, d_residual (or None), dgamma, dbeta."""
+def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta=None, dgamma_acc=None, dbeta_acc=None):
+    """Returns d_raw, d_residual (or None), dgamma, dbeta. y=None with relu: the ReLU mask is recomputed
+    from raw (needs beta; only valid when no residual entered before the ReLU). dgamma_acc/dbeta_acc:
+    f32[C] buffers the parameter gradients are also added to."""
     _need_gpu(dy, raw)
     assert dy.is_contiguous() and raw.is_contiguous() and (y is None or y.is_contiguous())
     Cc = raw.shape[-1]
@@ -194,9 +210,11 @@ def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres):
     draw = torch.empty_like(raw)
     dres = torch.empty_like(raw) if want_dres else None
     sums = torch.empty(2 * Cc, dtype=torch.float32, device=raw.device)
+    assert not (relu and y is None and want_dres), 'the recomputed mask ignores a residual'
     _lib.check(_lib.load().das_bn_train_backward(_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean),
-                                                 _ptr(invstd), _ptr(gamma), int(relu), _ptr(draw), _ptr(dres),
-                                                 _ptr(sums), _stream()), 'das_bn_train_backward')
+                                                 _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _ptr(draw),
+                                                 _ptr(dres), _ptr(sums), _ptr(dgamma_acc), _ptr(dbeta_acc),
+                                                 _stream()), 'das_bn_train_backward')
     return draw, dres, sums[Cc:], sums[:Cc]
 
 

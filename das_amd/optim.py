@@ -28,9 +28,38 @@ def _is_bias_param(name, module_of):
     return True
 
 
+class _Slot:
+    """Where one parameter lives in the flat buffers (attached to the parameter as `_das_slot`)."""
+    __slots__ = ('opt', 'off', 'numel', 'bucket', 'cl_shape', 'grad_cl', 'packable')
+
+    def fired(self):
+        """Tell the optimizer that this parameter's gradient of the current backward is complete."""
+        self.opt._fired(self)
+
+    def direct(self, cin, cout):
+        """True if a (cout, KH, KW, cin) weight-gradient kernel can add straight into the flat gradient."""
+        return self.cl_shape is not None and self.cl_shape[0] == cout and self.cl_shape[3] == cin
+
+    def packed(self, dtype, dgrad=False):
+        return self.opt._packed_view(self, dtype, dgrad)
+
+
 class FlatSGD:
+    """SGD with momentum over flat f32 buffers (parameters, gradients, momentum).
+
+    Conv weights are STORED in (Cout, KH, KW, Cin) order (the parameter is a channels-last strided OIHW view):
+    that is the forward kernels' operand layout and the weight-gradient kernels' output layout, so backward
+    adds straight into the flat gradient and one launch per step packs the bf16 / data-gradient copies of
+    every layer (`das_pack_conv_weights`).
+
+    Data parallel: gradients are all-reduced in param-aligned buckets of >= bucket_mb, launched on a side
+    stream DURING backward as soon as a bucket's gradients are complete (hooks count completions; the
+    expected counts are learned in the first iteration). Buckets always launch in the same order (from the
+    end of the buffer = the layers backward reaches first), so the collective sequence is identical on all
+    ranks whatever the timing."""
+
     def __init__(self, model, lr, momentum=0.9, weight_decay=1e-4, bias_lr_mult=1.0, bias_decay_mult=1.0,
-                 max_grad_norm=0.0, bucket_mb=64):
+                 max_grad_norm=0.0, bucket_mb=64, overlap=True):
         self.model, self.base_lr, self.momentum, self.max_grad_norm = model, lr, momentum, max_grad_norm
         module_of = {}
         for mname, mod in model.named_modules():
@@ -40,46 +69,158 @@ class FlatSGD:
         groups = {'main': [], 'bias': []}
         for n, p in named:
             groups['bias' if _is_bias_param(n, module_of) else 'main'].append((n, p))
-        self.groups = []
         dev = named[0][1].device
-        total = sum(p.numel() for _, p in named)
-        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        for key, lr_mult, wd in (('main', 1.0, weight_decay), ('bias', bias_lr_mult, weight_decay * bias_decay_mult)):
+        # layout: [bias group | main group]; 4-D tensors start on 8-element boundaries (16-byte aligned bf16 views)
+        plan, off = [], 0
+        bounds = {}
+        for key in ('bias', 'main'):
             start = off
             for n, p in groups[key]:
-                k = p.numel()
-                self.flat_p[off:off + k].copy_(p.data.reshape(-1))
-                p.data = self.flat_p[off:off + k].view_as(p)           # parameters become views of the flat buffer
-                p.grad = self.flat_g[off:off + k].view_as(p)          # autograd accumulates into the flat buffer
-                off += k
-            self.groups.append(dict(key=key, start=start, end=off, lr_mult=lr_mult, wd=wd))
+                if p.dim() == 4:
+                    off = (off + 7) // 8 * 8
+                plan.append((n, p, off))
+                off += p.numel()
+            bounds[key] = (start, off)
+        total = off
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.slots, self._conv_slots = [], []
+        for n, p, o in plan:
+            k = p.numel()
+            sl = _Slot()
+            sl.opt, sl.off, sl.numel, sl.bucket, sl.cl_shape, sl.grad_cl, sl.packable = self, o, k, 0, None, None, False
+            if p.dim() == 4:
+                O, I, KH, KW = p.shape
+                vp = self.flat_p[o:o + k].view(O, KH, KW, I)
+                vp.copy_(p.data.permute(0, 2, 3, 1))
+                p.data = vp.permute(0, 3, 1, 2)                       # OIHW-shaped view, channels-last storage
+                sl.grad_cl = self.flat_g[o:o + k].view(O, KH, KW, I)
+                p.grad = sl.grad_cl.permute(0, 3, 1, 2)
+                sl.cl_shape = (O, KH, KW, I)
+                sl.packable = O % 8 == 0 and I % 8 == 0
+                if sl.packable:
+                    self._conv_slots.append(sl)
+            else:
+                self.flat_p[o:o + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + k].view_as(p)               # parameters become views of the flat buffer
+                p.grad = self.flat_g[o:o + k].view_as(p)              # autograd accumulates into the flat buffer
+            p._das_slot = sl
+            self.slots.append(sl)
+            p.register_post_accumulate_grad_hook(lambda t, sl=sl: sl.opt._fired(sl))
+        self.groups = [dict(key='main', start=bounds['main'][0], end=bounds['main'][1], lr_mult=1.0, wd=weight_decay),
+                       dict(key='bias', start=bounds['bias'][0], end=bounds['bias'][1], lr_mult=bias_lr_mult,
+                            wd=weight_decay * bias_decay_mult)]
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.steps = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # param-aligned buckets in buffer order
         n_bucket = max(1, bucket_mb * (1 << 20) // 4)
-        self.buckets = [(s, min(s + n_bucket, total)) for s in range(0, total, n_bucket)]
+        self.buckets, bstart = [], 0
+        for i, sl in enumerate(self.slots):
+            sl.bucket = len(self.buckets)
+            end = sl.off + sl.numel
+            if end - bstart >= n_bucket or i == len(self.slots) - 1:
+                self.buckets.append((bstart, total if i == len(self.slots) - 1 else end))
+                bstart = end
+        self.overlap = overlap
         self.comm_stream = torch.cuda.Stream() if self.world > 1 and dev.type == 'cuda' else None
+        self._expected = None                      # completions per bucket in one backward (learned)
+        self._fires = [0] * len(self.buckets)
+        self._next = len(self.buckets) - 1         # next bucket to launch (descending)
+        self._works = []
+        self._late = False
+        self.overlapped_launches = 0               # buckets launched before all_reduce_grads() (diagnostic)
+        # one-launch weight packing
+        self._table = None
+        self._fwd, self._dgrad, self._packed_epoch = {}, {}, {}
+        if hasattr(model, 'register_load_state_dict_post_hook'):
+            from .nn import bump_param_epoch
+            model.register_load_state_dict_post_hook(lambda m, keys: bump_param_epoch())
 
+    # ------------------------------------------------------------------ packed weights
+    def _build_table(self):
+        import numpy as np
+        dt = np.dtype([('off', '<i8'), ('O', '<i4'), ('I', '<i4'), ('KH', '<i4'), ('KW', '<i4'), ('tile_start', '<i4')],
+                      align=True)
+        assert dt.itemsize == 32
+        tab = np.zeros(len(self._conv_slots), dtype=dt)
+        tiles = 0
+        for i, sl in enumerate(self._conv_slots):
+            O, KH, KW, I = sl.cl_shape
+            tab[i] = (sl.off, O, I, KH, KW, tiles)
+            tiles += KH * KW * ((O + 31) // 32) * ((I + 31) // 32)
+        self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.flat_p.device)
+        self._tiles = tiles
+
+    def _packed_view(self, sl, dtype, dgrad):
+        from .nn import PARAM_EPOCH
+        from . import ops
+        if self._packed_epoch.get(dtype) != PARAM_EPOCH[0]:
+            if self._table is None:
+                self._build_table()
+            if dtype not in self._dgrad:
+                self._dgrad[dtype] = torch.zeros(self.flat_p.numel(), dtype=dtype, device=self.flat_p.device)
+                if dtype != torch.float32:
+                    self._fwd[dtype] = torch.zeros_like(self._dgrad[dtype])
+            ops.pack_conv_weights(self.flat_p, self._fwd.get(dtype), self._dgrad[dtype], self._table,
+                                  len(self._conv_slots), self._tiles)
+            self._packed_epoch[dtype] = PARAM_EPOCH[0]
+        O, KH, KW, I = sl.cl_shape
+        if dgrad:
+            return self._dgrad[dtype][sl.off:sl.off + sl.numel].view(I, KH, KW, O)
+        src = self.flat_p if dtype == torch.float32 else self._fwd[dtype]
+        return src[sl.off:sl.off + sl.numel].view(O, KH, KW, I)
+
+    # ------------------------------------------------------------------ gradients
     def zero_grad(self):
         self.flat_g.zero_()
 
-    def all_reduce_grads(self):
-        """Sum gradients over ranks (mean is folded into the step's grad_scale). Large contiguous buckets,
-        issued on a side stream so the tail of backward / the next forward's packing can overlap."""
-        if self.world == 1:
-            return
+    def _launch(self, b):
+        s, e = self.buckets[b]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                for s, e in self.buckets:
-                    dist.all_reduce(self.flat_g[s:e])
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
-        else:
-            for s, e in self.buckets:
                 dist.all_reduce(self.flat_g[s:e])
+        else:
+            self._works.append(dist.all_reduce(self.flat_g[s:e], async_op=True))
+
+    def _fired(self, sl):
+        if self.world == 1 or not self.overlap:
+            return
+        b = sl.bucket
+        self._fires[b] += 1
+        if self._expected is None:
+            return
+        if b > self._next:
+            self._late = True                      # gradient arrived after its bucket went out
+            return
+        # (a bucket that never receives gradients has expected == 0 and goes out as soon as its turn comes)
+        while self._next >= 0 and self._fires[self._next] >= self._expected[self._next]:
+            self._launch(self._next)
+            self._next -= 1
+            self.overlapped_launches += 1
+
+    def all_reduce_grads(self):
+        """Finish the gradient sum over ranks (the mean is folded into the step's grad_scale): launch the
+        buckets that backward did not complete (unused parameters, first iteration), then wait."""
+        if self.world == 1:
+            return
+        if self._late:
+            raise RuntimeError('a gradient was produced after its bucket had been all-reduced (the set of '
+                               'parameters receiving gradients changed between iterations); use overlap=False')
+        while self._next >= 0:
+            self._launch(self._next)
+            self._next -= 1
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._expected is None and self.overlap:
+            self._expected = list(self._fires)
+        self._fires = [0] * len(self.buckets)
+        self._next = len(self.buckets) - 1
 
     def step(self, lr):
         scale = 1.0 / self.world

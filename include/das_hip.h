@@ -84,19 +84,41 @@ int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d,
  * Fp16OptimizerHook -> loss.backward() in the reference's runner).
  *
  * Data gradient of a conv = das_conv2d_nhwc on (dY, flipped + transposed weights, in_up = stride).
- * Weight gradient: dw f32[Cout][KH][KW][Cin] (zeroed by the call) = sum over output pixels of
+ * Weight gradient: dw f32[Cout][KH][KW][Cin] = sum over output pixels of
  * dY[m][o] * X[m @ tap][ci]; `d` describes the FORWARD conv (x geometry, Ho/Wo, stride, pad,
- * y_pix_stride = pixel stride of dy, ragged levels allowed).
+ * y_pix_stride = pixel stride of dy, ragged levels allowed). accumulate = 0: dw is zeroed by the call;
+ * accumulate = 1: the result is added to dw (the optimizer's flat gradient buffer holds conv weights in
+ * exactly this layout, so backward adds straight into it — what autograd's AccumulateGrad does in the
+ * reference).
  */
-int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, void* stream);
+int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate,
+                          void* stream);
 /* out f32[C] (zeroed by the call) = column sums of x (rows, C) — bias gradients. */
 int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream);
-/* Train-mode BatchNorm (+ReLU, + residual) backward. dZ = dY * (y > 0) when relu; sums f32[2C] (zeroed by
- * the call) receive [sum dZ, sum dZ*xhat] = [dbeta, dgamma]; draw = gamma*invstd*(dZ - s1/N - xhat*s2/N);
- * dres (optional) = dZ, the gradient of the residual input. raw = pre-norm conv output saved by forward. */
+/* Train-mode BatchNorm (+ReLU, + residual) backward. dZ = dY * (y > 0) when relu; with y == NULL (allowed
+ * when no residual was added before the ReLU) the mask is recomputed from raw, gamma and beta, which saves
+ * reading y in both passes. sums f32[2C] (zeroed by the call) receive [sum dZ, sum dZ*xhat] = [dbeta,
+ * dgamma]; draw = gamma*invstd*(dZ - s1/N - xhat*s2/N); dres (optional) = dZ, the gradient of the residual
+ * input. raw = pre-norm conv output saved by forward. dgamma_acc / dbeta_acc (both or neither): f32[C]
+ * parameter-gradient accumulators that the sums are added to. */
 int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
-                          const float* mean, const float* invstd, const float* gamma, int relu, void* draw,
-                          void* dres, float* sums, void* stream);
+                          const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                          void* draw, void* dres, float* sums, float* dgamma_acc, float* dbeta_acc, void* stream);
+
+/* All conv weights of the network packed in one launch, once per optimizer step. flat_src: the optimizer's
+ * f32 master buffer, conv weights stored as (Cout,KH,KW,Cin) (the forward operand layout). For every table
+ * entry: fwd_dst[off ...] = the same layout cast to dtype (fwd_dst may be NULL: the f32 path reads the
+ * master directly); dgrad_dst[off ...] = (Cin,KH,KW,Cout) with both tap axes flipped — the operand of the
+ * data-gradient conv. entries_dev: device copy of the table, tile_start = running sum of
+ * KH*KW*ceil(O/32)*ceil(I/32); total_tiles = the final sum. Replaces the per-layer permute / flip / cast
+ * that torch (cuDNN/MIOpen) does internally for every conv of `loss.backward()`. */
+typedef struct {
+  long long off;
+  int O, I, KH, KW;
+  int tile_start;
+} DasPackEntry;
+int das_pack_conv_weights(const float* flat_src, void* fwd_dst, void* dgrad_dst, int dtype,
+                          const DasPackEntry* entries_dev, int n_entries, int total_tiles, void* stream);
 
 /* GroupNorm(+ReLU) backward over ragged rows. x = pre-norm input saved by forward, y = forward output
  * (ReLU mask), fwd_stats = the forward's stats workspace (sum, sumsq per level/image/group).

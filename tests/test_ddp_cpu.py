@@ -41,6 +41,55 @@ def test_bucketed_allreduce_world2_gloo():
         assert main_n == total  # FPN with BN: every 'bias' belongs to a norm layer -> nothing in the bias group
 
 
+def _overlap_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from das_amd.optim import FlatSGD
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 8, 1),
+                              torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 4))
+    unused = torch.nn.Linear(3, 3)          # never enters the loss (like the reference's root-offset branch)
+    holder = torch.nn.ModuleDict(dict(net=net, unused=unused))
+    w0 = {n: p.detach().clone() for n, p in holder.named_parameters()}
+    opt = FlatSGD(holder, lr=0.1, bucket_mb=0, overlap=True)
+    same_values = all(torch.equal(p.detach(), w0[n]) for n, p in holder.named_parameters())
+    ref = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 8, 1),
+                              torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 4))
+    ref.load_state_dict({k: v.contiguous() for k, v in net.state_dict().items()})
+    ok, launched = True, []
+    for it in range(3):
+        xs = [torch.randn(2, 8, 6, 6, generator=torch.Generator().manual_seed(10 * it + r)) for r in range(world)]
+        opt.zero_grad()
+        net(xs[rank]).square().sum().backward()
+        before = opt.overlapped_launches
+        opt.all_reduce_grads()
+        launched.append(before)
+        ref.zero_grad()
+        for r in range(world):
+            ref(xs[r]).square().sum().backward()
+        for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+            ok = ok and torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-5)
+        ok = ok and float(unused.weight.grad.abs().sum()) == 0.0
+    ret[rank] = (ok, same_values, launched, len(opt.buckets))
+    dist.destroy_process_group()
+
+
+def test_allreduce_overlaps_backward_world2_gloo():
+    """Buckets are launched from gradient-completion hooks during backward (from the 2nd iteration on),
+    always in the same order; parameters that never get a gradient do not stall the others."""
+    mp.set_start_method('spawn', force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 30500 + os.getpid() % 1000
+    mp.spawn(_overlap_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        ok, same_values, launched, nb = ret[r]
+        assert ok and same_values
+        assert launched[0] == 0                      # first iteration only learns the completion counts
+        assert launched[1] > 0 and launched[2] > launched[1]   # later ones go out during backward
+        assert ret[0][2] == ret[1][2]
+
+
 def test_paramwise_groups_and_lr_schedule():
     import das_amd
     from das_amd.optim import FlatSGD, step_lr
@@ -49,9 +98,13 @@ def test_paramwise_groups_and_lr_schedule():
     nbias = sum(p.numel() for n, p in net.named_parameters() if n.endswith('.bias'))
     g = {x['key']: x for x in opt.groups}
     assert g['bias']['end'] - g['bias']['start'] == nbias and g['bias']['wd'] == 0.0 and g['bias']['lr_mult'] == 2.0
-    # parameters are views of the flat buffer
+    # parameters are views of the flat buffer: [bias group | main group]; conv weights keep their OIHW shape
+    # over (O,KH,KW,I) storage, i.e. the kernels' operand layout
     p0 = next(net.parameters())
-    assert p0.data_ptr() == opt.flat_p.data_ptr() and p0.grad.data_ptr() == opt.flat_g.data_ptr()
+    sl = p0._das_slot
+    assert g['bias']['start'] == 0 and sl.off >= g['main']['start'] and sl.off % 8 == 0
+    assert p0.data_ptr() == opt.flat_p[sl.off:].data_ptr() and p0.grad.data_ptr() == opt.flat_g[sl.off:].data_ptr()
+    assert p0.dim() == 4 and p0.data.permute(0, 2, 3, 1).is_contiguous() and p0.grad.shape == p0.shape
     # schedule: lr/3 at it 0, full lr at it 250, x0.1 at epochs 16 and 20 (exp_panoptic.py:206-212)
     assert step_lr(2e-3, 0, 0) == pytest.approx(2e-3 / 3)
     assert step_lr(2e-3, 0, 125) == pytest.approx(2e-3 * (1 - 0.5 * (2 / 3)))

@@ -1,0 +1,128 @@
+"""The flat-optimizer fast paths: backward kernels adding straight into the flat gradient buffer, the
+one-launch weight packing, and the BatchNorm backward that recomputes its ReLU mask — each against the
+plain (autograd-accumulated / per-layer packed) path on the same inputs. GPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+from test_model_gpu import tiny_detector_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def nhwc(t, dtype=torch.float32):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_wgrad_accumulates_into_existing_buffer(dtype):
+    from das_amd import ops as o
+    B, H, W, Cin, Cout, k = 2, 12, 10, 64, 72, 3
+    x = nhwc(cases.randn(1, B, Cin, H, W), dtype)
+    dy = nhwc(cases.randn(2, B, Cout, H, W), dtype)
+    ref = o.conv2d_wgrad(x, dy, k, k, 1, 1)
+    acc = torch.full((Cout, k, k, Cin), 0.5, dtype=torch.float32, device=DEV)
+    out = o.conv2d_wgrad(x, dy, k, k, 1, 1, out=acc, accumulate=True)
+    assert out.data_ptr() == acc.data_ptr()
+    np.testing.assert_allclose(acc.cpu().numpy(), ref.cpu().numpy() + 0.5, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pack_conv_weights_one_launch(dtype):
+    """Flat (O,KH,KW,I) master -> forward cast + flipped/transposed data-gradient weights for a table of tensors."""
+    from das_amd import ops as o
+    shapes = [(64, 64, 1, 1), (40, 24, 3, 3), (256, 128, 3, 3), (8, 8, 7, 7), (136, 72, 1, 1)]
+    ws = [cases.randn(10 + i, *s) for i, s in enumerate(shapes)]
+    dt = np.dtype([('off', '<i8'), ('O', '<i4'), ('I', '<i4'), ('KH', '<i4'), ('KW', '<i4'), ('tile_start', '<i4')],
+                  align=True)
+    tab = np.zeros(len(ws), dtype=dt)
+    off, tiles, chunks = 16, 0, [torch.zeros(16)]
+    for i, w in enumerate(ws):
+        O, I, KH, KW = w.shape
+        tab[i] = (off, O, I, KH, KW, tiles)
+        tiles += KH * KW * ((O + 31) // 32) * ((I + 31) // 32)
+        chunks.append(w.permute(0, 2, 3, 1).reshape(-1))
+        off += w.numel()
+    flat = torch.cat(chunks).to(DEV)
+    fwd = torch.zeros(flat.numel(), dtype=dtype, device=DEV) if dtype != torch.float32 else None
+    dg = torch.zeros(flat.numel(), dtype=dtype, device=DEV)
+    o.pack_conv_weights(flat, fwd, dg, torch.from_numpy(tab.view(np.uint8).copy()).to(DEV), len(ws), tiles)
+    for i, w in enumerate(ws):
+        O, I, KH, KW = w.shape
+        a = int(tab[i]['off'])
+        got_d = dg[a:a + w.numel()].view(I, KH, KW, O)
+        torch.testing.assert_close(got_d, o.pack_weight_dgrad(w.to(DEV), dtype), rtol=0, atol=0)
+        if fwd is not None:
+            torch.testing.assert_close(fwd[a:a + w.numel()].view(O, KH, KW, I), o.pack_weight(w.to(DEV), dtype),
+                                       rtol=0, atol=0)
+    assert float(dg[:16].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bn_backward_recomputed_mask_and_param_accumulators(dtype):
+    """y = None: the ReLU mask comes from raw/gamma/beta and must equal the y > 0 mask of the forward kernel;
+    the accumulators receive += [dgamma, dbeta]."""
+    from das_amd import ops as o
+    B, H, W, C = 3, 14, 10, 128
+    raw = nhwc(cases.randn(14, B, C, H, W) * 1.5 + 0.3, dtype)
+    gamma, beta = (cases.randn(16, C).abs() + 0.5).to(DEV), cases.randn(17, C).to(DEV)
+    dy = nhwc(cases.randn(21, B, C, H, W), dtype)
+    stats = torch.stack([raw.float().sum((0, 1, 2)), raw.float().square().sum((0, 1, 2))]).reshape(-1).contiguous()
+    y, mean, invstd = o.bn_train_apply(raw, stats, gamma, beta, None, None, 0.1, 1e-5, relu=True)
+    d_ref, _, dg_ref, db_ref = o.bn_train_backward(dy, y, raw, mean, invstd, gamma, True, False)
+    ga, ba = torch.full((C,), 2.0, device=DEV), torch.full((C,), -1.0, device=DEV)
+    d_new, _, dg, db = o.bn_train_backward(dy, None, raw, mean, invstd, gamma, True, False, beta=beta, dgamma_acc=ga,
+                                           dbeta_acc=ba)
+    torch.testing.assert_close(d_new, d_ref, rtol=0, atol=0)
+    torch.testing.assert_close(dg, dg_ref, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(ga, dg_ref + 2.0, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(ba, db_ref - 1.0, rtol=1e-5, atol=1e-4)
+
+
+def _model(dtype):
+    import das_amd
+    torch.manual_seed(0)
+    cfg = tiny_detector_cfg()
+    cfg['backbone']['compute_dtype'] = dtype
+    m = das_amd.build_model(cfg)
+    m.init_weights()
+    return m.to(DEV).train()
+
+
+def test_flat_optimizer_gradients_equal_autograd_gradients():
+    """Same weights, same batch: gradients accumulated by the kernels directly into the flat buffer (FlatSGD
+    attached) vs gradients delivered through autograd's AccumulateGrad (no optimizer), f32."""
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    from das_amd.optim import FlatSGD
+    ds = SyntheticPoseDataset(num_joints=15, img_shape=(128, 192), length=4, seed=3, max_persons=3)
+    data = collate([ds[i] for i in range(4)], device=DEV)
+    plain, flat = _model('f32'), _model('f32')
+    sd = {k: v.clone() for k, v in plain.state_dict().items()}
+    opt = FlatSGD(flat, lr=1e-3, max_grad_norm=35.0)
+    flat.load_state_dict(sd)
+    for k, v in flat.state_dict().items():
+        torch.testing.assert_close(v, sd[k], rtol=0, atol=0)
+    n_direct = sum(1 for p in flat.parameters() if p.dim() == 4 and p._das_slot.packable)
+    assert n_direct > 50
+    plain.train_step(data, None)['loss'].backward()
+    opt.zero_grad()
+    flat.train_step(data, None)['loss'].backward()
+    errs = []
+    for (n, p), q in zip(plain.named_parameters(), flat.parameters()):
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        scale = float(g.abs().max())
+        if scale == 0.0:
+            assert float(q.grad.abs().max()) == 0.0, n
+            continue
+        errs.append(float((g - q.grad).abs().max()) / scale)
+    errs = np.asarray(errs)
+    # same kernels, same inputs: only the order of the f32 atomics differs (BN statistics, weight gradients);
+    # a few parameters behind near-zero ReLU inputs amplify that (gradient conditioning)
+    assert np.median(errs) < 1e-4 and np.quantile(errs, 0.9) < 5e-3 and errs.max() < 0.2, \
+        (np.median(errs), np.quantile(errs, 0.9), errs.max())
+    # running statistics moved identically
+    for (n, b), c in zip(plain.named_buffers(), flat.buffers()):
+        torch.testing.assert_close(b, c, rtol=1e-5, atol=1e-6)

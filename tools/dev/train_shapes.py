@@ -1,0 +1,39 @@
+"""Dev tool: per-shape timing of every conv-family launch (forward, data-grad, weight-grad) of the
+training bench step (HIP events on the launch stream), sorted by time."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+from das_amd import ops
+from das_amd.datasets import SyntheticPoseDataset, collate
+from das_amd.optim import FlatSGD, train_iteration
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+dev = torch.device('cuda', 0)
+model = bench.build_model(dev, num_stages=4, train=True)
+ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=B, seed=0)
+data = collate([ds[i] for i in range(B)], device=dev)
+opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=35.0)
+for _ in range(2):
+    train_iteration(model, opt, data, 2e-3)
+ops.PROFILE = []
+R = 2
+for _ in range(R):
+    train_iteration(model, opt, data, 2e-3)
+torch.cuda.synchronize()
+agg = {}
+for tag, fl, e0, e1, shape in ops.PROFILE:
+    a = agg.setdefault((tag, shape), [0.0, 0.0, 0])
+    a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+tot = sum(a[1] for a in agg.values())
+print(f'total conv-family ms/step {tot / R * 1e3:.3f}')
+fam = {}
+for (tag, shape), (fl, sec, n) in agg.items():
+    f = fam.setdefault(tag, [0.0, 0.0])
+    f[0] += fl; f[1] += sec
+for tag, (fl, sec) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+    print(f'  {sec / R * 1e3:8.3f} ms {fl / sec / 1e12:7.1f} TF  {tag}')
+for (tag, shape), (fl, sec, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+    Bb, H, W, Cin, Cout, k, s, nl = shape
+    print(f'{sec / tot * 100:5.1f}% {sec / R * 1e3:7.3f}ms n={n // R:3d} {fl / sec / 1e12:7.1f}TF '
+          f'{tag[5:30]:26s} HxW={H}x{W} Cin={Cin} Cout={Cout} k={k} s={s} lv={nl}')
