@@ -49,22 +49,22 @@ class ConvBNTrainFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv, bn, relu):
-        from .nn import packed_weight
+        from .nn import packed_weight, zeroed_stats
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
-        stats = torch.zeros(2 * w.shape[0], dtype=torch.float32, device=x.device)
+        stats = zeroed_stats(2 * w.shape[0], x.device)
         raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
         mom = bn.momentum if bn.momentum is not None else 0.1
         y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,
-                                             residual=residual, relu=relu)
-        bn.num_batches_tracked += 1
+                                             residual=residual, relu=relu,
+                                             num_batches_tracked=bn.num_batches_tracked)
         bn.__dict__.pop('_das_cache', None)  # running stats changed under the cache's feet (raw-pointer update)
         ctx.save_for_backward(x, raw, y if residual is not None else None, mean, invstd, gamma, weight, beta)
         ctx.cfg = (k, s, p, relu, residual is not None, conv, bn)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         from .nn import packed_weight_dgrad
         x, raw, y, mean, invstd, gamma, weight, beta = ctx.saved_tensors
         k, s, p, relu, has_res, conv, bn = ctx.cfg
@@ -82,11 +82,32 @@ class ConvBNTrainFn(Function):
             ba[0].fired()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_dgrad(draw, packed_weight_dgrad(conv, x.dtype), k, k, s, p, (x.shape[1], x.shape[2]))
+            if dskip is not None:
+                dskip = dskip.contiguous()
+            dx = ops.conv2d_dgrad(draw, packed_weight_dgrad(conv, x.dtype), k, k, s, p, (x.shape[1], x.shape[2]),
+                                  residual=dskip)
             if dx.shape[-1] != x.shape[-1]:
                 dx = dx[..., :x.shape[-1]]
         dw = _wgrad(x, draw, conv.weight, k, s, p) if ctx.needs_input_grad[1] else None
         return dx, dw, dgamma, dbeta, dres, None, None, None
+
+
+class ConvBNTrainSkipFn(Function):
+    """ConvBNTrainFn that also hands its input through as a second output: y, x_skip = f(x).
+
+    In a bottleneck x feeds conv1 AND the identity path. Routing the identity through this node makes both
+    gradients of x arrive together, so the data-gradient kernel adds the skip gradient in its epilogue
+    (`residual`) instead of autograd running a separate elementwise add over the whole tensor."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, conv, bn, relu):
+        y = ConvBNTrainFn.forward(ctx, x, weight, gamma, beta, None, conv, bn, relu)
+        return y, x
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        dx, dw, dgamma, dbeta, _, _, _, _ = ConvBNTrainFn.backward(ctx, dy, dskip)
+        return dx, dw, dgamma, dbeta, None, None, None
 
 
 class ConvFn(Function):

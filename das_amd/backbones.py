@@ -38,9 +38,14 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = conv_bn(x, self.conv1, self.bn1, relu=True)
+        if self.downsample is None:
+            # identity path routed through conv1's autograd node: its gradient is added in conv1's
+            # data-gradient epilogue instead of by a separate elementwise kernel
+            out, identity = conv_bn(x, self.conv1, self.bn1, relu=True, skip_through=True)
+        else:
+            out = conv_bn(x, self.conv1, self.bn1, relu=True)
+            identity = self.downsample(x)
         out = conv_bn(out, self.conv2, self.bn2, relu=True)
-        identity = x if self.downsample is None else self.downsample(x)
         # relu(bn3(conv3(out)) + identity): residual add and ReLU ride in the conv/BN epilogue
         return conv_bn(out, self.conv3, self.bn3, relu=True, residual=identity)
 

@@ -131,28 +131,45 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   OT* yg = reinterpret_cast<OT*>(p.y);
   const OT* rg = reinterpret_cast<const OT*>(p.res);
   if (n < p.Cout) {
-#pragma unroll 2
-    for (int ml = r0; ml < BMT; ml += RP) {
-      const int m = m0 + ml;
-      if (m >= p.M) break;
-      const uint4 raw = *reinterpret_cast<const uint4*>(smem + ml * CS + vec * 16);
-      float f[EPVO];
-      Elem<OT>::unpack(raw, f);
-      if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < EPVO; ++j) { ssum[j] += f[j]; ssq[j] += f[j] * f[j]; }
-      }
+    constexpr int ITERS = BMT / RP, CH = ITERS < 4 ? ITERS : 4;  // rows per thread, processed CH at a time
+    static_assert(ITERS % CH == 0, "tile rows per thread must be a multiple of the chunk");
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITERS; it0 += CH) {
+      // the residual rows of a chunk are requested together, ahead of the LDS reads, so that their
+      // memory latency overlaps instead of adding up row by row
+      uint4 rv[CH];
       if (rg) {
-        float r[EPVO];
-        Elem<OT>::unpack(*reinterpret_cast<const uint4*>(rg + (long long)m * p.rps + n), r);
 #pragma unroll
-        for (int j = 0; j < EPVO; ++j) f[j] += r[j];
+        for (int u = 0; u < CH; ++u) {
+          const int m = m0 + r0 + (it0 + u) * RP;
+          rv[u] = make_uint4(0, 0, 0, 0);
+          if (m < p.M) rv[u] = *reinterpret_cast<const uint4*>(rg + (long long)m * p.rps + n);
+        }
       }
-      if (p.relu) {
 #pragma unroll
-        for (int j = 0; j < EPVO; ++j) f[j] = fmaxf(f[j], 0.f);
+      for (int u = 0; u < CH; ++u) {
+        const int ml = r0 + (it0 + u) * RP;
+        const int m = m0 + ml;
+        if (m >= p.M) break;
+        const uint4 raw = *reinterpret_cast<const uint4*>(smem + ml * CS + vec * 16);
+        float f[EPVO];
+        Elem<OT>::unpack(raw, f);
+        if (p.stats) {
+#pragma unroll
+          for (int j = 0; j < EPVO; ++j) { ssum[j] += f[j]; ssq[j] += f[j] * f[j]; }
+        }
+        if (rg) {
+          float r[EPVO];
+          Elem<OT>::unpack(rv[u], r);
+#pragma unroll
+          for (int j = 0; j < EPVO; ++j) f[j] += r[j];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < EPVO; ++j) f[j] = fmaxf(f[j], 0.f);
+        }
+        *reinterpret_cast<uint4*>(yg + (long long)m * p.yps + n) = (rg || p.relu) ? Elem<OT>::pack(f) : raw;
       }
-      *reinterpret_cast<uint4*>(yg + (long long)m * p.yps + n) = (rg || p.relu) ? Elem<OT>::pack(f) : raw;
     }
   }
   if (p.stats) {

@@ -13,10 +13,11 @@ inline int grid_for(long long n) {
 
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, long long count, int C, float* running_mean,
                                    float* running_var, float momentum, float eps, float* save_mean,
-                                   float* save_invstd) {
+                                   float* save_invstd, long long* num_batches_tracked) {
 #pragma clang fp contract(off)
   const int c = blockIdx.x * TPB + threadIdx.x;
   if (c >= C) return;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
   const float n = (float)count;
   const float mean = stats[c] / n;
   float var = stats[C + c] / n - mean * mean;
@@ -161,12 +162,12 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, DasL
 extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
                                   float momentum, float eps, const void* residual, int relu, float* save_mean,
-                                  float* save_invstd, void* stream) {
+                                  float* save_invstd, long long* num_batches_tracked, void* stream) {
   if (!x || !y || !stats || !gamma || !beta || !save_mean || !save_invstd || C % 8 || count <= 0) return DAS_ERR_ARG;
+  if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, s, stats, count, C, running_mean,
-                     running_var, momentum, eps, save_mean, save_invstd);
-  if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
+                     running_var, momentum, eps, save_mean, save_invstd, num_batches_tracked);
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
   const int grid = grid_for(count * vc);
   const bool fixed = ((long long)grid * TPB) % vc == 0;

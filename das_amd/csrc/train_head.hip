@@ -55,7 +55,9 @@ __global__ void deform_col2im_kernel(const T* __restrict__ x, const float* __res
         const long long pix = g.plane0 + (long long)yy * W + xx;
         const float f = Elem<T>::load(x + pix * xps + ch);
         const float dot = gc * f;
-        atomicAdd(dx + pix * C + ch, gc * mask * wts[c]);
+        // a corner with zero bilinear weight adds exactly 0.0: skip the atomic (wave-uniform). With samples on
+        // the integer grid (zero-initialised offset convs) three of the four corners are such no-ops.
+        if (wts[c] != 0.f) atomicAdd(dx + pix * C + ch, gc * mask * wts[c]);
         val += wts[c] * dot;
         gpy += wy[c] * dot;
         gpx += wx[c] * dot;

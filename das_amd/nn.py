@@ -125,31 +125,65 @@ def _channels(x):
 
 
 # ------------------------------------------------------------------ fused units
-def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False):
+def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False, skip_through=False):
     """ConvModule(conv, BN[, ReLU]) (+ residual add before the ReLU) on an NHWC tensor.
 
     eval: one kernel (BN folded into the conv epilogue). train: conv with fused per-channel
     sum / sum-of-squares, then the BN apply kernel (batch statistics, running-stat update).
+    skip_through: return (y, x) with x routed through the same autograd node (see ConvBNTrainSkipFn) —
+    use the returned x for the skip connection.
     """
     w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     if not bn.training:
         scale, shift = bn_eval_affine(conv, bn)
-        return ops.conv2d(x, w, k, k, s, p, scale=scale, shift=shift, residual=residual, relu=relu, relu_in=relu_in)
+        y = ops.conv2d(x, w, k, k, s, p, scale=scale, shift=shift, residual=residual, relu=relu, relu_in=relu_in)
+        return (y, x) if skip_through else y
     assert conv.bias is None
     from . import autograd as ag
     if ag.grad_mode(x, conv.weight, bn.weight, residual):
         assert not relu_in
+        if skip_through:
+            assert residual is None
+            return ag.ConvBNTrainSkipFn.apply(x, conv.weight, bn.weight, bn.bias, conv, bn, relu)
         return ag.ConvBNTrainFn.apply(x, conv.weight, bn.weight, bn.bias, residual, conv, bn, relu)
+    if skip_through:
+        return conv_bn(x, conv, bn, relu=relu, residual=residual, relu_in=relu_in), x
     cout = w.shape[0]
-    stats = torch.zeros(2 * cout, dtype=torch.float32, device=x.device)
+    stats = zeroed_stats(2 * cout, x.device)
     raw = ops.conv2d(x, w, k, k, s, p, relu_in=relu_in, stats=stats)
     mom = bn.momentum if bn.momentum is not None else 0.1
     y, mean, invstd = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
-                                         residual=residual, relu=relu)
-    bn.num_batches_tracked += 1
+                                         residual=residual, relu=relu, num_batches_tracked=bn.num_batches_tracked)
     bn.__dict__.pop('_das_cache', None)  # running stats were updated through raw pointers
     return y
+
+
+class _ZeroArena:
+    """Zero-filled f32 scratch handed out in slices (per-channel statistics accumulators of the conv
+    epilogue): one memset per ~1M floats instead of one per layer. A slice is only valid for the launches
+    issued right after it is taken (stream order makes the wrap-around memset safe)."""
+
+    def __init__(self, cap=1 << 20):
+        self.cap, self.buf, self.off = cap, None, 0
+
+    def take(self, n, device):
+        n = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != device:
+            self.buf, self.off = torch.zeros(self.cap, dtype=torch.float32, device=device), 0
+        if self.off + n > self.cap:
+            self.buf.zero_()
+            self.off = 0
+        s = self.buf[self.off:self.off + n]
+        self.off += n
+        return s
+
+
+_STATS_ARENA = _ZeroArena()
+
+
+def zeroed_stats(n, device):
+    return _STATS_ARENA.take(n, device)[:n]
 
 
 def conv_plain(x, conv, relu=False, out_dtype=None, out=None):

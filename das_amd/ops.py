@@ -140,11 +140,12 @@ def pack_conv_weights(flat_src, fwd_dst, dgrad_dst, table_dev, n_entries, total_
                'das_pack_conv_weights')
 
 
-def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw):
-    """dX of conv(x, w, stride, pad): a stride-1 conv of the (zero-upsampled) dY with flipped weights."""
+def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw, residual=None):
+    """dX of conv(x, w, stride, pad): a stride-1 conv of the (zero-upsampled) dY with flipped weights.
+    residual: another gradient of the same input, added in the epilogue (x that also feeds a skip path)."""
     if isinstance(dy, Ragged):
-        return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad)
-    return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, in_up=stride, out_hw=in_hw)
+        return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, residual=residual)
+    return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, in_up=stride, out_hw=in_hw, residual=residual)
 
 
 def conv2d_wgrad(x, dy, KH, KW, stride, pad, out=None, accumulate=False):
@@ -350,18 +351,22 @@ def add3(a, b, c=None, relu=False):
 
 
 def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None,
-                   relu=False):
-    """x (B,H,W,C) raw conv output, stats f32[2C] from the conv epilogue. Returns y, mean, invstd."""
+                   relu=False, num_batches_tracked=None):
+    """x (B,H,W,C) raw conv output, stats f32[2C] from the conv epilogue. Returns y, mean, invstd.
+    num_batches_tracked: the BatchNorm's int64 counter buffer, incremented on the device by the same launch."""
     _need_gpu(x, stats)
     assert x.is_contiguous()
     Cc = x.shape[-1]
     count = x.numel() // Cc
     y = torch.empty_like(x)
-    mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    invstd = torch.empty_like(mean)
+    mi = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+    mean, invstd = mi[0], mi[1]
+    if num_batches_tracked is not None:
+        assert num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda
     _lib.check(_lib.load().das_bn_train_apply(_ptr(x), _ptr(y), _DT[x.dtype], count, Cc, _ptr(stats), _ptr(gamma),
                                               _ptr(beta), _ptr(running_mean), _ptr(running_var), momentum, eps,
-                                              _ptr(residual), int(relu), _ptr(mean), _ptr(invstd), _stream()),
+                                              _ptr(residual), int(relu), _ptr(mean), _ptr(invstd),
+                                              _ptr(num_batches_tracked), _stream()),
                'das_bn_train_apply')
     return y, mean, invstd
 

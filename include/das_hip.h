@@ -159,11 +159,12 @@ int das_add3(const void* a, const void* b, const void* c, void* y, int dtype, lo
 /* Train-mode BatchNorm finalize (torch BatchNorm2d in training mode, mspn_mmpose.py:74-79):
  * from `stats` = [sum(C), sumsq(C)] over `count` pixels compute mean / biased var,
  * y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta + residual ), and update running stats
- * (momentum, unbiased var). save_mean/save_invstd: f32[C] outputs for backward. */
+ * (momentum, unbiased var). save_mean/save_invstd: f32[C] outputs for backward.
+ * num_batches_tracked: optional device int64 scalar (the BatchNorm buffer of that name), incremented by 1. */
 int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
                        const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, const void* residual, int relu, float* save_mean,
-                       float* save_invstd, void* stream);
+                       float* save_invstd, long long* num_batches_tracked, void* stream);
 
 /* Ragged multi-level pixel rows. The DASHead shares its weights across FPN levels
  * (das_head.py:176-178 `multi_apply(self.forward_single, feats, ...)`), so the head ops below take

@@ -53,8 +53,14 @@ def bilinear_zero(x, py, px):
     xf = x.reshape(B, C, H * W)
     shape = py.shape[1:]
 
+    # mmcv's kernels gate the WHOLE sample (`if (h_im > -1 && w_im > -1 && h_im < height && w_im < width)` in
+    # modulated_deformable_im2col / col2im / col2im_coord). The value is unchanged by the gate (the corner
+    # weights vanish there), but the gradient at exactly py == -1 or px == -1 is zero, not the one-sided
+    # derivative — which matters because zero-initialised offset convs put every border tap exactly there.
+    gate = (py > -1) & (px > -1) & (py < H) & (px < W)
+
     def corner(yy, xx, wgt):
-        valid = (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)
+        valid = (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1) & gate
         idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).long().reshape(B, 1, -1).expand(B, C, -1)
         v = torch.gather(xf, 2, idx).reshape(B, C, *shape)
         return v * (wgt * valid.to(x.dtype))[:, None]

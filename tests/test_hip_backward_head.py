@@ -27,14 +27,19 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
 
 
-def test_deform_im2col_backward_vs_oracle_autograd():
+@pytest.mark.parametrize('shape', [
+    (2, 16, 24, 9, 11, 1.5),     # tile overhang, offsets mostly inside the LDS window
+    (1, 136, 8, 19, 21, 4.0),    # two channel slabs (second one partial), offsets often beyond the 2-px halo
+    (2, 8, 8, 17, 8, 0.0),       # zero offsets: every sample on the integer grid
+])
+def test_deform_im2col_backward_vs_oracle_autograd(shape):
     from oracle.nn_ops import modulated_deform_conv2d
     o = ops()
-    B, C, O, H, W = 2, 16, 24, 9, 11
+    B, C, O, H, W, oscale = shape
     x = cases.randn(24, B, C, H, W).requires_grad_(True)
     w = (cases.randn(25, O, C, 3, 3) / 12)
     om = cases.randn(27, B, 27, H, W)
-    om[:, :18] *= 1.5
+    om[:, :18] *= oscale
     om = om.requires_grad_(True)
     y = modulated_deform_conv2d(x, om[:, :18], torch.sigmoid(om[:, 18:]), w, None)
     dy = cases.randn(28, *y.shape)
@@ -47,6 +52,24 @@ def test_deform_im2col_backward_vs_oracle_autograd():
     assert rel(nchw(dx).numpy(), x.grad.numpy()) < 1e-4
     assert rel(nchw(dom[..., :27]).numpy(), om.grad.numpy()) < 1e-4
     assert float(dom[..., 27:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_deform_im2col_backward_ragged_equals_per_level(dtype):
+    """All FPN levels in one launch (ragged rows) == one launch per level."""
+    o = ops()
+    B, C = 2, 64
+    sizes = [(16, 26), (8, 13), (4, 7)]
+    xs = [nhwc(cases.randn(50 + i, B, C, h, w), dtype) for i, (h, w) in enumerate(sizes)]
+    oms = [torch.cat([nhwc(cases.randn(60 + i, B, 27, h, w) * 1.2), torch.zeros(B, h, w, 5, device=DEV)], -1)
+           for i, (h, w) in enumerate(sizes)]
+    dcs = [nhwc(cases.randn(70 + i, B, 9 * C, h, w), dtype) for i, (h, w) in enumerate(sizes)]
+    R = o.Ragged.from_levels
+    dx, dom = o.deform_im2col3x3_backward(R(xs), R(oms), R(dcs))
+    for l in range(len(sizes)):
+        dxl, doml = o.deform_im2col3x3_backward(xs[l], oms[l], dcs[l])
+        assert rel(dx.level(l).float().cpu().numpy(), dxl.float().cpu().numpy()) < 1e-5
+        assert rel(dom.level(l).cpu().numpy(), doml.cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize('J,h,w,scale', [(3, 10, 14, 1.5), (15, 16, 26, 4.0)])
