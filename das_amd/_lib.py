@@ -89,6 +89,8 @@ SIGNATURES = {
     'das_sigmoid_focal_loss': (i32, [vp, i32, vp, i64, f32, f32, vp, vp, vp]),
     'das_smooth_l1_loss': (i32, [vp, vp, i64, f32, vp, vp, vp]),
     'das_bce_logits_loss': (i32, [vp, vp, i64, vp, vp, vp]),
+    'das_realnvp_log_prob': (i32, [vp, i32, i32, vp, i32, C.c_uint, vp, vp, vp]),
+    'das_realnvp_log_prob_backward': (i32, [vp, vp, i32, i32, vp, i32, C.c_uint, vp, vp, vp]),
     'das_grad_sumsq': (i32, [vp, i64, vp, i32, vp]),
     'das_sgd_momentum_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]),
     'das_decode_cap': (i32, [C.POINTER(DasDecodeDesc)]),

@@ -24,6 +24,7 @@ struct ConvP {
   int up_sh;  // log2 of the input zero-upsampling factor (dgrad of a strided conv): tap coordinate t
               // reads x[t >> up_sh] when t is a multiple of 1 << up_sh, else contributes zero
   int M, K, HoWo, ntiles, nblocks;
+  unsigned xbytes;  // addressable bytes of x from its base (0 if >= 4 GiB): range of the buffer descriptor
   // ragged multi-level input (stride 1, "same" padding): rows of level l start at lvStart[l]
   int nlev, B;
   int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];

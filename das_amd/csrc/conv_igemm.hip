@@ -150,6 +150,26 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
 // Same DMA issued from inline asm: hipcc does not track it, so it inserts no `s_waitcnt vmcnt(0)` in front
 // of the next ds_read (it does for the builtin: an LDS-DMA is a pending LDS write to its alias analysis).
 // The caller owns the vmcnt accounting. M0 = LDS destination of lane 0; restored afterwards.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+// Raw buffer descriptor (wave-uniform): base, num_records = bytes, stride 0.
+__device__ __forceinline__ v4i_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  v4i_t r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+// LDS-DMA through a buffer descriptor: lane l's 16 bytes at byte offset `voff` land at lds_byte_addr + 16*l;
+// offsets >= num_records deliver zeros. Same vmcnt / M0 rules as dma16_asm.
+__device__ __forceinline__ void dma16_buf(unsigned voff, v4i_t rsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(rsrc), "s"(lds_byte_addr)
+               : "memory");
+}
 __device__ __forceinline__ void dma16_asm(const void* src, unsigned lds_byte_addr) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -292,47 +312,61 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   const int m0 = (logical / p.ntiles) * BMT;
   const int wave_m0 = (wave & 3) * 64, wave_n0 = (wave >> 2) * 64;
 
+  // Operands are fetched with `buffer_load_dwordx4 ... offen lds`: 32-bit byte offsets against a buffer
+  // descriptor whose hardware range check returns zeros — padding taps, rows past M and weight rows past
+  // Cout need no zero page and no 64-bit address arithmetic (probe: tools/dev/probe/buf_lds_probe.hip).
+  // Per K-step and DMA instruction the address work is one add and one select; the tap walk is incremental.
+  constexpr unsigned E = sizeof(T);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
   const int lrow = lane >> 3, pslot = lane & 7;
-  const T* xg = reinterpret_cast<const T*>(p.x);
-  const T* wg = reinterpret_cast<const T*>(p.w);
-  const T* zero = reinterpret_cast<const T*>(g_das_zero_page);
-  RowGeom rg[A_INSTR];
-  const T* abase[A_INSTR];
+  const v4i_t xrs = make_rsrc(p.x, p.xbytes), wrs = make_rsrc(p.w, (unsigned)((long long)p.Cout * p.K * E));
+  unsigned acur[A_INSTR];     // byte offset of this lane's 16-byte piece at the current tap (valid or not)
+  unsigned arowstep[A_INSTR]; // bytes per input row of the lane's level
+  int ahi[A_INSTR], awi[A_INSTR], aH[A_INSTR], aW[A_INSTR];
+  bool aok[A_INSTR];
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
     const int row = (wave * A_INSTR + j) * 8 + lrow;
-    rg[j] = row_geom(p, m0 + row);
+    const RowGeom g = row_geom(p, m0 + row);
     const int akg = (pslot ^ ((row >> 1) & 7)) * EPV;
-    abase[j] = xg + (rg[j].pix0 + (long long)rg[j].hi0 * rg[j].W + rg[j].wi0) * p.xps + akg;
+    acur[j] = (unsigned)(((g.pix0 + (long long)g.hi0 * g.W + g.wi0) * p.xps + akg) * (long long)E);
+    arowstep[j] = (unsigned)g.W * (unsigned)p.xps * E;
+    ahi[j] = g.hi0; awi[j] = g.wi0; aH[j] = g.H; aW[j] = g.W;
+    aok[j] = (unsigned)g.hi0 < (unsigned)g.H && (unsigned)g.wi0 < (unsigned)g.W;
   }
-  const T* wrow[W_INSTR];
+  unsigned wcur[W_INSTR];
 #pragma unroll
   for (int j = 0; j < W_INSTR; ++j) {
     const int row = (wave * W_INSTR + j) * 8 + lrow;
-    const int n = n0 + row;
-    wrow[j] = (n < p.Cout) ? wg + (long long)n * p.K + (pslot ^ ((row >> 1) & 7)) * EPV : nullptr;
+    wcur[j] = (unsigned)(((long long)(n0 + row) * p.K + (pslot ^ ((row >> 1) & 7)) * EPV) * E);  // rows >= Cout: out of range
   }
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   int f_kh = 0, f_kw = 0, f_ci = 0;
+  const unsigned dA = BK * E, dB = (unsigned)(p.xps - p.Cin + BK) * E;
+  const unsigned dC = 0u - (unsigned)(p.KW - 1) * (unsigned)p.xps * E - (unsigned)(p.Cin - BK) * E;  // + rowstep
   auto issue = [&](int kt, int buf) {
     const unsigned sA = lds0 + buf * BUF, sW = sA + A_BYTES;
 #pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-      const int th = rg[j].hi0 + f_kh, tw = rg[j].wi0 + f_kw;
-      const bool ok = (unsigned)th < (unsigned)rg[j].H && (unsigned)tw < (unsigned)rg[j].W;
-      const T* cand = abase[j] + (long long)(f_kh * rg[j].W + f_kw) * p.xps + f_ci;
-      dma16_asm(ok ? cand : zero, sA + (wave * A_INSTR + j) * 1024);
-    }
+    for (int j = 0; j < A_INSTR; ++j) dma16_buf(aok[j] ? acur[j] : OOB, xrs, sA + (wave * A_INSTR + j) * 1024);
 #pragma unroll
     for (int j = 0; j < W_INSTR; ++j) {
-      const T* cand = wrow[j] + (long long)kt * BK;
-      dma16_asm(wrow[j] ? cand : zero, sW + (wave * W_INSTR + j) * 1024);
+      dma16_buf(wcur[j], wrs, sW + (wave * W_INSTR + j) * 1024);
+      wcur[j] += BK * E;
     }
     f_ci += BK;
-    if (f_ci >= p.Cin) {
+    if (f_ci < p.Cin) {
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) acur[j] += dA;
+    } else {  // next tap (wave-uniform branch): move the pointer, re-evaluate the bounds
       f_ci = 0;
-      if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+      const bool wrap = ++f_kw == p.KW;
+      if (wrap) { f_kw = 0; ++f_kh; }
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) {
+        acur[j] += wrap ? arowstep[j] + dC : dB;
+        aok[j] = (unsigned)(ahi[j] + f_kh) < (unsigned)aH[j] && (unsigned)(awi[j] + f_kw) < (unsigned)aW[j];
+      }
     }
   };
 
@@ -382,7 +416,8 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   ConvP p = p0;
   p.ntiles = (p.Cout + BN - 1) / BN;
   // 256-row tiles (8 waves, weight tile shared by twice the pixels) once they still fill the chip twice over
-  const bool big = glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((p.M + 255) / 256) * p.ntiles >= 384;
+  const bool big = glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((p.M + 255) / 256) * p.ntiles >= 384 &&
+                   p.xbytes != 0;  // (0 = more than 4 GiB of input: not addressable by 32-bit buffer offsets)
   const int bm = big ? 256 : BM;
   const int mtiles = (p.M + bm - 1) / bm;
   p.nblocks = p.ntiles * mtiles;
@@ -454,6 +489,11 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   p.up_sh = d->in_up == 2 ? 1 : 0;
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0;
+  {
+    const long long npix = p.nlev > 1 ? M : (long long)d->B * d->H * d->W;
+    const long long xb = ((npix - 1) * d->x_pix_stride + d->Cin) * (d->dtype == DAS_BF16 ? 2 : 4);
+    p.xbytes = xb < 0xFFFFFFF0LL ? (unsigned)xb : 0u;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == DAS_BF16) {
     const bool glds = (d->Cin % 64) == 0 && !d->relu_in, aligned = (d->Cin % 32) == 0;

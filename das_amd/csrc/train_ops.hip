@@ -443,7 +443,7 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.relu_in = p.relu = 0; p.up_sh = 0;
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
-  p.ntiles = p.nblocks = 0;
+  p.ntiles = p.nblocks = 0; p.xbytes = 0;
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * p.K, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int tiles = ((d->Cout + 127) / 128) * ((p.K + 127) / 128);

@@ -4,9 +4,9 @@ assembly (das_head.py:281-486).
 
 Dense work runs in HIP kernels over all rows of all levels in one launch each: target assignment
 (`das_assign_targets`), sigmoid focal loss (`das_sigmoid_focal_loss`); SmoothL1 and centerness BCE on the
-positives are HIP kernels too. The RLE / RealNVP term touches only the few hundred positive rows
-(<= 2J x 3 values each) and is expressed with torch tensor ops on the GPU — interim glue, listed in
-DESIGN.md, not a CPU fallback.
+positives are HIP kernels too, and so is the RealNVP log-density of the RLE term (`das_realnvp_log_prob`,
+forward and backward fused over all positives x joints). What remains in torch tensor ops on the GPU is
+the gather of the positive rows and the elementwise algebra around the flow (a few dozen small kernels).
 """
 import math
 
@@ -52,7 +52,13 @@ class RLELoss3D(nn.Module):
 
 
 def realnvp_log_prob(flow, x):
-    """RealNVP.log_prob (real_nvp.py:60-80): 6 coupling layers in reverse, then the N(0, I) prior."""
+    """RealNVP.log_prob (real_nvp.py:60-80) on the GPU: the fused forward / backward kernels."""
+    return T.realnvp_log_prob(flow, x)
+
+
+def realnvp_log_prob_torch(flow, x):
+    """The same density spelled with torch ops, layer by layer (kept as a cross-check for the tests; the
+    training path does not call it)."""
     d = x.shape[1]
     z, logdet = x, x.new_zeros(x.shape[0])
     for i in reversed(range(flow.mask.shape[0])):

@@ -259,6 +259,18 @@ int das_smooth_l1_loss(const float* pred, const float* target, long long n, floa
                        void* stream);
 int das_bce_logits_loss(const float* logits, const float* target, long long n, float* grad, float* loss_sum,
                         void* stream);
+/* RealNVP log-density of the RLE pose loss (mmdet3d/models/losses/real_nvp.py:60-80 `log_prob`, called from
+ * das_head.py:425-446 on (pred - gt) / sigma of every positive x joint). x f32[N][D], D = 3 (or 2); `layers`
+ * coupling layers, mask bit (i*D + d) of mask_bits = mask[i][d] (1 = passed through). params f32: per layer
+ * [t-net | s-net], net = W1[64][D] b1[64] W2[64][64] b2[64] W3[D][64] b3[D] (nn.Linear layouts; LeakyReLU(0.01)
+ * between, Tanh after the s-net). Outputs: logp f32[N] and the final latent z f32[N][D] (all the backward
+ * needs: the coupling layers are inverted on the way back).
+ * Backward: grad_logp f32[N] -> dx f32[N][D] and dparams (same layout as params, zeroed by the call). */
+int das_realnvp_log_prob(const float* x, int N, int D, const float* params, int layers, unsigned mask_bits,
+                         float* logp, float* z_out, void* stream);
+int das_realnvp_log_prob_backward(const float* z_final, const float* grad_logp, int N, int D, const float* params,
+                                  int layers, unsigned mask_bits, float* dx, float* dparams, void* stream);
+
 /* out (+)= sum g^2 over a flat f32 gradient buffer (global-norm clipping, exp_panoptic.py:204-205). */
 int das_grad_sumsq(const float* g, long long n, float* out, int zero_first, void* stream);
 /* torch.optim.SGD step (momentum, weight decay) on flat f32 buffers with the clip coefficient
