@@ -61,7 +61,7 @@ SIGNATURES = {
     'das_conv2d_wgrad_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), i32, vp]),
     'das_pack_conv_weights': (i32, [vp, vp, vp, i32, vp, i32, i32, vp]),
     'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
-    'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
     'das_groupnorm_backward': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp,
                                      vp, vp, vp]),
     'das_maxpool3x3s2_backward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -90,7 +90,7 @@ SIGNATURES = {
     'das_smooth_l1_loss': (i32, [vp, vp, i64, f32, vp, vp, vp]),
     'das_bce_logits_loss': (i32, [vp, vp, i64, vp, vp, vp]),
     'das_realnvp_log_prob': (i32, [vp, i32, i32, vp, i32, C.c_uint, vp, vp, vp]),
-    'das_realnvp_log_prob_backward': (i32, [vp, vp, i32, i32, vp, i32, C.c_uint, vp, vp, vp]),
+    'das_realnvp_log_prob_backward': (i32, [vp, vp, i32, i32, vp, i32, C.c_uint, vp, vp, vp, vp]),
     'das_grad_sumsq': (i32, [vp, i64, vp, i32, vp]),
     'das_sgd_momentum_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]),
     'das_decode_cap': (i32, [C.POINTER(DasDecodeDesc)]),

@@ -156,7 +156,8 @@ template <int D>
 __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict__ zfin, const float* __restrict__ glogp,
                                                          int N, const float* __restrict__ params, int layers,
                                                          unsigned mask_bits, float* __restrict__ dx,
-                                                         float* __restrict__ dparams) {
+                                                         float* __restrict__ dparams,
+                                                         float* const* __restrict__ dst_table) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* buf0 = sm;                       // [FR][FH]
   float* buf1 = buf0 + FR * FH;           // [FR][FH]
@@ -209,7 +210,16 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int d = 0; d < D; ++d) d3[d] = 0.f;
       }
-      float* gp = dparams + (size_t)(i * 2 + which) * Net<D>::SIZE;
+      // gradient destinations of this net's six tensors: slices of dparams, or the caller's table of
+      // pointers (the optimizer's flat gradient buffer: accumulate in place)
+      float* gp = dparams ? dparams + (size_t)(i * 2 + which) * Net<D>::SIZE : nullptr;
+      float* const* tb = dst_table ? dst_table + (i * 2 + which) * 6 : nullptr;
+      float* gW1 = tb ? tb[0] : gp + Net<D>::W1;
+      float* gB1 = tb ? tb[1] : gp + Net<D>::B1;
+      float* gW2 = tb ? tb[2] : gp + Net<D>::W2;
+      float* gB2 = tb ? tb[3] : gp + Net<D>::B2;
+      float* gW3 = tb ? tb[4] : gp + Net<D>::W3;
+      float* gB3 = tb ? tb[5] : gp + Net<D>::B3;
       // ---- layer 3: dW3 = sum_r d3 (x) h2
 #pragma unroll
       for (int k = 0; k < FH; ++k) buf1[tid * FH + k] = Bv[k];
@@ -223,12 +233,12 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
         const int c = tid / FH, k = tid - c * FH;
         float acc = 0.f;
         for (int rr = 0; rr < FR; ++rr) acc += sm3[rr * 4 + c] * buf1[rr * FH + k];
-        atomicAdd(gp + Net<D>::W3 + c * FH + k, acc);
+        atomicAdd(gW3 + c * FH + k, acc);
       } else if (tid < D * FH + D) {
         const int c = tid - D * FH;
         float acc = 0.f;
         for (int rr = 0; rr < FR; ++rr) acc += sm3[rr * 4 + c];
-        atomicAdd(gp + Net<D>::B3 + c, acc);
+        atomicAdd(gB3 + c, acc);
       }
       // delta2 = (W3^T d3) * lrelu'(a2)   (sign(a2) = sign(h2)), overwriting h2
 #pragma unroll
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
 #pragma unroll
       for (int k = 0; k < FH; ++k) { buf0[tid * FH + k] = A[k]; buf1[tid * FH + k] = Bv[k]; }
       __syncthreads();
-      reduce_w2(buf0, buf1, gp + Net<D>::W2, gp + Net<D>::B2);
+      reduce_w2(buf0, buf1, gW2, gB2);
       // delta1 = (W2^T delta2) * lrelu'(a1), overwriting h1
       unsigned long long pos = 0ull;
 #pragma unroll
@@ -281,12 +291,12 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
         const int k = tid / D, d = tid - k * D;
         float acc = 0.f;
         for (int rr = 0; rr < FR; ++rr) acc += buf0[rr * FH + k] * smz[rr * 4 + d];
-        atomicAdd(gp + Net<D>::W1 + k * D + d, acc);
+        atomicAdd(gW1 + k * D + d, acc);
       } else if (tid < FH * D + FH) {
         const int k = tid - FH * D;
         float acc = 0.f;
         for (int rr = 0; rr < FR; ++rr) acc += buf0[rr * FH + k];
-        atomicAdd(gp + Net<D>::B1 + k, acc);
+        atomicAdd(gB1 + k, acc);
       }
 #pragma unroll
       for (int d = 0; d < D; ++d) {
@@ -340,8 +350,8 @@ extern "C" int das_realnvp_log_prob(const float* x, int N, int D, const float* p
 
 extern "C" int das_realnvp_log_prob_backward(const float* z_final, const float* grad_logp, int N, int D,
                                              const float* params, int layers, unsigned mask_bits, float* dx,
-                                             float* dparams, void* stream) {
-  if (!z_final || !grad_logp || !params || !dx || !dparams || N < 1 || layers < 1 || layers * D > 32 ||
+                                             float* dparams, float* const* dst_table, void* stream) {
+  if (!z_final || !grad_logp || !params || !dx || (!dparams == !dst_table) || N < 1 || layers < 1 || layers * D > 32 ||
       (D != 2 && D != 3))
     return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -355,13 +365,13 @@ extern "C" int das_realnvp_log_prob_backward(const float* z_final, const float* 
     attr_set = true;
   }
   if (D == 3) {
-    if (hipMemsetAsync(dparams, 0, sizeof(float) * 2 * layers * Net<3>::SIZE, s) != hipSuccess) return DAS_ERR_LAUNCH;
+    if (dparams && hipMemsetAsync(dparams, 0, sizeof(float) * 2 * layers * Net<3>::SIZE, s) != hipSuccess) return DAS_ERR_LAUNCH;
     hipLaunchKernelGGL(realnvp_bwd_kernel<3>, dim3(blocks), dim3(FR), bwd_smem<3>(), s, z_final, grad_logp, N, params,
-                       layers, mask_bits, dx, dparams);
+                       layers, mask_bits, dx, dparams, dst_table);
   } else {
-    if (hipMemsetAsync(dparams, 0, sizeof(float) * 2 * layers * Net<2>::SIZE, s) != hipSuccess) return DAS_ERR_LAUNCH;
+    if (dparams && hipMemsetAsync(dparams, 0, sizeof(float) * 2 * layers * Net<2>::SIZE, s) != hipSuccess) return DAS_ERR_LAUNCH;
     hipLaunchKernelGGL(realnvp_bwd_kernel<2>, dim3(blocks), dim3(FR), bwd_smem<2>(), s, z_final, grad_logp, N, params,
-                       layers, mask_bits, dx, dparams);
+                       layers, mask_bits, dx, dparams, dst_table);
   }
   DAS_CHECK_LAUNCH();
   return DAS_OK;

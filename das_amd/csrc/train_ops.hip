@@ -490,14 +490,14 @@ extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int p
 
 extern "C" int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
                                      const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                     int relu, void* draw, void* dres, float* sums, float* dgamma_acc,
-                                     float* dbeta_acc, void* stream) {
+                                     int relu, void* draw, void* dres, float* sums, int sums_prezeroed,
+                                     float* dgamma_acc, float* dbeta_acc, void* stream) {
   if (!dy || !raw || !mean || !invstd || !gamma || !draw || !sums || rows <= 0 || C % 8 || C > 2048) return DAS_ERR_ARG;
   if (relu && !y && !beta) return DAS_ERR_ARG;
   if ((dgamma_acc == nullptr) != (dbeta_acc == nullptr)) return DAS_ERR_ARG;
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (!sums_prezeroed && hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int mask = !relu ? 0 : (y ? 1 : 2);
 #define DAS_BN_BWD(T, MASK)                                                                                       \
   launch_bn_backward<T, MASK>(dy, y, raw, rows, C, mean, invstd, gamma, beta, draw, dres, sums, dgamma_acc, dbeta_acc, s)

@@ -210,12 +210,17 @@ def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta=Non
     rows = raw.numel() // Cc
     draw = torch.empty_like(raw)
     dres = torch.empty_like(raw) if want_dres else None
-    sums = torch.empty(2 * Cc, dtype=torch.float32, device=raw.device)
+    if dgamma_acc is not None:
+        # the sums are scratch here (the gradients go to the accumulators): a slice of the zeroed arena
+        from .nn import zeroed_stats
+        sums, prezeroed = zeroed_stats(2 * Cc, raw.device), 1
+    else:
+        sums, prezeroed = torch.empty(2 * Cc, dtype=torch.float32, device=raw.device), 0
     assert not (relu and y is None and want_dres), 'the recomputed mask ignores a residual'
     _lib.check(_lib.load().das_bn_train_backward(_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean),
                                                  _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _ptr(draw),
-                                                 _ptr(dres), _ptr(sums), _ptr(dgamma_acc), _ptr(dbeta_acc),
-                                                 _stream()), 'das_bn_train_backward')
+                                                 _ptr(dres), _ptr(sums), prezeroed, _ptr(dgamma_acc),
+                                                 _ptr(dbeta_acc), _stream()), 'das_bn_train_backward')
     return draw, dres, sums[Cc:], sums[:Cc]
 
 

@@ -127,47 +127,67 @@ class RealNVPLogProbFn(Function):
     (flow_param_list), passed as inputs so that autograd delivers their gradients."""
 
     @staticmethod
-    def forward(ctx, x, layers, mask_bits, *plist):
+    def forward(ctx, x, layers, mask_bits, packed, table, *plist):
         _need_gpu(x)
         x = x.contiguous().float()
         N, D = x.shape
-        params = torch.cat([p.detach().reshape(-1).float() for p in plist])
+        params = packed if packed is not None else torch.cat([p.detach().reshape(-1).float() for p in plist])
         logp = torch.empty(N, dtype=torch.float32, device=x.device)
         z = torch.empty(N, D, dtype=torch.float32, device=x.device)
         _lib.check(_lib.load().das_realnvp_log_prob(_ptr(x), N, D, _ptr(params), layers, mask_bits, _ptr(logp), _ptr(z),
                                                     _stream()), 'das_realnvp_log_prob')
         ctx.save_for_backward(z, params)
-        ctx.cfg = (layers, mask_bits, [p.shape for p in plist])
+        ctx.cfg = (layers, mask_bits, plist, table)
         return logp
 
     @staticmethod
     def backward(ctx, g):
         z, params = ctx.saved_tensors
-        layers, mask_bits, shapes = ctx.cfg
+        layers, mask_bits, plist, table = ctx.cfg
         N, D = z.shape
         g = g.contiguous().float()
         dx = torch.empty_like(z)
+        if table is not None:
+            # the optimizer's flat gradient: the kernel adds every tensor's gradient in place
+            _lib.check(_lib.load().das_realnvp_log_prob_backward(_ptr(z), _ptr(g), N, D, _ptr(params), layers,
+                                                                 mask_bits, _ptr(dx), None, _ptr(table), _stream()),
+                       'das_realnvp_log_prob_backward')
+            for p in plist:
+                p._das_slot.fired()
+            return (dx, None, None, None, None) + (None,) * len(plist)
         dparams = torch.empty_like(params)
         _lib.check(_lib.load().das_realnvp_log_prob_backward(_ptr(z), _ptr(g), N, D, _ptr(params), layers, mask_bits,
-                                                             _ptr(dx), _ptr(dparams), _stream()),
+                                                             _ptr(dx), _ptr(dparams), None, _stream()),
                    'das_realnvp_log_prob_backward')
         grads, off = [], 0
-        for s in shapes:
-            n = 1
-            for v in s:
-                n *= v
-            grads.append(dparams[off:off + n].view(s))
+        for p in plist:
+            n = p.numel()
+            grads.append(dparams[off:off + n].view(p.shape))
             off += n
-        return (dx, None, None) + tuple(grads)
+        return (dx, None, None, None, None) + tuple(grads)
 
 
 def realnvp_log_prob(flow, x):
-    """RealNVP.log_prob (real_nvp.py:60-80) through the fused kernels."""
+    """RealNVP.log_prob (real_nvp.py:60-80) through the fused kernels. The flow's 72 tensors are packed into the
+    kernel's layout once per optimizer step; with the flat optimizer the backward kernel adds their gradients
+    straight into the flat gradient buffer (table of destination pointers)."""
     if x.shape[0] == 0:
         return x.new_zeros(0)
-    cache = flow.__dict__.get('_das_flow')
-    if cache is None:
-        cache = (flow_param_list(flow), flow_mask_bits(flow))
-        flow.__dict__['_das_flow'] = cache
-    plist, bits = cache
-    return RealNVPLogProbFn.apply(x, len(flow.t), bits, *plist)
+    from .nn import PARAM_EPOCH
+    c = flow.__dict__.get('_das_flow')
+    if c is None:
+        c = dict(plist=flow_param_list(flow), bits=flow_mask_bits(flow), epoch=None, packed=None, table=None, tkey=None)
+        flow.__dict__['_das_flow'] = c
+    plist = c['plist']
+    if c['epoch'] != PARAM_EPOCH[0] or c['packed'] is None or c['packed'].device != x.device:
+        with torch.no_grad():
+            c['packed'] = torch.cat([p.detach().reshape(-1).float() for p in plist])
+        c['epoch'] = PARAM_EPOCH[0]
+    table = None
+    if torch.is_grad_enabled() and all(getattr(p, '_das_slot', None) is not None and p.grad is not None for p in plist):
+        key = tuple(p.grad.data_ptr() for p in plist)
+        if c['tkey'] != key:
+            c['table'] = torch.tensor(key, dtype=torch.int64, device=x.device)
+            c['tkey'] = key
+        table = c['table']
+    return RealNVPLogProbFn.apply(x, len(flow.t), c['bits'], c['packed'], table, *plist)

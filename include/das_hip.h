@@ -103,7 +103,10 @@ int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, 
  * parameter-gradient accumulators that the sums are added to. */
 int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
                           const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
-                          void* draw, void* dres, float* sums, float* dgamma_acc, float* dbeta_acc, void* stream);
+                          void* draw, void* dres, float* sums, int sums_prezeroed, float* dgamma_acc,
+                          float* dbeta_acc, void* stream);
+/* (sums_prezeroed != 0: the caller hands sums already zero-filled — e.g. a slice of a larger scratch cleared
+ * once — and the call skips its own memset.) */
 
 /* All conv weights of the network packed in one launch, once per optimizer step. flat_src: the optimizer's
  * f32 master buffer, conv weights stored as (Cout,KH,KW,Cin) (the forward operand layout). For every table
@@ -265,11 +268,15 @@ int das_bce_logits_loss(const float* logits, const float* target, long long n, f
  * [t-net | s-net], net = W1[64][D] b1[64] W2[64][64] b2[64] W3[D][64] b3[D] (nn.Linear layouts; LeakyReLU(0.01)
  * between, Tanh after the s-net). Outputs: logp f32[N] and the final latent z f32[N][D] (all the backward
  * needs: the coupling layers are inverted on the way back).
- * Backward: grad_logp f32[N] -> dx f32[N][D] and dparams (same layout as params, zeroed by the call). */
+ * Backward: grad_logp f32[N] -> dx f32[N][D] and the parameter gradients, delivered EITHER into dparams
+ * (same layout as params, zeroed by the call) OR added in place through dst_table, a device array of
+ * 2*layers*6 pointers (one per tensor in the params order: the optimizer's flat-gradient slices). Exactly one
+ * of dparams / dst_table is non-NULL. */
 int das_realnvp_log_prob(const float* x, int N, int D, const float* params, int layers, unsigned mask_bits,
                          float* logp, float* z_out, void* stream);
 int das_realnvp_log_prob_backward(const float* z_final, const float* grad_logp, int N, int D, const float* params,
-                                  int layers, unsigned mask_bits, float* dx, float* dparams, void* stream);
+                                  int layers, unsigned mask_bits, float* dx, float* dparams,
+                                  float* const* dst_table, void* stream);
 
 /* out (+)= sum g^2 over a flat f32 gradient buffer (global-norm clipping, exp_panoptic.py:204-205). */
 int das_grad_sumsq(const float* g, long long n, float* out, int zero_first, void* stream);
