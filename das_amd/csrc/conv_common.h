@@ -30,6 +30,29 @@ struct ConvP {
   int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];
 };
 
+// ---- LDS-DMA through a buffer descriptor (inline asm: the compiler must not wait for it, cdna guide 5.7)
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+// Raw buffer descriptor (wave-uniform): base, num_records = bytes, stride 0.
+__device__ __forceinline__ v4i_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  v4i_t r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+// Lane l's 16 bytes at byte offset `voff` land at lds_byte_addr + 16*l (M0 = LDS destination of lane 0,
+// restored afterwards); offsets >= num_records deliver zeros (probe: tools/dev/probe/buf_lds_probe.hip).
+// The caller owns the vmcnt accounting.
+__device__ __forceinline__ void dma16_buf(unsigned voff, v4i_t rsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(rsrc), "s"(lds_byte_addr)
+               : "memory");
+}
+
 template <typename T>
 __device__ __forceinline__ uint4 relu_vec(uint4 v);
 template <>

@@ -18,6 +18,7 @@
 // A "ragged multi-level" mode (nlev > 1) lets one launch cover all FPN levels of the shared-weight
 // head convs: rows of level l start at lvStart[l] and carry their own (H, W).
 #include <algorithm>
+#include <cstdlib>
 
 #include "conv_common.h"
 
@@ -150,26 +151,7 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
 // Same DMA issued from inline asm: hipcc does not track it, so it inserts no `s_waitcnt vmcnt(0)` in front
 // of the next ds_read (it does for the builtin: an LDS-DMA is a pending LDS write to its alias analysis).
 // The caller owns the vmcnt accounting. M0 = LDS destination of lane 0; restored afterwards.
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-// Raw buffer descriptor (wave-uniform): base, num_records = bytes, stride 0.
-__device__ __forceinline__ v4i_t make_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  v4i_t r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
-  r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
-  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-  r.w = 0x00020000;
-  return r;
-}
-// LDS-DMA through a buffer descriptor: lane l's 16 bytes at byte offset `voff` land at lds_byte_addr + 16*l;
-// offsets >= num_records deliver zeros. Same vmcnt / M0 rules as dma16_asm.
-__device__ __forceinline__ void dma16_buf(unsigned voff, v4i_t rsrc, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(rsrc), "s"(lds_byte_addr)
-               : "memory");
-}
+// (make_rsrc / dma16_buf, the buffer-descriptor form, live in conv_common.h: the weight-gradient kernel uses them too)
 __device__ __forceinline__ void dma16_asm(const void* src, unsigned lds_byte_addr) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -416,7 +398,10 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   ConvP p = p0;
   p.ntiles = (p.Cout + BN - 1) / BN;
   // 256-row tiles (8 waves, weight tile shared by twice the pixels) once they still fill the chip twice over
+  static const char* dev_mink = getenv("DAS_DEV_BIG_MINK");  // tuning only
+  const int mink = dev_mink ? atoi(dev_mink) : 0;
   const bool big = glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((p.M + 255) / 256) * p.ntiles >= 384 &&
+                   p.K >= mink &&
                    p.xbytes != 0;  // (0 = more than 4 GiB of input: not addressable by 32-bit buffer offsets)
   const int bm = big ? 256 : BM;
   const int mtiles = (p.M + bm - 1) / bm;

@@ -9,7 +9,11 @@ shapes = [  # B,H,W,Cin,Cout,k,s
     (8, 128, 208, 64, 64, 3, 1), (8, 64, 104, 128, 128, 3, 1), (8, 32, 52, 1024, 256, 1, 1),
     (8, 32, 52, 256, 1024, 1, 1), (8, 16, 26, 512, 512, 3, 1), (8, 64, 104, 256, 32, 3, 1),
     (8, 128, 208, 256, 512, 1, 2), (8, 64, 104, 256, 768, 3, 1),
+    (8, 128, 208, 256, 256, 1, 1), (8, 64, 104, 128, 512, 1, 1), (8, 64, 104, 512, 128, 1, 1),
+    (8, 64, 104, 512, 256, 1, 1), (8, 16, 26, 512, 2048, 1, 1), (8, 16, 26, 2048, 512, 1, 1),
 ]
+if len(sys.argv) > 1:
+    shapes = [(int(sys.argv[1]),) + sh[1:] for sh in shapes]
 torch.manual_seed(0)
 for (B, H, W, Cin, Cout, k, s) in shapes:
     x = torch.randn(B, H, W, Cin, device='cuda', dtype=torch.bfloat16)
