@@ -93,13 +93,14 @@ __device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4
 template <int BN, int BMT = 128>
 struct Tiling {
   static constexpr int NT = BMT * 2;               // threads per workgroup
-  static constexpr int TM = (BN == 128) ? 4 : 2;   // 16-row pixel tiles per wave
-  static constexpr int TN = (BN >= 64) ? 4 : 2;    // 16-row channel tiles per wave
+  static constexpr int TM = (BN == 256) ? 8 : (BN == 128) ? 4 : 2;   // 16-row pixel tiles per wave
+  static constexpr int TN = (BN >= 64) ? 4 : 2;                      // 16-row channel tiles per wave
+  // BN = 256 (with BMT = 256): 2 x 4 waves of 128 pixels x 64 channels
   static __device__ __forceinline__ int wave_m0(int wave) {
-    return BMT == 256 ? (wave & 3) * 64 : ((BN == 128) ? (wave & 1) * 64 : wave * 32);
+    return BN == 256 ? (wave & 1) * 128 : BMT == 256 ? (wave & 3) * 64 : ((BN == 128) ? (wave & 1) * 64 : wave * 32);
   }
   static __device__ __forceinline__ int wave_n0(int wave) {
-    return BMT == 256 ? (wave >> 2) * 64 : ((BN == 128) ? (wave >> 1) * 64 : 0);
+    return BN == 256 ? (wave >> 1) * 64 : BMT == 256 ? (wave >> 2) * 64 : ((BN == 128) ? (wave >> 1) * 64 : 0);
   }
 };
 

@@ -392,6 +392,125 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
 }
 
+// =============================================================== 4-stage pipeline, 256 x 256 tile, 8 waves
+// At the 256 x 128 tile the MFMA-bound layers sit on the L2 -> LDS path: one K-step of 64 moves 48 KiB per
+// workgroup for 256*128*64 MACs, ~29 TB/s chip-wide at the full MFMA rate. The square tile moves 32 KiB per
+// 256*256*32 MACs (1.5x fewer bytes per MAC). K-steps of 32 (64-byte rows) keep a stage at 32 KiB, so four
+// stages fit (128 KiB) and the DMAs run three steps ahead; each wave owns 128 pixels x 64 channels (8 x 4
+// MFMA tiles, 128 accumulator registers). Wait / barrier scheme as in conv_glds3_kernel with 4 DMAs per wave
+// and stage. Needs Cin % 32 == 0; used for Cout >= 256.
+template <typename T, typename OT>
+__global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
+  constexpr int BN = 256, BMT = 256, NBUF = 4;
+  constexpr int EPV = Elem<T>::EPV;
+  constexpr int BK = 4 * EPV;  // 64-byte rows
+  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN;
+  constexpr int A_BYTES = BMT * 64, W_BYTES = BN * 64, BUF = A_BYTES + W_BYTES;
+  constexpr int A_INSTR = 2, W_INSTR = 2;  // 16 rows x 64 B per wave-instruction
+  constexpr unsigned E = sizeof(T);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int logical = xcd_remap(blockIdx.x, p.nblocks);
+  const int n0 = (logical % p.ntiles) * BN;
+  const int m0 = (logical / p.ntiles) * BMT;
+  const int wave_m0 = Tiling<BN, BMT>::wave_m0(wave), wave_n0 = Tiling<BN, BMT>::wave_n0(wave);
+
+  const int lrow = lane >> 2, pslot = lane & 3;
+  const v4i_t xrs = make_rsrc(p.x, p.xbytes), wrs = make_rsrc(p.w, (unsigned)((long long)p.Cout * p.K * E));
+  unsigned acur[A_INSTR], arowstep[A_INSTR];
+  int ahi[A_INSTR], awi[A_INSTR], aH[A_INSTR], aW[A_INSTR];
+  bool aok[A_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int row = (wave * A_INSTR + j) * 16 + lrow;
+    const RowGeom g = row_geom(p, m0 + row);
+    const int akg = (pslot ^ ((-(row >> 2)) & 3)) * EPV;   // logical k-group stored at this physical slot
+    acur[j] = (unsigned)(((g.pix0 + (long long)g.hi0 * g.W + g.wi0) * p.xps + akg) * (long long)E);
+    arowstep[j] = (unsigned)g.W * (unsigned)p.xps * E;
+    ahi[j] = g.hi0; awi[j] = g.wi0; aH[j] = g.H; aW[j] = g.W;
+    aok[j] = (unsigned)g.hi0 < (unsigned)g.H && (unsigned)g.wi0 < (unsigned)g.W;
+  }
+  unsigned wcur[W_INSTR];
+#pragma unroll
+  for (int j = 0; j < W_INSTR; ++j) {
+    const int row = (wave * W_INSTR + j) * 16 + lrow;
+    wcur[j] = (unsigned)(((long long)(n0 + row) * p.K + (pslot ^ ((-(row >> 2)) & 3)) * EPV) * E);  // rows >= Cout: out of range
+  }
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  int f_kh = 0, f_kw = 0, f_ci = 0;
+  const unsigned dA = BK * E, dB = (unsigned)(p.xps - p.Cin + BK) * E;
+  const unsigned dC = 0u - (unsigned)(p.KW - 1) * (unsigned)p.xps * E - (unsigned)(p.Cin - BK) * E;  // + rowstep
+  auto issue = [&](int buf) {
+    const unsigned sA = lds0 + buf * BUF, sW = sA + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) dma16_buf(aok[j] ? acur[j] : OOB, xrs, sA + (wave * A_INSTR + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) {
+      dma16_buf(wcur[j], wrs, sW + (wave * W_INSTR + j) * 1024);
+      wcur[j] += BK * E;
+    }
+    f_ci += BK;
+    if (f_ci < p.Cin) {
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) acur[j] += dA;
+    } else {  // next tap (wave-uniform branch)
+      f_ci = 0;
+      const bool wrap = ++f_kw == p.KW;
+      if (wrap) { f_kw = 0; ++f_kh; }
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) {
+        acur[j] += wrap ? arowstep[j] + dC : dB;
+        aok[j] = (unsigned)(ahi[j] + f_kh) < (unsigned)aH[j] && (unsigned)(awi[j] + f_kw) < (unsigned)aW[j];
+      }
+    }
+  };
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  const int frow = lane & 15, fkg = lane >> 4;
+  int buf = 0, nbuf = 3;  // buffer of tile kt, buffer tile kt+3 goes to
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt landed; the (up to two) younger tiles, 4 DMAs per wave each, may still fly
+    if (kt + 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + 3 < nk) issue(nbuf);
+    const char* sA = smem + buf * BUF;
+    const char* sW = sA + A_BYTES;
+    uint4 fb[TM], fa[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fa[i] = *reinterpret_cast<const uint4*>(sW + slot64(wave_n0 + i * 16 + frow, fkg));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fb[i] = *reinterpret_cast<const uint4*>(sA + slot64(wave_m0 + i * 16 + frow, fkg));
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int a = 0; a < TN; ++a) mma<T>(fa[a], fb[b], acc[a][b]);
+    buf = buf == NBUF - 1 ? 0 : buf + 1;
+    nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
+  }
+  __syncthreads();  // all LDS reads done before the C tile reuses the buffers
+  conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
+}
+
 // =============================================================== launch
 template <typename T, typename OT, int BN>
 int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
@@ -431,8 +550,37 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   return DAS_OK;
 }
 
+// 256 x 256 tile kernel: bf16 in / bf16 out, Cout >= 256, Cin % 32 == 0, enough tiles to cover the chip
+template <typename T, typename OT>
+bool try_launch4(const ConvP& p0, hipStream_t s) {
+  if constexpr (sizeof(T) == 2 && sizeof(OT) == 2) {
+    static const char* dev4 = getenv("DAS_DEV_GLDS4_MINBLOCKS");  // tuning only (0 disables)
+    const long long minblocks = dev4 ? atoll(dev4) : 128;  // half a chip of 256 x 256 tiles (measured break-even)
+    ConvP p = p0;
+    p.ntiles = (p.Cout + 255) / 256;
+    const long long nb = (long long)((p.M + 255) / 256) * p.ntiles;
+    if (minblocks <= 0 || p.Cout < 256 || p.Cin % 32 || p.relu_in || p.up_sh != 0 || p.xbytes == 0 || nb < minblocks)
+      return false;
+    p.nblocks = (int)nb;
+    const size_t sm4 = std::max<size_t>(4 * (size_t)(256 + 256) * 64, epilogue_smem_bytes<OT, 256, 256>());
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_glds4_kernel<T, OT>), dim3(p.nblocks), dim3(512), sm4, s, p);
+    return true;
+  } else {
+    return false;
+  }
+}
+
 template <typename T, typename OT>
 int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
+  if (try_launch4<T, OT>(p, s)) {
+    DAS_CHECK_LAUNCH();
+    return DAS_OK;
+  }
   if (p.Cout > 64) return launch<T, OT, 128>(p, glds, aligned, s);
   if (p.Cout > 32) return launch<T, OT, 64>(p, glds, aligned, s);
   return launch<T, OT, 32>(p, glds, aligned, s);

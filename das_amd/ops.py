@@ -283,7 +283,11 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         # mirrors the dispatch in conv_igemm.hip::launch so that tags equal the rocprof kernel names
         big = (glds and bn == 128 and out_dtype == torch.bfloat16 and in_up == 1 and
                ((rows + 255) // 256) * ((Cout + 127) // 128) >= 384)
-        if big:
+        sq = (xd.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and Cout >= 256 and Cin % 32 == 0 and
+              not relu_in and in_up == 1 and ((rows + 255) // 256) * ((Cout + 255) // 256) >= 128)
+        if sq:
+            tag = 'conv_glds4_kernel<bf16, bf16>'
+        elif big:
             tag = f'conv_glds3_kernel<{short[xd.dtype]}, {short[out_dtype]}>'
         else:
             tag = f'{"conv_glds_kernel" if glds else "conv_reg_kernel"}<{short[xd.dtype]}, {short[out_dtype]}, {bn}' + \
