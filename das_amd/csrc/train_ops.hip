@@ -102,9 +102,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = (p.K + 127) / 128;
-  const int o0 = (blockIdx.x / ntiles) * 128, n0 = (blockIdx.x % ntiles) * 128;
+  // XCD-aware order: all (Cout, K) tiles of one pixel chunk get consecutive logical ids, i.e. run on the same
+  // XCD at the same time, so the chunk's dY / X rows are fetched into ONE L2 instead of eight
+  const int tiles = gridDim.x;
+  const int logical = xcd_remap(blockIdx.x + blockIdx.y * tiles, tiles * gridDim.y);
+  const int tile = logical % tiles, chunk = logical / tiles;
+  const int o0 = (tile / ntiles) * 128, n0 = (tile % ntiles) * 128;
   const int wave_o0 = (wave >> 1) * 64, wave_n0 = (wave & 1) * 64;
-  const long long m_begin = (long long)blockIdx.y * steps_per_block * BKM;
+  const long long m_begin = (long long)chunk * steps_per_block * BKM;
 
   const T* xg = reinterpret_cast<const T*>(p.x);
   const T* dyg = reinterpret_cast<const T*>(p.res);
