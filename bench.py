@@ -5,6 +5,7 @@ Workloads (BASELINE.json `configs`):
                               f32 master weights, batch 16 x 3x512x832 synthetic frames + GT per GPU, one FULL
                               train step = forward + 4 losses + backward + gradient all-reduce (N>1) + clip + SGD.
   --workload infer            configs[1]: MSPN-50 1-stage, batch 8, forward + decode.
+  --workload decode           configs[4]: exp_mupots geometry (1024x768, J=21), decode + OKS-NMS only, 512 images/step.
 Inputs are resident in HBM when the timed region starts. N>1: one process per GPU (torchrun), independent
 per-rank batches (weak scaling); training exchanges gradients with RCCL all-reduce, inference has no collective.
 
@@ -181,12 +182,106 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
                                       launches=v[2] // reps) for k, v in fam.items()})
 
 
+def decode_workload(args, rank, world, dev):
+    """BASELINE configs[4]: exp_mupots geometry (1024x768 input, J=21, strides 8..64 -> 16 320 locations per
+    image), decode only: score / threshold / per-level top-k / OKS-NMS of `batch` images per step (one workgroup
+    per image). Synthetic eval-mode head outputs, calibrated to ~150 candidates per image above score_thr."""
+    import torch.distributed as dist
+    from das_amd import ops
+    Jm, HW = 21, [(96, 128), (48, 64), (24, 32), (12, 16)]
+    B = args.batch or 512
+    steps = args.steps or 20
+    warmup = args.warmup if args.warmup is not None else 3
+    g = torch.Generator(device='cpu').manual_seed(100 + rank)
+    cls, ctr, pose = [], [], []
+    for h, w in HW:
+        cls.append(torch.randn(B, h, w, 1, generator=g))
+        ctr.append(torch.randn(B, h, w, 1, generator=g) + 0.5)
+        p = torch.randn(B, h, w, 3 + 6 * Jm, generator=g)   # (depth, offsets, uvd, sigma) as the eval head emits
+        p[..., 3:3 + 3 * Jm] *= 30.0
+        p[..., 2] = p[..., 2].abs() * 0.2 + 0.2
+        pose.append(p)
+    # shift the class logits so that ~150 locations per image pass score_thr = 0.07
+    sc = torch.cat([(torch.sigmoid(c) * torch.sigmoid(t)).reshape(B, -1) for c, t in zip(cls, ctr)], 1)
+    lo, hi = -12.0, 4.0
+    for _ in range(30):
+        mid = 0.5 * (lo + hi)
+        n = float(sum(((torch.sigmoid(c + mid) * torch.sigmoid(t)) > 0.07).sum() for c, t in zip(cls, ctr))) / B
+        lo, hi = (mid, hi) if n < 150 else (lo, mid)
+    del sc
+    cls = [(c + lo).to(dev).contiguous() for c in cls]
+    ctr = [t.to(dev).contiguous() for t in ctr]
+    pose = [p.to(dev).contiguous() for p in pose]
+    sf = torch.ones(B, 2, dtype=torch.float32, device=dev)
+    strides = [8, 16, 32, 64]
+
+    def step():
+        return ops.decode(cls, ctr, pose, strides, sf, Jm, 1000, 100, 0.07, 0.9)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        out = step()
+    sync_all()
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = step()
+        e1.record()
+        evs.append((e0, e1))
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        return
+    kern_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / steps     # events bracket the launch on its stream
+    nloc = sum(h * w for h, w in HW)
+    bytes_img = nloc * (1 + 1 + 3 + 3 * Jm) * 4                        # every logit / pose value read once
+    poses = int(out['count'].sum().item())
+    line = {
+        'metric': 'imgs/sec decode', 'value': round(B * world * steps / dt, 1), 'unit': 'img/s', 'n_gpus': world,
+        'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[4]: exp_mupots geometry, 1024x768 input, J={Jm}, {nloc} locations/img, '
+                               f'decode only (threshold, top-k 1000 per level, OKS-NMS 0.9, keep 100), batch {B} per GPU',
+                   'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'replicas{world}'},
+        'poses_per_sec': round(poses * world * steps / dt, 1), 'poses_per_step_rank0': poses,
+        'roofline': {'bound': 'hbm', 'kernel': 'decode_kernel', 'achieved': round(bytes_img * B / kern_s / 1e9, 1),
+                     'peak': 8000.0, 'unit': 'GB/s', 'frac': round(bytes_img * B / kern_s / 8e12, 4), 'traffic': None,
+                     'avg_launch_us': round(kern_s * 1e6, 1),
+                     'note': 'one 1024-thread workgroup per image: a sort / NMS latency chain, not a streaming kernel'},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import decode as OD
+        n, t0 = 0, time.perf_counter()
+        while n < 4 or (time.perf_counter() - t0 < 10.0 and n < 64):
+            b = n % B
+            OD.get_poses([c[b:b + 1].permute(0, 3, 1, 2).cpu() for c in cls],
+                         [p[b:b + 1].permute(0, 3, 1, 2).cpu() for p in pose],
+                         [t[b:b + 1].permute(0, 3, 1, 2).cpu() for t in ctr],
+                         [dict(scale_factor=np.ones(4, dtype=np.float32), filename='')], Jm, strides,
+                         dict(nms_pre=1000, nms_post=100, nms_thr=0.9, score_thr=0.07))
+            n += 1
+        line['cpu_baseline'] = dict(value=round(n / (time.perf_counter() - t0), 2), unit='img/s', cores=1, kind='port',
+                                    sample=f'{n} images, CPU oracle decode + OKS-NMS (numpy / python), 1 thread')
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
-    ap.add_argument('--workload', default='train', choices=['train', 'infer'])
+    ap.add_argument('--workload', default='train', choices=['train', 'infer', 'decode'])
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step (train 16, infer 8)')
     ap.add_argument('--stages', type=int, default=None, help='MSPN stages (train 4, infer 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -208,6 +303,12 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    if args.workload == 'decode':
+        decode_workload(args, rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from das_amd import ops
     from das_amd.datasets import SyntheticPoseDataset, collate
