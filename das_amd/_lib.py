@@ -30,6 +30,10 @@ class DasPackEntry(C.Structure):
     _fields_ = [('off', i64), ('O', i32), ('I', i32), ('KH', i32), ('KW', i32), ('tile_start', i32)]
 
 
+class DasFlowJob(C.Structure):
+    _fields_ = [('params', vp), ('dparams', vp), ('dst_table', vp), ('row_start', i32), ('row_end', i32)]
+
+
 class DasLevels(C.Structure):
     _fields_ = [('num_levels', i32), ('B', i32), ('H', i32 * 5), ('W', i32 * 5)]
 
@@ -90,6 +94,8 @@ SIGNATURES = {
     'das_smooth_l1_loss': (i32, [vp, vp, i64, f32, vp, vp, vp]),
     'das_bce_logits_loss': (i32, [vp, vp, i64, vp, vp, vp]),
     'das_realnvp_log_prob': (i32, [vp, i32, i32, vp, i32, C.c_uint, vp, vp, vp]),
+    'das_realnvp_log_prob_multi': (i32, [vp, i32, i32, C.POINTER(DasFlowJob), i32, i32, C.c_uint, vp, vp, vp]),
+    'das_realnvp_log_prob_multi_backward': (i32, [vp, vp, i32, i32, C.POINTER(DasFlowJob), i32, i32, C.c_uint, vp, vp]),
     'das_realnvp_log_prob_backward': (i32, [vp, vp, i32, i32, vp, i32, C.c_uint, vp, vp, vp, vp]),
     'das_grad_sumsq': (i32, [vp, i64, vp, i32, vp]),
     'das_sgd_momentum_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]),

@@ -6,7 +6,8 @@
 //                log p = -|z|^2/2 - D/2 log 2pi + logdet
 // The reference runs this as ~1000 tiny torch kernels per step; here it is two kernels (forward, backward)
 // over N = positives x joints rows:
-//   forward : one thread per row, the current net's weights broadcast from LDS, activations in registers.
+//   forward : one thread per row, activations in registers; every lane uses the same weights, so they are
+//             fetched with scalar loads (wave-uniform addresses) and the FMAs read them from SGPRs.
 //   backward: the coupling layers are invertible, so nothing but the final z is saved — each layer's input is
 //             recovered from its output while walking back. Per net: a row phase (thread = row: recompute the
 //             MLP, back-propagate) alternates with a weight phase (thread = 16 weights of W2, or one weight of
@@ -27,6 +28,20 @@ struct Net {
 };
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : SLOPE * v; }
+
+// Several flows (e.g. the `flow3d` and `flow3d_update` of the head) run in ONE launch: each job owns a
+// block-aligned range of rows and brings its own parameters / gradient destinations.
+struct FlowJobs {
+  int n;
+  DasFlowJob j[DAS_FLOW_MAX_JOBS];
+};
+__device__ __forceinline__ DasFlowJob job_of_block(const FlowJobs& jobs) {
+  const int row0 = blockIdx.x * FR;
+  int ji = 0;
+  for (int q = 1; q < DAS_FLOW_MAX_JOBS; ++q)
+    if (q < jobs.n && row0 >= jobs.j[q].row_start) ji = q;
+  return jobs.j[ji];
+}
 
 // a1 -> h1 -> a2 -> h2 -> out for one row; w = the net's parameters in LDS. zin: masked input (D values).
 template <int D>
@@ -76,21 +91,15 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ w, const f
   }
 }
 
-template <int D>
-__device__ __forceinline__ void stage_net(float* wl, const float* __restrict__ params, int layer, int which) {
-  const float* src = params + (size_t)(layer * 2 + which) * Net<D>::SIZE;
-  for (int i = threadIdx.x; i < Net<D>::SIZE; i += FR) wl[i] = src[i];
-}
-
 // ------------------------------------------------------------------ forward
 template <int D>
-__global__ __launch_bounds__(FR) void realnvp_fwd_kernel(const float* __restrict__ x, int N,
-                                                         const float* __restrict__ params, int layers,
+__global__ __launch_bounds__(FR) void realnvp_fwd_kernel(const float* __restrict__ x, FlowJobs jobs, int layers,
                                                          unsigned mask_bits, float* __restrict__ logp,
                                                          float* __restrict__ zout) {
-  __shared__ __attribute__((aligned(16))) float wl[(Net<D>::SIZE + 3) / 4 * 4];
+  const DasFlowJob job = job_of_block(jobs);
+  const float* __restrict__ params = job.params;
   const int r = blockIdx.x * FR + threadIdx.x;
-  const bool live = r < N;
+  const bool live = r >= job.row_start && r < job.row_end;
   float z[D], logdet = 0.f;
 #pragma unroll
   for (int d = 0; d < D; ++d) z[d] = live ? x[(size_t)r * D + d] : 0.f;
@@ -101,10 +110,9 @@ __global__ __launch_bounds__(FR) void realnvp_fwd_kernel(const float* __restrict
     for (int d = 0; d < D; ++d) zin[d] = ((m >> d) & 1u) ? z[d] : 0.f;
     for (int which = 1; which >= 0; --which) {   // s-net, then t-net (one inlined copy of the MLP code)
       float h1[FH], h2[FH], out[D];
-      __syncthreads();
-      stage_net<D>(wl, params, i, which);
-      __syncthreads();
-      mlp_forward<D>(wl, zin, h1, h2, out);
+      // every lane uses the same weights: wave-uniform addresses -> scalar loads, the FMAs take them from SGPRs
+      const float* w = params + (size_t)(i * 2 + which) * Net<D>::SIZE;
+      mlp_forward<D>(w, zin, h1, h2, out);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if (which == 1) s[d] = out[d]; else t[d] = out[d];
@@ -154,19 +162,20 @@ __device__ __forceinline__ void reduce_w2(const float* __restrict__ H1, const fl
 
 template <int D>
 __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict__ zfin, const float* __restrict__ glogp,
-                                                         int N, const float* __restrict__ params, int layers,
-                                                         unsigned mask_bits, float* __restrict__ dx,
-                                                         float* __restrict__ dparams,
-                                                         float* const* __restrict__ dst_table) {
+                                                         FlowJobs jobs, int layers, unsigned mask_bits,
+                                                         float* __restrict__ dx) {
+  const DasFlowJob job = job_of_block(jobs);
+  const float* __restrict__ params = job.params;
+  float* __restrict__ dparams = job.dparams;
+  float* const* __restrict__ dst_table = job.dst_table;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* buf0 = sm;                       // [FR][FH]
   float* buf1 = buf0 + FR * FH;           // [FR][FH]
-  float* wl = buf1 + FR * FH;             // net parameters
-  float* sm3 = wl + (Net<D>::SIZE + 3) / 4 * 4;   // [FR][4] delta3 rows
+  float* sm3 = buf1 + FR * FH;            // [FR][4] delta3 rows
   float* smz = sm3 + FR * 4;              // [FR][4] masked inputs
   const int tid = threadIdx.x;
   const int r = blockIdx.x * FR + tid;
-  const bool live = r < N;
+  const bool live = r >= job.row_start && r < job.row_end;
   const float g = live ? glogp[r] : 0.f;
   float z[D], dz[D];
 #pragma unroll
@@ -186,9 +195,9 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
     // two passes: s-net first (its output is needed to invert the layer), then t-net
     for (int which = 1; which >= 0; --which) {
       float A[FH], Bv[FH], out[D], d3[D];
-      __syncthreads();
-      stage_net<D>(wl, params, i, which);
-      __syncthreads();
+      // the net's weights: wave-uniform global addresses -> scalar loads (no LDS staging)
+      const float* wl = params + (size_t)(i * 2 + which) * Net<D>::SIZE;
+      __syncthreads();   // the previous net's weight phase has finished reading buf0 / smz
       mlp_forward<D>(wl, zin, A, Bv, out);       // A = h1, Bv = h2
       if (which == 1) {
 #pragma unroll
@@ -328,34 +337,52 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
 
 template <int D>
 constexpr size_t bwd_smem() {
-  return (size_t)(2 * FR * FH + (Net<D>::SIZE + 3) / 4 * 4 + 2 * FR * 4) * sizeof(float);
+  return (size_t)(2 * FR * FH + 2 * FR * 4) * sizeof(float);
 }
 
 }  // namespace
 
-extern "C" int das_realnvp_log_prob(const float* x, int N, int D, const float* params, int layers, unsigned mask_bits,
-                                    float* logp, float* z_out, void* stream) {
-  if (!x || !params || !logp || !z_out || N < 1 || layers < 1 || layers * D > 32 || (D != 2 && D != 3)) return DAS_ERR_ARG;
-  const int blocks = (N + FR - 1) / FR;
+static bool jobs_ok(const DasFlowJob* jobs, int njobs, int rows_total, bool backward) {
+  if (!jobs || njobs < 1 || njobs > DAS_FLOW_MAX_JOBS) return false;
+  for (int q = 0; q < njobs; ++q) {
+    const DasFlowJob& j = jobs[q];
+    if (!j.params || j.row_start % FR || j.row_start < 0 || j.row_end < j.row_start || j.row_end > rows_total) return false;
+    if (q > 0 && j.row_start < jobs[q - 1].row_end) return false;
+    if (backward && (!j.dparams == !j.dst_table)) return false;
+  }
+  return jobs[0].row_start == 0;
+}
+
+extern "C" int das_realnvp_log_prob_multi(const float* x, int rows_total, int D, const DasFlowJob* jobs, int njobs,
+                                          int layers, unsigned mask_bits, float* logp, float* z_out, void* stream) {
+  if (!x || !logp || !z_out || rows_total < 1 || layers < 1 || layers * D > 32 || (D != 2 && D != 3)) return DAS_ERR_ARG;
+  if (!jobs_ok(jobs, njobs, rows_total, false)) return DAS_ERR_ARG;
+  FlowJobs fj;
+  fj.n = njobs;
+  for (int q = 0; q < DAS_FLOW_MAX_JOBS; ++q) fj.j[q] = jobs[q < njobs ? q : 0];
+  const int blocks = (rows_total + FR - 1) / FR;
   if (D == 3) {
-    hipLaunchKernelGGL(realnvp_fwd_kernel<3>, dim3(blocks), dim3(FR), 0, (hipStream_t)stream, x, N, params, layers,
-                       mask_bits, logp, z_out);
+    hipLaunchKernelGGL(realnvp_fwd_kernel<3>, dim3(blocks), dim3(FR), 0, (hipStream_t)stream, x, fj, layers, mask_bits,
+                       logp, z_out);
   } else {
-    hipLaunchKernelGGL(realnvp_fwd_kernel<2>, dim3(blocks), dim3(FR), 0, (hipStream_t)stream, x, N, params, layers,
-                       mask_bits, logp, z_out);
+    hipLaunchKernelGGL(realnvp_fwd_kernel<2>, dim3(blocks), dim3(FR), 0, (hipStream_t)stream, x, fj, layers, mask_bits,
+                       logp, z_out);
   }
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }
 
-extern "C" int das_realnvp_log_prob_backward(const float* z_final, const float* grad_logp, int N, int D,
-                                             const float* params, int layers, unsigned mask_bits, float* dx,
-                                             float* dparams, float* const* dst_table, void* stream) {
-  if (!z_final || !grad_logp || !params || !dx || (!dparams == !dst_table) || N < 1 || layers < 1 || layers * D > 32 ||
-      (D != 2 && D != 3))
+extern "C" int das_realnvp_log_prob_multi_backward(const float* z_final, const float* grad_logp, int rows_total, int D,
+                                                   const DasFlowJob* jobs, int njobs, int layers, unsigned mask_bits,
+                                                   float* dx, void* stream) {
+  if (!z_final || !grad_logp || !dx || rows_total < 1 || layers < 1 || layers * D > 32 || (D != 2 && D != 3))
     return DAS_ERR_ARG;
+  if (!jobs_ok(jobs, njobs, rows_total, true)) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int blocks = (N + FR - 1) / FR;
+  FlowJobs fj;
+  fj.n = njobs;
+  for (int q = 0; q < DAS_FLOW_MAX_JOBS; ++q) fj.j[q] = jobs[q < njobs ? q : 0];
+  const int blocks = (rows_total + FR - 1) / FR;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)realnvp_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -364,15 +391,31 @@ extern "C" int das_realnvp_log_prob_backward(const float* z_final, const float* 
                               (int)bwd_smem<2>());
     attr_set = true;
   }
+  const size_t psize = sizeof(float) * 2 * layers * (D == 3 ? Net<3>::SIZE : Net<2>::SIZE);
+  for (int q = 0; q < njobs; ++q)
+    if (jobs[q].dparams && hipMemsetAsync(jobs[q].dparams, 0, psize, s) != hipSuccess) return DAS_ERR_LAUNCH;
   if (D == 3) {
-    if (dparams && hipMemsetAsync(dparams, 0, sizeof(float) * 2 * layers * Net<3>::SIZE, s) != hipSuccess) return DAS_ERR_LAUNCH;
-    hipLaunchKernelGGL(realnvp_bwd_kernel<3>, dim3(blocks), dim3(FR), bwd_smem<3>(), s, z_final, grad_logp, N, params,
-                       layers, mask_bits, dx, dparams, dst_table);
+    hipLaunchKernelGGL(realnvp_bwd_kernel<3>, dim3(blocks), dim3(FR), bwd_smem<3>(), s, z_final, grad_logp, fj, layers,
+                       mask_bits, dx);
   } else {
-    if (dparams && hipMemsetAsync(dparams, 0, sizeof(float) * 2 * layers * Net<2>::SIZE, s) != hipSuccess) return DAS_ERR_LAUNCH;
-    hipLaunchKernelGGL(realnvp_bwd_kernel<2>, dim3(blocks), dim3(FR), bwd_smem<2>(), s, z_final, grad_logp, N, params,
-                       layers, mask_bits, dx, dparams, dst_table);
+    hipLaunchKernelGGL(realnvp_bwd_kernel<2>, dim3(blocks), dim3(FR), bwd_smem<2>(), s, z_final, grad_logp, fj, layers,
+                       mask_bits, dx);
   }
   DAS_CHECK_LAUNCH();
   return DAS_OK;
+}
+
+extern "C" int das_realnvp_log_prob(const float* x, int N, int D, const float* params, int layers, unsigned mask_bits,
+                                    float* logp, float* z_out, void* stream) {
+  DasFlowJob j;
+  j.params = params; j.dparams = nullptr; j.dst_table = nullptr; j.row_start = 0; j.row_end = N;
+  return das_realnvp_log_prob_multi(x, N, D, &j, 1, layers, mask_bits, logp, z_out, stream);
+}
+
+extern "C" int das_realnvp_log_prob_backward(const float* z_final, const float* grad_logp, int N, int D,
+                                             const float* params, int layers, unsigned mask_bits, float* dx,
+                                             float* dparams, float* const* dst_table, void* stream) {
+  DasFlowJob j;
+  j.params = params; j.dparams = dparams; j.dst_table = dst_table; j.row_start = 0; j.row_end = N;
+  return das_realnvp_log_prob_multi_backward(z_final, grad_logp, N, D, &j, 1, layers, mask_bits, dx, stream);
 }

@@ -139,14 +139,16 @@ def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d):
     bar = (pred - real2) / sig2
     two_d = (real2[..., 2] == 0).all(1)
     log_phi = bar.new_zeros(npos, bar.size(1))
-    for suffix, sl in flows:
-        if bool(two_d.any()):
-            v = realnvp_log_prob(getattr(head, 'flow2d' + suffix), bar[two_d][:, sl, :2].reshape(-1, 2))
-            idx = two_d.nonzero().reshape(-1)
-            log_phi = log_phi.index_put((idx[:, None], torch.arange(sl.start, sl.stop, device=dev)[None]), v.view(-1, J))
-        if bool((~two_d).any()):
-            v = realnvp_log_prob(getattr(head, 'flow3d' + suffix), bar[~two_d][:, sl].reshape(-1, 3))
-            idx = (~two_d).nonzero().reshape(-1)
+    n2d = int(two_d.sum())
+    # per dimension ONE forward (and one backward) launch covers the flows of both prediction sets
+    for D, sel, name, n in ((2, two_d, 'flow2d', n2d), (3, ~two_d, 'flow3d', npos - n2d)):
+        if n == 0:
+            continue
+        idx = sel.nonzero().reshape(-1)
+        rows = bar[sel]
+        outs = T.realnvp_log_prob_multi([(getattr(head, name + suffix), rows[:, sl, :D].reshape(-1, D))
+                                         for suffix, sl in flows])
+        for (suffix, sl), v in zip(flows, outs):
             log_phi = log_phi.index_put((idx[:, None], torch.arange(sl.start, sl.stop, device=dev)[None]), v.view(-1, J))
     nf = torch.log(sig2) - log_phi[..., None]
     lp = head.loss_pose

@@ -121,65 +121,19 @@ def flow_mask_bits(flow):
     return bits
 
 
-class RealNVPLogProbFn(Function):
-    """log p(x) under the flow for x (N, D): one forward and one backward kernel (das_realnvp_log_prob*)
-    instead of ~80 GEMM / elementwise launches each way. `plist` are the flow's parameters
-    (flow_param_list), passed as inputs so that autograd delivers their gradients."""
-
-    @staticmethod
-    def forward(ctx, x, layers, mask_bits, packed, table, *plist):
-        _need_gpu(x)
-        x = x.contiguous().float()
-        N, D = x.shape
-        params = packed if packed is not None else torch.cat([p.detach().reshape(-1).float() for p in plist])
-        logp = torch.empty(N, dtype=torch.float32, device=x.device)
-        z = torch.empty(N, D, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().das_realnvp_log_prob(_ptr(x), N, D, _ptr(params), layers, mask_bits, _ptr(logp), _ptr(z),
-                                                    _stream()), 'das_realnvp_log_prob')
-        ctx.save_for_backward(z, params)
-        ctx.cfg = (layers, mask_bits, plist, table)
-        return logp
-
-    @staticmethod
-    def backward(ctx, g):
-        z, params = ctx.saved_tensors
-        layers, mask_bits, plist, table = ctx.cfg
-        N, D = z.shape
-        g = g.contiguous().float()
-        dx = torch.empty_like(z)
-        if table is not None:
-            # the optimizer's flat gradient: the kernel adds every tensor's gradient in place
-            _lib.check(_lib.load().das_realnvp_log_prob_backward(_ptr(z), _ptr(g), N, D, _ptr(params), layers,
-                                                                 mask_bits, _ptr(dx), None, _ptr(table), _stream()),
-                       'das_realnvp_log_prob_backward')
-            for p in plist:
-                p._das_slot.fired()
-            return (dx, None, None, None, None) + (None,) * len(plist)
-        dparams = torch.empty_like(params)
-        _lib.check(_lib.load().das_realnvp_log_prob_backward(_ptr(z), _ptr(g), N, D, _ptr(params), layers, mask_bits,
-                                                             _ptr(dx), _ptr(dparams), None, _stream()),
-                   'das_realnvp_log_prob_backward')
-        grads, off = [], 0
-        for p in plist:
-            n = p.numel()
-            grads.append(dparams[off:off + n].view(p.shape))
-            off += n
-        return (dx, None, None, None, None) + tuple(grads)
+_FLOW_ALIGN = 256   # rows per workgroup of the flow kernels: every job starts on this boundary
 
 
-def realnvp_log_prob(flow, x):
-    """RealNVP.log_prob (real_nvp.py:60-80) through the fused kernels. The flow's 72 tensors are packed into the
-    kernel's layout once per optimizer step; with the flat optimizer the backward kernel adds their gradients
-    straight into the flat gradient buffer (table of destination pointers)."""
-    if x.shape[0] == 0:
-        return x.new_zeros(0)
+def _flow_state(flow, device):
+    """Per-flow cache: parameter list in kernel order, mask bits, the parameters packed into the kernel layout
+    (once per optimizer step) and, with the flat optimizer, the device table of gradient destinations."""
     from .nn import PARAM_EPOCH
     c = flow.__dict__.get('_das_flow')
     if c is None:
         c = dict(plist=flow_param_list(flow), bits=flow_mask_bits(flow), epoch=None, packed=None, table=None, tkey=None)
         flow.__dict__['_das_flow'] = c
     plist = c['plist']
-    if c['epoch'] != PARAM_EPOCH[0] or c['packed'] is None or c['packed'].device != x.device:
+    if c['epoch'] != PARAM_EPOCH[0] or c['packed'] is None or c['packed'].device != device:
         with torch.no_grad():
             c['packed'] = torch.cat([p.detach().reshape(-1).float() for p in plist])
         c['epoch'] = PARAM_EPOCH[0]
@@ -187,7 +141,105 @@ def realnvp_log_prob(flow, x):
     if torch.is_grad_enabled() and all(getattr(p, '_das_slot', None) is not None and p.grad is not None for p in plist):
         key = tuple(p.grad.data_ptr() for p in plist)
         if c['tkey'] != key:
-            c['table'] = torch.tensor(key, dtype=torch.int64, device=x.device)
+            c['table'] = torch.tensor(key, dtype=torch.int64, device=device)
             c['tkey'] = key
         table = c['table']
-    return RealNVPLogProbFn.apply(x, len(flow.t), c['bits'], c['packed'], table, *plist)
+    return c, table
+
+
+class RealNVPLogProbFn(Function):
+    """log p(x) of several flows of one dimension in ONE forward and ONE backward launch
+    (das_realnvp_log_prob_multi*), instead of ~80 GEMM / elementwise launches per flow and direction.
+    x_cat (rows, D): the jobs' rows back to back, each job starting on a 256-row boundary.
+    jobs: list of (row_start, row_end, packed params, gradient-destination table or None, parameter list);
+    the parameters also come in as inputs so that autograd can deliver their gradients when there is no table."""
+
+    @staticmethod
+    def forward(ctx, x_cat, layers, mask_bits, jobs, *flat_plist):
+        _need_gpu(x_cat)
+        x_cat = x_cat.contiguous().float()
+        rows, D = x_cat.shape
+        arr = (_lib.DasFlowJob * len(jobs))()
+        for q, (r0, r1, packed, table, plist) in enumerate(jobs):
+            arr[q].params, arr[q].dparams, arr[q].dst_table = packed.data_ptr(), None, None
+            arr[q].row_start, arr[q].row_end = r0, r1
+        logp = torch.zeros(rows, dtype=torch.float32, device=x_cat.device)
+        z = torch.zeros(rows, D, dtype=torch.float32, device=x_cat.device)
+        _lib.check(_lib.load().das_realnvp_log_prob_multi(_ptr(x_cat), rows, D, arr, len(jobs), layers, mask_bits,
+                                                          _ptr(logp), _ptr(z), _stream()), 'das_realnvp_log_prob_multi')
+        ctx.save_for_backward(z, *[j[2] for j in jobs])
+        ctx.cfg = (layers, mask_bits, jobs)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        z = ctx.saved_tensors[0]
+        layers, mask_bits, jobs = ctx.cfg
+        rows, D = z.shape
+        g = g.contiguous().float()
+        dx = torch.zeros_like(z)
+        arr = (_lib.DasFlowJob * len(jobs))()
+        outs = []
+        for q, (r0, r1, packed, table, plist) in enumerate(jobs):
+            arr[q].params, arr[q].row_start, arr[q].row_end = packed.data_ptr(), r0, r1
+            if table is not None:   # the optimizer's flat gradient: the kernel adds every tensor's gradient in place
+                arr[q].dparams, arr[q].dst_table = None, table.data_ptr()
+                outs.append(None)
+            else:
+                dp = torch.empty_like(packed)
+                arr[q].dparams, arr[q].dst_table = dp.data_ptr(), None
+                outs.append(dp)
+        _lib.check(_lib.load().das_realnvp_log_prob_multi_backward(_ptr(z), _ptr(g), rows, D, arr, len(jobs), layers,
+                                                                   mask_bits, _ptr(dx), _stream()),
+                   'das_realnvp_log_prob_multi_backward')
+        grads = []
+        for (r0, r1, packed, table, plist), dp in zip(jobs, outs):
+            if dp is None:
+                for p in plist:
+                    p._das_slot.fired()
+                grads += [None] * len(plist)
+            else:
+                off = 0
+                for p in plist:
+                    n = p.numel()
+                    grads.append(dp[off:off + n].view(p.shape))
+                    off += n
+        return (dx, None, None, None) + tuple(grads)
+
+
+def realnvp_log_prob_multi(pairs):
+    """[(flow, x (N_i, D)), ...] with one common D -> [log p_i (N_i)]: RealNVP.log_prob (real_nvp.py:60-80) of
+    every pair in one forward (and one backward) launch."""
+    pairs = [(f, x) for f, x in pairs]
+    res = [None] * len(pairs)
+    live = [(i, f, x) for i, (f, x) in enumerate(pairs) if x.shape[0] > 0]
+    for i, (f, x) in enumerate(pairs):
+        if x.shape[0] == 0:
+            res[i] = x.new_zeros(0)
+    if not live:
+        return res
+    D = live[0][2].shape[1]
+    dev = live[0][2].device
+    chunks, jobs, flat, r = [], [], [], 0
+    for i, f, x in live:
+        assert x.shape[1] == D and f.mask.shape[1] == D
+        c, table = _flow_state(f, dev)
+        n = x.shape[0]
+        jobs.append((r, r + n, c['packed'], table, c['plist']))
+        flat += c['plist']
+        chunks.append(x.float())
+        pad = (-n) % _FLOW_ALIGN
+        if pad and (i, f, x) is not live[-1]:
+            chunks.append(x.new_zeros(pad, D, dtype=torch.float32))
+        r += n + (pad if (i, f, x) is not live[-1] else 0)
+    x_cat = torch.cat(chunks) if len(chunks) > 1 else chunks[0]
+    c0, _ = _flow_state(live[0][1], dev)
+    logp = RealNVPLogProbFn.apply(x_cat, len(live[0][1].t), c0['bits'], jobs, *flat)
+    for (i, f, x), (r0, r1, _, _, _) in zip(live, jobs):
+        res[i] = logp[r0:r1]
+    return res
+
+
+def realnvp_log_prob(flow, x):
+    """RealNVP.log_prob (real_nvp.py:60-80) through the fused kernels."""
+    return realnvp_log_prob_multi([(flow, x)])[0]

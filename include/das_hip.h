@@ -274,6 +274,23 @@ int das_bce_logits_loss(const float* logits, const float* target, long long n, f
  * of dparams / dst_table is non-NULL. */
 int das_realnvp_log_prob(const float* x, int N, int D, const float* params, int layers, unsigned mask_bits,
                          float* logp, float* z_out, void* stream);
+/* Several flows of the same dimension in ONE launch (the head evaluates `flow3d` on the recursive-update
+ * prediction and `flow3d_update`-less `flow3d` on the direct one, das_head.py:425-446): x / logp / z / dx hold
+ * the jobs' rows back to back, job q owning rows [row_start, row_end) with row_start a multiple of 256 (pad the
+ * gap; padded rows are ignored) and jobs[0].row_start == 0. params / dparams / dst_table as in the single-flow
+ * calls (backward: exactly one of dparams / dst_table per job). */
+#define DAS_FLOW_MAX_JOBS 4
+typedef struct {
+  const float* params;
+  float* dparams;
+  float* const* dst_table;
+  int row_start, row_end;
+} DasFlowJob;
+int das_realnvp_log_prob_multi(const float* x, int rows_total, int D, const DasFlowJob* jobs, int njobs, int layers,
+                               unsigned mask_bits, float* logp, float* z_out, void* stream);
+int das_realnvp_log_prob_multi_backward(const float* z_final, const float* grad_logp, int rows_total, int D,
+                                        const DasFlowJob* jobs, int njobs, int layers, unsigned mask_bits, float* dx,
+                                        void* stream);
 int das_realnvp_log_prob_backward(const float* z_final, const float* grad_logp, int N, int D, const float* params,
                                   int layers, unsigned mask_bits, float* dx, float* dparams,
                                   float* const* dst_table, void* stream);

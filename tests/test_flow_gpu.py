@@ -52,6 +52,31 @@ def test_realnvp_log_prob_forward_backward(dim, N):
         assert err < 3e-4 * max(float(ref.abs().max()), 1.0), (k, err, float(ref.abs().max()))
 
 
+def test_realnvp_two_flows_in_one_launch():
+    """Two flows with different weights and row counts (second job starts on a padded 256-row boundary):
+    values and all gradients equal the one-flow-per-launch results."""
+    from das_amd.train_ops import realnvp_log_prob, realnvp_log_prob_multi
+    fa, fb = _flow(3, 11).to(DEV), _flow(3, 12).to(DEV)
+    xa = (cases.randn(80, 300, 3) * 1.5).to(DEV).requires_grad_(True)
+    xb = (cases.randn(81, 777, 3) * 1.5).to(DEV).requires_grad_(True)
+    ga, gb = cases.randn(82, 300).to(DEV), cases.randn(83, 777).to(DEV)
+    la, lb = realnvp_log_prob_multi([(fa, xa), (fb, xb)])
+    (la * ga).sum().backward(retain_graph=True)
+    (lb * gb).sum().backward()
+    got = [la.detach().clone(), lb.detach().clone(), xa.grad.clone(), xb.grad.clone()] + \
+        [p.grad.clone() for f in (fa, fb) for p in f.parameters()]
+    for t in (xa, xb):
+        t.grad = None
+    for f in (fa, fb):
+        f.zero_grad()
+    ra, rb = realnvp_log_prob(fa, xa), realnvp_log_prob(fb, xb)
+    ra.backward(ga)
+    rb.backward(gb)
+    ref = [ra.detach(), rb.detach(), xa.grad, xb.grad] + [p.grad for f in (fa, fb) for p in f.parameters()]
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)
+
+
 def test_realnvp_matches_the_torch_path_in_the_loss():
     """Same flow, same input: the fused op equals the layer-by-layer torch evaluation the loss used before."""
     from das_amd.losses import realnvp_log_prob_torch
