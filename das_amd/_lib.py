@@ -66,6 +66,7 @@ SIGNATURES = {
     'das_pack_conv_weights': (i32, [vp, vp, vp, i32, vp, i32, i32, vp]),
     'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
     'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
+    'das_bn_train_backward_phase': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i64, vp]),
     'das_groupnorm_backward': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp,
                                      vp, vp, vp]),
     'das_maxpool3x3s2_backward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -77,7 +78,7 @@ SIGNATURES = {
     'das_upsample_bilinear_ac': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_add_upsample_nearest': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_add3': (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
-    'das_bn_train_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp, vp]),
+    'das_bn_train_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp, i64, vp]),
     'das_groupnorm_nhwc': (i32, [vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp, vp]),
     'das_deform_im2col3x3': (i32, [vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp]),
     'das_offset_sample': (i32, [vp, vp, vp, vp, C.POINTER(DasLevels), i32, i32, i32, i32, i32, i32, vp]),

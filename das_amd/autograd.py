@@ -44,6 +44,20 @@ def _param_acc(param):
     return None if sl is None or param.grad is None else (sl, param.grad)
 
 
+def _sync_world(bn):
+    """Number of ranks a BatchNorm's statistics span: > 1 only for layers built from `type='SyncBN'` inside an
+    initialised process group (mmcv's SyncBN -> torch SyncBatchNorm in the reference)."""
+    if not getattr(bn, '_das_sync', False):
+        return 1
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _all_reduce(t):
+    import torch.distributed as dist
+    dist.all_reduce(t)
+
+
 class ConvBNTrainFn(Function):
     """conv (no bias) -> train-mode BatchNorm (+ residual) (+ ReLU). mspn_mmpose.py:126-157,381-404."""
 
@@ -55,12 +69,18 @@ class ConvBNTrainFn(Function):
         stats = zeroed_stats(2 * w.shape[0], x.device)
         raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
         mom = bn.momentum if bn.momentum is not None else 0.1
+        world = _sync_world(bn)
+        stat_count = 0
+        if world > 1:   # SyncBN: the statistics are those of all ranks' pixels
+            _all_reduce(stats)
+            stat_count = (raw.numel() // raw.shape[-1]) * world
         y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,
                                              residual=residual, relu=relu,
-                                             num_batches_tracked=bn.num_batches_tracked)
+                                             num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count)
         bn.__dict__.pop('_das_cache', None)  # running stats changed under the cache's feet (raw-pointer update)
         ctx.save_for_backward(x, raw, y if residual is not None else None, mean, invstd, gamma, weight, beta)
         ctx.cfg = (k, s, p, relu, residual is not None, conv, bn)
+        ctx.world = world
         return y
 
     @staticmethod
@@ -72,10 +92,15 @@ class ConvBNTrainFn(Function):
         ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
         direct = ga is not None and ba is not None
         # without a residual the ReLU mask is recomputed from raw: y is not read at all
-        draw, dres, dgamma, dbeta = ops.bn_train_backward(dy, y if (relu and has_res) else None, raw, mean, invstd, gamma,
-                                                          relu, has_res, beta=beta,
-                                                          dgamma_acc=ga[1] if direct else None,
-                                                          dbeta_acc=ba[1] if direct else None)
+        if ctx.world > 1:   # SyncBN: reduce, sum over ranks, apply; parameter gradients stay local
+            direct = False
+            draw, dres, dgamma, dbeta = ops.bn_train_backward_sync(dy, y if (relu and has_res) else None, raw, mean, invstd,
+                                                                   gamma, relu, has_res, beta, _all_reduce, ctx.world)
+        else:
+            draw, dres, dgamma, dbeta = ops.bn_train_backward(dy, y if (relu and has_res) else None, raw, mean, invstd,
+                                                              gamma, relu, has_res, beta=beta,
+                                                              dgamma_acc=ga[1] if direct else None,
+                                                              dbeta_acc=ba[1] if direct else None)
         if direct:
             dgamma = dbeta = None
             ga[0].fired()

@@ -162,12 +162,14 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, DasL
 extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
                                   float momentum, float eps, const void* residual, int relu, float* save_mean,
-                                  float* save_invstd, long long* num_batches_tracked, void* stream) {
+                                  float* save_invstd, long long* num_batches_tracked, long long stat_count,
+                                  void* stream) {
   if (!x || !y || !stats || !gamma || !beta || !save_mean || !save_invstd || C % 8 || count <= 0) return DAS_ERR_ARG;
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
+  if (stat_count != 0 && stat_count < count) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, s, stats, count, C, running_mean,
-                     running_var, momentum, eps, save_mean, save_invstd, num_batches_tracked);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, s, stats, stat_count ? stat_count : count,
+                     C, running_mean, running_var, momentum, eps, save_mean, save_invstd, num_batches_tracked);
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
   const int grid = grid_for(count * vc);
   const bool fixed = ((long long)grid * TPB) % vc == 0;

@@ -341,11 +341,10 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ sums, long long rows, int C, T* __restrict__ draw,
                                     T* __restrict__ dres, float* __restrict__ dgamma_acc,
-                                    float* __restrict__ dbeta_acc) {
+                                    float* __restrict__ dbeta_acc, float inv_n) {
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV;
   const long long total = rows * VC;
-  const float inv_n = 1.f / (float)rows;
   const long long stride = (long long)gridDim.x * TPB;
   if (blockIdx.x == 0 && dgamma_acc) {
     for (int c = threadIdx.x; c < C; c += TPB) { dbeta_acc[c] += sums[c]; dgamma_acc[c] += sums[C + c]; }
@@ -396,28 +395,33 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
 template <typename T, int MASK>
 void launch_bn_backward(const void* dy, const void* y, const void* raw, long long rows, int C, const float* mean,
                         const float* invstd, const float* gamma, const float* beta, void* draw, void* dres,
-                        float* sums, float* dgamma_acc, float* dbeta_acc, hipStream_t s) {
+                        float* sums, float* dgamma_acc, float* dbeta_acc, int phase, long long stat_rows,
+                        hipStream_t s) {
   const int vc = C / Elem<T>::EPV;
-  static const char* dev_cfg = getenv("DAS_DEV_BN_REDUCE");  // "<blocks>,<threads>" (tuning only)
-  int cap = 256, nt = 256;  // every block ends in 2C global atomics on the same words: ~20 ns per block of tail
-  if (dev_cfg) sscanf(dev_cfg, "%d,%d", &cap, &nt);
-  const int blocks = (int)std::min<long long>(cap, std::max<long long>(1, rows / 64));
-  if (nt == 1024) {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 1024>), dim3(blocks), dim3(1024), 2 * C * sizeof(float), s,
-                       (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
-  } else {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 256>), dim3(blocks), dim3(256), 2 * C * sizeof(float), s,
-                       (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
+  if (phase != 2) {   // pass 1: per-channel sums
+    static const char* dev_cfg = getenv("DAS_DEV_BN_REDUCE");  // "<blocks>,<threads>" (tuning only)
+    int cap = 256, nt = 256;  // every block ends in 2C global atomics on the same words: ~20 ns per block of tail
+    if (dev_cfg) sscanf(dev_cfg, "%d,%d", &cap, &nt);
+    const int blocks = (int)std::min<long long>(cap, std::max<long long>(1, rows / 64));
+    if (nt == 1024) {
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 1024>), dim3(blocks), dim3(1024), 2 * C * sizeof(float), s,
+                         (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
+    } else {
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 256>), dim3(blocks), dim3(256), 2 * C * sizeof(float), s,
+                         (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
+    }
   }
+  if (phase == 1) return;
+  const float inv_n = 1.f / (float)stat_rows;   // statistics population (all ranks' rows for SyncBN)
   const int grid = grid_for(rows * vc);
   if (((long long)grid * TPB) % vc == 0) {
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, true>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
                        (const T*)raw, mean, invstd, gamma, beta, sums, rows, C, (T*)draw, (T*)dres, dgamma_acc,
-                       dbeta_acc);
+                       dbeta_acc, inv_n);
   } else {
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, false>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
                        (const T*)raw, mean, invstd, gamma, beta, sums, rows, C, (T*)draw, (T*)dres, dgamma_acc,
-                       dbeta_acc);
+                       dbeta_acc, inv_n);
   }
 }
 }  // namespace
@@ -493,19 +497,23 @@ extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int p
   return DAS_OK;
 }
 
-extern "C" int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
-                                     const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                     int relu, void* draw, void* dres, float* sums, int sums_prezeroed,
-                                     float* dgamma_acc, float* dbeta_acc, void* stream) {
-  if (!dy || !raw || !mean || !invstd || !gamma || !draw || !sums || rows <= 0 || C % 8 || C > 2048) return DAS_ERR_ARG;
+extern "C" int das_bn_train_backward_phase(const void* dy, const void* y, const void* raw, int dtype, long long rows,
+                                           int C, const float* mean, const float* invstd, const float* gamma,
+                                           const float* beta, int relu, void* draw, void* dres, float* sums,
+                                           int sums_prezeroed, float* dgamma_acc, float* dbeta_acc, int phase,
+                                           long long stat_rows, void* stream) {
+  if (!dy || !raw || !mean || !invstd || !gamma || !sums || rows <= 0 || C % 8 || C > 2048) return DAS_ERR_ARG;
+  if (phase < 0 || phase > 2 || (phase != 1 && !draw) || stat_rows < rows) return DAS_ERR_ARG;
   if (relu && !y && !beta) return DAS_ERR_ARG;
   if ((dgamma_acc == nullptr) != (dbeta_acc == nullptr)) return DAS_ERR_ARG;
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (!sums_prezeroed && hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (phase != 2 && !sums_prezeroed && hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, s) != hipSuccess)
+    return DAS_ERR_LAUNCH;
   const int mask = !relu ? 0 : (y ? 1 : 2);
-#define DAS_BN_BWD(T, MASK)                                                                                       \
-  launch_bn_backward<T, MASK>(dy, y, raw, rows, C, mean, invstd, gamma, beta, draw, dres, sums, dgamma_acc, dbeta_acc, s)
+#define DAS_BN_BWD(T, MASK)                                                                                         \
+  launch_bn_backward<T, MASK>(dy, y, raw, rows, C, mean, invstd, gamma, beta, draw, dres, sums, dgamma_acc, dbeta_acc, \
+                              phase, stat_rows, s)
   if (dtype == DAS_BF16) {
     if (mask == 0) DAS_BN_BWD(bf16_t, 0); else if (mask == 1) DAS_BN_BWD(bf16_t, 1); else DAS_BN_BWD(bf16_t, 2);
   } else {
@@ -514,4 +522,12 @@ extern "C" int das_bn_train_backward(const void* dy, const void* y, const void* 
 #undef DAS_BN_BWD
   DAS_CHECK_LAUNCH();
   return DAS_OK;
+}
+
+extern "C" int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
+                                     const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                     int relu, void* draw, void* dres, float* sums, int sums_prezeroed,
+                                     float* dgamma_acc, float* dbeta_acc, void* stream) {
+  return das_bn_train_backward_phase(dy, y, raw, dtype, rows, C, mean, invstd, gamma, beta, relu, draw, dres, sums,
+                                     sums_prezeroed, dgamma_acc, dbeta_acc, 0, rows, stream);
 }

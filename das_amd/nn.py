@@ -153,8 +153,13 @@ def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False, skip_through=
     stats = zeroed_stats(2 * cout, x.device)
     raw = ops.conv2d(x, w, k, k, s, p, relu_in=relu_in, stats=stats)
     mom = bn.momentum if bn.momentum is not None else 0.1
+    world, stat_count = ag._sync_world(bn), 0
+    if world > 1:   # SyncBN
+        ag._all_reduce(stats)
+        stat_count = (raw.numel() // raw.shape[-1]) * world
     y, mean, invstd = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
-                                         residual=residual, relu=relu, num_batches_tracked=bn.num_batches_tracked)
+                                         residual=residual, relu=relu, num_batches_tracked=bn.num_batches_tracked,
+                                         stat_count=stat_count)
     bn.__dict__.pop('_das_cache', None)  # running stats were updated through raw pointers
     return y
 
@@ -280,7 +285,8 @@ def build_norm(cfg, num_features):
     t = cfg.pop('type')
     requires_grad = cfg.pop('requires_grad', True)
     if t in ('BN', 'SyncBN', 'BN2d'):
-        # SyncBN's cross-rank statistics exchange is handled by the DDP wrapper
+        # SyncBN: `_das_sync` makes ConvBNTrainFn all-reduce the batch statistics (forward) and the two
+        # per-channel gradient sums (backward) over the process group, as torch.nn.SyncBatchNorm does
         name, layer = 'bn', nn.BatchNorm2d(num_features, **cfg)
         layer._das_sync = (t == 'SyncBN')
     elif t == 'GN':

@@ -224,6 +224,28 @@ def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta=Non
     return draw, dres, sums[Cc:], sums[:Cc]
 
 
+def bn_train_backward_sync(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta, all_reduce, world):
+    """SyncBN backward in two phases around a cross-rank sum of the per-channel sums (what torch's
+    SyncBatchNorm does with its all_reduce of sum_dy / sum_dy_xmu). `all_reduce(t)` sums t over the ranks in
+    place. Returns d_raw, d_residual, dgamma, dbeta (the LOCAL parameter gradients: the data-parallel
+    gradient all-reduce adds the ranks' contributions, exactly as for every other parameter)."""
+    _need_gpu(dy, raw)
+    assert dy.is_contiguous() and raw.is_contiguous() and (y is None or y.is_contiguous())
+    Cc = raw.shape[-1]
+    rows = raw.numel() // Cc
+    draw = torch.empty_like(raw)
+    dres = torch.empty_like(raw) if want_dres else None
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=raw.device)
+    lib = _lib.load()
+    args = (_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+            int(relu), _ptr(draw), _ptr(dres), _ptr(sums), 0, None, None)
+    _lib.check(lib.das_bn_train_backward_phase(*args, 1, rows, _stream()), 'das_bn_train_backward_phase')
+    local = sums.clone()
+    all_reduce(sums)
+    _lib.check(lib.das_bn_train_backward_phase(*args, 2, rows * world, _stream()), 'das_bn_train_backward_phase')
+    return draw, dres, local[Cc:], local[:Cc]
+
+
 def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, relu_in=False,
            out_dtype=None, stats=None, out=None, in_up=1, out_hw=None):
     """x (B,H,W,Cin[view]) or Ragged; w packed (Cout,KH,KW,Cin). Returns y (B,Ho,Wo,Cout) / Ragged.
@@ -360,9 +382,10 @@ def add3(a, b, c=None, relu=False):
 
 
 def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None,
-                   relu=False, num_batches_tracked=None):
+                   relu=False, num_batches_tracked=None, stat_count=0):
     """x (B,H,W,C) raw conv output, stats f32[2C] from the conv epilogue. Returns y, mean, invstd.
-    num_batches_tracked: the BatchNorm's int64 counter buffer, incremented on the device by the same launch."""
+    num_batches_tracked: the BatchNorm's int64 counter buffer, incremented on the device by the same launch.
+    stat_count: global row count when `stats` was all-reduced over ranks (SyncBN); 0 = this tensor's rows."""
     _need_gpu(x, stats)
     assert x.is_contiguous()
     Cc = x.shape[-1]
@@ -375,7 +398,7 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     _lib.check(_lib.load().das_bn_train_apply(_ptr(x), _ptr(y), _DT[x.dtype], count, Cc, _ptr(stats), _ptr(gamma),
                                               _ptr(beta), _ptr(running_mean), _ptr(running_var), momentum, eps,
                                               _ptr(residual), int(relu), _ptr(mean), _ptr(invstd),
-                                              _ptr(num_batches_tracked), _stream()),
+                                              _ptr(num_batches_tracked), int(stat_count), _stream()),
                'das_bn_train_apply')
     return y, mean, invstd
 

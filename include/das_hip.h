@@ -107,6 +107,14 @@ int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dt
                           float* dbeta_acc, void* stream);
 /* (sums_prezeroed != 0: the caller hands sums already zero-filled — e.g. a slice of a larger scratch cleared
  * once — and the call skips its own memset.) */
+/* The same in two phases for SyncBN: phase 1 = only the per-channel sums of this rank's rows; the caller
+ * all-reduces `sums`; phase 2 = only the apply pass with 1/N taken from stat_rows (all ranks' rows) — what
+ * torch's SyncBatchNorm backward does with its all_reduce of (sum_dy, sum_dy_xmu). phase 0 = both at once.
+ * The parameter-gradient accumulators are fed from `sums` in phase 2: hand them only when `sums` is local. */
+int das_bn_train_backward_phase(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                int relu, void* draw, void* dres, float* sums, int sums_prezeroed, float* dgamma_acc,
+                                float* dbeta_acc, int phase, long long stat_rows, void* stream);
 
 /* All conv weights of the network packed in one launch, once per optimizer step. flat_src: the optimizer's
  * f32 master buffer, conv weights stored as (Cout,KH,KW,Cin) (the forward operand layout). For every table
@@ -163,11 +171,14 @@ int das_add3(const void* a, const void* b, const void* c, void* y, int dtype, lo
  * from `stats` = [sum(C), sumsq(C)] over `count` pixels compute mean / biased var,
  * y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta + residual ), and update running stats
  * (momentum, unbiased var). save_mean/save_invstd: f32[C] outputs for backward.
- * num_batches_tracked: optional device int64 scalar (the BatchNorm buffer of that name), incremented by 1. */
+ * num_batches_tracked: optional device int64 scalar (the BatchNorm buffer of that name), incremented by 1.
+ * stat_count: the population behind `stats` when it is larger than this tensor's `count` rows — SyncBN
+ * (`norm_cfg=dict(type='SyncBN')`, configs/_base_/models/das.py): the caller all-reduces `stats` over the ranks
+ * first and passes the global row count; 0 = count. */
 int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
                        const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, const void* residual, int relu, float* save_mean,
-                       float* save_invstd, long long* num_batches_tracked, void* stream);
+                       float* save_invstd, long long* num_batches_tracked, long long stat_count, void* stream);
 
 /* Ragged multi-level pixel rows. The DASHead shares its weights across FPN levels
  * (das_head.py:176-178 `multi_apply(self.forward_single, feats, ...)`), so the head ops below take

@@ -1,0 +1,72 @@
+"""SyncBN arithmetic: two emulated ranks (the two halves of a batch, statistics summed by hand where the
+process group would all-reduce them) reproduce full-batch BatchNorm forward and backward. GPU only; the
+real multi-process path uses torch.distributed.all_reduce at exactly the points emulated here
+(`das_amd/autograd.py::ConvBNTrainFn`)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def nhwc(t, dtype=torch.float32):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def stats_of(raw):
+    f = raw.float()
+    return torch.cat([f.sum((0, 1, 2)), f.square().sum((0, 1, 2))]).contiguous()
+
+
+@pytest.mark.parametrize('relu,res', [(True, False), (True, True), (False, False)])
+def test_two_emulated_ranks_equal_full_batch(relu, res):
+    from das_amd import ops as o
+    B, H, W, C = 4, 9, 7, 64
+    raw = nhwc(cases.randn(1, B, C, H, W) * 1.3 + 0.2)
+    dy = nhwc(cases.randn(2, B, C, H, W))
+    r = nhwc(cases.randn(3, B, C, H, W)) if res else None
+    gamma, beta = (cases.randn(4, C).abs() + 0.5).to(DEV), cases.randn(5, C).to(DEV)
+    rows = B * H * W
+
+    # full batch, one rank
+    y, mean, invstd = o.bn_train_apply(raw, stats_of(raw), gamma, beta, None, None, 0.1, 1e-5, residual=r, relu=relu)
+    d_full, dres_full, dg_full, db_full = o.bn_train_backward(dy, y if (relu and res) else None, raw, mean, invstd, gamma,
+                                                              relu, res, beta=beta)
+
+    halves = [slice(0, 2), slice(2, 4)]
+    st = [stats_of(raw[h]) for h in halves]
+    total = st[0] + st[1]                                 # = all_reduce(stats)
+    ys, outs = [], []
+    for h in halves:
+        yh, mh, ih = o.bn_train_apply(raw[h].contiguous(), total.clone(), gamma, beta, None, None, 0.1, 1e-5,
+                                      residual=r[h].contiguous() if res else None, relu=relu, stat_count=rows)
+        torch.testing.assert_close(mh, mean, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(ih, invstd, rtol=1e-5, atol=1e-6)
+        ys.append(yh)
+    torch.testing.assert_close(torch.cat(ys), y, rtol=1e-6, atol=1e-6)
+
+    # backward: local sums of the other rank, obtained from a local (unsynchronised) call
+    local = []
+    for h, yh in zip(halves, ys):
+        _, _, dg, db = o.bn_train_backward(dy[h].contiguous(), yh if (relu and res) else None, raw[h].contiguous(), mean,
+                                           invstd, gamma, relu, res, beta=beta)
+        local.append(torch.cat([db, dg]))                 # layout of `sums`: [sum dz, sum dz*xhat]
+    for i, (h, yh) in enumerate(zip(halves, ys)):
+        other = local[1 - i]
+
+        def all_reduce(t, other=other):
+            t += other
+
+        d, dres, dg, db = o.bn_train_backward_sync(dy[h].contiguous(), yh if (relu and res) else None,
+                                                   raw[h].contiguous(), mean, invstd, gamma, relu, res, beta,
+                                                   all_reduce, 2)
+        outs.append((d, dres, dg, db))
+    torch.testing.assert_close(torch.cat([a[0] for a in outs]), d_full, rtol=1e-5, atol=2e-6)
+    if res:
+        torch.testing.assert_close(torch.cat([a[1] for a in outs]), dres_full, rtol=0, atol=0)
+    # the ranks' local parameter gradients add up to the full-batch ones (the gradient all-reduce does that)
+    torch.testing.assert_close(outs[0][2] + outs[1][2], dg_full, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(outs[0][3] + outs[1][3], db_full, rtol=1e-5, atol=1e-4)
