@@ -90,11 +90,13 @@ class DAS(nn.Module):
                 raise TypeError(f'{name} is not a tensor or list of tensors')
         loss = sum(v for k, v in log_vars.items() if 'loss' in k)
         log_vars['loss'] = loss
-        for name, value in log_vars.items():
-            if dist.is_available() and dist.is_initialized():
-                value = value.data.clone()
-                dist.all_reduce(value.div_(dist.get_world_size()))
-            log_vars[name] = value.item()
+        # mmdet averages every log var over the ranks and reads it back one by one (a collective and a host
+        # sync per entry); same values here from ONE stacked all-reduce and ONE device-to-host copy
+        vals = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(vals.div_(dist.get_world_size()))
+        for name, v in zip(list(log_vars), vals.tolist()):
+            log_vars[name] = v
         return loss, log_vars
 
     def train_step(self, data, optimizer=None):

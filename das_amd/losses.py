@@ -108,7 +108,11 @@ def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d):
     gt_uvd = pt[:, 3:3 + 3 * J]
     is2d = (gt_uvd[:, 2::3] == 0).all(1)
     is3d = ~is2d
-    n3d = int(is3d.sum())
+    # the host-side branch conditions of this function (3-D positives, 2-D-only positives, visible joints)
+    # depend on the targets only: one device-to-host copy for all of them
+    vis_sum = pt[:, 3 + 3 * J:].sum() * (2 if head.prev_loss else 1)
+    n3d, nvis_host = torch.stack([is3d.sum().float(), vis_sum]).tolist()
+    n3d = int(n3d)
     if n3d > 0:
         lr = head.loss_reg
         loss_depth = T.SmoothL1SumFn.apply(pp[is3d, 2], pt[is3d, 2] * head.depth_factor, lr.beta) * \
@@ -137,9 +141,9 @@ def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d):
         pred, real2, sig2, vis2 = upd, real, sig, vis_w
         flows = [('', slice(0, J))]
     bar = (pred - real2) / sig2
-    two_d = (real2[..., 2] == 0).all(1)
+    two_d = (real2[..., 2] == 0).all(1)   # == is2d: the root's z is 0, so real z == 0 <=> gt dz == 0
     log_phi = bar.new_zeros(npos, bar.size(1))
-    n2d = int(two_d.sum())
+    n2d = npos - n3d
     # per dimension ONE forward (and one backward) launch covers the flows of both prediction sets
     for D, sel, name, n in ((2, two_d, 'flow2d', n2d), (3, ~two_d, 'flow3d', npos - n2d)):
         if n == 0:
@@ -153,7 +157,7 @@ def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d):
     nf = torch.log(sig2) - log_phi[..., None]
     lp = head.loss_pose
     nvis = vis2[..., 0].sum()
-    if float(nvis) < 1:  # residual_log_likelihood_loss.py:24-25
+    if nvis_host < 1:  # residual_log_likelihood_loss.py:24-25
         loss_pose = nvis
     else:
         q = (torch.log(sig2 / lp.amp) + (real2 - pred).abs() / (math.sqrt(2) * sig2 + 1e-9)) * vis2
