@@ -11,24 +11,37 @@ inline int grid_for(long long n) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, long long count, int C, float* running_mean,
-                                   float* running_var, float momentum, float eps, float* save_mean,
-                                   float* save_invstd, long long* num_batches_tracked) {
+// Batch statistics of one channel from the conv epilogue's [sum, sum of squares] (biased variance).
+struct BnStat {
+  float mean, var, invstd;
+};
+__device__ __forceinline__ BnStat bn_stat(const float* __restrict__ stats, int C, int c, float n, float eps) {
 #pragma clang fp contract(off)
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= C) return;
-  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  BnStat s;
+  s.mean = stats[c] / n;
+  s.var = fmaxf(stats[C + c] / n - s.mean * s.mean, 0.f);
+  s.invstd = 1.0f / sqrtf(s.var + eps);
+  return s;
+}
+
+// The "finalize" duties, done by workgroup 0 of the apply kernel (no separate launch): publish mean / invstd for
+// the backward pass, update the running statistics (momentum, unbiased variance) and the batch counter.
+__device__ __forceinline__ void bn_publish(const float* __restrict__ stats, long long count, int C, float* running_mean,
+                                           float* running_var, float momentum, float eps, float* save_mean,
+                                           float* save_invstd, long long* num_batches_tracked) {
+#pragma clang fp contract(off)
   const float n = (float)count;
-  const float mean = stats[c] / n;
-  float var = stats[C + c] / n - mean * mean;
-  var = fmaxf(var, 0.f);
-  save_mean[c] = mean;
-  save_invstd[c] = 1.0f / sqrtf(var + eps);
-  if (running_mean) {
-    const float unbiased = count > 1 ? var * (n / (n - 1.f)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const BnStat s = bn_stat(stats, C, c, n, eps);
+    save_mean[c] = s.mean;
+    save_invstd[c] = s.invstd;
+    if (running_mean) {
+      const float unbiased = count > 1 ? s.var * (n / (n - 1.f)) : s.var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * s.mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
   }
+  if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
 }
 
 // One 16-byte channel vector per thread and iteration. The grid stride is a multiple of the channel-vector
@@ -36,17 +49,28 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, long long co
 // whole loop and the per-channel constants live in registers (FIXED); two iterations are kept in flight.
 template <typename T, bool FIXED>
 __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long long count, int C,
-                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ stats, long long stat_count, float eps,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const T* __restrict__ res, int relu) {
+                                const T* __restrict__ res, int relu, float* running_mean, float* running_var,
+                                float momentum, float* save_mean, float* save_invstd,
+                                long long* num_batches_tracked) {
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV;
   const long long total = count * VC;
   const long long stride = (long long)gridDim.x * TPB;
+  if (blockIdx.x == 0)
+    bn_publish(stats, stat_count, C, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+               num_batches_tracked);
+  // every thread derives mean / invstd of its channels from the raw sums itself (same arithmetic as
+  // bn_publish), so nothing waits for workgroup 0
+  const float nstat = (float)stat_count;
   float mu[EPV], is[EPV], ga[EPV], be[EPV];
   auto load_consts = [&](int c0) {
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }
+    for (int j = 0; j < EPV; ++j) {
+      const BnStat s = bn_stat(stats, C, c0 + j, nstat, eps);
+      mu[j] = s.mean; is[j] = s.invstd; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
+    }
   };
   auto finish = [&](long long i, const uint4& raw, const uint4& rv) {
     float f[EPV];
@@ -168,14 +192,14 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
   if (stat_count != 0 && stat_count < count) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, s, stats, stat_count ? stat_count : count,
-                     C, running_mean, running_var, momentum, eps, save_mean, save_invstd, num_batches_tracked);
+  const long long nstat = stat_count ? stat_count : count;
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
   const int grid = grid_for(count * vc);
   const bool fixed = ((long long)grid * TPB) % vc == 0;
-#define DAS_BN_APPLY(T, F)                                                                                      \
-  hipLaunchKernelGGL((bn_apply_kernel<T, F>), dim3(grid), dim3(TPB), 0, s, (const T*)x, (T*)y, count, C, save_mean, \
-                     save_invstd, gamma, beta, (const T*)residual, relu)
+#define DAS_BN_APPLY(T, F)                                                                                          \
+  hipLaunchKernelGGL((bn_apply_kernel<T, F>), dim3(grid), dim3(TPB), 0, s, (const T*)x, (T*)y, count, C, stats, nstat, \
+                     eps, gamma, beta, (const T*)residual, relu, running_mean, running_var, momentum, save_mean,      \
+                     save_invstd, num_batches_tracked)
   if (dtype == DAS_BF16) {
     if (fixed) DAS_BN_APPLY(bf16_t, true); else DAS_BN_APPLY(bf16_t, false);
   } else {
