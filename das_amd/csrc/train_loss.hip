@@ -129,7 +129,13 @@ __global__ void bce_logits_kernel(const float* __restrict__ x, const float* __re
 }
 
 // ------------------------------------------------------------------ optimizer
-__global__ void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+// Sum of squares in two deterministic stages (per-workgroup partials, then one workgroup adds them in a fixed
+// order): the clip coefficient derived from it must be bit-identical on every data-parallel rank, or the
+// replicas' parameters drift apart by an ulp per step — float atomics would make the order launch-dependent.
+constexpr int SUMSQ_MAX_BLOCKS = 2048;
+__device__ float g_sumsq_partials[SUMSQ_MAX_BLOCKS];
+
+__global__ void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ partials) {
   __shared__ float sh[TPB / 64];
   float acc = 0.f;
   const long long nv = n / 4;
@@ -139,7 +145,16 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long long n, float* __
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[nv * 4 + threadIdx.x]; acc += v * v; }
   const float tot = block_sum(acc, sh);
-  if (threadIdx.x == 0) atomicAdd(out, tot);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ void sumsq_final_kernel(const float* __restrict__ partials, int nblocks, float* __restrict__ out,
+                                   int zero_first) {
+  __shared__ float sh[TPB / 64];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += TPB) acc += partials[i];
+  const float tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) *out = (zero_first ? 0.f : *out) + tot;
 }
 
 // torch.optim.SGD (momentum, no dampening/nesterov) with the clip coefficient folded in:
@@ -205,8 +220,11 @@ extern "C" int das_bce_logits_loss(const float* logits, const float* target, lon
 extern "C" int das_grad_sumsq(const float* g, long long n, float* out, int zero_first, void* stream) {
   if (!g || !out || n <= 0) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (zero_first && hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return DAS_ERR_LAUNCH;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 2048)), dim3(TPB), 0, s, g, n, out);
+  float* partials = nullptr;
+  if (hipGetSymbolAddress((void**)&partials, HIP_SYMBOL(g_sumsq_partials)) != hipSuccess) return DAS_ERR_LAUNCH;
+  const int blocks = grid_for(n / 4 + 1, SUMSQ_MAX_BLOCKS);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(TPB), 0, s, g, n, partials);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(TPB), 0, s, partials, blocks, out, zero_first);
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }

@@ -30,7 +30,7 @@ def _is_bias_param(name, module_of):
 
 class _Slot:
     """Where one parameter lives in the flat buffers (attached to the parameter as `_das_slot`)."""
-    __slots__ = ('opt', 'off', 'numel', 'bucket', 'cl_shape', 'grad_cl', 'packable')
+    __slots__ = ('opt', 'off', 'numel', 'bucket', 'cl_shape', 'grad_cl', 'packable', 'index')
 
     def fired(self):
         """Tell the optimizer that this parameter's gradient of the current backward is complete."""
@@ -126,8 +126,13 @@ class FlatSGD:
                 bstart = end
         self.overlap = overlap
         self.comm_stream = torch.cuda.Stream() if self.world > 1 and dev.type == 'cuda' else None
-        self._expected = None                      # completions per bucket in one backward (learned)
-        self._fires = [0] * len(self.buckets)
+        for i, sl in enumerate(self.slots):
+            sl.index = i
+        self._pexp = None                          # completions per parameter in one backward (learned in iteration 0)
+        self._pfires = [0] * len(self.slots)
+        self._endonly = [False] * len(self.buckets)   # buckets holding parameters that may or may not get gradients
+        self._remaining = [0] * len(self.buckets)  # parameters of the bucket still incomplete in this backward
+        self._launched = [False] * len(self.buckets)
         self._next = len(self.buckets) - 1         # next bucket to launch (descending)
         self._works = []
         self._late = False
@@ -186,21 +191,53 @@ class FlatSGD:
         else:
             self._works.append(dist.all_reduce(self.flat_g[s:e], async_op=True))
 
+    def _advance(self):
+        """Launch, in descending bucket order, every bucket whose parameters are all complete; buckets that
+        hold a parameter without a guaranteed gradient (`_endonly`) are skipped here and go out at the end."""
+        while self._next >= 0 and (self._endonly[self._next] or self._remaining[self._next] == 0):
+            if not self._endonly[self._next]:
+                self._launch(self._next)
+                self._launched[self._next] = True
+                self.overlapped_launches += 1
+            self._next -= 1
+
     def _fired(self, sl):
         if self.world == 1 or not self.overlap:
             return
-        b = sl.bucket
-        self._fires[b] += 1
-        if self._expected is None:
+        i = sl.index
+        self._pfires[i] += 1
+        if self._pexp is None:
             return
-        if b > self._next:
+        b = sl.bucket
+        if self._launched[b]:
             self._late = True                      # gradient arrived after its bucket went out
             return
-        # (a bucket that never receives gradients has expected == 0 and goes out as soon as its turn comes)
-        while self._next >= 0 and self._fires[self._next] >= self._expected[self._next]:
-            self._launch(self._next)
-            self._next -= 1
-            self.overlapped_launches += 1
+        if self._pfires[i] == self._pexp[i]:
+            self._remaining[b] -= 1
+            self._advance()
+
+    def _learn(self):
+        """After the first backward: expected completions per parameter. A bucket is launched early only if every
+        one of its parameters produced a gradient on EVERY rank (one MAX all-reduce of the flags); the others
+        (the reference's unused root-offset branch, the 2-D flows when a batch has no 2-D-only person, ...) are
+        summed at the end of backward, so a parameter that wakes up later can never be late."""
+        self._pexp = list(self._pfires)
+        flags = torch.zeros(len(self.buckets), dtype=torch.int32, device=self.flat_g.device)
+        bad = sorted({sl.bucket for sl in self.slots if self._pexp[sl.index] == 0})
+        if bad:
+            flags[bad] = 1
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        self._endonly = [bool(v) for v in flags.tolist()]
+
+    def _reset_iteration(self):
+        self._pfires = [0] * len(self.slots)
+        self._launched = [False] * len(self.buckets)
+        self._next = len(self.buckets) - 1
+        if self._pexp is not None:
+            self._remaining = [0] * len(self.buckets)
+            for sl in self.slots:
+                if self._pexp[sl.index] > 0:
+                    self._remaining[sl.bucket] += 1
 
     def all_reduce_grads(self):
         """Finish the gradient sum over ranks (the mean is folded into the step's grad_scale): launch the
@@ -208,20 +245,23 @@ class FlatSGD:
         if self.world == 1:
             return
         if self._late:
-            raise RuntimeError('a gradient was produced after its bucket had been all-reduced (the set of '
-                               'parameters receiving gradients changed between iterations); use overlap=False')
-        while self._next >= 0:
-            self._launch(self._next)
-            self._next -= 1
+            raise RuntimeError('a gradient was produced after its bucket had been all-reduced (a parameter '
+                               'produced more gradients than in the first iteration); use overlap=False')
+        # whatever is left: first the remaining early-launch buckets, then the end-only ones, each in descending
+        # order — so that the sequence of collectives is the same on every rank however far its backward got
+        for endonly in (False, True):
+            for b in range(len(self.buckets) - 1, -1, -1):
+                if not self._launched[b] and self._endonly[b] == endonly:
+                    self._launch(b)
+                    self._launched[b] = True
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         for w in self._works:
             w.wait()
         self._works = []
-        if self._expected is None and self.overlap:
-            self._expected = list(self._fires)
-        self._fires = [0] * len(self.buckets)
-        self._next = len(self.buckets) - 1
+        if self._pexp is None and self.overlap:
+            self._learn()
+        self._reset_iteration()
 
     def step(self, lr):
         scale = 1.0 / self.world

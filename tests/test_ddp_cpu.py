@@ -51,7 +51,8 @@ def _overlap_worker(rank, world, port, ret):
     net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 8, 1),
                               torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 4))
     unused = torch.nn.Linear(3, 3)          # never enters the loss (like the reference's root-offset branch)
-    holder = torch.nn.ModuleDict(dict(net=net, unused=unused))
+    sometimes = torch.nn.Linear(3, 2)       # enters the loss late, on one rank only (like the 2-D flows)
+    holder = torch.nn.ModuleDict(dict(net=net, sometimes=sometimes, unused=unused))
     w0 = {n: p.detach().clone() for n, p in holder.named_parameters()}
     opt = FlatSGD(holder, lr=0.1, bucket_mb=0, overlap=True)
     same_values = all(torch.equal(p.detach(), w0[n]) for n, p in holder.named_parameters())
@@ -62,7 +63,11 @@ def _overlap_worker(rank, world, port, ret):
     for it in range(3):
         xs = [torch.randn(2, 8, 6, 6, generator=torch.Generator().manual_seed(10 * it + r)) for r in range(world)]
         opt.zero_grad()
-        net(xs[rank]).square().sum().backward()
+        loss = net(xs[rank]).square().sum()
+        late = it == 2 and rank == 0
+        if late:   # a parameter that produced no gradient in the first iteration wakes up, on this rank only
+            loss = loss + sometimes(torch.ones(1, 3)).sum()
+        loss.backward()
         before = opt.overlapped_launches
         opt.all_reduce_grads()
         launched.append(before)
@@ -72,6 +77,8 @@ def _overlap_worker(rank, world, port, ret):
         for (n, p), q in zip(net.named_parameters(), ref.parameters()):
             ok = ok and torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-5)
         ok = ok and float(unused.weight.grad.abs().sum()) == 0.0
+        want = torch.ones(2, 3) if it == 2 else torch.zeros(2, 3)   # rank 0's contribution reaches every rank
+        ok = ok and torch.allclose(sometimes.weight.grad, want)
     ret[rank] = (ok, same_values, launched, len(opt.buckets))
     dist.destroy_process_group()
 
