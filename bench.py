@@ -286,6 +286,8 @@ def main():
     ap.add_argument('--stages', type=int, default=None, help='MSPN stages (train 4, infer 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='testing only: run all ranks on cuda:0 with the gloo transport (not a measurement)')
     args = ap.parse_args()
     train = args.workload == 'train'
     batch = args.batch or (16 if train else 8)
@@ -298,11 +300,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, f'WORLD_SIZE={world} but --gpus {args.gpus}'
     import torch.distributed as dist
+    if args.share_gpu:   # plumbing test on a 1-GPU box: all ranks on cuda:0 over gloo (RCCL needs a GPU per rank)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     if args.workload == 'decode':
         decode_workload(args, rank, world, dev)
