@@ -100,7 +100,9 @@ def main():
             if args.max_iters and it >= args.max_iters:
                 break
         if rank == 0:  # CheckpointHook(interval=1): state_dict + meta (tools/train.py:200-210)
-            torch.save(dict(state_dict=model.state_dict(),
+            # dense OIHW copies on the host: the live parameters are channels-last views of the optimizer's
+            # flat buffer, and a checkpoint must load into the reference (mmcv) as well
+            torch.save(dict(state_dict={k: v.detach().contiguous().cpu() for k, v in model.state_dict().items()},
                             meta=dict(epoch=epoch + 1, iter=it, config=cfg.text, CLASSES=model.CLASSES,
                                       das_amd_version=das_amd.__version__)),
                        os.path.join(work_dir, f'epoch_{epoch + 1}.pth'))
