@@ -399,7 +399,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
 // stages fit (128 KiB) and the DMAs run three steps ahead; each wave owns 128 pixels x 64 channels (8 x 4
 // MFMA tiles, 128 accumulator registers). Wait / barrier scheme as in conv_glds3_kernel with 4 DMAs per wave
 // and stage. Needs Cin % 32 == 0; used for Cout >= 256.
-template <typename T, typename OT>
+template <typename T, typename OT, bool PP>
 __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   constexpr int BN = 256, BMT = 256, NBUF = 4;
   constexpr int EPV = Elem<T>::EPV;
@@ -482,6 +482,59 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   if (nk > 2) issue(2);
   const int frow = lane & 15, fkg = lane >> 4;
   int buf = 0, nbuf = 3;  // buffer of tile kt, buffer tile kt+3 goes to
+  if constexpr (PP) {
+    // Ping-pong: every K-step is two barrier intervals, R (issue tile kt+3, read the fragments of tile kt into
+    // registers) and M (the 32 MFMAs). Waves 4-7 run one interval behind waves 0-3, and wave w / w+4 share a SIMD:
+    // while one of them holds the matrix pipe the other one does its LDS reads and DMA issue. Tile kt+1 must have
+    // landed (every wave's DMAs waited for) before the barrier that opens the leading group's R of step kt+1: the
+    // leading group waits at the end of its M, the trailing group at the end of its R (the same interval).
+    const int grp = wave >> 2;
+    auto wait_next = [&](int kt) {   // this wave's DMAs of tile kt+1 (tiles kt+2, kt+3 may still fly: 4 DMAs each)
+      if (kt + 3 < nk) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (kt + 2 < nk) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    if (nk > 2) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (nk > 1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                 // tile 0 landed
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // trailing group: one interval behind
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---- R
+      if (kt + 3 < nk) issue(nbuf);
+      const char* sA = smem + buf * BUF;
+      const char* sW = sA + A_BYTES;
+      uint4 fb[TM], fa[TN];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fa[i] = *reinterpret_cast<const uint4*>(sW + slot64(wave_n0 + i * 16 + frow, fkg));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fb[i] = *reinterpret_cast<const uint4*>(sA + slot64(wave_m0 + i * 16 + frow, fkg));
+      if (grp == 1) wait_next(kt);
+      // retire the fragment reads before the barrier: the other group's next R re-stages buffers one interval later
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- M
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int a = 0; a < TN; ++a) mma<T>(fa[a], fb[b], acc[a][b]);
+      __builtin_amdgcn_s_setprio(0);
+      if (grp == 0) wait_next(kt);
+      __builtin_amdgcn_s_barrier();
+      buf = buf == NBUF - 1 ? 0 : buf + 1;
+      nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // leading group: match the trailing group's extra interval
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt landed; the (up to two) younger tiles, 4 DMAs per wave each, may still fly
     if (kt + 2 < nk) {
@@ -565,10 +618,19 @@ bool try_launch4(const ConvP& p0, hipStream_t s) {
     const size_t sm4 = std::max<size_t>(4 * (size_t)(256 + 256) * 64, epilogue_smem_bytes<OT, 256, 256>());
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
       attr_set = true;
     }
-    hipLaunchKernelGGL((conv_glds4_kernel<T, OT>), dim3(p.nblocks), dim3(512), sm4, s, p);
+    // ping-pong schedule for the MFMA-bound shapes (+12...15 % at K >= 512, neutral at 256, a loss for the
+    // HBM-bound K = 64 / 128 layers that finish in two or four steps)
+    static const char* dev_pp = getenv("DAS_DEV_GLDS4_PP");  // tuning only: 0 / 1 forces the choice
+    const bool pp = dev_pp ? atoi(dev_pp) == 1 : p.K >= 256;
+    if (pp) {
+      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true>), dim3(p.nblocks), dim3(512), sm4, s, p);
+    } else {
+      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, false>), dim3(p.nblocks), dim3(512), sm4, s, p);
+    }
     return true;
   } else {
     return false;
