@@ -237,15 +237,16 @@ __device__ __forceinline__ RowGeom row_geom(const ConvP& p, int m) {
     g.H = p.H; g.W = p.W;
     return g;
   }
-  int l = 0;
+  // (static indices only: a dynamically indexed p.lvH[l] makes the compiler keep a private copy of p in scratch)
+  int Hl = p.lvH[0], Wl = p.lvW[0], start = p.lvStart[0];
 #pragma unroll
   for (int i = 1; i < MAXLV; ++i)
-    if (i < p.nlev && m >= p.lvStart[i]) l = i;
-  const int Hl = p.lvH[l], Wl = p.lvW[l], hw = Hl * Wl;
-  const int local = m - p.lvStart[l];
+    if (i < p.nlev && m >= p.lvStart[i]) { Hl = p.lvH[i]; Wl = p.lvW[i]; start = p.lvStart[i]; }
+  const int hw = Hl * Wl;
+  const int local = m - start;
   const int b = local / hw, rem = local - b * hw;
   const int ho = rem / Wl, wo = rem - ho * Wl;
-  g.pix0 = (long long)p.lvStart[l] + (long long)b * hw;
+  g.pix0 = (long long)start + (long long)b * hw;
   g.hi0 = ho - p.pad;
   g.wi0 = wo - p.pad;
   g.H = Hl; g.W = Wl;

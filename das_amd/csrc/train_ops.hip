@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <type_traits>
 
 #include "conv_common.h"
 
@@ -44,51 +46,142 @@ struct WG<float> {
   static __device__ __forceinline__ int swz(int slot, int row) { return slot; }
 };
 
-// Walks an output-pixel row index forward without divisions (the pixel-row reduction advances every lane's
-// row by a constant each step); falls back to a full decode only when a ragged level boundary is crossed.
+// The pixel-row reduction advances every staged row by a constant each step, and the rows ONE wave stages per
+// step are ROWS consecutive pixel rows. So a single wave-uniform walker (scalar registers, SALU) follows the
+// first of them — without divisions and, on the common path, WITHOUT BRANCHES — and each lane derives its own
+// row from it with one wrap test; only when the ROWS rows straddle the end of an image plane (or of the tensor)
+// do the lanes decode their row in full. What this replaced and why (both measured on the 3x3 256->256 layer):
+// a walker per lane costs ~100 VALU instructions per staged instruction pair, more than the MFMAs the data
+// feeds; and a walker with loops and early-outs costs ~10 taken branches per step, each an instruction-fetch
+// round trip — the kernel ran at the same speed with its MFMAs or its DMAs removed.
 struct RowWalk {
-  int b, h, w;   // image, output row, output column inside the current level
-  RowGeom g;     // input-space geometry of the current row
-  int Ho, Wo;    // output plane size of the current level
-  long long m;
+  int m;            // first row of the wave (saturates at M)
+  int h, w;         // output row / column of row m inside its image plane
+  int Ho, Wo;       // output plane of the current level
+  int H, W;         // input plane of the current level
+  long long pix0;   // first pixel of the image plane in x
+  unsigned wmagic;  // 2^32 / Wo + 1: umulhi(t, wmagic) == t / Wo for the t < Wo + 64 a step produces
 };
 __device__ __forceinline__ void walk_refresh(const ConvP& p, RowWalk& r) {
-  r.g = row_geom(p, (int)min(r.m, (long long)p.M));
-  if (r.m >= p.M) return;
+  const RowGeom g = row_geom(p, r.m);
+  if (r.m >= p.M) {  // past the end: every lane takes the full decode, which masks the row
+    r.h = r.w = 0; r.Ho = r.Wo = 1; r.H = r.W = 0; r.pix0 = 0; r.wmagic = 0;
+    return;
+  }
+  r.H = g.H; r.W = g.W; r.pix0 = g.pix0;
   if (p.nlev <= 1) {
-    const int mm = (int)r.m;
-    r.b = mm / p.HoWo;
-    const int rem = mm - r.b * p.HoWo;
+    const int rem = r.m % p.HoWo;
     r.h = rem / p.Wo; r.w = rem - r.h * p.Wo; r.Ho = p.Ho; r.Wo = p.Wo;
+  } else {  // stride 1, "same" padding
+    r.Ho = g.H; r.Wo = g.W;
+    r.h = g.hi0 + p.pad; r.w = g.wi0 + p.pad;
+  }
+  r.wmagic = 0xFFFFFFFFu / (unsigned)r.Wo + 1u;
+}
+__device__ __forceinline__ void walk_advance(const ConvP& p, RowWalk& r, int n) {   // n <= 64
+  r.m = min(r.m + n, p.M);
+  const int t = r.w + n;
+  const int k = r.Wo == 1 ? t : (int)__umulhi((unsigned)t, r.wmagic);   // image rows wrapped
+  r.w = t - k * r.Wo;
+  r.h += k;
+  // next image (or next ragged level, or the end): decode once — every Ho * Wo / n steps
+  if (__builtin_expect(r.h >= r.Ho || r.m >= p.M, 0)) walk_refresh(p, r);
+}
+template <int ROWS>
+__device__ __forceinline__ bool rows_in_plane(const ConvP& p, const RowWalk& r) {
+  return r.m + ROWS <= p.M && r.Wo >= ROWS && (r.Ho - r.h) * r.Wo - r.w >= ROWS;
+}
+struct LaneRow {
+  int hi0, wi0, H, W;
+  long long pix0;
+  bool ok;   // row < M
+};
+template <bool IN_PLANE>
+__device__ __forceinline__ LaneRow lane_row(const ConvP& p, const RowWalk& r, int d) {
+  LaneRow o;
+  if constexpr (IN_PLANE) {
+    int w = r.w + d;
+    const bool wrap = w >= r.Wo;
+    w -= wrap ? r.Wo : 0;
+    const int h = r.h + (wrap ? 1 : 0);
+    o.hi0 = h * p.stride - p.pad;
+    o.wi0 = w * p.stride - p.pad;
+    o.H = r.H; o.W = r.W; o.pix0 = r.pix0; o.ok = true;
   } else {
-    r.Ho = r.g.H; r.Wo = r.g.W;
-    r.h = r.g.hi0 + p.pad; r.w = r.g.wi0 + p.pad;
-    int l = 0;
-    for (int i = 1; i < MAXLV; ++i)
-      if (i < p.nlev && r.m >= p.lvStart[i]) l = i;
-    r.b = (int)((r.m - p.lvStart[l]) / (r.Ho * r.Wo));
+    const RowGeom g = row_geom(p, min(r.m + d, p.M));
+    o.hi0 = g.hi0; o.wi0 = g.wi0; o.H = g.H; o.W = g.W; o.pix0 = g.pix0; o.ok = r.m + d < p.M;
+  }
+  return o;
+}
+
+// ---- the pixel-row splits of one (Cout, K) tile are summed in a second pass, not with atomics ----
+// f32 atomics retire at ~1 lane per clock per L2 channel: the 12.6 M atomics of a 768-workgroup launch cost
+// 38 us whatever their address pattern (probe: tools/dev/probe/atomic_probe.hip), 40 % of the average
+// weight-gradient launch of a training step. Plain stores move the same bytes at HBM speed, so every workgroup
+// stores its accumulators — in register order, one coalesced float4 per lane — into a per-stream workspace
+// [split][tile][slot], and wgrad_reduce_kernel sums the splits of every slot in a fixed order (deterministic
+// when one reduce group covers all splits) and adds the result into dW.
+template <int WAVES_, int TA_>
+struct AccMap {   // register order of a workgroup tile: slot = ((wave * TA + a) * 4 + b) * 64 + lane, float4 = j
+  static constexpr int WAVES = WAVES_, TA = TA_, SLOTS = WAVES_ * TA_ * 4 * 64;
+};
+struct AccMap128 : AccMap<4, 4> {   // conv_wgrad_kernel: 128 x 128, waves 2 x 2 of 64 x 64
+  static constexpr int TILE = 128;
+  static __device__ __forceinline__ int wave_o(int wave) { return (wave >> 1) * 64; }
+  static __device__ __forceinline__ int wave_n(int wave) { return (wave & 1) * 64; }
+};
+struct AccMap256 : AccMap<8, 8> {   // conv_wgrad_pp_kernel: 256 x 256, waves 2 x 4 of 128 x 64
+  static constexpr int TILE = 256;
+  static __device__ __forceinline__ int wave_o(int wave) { return (wave & 1) * 128; }
+  static __device__ __forceinline__ int wave_n(int wave) { return (wave >> 2) * 128 + ((wave >> 1) & 1) * 64; }
+};
+template <typename MAP, int TA>
+__device__ __forceinline__ void store_partial_tile(float* ws, int split, int tiles, int tile, int wave, int lane,
+                                                   int o_left, int n_left, const f32x4_t (&acc)[TA][4]) {
+  f32x4_t* dst = reinterpret_cast<f32x4_t*>(ws) + ((size_t)split * tiles + tile) * MAP::SLOTS + wave * (TA * 4 * 64) + lane;
+#pragma unroll
+  for (int a = 0; a < TA; ++a) {
+    if (MAP::wave_o(wave) + a * 16 >= o_left) break;   // rows past Cout / columns past K: never read back
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (MAP::wave_n(wave) + b * 16 < n_left) dst[(a * 4 + b) * 64] = acc[a][b];
   }
 }
-__device__ __forceinline__ void walk_advance(const ConvP& p, RowWalk& r, int n) {
-  r.m += n;
-  if (r.m >= p.M) { r.g.hi0 = -(1 << 28); return; }
-  r.w += n;
-  while (r.w >= r.Wo) { r.w -= r.Wo; ++r.h; }
-  bool crossed = false;
-  while (r.h >= r.Ho) { r.h -= r.Ho; ++r.b; crossed = true; }
-  if (crossed && (p.nlev > 1 && r.b >= p.B)) { walk_refresh(p, r); return; }   // next ragged level
-  if (crossed) r.g.pix0 = (p.nlev <= 1) ? (long long)r.b * p.H * p.W : r.g.pix0;  // (ragged: fixed below)
-  if (p.nlev <= 1) {
-    r.g.hi0 = r.h * p.stride - p.pad;
-    r.g.wi0 = r.w * p.stride - p.pad;
-  } else {
-    if (crossed) { walk_refresh(p, r); return; }  // new image inside a level: recompute the plane origin
-    r.g.hi0 = r.h - p.pad;
-    r.g.wi0 = r.w - p.pad;
+// grid (tiles * SLOTS / 256, groups): every thread owns one float4 slot of one tile and sums it over the splits
+// of its group; one group writes (or adds to) dW directly, several groups (tiny layers: few tiles, hundreds of
+// splits) add atomically into a zeroed / accumulating dW.
+template <typename MAP>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           int tiles, int ntiles, int splits, int Cout, int K,
+                                                           int accumulate) {
+  constexpr int BPT = MAP::SLOTS / 256;
+  const int tile = blockIdx.x / BPT, slot = (blockIdx.x % BPT) * 256 + threadIdx.x;
+  const int lane = slot & 63, b = (slot >> 6) & 3, a = (slot >> 8) % MAP::TA, wave = slot / (MAP::TA * 256);
+  const int o0 = (tile / ntiles) * MAP::TILE + MAP::wave_o(wave) + a * 16 + (lane >> 4) * 4;
+  const int n = (tile % ntiles) * MAP::TILE + MAP::wave_n(wave) + b * 16 + (lane & 15);
+  if ((tile / ntiles) * MAP::TILE + MAP::wave_o(wave) + a * 16 >= Cout || n >= K) return;
+  const int per = (splits + gridDim.y - 1) / gridDim.y;
+  const int s0 = blockIdx.y * per, s1 = min(splits, s0 + per);
+  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(ws) + (size_t)tile * MAP::SLOTS + slot;
+  const size_t stride = (size_t)tiles * MAP::SLOTS;
+  f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+  int s = s0;
+  for (; s + 4 <= s1; s += 4) {
+    const f32x4_t v0 = src[(size_t)s * stride], v1 = src[(size_t)(s + 1) * stride];
+    const f32x4_t v2 = src[(size_t)(s + 2) * stride], v3 = src[(size_t)(s + 3) * stride];
+    sum += (v0 + v1) + (v2 + v3);
+  }
+  for (; s < s1; ++s) sum += src[(size_t)s * stride];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (o0 + j >= Cout) break;
+    float* d = dw + (size_t)(o0 + j) * K + n;
+    if (gridDim.y > 1) atomicAdd(d, sum[j]);
+    else *d = accumulate ? *d + sum[j] : sum[j];
   }
 }
 
-// p.x = forward input X, p.res = dY (pixel stride p.rps), p.y = dW f32 [Cout][K] (atomically added to).
+// p.x = forward input X, p.res = dY (pixel stride p.rps), p.y = the workspace the partial tiles are stored to.
 template <typename T, int BKM>   // BKM = pixel rows per step
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_block) {
   constexpr int EPV = Elem<T>::EPV;
@@ -114,41 +207,52 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_
   const T* dyg = reinterpret_cast<const T*>(p.res);
   const T* zero = reinterpret_cast<const T*>(g_das_zero_page_train);
 
-  // per (lane, instruction) constants: dY channel, X column -> (tap, ci); plus the row walker
-  int och[IPW], xkh[IPW], xkw[IPW], xci[IPW];
+  // per (lane, instruction) constants: dY pointer of the current row, X column -> (tap, ci); plus the row walker
+  // (wave-uniform: the first of the ROWS consecutive rows this wave stages)
+  constexpr int ROWS = IPW * RPI;
+  int xkh[IPW], xkw[IPW], xci[IPW];
   bool ook[IPW], nok[IPW];
-  RowWalk rw[IPW];
+  const T* dcur[IPW];
+  const int d0 = lane / SLOTS;
 #pragma unroll
   for (int j = 0; j < IPW; ++j) {
-    const int row = (wave * IPW + j) * RPI + lane / SLOTS;
+    const int row = (wave * IPW + j) * RPI + d0;
     const int logical = WG<T>::swz(lane % SLOTS, row);
-    och[j] = o0 + logical * EPV;
-    ook[j] = och[j] < p.Cout;
+    ook[j] = o0 + logical * EPV < p.Cout;
+    dcur[j] = dyg + (m_begin + row) * p.rps + o0 + logical * EPV;
     const int n = n0 + logical * EPV;
     nok[j] = n < p.K;
     const int tap = n / p.Cin;
     xci[j] = n - tap * p.Cin;
     xkh[j] = tap / p.KW;
     xkw[j] = tap - xkh[j] * p.KW;
-    rw[j].m = m_begin + row;
-    walk_refresh(p, rw[j]);
   }
+  RowWalk rw;
+  rw.m = (int)min(m_begin + wave * ROWS, (long long)p.M);
+  walk_refresh(p, rw);
+  const long long dstep = (long long)BKM * p.rps;
 
-  auto issue = [&](int buf) {  // DMA the tiles of the walkers' current rows, then advance them one step
+  auto issue = [&](int buf) {  // DMA the tiles of the walker's current rows, then advance it one step
     char* sD = smem + buf * 2 * TILE;
     char* sX = sD + TILE;
+    auto stage = [&](auto in_plane) {
 #pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      const bool mok = rw[j].m < p.M;
-      const T* sd = (mok && ook[j]) ? dyg + rw[j].m * p.rps + och[j] : zero;
-      dma16(sd, sD + (wave * IPW + j) * 1024);
-      const RowGeom& g = rw[j].g;
-      const int hi = g.hi0 + xkh[j], wi = g.wi0 + xkw[j];
-      const bool ok = mok && nok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-      const T* sx = ok ? xg + (g.pix0 + (long long)hi * g.W + wi) * p.xps + xci[j] : zero;
-      dma16(sx, sX + (wave * IPW + j) * 1024);
-      walk_advance(p, rw[j], BKM);
+      for (int j = 0; j < IPW; ++j) {
+        const LaneRow lr = lane_row<decltype(in_plane)::value>(p, rw, j * RPI + d0);
+        dma16((lr.ok && ook[j]) ? dcur[j] : zero, sD + (wave * IPW + j) * 1024);
+        dcur[j] += dstep;
+        const int hi = lr.hi0 + xkh[j], wi = lr.wi0 + xkw[j];
+        const bool ok = lr.ok && nok[j] && (unsigned)hi < (unsigned)lr.H && (unsigned)wi < (unsigned)lr.W;
+        const T* sx = ok ? xg + (lr.pix0 + hi * lr.W + wi) * p.xps + xci[j] : zero;
+        dma16(sx, sX + (wave * IPW + j) * 1024);
+      }
+    };
+    if (__builtin_expect(rows_in_plane<ROWS>(p, rw), 1)) {
+      stage(std::true_type{});
+    } else {
+      stage(std::false_type{});
     }
+    walk_advance(p, rw, BKM);
   };
 
   f32x4_t acc[4][4];
@@ -159,7 +263,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_
 
   const long long m_left = (long long)p.M - m_begin;
   const int nsteps = (int)std::min<long long>(steps_per_block, (m_left + BKM - 1) / BKM);
-  if (nsteps <= 0) return;
+  if (nsteps <= 0) {   // (the host sizes the grid so that this does not happen; the reduction reads every split)
+    store_partial_tile<AccMap128>(reinterpret_cast<float*>(p.y), chunk, tiles, tile, wave, lane, p.Cout - o0, p.K - n0,
+                                  acc);
+    return;
+  }
   issue(0);
   __syncthreads();
   const int g4 = lane >> 4, q = lane & 15;
@@ -217,18 +325,179 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_
     __syncthreads();
   }
 
-  float* dw = reinterpret_cast<float*>(p.y);
+  store_partial_tile<AccMap128>(reinterpret_cast<float*>(p.y), chunk, tiles, tile, wave, lane, p.Cout - o0, p.K - n0,
+                                  acc);
+}
+
+// Ping-pong variant for bf16 with Cout >= 256 and K >= 256: 256 (Cout) x 256 (K columns) tile, 8 waves (2 x 4),
+// 128 x 64 per wave — at 64 x 64 per wave the transposing LDS reads take as long as the MFMAs they feed (8 KiB
+// per 16 MFMAs, 128 B/clk); 128 x 64 reads 12 KiB per 32. 32 pixel rows per step, four LDS stages of four
+// 8 KiB sub-tiles {dY 0..127 | dY 128..255 | X 0..127 | X 128..255} = 128 KiB -> one workgroup per CU.
+// Operands come in by buffer_load ... lds (out-of-range offset = zeros: rows past M, channels past Cout, padding
+// taps, columns past K), issued three steps ahead. Every step is two barrier intervals, R (issue step s+3, walk
+// the row pointers, transposing LDS reads of step s into registers) and M (32 MFMAs); waves 4-7 run one
+// interval behind waves 0-3 and wave w / w+4 share a SIMD, so the address walk and the LDS reads of one group
+// hide behind the other group's MFMAs (same scheme as conv_glds4_kernel<PP>).
+__global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(ConvP p, int steps_per_block) {
+  using T = bf16_t;
+  constexpr int EPV = 8, ROWB = 256, SLOTS = 16, BKM = 32;
+  constexpr int SUB = BKM * ROWB;                // 8 KiB: 32 rows x 128 channels
+  constexpr int STAGE = 4 * SUB;
+  constexpr int NST = 4;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int ntiles = (p.K + 255) / 256;
+  const int tiles = gridDim.x;
+  const int logical = xcd_remap(blockIdx.x + blockIdx.y * tiles, tiles * gridDim.y);
+  const int tile = logical % tiles, chunk = logical / tiles;
+  const int o0 = (tile / ntiles) * 256, n0 = (tile % ntiles) * 256;
+  // wave tiles: Cout half = wave & 1 (dY sub-tile), K-column quarter = wave >> 1 (X sub-tile wave >> 2)
+  const int wave_dsub = wave & 1, wave_xsub = wave >> 2, wave_n0 = ((wave >> 1) & 1) * 64;
+  const long long m_begin = (long long)chunk * steps_per_block * BKM;
+
+  const v4i_t xrs = make_rsrc(p.x, p.xbytes);
+  const v4i_t drs = make_rsrc(p.res, (unsigned)(((long long)(p.M - 1) * p.rps + p.Cout) * 2));
+
+  // per sub-tile 8 DMA instructions (4 rows each); wave w stages instructions (w & 3) * 2 + {0, 1} of the dY and
+  // of the X sub-tile (w >> 2)
+  unsigned dcur[2];
+  bool dok[2], nok[2];
+  int xkh[2], xkw[2], xci2[2];
+  RowWalk rw;   // wave-uniform: the first of this wave's 8 consecutive rows
+  rw.m = (int)min(m_begin + (wave & 3) * 8, (long long)p.M);
+  walk_refresh(p, rw);
+  const int d0 = lane / SLOTS;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int j = 0; j < 2; ++j) {
+    const int row = ((wave & 3) * 2 + j) * 4 + d0;
+    const int c = (wave >> 2) * 128 + WG<T>::swz(lane % SLOTS, row) * EPV;
+    dok[j] = o0 + c < p.Cout;
+    dcur[j] = (unsigned)((((long long)m_begin + row) * p.rps + o0 + c) * 2);
+    const int n = n0 + c;
+    nok[j] = n < p.K;
+    const int tap = n / p.Cin;
+    xci2[j] = (n - tap * p.Cin) * 2;
+    xkh[j] = tap / p.KW;
+    xkw[j] = tap - xkh[j] * p.KW;
+  }
+  const unsigned dstep = (unsigned)BKM * (unsigned)p.rps * 2u;
+  const int xps2 = p.xps * 2;
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto issue = [&](int stage) {   // DMA the tiles of the walker's current rows, then advance it one step
+    const unsigned sD = lds0 + stage * STAGE + (wave >> 2) * SUB + (wave & 3) * 2048;
+    const unsigned sX = sD + 2 * SUB;
+    auto stage_rows = [&](auto in_plane) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int n = n0 + wave_n0 + b * 16 + q;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int o = o0 + wave_o0 + a * 16 + g4 * 4 + j;
-        if (o < p.Cout && n < p.K) atomicAdd(dw + (long long)o * p.K + n, acc[a][b][j]);
+      for (int j = 0; j < 2; ++j) {
+        const LaneRow lr = lane_row<decltype(in_plane)::value>(p, rw, j * 4 + d0);
+        dma16_buf(dok[j] && lr.ok ? dcur[j] : OOB, drs, sD + j * 1024);
+        dcur[j] += dstep;
+        const int hi = lr.hi0 + xkh[j], wi = lr.wi0 + xkw[j];
+        const bool ok = lr.ok && nok[j] && (unsigned)hi < (unsigned)lr.H && (unsigned)wi < (unsigned)lr.W;
+        // (32-bit: the host only takes this kernel when x is addressable by a buffer descriptor)
+        const unsigned off = (unsigned)(((int)lr.pix0 + hi * lr.W + wi) * xps2 + xci2[j]);
+        dma16_buf(ok ? off : OOB, xrs, sX + j * 1024);
       }
+    };
+    if (__builtin_expect(rows_in_plane<8>(p, rw), 1)) {
+      stage_rows(std::true_type{});
+    } else {
+      stage_rows(std::false_type{});
     }
+    walk_advance(p, rw, BKM);
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const long long m_left = (long long)p.M - m_begin;
+  const int nsteps = (int)std::min<long long>(steps_per_block, (m_left + BKM - 1) / BKM);
+  if (nsteps <= 0) {   // (the host sizes the grid so that this does not happen; the reduction reads every split)
+    store_partial_tile<AccMap256>(reinterpret_cast<float*>(p.y), chunk, tiles, tile, wave, lane, p.Cout - o0, p.K - n0,
+                                  acc);
+    return;
+  }
+  // each wave has 4 DMAs in flight per staged step
+  auto wait_steps = [&](int ahead) {   // ... until at most `ahead` staged steps of this wave are still in flight
+    if (ahead >= 2) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (ahead == 1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  issue(0);
+  if (nsteps > 1) issue(1);
+  if (nsteps > 2) issue(2);
+  wait_steps(std::min(nsteps, 3) - 1);
+  __builtin_amdgcn_s_barrier();                 // step 0 landed
+  if (grp == 1) __builtin_amdgcn_s_barrier();   // trailing group: one interval behind
+  const int g4 = lane >> 4, q = lane & 15;
+  int st = 0, nst = 3;   // stage of step s, stage that step s+3 goes to
+  for (int s = 0; s < nsteps; ++s) {
+    // ---- R
+    if (s + 3 < nsteps) issue(nst);
+    const char* sD = smem + st * STAGE + wave_dsub * SUB;
+    const char* sX = smem + st * STAGE + (2 + wave_xsub) * SUB;
+    uint4 fa[8], fb[4];
+    const int sub = q & 3;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      v4i16_t lo[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = h * 16 + g4 * 4 + (q >> 2);
+        const int sa = WG<T>::swz(t * 2 + (sub >> 1), row);
+        lo[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t*)(sD + row * ROWB + sa * 16 + (sub & 1) * 8));
+      }
+      fa[t] = make_uint4(__builtin_bit_cast(uint2, lo[0]).x, __builtin_bit_cast(uint2, lo[0]).y,
+                         __builtin_bit_cast(uint2, lo[1]).x, __builtin_bit_cast(uint2, lo[1]).y);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      v4i16_t hi[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = h * 16 + g4 * 4 + (q >> 2);
+        const int sb = WG<T>::swz(((wave_n0 + t * 16) >> 3) + (sub >> 1), row);
+        hi[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4i16_t*)(sX + row * ROWB + sb * 16 + (sub & 1) * 8));
+      }
+      fb[t] = make_uint4(__builtin_bit_cast(uint2, hi[0]).x, __builtin_bit_cast(uint2, hi[0]).y,
+                         __builtin_bit_cast(uint2, hi[1]).x, __builtin_bit_cast(uint2, hi[1]).y);
+    }
+    // the steps issued after step s+1 that may still fly: s+2 and (if it exists) s+3
+    if (grp == 1) wait_steps(std::min(nsteps - 1, s + 3) - (s + 1));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired before the buffers are re-staged
+    __builtin_amdgcn_s_barrier();
+    // ---- M
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                            __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) wait_steps(std::min(nsteps - 1, s + 3) - (s + 1));
+    __builtin_amdgcn_s_barrier();
+    st = (st + 1) & (NST - 1);
+    nst = (nst + 1) & (NST - 1);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // leading group: match the trailing group's extra interval
+
+  store_partial_tile<AccMap256>(reinterpret_cast<float*>(p.y), chunk, tiles, tile, wave, lane, p.Cout - o0, p.K - n0,
+                                  acc);
 }
 
 // ------------------------------------------------------------------ column sums (bias gradient)
@@ -425,6 +694,43 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
 }
 }  // namespace
 
+// Workspace of the weight gradient's partial tiles: one buffer per (device, stream) — launches on one stream are
+// ordered, so consecutive layers reuse it — 64 MiB covers every grid the launcher below picks (1024 workgroups
+// x 64 KiB, or 256 x 256 KiB); a larger request (tuning overrides) grows it after draining the stream.
+static float* wgrad_workspace(hipStream_t s, size_t bytes) {
+  struct Entry { int dev; hipStream_t s; float* buf; size_t bytes; bool used; };
+  static Entry table[16];
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  Entry* e = nullptr;
+  for (Entry& t : table)
+    if (t.used && t.dev == dev && t.s == s) { e = &t; break; }
+  if (!e) {
+    for (Entry& t : table)
+      if (!t.used) { e = &t; break; }
+    if (!e) {   // table full (streams that came and went): take over the first entry's buffer
+      e = &table[0];
+      if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+      if (e->dev != dev && e->buf) { (void)hipFree(e->buf); e->buf = nullptr; e->bytes = 0; }
+      e->dev = dev; e->s = s;
+    } else {
+      *e = Entry{dev, s, nullptr, 0, true};
+    }
+  }
+  if (e->bytes < bytes) {
+    if (e->buf) {
+      if (hipStreamSynchronize(s) != hipSuccess || hipFree(e->buf) != hipSuccess) return nullptr;
+      e->buf = nullptr; e->bytes = 0;
+    }
+    const size_t want = std::max<size_t>(bytes, (size_t)64 << 20);
+    if (hipMalloc(reinterpret_cast<void**>(&e->buf), want) != hipSuccess) { e->buf = nullptr; return nullptr; }
+    e->bytes = want;
+  }
+  return e->buf;
+}
+
 extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate,
                                      void* stream) {
   if (!x || !dy || !dw || !d) return DAS_ERR_ARG;
@@ -443,7 +749,7 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
     }
   }
   for (int l = (p.nlev > 1 ? p.nlev : 0); l < MAXLV; ++l) { p.lvH[l] = 0; p.lvW[l] = 0; p.lvStart[l] = 0x7fffffff; }
-  if (M <= 0 || M > 0x7fffffffLL) return DAS_ERR_ARG;
+  if (M <= 0 || M > 0x7fffff00LL) return DAS_ERR_ARG;   // (the row walker adds a step to a row index in 32 bits)
   p.x = (const char*)x; p.w = nullptr; p.y = (char*)dw; p.res = (const char*)dy;
   p.scale = p.shift = nullptr; p.stats = nullptr;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.xps = d->x_pix_stride;
@@ -453,8 +759,48 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0; p.xbytes = 0;
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * p.K, s) != hipSuccess) return DAS_ERR_LAUNCH;
-  const int tiles = ((d->Cout + 127) / 128) * ((p.K + 127) / 128);
+  // second pass: sum the splits of every tile into dW (see wgrad_reduce_kernel)
+  auto reduce = [&](auto map, int tiles, int ntiles, long long splits) -> int {
+    using MAP = decltype(map);
+    const int blocks = tiles * (MAP::SLOTS / 256);
+    // tiny layers have few tiles and hundreds of splits: several reduce groups, each adding atomically
+    const int groups = (int)std::max<long long>(1, std::min<long long>(splits / 4, 512 / blocks));
+    if (groups > 1 && !accumulate &&
+        hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * p.K, s) != hipSuccess)
+      return DAS_ERR_LAUNCH;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<MAP>, dim3(blocks, groups), dim3(256), 0, s, (const float*)p.y, dw, tiles,
+                       ntiles, (int)splits, d->Cout, p.K, accumulate);
+    DAS_CHECK_LAUNCH();
+    return DAS_OK;
+  };
+  static const char* dev_pp = getenv("DAS_DEV_WGRAD_PP");  // tuning only: minimum K for the ping-pong kernel
+  if (d->dtype == DAS_BF16 && dev_pp && p.K >= atoi(dev_pp) && d->Cout >= 256) {
+    const long long npix = p.nlev > 1 ? M : (long long)d->B * d->H * d->W;
+    const long long xb = ((npix - 1) * d->x_pix_stride + d->Cin) * 2;
+    const long long db = ((M - 1) * d->y_pix_stride + d->Cout) * 2;
+    if (xb < 0xFFFFFFF0LL && db < 0xFFFFFFE0LL) {
+      p.xbytes = (unsigned)xb;
+      const int ntiles = (p.K + 255) / 256, tiles = ((d->Cout + 255) / 256) * ntiles;
+      const long long total_steps = (M + 31) / 32;
+      long long splits = std::max<long long>(1, 256 / tiles);
+      long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
+      splits = (total_steps + spb - 1) / spb;
+      p.y = (char*)wgrad_workspace(s, (size_t)splits * tiles * AccMap256::SLOTS * 16);
+      if (!p.y) return DAS_ERR_LAUNCH;
+      const size_t sm = 4 * 4 * 32 * 256;
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_wgrad_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
+            hipSuccess)
+          return DAS_ERR_LAUNCH;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3(tiles, (unsigned)splits), dim3(512), sm, s, p, (int)spb);
+      DAS_CHECK_LAUNCH();
+      return reduce(AccMap256{}, tiles, ntiles, splits);
+    }
+  }
+  const int ntiles = (p.K + 127) / 128, tiles = ((d->Cout + 127) / 128) * ntiles;
   // bf16: 32 pixel rows per step = 32 KiB of LDS per workgroup, three workgroups resident per CU (register bound):
   // more independent DMA -> MFMA chains in flight than two workgroups of 64-row steps (+10...14 % measured)
   static const char* dev_bkm = getenv("DAS_DEV_WGRAD_BKM");  // tuning only
@@ -468,6 +814,8 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   long long splits = std::max<long long>(1, target / tiles);
   long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
   splits = (total_steps + spb - 1) / spb;
+  p.y = (char*)wgrad_workspace(s, (size_t)splits * tiles * AccMap128::SLOTS * 16);
+  if (!p.y) return DAS_ERR_LAUNCH;
   if (d->dtype == DAS_BF16) {
     const size_t sm = 2 * 2 * (size_t)bkm * 256;
     if (bkm == 32) {
@@ -482,7 +830,7 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
     return DAS_ERR_ARG;
   }
   DAS_CHECK_LAUNCH();
-  return DAS_OK;
+  return reduce(AccMap128{}, tiles, ntiles, splits);
 }
 
 extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream) {
