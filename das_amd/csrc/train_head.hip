@@ -12,30 +12,132 @@ inline int grid_for(long long n, int cap = 16384) {
 }
 
 // ------------------------------------------------------------------ DCNv2 col2im
-// One thread = one (pixel, tap, channel vector): dx += mask*w_corner*dcol (f32 atomics),
-// d_om[dy,dx,mask logit] += sum over the vector's channels.
-// One WAVE = one (pixel, tap); lane = channel (64 at a time). The four corner scatters of a wave are
-// 256-byte contiguous f32 atomic bursts (two cache lines each) instead of 32-byte-strided ones, and the
-// offset / mask gradients are a wave reduction written once, without atomics.
+// dx[p] = sum over (position q, tap k, corner) whose bilinear corner is pixel p of mask * w_corner * dcol[q][k].
+// As a scatter that is 4 * 9 * C f32 atomics per position, and f32 atomics retire at ~1 lane per clock per L2
+// channel (0.33 G/us on the whole chip, tools/dev/probe/atomic_probe.hip): 3.9 ms per head layer with ONE live
+// corner per tap (zero-initialised offsets), four times that once the offsets have been trained. So dx is
+// computed as a GATHER instead: one wave per pixel p tests the (2R+1)^2 * 9 (position, tap) pairs around p, one
+// pair per lane, and sums the hits — plain stores, a fixed summation order, no zero fill. A pair is REGULAR when
+// both corner rows and columns of its sample lie within R of its own position (|offset| < R - 1): exactly those
+// pairs are complete in the gather. The pair-centric kernel below (offset / mask gradients, a wave reduction
+// written once) scatters only the irregular pairs with atomics, after the gather has written dx.
+constexpr int DCN_R = 3;
+__device__ __forceinline__ void load4(const float* p, float* v) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float* v) {
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ bool dcn_regular(int y0, int x0, int qy, int qx) {
+  return y0 >= qy - DCN_R && y0 + 1 <= qy + DCN_R && x0 >= qx - DCN_R && x0 + 1 <= qx + DCN_R;
+}
+
 template <typename T>
-__global__ void deform_col2im_kernel(const T* __restrict__ x, const float* __restrict__ om, const T* __restrict__ dcol,
-                                     float* __restrict__ dx, float* __restrict__ dom, DasLevels lv, int C, int xps,
-                                     int omps, int domps, long long npairs) {
+__global__ __launch_bounds__(TPB) void deform_col2im_gather_kernel(const float* __restrict__ om,
+                                                                   const T* __restrict__ dcol, float* __restrict__ dx,
+                                                                   DasLevels lv, int C, int omps, long long rows) {
+#pragma clang fp contract(off)
+  constexpr int S = 2 * DCN_R + 1, NP = S * S * 9, ROUNDS = (NP + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const long long m = ((long long)blockIdx.x * TPB + threadIdx.x) >> 6;   // one wave per pixel
+  if (m >= rows) return;
+  const LvGeom g = lv_geom(lv, m);
+  // the candidate pairs of this pixel, one per lane and round: hit / coefficient / dcol row
+  float coef[ROUNDS];
+  int drow[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int e = r * 64 + lane;
+    const int nq = e / 9, k = e - nq * 9;
+    const int qy = g.h + nq / S - DCN_R, qx = g.w + nq % S - DCN_R;
+    coef[r] = 0.f;
+    drow[r] = 0;
+    if (e < NP && (unsigned)qy < (unsigned)g.H && (unsigned)qx < (unsigned)g.W) {
+      const long long mq = m + (long long)(qy - g.h) * g.W + (qx - g.w);
+      const float* o = om + mq * omps;
+      const float ody = o[2 * k], odx = o[2 * k + 1], logit = o[18 + k];
+      const float py = (float)(qy - 1 + k / 3) + ody;
+      const float px = (float)(qx - 1 + k % 3) + odx;
+      if (py > -1.f && px > -1.f && py < (float)g.H && px < (float)g.W) {
+        const float fy = floorf(py), fx = floorf(px);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int cy = g.h - y0, cx = g.w - x0;
+        if (dcn_regular(y0, x0, qy, qx) && (unsigned)cy < 2u && (unsigned)cx < 2u) {
+          const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+          const float wgt = (cy ? ly : hy) * (cx ? lx : hx);
+          const float mask = 1.f / (1.f + expf(-logit));
+          coef[r] = mask * wgt;
+          drow[r] = (int)(mq * 9 + k);
+        }
+      }
+    }
+  }
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int ch = c0 + lane * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      unsigned long long hits = __ballot(coef[r] != 0.f);
+      while (hits) {
+        const int l = __builtin_ctzll(hits);
+        hits &= hits - 1;
+        const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef[r]), l));
+        const int dr = __builtin_amdgcn_readlane(drow[r], l);
+        if (ch < C) {
+          float v[4];
+          load4(dcol + (long long)dr * C + ch, v);
+          a0 += cf * v[0]; a1 += cf * v[1]; a2 += cf * v[2]; a3 += cf * v[3];
+        }
+      }
+    }
+    if (ch < C) *reinterpret_cast<float4*>(dx + m * C + ch) = make_float4(a0, a1, a2, a3);
+  }
+}
+
+// Sum over the wave by DPP row shifts / row broadcasts (no LDS traffic); the total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum63(float v) {
+  v = dpp_add<0x111, 0xF>(v);   // row_shr:1
+  v = dpp_add<0x112, 0xF>(v);   // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);   // row_shr:8  -> lane 15 of every row holds the row's sum
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1, 3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's sum
+  return v;
+}
+
+// One WAVE = one pixel (its nine taps in turn); lane = four channels (256 at a time): the offset / mask
+// gradients, one wave reduction per tap written once, and the corner scatters of the irregular pairs as f32
+// atomics (lane = one channel there, so that a wave's atomics are contiguous). Measured: fetching the nine taps'
+// dcol vectors up front and batching the 27 reductions costs more in registers than it hides in latency.
+template <typename T>
+__global__ __launch_bounds__(TPB) void deform_col2im_kernel(const T* __restrict__ x, const float* __restrict__ om,
+                                                            const T* __restrict__ dcol, float* __restrict__ dx,
+                                                            float* __restrict__ dom, DasLevels lv, int C, int xps,
+                                                            int omps, int domps, long long rows) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
-  const long long wave0 = ((long long)blockIdx.x * TPB + threadIdx.x) >> 6;
-  const long long nwaves = ((long long)gridDim.x * TPB) >> 6;
-  for (long long r = wave0; r < npairs; r += nwaves) {
-    const int k = (int)(r % 9);
-    const long long m = r / 9;
-    const LvGeom g = lv_geom(lv, m);
-    const int H = g.H, W = g.W;
-    const float* o = om + m * omps;
-    const float ody = o[2 * k], odx = o[2 * k + 1];
-    const float mask = 1.f / (1.f + expf(-o[18 + k]));
+  const long long m = ((long long)blockIdx.x * TPB + threadIdx.x) >> 6;
+  if (m >= rows) return;
+  const LvGeom g = lv_geom(lv, m);
+  const int H = g.H, W = g.W;
+  const float ov = lane < 27 ? om[m * omps + lane] : 0.f;
+  const T* dc = dcol + m * 9 * C;
+  float* d = dom + m * domps;
+#pragma unroll 1
+  for (int k = 0; k < 9; ++k) {
+    const float ody = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ov), 2 * k));
+    const float odx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ov), 2 * k + 1));
+    const float logit = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ov), 18 + k));
+    const float mask = 1.f / (1.f + expf(-logit));
     const float py = (float)(g.h - 1 + k / 3) + ody;
     const float px = (float)(g.w - 1 + k % 3) + odx;
-    float* d = dom + m * domps;
     if (!(py > -1.f && px > -1.f && py < (float)H && px < (float)W)) continue;  // wave-uniform
     const float fy = floorf(py), fx = floorf(px);
     const int y0 = (int)fy, x0 = (int)fx;
@@ -44,29 +146,38 @@ __global__ void deform_col2im_kernel(const T* __restrict__ x, const float* __res
     const float wy[4] = {-hx, -lx, hx, lx};   // d(weight)/d(py)
     const float wx[4] = {-hy, hy, -ly, ly};   // d(weight)/d(px)
     float val = 0.f, gpy = 0.f, gpx = 0.f;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-      const int ch = c0 + lane;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+      const int ch = c0 + lane * 4;
       if (ch >= C) break;
-      const float gc = Elem<T>::load(dcol + (m * 9 + k) * C + ch);
+      float gc[4];
+      load4(dc + k * C + ch, gc);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
         if (yy < 0 || yy > H - 1 || xx < 0 || xx > W - 1) continue;  // wave-uniform
         const long long pix = g.plane0 + (long long)yy * W + xx;
-        const float f = Elem<T>::load(x + pix * xps + ch);
-        const float dot = gc * f;
-        // a corner with zero bilinear weight adds exactly 0.0: skip the atomic (wave-uniform). With samples on
-        // the integer grid (zero-initialised offset convs) three of the four corners are such no-ops.
-        if (wts[c] != 0.f) atomicAdd(dx + pix * C + ch, gc * mask * wts[c]);
+        float f[4];
+        load4(x + pix * xps + ch, f);
+        const float dot = (gc[0] * f[0] + gc[1] * f[1]) + (gc[2] * f[2] + gc[3] * f[3]);
         val += wts[c] * dot;
         gpy += wy[c] * dot;
         gpx += wx[c] * dot;
       }
     }
-    val = wave_sum(val);
-    gpy = wave_sum(gpy);
-    gpx = wave_sum(gpx);
-    if (lane == 0) {
+    if (!dcn_regular(y0, x0, g.h, g.w)) {   // (regular pairs: dx comes from the gather kernel)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
+        // a corner with zero bilinear weight adds exactly 0.0: skip the atomics (wave-uniform)
+        if (yy < 0 || yy > H - 1 || xx < 0 || xx > W - 1 || wts[c] == 0.f) continue;
+        float* dst = dx + (g.plane0 + (long long)yy * W + xx) * C;
+        for (int ch = lane; ch < C; ch += 64) atomicAdd(dst + ch, Elem<T>::load(dc + k * C + ch) * mask * wts[c]);
+      }
+    }
+    val = wave_sum63(val);
+    gpy = wave_sum63(gpy);
+    gpx = wave_sum63(gpx);
+    if (lane == 63) {
       d[2 * k] = gpy * mask;
       d[2 * k + 1] = gpx * mask;
       d[18 + k] = val * mask * (1.f - mask);
@@ -293,16 +404,28 @@ extern "C" int das_deform_im2col3x3_backward(const void* x, const float* om, con
   if (!x || !om || !dcol || !dx || !dom || !lv_valid(lv) || C % 8 || x_pix_stride % 8 || om_pix_stride < 27 ||
       dom_pix_stride < 27)
     return DAS_ERR_ARG;
-  const long long npairs = lv_total_rows(*lv) * 9;  // one wave per (pixel, tap)
-  const int blocks = grid_for(npairs * 64, 32768);
+  const long long rows = lv_total_rows(*lv);
+  const long long npairs = rows * 9;  // one wave per (pixel, tap)
+  if (npairs >= 0x7fffffffLL || rows * 64 / TPB >= 0x7fffffffLL) return DAS_ERR_ARG;
+  const int gblocks = (int)((rows * 64 + TPB - 1) / TPB);   // gather: one wave per pixel, writes all of dx
   if (dtype == DAS_BF16) {
-    hipLaunchKernelGGL(deform_col2im_kernel<bf16_t>, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, om, (const bf16_t*)dcol, dx, dom, *lv, C, x_pix_stride, om_pix_stride,
-                       dom_pix_stride, npairs);
+    hipLaunchKernelGGL(deform_col2im_gather_kernel<bf16_t>, dim3(gblocks), dim3(TPB), 0, (hipStream_t)stream, om,
+                       (const bf16_t*)dcol, dx, *lv, C, om_pix_stride, rows);
   } else if (dtype == DAS_F32) {
-    hipLaunchKernelGGL(deform_col2im_kernel<float>, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(deform_col2im_gather_kernel<float>, dim3(gblocks), dim3(TPB), 0, (hipStream_t)stream, om,
+                       (const float*)dcol, dx, *lv, C, om_pix_stride, rows);
+  } else {
+    return DAS_ERR_ARG;
+  }
+  DAS_CHECK_LAUNCH();
+  if (dtype == DAS_BF16) {   // offset / mask gradients (+ the irregular pairs' scatter): one wave per pixel too
+    hipLaunchKernelGGL(deform_col2im_kernel<bf16_t>, dim3(gblocks), dim3(TPB), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, om, (const bf16_t*)dcol, dx, dom, *lv, C, x_pix_stride, om_pix_stride,
+                       dom_pix_stride, rows);
+  } else if (dtype == DAS_F32) {
+    hipLaunchKernelGGL(deform_col2im_kernel<float>, dim3(gblocks), dim3(TPB), 0, (hipStream_t)stream,
                        (const float*)x, om, (const float*)dcol, dx, dom, *lv, C, x_pix_stride, om_pix_stride,
-                       dom_pix_stride, npairs);
+                       dom_pix_stride, rows);
   } else {
     return DAS_ERR_ARG;
   }

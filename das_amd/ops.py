@@ -541,8 +541,7 @@ def deform_im2col3x3_backward(x, om, dcol):
     Cc = xd.shape[-1]
     dx = _empty_like_rows(x, Cc, torch.float32)
     dom = _empty_like_rows(om, omd.shape[-1], torch.float32)
-    _data(dx).zero_()
-    _data(dom).zero_()
+    _data(dom).zero_()   # (dx is written in full by the call)
     lv = _levels(x)
     assert dcd.is_contiguous() and dcd.dtype == xd.dtype
     _lib.check(_lib.load().das_deform_im2col3x3_backward(_ptr(xd), _ptr(omd), _ptr(dcd), _ptr(_data(dx)),

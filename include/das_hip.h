@@ -231,9 +231,10 @@ int das_head_finalize(float* pose_pred, float* ref_uvd, const DasLevels* lv, con
                       int eval_mode, void* stream);
 
 /* Gradients of the head ops above. Scatter-type gradients accumulate into caller-zeroed f32 buffers:
- * dx (rows, C) dense f32, dom (rows, dom_pix_stride) f32 in the om channel order, d_uvd (rows,3J),
- * d_samp_off (rows,8J), d_conf (rows,3J) dense f32. d_raw must be zero-filled by the caller; d_scale
- * f32[5][4] is zeroed by the call. */
+ * dom (rows, dom_pix_stride) f32 in the om channel order, d_uvd (rows,3J), d_samp_off (rows,8J),
+ * d_conf (rows,3J) dense f32. d_raw must be zero-filled by the caller; d_scale f32[5][4] is zeroed by the
+ * call. dx (rows, C) dense f32 of das_deform_im2col3x3_backward is WRITTEN by the call (every element; a
+ * gather over the (position, tap) pairs around each pixel, atomics only for offsets beyond two pixels). */
 int das_deform_im2col3x3_backward(const void* x, const float* om, const void* dcol, float* dx, float* dom, int dtype,
                                   const DasLevels* lv, int C, int x_pix_stride, int om_pix_stride,
                                   int dom_pix_stride, void* stream);
