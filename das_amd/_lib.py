@@ -23,7 +23,7 @@ class DasConvDesc(C.Structure):
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('relu_in', i32), ('relu', i32),
                 ('scale', vp), ('shift', vp), ('residual', vp), ('res_pix_stride', i32), ('stats', vp),
-                ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5), ('in_up', i32)]
+                ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5), ('in_up', i32), ('stats_slots', i32)]
 
 
 class DasPackEntry(C.Structure):
@@ -78,7 +78,8 @@ SIGNATURES = {
     'das_upsample_bilinear_ac': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_add_upsample_nearest': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_add3': (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
-    'das_bn_train_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp, i64, vp]),
+    'das_bn_train_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp, i64, i32,
+                                 vp]),
     'das_groupnorm_nhwc': (i32, [vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp, vp]),
     'das_deform_im2col3x3': (i32, [vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp]),
     'das_offset_sample': (i32, [vp, vp, vp, vp, C.POINTER(DasLevels), i32, i32, i32, i32, i32, i32, vp]),

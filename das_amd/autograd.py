@@ -63,16 +63,16 @@ class ConvBNTrainFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv, bn, relu):
-        from .nn import packed_weight, zeroed_stats
+        from .nn import bn_stats_buffer, packed_weight, sync_stats
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
-        stats = zeroed_stats(2 * w.shape[0], x.device)
+        stats = bn_stats_buffer(x, w.shape[0])
         raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
         mom = bn.momentum if bn.momentum is not None else 0.1
         world = _sync_world(bn)
         stat_count = 0
         if world > 1:   # SyncBN: the statistics are those of all ranks' pixels
-            _all_reduce(stats)
+            stats = sync_stats(stats, w.shape[0], _all_reduce)
             stat_count = (raw.numel() // raw.shape[-1]) * world
         y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,
                                              residual=residual, relu=relu,

@@ -17,6 +17,7 @@ struct ConvP {
   const float* shift;
   const char* res;
   float* stats;
+  int stat_slots;  // stats is [stat_slots][2][Cout]; workgroup b adds into slot b % stat_slots
   int H, W, Cin, xps;
   int Ho, Wo, Cout, yps;
   int KH, KW, stride, pad;
@@ -211,7 +212,8 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
       if (n0 + c < p.Cout) {
         float s = 0.f;
         for (int r = 0; r < RP; ++r) s += red[(which * RP + r) * BN + c];
-        atomicAdd(p.stats + which * p.Cout + n0 + c, s);
+        const int slot = p.stat_slots > 1 ? (int)(blockIdx.x % (unsigned)p.stat_slots) : 0;
+        atomicAdd(p.stats + (slot * 2 + which) * p.Cout + n0 + c, s);
       }
     }
   }

@@ -675,6 +675,7 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   if (M <= 0 || M > 0x7fffffffLL) return DAS_ERR_ARG;
   p.x = (const char*)x; p.w = (const char*)w; p.y = (char*)y;
   p.scale = d->scale; p.shift = d->shift; p.res = (const char*)d->residual; p.stats = d->stats;
+  p.stat_slots = d->stats_slots < 1 ? 1 : d->stats_slots;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.xps = d->x_pix_stride;
   p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.yps = d->y_pix_stride;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;

@@ -24,6 +24,14 @@ __device__ __forceinline__ BnStat bn_stat(const float* __restrict__ stats, int C
   return s;
 }
 
+__global__ void bn_fold_slots_kernel(float* __restrict__ stats, int slots, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = stats[i];
+  for (int k = 1; k < slots; ++k) a += stats[k * n + i];
+  stats[i] = a;
+}
+
 // The "finalize" duties, done by workgroup 0 of the apply kernel (no separate launch): publish mean / invstd for
 // the backward pass, update the running statistics (momentum, unbiased variance) and the batch counter.
 __device__ __forceinline__ void bn_publish(const float* __restrict__ stats, long long count, int C, float* running_mean,
@@ -187,11 +195,19 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
                                   float momentum, float eps, const void* residual, int relu, float* save_mean,
                                   float* save_invstd, long long* num_batches_tracked, long long stat_count,
-                                  void* stream) {
+                                  int stats_slots, void* stream) {
   if (!x || !y || !stats || !gamma || !beta || !save_mean || !save_invstd || C % 8 || count <= 0) return DAS_ERR_ARG;
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
   if (stat_count != 0 && stat_count < count) return DAS_ERR_ARG;
+  if (stats_slots < 0 || stats_slots > 64) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  // the conv epilogue's workgroup slots are folded into slot 0 first (one tiny launch, fixed order): the apply
+  // kernel's 2 M threads each derive their channels' mean / invstd from ONE [2C] array
+  if (stats_slots > 1) {
+    hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((2 * C + TPB - 1) / TPB), dim3(TPB), 0, s, const_cast<float*>(stats),
+                       stats_slots, 2 * C);
+    DAS_CHECK_LAUNCH();
+  }
   const long long nstat = stat_count ? stat_count : count;
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
   const int grid = grid_for(count * vc);

@@ -150,12 +150,12 @@ def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False, skip_through=
     if skip_through:
         return conv_bn(x, conv, bn, relu=relu, residual=residual, relu_in=relu_in), x
     cout = w.shape[0]
-    stats = zeroed_stats(2 * cout, x.device)
+    stats = bn_stats_buffer(x, cout)
     raw = ops.conv2d(x, w, k, k, s, p, relu_in=relu_in, stats=stats)
     mom = bn.momentum if bn.momentum is not None else 0.1
     world, stat_count = ag._sync_world(bn), 0
     if world > 1:   # SyncBN
-        ag._all_reduce(stats)
+        stats = sync_stats(stats, cout, ag._all_reduce)
         stat_count = (raw.numel() // raw.shape[-1]) * world
     y, mean, invstd = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
                                          residual=residual, relu=relu, num_batches_tracked=bn.num_batches_tracked,
@@ -169,7 +169,7 @@ class _ZeroArena:
     epilogue): one memset per ~1M floats instead of one per layer. A slice is only valid for the launches
     issued right after it is taken (stream order makes the wrap-around memset safe)."""
 
-    def __init__(self, cap=1 << 20):
+    def __init__(self, cap=1 << 22):
         self.cap, self.buf, self.off = cap, None, 0
 
     def take(self, n, device):
@@ -189,6 +189,24 @@ _STATS_ARENA = _ZeroArena()
 
 def zeroed_stats(n, device):
     return _STATS_ARENA.take(n, device)[:n]
+
+
+def bn_stats_buffer(x, cout):
+    """Zeroed [slots, 2*cout] accumulators for the conv epilogue's BatchNorm statistics. Thousands of workgroups
+    adding into one [2*cout] array serialise on the same words, so large-M layers spread them over slots
+    (DasConvDesc.stats_slots); das_bn_train_apply sums the slots."""
+    xd = x.data if hasattr(x, 'sizes') else x
+    rows = xd.numel() // xd.shape[-1]
+    slots = 16 if rows >= 65536 else (4 if rows >= 16384 else 1)
+    return zeroed_stats(slots * 2 * cout, xd.device)
+
+
+def sync_stats(stats, cout, all_reduce):
+    """SyncBN: fold the slots, then sum [sum, sum of squares] over the ranks."""
+    if stats.numel() != 2 * cout:
+        stats = stats.view(-1, 2 * cout).sum(0)
+    all_reduce(stats)
+    return stats
 
 
 def conv_plain(x, conv, relu=False, out_dtype=None, out=None):

@@ -287,7 +287,7 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         scale=scale.data_ptr() if scale is not None else None, shift=shift.data_ptr() if shift is not None else None,
         residual=rd.data_ptr() if rd is not None else None, res_pix_stride=_ps(residual) if rd is not None else 0,
         stats=stats.data_ptr() if stats is not None else None, num_levels=len(x.sizes) if ragged else 0,
-        in_up=in_up)
+        in_up=in_up, stats_slots=stats.numel() // (2 * Cout) if stats is not None else 0)
     if ragged:
         for l, (h, w_) in enumerate(x.sizes):
             d.lvl_H[l], d.lvl_W[l] = h, w_
@@ -383,7 +383,7 @@ def add3(a, b, c=None, relu=False):
 
 def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None,
                    relu=False, num_batches_tracked=None, stat_count=0):
-    """x (B,H,W,C) raw conv output, stats f32[2C] from the conv epilogue. Returns y, mean, invstd.
+    """x (B,H,W,C) raw conv output, stats f32[slots][2C] from the conv epilogue. Returns y, mean, invstd.
     num_batches_tracked: the BatchNorm's int64 counter buffer, incremented on the device by the same launch.
     stat_count: global row count when `stats` was all-reduced over ranks (SyncBN); 0 = this tensor's rows."""
     _need_gpu(x, stats)
@@ -398,7 +398,8 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     _lib.check(_lib.load().das_bn_train_apply(_ptr(x), _ptr(y), _DT[x.dtype], count, Cc, _ptr(stats), _ptr(gamma),
                                               _ptr(beta), _ptr(running_mean), _ptr(running_var), momentum, eps,
                                               _ptr(residual), int(relu), _ptr(mean), _ptr(invstd),
-                                              _ptr(num_batches_tracked), int(stat_count), _stream()),
+                                              _ptr(num_batches_tracked), int(stat_count),
+                                              stats.numel() // (2 * Cc), _stream()),
                'das_bn_train_apply')
     return y, mean, invstd
 

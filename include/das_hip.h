@@ -76,6 +76,10 @@ typedef struct {
    * das_conv2d_nhwc(x = dY, w = flipped/transposed weights, stride 1, pad = KH-1-pad, in_up = s,
    * Ho/Wo = the forward input size). */
   int in_up;
+  /* stats is f32[stats_slots][2*Cout] (0 = 1 slot): workgroup b adds into slot b % stats_slots. Thousands of
+   * workgroups adding into ONE [2*Cout] array serialise on the same words (~13 ns each: +44 us on the
+   * 64-channel convs of the 128 x 208 stage); das_bn_train_apply sums the slots. */
+  int stats_slots;
 } DasConvDesc;
 int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream);
 
@@ -174,11 +178,13 @@ int das_add3(const void* a, const void* b, const void* c, void* y, int dtype, lo
  * num_batches_tracked: optional device int64 scalar (the BatchNorm buffer of that name), incremented by 1.
  * stat_count: the population behind `stats` when it is larger than this tensor's `count` rows — SyncBN
  * (`norm_cfg=dict(type='SyncBN')`, configs/_base_/models/das.py): the caller all-reduces `stats` over the ranks
- * first and passes the global row count; 0 = count. */
+ * first and passes the global row count; 0 = count. stats_slots: `stats` is f32[stats_slots][2*C] partial sums
+ * (DasConvDesc.stats_slots; 0 = 1); with more than one slot the call folds them into slot 0 in place first. */
 int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
                        const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, const void* residual, int relu, float* save_mean,
-                       float* save_invstd, long long* num_batches_tracked, long long stat_count, void* stream);
+                       float* save_invstd, long long* num_batches_tracked, long long stat_count, int stats_slots,
+                       void* stream);
 
 /* Ragged multi-level pixel rows. The DASHead shares its weights across FPN levels
  * (das_head.py:176-178 `multi_apply(self.forward_single, feats, ...)`), so the head ops below take
