@@ -182,6 +182,24 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
                                       launches=v[2] // reps) for k, v in fam.items()})
 
 
+def attach_traffic(roof, workload, batch):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel family from the PMC passes (FETCH_SIZE x 2 +
+    WRITE_SIZE; collected in separate rocprofv3 --pmc runs, tools/dev/scripts/pmc_*.sh -> profiles/traffic.json).
+    Only a measurement taken on this workload's shapes and batch size is used; anything else stays null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic.json')
+    default_batch = {'train': 16, 'infer': 8}[workload]
+    try:
+        with open(path) as f:
+            entry = json.load(f)['families'][roof['kernel']][workload]
+    except (OSError, KeyError, ValueError):
+        return
+    if batch != default_batch:
+        return
+    roof['traffic'] = round(entry['hbm_mb_per_launch'] * 1e6)
+    roof['traffic_unit'] = 'bytes per launch (HBM, PMC)'
+    roof['traffic_source'] = entry['source']
+
+
 def decode_workload(args, rank, world, dev):
     """BASELINE configs[4]: exp_mupots geometry (1024x768 input, J=21, strides 8..64 -> 16 320 locations per
     image), decode only: score / threshold / per-level top-k / OKS-NMS of `batch` images per step (one workgroup
@@ -365,6 +383,8 @@ def main():
         extra['poses_per_step_rank0'] = sum(len(r['scores']) for r in res)
 
     roof = roofline_from_profile(ops, step, args.dtype)
+    if roof is not None:
+        attach_traffic(roof, 'train' if train else 'infer', batch)
 
     if rank == 0:
         total_imgs = batch * world * steps

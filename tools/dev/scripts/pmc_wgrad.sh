@@ -12,7 +12,9 @@ timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc/ww -o ww
 echo "write pass rc=$?"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc/inf -o inf -- python3 bench.py --workload infer --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc/inf.log 2>&1
 echo "infer fetch pass rc=$?"
-for t in wf ww inf; do
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc/infw -o infw -- python3 bench.py --workload infer --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc/infw.log 2>&1
+echo "infer write pass rc=$?"
+for t in wf ww inf infw; do
   db=$(find gpurun_out/pmc/$t -name "*.db" | head -1)
   [ -n "$db" ] && python3 tools/dev/pmc_summary.py "$db" gpurun_out/pmc/$t.md "$t" gpurun_out/pmc/$t.json | tail -1
   # the raw databases are large: keep only the summaries
