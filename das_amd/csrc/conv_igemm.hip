@@ -603,6 +603,211 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   return DAS_OK;
 }
 
+// ------------------------------------------------------------------ streaming 1x1 convolution
+// The large-M 1x1 layers with K <= 256 (the expand / reduce convs of the 128x208 ... 32x52 stages, forward and data
+// gradient) are HBM-bound: 2 * M * (Cin + Cout) bytes against K <= 256 MACs per output. On the tile kernels above
+// they run at 2...3.6x their HBM floor, because a workgroup that finishes its K loop in 2...8 steps spends its life in
+// the serial load -> MFMA -> store phases of one tile. This kernel is PERSISTENT: the wave's slice of the weights
+// (32 channels x K, the MFMA A fragments) stays in registers for the whole launch, the workgroup walks the pixel rows
+// in tiles of 64, DMAs them (64 x K, 64-channel sub-tiles with the 128-byte-row swizzle of conv_glds_kernel) three
+// tiles ahead into four LDS stages, and stores straight from the accumulators: with the MFMA row
+// -> channel permutation below a lane owns EIGHT consecutive channels of a pixel, i.e. one 16-byte store.
+// BatchNorm statistics accumulate in registers over the whole launch (one round of atomics per workgroup).
+// vmcnt counts loads and stores alike and orders them only within each kind, so a wave that stores cannot count its
+// way to "tile i has landed". Hence two kinds of waves: waves 0-7 multiply and store and never wait on memory;
+// waves 8-9 only issue the DMA, three tiles ahead into four LDS stages, wait with a counted vmcnt and release the
+// others through the workgroup barrier (one barrier per tile).
+template <int KB, int WN>   // K = 32 * KB input channels; WN waves across the 32-channel groups, 8 / WN across pixels
+__global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, int ntiles) {
+  using T = bf16_t;
+  constexpr int WM = 8 / WN, TM = 64, PB = TM / WM / 16;    // 16-pixel blocks per wave and tile
+  constexpr int K = KB * 32, SUBS = (K + 63) / 64;
+  constexpr int SUBB = TM * 128, STAGE = SUBS * SUBB;       // bytes
+  constexpr int NS = 4, AHEAD = 3;                          // LDS stages, tiles in flight
+  constexpr int IPL = SUBS * 4;                             // DMA instructions per loader wave and tile
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int logical0 = xcd_remap(blockIdx.x, gridDim.x);
+  if (wave >= 8) {   // ---- loader waves
+    const int first = logical0 / ncol, tstride = gridDim.x / ncol;
+    const int ldr = wave - 8;
+    const v4i_t xrs = make_rsrc(p.x, p.xbytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned xrow2 = (unsigned)p.xps * 2u;
+    auto issue = [&](int tile, int stage) {
+#pragma unroll
+      for (int j = 0; j < IPL; ++j) {
+        const int ii = ldr * IPL + j, sub = ii >> 3, rr = ii & 7;
+        const int row = rr * 8 + (lane >> 3);
+        const int kslot = (lane & 7) ^ ((row >> 1) & 7);
+        const long long m = (long long)tile * TM + row;
+        const bool ok = m < p.M && sub * 64 + kslot * 8 < K;
+        const unsigned off = (unsigned)m * xrow2 + (unsigned)(sub * 64 + kslot * 8) * 2u;
+        dma16_buf(ok ? off : OOB, xrs, lds0 + stage * STAGE + sub * SUBB + rr * 1024);
+      }
+    };
+    const int mine = first < ntiles ? (ntiles - first + tstride - 1) / tstride : 0;   // tiles of this workgroup
+    for (int i = 0; i < AHEAD && i < mine; ++i) issue(first + i * tstride, i);
+    for (int i = 0; i < mine; ++i) {
+      const int later = min(mine - 1 - i, AHEAD - 1);   // tiles issued after tile i that may still be in flight
+      if (later >= 2) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPL) : "memory");
+      } else if (later == 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPL) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();   // tile i is in LDS; the other waves are done with tile i - 1
+      if (i + AHEAD < mine) issue(first + (i + AHEAD) * tstride, (i + AHEAD) % NS);
+    }
+    return;
+  }
+  const int wn = wave % WN, wm = wave / WN;
+  const int logical = logical0;   // the column blocks of a tile share an XCD (its L2)
+  const int col = logical % ncol, first = logical / ncol, tstride = gridDim.x / ncol;
+  const int n0 = col * (32 * WN) + wn * 32;                // this wave's 32 output channels
+  const int q = lane & 15, g4 = lane >> 4;
+
+  // weights -> MFMA A fragments. MFMA row R of half a holds channel n0 + (R >> 2) * 8 + a * 4 + (R & 3), so that the
+  // accumulator lane (pixel q, rows g4 * 4 + j) owns channels n0 + g4 * 8 + a * 4 + j: eight consecutive ones.
+  uint4 wf[2][KB];
+  {
+    const T* wg = reinterpret_cast<const T*>(p.w);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ch = n0 + (q >> 2) * 8 + a * 4 + (q & 3);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+        wf[a][kb] = ch < p.Cout ? *reinterpret_cast<const uint4*>(wg + (long long)ch * K + kb * 32 + g4 * 8)
+                                : make_uint4(0, 0, 0, 0);
+    }
+  }
+  const int c8 = n0 + g4 * 8;   // this lane's eight output channels
+  const bool cok = c8 < p.Cout;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = (p.scale && cok) ? p.scale[c8 + j] : 1.f;
+    sh[j] = (p.shift && cok) ? p.shift[c8 + j] : 0.f;
+  }
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+
+  T* yg = reinterpret_cast<T*>(p.y);
+  const T* rg = reinterpret_cast<const T*>(p.res);
+  int st = 0;
+  for (int t = first; t < ntiles; t += tstride) {
+    asm volatile("" ::: "memory");   // (this wave's LDS reads and stores of the previous tile stay above the barrier)
+    __builtin_amdgcn_s_barrier();    // the loader waves saw tile t land
+    asm volatile("" ::: "memory");
+    const char* sx = smem + st * STAGE;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const int row = wm * (TM / WM) + pb * 16 + q;
+      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int slot = ((kb & 1) * 4 + g4) ^ ((row >> 1) & 7);
+        const uint4 bf = *reinterpret_cast<const uint4*>(sx + (kb >> 1) * SUBB + row * 128 + slot * 16);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[0][kb]),
+                                                       __builtin_bit_cast(bf16x8_t, bf), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[1][kb]),
+                                                       __builtin_bit_cast(bf16x8_t, bf), acc1, 0, 0, 0);
+      }
+      const long long m = (long long)t * TM + row;
+      if (m < p.M && cok) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = acc0[j] * sc[j] + sh[j]; v[4 + j] = acc1[j] * sc[4 + j] + sh[4 + j]; }
+        uint4 o = Elem<T>::pack(v);
+        if (p.stats || rg || p.relu) {
+          Elem<T>::unpack(o, v);   // the values as stored: statistics and the residual add see the rounded ones
+          if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+          }
+          if (rg) {
+            float r[8];
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(rg + m * p.rps + c8), r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r[j];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          if (rg || p.relu) o = Elem<T>::pack(v);
+        }
+        *reinterpret_cast<uint4*>(yg + m * p.yps + c8) = o;
+      }
+    }
+    st = (st + 1) % NS;
+  }
+  if (p.stats) {
+    // sum over the 16 pixels (lanes) of a DPP row, then one atomic per channel from lane 15 of each row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        float v = w ? ssq[j] : ssum[j];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));
+        if (q == 15 && cok) {
+          const int slot = p.stat_slots > 1 ? (int)(blockIdx.x % (unsigned)p.stat_slots) : 0;
+          atomicAdd(p.stats + (slot * 2 + w) * p.Cout + c8 + j, v);
+        }
+      }
+    }
+  }
+}
+
+// Takes the 1x1, stride-1, bf16 -> bf16 convs with K in {64, 128, 256}, Cout 64 / 128 / a multiple of 256 and enough
+// rows to keep a persistent grid busy. Returns false when the shape is not its.
+inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
+  static const char* dev = getenv("DAS_DEV_STREAM1X1");   // tuning only: 0 disables, N = minimum rows
+  const long long min_rows = dev ? atoll(dev) : 16384;
+  if (min_rows <= 0 || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.up_sh != 0 || p.relu_in ||
+      p.xbytes == 0 || p.M < min_rows)
+    return false;
+  if (p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
+  if (p.Cout != 64 && p.Cout != 128 && p.Cout % 256 != 0) return false;
+  if (p.yps % 8 || (p.res && p.rps % 8)) return false;
+  const int wn = p.Cout >= 256 ? 8 : p.Cout / 32, ncol = p.Cout >= 256 ? p.Cout / 256 : 1;
+  const int ntiles = (p.M + 63) / 64;
+  const int kb = p.Cin / 32;
+  const size_t sm = 4 * (size_t)((p.Cin + 63) / 64) * 64 * 128;   // four stages of 64 pixel rows
+  auto go = [&](auto kern) -> bool {
+    static int per_cu = 0;   // (one static per template instance: the lambda is instantiated per kernel type)
+    if (per_cu == 0) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        return false;
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 640, sm) != hipSuccess || n < 1) return false;
+      per_cu = n > 2 ? 2 : n;
+    }
+    int dev_id = 0, cus = 256;
+    if (hipGetDevice(&dev_id) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
+    long long grid = (long long)per_cu * cus;
+    grid = std::min<long long>(grid, (long long)ntiles * ncol);
+    grid = std::max<long long>(ncol, grid / ncol * ncol);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(640), sm, s, p, ncol, ntiles);
+    return true;
+  };
+#define DAS_STREAM_CASE(KBV, WNV) \
+  if (kb == KBV && wn == WNV) return go(conv1x1_stream_kernel<KBV, WNV>);
+  DAS_STREAM_CASE(2, 2) DAS_STREAM_CASE(2, 4) DAS_STREAM_CASE(2, 8)
+  DAS_STREAM_CASE(4, 2) DAS_STREAM_CASE(4, 4) DAS_STREAM_CASE(4, 8)
+  DAS_STREAM_CASE(8, 2) DAS_STREAM_CASE(8, 4) DAS_STREAM_CASE(8, 8)
+#undef DAS_STREAM_CASE
+  return false;
+}
+
 // 256 x 256 tile kernel: bf16 in / bf16 out, Cout >= 256, Cin % 32 == 0, enough tiles to cover the chip
 template <typename T, typename OT>
 bool try_launch4(const ConvP& p0, hipStream_t s) {
@@ -639,6 +844,12 @@ bool try_launch4(const ConvP& p0, hipStream_t s) {
 
 template <typename T, typename OT>
 int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
+  if constexpr (sizeof(T) == 2 && sizeof(OT) == 2) {
+    if (try_launch_stream1x1(p, s)) {
+      DAS_CHECK_LAUNCH();
+      return DAS_OK;
+    }
+  }
   if (try_launch4<T, OT>(p, s)) {
     DAS_CHECK_LAUNCH();
     return DAS_OK;

@@ -197,7 +197,7 @@ def bn_stats_buffer(x, cout):
     (DasConvDesc.stats_slots); das_bn_train_apply sums the slots."""
     xd = x.data if hasattr(x, 'sizes') else x
     rows = xd.numel() // xd.shape[-1]
-    slots = 16 if rows >= 65536 else (4 if rows >= 16384 else 1)
+    slots = 16 if rows >= 16384 else 1
     return zeroed_stats(slots * 2 * cout, xd.device)
 
 

@@ -307,7 +307,12 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
                ((rows + 255) // 256) * ((Cout + 127) // 128) >= 384)
         sq = (xd.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and Cout >= 256 and Cin % 32 == 0 and
               not relu_in and in_up == 1 and ((rows + 255) // 256) * ((Cout + 255) // 256) >= 128)
-        if sq:
+        stream = (xd.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and KH == 1 and KW == 1 and stride == 1 and
+                  pad == 0 and in_up == 1 and not relu_in and rows >= 16384 and Cin in (64, 128, 256) and
+                  (Cout in (64, 128) or Cout % 256 == 0))
+        if stream:
+            tag = 'conv1x1_stream_kernel'
+        elif sq:
             tag = 'conv_glds4_kernel<bf16, bf16>'
         elif big:
             tag = f'conv_glds3_kernel<{short[xd.dtype]}, {short[out_dtype]}>'

@@ -80,6 +80,32 @@ def test_conv_epilogue_scale_shift_residual_relu_stats(dtype):
                                atol=3e-3 if dtype != torch.float32 else 1e-4)
 
 
+@pytest.mark.parametrize('Cin,Cout', [(64, 64), (64, 256), (128, 128), (256, 64), (256, 512), (128, 256)])
+def test_conv_stream1x1(Cin, Cout):
+    """The persistent 1x1 kernel (bf16, K <= 256, >= 16384 rows): scale / shift / residual / ReLU / statistics,
+    a channel-slice input, a last tile that overhangs M."""
+    dtype = torch.bfloat16
+    B, H, W = 2, 91, 93    # 16926 rows = 132 tiles of 128 + 30 rows
+    x, w = cases.randn(11, B, Cin + 32, H, W), cases.randn(12, Cout, Cin, 1, 1) / Cin ** 0.5
+    scale, shift = cases.randn(13, Cout).abs() + 0.5, cases.randn(14, Cout)
+    res = cases.randn(15, B, Cout, H, W)
+    o = ops()
+    xs = nhwc(x, dtype)[..., 16:16 + Cin]
+    wq = o.pack_weight(w.to(DEV), dtype)
+    conv = F.conv2d(rnd(x[:, 16:16 + Cin], dtype), rnd(w, dtype))
+    y = o.conv2d(xs, wq, 1, 1)
+    np.testing.assert_allclose(nchw(y).numpy(), conv.numpy(), **tol(dtype))
+    conv_q = rnd(conv * scale[None, :, None, None] + shift[None, :, None, None], dtype)
+    ref = F.relu(conv_q + rnd(res, dtype))
+    stats = torch.zeros(4, 2 * Cout, device=DEV)
+    y = o.conv2d(xs, wq, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), residual=nhwc(res, dtype), relu=True,
+                 stats=stats.view(-1))
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **tol(dtype))
+    n = B * H * W
+    s_ref = torch.cat([conv_q.sum((0, 2, 3)), (conv_q ** 2).sum((0, 2, 3))])
+    np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=3e-3, atol=3e-3)
+
+
 def test_conv_relu_in_slices_and_f32_out():
     """bf16 in, f32 out (head predictors), reading a channel slice and writing into a slice."""
     o = ops()
