@@ -617,9 +617,12 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
 // way to "tile i has landed". Hence two kinds of waves: waves 0-7 multiply and store and never wait on memory;
 // waves 8-9 only issue the DMA, three tiles ahead into four LDS stages, wait with a counted vmcnt and release the
 // others through the workgroup barrier (one barrier per tile).
-template <int KB, int WN>   // K = 32 * KB input channels; WN waves across the 32-channel groups, 8 / WN across pixels
+// MODE (keeps each variant under the 168 registers that ten waves per workgroup allow): 0 = plain, optional BatchNorm
+// statistics (training forward); 1 = scale / shift, optional ReLU (eval); 2 = residual add, optional ReLU (data gradient).
+template <int KB, int WN, int MODE>   // K = 32 * KB input channels; WN waves across the 32-channel groups, 8 / WN across pixels
 __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, int ntiles) {
   using T = bf16_t;
+  constexpr bool STATS = MODE == 0, AFF = MODE == 1, RES = MODE == 2;
   constexpr int WM = 8 / WN, TM = 64, PB = TM / WM / 16;    // 16-pixel blocks per wave and tile
   constexpr int K = KB * 32, SUBS = (K + 63) / 64;
   constexpr int SUBB = TM * 128, STAGE = SUBS * SUBB;       // bytes
@@ -690,20 +693,38 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
   float sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sc[j] = (p.scale && cok) ? p.scale[c8 + j] : 1.f;
-    sh[j] = (p.shift && cok) ? p.shift[c8 + j] : 0.f;
+    sc[j] = (AFF && p.scale && cok) ? p.scale[c8 + j] : 1.f;
+    sh[j] = (AFF && p.shift && cok) ? p.shift[c8 + j] : 0.f;
   }
   float ssum[8], ssq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
 
   T* yg = reinterpret_cast<T*>(p.y);
-  const T* rg = reinterpret_cast<const T*>(p.res);
+  const T* rg = RES ? reinterpret_cast<const T*>(p.res) : nullptr;
+  // Residual rows are fetched one tile ahead by hand-issued loads: if the compiler tracked them it would have to
+  // wait with vmcnt(0) (loads and stores mixed in one counter), i.e. for the rows just requested and for every store.
+  // Loads return in order among themselves, so "at most PB operations outstanding" right after the PB loads of the
+  // NEXT tile were issued proves this tile's rows have landed, whatever the stores do. The instruction count per tile
+  // is kept constant (rows past M / past the last tile re-read a valid row).
+  v4i_t rv[PB], rnext[PB];
+  auto res_issue = [&](int tile, v4i_t (&dst)[PB]) {
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      long long m = (long long)tile * TM + wm * (TM / WM) + pb * 16 + q;
+      m = m < p.M ? m : p.M - 1;
+      const T* src = rg + m * p.rps + (cok ? c8 : 0);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[pb]) : "v"(src) : "memory");
+    }
+  };
+  if (rg) res_issue(min(first, ntiles - 1), rv);
   int st = 0;
-  for (int t = first; t < ntiles; t += tstride) {
+  // (two register sets for the residual rows, used alternately: a copy would read registers with loads in flight)
+  auto do_tile = [&](int t, v4i_t (&cur)[PB], v4i_t (&nxt)[PB]) {
     asm volatile("" ::: "memory");   // (this wave's LDS reads and stores of the previous tile stay above the barrier)
     __builtin_amdgcn_s_barrier();    // the loader waves saw tile t land
     asm volatile("" ::: "memory");
+    if (rg) res_issue(min(t + tstride, ntiles - 1), nxt);
     const char* sx = smem + st * STAGE;
 #pragma unroll
     for (int pb = 0; pb < PB; ++pb) {
@@ -719,20 +740,28 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
                                                        __builtin_bit_cast(bf16x8_t, bf), acc1, 0, 0, 0);
       }
       const long long m = (long long)t * TM + row;
+      if (rg && pb == 0) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cur[i]) : "n"(PB) : "memory");
+      }
       if (m < p.M && cok) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = acc0[j] * sc[j] + sh[j]; v[4 + j] = acc1[j] * sc[4 + j] + sh[4 + j]; }
+        for (int j = 0; j < 4; ++j) {
+          v[j] = AFF ? acc0[j] * sc[j] + sh[j] : acc0[j];
+          v[4 + j] = AFF ? acc1[j] * sc[4 + j] + sh[4 + j] : acc1[j];
+        }
         uint4 o = Elem<T>::pack(v);
-        if (p.stats || rg || p.relu) {
+        const bool stats = STATS && p.stats;
+        if (stats || rg || p.relu) {
           Elem<T>::unpack(o, v);   // the values as stored: statistics and the residual add see the rounded ones
-          if (p.stats) {
+          if (stats) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
           }
           if (rg) {
             float r[8];
-            Elem<T>::unpack(*reinterpret_cast<const uint4*>(rg + m * p.rps + c8), r);
+            Elem<T>::unpack(__builtin_bit_cast(uint4, cur[pb]), r);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += r[j];
           }
@@ -746,8 +775,17 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
       }
     }
     st = (st + 1) % NS;
+  };
+  for (int t = first; t < ntiles; t += 2 * tstride) {
+    do_tile(t, rv, rnext);
+    if (t + tstride >= ntiles) break;
+    do_tile(t + tstride, rnext, rv);
   }
-  if (p.stats) {
+  if (rg) {   // the trailing dummy loads: their destination registers stay allocated until they have landed
+#pragma unroll
+    for (int i = 0; i < PB; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[i]), "+v"(rnext[i])::"memory");
+  }
+  if (STATS && p.stats) {
     // sum over the 16 pixels (lanes) of a DPP row, then one atomic per channel from lane 15 of each row
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -799,8 +837,15 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(640), sm, s, p, ncol, ntiles);
     return true;
   };
-#define DAS_STREAM_CASE(KBV, WNV) \
-  if (kb == KBV && wn == WNV) return go(conv1x1_stream_kernel<KBV, WNV>);
+  const bool aff = p.scale || p.shift;
+  if ((aff && (p.res || p.stats)) || (p.res && p.stats)) return false;   // (combinations no caller on the path uses)
+  const int mode = p.res ? 2 : (aff ? 1 : 0);
+#define DAS_STREAM_CASE(KBV, WNV)                                         \
+  if (kb == KBV && wn == WNV) {                                           \
+    if (mode == 0) return go(conv1x1_stream_kernel<KBV, WNV, 0>);         \
+    if (mode == 1) return go(conv1x1_stream_kernel<KBV, WNV, 1>);         \
+    return go(conv1x1_stream_kernel<KBV, WNV, 2>);                        \
+  }
   DAS_STREAM_CASE(2, 2) DAS_STREAM_CASE(2, 4) DAS_STREAM_CASE(2, 8)
   DAS_STREAM_CASE(4, 2) DAS_STREAM_CASE(4, 4) DAS_STREAM_CASE(4, 8)
   DAS_STREAM_CASE(8, 2) DAS_STREAM_CASE(8, 4) DAS_STREAM_CASE(8, 8)

@@ -309,7 +309,9 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
               not relu_in and in_up == 1 and ((rows + 255) // 256) * ((Cout + 255) // 256) >= 128)
         stream = (xd.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and KH == 1 and KW == 1 and stride == 1 and
                   pad == 0 and in_up == 1 and not relu_in and rows >= 16384 and Cin in (64, 128, 256) and
-                  (Cout in (64, 128) or Cout % 256 == 0))
+                  (Cout in (64, 128) or Cout % 256 == 0) and
+                  not ((scale is not None or shift is not None) and (residual is not None or stats is not None)) and
+                  not (residual is not None and stats is not None))
         if stream:
             tag = 'conv1x1_stream_kernel'
         elif sq:

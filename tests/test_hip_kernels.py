@@ -95,15 +95,26 @@ def test_conv_stream1x1(Cin, Cout):
     conv = F.conv2d(rnd(x[:, 16:16 + Cin], dtype), rnd(w, dtype))
     y = o.conv2d(xs, wq, 1, 1)
     np.testing.assert_allclose(nchw(y).numpy(), conv.numpy(), **tol(dtype))
-    conv_q = rnd(conv * scale[None, :, None, None] + shift[None, :, None, None], dtype)
-    ref = F.relu(conv_q + rnd(res, dtype))
+    # mode 0: BatchNorm statistics of the stored values, in slots
     stats = torch.zeros(4, 2 * Cout, device=DEV)
-    y = o.conv2d(xs, wq, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), residual=nhwc(res, dtype), relu=True,
-                 stats=stats.view(-1))
-    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **tol(dtype))
+    y = o.conv2d(xs, wq, 1, 1, stats=stats.view(-1))
+    conv_q = rnd(conv, dtype)
+    np.testing.assert_allclose(nchw(y).numpy(), conv_q.numpy(), **tol(dtype))
     n = B * H * W
     s_ref = torch.cat([conv_q.sum((0, 2, 3)), (conv_q ** 2).sum((0, 2, 3))])
     np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=3e-3, atol=3e-3)
+    # mode 1: scale / shift + ReLU (eval-mode BatchNorm folded into the conv)
+    aff_q = rnd(conv * scale[None, :, None, None] + shift[None, :, None, None], dtype)
+    y = o.conv2d(xs, wq, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), relu=True)
+    np.testing.assert_allclose(nchw(y).numpy(), F.relu(aff_q).numpy(), **tol(dtype))
+    # mode 2: residual add (+ ReLU), the data-gradient epilogue
+    y = o.conv2d(xs, wq, 1, 1, residual=nhwc(res, dtype))
+    np.testing.assert_allclose(nchw(y).numpy(), rnd(conv_q + rnd(res, dtype), dtype).numpy(), **tol(dtype))
+    y = o.conv2d(xs, wq, 1, 1, residual=nhwc(res, dtype), relu=True)
+    np.testing.assert_allclose(nchw(y).numpy(), F.relu(conv_q + rnd(res, dtype)).numpy(), **tol(dtype))
+    # every epilogue feature at once is not the persistent kernel's: the tile kernels take it
+    y = o.conv2d(xs, wq, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), residual=nhwc(res, dtype), relu=True)
+    np.testing.assert_allclose(nchw(y).numpy(), F.relu(aff_q + rnd(res, dtype)).numpy(), **tol(dtype))
 
 
 def test_conv_relu_in_slices_and_f32_out():
