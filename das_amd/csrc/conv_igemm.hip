@@ -572,7 +572,11 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   // 256-row tiles (8 waves, weight tile shared by twice the pixels) once they still fill the chip twice over
   static const char* dev_mink = getenv("DAS_DEV_BIG_MINK");  // tuning only
   const int mink = dev_mink ? atoi(dev_mink) : 0;
-  const bool big = glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((p.M + 255) / 256) * p.ntiles >= 384 &&
+  static const char* dev_minb = getenv("DAS_DEV_BIG_MINBLOCKS");  // tuning only
+  // (cold operands, tools/dev/conv_cold_bench.py: 104 tiles of 256 x 128 on 256 CUs still beat 208 of 128 x 128 by
+  // 18...22 % on the 3x3 layers of the 32x52 / 16x26 stages — the 3-stage pipeline matters more than the fill)
+  const long long minb = dev_minb ? atoll(dev_minb) : 100;
+  const bool big = glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((p.M + 255) / 256) * p.ntiles >= minb &&
                    p.K >= mink &&
                    p.xbytes != 0;  // (0 = more than 4 GiB of input: not addressable by 32-bit buffer offsets)
   const int bm = big ? 256 : BM;

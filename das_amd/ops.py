@@ -304,7 +304,7 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         glds = Cin % (64 if xd.dtype == torch.bfloat16 else 32) == 0 and not relu_in
         # mirrors the dispatch in conv_igemm.hip::launch so that tags equal the rocprof kernel names
         big = (glds and bn == 128 and out_dtype == torch.bfloat16 and in_up == 1 and
-               ((rows + 255) // 256) * ((Cout + 127) // 128) >= 384)
+               ((rows + 255) // 256) * ((Cout + 127) // 128) >= 100)
         sq = (xd.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and Cout >= 256 and Cin % 32 == 0 and
               not relu_in and in_up == 1 and ((rows + 255) // 256) * ((Cout + 255) // 256) >= 128)
         stream = (xd.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and KH == 1 and KW == 1 and stride == 1 and

@@ -194,6 +194,31 @@ def test_bn_train_apply(dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bn_statistics_slots_equal_single_array(dtype):
+    """Workgroup slots (DasConvDesc.stats_slots) only regroup the same partial sums: conv + BatchNorm through 5 slots
+    equals the single-array path; the SyncBN helper folds the slots before the all-reduce."""
+    from das_amd import nn as dnn
+    o = ops()
+    B, H, W, Cin, Cout = 2, 37, 41, 64, 72
+    x, w = cases.randn(30, B, Cin, H, W), cases.randn(31, Cout, Cin, 3, 3) / 24
+    gamma, beta = (cases.randn(32, Cout).abs() + 0.5).to(DEV), cases.randn(33, Cout).to(DEV)
+    xd, wd = nhwc(x, dtype), o.pack_weight(w.to(DEV), dtype)
+    s1, s5 = torch.zeros(2 * Cout, device=DEV), torch.zeros(5 * 2 * Cout, device=DEV)
+    raw1 = o.conv2d(xd, wd, 3, 3, 1, 1, stats=s1)
+    raw5 = o.conv2d(xd, wd, 3, 3, 1, 1, stats=s5)
+    assert torch.equal(raw1, raw5)
+    np.testing.assert_allclose(s5.view(5, -1).sum(0).cpu().numpy(), s1.cpu().numpy(), rtol=2e-5, atol=1e-3)
+    assert int((s5.view(5, -1).abs().sum(1) > 0).sum()) == 5          # every slot took part
+    folded = dnn.sync_stats(s5.clone(), Cout, lambda t: None)          # (world of one: the all-reduce is a no-op)
+    np.testing.assert_allclose(folded.cpu().numpy(), s1.cpu().numpy(), rtol=2e-5, atol=1e-3)
+    y1, m1, i1 = o.bn_train_apply(raw1, s1, gamma, beta, None, None, relu=True)
+    y5, m5, i5 = o.bn_train_apply(raw5, s5, gamma, beta, None, None, relu=True)
+    np.testing.assert_allclose(m5.cpu().numpy(), m1.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(i5.cpu().numpy(), i1.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(y5.float().cpu().numpy(), y1.float().cpu().numpy(), **tol(dtype))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('C,G', [(256, 32), (64, 32), (32, 32), (768, 96)])
 def test_groupnorm(dtype, C, G):
     o = ops()
