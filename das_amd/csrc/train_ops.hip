@@ -773,8 +773,11 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
     DAS_CHECK_LAUNCH();
     return DAS_OK;
   };
-  static const char* dev_pp = getenv("DAS_DEV_WGRAD_PP");  // tuning only: minimum K for the ping-pong kernel
-  if (d->dtype == DAS_BF16 && dev_pp && p.K >= atoi(dev_pp) && d->Cout >= 256) {
+  // the ping-pong 256 x 256 kernel for the wide layers (K >= 1024, Cout >= 256): -5...19 % with cold operands
+  // (tools/dev/wgrad_cold_bench.py); below that its larger workspace and prologue cost more than its loop gains
+  static const char* dev_pp = getenv("DAS_DEV_WGRAD_PP");  // tuning only: minimum K for the ping-pong kernel, 0 = off
+  const int pp_mink = dev_pp ? atoi(dev_pp) : 1024;
+  if (d->dtype == DAS_BF16 && pp_mink > 0 && p.K >= pp_mink && d->Cout >= 256) {
     const long long npix = p.nlev > 1 ? M : (long long)d->B * d->H * d->W;
     const long long xb = ((npix - 1) * d->x_pix_stride + d->Cin) * 2;
     const long long db = ((M - 1) * d->y_pix_stride + d->Cout) * 2;
@@ -810,7 +813,8 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   // 32-row steps, 2 per CU for f32: 64 KiB of LDS each) — a second, partial wave costs a full pass, and every
   // extra split is one more round of atomics on the same dW words. At least 8 steps per workgroup.
   static const char* dev_blocks = getenv("DAS_DEV_WGRAD_BLOCKS");  // tuning only
-  const int target = dev_blocks ? atoi(dev_blocks) : (d->dtype == DAS_BF16 && bkm == 32 ? 768 : 512);
+  // (128 registers -> four workgroups per CU fit; the fourth pays off only on the longest reductions)
+  const int target = dev_blocks ? atoi(dev_blocks) : (d->dtype == DAS_BF16 && bkm == 32 ? (M >= 262144 ? 1024 : 768) : 512);
   long long splits = std::max<long long>(1, target / tiles);
   long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
   splits = (total_steps + spb - 1) / spb;

@@ -41,7 +41,8 @@ CASES = [
     (2, 16, 20, 64, 128, 1, 2, 0),
     (1, 18, 22, 128, 136, 3, 2, 1),
     (2, 13, 15, 64, 64, 3, 2, 1),     # odd sizes, stride 2
-    (3, 8, 13, 256, 256, 3, 1, 1),
+    (3, 8, 13, 256, 256, 3, 1, 1),    # K = 2304, Cout = 256: the ping-pong 256 x 256 weight-gradient kernel (bf16)
+    (2, 9, 7, 128, 512, 3, 1, 1),     # same kernel: two Cout tiles, K = 1152 ends inside a 256-column tile
     (1, 20, 24, 8, 64, 7, 2, 3),      # stem (only wgrad is needed in training; dgrad checked anyway)
 ]
 
@@ -66,9 +67,10 @@ def test_conv_dgrad_wgrad(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_conv_wgrad_ragged_and_bias(dtype):
+@pytest.mark.parametrize('C,O', [(64, 72), (128, 256)])   # (128, 256): K = 1152 -> the ping-pong kernel in bf16
+def test_conv_wgrad_ragged_and_bias(dtype, C, O):
     o = ops()
-    B, C, O = 2, 64, 72
+    B = 2
     sizes = [(12, 20), (6, 10), (3, 5)]
     xs = [cases.randn(50 + i, B, C, h, w) for i, (h, w) in enumerate(sizes)]
     dys = [cases.randn(60 + i, B, O, h, w) for i, (h, w) in enumerate(sizes)]
