@@ -773,10 +773,10 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
     DAS_CHECK_LAUNCH();
     return DAS_OK;
   };
-  // the ping-pong 256 x 256 kernel for the wide layers (K >= 1024, Cout >= 256): -5...19 % with cold operands
-  // (tools/dev/wgrad_cold_bench.py); below that its larger workspace and prologue cost more than its loop gains
+  // the ping-pong 256 x 256 kernel for the wide layers (K >= 256, Cout >= 256): -5...19 % with cold operands
+  // (tools/dev/wgrad_cold_bench.py)
   static const char* dev_pp = getenv("DAS_DEV_WGRAD_PP");  // tuning only: minimum K for the ping-pong kernel, 0 = off
-  const int pp_mink = dev_pp ? atoi(dev_pp) : 1024;
+  const int pp_mink = dev_pp ? atoi(dev_pp) : 256;
   if (d->dtype == DAS_BF16 && pp_mink > 0 && p.K >= pp_mink && d->Cout >= 256) {
     const long long npix = p.nlev > 1 ? M : (long long)d->B * d->H * d->W;
     const long long xb = ((npix - 1) * d->x_pix_stride + d->Cin) * 2;
