@@ -831,7 +831,9 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
         return false;
       int n = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 640, sm) != hipSuccess || n < 1) return false;
-      per_cu = n > 2 ? 2 : n;
+      static const char* dev_cap = getenv("DAS_DEV_STREAM_PERCU");   // tuning only
+      const int cap = dev_cap ? atoi(dev_cap) : 2;
+      per_cu = n > cap ? cap : n;
     }
     int dev_id = 0, cus = 256;
     if (hipGetDevice(&dev_id) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);

@@ -27,9 +27,11 @@ def family(fetch, write, match):
 def main(d, out):
     wf, ww, cf, cw, inf, infw = (load(d, n) for n in ('wf', 'ww', 'cf', 'cw', 'inf', 'infw'))
     fam = {}
-    # weight gradient = main kernel + split reduction per op: sum of the two kernels' per-dispatch means
-    f = sum(v.get('fetch_mb', 0) for k, v in wf.items() if 'wgrad' in k)
-    w = sum(v.get('write_size_mb', 0) for k, v in ww.items() if 'wgrad' in k)
+    # weight gradient = main kernel (128 x 128 or ping-pong 256 x 256) + split reduction per op: all bytes of the
+    # weight-gradient kernels divided by the number of ops (= dispatches of the reduce kernels)
+    nops = sum(v['dispatches'] for k, v in wf.items() if 'wgrad_reduce' in k)
+    f = sum(v['dispatches'] * v.get('fetch_mb', 0) for k, v in wf.items() if 'wgrad' in k) / nops
+    w = sum(v['dispatches'] * v.get('write_size_mb', 0) for k, v in ww.items() if 'wgrad' in k) / nops
     fam['conv_wgrad_kernel<bf16>'] = dict(train=dict(
         fetch_mb=round(f, 2), write_mb=round(w, 2), hbm_mb_per_launch=round(f + w, 2),
         source=PASSES + ' over tools/dev/wgrad_mix.py: the 30 most expensive weight-gradient shapes of the train '
