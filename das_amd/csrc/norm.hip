@@ -210,7 +210,11 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
   }
   const long long nstat = stat_count ? stat_count : count;
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
-  const int grid = grid_for(count * vc);
+  // at least eight vectors per thread (the per-thread mean / invstd / gamma / beta set-up is ~60 instructions and 32
+  // loads): the mid-size layers ran at 1.7...3 TB/s with one vector per thread (1024 channels at 32x52: 37 -> 22 us)
+  static const char* dev_vpt = getenv("DAS_DEV_BN_VPT");   // tuning only
+  const int vpt = dev_vpt ? atoi(dev_vpt) : 8;
+  const int grid = std::max(1, std::min(grid_for(count * vc), (int)((count * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
   const bool fixed = ((long long)grid * TPB) % vc == 0;
 #define DAS_BN_APPLY(T, F)                                                                                          \
   hipLaunchKernelGGL((bn_apply_kernel<T, F>), dim3(grid), dim3(TPB), 0, s, (const T*)x, (T*)y, count, C, stats, nstat, \

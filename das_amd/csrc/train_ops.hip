@@ -681,7 +681,9 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
   }
   if (phase == 1) return;
   const float inv_n = 1.f / (float)stat_rows;   // statistics population (all ranks' rows for SyncBN)
-  const int grid = grid_for(rows * vc);
+  static const char* dev_vpt = getenv("DAS_DEV_BN_VPT");   // tuning only: vectors per thread (see das_bn_train_apply)
+  const int vpt = dev_vpt ? atoi(dev_vpt) : 8;
+  const int grid = std::max(1, std::min(grid_for(rows * vc), (int)((rows * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
   if (((long long)grid * TPB) % vc == 0) {
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, true>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
                        (const T*)raw, mean, invstd, gamma, beta, sums, rows, C, (T*)draw, (T*)dres, dgamma_acc,
