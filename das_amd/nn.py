@@ -8,6 +8,7 @@ NHWC/K-contiguous layout the HIP kernels want (cache keyed on parameter version)
 libdas_hip.so through `das_amd.ops`.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -191,13 +192,16 @@ def zeroed_stats(n, device):
     return _STATS_ARENA.take(n, device)[:n]
 
 
+_SLOT_ROWS = int(os.environ.get('DAS_DEV_STAT_SLOT_ROWS', 16384))   # tuning only
+
+
 def bn_stats_buffer(x, cout):
     """Zeroed [slots, 2*cout] accumulators for the conv epilogue's BatchNorm statistics. Thousands of workgroups
     adding into one [2*cout] array serialise on the same words, so large-M layers spread them over slots
     (DasConvDesc.stats_slots); das_bn_train_apply sums the slots."""
     xd = x.data if hasattr(x, 'sizes') else x
     rows = xd.numel() // xd.shape[-1]
-    slots = 16 if rows >= 16384 else 1
+    slots = 16 if rows >= _SLOT_ROWS else 1
     return zeroed_stats(slots * 2 * cout, xd.device)
 
 
