@@ -245,7 +245,10 @@ extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLe
   // enough blocks to fill the chip, at least 64 pixels per block
   int chunks = (256 * 4 + lv->B - 1) / lv->B;
   int ppb = (maxhw + chunks - 1) / chunks;
-  if (ppb < 64) ppb = 64;
+  // (64 pixels per workgroup left the pass launch / latency bound: 42 us for 72 MB; 256: infer +3 %)
+  static const char* dev_ppb = getenv("DAS_DEV_GN_PPB");   // tuning only: minimum pixels per workgroup
+  const int ppb_min = dev_ppb ? atoi(dev_ppb) : 256;
+  if (ppb < ppb_min) ppb = ppb_min;
   chunks = (maxhw + ppb - 1) / ppb;
   const long long total = lv_total_rows(*lv) * (C / epv);
   if (dtype == DAS_BF16) {

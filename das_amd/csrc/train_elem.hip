@@ -279,7 +279,8 @@ extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void*
   int maxhw = 0;
   for (int l = 0; l < lv->num_levels; ++l) maxhw = std::max(maxhw, lv->H[l] * lv->W[l]);
   int chunks = (256 * 4 + lv->B - 1) / lv->B;
-  int ppb = std::max(64, (maxhw + chunks - 1) / chunks);
+  static const char* dev_ppb = getenv("DAS_DEV_GN_PPB");   // tuning only: minimum pixels per workgroup (see norm.hip)
+  int ppb = std::max(dev_ppb ? atoi(dev_ppb) : 256, (maxhw + chunks - 1) / chunks);
   chunks = (maxhw + ppb - 1) / ppb;
   const long long total = lv_total_rows(*lv) * (C / epv);
   DISPATCH_T(dtype, {
