@@ -61,6 +61,10 @@ class DasDecodeDesc(C.Structure):
 SIGNATURES = {
     'das_abi_version': (i32, []),
     'das_target_arch': (C.c_char_p, []),
+    'das_tuning_set': (i32, [C.c_char_p, i64]),
+    'das_tuning_get': (i32, [C.c_char_p, C.POINTER(i64)]),
+    'das_tuning_reset': (i32, []),
+    'das_last_kernel': (C.c_char_p, []),
     'das_conv2d_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), vp]),
     'das_conv2d_wgrad_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), i32, vp]),
     'das_pack_conv_weights': (i32, [vp, vp, vp, i32, vp, i32, i32, vp]),
@@ -91,10 +95,10 @@ SIGNATURES = {
                                          i32, vp]),
     'das_sigmoid_blend_backward': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     'das_head_assemble_backward': (i32, [vp, vp, vp, vp, vp, C.POINTER(DasLevels), C.POINTER(DasHeadDesc), vp]),
-    'das_assign_targets': (i32, [C.POINTER(DasLevels), C.POINTER(DasTargetDesc), vp, vp, vp, vp, vp, vp]),
-    'das_sigmoid_focal_loss': (i32, [vp, i32, vp, i64, f32, f32, vp, vp, vp]),
-    'das_smooth_l1_loss': (i32, [vp, vp, i64, f32, vp, vp, vp]),
-    'das_bce_logits_loss': (i32, [vp, vp, i64, vp, vp, vp]),
+    'das_assign_targets': (i32, [C.POINTER(DasLevels), C.POINTER(DasTargetDesc), vp, vp, vp, vp, vp, vp, vp]),
+    'das_sigmoid_focal_loss': (i32, [vp, i32, vp, vp, i64, f32, f32, vp, vp, vp]),
+    'das_smooth_l1_loss': (i32, [vp, vp, vp, i64, f32, vp, vp, vp]),
+    'das_bce_logits_loss': (i32, [vp, vp, vp, i64, vp, vp, vp]),
     'das_realnvp_log_prob': (i32, [vp, i32, i32, vp, i32, C.c_uint, vp, vp, vp]),
     'das_realnvp_log_prob_multi': (i32, [vp, i32, i32, C.POINTER(DasFlowJob), i32, i32, C.c_uint, vp, vp, vp]),
     'das_realnvp_log_prob_multi_backward': (i32, [vp, vp, i32, i32, C.POINTER(DasFlowJob), i32, i32, C.c_uint, vp, vp]),

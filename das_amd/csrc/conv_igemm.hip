@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "conv_common.h"
+#include "tuning.h"
 
 using namespace dasconv;
 
@@ -570,12 +571,9 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   ConvP p = p0;
   p.ntiles = (p.Cout + BN - 1) / BN;
   // 256-row tiles (8 waves, weight tile shared by twice the pixels) once they still fill the chip twice over
-  static const char* dev_mink = getenv("DAS_DEV_BIG_MINK");  // tuning only
-  const int mink = dev_mink ? atoi(dev_mink) : 0;
-  static const char* dev_minb = getenv("DAS_DEV_BIG_MINBLOCKS");  // tuning only
   // (cold operands, tools/dev/conv_cold_bench.py: 104 tiles of 256 x 128 on 256 CUs still beat 208 of 128 x 128 by
   // 18...22 % on the 3x3 layers of the 32x52 / 16x26 stages — the 3-stage pipeline matters more than the fill)
-  const long long minb = dev_minb ? atoll(dev_minb) : 100;
+  const long long mink = dastune::get(dastune::CONV_BIG_MINK), minb = dastune::get(dastune::CONV_BIG_MINBLOCKS);
   const bool big = glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((p.M + 255) / 256) * p.ntiles >= minb &&
                    p.K >= mink &&
                    p.xbytes != 0;  // (0 = more than 4 GiB of input: not addressable by 32-bit buffer offsets)
@@ -595,12 +593,16 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
     attr_set = true;
   }
   if (big) {
+    dastune::note_kernel("conv_glds3_kernel");
     hipLaunchKernelGGL((conv_glds3_kernel<T, OT>), dim3(p.nblocks), dim3(512), sm_big, s, p);
   } else if (glds) {
+    dastune::note_kernel("conv_glds_kernel");
     hipLaunchKernelGGL((conv_glds_kernel<T, OT, BN, 128>), dim3(p.nblocks), dim3(256), sm_glds, s, p);
   } else if (aligned) {
+    dastune::note_kernel("conv_reg_kernel");
     hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, true>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
   } else {
+    dastune::note_kernel("conv_reg_kernel");
     hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, false>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
   }
   DAS_CHECK_LAUNCH();
@@ -812,8 +814,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
 // Takes the 1x1, stride-1, bf16 -> bf16 convs with K in {64, 128, 256}, Cout 64 / 128 / a multiple of 256 and enough
 // rows to keep a persistent grid busy. Returns false when the shape is not its.
 inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
-  static const char* dev = getenv("DAS_DEV_STREAM1X1");   // tuning only: 0 disables, N = minimum rows
-  const long long min_rows = dev ? atoll(dev) : 16384;
+  const long long min_rows = dastune::get(dastune::CONV_STREAM_MINROWS);   // 0 disables
   if (min_rows <= 0 || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.up_sh != 0 || p.relu_in ||
       p.xbytes == 0 || p.M < min_rows)
     return false;
@@ -831,15 +832,15 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
         return false;
       int n = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 640, sm) != hipSuccess || n < 1) return false;
-      static const char* dev_cap = getenv("DAS_DEV_STREAM_PERCU");   // tuning only
-      const int cap = dev_cap ? atoi(dev_cap) : 2;
-      per_cu = n > cap ? cap : n;
+      per_cu = n;
     }
+    const int cap = (int)dastune::get(dastune::CONV_STREAM_PERCU);
     int dev_id = 0, cus = 256;
     if (hipGetDevice(&dev_id) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-    long long grid = (long long)per_cu * cus;
+    long long grid = (long long)(per_cu > cap && cap > 0 ? cap : per_cu) * cus;
     grid = std::min<long long>(grid, (long long)ntiles * ncol);
     grid = std::max<long long>(ncol, grid / ncol * ncol);
+    dastune::note_kernel("conv1x1_stream_kernel");
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(640), sm, s, p, ncol, ntiles);
     return true;
   };
@@ -863,8 +864,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
 template <typename T, typename OT>
 bool try_launch4(const ConvP& p0, hipStream_t s) {
   if constexpr (sizeof(T) == 2 && sizeof(OT) == 2) {
-    static const char* dev4 = getenv("DAS_DEV_GLDS4_MINBLOCKS");  // tuning only (0 disables)
-    const long long minblocks = dev4 ? atoll(dev4) : 128;  // half a chip of 256 x 256 tiles (measured break-even)
+    const long long minblocks = dastune::get(dastune::CONV_GLDS4_MINBLOCKS);  // default: half a chip of 256 x 256 tiles (measured break-even)
     ConvP p = p0;
     p.ntiles = (p.Cout + 255) / 256;
     const long long nb = (long long)((p.M + 255) / 256) * p.ntiles;
@@ -880,8 +880,9 @@ bool try_launch4(const ConvP& p0, hipStream_t s) {
     }
     // ping-pong schedule for the MFMA-bound shapes (+12...15 % at K >= 512, neutral at 256, a loss for the
     // HBM-bound K = 64 / 128 layers that finish in two or four steps)
-    static const char* dev_pp = getenv("DAS_DEV_GLDS4_PP");  // tuning only: 0 / 1 forces the choice
-    const bool pp = dev_pp ? atoi(dev_pp) == 1 : p.K >= 256;
+    const long long force_pp = dastune::get(dastune::CONV_GLDS4_PP);
+    const bool pp = force_pp >= 0 ? force_pp == 1 : p.K >= 256;
+    dastune::note_kernel(pp ? "conv_glds4_kernel<pp>" : "conv_glds4_kernel");
     if (pp) {
       hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true>), dim3(p.nblocks), dim3(512), sm4, s, p);
     } else {

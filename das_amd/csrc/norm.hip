@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 constexpr int TPB = 256;
@@ -212,8 +213,7 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
   // at least eight vectors per thread (the per-thread mean / invstd / gamma / beta set-up is ~60 instructions and 32
   // loads): the mid-size layers ran at 1.7...3 TB/s with one vector per thread (1024 channels at 32x52: 37 -> 22 us)
-  static const char* dev_vpt = getenv("DAS_DEV_BN_VPT");   // tuning only
-  const int vpt = dev_vpt ? atoi(dev_vpt) : 8;
+  const int vpt = std::max(1, (int)dastune::get(dastune::BN_VPT));
   const int grid = std::max(1, std::min(grid_for(count * vc), (int)((count * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
   const bool fixed = ((long long)grid * TPB) % vc == 0;
 #define DAS_BN_APPLY(T, F)                                                                                          \
@@ -246,8 +246,7 @@ extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLe
   int chunks = (256 * 4 + lv->B - 1) / lv->B;
   int ppb = (maxhw + chunks - 1) / chunks;
   // (64 pixels per workgroup left the pass launch / latency bound: 42 us for 72 MB; 256: infer +3 %)
-  static const char* dev_ppb = getenv("DAS_DEV_GN_PPB");   // tuning only: minimum pixels per workgroup
-  const int ppb_min = dev_ppb ? atoi(dev_ppb) : 256;
+  const int ppb_min = (int)dastune::get(dastune::GN_PPB);   // minimum pixels per workgroup
   if (ppb < ppb_min) ppb = ppb_min;
   chunks = (maxhw + ppb - 1) / ppb;
   const long long total = lv_total_rows(*lv) * (C / epv);

@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 constexpr int TPB = 256;
@@ -279,8 +280,7 @@ extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void*
   int maxhw = 0;
   for (int l = 0; l < lv->num_levels; ++l) maxhw = std::max(maxhw, lv->H[l] * lv->W[l]);
   int chunks = (256 * 4 + lv->B - 1) / lv->B;
-  static const char* dev_ppb = getenv("DAS_DEV_GN_PPB");   // tuning only: minimum pixels per workgroup (see norm.hip)
-  int ppb = std::max(dev_ppb ? atoi(dev_ppb) : 256, (maxhw + chunks - 1) / chunks);
+  int ppb = std::max((int)dastune::get(dastune::GN_PPB), (maxhw + chunks - 1) / chunks);   // (see norm.hip)
   chunks = (maxhw + ppb - 1) / ppb;
   const long long total = lv_total_rows(*lv) * (C / epv);
   DISPATCH_T(dtype, {

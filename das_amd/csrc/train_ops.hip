@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#include "tuning.h"
 
 using namespace dasconv;
 
@@ -667,9 +668,8 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
                         hipStream_t s) {
   const int vc = C / Elem<T>::EPV;
   if (phase != 2) {   // pass 1: per-channel sums
-    static const char* dev_cfg = getenv("DAS_DEV_BN_REDUCE");  // "<blocks>,<threads>" (tuning only)
-    int cap = 256, nt = 256;  // every block ends in 2C global atomics on the same words: ~20 ns per block of tail
-    if (dev_cfg) sscanf(dev_cfg, "%d,%d", &cap, &nt);
+    // every block ends in 2C global atomics on the same words: ~20 ns per block of tail
+    const int cap = (int)dastune::get(dastune::BN_REDUCE_BLOCKS), nt = (int)dastune::get(dastune::BN_REDUCE_THREADS);
     const int blocks = (int)std::min<long long>(cap, std::max<long long>(1, rows / 64));
     if (nt == 1024) {
       hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 1024>), dim3(blocks), dim3(1024), 2 * C * sizeof(float), s,
@@ -681,8 +681,7 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
   }
   if (phase == 1) return;
   const float inv_n = 1.f / (float)stat_rows;   // statistics population (all ranks' rows for SyncBN)
-  static const char* dev_vpt = getenv("DAS_DEV_BN_VPT");   // tuning only: vectors per thread (see das_bn_train_apply)
-  const int vpt = dev_vpt ? atoi(dev_vpt) : 8;
+  const int vpt = std::max(1, (int)dastune::get(dastune::BN_VPT));   // vectors per thread (see das_bn_train_apply)
   const int grid = std::max(1, std::min(grid_for(rows * vc), (int)((rows * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
   if (((long long)grid * TPB) % vc == 0) {
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, true>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
@@ -777,8 +776,7 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   };
   // the ping-pong 256 x 256 kernel for the wide layers (K >= 256, Cout >= 256): -5...19 % with cold operands
   // (tools/dev/wgrad_cold_bench.py)
-  static const char* dev_pp = getenv("DAS_DEV_WGRAD_PP");  // tuning only: minimum K for the ping-pong kernel, 0 = off
-  const int pp_mink = dev_pp ? atoi(dev_pp) : 256;
+  const int pp_mink = (int)dastune::get(dastune::WGRAD_PP_MINK);   // 0 = off
   if (d->dtype == DAS_BF16 && pp_mink > 0 && p.K >= pp_mink && d->Cout >= 256) {
     const long long npix = p.nlev > 1 ? M : (long long)d->B * d->H * d->W;
     const long long xb = ((npix - 1) * d->x_pix_stride + d->Cin) * 2;
@@ -800,6 +798,7 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
           return DAS_ERR_LAUNCH;
         attr_set = true;
       }
+      dastune::note_kernel("conv_wgrad_pp_kernel");
       hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3(tiles, (unsigned)splits), dim3(512), sm, s, p, (int)spb);
       DAS_CHECK_LAUNCH();
       return reduce(AccMap256{}, tiles, ntiles, splits);
@@ -808,20 +807,20 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   const int ntiles = (p.K + 127) / 128, tiles = ((d->Cout + 127) / 128) * ntiles;
   // bf16: 32 pixel rows per step = 32 KiB of LDS per workgroup, three workgroups resident per CU (register bound):
   // more independent DMA -> MFMA chains in flight than two workgroups of 64-row steps (+10...14 % measured)
-  static const char* dev_bkm = getenv("DAS_DEV_WGRAD_BKM");  // tuning only
-  const int bkm = d->dtype == DAS_BF16 ? (dev_bkm ? atoi(dev_bkm) : 32) : 32;
+  const int bkm = d->dtype == DAS_BF16 && dastune::get(dastune::WGRAD_BKM) == 64 ? 64 : 32;
   const long long total_steps = (M + bkm - 1) / bkm;
   // Split the pixel reduction so that the whole grid is ONE resident wave of workgroups (3 per CU for bf16 at
   // 32-row steps, 2 per CU for f32: 64 KiB of LDS each) — a second, partial wave costs a full pass, and every
   // extra split is one more round of atomics on the same dW words. At least 8 steps per workgroup.
-  static const char* dev_blocks = getenv("DAS_DEV_WGRAD_BLOCKS");  // tuning only
   // (128 registers -> four workgroups per CU fit; the fourth pays off only on the longest reductions)
-  const int target = dev_blocks ? atoi(dev_blocks) : (d->dtype == DAS_BF16 && bkm == 32 ? (M >= 262144 ? 1024 : 768) : 512);
+  const int forced_blocks = (int)dastune::get(dastune::WGRAD_BLOCKS);
+  const int target = forced_blocks > 0 ? forced_blocks : (d->dtype == DAS_BF16 && bkm == 32 ? (M >= 262144 ? 1024 : 768) : 512);
   long long splits = std::max<long long>(1, target / tiles);
   long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
   splits = (total_steps + spb - 1) / spb;
   p.y = (char*)wgrad_workspace(s, (size_t)splits * tiles * AccMap128::SLOTS * 16);
   if (!p.y) return DAS_ERR_LAUNCH;
+  dastune::note_kernel("conv_wgrad_kernel");
   if (d->dtype == DAS_BF16) {
     const size_t sm = 2 * 2 * (size_t)bkm * 256;
     if (bkm == 32) {

@@ -1,0 +1,31 @@
+// Dispatch thresholds of the kernel launchers (host side, process-global) and the record of which kernel a
+// launcher picked. Values are set through das_tuning_set (include/das_hip.h): parity tests use it to drive a small
+// problem through the kernels that production-size layers dispatch to, benchmarks use it for A/B runs.
+// Nothing here reads the environment.
+#pragma once
+
+namespace dastune {
+
+enum Key {
+  CONV_BIG_MINBLOCKS,    // conv_glds3_kernel (256 x 128 tile) from this many tiles up
+  CONV_BIG_MINK,         // ... and K at least this
+  CONV_GLDS4_MINBLOCKS,  // conv_glds4_kernel (256 x 256 tile) from this many tiles up; 0 disables the kernel
+  CONV_GLDS4_PP,         // -1 = ping-pong schedule for K >= 256, 0 / 1 force the choice
+  CONV_STREAM_MINROWS,   // conv1x1_stream_kernel from this many pixel rows up; 0 disables the kernel
+  CONV_STREAM_PERCU,     // ... workgroups per CU of its persistent grid
+  CONV_GLDS8_MINBLOCKS,  // conv_glds8_kernel (256 x 256 tile, K-steps of 64, 8 phases); 0 disables the kernel
+  WGRAD_PP_MINK,         // conv_wgrad_pp_kernel for K >= this (and Cout >= 256); 0 disables the kernel
+  WGRAD_BKM,             // pixel rows per step of conv_wgrad_kernel<bf16>: 32 or 64
+  WGRAD_BLOCKS,          // target grid of conv_wgrad_kernel; 0 = by shape
+  BN_REDUCE_BLOCKS,      // grid / block size of bn_bwd_reduce_kernel
+  BN_REDUCE_THREADS,
+  BN_VPT,                // 16-byte vectors per thread of the BatchNorm apply passes
+  GN_PPB,                // minimum pixels per workgroup of the GroupNorm statistic passes
+  N_KEYS
+};
+
+long long get(Key k);
+// `name` must be a string literal (kept by pointer): the kernel the calling thread's last launcher call picked
+void note_kernel(const char* name);
+
+}  // namespace dastune

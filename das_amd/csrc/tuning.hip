@@ -1,0 +1,69 @@
+// Host-side dispatch tuning table and last-kernel record (see tuning.h; C ABI in include/das_hip.h).
+#include "tuning.h"
+
+#include <atomic>
+#include <cstring>
+
+#include "das_hip.h"
+
+namespace dastune {
+namespace {
+struct Entry {
+  const char* name;
+  long long def;
+};
+// (defaults: break-even points measured with cold operands, tools/dev/conv_cold_bench.py / wgrad_cold_bench.py)
+constexpr Entry kTable[N_KEYS] = {
+    {"conv.big_minblocks", 100},  {"conv.big_mink", 0},       {"conv.glds4_minblocks", 128}, {"conv.glds4_pp", -1},
+    {"conv.stream_minrows", 16384}, {"conv.stream_percu", 2}, {"conv.glds8_minblocks", 0},   {"wgrad.pp_mink", 256},
+    {"wgrad.bkm", 32},            {"wgrad.blocks", 0},        {"bn.reduce_blocks", 256},     {"bn.reduce_threads", 256},
+    {"bn.vpt", 8},                {"gn.ppb", 256},
+};
+std::atomic<long long> g_val[N_KEYS];
+std::atomic<bool> g_init{false};
+void init_once() {
+  if (g_init.load(std::memory_order_acquire)) return;
+  for (int i = 0; i < N_KEYS; ++i) g_val[i].store(kTable[i].def, std::memory_order_relaxed);
+  g_init.store(true, std::memory_order_release);
+}
+thread_local const char* t_last = "";
+}  // namespace
+
+long long get(Key k) {
+  init_once();
+  return g_val[k].load(std::memory_order_relaxed);
+}
+void note_kernel(const char* name) { t_last = name; }
+}  // namespace dastune
+
+using namespace dastune;
+
+extern "C" int das_tuning_set(const char* key, long long value) {
+  if (!key) return DAS_ERR_ARG;
+  init_once();
+  for (int i = 0; i < N_KEYS; ++i)
+    if (!strcmp(key, kTable[i].name)) {
+      g_val[i].store(value, std::memory_order_relaxed);
+      return DAS_OK;
+    }
+  return DAS_ERR_ARG;
+}
+
+extern "C" int das_tuning_get(const char* key, long long* value) {
+  if (!key || !value) return DAS_ERR_ARG;
+  init_once();
+  for (int i = 0; i < N_KEYS; ++i)
+    if (!strcmp(key, kTable[i].name)) {
+      *value = g_val[i].load(std::memory_order_relaxed);
+      return DAS_OK;
+    }
+  return DAS_ERR_ARG;
+}
+
+extern "C" int das_tuning_reset(void) {
+  init_once();
+  for (int i = 0; i < N_KEYS; ++i) g_val[i].store(kTable[i].def, std::memory_order_relaxed);
+  return DAS_OK;
+}
+
+extern "C" const char* das_last_kernel(void) { return t_last; }

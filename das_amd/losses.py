@@ -19,36 +19,99 @@ from .ops import Ragged
 from .registry import LOSSES
 
 
+def _reduce(total, n_elems, reduction, avg_factor):
+    """mmdet `weight_reduce_loss` for a loss whose elementwise values were already summed by the kernel."""
+    if avg_factor is None:
+        if reduction == 'mean':
+            return total / max(n_elems, 1)
+        if reduction == 'sum':
+            return total
+    elif reduction == 'mean':
+        return total / avg_factor
+    elif reduction == 'sum':
+        raise ValueError('avg_factor can not be used with reduction="sum"')
+    raise NotImplementedError("reduction='none' needs the per-element losses; the HIP kernels return their sum "
+                              '(and per-element gradients)')
+
+
 @LOSSES.register_module()
 class FocalLoss(nn.Module):
+    """mmdet 2.14 FocalLoss (sigmoid) for ONE class, label 0 = positive, label num_classes = 1 = background
+    (configs/_base_/models/das.py:40-45, call site das_head.py:341-344): `das_sigmoid_focal_loss`."""
+
     def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0):
         super().__init__()
         assert use_sigmoid, 'only sigmoid focal loss is supported'
         self.use_sigmoid, self.gamma, self.alpha = use_sigmoid, gamma, alpha
         self.reduction, self.loss_weight = reduction, loss_weight
 
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        if pred.dim() != 2 or pred.shape[1] != 1:
+            raise NotImplementedError('FocalLoss on the DAS path has num_classes = 1: pred must be (N, 1)')
+        total = T.FocalLossSumFn.apply(pred.float(), target.to(torch.int32), self.gamma, self.alpha, weight)
+        return self.loss_weight * _reduce(total, pred.numel(), reduction_override or self.reduction, avg_factor)
+
 
 @LOSSES.register_module()
 class SmoothL1Loss(nn.Module):
+    """mmdet 2.14 SmoothL1Loss (call site das_head.py:375-379): `das_smooth_l1_loss`."""
+
     def __init__(self, beta=1.0, reduction='mean', loss_weight=1.0):
         super().__init__()
         self.beta, self.reduction, self.loss_weight = beta, reduction, loss_weight
 
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        if target.numel() == 0:
+            return pred.sum() * 0
+        total = T.SmoothL1SumFn.apply(pred.float(), target.float(), self.beta, weight)
+        return self.loss_weight * _reduce(total, pred.numel(), reduction_override or self.reduction, avg_factor)
+
 
 @LOSSES.register_module()
 class CrossEntropyLoss(nn.Module):
+    """mmdet 2.14 CrossEntropyLoss(use_sigmoid=True) = BCE with logits (call site das_head.py:470-471):
+    `das_bce_logits_loss`."""
+
     def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', class_weight=None, loss_weight=1.0):
         super().__init__()
         assert use_sigmoid and not use_mask and class_weight is None
         self.use_sigmoid, self.reduction, self.loss_weight = use_sigmoid, reduction, loss_weight
 
+    def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        total = T.BCELogitsSumFn.apply(cls_score.float(), label.float(), weight)
+        return self.loss_weight * _reduce(total, cls_score.numel(), reduction_override or self.reduction, avg_factor)
+
 
 @LOSSES.register_module()
 class RLELoss3D(nn.Module):
-    def __init__(self, residual=True, avg_factor=False, loss_weight=1.0, **kwargs):
+    """residual_log_likelihood_loss.py:7-37. `loss_weight` is accepted and ignored, as the reference's
+    `**kwargs` does (configs/_base_/models/das.py:49)."""
+
+    def __init__(self, residual=True, avg_factor=False, **kwargs):
         super().__init__()
-        self.residual, self.avg_factor, self.loss_weight = residual, avg_factor, loss_weight
+        self.residual, self.avg_factor = residual, avg_factor
         self.amp = 1 / math.sqrt(2 * math.pi)
+
+    def logQ(self, gt_uv, pred_jts, sigma):
+        return torch.log(sigma / self.amp) + torch.abs(gt_uv - pred_jts) / (math.sqrt(2) * sigma + 1e-9)
+
+    def forward(self, nf_loss, uvd, sigma, gt_uvd, gt_uv_weight, weight=None, avg_factor=None):
+        """Generic entry (elementwise tensor algebra on the caller's device). DASHead.loss does not come through
+        here: its RLE term is fused with the positive-row gather and the flows (`das_head_loss_rows`)."""
+        gt_uv_weight = gt_uv_weight.expand_as(gt_uvd)
+        nf_loss = nf_loss * gt_uv_weight
+        nvis = gt_uv_weight[..., 0].sum()
+        if nvis < 1:
+            return nvis
+        loss = nf_loss + self.logQ(gt_uvd, uvd, sigma) * gt_uv_weight if self.residual else nf_loss
+        if weight is not None:
+            loss = loss * weight
+        if avg_factor is not None and self.avg_factor:
+            return loss.sum() / avg_factor
+        return loss.sum() / nvis
 
 
 def realnvp_log_prob(flow, x):
@@ -81,14 +144,26 @@ def _pack_gt(gt_poses_3d, device):
     return rows.contiguous(), torch.tensor(starts, dtype=torch.int32, device=device)
 
 
-def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d):
+def _pack_centers(centers2d, depths, n, device):
+    """[centers2d | depths] rows for das_assign_targets, or None when the caller did not pass them."""
+    if centers2d is None or depths is None:
+        return None
+    if n == 0:
+        return torch.zeros(0, 3, dtype=torch.float32, device=device)
+    return torch.cat([torch.cat([c.to(device=device, dtype=torch.float32).reshape(-1, 2),
+                                 d.to(device=device, dtype=torch.float32).reshape(-1, 1)], 1)
+                      for c, d in zip(centers2d, depths)]).contiguous()
+
+
+def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d, centers2d=None, depths=None):
     """cls (rows,1), pose (rows,3+6J), ctr (rows,1), aux = refined uvd (rows,3J): Ragged f32, rows ordered
     level-major / image / (h,w) exactly like the reference's flatten-and-concat (das_head.py:306-333).
     gt_poses_3d: list per image of (G, 3+4J) [cx,cy,depth, J x (u,v,dz), J x vis]."""
     J, B, dev = head.num_joints, cls.B, cls.device
     gt_rows, gt_start = _pack_gt(gt_poses_3d, dev)
     labels, targets, ctr_t = T.assign_targets(cls, head.strides, head.regress_ranges, gt_rows, gt_start, J,
-                                              head.center_sample_radius, head.centerness_alpha, head.background_label)
+                                              head.center_sample_radius, head.centerness_alpha, head.background_label,
+                                              centers=_pack_centers(centers2d, depths, gt_rows.shape[0], dev))
     pos = (labels == 0).nonzero().reshape(-1)
     npos = int(pos.numel())
     if npos == 0:  # das_head.py:473-478
@@ -161,7 +236,7 @@ def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d):
         loss_pose = nvis
     else:
         q = (torch.log(sig2 / lp.amp) + (real2 - pred).abs() / (math.sqrt(2) * sig2 + 1e-9)) * vis2
-        loss_pose = ((nf * vis2 + q) * float(cw[3])).sum() / nvis * lp.loss_weight
+        loss_pose = ((nf * vis2 + q) * float(cw[3])).sum() / nvis
 
     lctr = head.loss_centerness
     loss_ctr = T.BCELogitsSumFn.apply(pc, pct) * (lctr.loss_weight / npos)
@@ -177,4 +252,4 @@ def das_head_loss(head, cls_scores, pose_preds, centernesses, aux_pose_preds, gt
     def rag(lst):
         return Ragged(torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in lst], 0).float(), B, sizes)
     return das_head_loss_rows(head, rag(cls_scores), rag(pose_preds), rag(centernesses), rag(aux_pose_preds),
-                              gt_poses_3d)
+                              gt_poses_3d, centers2d, depths)

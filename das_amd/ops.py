@@ -18,6 +18,33 @@ _DT = {torch.float32: _lib.DAS_F32, torch.bfloat16: _lib.DAS_BF16}
 PROFILE = None
 
 
+class tuning:
+    """Context manager over das_tuning_set: `with ops.tuning(**{'conv.glds4_minblocks': 1}): ...` (tests, A/B runs)."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        lib = _lib.load()
+        for k, v in self.kv.items():
+            cur = C.c_longlong()
+            _lib.check(lib.das_tuning_get(k.encode(), C.byref(cur)), f'das_tuning_get({k})')
+            self.old[k] = cur.value
+            _lib.check(lib.das_tuning_set(k.encode(), int(v)), f'das_tuning_set({k})')
+        return self
+
+    def __exit__(self, *exc):
+        lib = _lib.load()
+        for k, v in self.old.items():
+            lib.das_tuning_set(k.encode(), int(v))
+        return False
+
+
+def last_kernel():
+    """Kernel name picked by the last conv2d / conv2d_wgrad call of this thread."""
+    return _lib.load().das_last_kernel().decode()
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -299,28 +326,7 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
     _lib.check(lib.das_conv2d_nhwc(_ptr(xd), _ptr(w), _ptr(od), C.byref(d), _stream()), 'das_conv2d_nhwc')
     if PROFILE is not None:
         e1.record()
-        bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
-        short = {torch.bfloat16: 'bf16', torch.float32: 'float'}
-        glds = Cin % (64 if xd.dtype == torch.bfloat16 else 32) == 0 and not relu_in
-        # mirrors the dispatch in conv_igemm.hip::launch so that tags equal the rocprof kernel names
-        big = (glds and bn == 128 and out_dtype == torch.bfloat16 and in_up == 1 and
-               ((rows + 255) // 256) * ((Cout + 127) // 128) >= 100)
-        sq = (xd.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and Cout >= 256 and Cin % 32 == 0 and
-              not relu_in and in_up == 1 and ((rows + 255) // 256) * ((Cout + 255) // 256) >= 128)
-        stream = (xd.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and KH == 1 and KW == 1 and stride == 1 and
-                  pad == 0 and in_up == 1 and not relu_in and rows >= 16384 and Cin in (64, 128, 256) and
-                  (Cout in (64, 128) or Cout % 256 == 0) and
-                  not ((scale is not None or shift is not None) and (residual is not None or stats is not None)) and
-                  not (residual is not None and stats is not None))
-        if stream:
-            tag = 'conv1x1_stream_kernel'
-        elif sq:
-            tag = 'conv_glds4_kernel<bf16, bf16>'
-        elif big:
-            tag = f'conv_glds3_kernel<{short[xd.dtype]}, {short[out_dtype]}>'
-        else:
-            tag = f'{"conv_glds_kernel" if glds else "conv_reg_kernel"}<{short[xd.dtype]}, {short[out_dtype]}, {bn}' + \
-                  (', 128>' if glds else '>')
+        tag = last_kernel()   # the kernel the launcher picked (das_last_kernel): equals the rocprof kernel family
         PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1,
                         (B, H, W, Cin, Cout, KH, stride, len(x.sizes) if ragged else 1)))
     return out

@@ -87,6 +87,7 @@ class FlatSGD:
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.slots, self._conv_slots = [], []
+        self._params, self._names = [p for _, p, _ in plan], [n for n, _, _ in plan]
         for n, p, o in plan:
             k = p.numel()
             sl = _Slot()
@@ -114,6 +115,7 @@ class FlatSGD:
                             wd=weight_decay * bias_decay_mult)]
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.steps = 0
+        self._sig = self._param_signature()
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # param-aligned buckets in buffer order
         n_bucket = max(1, bucket_mb * (1 << 20) // 4)
@@ -179,8 +181,28 @@ class FlatSGD:
         return src[sl.off:sl.off + sl.numel].view(O, KH, KW, I)
 
     # ------------------------------------------------------------------ gradients
+    def _param_signature(self):
+        """Sum of the parameters' autograd version counters: changes whenever anybody writes a parameter in place
+        through torch (init_weights(), p.normal_(), copy_(), EMA, a second optimizer ...). The fused step itself
+        goes through raw pointers and bumps PARAM_EPOCH instead."""
+        return sum(p._version for p in self._params)
+
     def zero_grad(self):
+        """Clears the flat gradient. Also the once-per-iteration guard of the packed weight copies: an in-place
+        parameter edit since the last call invalidates them (they are keyed on PARAM_EPOCH only)."""
         self.flat_g.zero_()
+        sig = self._param_signature()
+        if sig != self._sig:
+            from .nn import bump_param_epoch
+            bump_param_epoch()
+            self._sig = sig
+
+    def _check_grad_aliasing(self):
+        for p, sl in zip(self._params, self.slots):
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * sl.off:
+                raise RuntimeError('FlatSGD: a parameter\'s .grad no longer aliases the flat gradient buffer '
+                                   '(model.zero_grad(set_to_none=True) or p.grad = ... detached it); use '
+                                   'optimizer.zero_grad()')
 
     def _launch(self, b):
         s, e = self.buckets[b]
@@ -264,6 +286,7 @@ class FlatSGD:
         self._reset_iteration()
 
     def step(self, lr):
+        self._check_grad_aliasing()
         scale = 1.0 / self.world
         sumsq = None
         if self.max_grad_norm > 0:
@@ -279,6 +302,34 @@ class FlatSGD:
         from .nn import bump_param_epoch
         bump_param_epoch()  # packed bf16 weight copies are rebuilt on the next forward
 
+    # ------------------------------------------------------------------ checkpointing
+    def state_dict(self):
+        """Momentum buffers as dense tensors in the parameters' own (OIHW) shapes, keyed by parameter name, plus
+        the step count — enough to resume exactly (mmcv's checkpoint carries `optimizer` the same way,
+        tools/train.py:200-210 / CheckpointHook)."""
+        mom = {}
+        for n, p, sl in zip(self._names, self._params, self.slots):
+            m = self.flat_m[sl.off:sl.off + sl.numel]
+            if sl.cl_shape is not None:
+                O, KH, KW, I = sl.cl_shape
+                m = m.view(O, KH, KW, I).permute(0, 3, 1, 2)
+            mom[n] = m.reshape(p.shape).detach().contiguous().cpu()
+        return dict(momentum_buffer=mom, steps=self.steps, base_lr=self.base_lr)
+
+    def load_state_dict(self, sd):
+        mom = sd['momentum_buffer']
+        for n, p, sl in zip(self._names, self._params, self.slots):
+            if n not in mom:
+                raise KeyError(f'optimizer state has no momentum buffer for {n}')
+            m = mom[n].to(self.flat_m.device, torch.float32)
+            dst = self.flat_m[sl.off:sl.off + sl.numel]
+            if sl.cl_shape is not None:
+                O, KH, KW, I = sl.cl_shape
+                dst.view(O, KH, KW, I).copy_(m.permute(0, 2, 3, 1))
+            else:
+                dst.copy_(m.reshape(-1))
+        self.steps = int(sd.get('steps', 1))
+
     def grad_norm(self):
         return float(torch.sqrt(T.grad_sumsq(self.flat_g)).item()) / self.world
 
@@ -291,8 +342,11 @@ def step_lr(base_lr, epoch, it, steps=(16, 20), gamma=0.1, warmup_iters=250, war
     return lr
 
 
-def build_optimizer(model, cfg):
-    """cfg: the reference's `optimizer` + `optimizer_config` dicts."""
+def build_optimizer(model, cfg, optimizer_config=None):
+    """build_optimizer(model, cfg) with the whole config, or — the reference's call shape (mmdet3d/apis/train.py
+    via mmcv `build_optimizer(model, cfg.optimizer)`) — build_optimizer(model, cfg.optimizer, cfg.optimizer_config)."""
+    if 'optimizer' not in cfg and ('type' in cfg or 'lr' in cfg):
+        cfg = dict(optimizer=cfg, optimizer_config=optimizer_config or {})
     opt = dict(cfg.get('optimizer', {}))
     assert opt.get('type', 'SGD') == 'SGD'
     pw = opt.get('paramwise_cfg', {}) or {}

@@ -414,7 +414,7 @@ class DASHead(nn.Module):
         dtype = self.compute_dtype or x[0].dtype
         rows = ops.Ragged.from_levels([as_nhwc(f, dtype) for f in x])
         cls, pose, ctr, ref = self.forward_rows(rows, list(range(len(x))))
-        return das_head_loss_rows(self, cls, pose, ctr, ref, gt_poses_3d)
+        return das_head_loss_rows(self, cls, pose, ctr, ref, gt_poses_3d, centers2d, depths)
 
     def loss(self, cls_scores, pose_preds, centernesses, aux_pose_preds, gt_bboxes, gt_labels, gt_poses_3d,
              gt_labels_3d, centers2d, depths, img_metas, gt_bboxes_ignore=None):

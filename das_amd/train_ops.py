@@ -8,9 +8,11 @@ from . import _lib
 from .ops import Ragged, _levels, _need_gpu, _ptr, _stream
 
 
-def assign_targets(geom_like, strides, regress_ranges, gt_rows, gt_start, J, radius=1.5, alpha=2.5, background=1):
+def assign_targets(geom_like, strides, regress_ranges, gt_rows, gt_start, J, radius=1.5, alpha=2.5, background=1,
+                   centers=None):
     """geom_like: a Ragged giving (B, level sizes). gt_rows (sum G, 3+4J) f32, gt_start (B+1,) int32, both on
-    the GPU. Returns labels int32 (rows,), targets f32 (rows, 3+4J), centerness f32 (rows,)."""
+    the GPU; centers (sum G, 3) f32 = [centers2d, depths] or None (= gt_rows[:, :3]).
+    Returns labels int32 (rows,), targets f32 (rows, 3+4J), centerness f32 (rows,)."""
     _need_gpu(gt_rows, gt_start)
     lv = _levels(geom_like)
     d = _lib.DasTargetDesc(J=J, background=background, radius=radius, alpha=alpha)
@@ -22,40 +24,75 @@ def assign_targets(geom_like, strides, regress_ranges, gt_rows, gt_start, J, rad
     ctr = torch.empty(rows, dtype=torch.float32, device=dev)
     assert gt_rows.dtype == torch.float32 and gt_start.dtype == torch.int32 and gt_start.numel() == geom_like.B + 1
     assert gt_rows.numel() == 0 or (gt_rows.is_contiguous() and gt_rows.shape[1] == 3 + 4 * J)
-    _lib.check(_lib.load().das_assign_targets(C.byref(lv), C.byref(d), _ptr(gt_rows), _ptr(gt_start), _ptr(labels),
+    if centers is not None:
+        assert centers.dtype == torch.float32 and centers.is_contiguous() and centers.shape == (gt_rows.shape[0], 3)
+        _need_gpu(centers)
+    _lib.check(_lib.load().das_assign_targets(C.byref(lv), C.byref(d), _ptr(gt_rows), _ptr(centers), _ptr(gt_start), _ptr(labels),
                                               _ptr(targets), _ptr(ctr), _stream()), 'das_assign_targets')
     return labels, targets, ctr
+
+
+def _weight(w, n):
+    """mmdet's per-element `weight` -> dense f32 of n elements (or None)."""
+    if w is None:
+        return None
+    w = w.detach().float().expand(n) if w.numel() == 1 else w.detach().float().reshape(-1)
+    assert w.numel() == n, (w.shape, n)
+    return w.contiguous()
 
 
 class FocalLossSumFn(Function):
     """sum_i focal(logit_i, label_i); logits (rows, 1) view with any row stride."""
 
     @staticmethod
-    def forward(ctx, logits, labels, gamma, alpha):
-        _need_gpu(logits, labels)
+    def forward(ctx, logits, labels, gamma, alpha, weight=None):
+        _need_gpu(logits, labels, weight)
         rows = logits.shape[0]
         grad = torch.empty(rows, dtype=torch.float32, device=logits.device)
         out = torch.empty(1, dtype=torch.float32, device=logits.device)
         assert logits.dtype == torch.float32 and labels.dtype == torch.int32
-        _lib.check(_lib.load().das_sigmoid_focal_loss(_ptr(logits), logits.stride(0), _ptr(labels), rows, gamma, alpha,
-                                                      _ptr(grad), _ptr(out), _stream()), 'das_sigmoid_focal_loss')
+        weight = _weight(weight, rows)
+        _lib.check(_lib.load().das_sigmoid_focal_loss(_ptr(logits), logits.stride(0), _ptr(labels), _ptr(weight), rows,
+                                                      gamma, alpha, _ptr(grad), _ptr(out), _stream()),
+                   'das_sigmoid_focal_loss')
         ctx.save_for_backward(grad)
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return (grad * g).unsqueeze(1), None, None, None
+        return (grad * g).unsqueeze(1), None, None, None, None
 
 
 class SmoothL1SumFn(Function):
     @staticmethod
-    def forward(ctx, pred, target, beta):
+    def forward(ctx, pred, target, beta, weight=None):
+        _need_gpu(pred, target, weight)
         pred, target = pred.contiguous(), target.contiguous()
         grad = torch.empty_like(pred)
         out = torch.empty(1, dtype=torch.float32, device=pred.device)
-        _lib.check(_lib.load().das_smooth_l1_loss(_ptr(pred), _ptr(target), pred.numel(), beta, _ptr(grad), _ptr(out),
-                                                  _stream()), 'das_smooth_l1_loss')
+        weight = _weight(weight, pred.numel())
+        _lib.check(_lib.load().das_smooth_l1_loss(_ptr(pred), _ptr(target), _ptr(weight), pred.numel(), beta,
+                                                  _ptr(grad), _ptr(out), _stream()), 'das_smooth_l1_loss')
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+class BCELogitsSumFn(Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight=None):
+        _need_gpu(logits, target, weight)
+        logits, target = logits.contiguous(), target.contiguous()
+        grad = torch.empty_like(logits)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        weight = _weight(weight, logits.numel())
+        _lib.check(_lib.load().das_bce_logits_loss(_ptr(logits), _ptr(target), _ptr(weight), logits.numel(), _ptr(grad),
+                                                   _ptr(out), _stream()), 'das_bce_logits_loss')
         ctx.save_for_backward(grad)
         return out[0]
 
@@ -63,23 +100,6 @@ class SmoothL1SumFn(Function):
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
         return grad * g, None, None
-
-
-class BCELogitsSumFn(Function):
-    @staticmethod
-    def forward(ctx, logits, target):
-        logits, target = logits.contiguous(), target.contiguous()
-        grad = torch.empty_like(logits)
-        out = torch.empty(1, dtype=torch.float32, device=logits.device)
-        _lib.check(_lib.load().das_bce_logits_loss(_ptr(logits), _ptr(target), logits.numel(), _ptr(grad), _ptr(out),
-                                                   _stream()), 'das_bce_logits_loss')
-        ctx.save_for_backward(grad)
-        return out[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        (grad,) = ctx.saved_tensors
-        return grad * g, None
 
 
 def grad_sumsq(flat_grad, out=None, zero_first=True):

@@ -40,6 +40,21 @@ typedef struct {
 int das_abi_version(void);
 const char* das_target_arch(void);
 
+/* Dispatch thresholds of the launchers (which tile kernel a conv / weight-gradient shape goes to, grid sizes of the
+ * norm passes): process-global integers addressed by name, e.g. "conv.glds4_minblocks". The defaults are the
+ * measured break-even points; parity tests lower them so that small problems run through the kernels
+ * production-size layers dispatch to, A/B benchmarks flip them. No reference counterpart (torch picks its cuDNN /
+ * MIOpen algorithm internally: torch.backends.cudnn.benchmark, tools/train.py:115-116). Unknown key: DAS_ERR_ARG.
+ * Keys: conv.big_minblocks, conv.big_mink, conv.glds4_minblocks, conv.glds4_pp (-1 auto / 0 / 1),
+ * conv.stream_minrows, conv.stream_percu, conv.glds8_minblocks, wgrad.pp_mink, wgrad.bkm, wgrad.blocks,
+ * bn.reduce_blocks, bn.reduce_threads, bn.vpt, gn.ppb. */
+int das_tuning_set(const char* key, long long value);
+int das_tuning_get(const char* key, long long* value);
+int das_tuning_reset(void);
+/* Name of the kernel the calling thread's last das_conv2d_nhwc / das_conv2d_wgrad_nhwc call launched
+ * ("conv_glds4_kernel<pp>", "conv1x1_stream_kernel", ...): lets a parity test assert WHICH kernel it checked. */
+const char* das_last_kernel(void);
+
 /* ------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA, fused epilogue.
  * Replaces: every torch `nn.Conv2d` / mmcv `ConvModule` conv on the path
@@ -261,6 +276,9 @@ int das_head_assemble_backward(const float* raw, const float* d_pose, const floa
  * [cx, cy, depth, J x (u,v,dz), J x vis] of all images back to back, gt_start int32[B+1] = first row of
  * each image. Outputs: labels int32 (0 = person, `background` otherwise), targets f32 (rows, 3+4J) =
  * [dx/stride, dy/stride, depth, J x (du,dv,dz), J x vis] of the chosen person, centerness f32.
+ * centers (optional, NULL = gt[:, :3]): f32 rows [centers2d.x, centers2d.y, depths] per person — the
+ * reference's separate `centers2d` / `depths` arguments (das_head.py:570-577): root offsets, centre box,
+ * nearest-centre choice and the depth target come from them, the joint offsets from gt[:, :3].
  */
 typedef struct {
   int J, background;
@@ -268,18 +286,20 @@ typedef struct {
   float range_lo[5], range_hi[5];
   float radius, alpha;
 } DasTargetDesc;
-int das_assign_targets(const DasLevels* lv, const DasTargetDesc* d, const float* gt, const int* gt_start, int* labels,
-                       float* targets, float* centerness, void* stream);
+int das_assign_targets(const DasLevels* lv, const DasTargetDesc* d, const float* gt, const float* centers,
+                       const int* gt_start, int* labels, float* targets, float* centerness, void* stream);
 /* mmdet FocalLoss(use_sigmoid) / mmcv sigmoid_focal_loss for one class (das_head.py:341-344): per-row
- * gradient + sum of the per-row loss (loss_sum zeroed by the call). logits: row i at logits[i*pix_stride]. */
-int das_sigmoid_focal_loss(const float* logits, int pix_stride, const int* labels, long long rows, float gamma,
-                           float alpha, float* grad, float* loss_sum, void* stream);
+ * gradient + sum of the per-row loss (loss_sum zeroed by the call). logits: row i at logits[i*pix_stride].
+ * weight (here and in the two losses below): optional f32 per-element factor, mmdet's `weight` argument
+ * (weight_reduce_loss); NULL = 1. */
+int das_sigmoid_focal_loss(const float* logits, int pix_stride, const int* labels, const float* weight, long long rows,
+                           float gamma, float alpha, float* grad, float* loss_sum, void* stream);
 /* mmdet SmoothL1Loss (das_head.py:375-379) and CrossEntropyLoss(use_sigmoid) (:470): elementwise gradient
  * and loss sum over n dense f32 elements (loss_sum zeroed by the call). */
-int das_smooth_l1_loss(const float* pred, const float* target, long long n, float beta, float* grad, float* loss_sum,
-                       void* stream);
-int das_bce_logits_loss(const float* logits, const float* target, long long n, float* grad, float* loss_sum,
-                        void* stream);
+int das_smooth_l1_loss(const float* pred, const float* target, const float* weight, long long n, float beta,
+                       float* grad, float* loss_sum, void* stream);
+int das_bce_logits_loss(const float* logits, const float* target, const float* weight, long long n, float* grad,
+                        float* loss_sum, void* stream);
 /* RealNVP log-density of the RLE pose loss (mmdet3d/models/losses/real_nvp.py:60-80 `log_prob`, called from
  * das_head.py:425-446 on (pred - gt) / sigma of every positive x joint). x f32[N][D], D = 3 (or 2); `layers`
  * coupling layers, mask bit (i*D + d) of mask_bits = mask[i][d] (1 = passed through). params f32: per layer

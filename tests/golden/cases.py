@@ -14,6 +14,14 @@ HEAD_CFG = dict(num_joints=J, root_idx=1, depth_factor=20, z_norm=50, strides=[8
 TEST_CFG = dict(nms_pre=50, nms_post=100, nms_thr=0.9, score_thr=0.07)
 HEAD_SIZES = [(16, 24), (8, 12)]
 
+# exp_mupots.py head topology (configs/das/exp_mupots.py:7,33-46): J = 21, root 14, depth_factor 1, two
+# recursive-update layers, four levels (tiny widths / maps)
+MUPOTS_J = 21
+MUPOTS_CFG = dict(num_joints=MUPOTS_J, root_idx=14, depth_factor=1, z_norm=50, strides=[8, 16, 32, 64], stacked_convs=2,
+                  num_heads=4, num_layers=2, regress_ranges=((-1, 80), (80, 160), (160, 320), (320, 1e8)),
+                  code_weight=[1.0, 1.0, 1] + [2] * MUPOTS_J * 6, prev_loss=True, feat_channels=32)
+MUPOTS_SIZES = [(16, 24), (8, 12), (4, 6), (2, 3)]
+
 FULL_J = 15
 FULL_SIZES = [(64, 104), (32, 52), (16, 26), (8, 13)]
 FULL_STRIDES = [8, 16, 32, 64]
@@ -101,8 +109,19 @@ def head_gts(counts=(3, 0), seed=5):
     return dict(gt_labels_3d=labels, gt_poses_3d=poses, centers2d=c2d, depths=dep)
 
 
-def head_feats(seed=11, B=2, C=32):
-    return [randn(seed + i, B, C, h, w) for i, (h, w) in enumerate(HEAD_SIZES)]
+def head_feats(seed=11, B=2, C=32, sizes=None):
+    return [randn(seed + i, B, C, h, w) for i, (h, w) in enumerate(sizes or HEAD_SIZES)]
+
+
+def mupots_gts(counts=(2, 3), seed=6):
+    rs = np.random.RandomState(seed)
+    W, H = MUPOTS_SIZES[0][1] * 8, MUPOTS_SIZES[0][0] * 8
+    g = [make_gt(rs, n, MUPOTS_J, W, H, two_d_first=(i == 1)) for i, n in enumerate(counts)]
+    for x in g:      # (make_gt pins dz of joint 1; the mupots root is joint 14)
+        x[0][:, 3 + 3 * 14 + 2] = 0
+    poses, c2d, dep = [x[0] for x in g], [x[1] for x in g], [x[2] for x in g]
+    labels = [torch.zeros(len(x), dtype=torch.long) for x in poses]
+    return dict(gt_labels_3d=labels, gt_poses_3d=poses, centers2d=c2d, depths=dep)
 
 
 def full_decode_inputs(seed=21, B=2, Jn=FULL_J, sizes=FULL_SIZES, bias=-4.0):

@@ -29,8 +29,8 @@ def save(name, **arrs):
     print('wrote', name, {k: getattr(v, 'shape', None) for k, v in out.items() if not k.startswith('sd_')})
 
 
-def build_head(R):
-    c = cases.HEAD_CFG
+def build_head(R, c=None, test_cfg=None):
+    c = c or cases.HEAD_CFG
     J, C = c['num_joints'], c['feat_channels']
     return R.DASHead(
         num_classes=1, in_channels=C, feat_channels=C, stacked_convs=2, strides=c['strides'],
@@ -39,7 +39,47 @@ def build_head(R):
         centerness_on_reg=True, conv_bias=True, dcn_on_last_conv=True,
         recursive_update=dict(prev_loss=True, num_heads=c['num_heads'], in_channels=C, feat_channels=C,
                               num_layers=c['num_layers'], dim=3, num_joints=J),
-        train_cfg=dict(code_weight=c['code_weight']), test_cfg=cases.TEST_CFG)
+        train_cfg=dict(code_weight=c['code_weight']), test_cfg=test_cfg or cases.TEST_CFG)
+
+
+def mupots_head_fixtures(R):
+    """exp_mupots.py head topology (J=21, root 14, depth_factor 1, two recursive-update layers, four levels):
+    forward train / eval, the four losses with gradients, decode (das_head.py:176-267,281-486,653-796)."""
+    head = build_head(R, cases.MUPOTS_CFG, cases.FULL_TEST_CFG)
+    sd = cases.det_fill(head.state_dict(), 13)
+    man = cases.manifest(sd)
+    feats = cases.head_feats(seed=61, sizes=cases.MUPOTS_SIZES)
+    gts = cases.mupots_gts()
+    gt_boxes = [torch.zeros(len(g), 4) for g in gts['gt_poses_3d']]
+    head.train(True)
+    fg = [f.clone().requires_grad_(True) for f in feats]
+    outs = head(fg)
+    losses = head.loss(*outs, gt_boxes, gts['gt_labels_3d'], gts['gt_poses_3d'], gts['gt_labels_3d'],
+                       gts['centers2d'], gts['depths'], [{}, {}])
+    sum(losses.values()).backward()
+    arrs = dict(man)
+    for name, lst in zip(('cls', 'pose', 'ctr', 'ref'), outs):
+        for i, t in enumerate(lst):
+            arrs[f'{name}{i}'] = t
+    for k, v in losses.items():
+        arrs[k] = v
+    for i, f in enumerate(fg):
+        arrs[f'grad_feat{i}'] = f.grad
+    save('head_mupots_train', **arrs)
+    head.train(False)
+    with torch.no_grad():
+        outs = head(feats)
+        arrs = dict(man)
+        for name, lst in zip(('cls', 'pose', 'ctr'), outs):
+            for i, t in enumerate(lst):
+                arrs[f'{name}{i}'] = t
+        metas = [dict(scale_factor=np.array([1.25, 1.25, 1.25, 1.25], dtype=np.float32), filename='a'),
+                 dict(scale_factor=np.array([1., 1., 1., 1.], dtype=np.float32), filename='b')]
+        res = head.get_poses([o + 1.5 for o in outs[0]], [o.clone() for o in outs[1]], [o + 1.0 for o in outs[2]], metas)
+        for b, r in enumerate(res):
+            arrs[f'dec_poses{b}'], arrs[f'dec_centers{b}'] = r['poses'], r['centers']
+            arrs[f'dec_scores{b}'] = np.array(r['scores'], dtype=np.float32)
+        save('head_mupots_eval', **arrs)
 
 
 def main():
@@ -47,7 +87,8 @@ def main():
     torch.manual_seed(0)
 
     # ---- MSPN2 (tiny widths in the upsample path; bottleneck widths are fixed by the class)
-    for stages, train in ((1, False), (2, False), (2, True)):
+    # (3 stages = exp_mupots.py:17; 4 stages = BASELINE configs[2]/[3])
+    for stages, train in ((1, False), (2, False), (2, True), (3, False), (4, True)):
         m = R.MSPN2(unit_channels=16, num_stages=stages, num_blocks=[1, 1, 1, 1], norm_cfg=dict(type='BN'))
         sd = cases.det_fill(m.state_dict(), 1)
         man = cases.manifest(sd)
@@ -114,6 +155,8 @@ def main():
             arrs[f'poses{b}'], arrs[f'centers{b}'], arrs[f'vis{b}'] = r['poses'], r['centers'], r['vis']
             arrs[f'scores{b}'] = np.array(r['scores'], dtype=np.float32)
         save('decode_tiny', **arrs)
+
+    mupots_head_fixtures(R)
 
     # ---- decode at the full 512x832 level sizes, J=15 (topk(1000) on levels 0 and 1)
     full = build_full_head(R)

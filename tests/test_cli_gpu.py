@@ -29,7 +29,7 @@ def test_train_then_test_cli(tmp_path):
     assert 'loss_pose' in out
     ck = os.path.join(work, 'epoch_1.pth')
     sd = torch.load(ck, map_location='cpu', weights_only=False)
-    assert set(sd) == {'state_dict', 'meta'} and sd['meta']['iter'] == 3
+    assert set(sd) == {'state_dict', 'optimizer', 'meta'} and sd['meta']['iter'] == 3
     w = sd['state_dict']['backbone.top.top.0.conv.weight']
     assert w.shape == (64, 3, 7, 7) and w.is_contiguous()           # dense OIHW, loadable by the reference
     res = str(tmp_path / 'res.pkl')
@@ -38,3 +38,34 @@ def test_train_then_test_cli(tmp_path):
     with open(res, 'rb') as f:
         results = pickle.load(f)
     assert len(results) == 3 and set(results[0]) >= {'poses', 'vis', 'centers', 'image_paths', 'scores'}
+
+
+def test_resume_restores_momentum_and_iteration(tmp_path):
+    """--resume-from continues where the checkpoint stopped: iteration counter, momentum, and a 9-image dataset on
+    one rank runs ceil(9 / 2) = 5 iterations per epoch (padded by wrap-around like DistributedSampler)."""
+    work = str(tmp_path / 'w')
+    small = ['model.backbone.num_stages=1', 'data.samples_per_gpu=2', 'data.train.type=SyntheticPoseDataset',
+             'data.train.length=9', 'data.train.img_shape=(128,192)', 'runner.max_epochs=2', 'log_config.interval=1']
+    run('tools/train.py', 'configs/das/exp_panoptic.py', '--work-dir', work, '--cfg-options', *small[:-2], 'runner.max_epochs=1',
+        'log_config.interval=1')
+    ck1 = torch.load(os.path.join(work, 'epoch_1.pth'), map_location='cpu', weights_only=False)
+    assert ck1['meta']['iter'] == 5 and ck1['optimizer']['steps'] == 5
+    mom = ck1['optimizer']['momentum_buffer']['backbone.top.top.0.conv.weight']
+    assert mom.shape == (64, 3, 7, 7) and float(mom.abs().max()) > 0
+    run('tools/train.py', 'configs/das/exp_panoptic.py', '--work-dir', work, '--resume-from', os.path.join(work, 'epoch_1.pth'),
+        '--cfg-options', *small)
+    ck2 = torch.load(os.path.join(work, 'epoch_2.pth'), map_location='cpu', weights_only=False)
+    assert ck2['meta']['iter'] == 10 and ck2['meta']['epoch'] == 2 and ck2['optimizer']['steps'] == 10
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` without torchrun starts its own ranks; --share-gpu puts both on
+    cuda:0 over gloo so that this runs on a 1-GPU box. All three workloads."""
+    import json
+    for wl, extra in (('train', ['--stages', '1', '--batch', '2']), ('infer', ['--batch', '2']),
+                      ('decode', ['--batch', '16'])):
+        out = run('bench.py', '--gpus', '2', '--share-gpu', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+                  '--workload', wl, *extra)
+        line = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+        assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0, line
+        assert line['config']['parallelism'] in ('dp2', 'replicas2')

@@ -1,0 +1,261 @@
+"""Parity of the tile kernels the benchmark actually runs — conv_glds3_kernel (256 x 128, 3 stages),
+conv_glds4_kernel (256 x 256, 4 stages; plain and ping-pong schedule), conv_glds8_kernel (256 x 256, 8 phases),
+conv1x1_stream_kernel, conv_wgrad_kernel / conv_wgrad_pp_kernel at their production split — against
+F.conv2d on bf16-rounded operands ("what's weak" #1).
+
+Two kinds of cases:
+  * forced: a small problem is pushed through a given kernel by lowering its dispatch threshold
+    (ops.tuning -> das_tuning_set), which covers the 3x3 tap walk and its border predicates, stride 2, ragged
+    multi-level rows, overhanging M / N tiles, K loops far longer than the pipeline depth, every epilogue;
+  * real: production-size layers with the default thresholds.
+Every case asserts WHICH kernel the launcher picked (ops.last_kernel -> das_last_kernel).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+BF = torch.bfloat16
+TOL = dict(rtol=1.6e-2, atol=1.6e-2)
+
+
+def ops():
+    from das_amd import ops as o
+    return o
+
+
+def nhwc(t, dtype=BF):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def q(t):
+    return t.to(BF).float()
+
+
+def conv_ref(x, w, s, p):
+    """f32 reference on the GPU's own f32 path would be another kernel of ours; use torch on the CPU."""
+    return F.conv2d(q(x), q(w), None, s, p)
+
+
+FORCE = {
+    'conv_glds3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.glds8_minblocks': 0,
+                          'conv.stream_minrows': 0},
+    'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.glds8_minblocks': 0,
+                          'conv.stream_minrows': 0},
+    'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.glds8_minblocks': 0,
+                              'conv.stream_minrows': 0},
+    'conv_glds8_kernel': {'conv.glds8_minblocks': 1, 'conv.stream_minrows': 0},
+}
+
+# B, H, W, Cin, Cout, k, stride, pad
+SHAPES3 = [
+    (2, 19, 23, 128, 128, 3, 1, 1),    # 18 K-steps: the steady-state 3-stage loop, borders on every side
+    (1, 33, 47, 64, 96, 3, 2, 1),      # stride 2, N tile overhangs Cout
+    (2, 9, 31, 512, 136, 1, 1, 0),     # 1x1, two N tiles (the second nearly empty), M overhang
+    (1, 40, 40, 64, 128, 1, 1, 0),     # a single K-step (prologue == epilogue)
+    (3, 7, 5, 192, 128, 3, 1, 1),      # planes smaller than a tile: several images per M tile
+]
+SHAPES4 = [
+    (2, 13, 17, 256, 256, 3, 1, 1),    # head-like 3x3, 72 K-steps of 32
+    (1, 29, 31, 96, 384, 3, 2, 1),     # Cin % 64 != 0, stride 2, the second N tile half empty
+    (2, 8, 13, 2048, 256, 1, 1, 0),    # the 2048 -> 256 lateral (K = 2048)
+    (1, 21, 10, 32, 512, 1, 1, 0),     # one K-step
+    (1, 16, 26, 64, 256, 3, 1, 1),     # two K-steps per tap
+    (3, 6, 7, 256, 264, 3, 1, 1),      # several images per tile, Cout = 256 + 8
+]
+
+
+def _run_forced(kernel, case, **kw):
+    o = ops()
+    B, H, W, Cin, Cout, k, s, p = case
+    x = cases.randn(101, B, Cin, H, W)
+    w = cases.randn(102, Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    with o.tuning(**FORCE[kernel]):
+        y = o.conv2d(nhwc(x), o.pack_weight(w.to(DEV), BF), k, k, s, p, **kw)
+        assert o.last_kernel() == kernel, o.last_kernel()
+    return x, w, y
+
+
+@pytest.mark.parametrize('case', SHAPES3)
+def test_glds3_forced(case):
+    x, w, y = _run_forced('conv_glds3_kernel', case)
+    np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
+
+
+@pytest.mark.parametrize('kernel', ['conv_glds4_kernel', 'conv_glds4_kernel<pp>'])
+@pytest.mark.parametrize('case', SHAPES4)
+def test_glds4_forced(kernel, case):
+    x, w, y = _run_forced(kernel, case)
+    np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
+
+
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>'])
+def test_tile_epilogues_forced(kernel):
+    """scale / shift / residual / ReLU, then the BatchNorm statistics of the stored values (in slots)."""
+    o = ops()
+    B, H, W, Cin, Cout = 2, 18, 15, 128, 256 if 'glds4' in kernel else 128
+    x, w = cases.randn(111, B, Cin, H, W), cases.randn(112, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
+    scale, shift = cases.randn(113, Cout).abs() + 0.5, cases.randn(114, Cout)
+    res = cases.randn(115, B, Cout, H, W)
+    conv = conv_ref(x, w, 1, 1)
+    xd, wd = nhwc(x), o.pack_weight(w.to(DEV), BF)
+    with o.tuning(**FORCE[kernel]):
+        y = o.conv2d(xd, wd, 3, 3, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), residual=nhwc(res), relu=True)
+        assert o.last_kernel() == kernel
+        aff_q = q(conv * scale[None, :, None, None] + shift[None, :, None, None])
+        np.testing.assert_allclose(nchw(y).numpy(), F.relu(aff_q + q(res)).numpy(), **TOL)
+        stats = torch.zeros(3, 2 * Cout, device=DEV)
+        y = o.conv2d(xd, wd, 3, 3, 1, 1, stats=stats.view(-1))
+        assert o.last_kernel() == kernel
+    yq = nchw(y)
+    np.testing.assert_allclose(yq.numpy(), q(conv).numpy(), **TOL)
+    n = B * H * W
+    s_ref = torch.cat([yq.sum((0, 2, 3)), (yq ** 2).sum((0, 2, 3))])      # of the values as stored
+    np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>'])
+def test_tile_ragged_levels_forced(kernel):
+    """The head's mode: four FPN levels in one launch, shared 3x3 weights (das_head.py:176-178)."""
+    o = ops()
+    B, Cin, Cout = 2, 64, 256 if 'glds4' in kernel else 128
+    sizes = [(16, 26), (8, 13), (4, 7), (2, 4)]
+    w = cases.randn(120, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
+    bias = cases.randn(121, Cout)
+    xs = [cases.randn(122 + i, B, Cin, h, ww) for i, (h, ww) in enumerate(sizes)]
+    rag = o.Ragged.from_levels([nhwc(t) for t in xs])
+    with o.tuning(**FORCE[kernel]):
+        y = o.conv2d(rag, o.pack_weight(w.to(DEV), BF), 3, 3, 1, 1, shift=bias.to(DEV), relu=True)
+        assert o.last_kernel() == kernel
+    for l, t in enumerate(xs):
+        ref = F.relu(conv_ref(t, w, 1, 1) + bias[None, :, None, None])
+        np.testing.assert_allclose(nchw(y.level(l)).numpy(), ref.numpy(), **TOL)
+
+
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel<pp>'])
+def test_tile_dgrad_forced(kernel):
+    """Data gradient of a stride-1 3x3 conv on the tile kernels (flipped weights), with a second gradient of the
+    same tensor added in the epilogue."""
+    o = ops()
+    B, H, W, Cin, Cout = 2, 14, 19, 256 if 'glds4' in kernel else 128, 128
+    x = cases.randn(130, B, Cin, H, W).requires_grad_(True)
+    w = cases.randn(131, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
+    dy = cases.randn(132, B, Cout, H, W)
+    other = cases.randn(133, B, Cin, H, W)
+    F.conv2d(x, q(w), None, 1, 1).backward(q(dy))
+    with o.tuning(**FORCE[kernel]):
+        dx = o.conv2d_dgrad(nhwc(dy), o.pack_weight_dgrad(w.to(DEV), BF), 3, 3, 1, 1, (H, W), residual=nhwc(other))
+        assert o.last_kernel() == kernel
+    np.testing.assert_allclose(nchw(dx).numpy(), q(q(x.grad) + q(other)).numpy(), **TOL)
+
+
+# ---------------------------------------------------------------- production sizes, default dispatch
+REAL = [
+    # B, H, W, Cin, Cout, k, stride, pad, expected kernel
+    (2, 128, 208, 256, 256, 3, 1, 1, 'conv_glds4_kernel<pp>'),      # 208 tiles of 256 x 256, K = 2304
+    (2, 128, 208, 64, 256, 3, 1, 1, 'conv_glds4_kernel<pp>'),       # K = 576
+    (16, 16, 26, 2048, 2048, 1, 1, 0, 'conv_glds4_kernel<pp>'),     # out_skip1 of the coarsest unit: 26 x 8 tiles
+    (4, 128, 208, 128, 128, 3, 1, 1, 'conv_glds3_kernel'),          # layer2-like 3x3 on a large map
+    (16, 32, 52, 1024, 128, 1, 1, 0, 'conv_glds3_kernel'),          # 104 tiles, K = 1024
+    (2, 128, 208, 256, 64, 1, 1, 0, 'conv1x1_stream_kernel'),
+]
+
+
+@pytest.mark.parametrize('case', REAL)
+def test_tiles_real_sizes(case):
+    o = ops()
+    B, H, W, Cin, Cout, k, s, p, expect = case
+    x = cases.randn(141, B, Cin, H, W)
+    w = cases.randn(142, Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    torch.set_num_threads(8)
+    ref = conv_ref(x, w, s, p)
+    y = o.conv2d(nhwc(x), o.pack_weight(w.to(DEV), BF), k, k, s, p)
+    assert o.last_kernel() == expect, o.last_kernel()
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **TOL)
+
+
+def test_head_ragged_real_size():
+    """The real head launch: 4 levels x B=16 x 256 channels, 3x3 256 -> 256 (187 tiles of 256 x 256, ping-pong)."""
+    o = ops()
+    B, Cc = 16, 256
+    sizes = [(64, 104), (32, 52), (16, 26), (8, 13)]
+    w = cases.randn(150, Cc, Cc, 3, 3) / (9 * Cc) ** 0.5
+    xs = [cases.randn(151 + i, B, Cc, h, ww) for i, (h, ww) in enumerate(sizes)]
+    rag = o.Ragged.from_levels([nhwc(t) for t in xs])
+    y = o.conv2d(rag, o.pack_weight(w.to(DEV), BF), 3, 3, 1, 1)
+    assert o.last_kernel() == 'conv_glds4_kernel<pp>', o.last_kernel()
+    torch.set_num_threads(8)
+    for l in (3, 2, 1):      # (level 0 alone is 106k rows x 2304 x 256: skipped on the CPU side, levels share the code path)
+        np.testing.assert_allclose(nchw(y.level(l)).numpy(), conv_ref(xs[l], w, 1, 1).numpy(), **TOL)
+    # level 0: a band of rows across the top border, an interior band and the bottom border of the last image
+    ref0 = conv_ref(xs[0][-1:], w, 1, 1)
+    np.testing.assert_allclose(nchw(y.level(0)[-1:]).numpy(), ref0.numpy(), **TOL)
+
+
+WGRAD_REAL = [
+    # B, H, W, Cin, Cout, k, stride, pad, expected kernel
+    (2, 128, 208, 64, 64, 3, 1, 1, 'conv_wgrad_kernel'),        # 5 tiles x 153 splits = 765 workgroups
+    (3, 128, 208, 256, 256, 1, 1, 0, 'conv_wgrad_pp_kernel'),   # 1 tile x 256 splits
+    (16, 32, 52, 256, 256, 3, 1, 1, 'conv_wgrad_pp_kernel'),    # 9 tiles x 28 splits
+    (8, 64, 104, 256, 512, 1, 2, 0, 'conv_wgrad_pp_kernel'),    # stride-2 1x1 (the downsample branch)
+    (4, 64, 104, 128, 128, 3, 2, 1, 'conv_wgrad_kernel'),       # stride-2 3x3
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_REAL)
+def test_wgrad_real_split(case):
+    o = ops()
+    B, H, W, Cin, Cout, k, s, p, expect = case
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = cases.randn(161, B, Cin, H, W)
+    dy = cases.randn(162, B, Cout, Ho, Wo) / (B * Ho * Wo) ** 0.5
+    torch.set_num_threads(8)
+    w0 = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    F.conv2d(q(x), w0, None, s, p).backward(q(dy))
+    dw = o.conv2d_wgrad(nhwc(x), nhwc(dy), k, k, s, p)
+    assert o.last_kernel() == expect, o.last_kernel()
+    got = dw.cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), w0.grad.numpy(), rtol=2e-3, atol=2e-3 * float(w0.grad.abs().max()))
+    # accumulate = 1 adds to what is there (the flat-gradient path), deterministically
+    acc = dw.clone()
+    o.conv2d_wgrad(nhwc(x), nhwc(dy), k, k, s, p, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), 2 * dw.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    dw2 = o.conv2d_wgrad(nhwc(x), nhwc(dy), k, k, s, p)
+    np.testing.assert_allclose(dw2.cpu().numpy(), dw.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_wgrad_ragged_real_split():
+    """Head weight gradient over the four ragged levels at B=16 (the ping-pong kernel's row walker crosses image
+    planes and level boundaries inside a split)."""
+    o = ops()
+    B, Cc = 8, 256
+    sizes = [(64, 104), (32, 52), (16, 26), (8, 13)]
+    xs = [cases.randn(171 + i, B, Cc, h, ww) for i, (h, ww) in enumerate(sizes)]
+    rows = sum(B * h * ww for h, ww in sizes)
+    dys = [cases.randn(181 + i, B, Cc, h, ww) / rows ** 0.5 for i, (h, ww) in enumerate(sizes)]
+    torch.set_num_threads(8)
+    w0 = torch.zeros(Cc, Cc, 3, 3, requires_grad=True)
+    for xl, dl in zip(xs[1:], dys[1:]):       # CPU reference over levels 1..3 (level 0 is 53k rows x 2304 x 256)
+        F.conv2d(q(xl), w0, None, 1, 1).backward(q(dl))
+    xr = o.Ragged.from_levels([nhwc(t) for t in xs])
+    dyr = o.Ragged.from_levels([nhwc(t) if i else torch.zeros_like(nhwc(t)) for i, t in enumerate(dys)])
+    dw = o.conv2d_wgrad(xr, dyr, 3, 3, 1, 1)
+    assert o.last_kernel() == 'conv_wgrad_pp_kernel'
+    got = dw.cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), w0.grad.numpy(), rtol=2e-3, atol=2e-3 * float(w0.grad.abs().max()))
+
+
+def test_tuning_api_rejects_unknown_key():
+    from das_amd import _lib
+    lib = _lib.load()
+    assert lib.das_tuning_set(b'no.such.key', 1) == _lib.DAS_ERR_ARG
+    assert lib.das_tuning_reset() == 0

@@ -43,6 +43,84 @@ def test_assign_targets_vs_reference_fixture(golden_dir):
         np.testing.assert_allclose(ctr[s:e].cpu().numpy(), z[f'ctr{l}'], rtol=1e-5, atol=1e-7)
 
 
+def test_assign_targets_separate_centers_and_depths_vs_oracle():
+    """centers2d / depths that differ from gt_poses_3d[:, :3] (das_head.py:570-589 takes root offsets, centre box
+    and depth from them, joint offsets from gt_poses_3d)."""
+    from das_amd import ops, train_ops as T
+    from das_amd.losses import _pack_centers, _pack_gt
+    from oracle import loss as ol
+    J, B = 15, 2
+    rs = np.random.RandomState(9)
+    gts = [cases.make_gt(rs, n, J, 832, 512, spread=60.0) for n in (4, 3)]
+    poses = [g[0] for g in gts]
+    c2d = [g[1] + torch.from_numpy(rs.normal(0, 6, g[1].shape).astype(np.float32)) for g in gts]
+    dep = [g[2] * 1.5 + 0.1 for g in gts]
+    labels = [torch.zeros(len(p), dtype=torch.long) for p in poses]
+    ranges = ((-1, 80), (80, 160), (160, 320), (320, 1e8))
+    pts = ol.get_points(cases.FULL_SIZES, cases.FULL_STRIDES)
+    rl, rt, rc = ol.get_targets(pts, cases.FULL_STRIDES, ranges, labels, poses, c2d, dep, J)
+    geom = ops.Ragged(torch.empty(sum(B * h * w for h, w in cases.FULL_SIZES), 1, device=DEV), B, cases.FULL_SIZES)
+    rows, start = _pack_gt(poses, DEV)
+    lab, tgt, ctr = T.assign_targets(geom, cases.FULL_STRIDES, ranges, rows, start, J,
+                                     centers=_pack_centers(c2d, dep, rows.shape[0], DEV))
+    for l in range(4):
+        s, e = geom.starts[l], geom.starts[l + 1]
+        np.testing.assert_array_equal(lab[s:e].cpu().numpy(), rl[l].numpy())
+        np.testing.assert_allclose(tgt[s:e].cpu().numpy(), rt[l].numpy(), rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(ctr[s:e].cpu().numpy(), rc[l].numpy(), rtol=1e-5, atol=1e-7)
+    assert sum(int((x == 0).sum()) for x in rl) > 5
+
+
+def test_loss_modules_follow_the_mmdet_protocol():
+    """build_loss(cfg)(pred, target, weight=, avg_factor=) — das_head.py:40-53 configs, call sites :341-344,
+    :375-379, :470-471 — against the published mmdet formulas spelled in torch."""
+    import torch.nn.functional as F
+    from das_amd.registry import build_loss
+    rs = np.random.RandomState(4)
+    N = 1000
+    x = torch.from_numpy(rs.standard_normal((N, 1)).astype(np.float32)).to(DEV).requires_grad_(True)
+    lab = torch.from_numpy((rs.uniform(0, 1, N) > 0.1).astype(np.int64)).to(DEV)      # 0 = person, 1 = background
+    w = torch.from_numpy(rs.uniform(0.5, 2, N).astype(np.float32)).to(DEV)
+    fl = build_loss(dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.5))
+    t = (lab == 0).float()[:, None]
+    xr = x.detach().clone().requires_grad_(True)
+    p = xr.sigmoid()
+    ref_el = F.binary_cross_entropy_with_logits(xr, t, reduction='none') * (0.25 * t + 0.75 * (1 - t)) * \
+        ((1 - p) * t + p * (1 - t)) ** 2
+    for kw, ref in ((dict(avg_factor=37.0), ref_el.sum() / 37.0), (dict(), ref_el.mean()),
+                    (dict(weight=w, avg_factor=5.0), (ref_el[:, 0] * w).sum() / 5.0),
+                    (dict(reduction_override='sum'), ref_el.sum())):
+        out = fl(x, lab, **kw)
+        np.testing.assert_allclose(out.item(), 1.5 * ref.item(), rtol=2e-5)
+    x.grad = None
+    fl(x, lab, weight=w, avg_factor=5.0).backward()
+    (1.5 * (ref_el[:, 0] * w).sum() / 5.0).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+    a = torch.from_numpy(rs.standard_normal(257).astype(np.float32)).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(rs.standard_normal(257).astype(np.float32)).to(DEV)
+    wv = torch.from_numpy(rs.uniform(0.5, 2, 257).astype(np.float32)).to(DEV)
+    sl = build_loss(dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0))
+    ref_el = F.smooth_l1_loss(a.detach(), b, beta=1.0 / 9.0, reduction='none')
+    np.testing.assert_allclose(sl(a, b, weight=wv, avg_factor=11.0).item(), ((ref_el * wv).sum() / 11.0).item(), rtol=2e-5)
+    np.testing.assert_allclose(sl(a, b).item(), ref_el.mean().item(), rtol=2e-5)
+    ce = build_loss(dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0))
+    tgt = b.sigmoid()
+    np.testing.assert_allclose(ce(a, tgt).item(), F.binary_cross_entropy_with_logits(a.detach(), tgt).item(), rtol=2e-5)
+    ce(a, tgt).backward()
+    ar = a.detach().clone().requires_grad_(True)
+    F.binary_cross_entropy_with_logits(ar, tgt).backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), ar.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
+    # RLELoss3D.forward: residual_log_likelihood_loss.py:21-37 (realnvp_rle.npz pins the oracle; here vs the oracle)
+    from oracle import loss as ol
+    rle = build_loss(dict(type='RLELoss3D', residual=True, loss_weight=1.0))
+    nf, pred, gt = cases.randn(45, 5, 6, 3), cases.randn(46, 5, 6, 3), cases.randn(47, 5, 6, 3)
+    sigma = cases.randn(48, 5, 6, 3).sigmoid() + 1e-9
+    visw = (cases.randn(49, 5, 6, 1) > 0).float()
+    got = rle(nf.to(DEV), pred.to(DEV), sigma.to(DEV), gt.to(DEV), visw.to(DEV), weight=2.0)
+    np.testing.assert_allclose(got.item(), ol.rle_loss3d(nf, pred, sigma, gt, visw.expand(5, 6, 3), 2.0).item(), rtol=1e-5)
+
+
 def test_assign_targets_full_size_vs_oracle():
     from das_amd import ops, train_ops as T
     from das_amd.losses import _pack_gt

@@ -24,7 +24,7 @@ def sd_of(z, seed, prefix=''):
     return cases.sd_from_manifest(z[prefix + 'sd_keys'], shapes, z[prefix + 'sd_dtypes'], seed)
 
 
-@pytest.mark.parametrize('stages,train', [(1, False), (2, False), (2, True)])
+@pytest.mark.parametrize('stages,train', [(1, False), (2, False), (2, True), (3, False), (4, True)])
 def test_mspn2_forward_backward(golden_dir, stages, train):
     z = load(golden_dir, f'mspn_s{stages}_{"train" if train else "eval"}')
     sd = sd_of(z, 1)
@@ -72,6 +72,47 @@ def test_head_train_loss_and_grads(golden_dir):
     for k in z.files:
         if k.startswith('pgrad:'):
             close(sd[k[6:]].grad.numpy(), z[k])
+
+
+def _mupots_metas():
+    return [dict(scale_factor=np.array([1.25, 1.25, 1.25, 1.25], dtype=np.float32), filename='a'),
+            dict(scale_factor=np.array([1., 1., 1., 1.], dtype=np.float32), filename='b')]
+
+
+def test_head_mupots_topology(golden_dir):
+    """exp_mupots.py head (J=21, root 14, depth_factor 1, two recursive-update layers, 4 levels): forward eval +
+    decode, forward train + the four losses + feature gradients, against the reference fixtures."""
+    c = cases.MUPOTS_CFG
+    z = load(golden_dir, 'head_mupots_eval')
+    feats = cases.head_feats(seed=61, sizes=cases.MUPOTS_SIZES)
+    with torch.no_grad():
+        outs = oh.head_forward(sd_of(z, 13), feats, c, '', train=False)
+    for name, lst in zip(('cls', 'pose', 'ctr'), outs):
+        for i, t in enumerate(lst):
+            np.testing.assert_allclose(t.numpy(), z[f'{name}{i}'], **TOL)
+    res = od.get_poses([o + 1.5 for o in outs[0]], outs[1], [o + 1.0 for o in outs[2]], _mupots_metas(),
+                       cases.MUPOTS_J, c['strides'], cases.FULL_TEST_CFG)
+    for b, r in enumerate(res):
+        assert r['poses'].shape == z[f'dec_poses{b}'].shape
+        np.testing.assert_allclose(np.array(r['scores'], dtype=np.float32), z[f'dec_scores{b}'], rtol=1e-5)
+        np.testing.assert_allclose(r['poses'].numpy(), z[f'dec_poses{b}'], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(r['centers'].numpy(), z[f'dec_centers{b}'], rtol=1e-4, atol=1e-4)
+
+    z = load(golden_dir, 'head_mupots_train')
+    sd = {k: (v.requires_grad_(True) if v.is_floating_point() and not k.endswith('.mask') else v)
+          for k, v in sd_of(z, 13).items()}
+    fg = [f.requires_grad_(True) for f in feats]
+    outs = oh.head_forward(sd, fg, c, '', train=True)
+    for name, lst in zip(('cls', 'pose', 'ctr', 'ref'), outs):
+        for i, t in enumerate(lst):
+            np.testing.assert_allclose(t.detach().numpy(), z[f'{name}{i}'], **TOL)
+    losses = ol.head_loss(sd, '', *outs, cases.mupots_gts(), c)
+    for k, v in losses.items():
+        np.testing.assert_allclose(v.item(), z[k], rtol=1e-4)
+    sum(losses.values()).backward()
+    for i, f in enumerate(fg):
+        g = z[f'grad_feat{i}']
+        np.testing.assert_allclose(f.grad.numpy(), g, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(g).max()))
 
 
 def test_points_and_targets(golden_dir):

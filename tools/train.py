@@ -72,22 +72,30 @@ def main():
     if args.autoscale_lr:
         cfg.optimizer['lr'] = cfg.optimizer['lr'] * world / 8
     opt = build_optimizer(model, cfg)
-    start_epoch = 0
-    if args.resume_from:
-        ck = torch.load(args.resume_from, map_location='cpu')
+    start_epoch, it = 0, 0
+    if args.resume_from:   # mmcv `runner.resume`: weights, optimizer state, epoch and iteration counters
+        ck = torch.load(args.resume_from, map_location='cpu', weights_only=False)
         model.load_state_dict(ck['state_dict'])
+        if 'optimizer' in ck:
+            opt.load_state_dict(ck['optimizer'])
         start_epoch = ck.get('meta', {}).get('epoch', 0)
+        it = ck.get('meta', {}).get('iter', 0)
 
     spg = cfg.data.get('samples_per_gpu', 4)
     lrc = cfg.get('lr_config', {})
     max_epochs = cfg.get('runner', {}).get('max_epochs', 12)
     log_every = cfg.get('log_config', {}).get('interval', 50)
-    it = 0
     for epoch in range(start_epoch, max_epochs):
         order = torch.randperm(len(dataset), generator=torch.Generator().manual_seed(args.seed + epoch)).tolist()
+        # torch DistributedSampler semantics (mmdet's samplers build on it): pad by wrapping around to a multiple of
+        # world x samples_per_gpu, so every rank runs the SAME number of iterations (unequal counts would leave
+        # the last gradient all-reduce of the epoch waiting for a rank that has already finished)
+        chunk = world * spg
+        total = (len(order) + chunk - 1) // chunk * chunk
+        order = (order * (total // max(len(order), 1) + 1))[:total]
         order = order[rank::world]
         t0 = time.time()
-        for b in range(0, len(order) - spg + 1, spg):
+        for b in range(0, len(order), spg):
             data = collate([dataset[i] for i in order[b:b + spg]], device='cuda')
             lr = step_lr(opt.base_lr, epoch, it, steps=lrc.get('step', (16, 20)), warmup_iters=lrc.get('warmup_iters', 0),
                          warmup_ratio=lrc.get('warmup_ratio', 1.0))
@@ -103,6 +111,7 @@ def main():
             # dense OIHW copies on the host: the live parameters are channels-last views of the optimizer's
             # flat buffer, and a checkpoint must load into the reference (mmcv) as well
             torch.save(dict(state_dict={k: v.detach().contiguous().cpu() for k, v in model.state_dict().items()},
+                            optimizer=opt.state_dict(),
                             meta=dict(epoch=epoch + 1, iter=it, config=cfg.text, CLASSES=model.CLASSES,
                                       das_amd_version=das_amd.__version__)),
                        os.path.join(work_dir, f'epoch_{epoch + 1}.pth'))
