@@ -207,10 +207,16 @@ def cpu_baseline(workload, budget_s=30.0, full=False, threads=None):
 
 def roofline_from_profile(ops, run_step, dtype, reps=2):
     """HIP events around every conv-family launch (forward, data-grad, weight-grad), on the launch stream."""
+    # Kernel quality is measured with the kernels running one at a time: the weight gradients' side stream (which
+    # overlaps them with the main stream in the timed region) is switched off for these passes, otherwise a launch's
+    # event-to-event time would include whatever ran beside it.
+    from das_amd import autograd as ag
+    side_was, ag.WGRAD_SIDE_STREAM = ag.WGRAD_SIDE_STREAM, False
     ops.PROFILE = []
     for _ in range(reps):
         run_step()
     torch.cuda.synchronize()
+    ag.WGRAD_SIDE_STREAM = side_was
     fam = {}
     for tag, flops, e0, e1, _shape in ops.PROFILE:
         f = fam.setdefault(tag, [0.0, 0.0, 0])

@@ -1,6 +1,8 @@
 """torch.autograd.Function wrappers: autograd sequences the backward pass (plumbing), every forward
 and backward body is a HIP kernel from libdas_hip.so. Activations are NHWC tensors or the 2-D `data`
 of an `ops.Ragged`; geometry travels as plain python arguments."""
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -26,13 +28,81 @@ def _dw_to_oihw(dw, weight):
     return dw[:O, :, :, :I].permute(0, 3, 1, 2)
 
 
+# ---- weight gradients on a side stream ----------------------------------------------------------------
+# A weight gradient feeds nothing but the optimizer, so it need not sit on backward's critical path
+# (BN backward -> data gradient -> next layer's BN backward ...). It is launched on a second HIP stream right after
+# its operand dY is ready; the MFMA / LDS-bound weight-gradient kernels then overlap the HBM-bound BatchNorm passes
+# and the under-filled mid-size data-gradient launches of the main stream. The main stream joins the side stream when
+# the backward pass ends (autograd engine callback), before the gradient all-reduce / optimizer step.
+WGRAD_SIDE_STREAM = os.environ.get('DAS_WGRAD_STREAM', '1') != '0'
+_side = {}           # device index -> [stream, join callback queued for the running backward?]
+
+
+def _side_stream(dev):
+    ent = _side.get(dev.index)
+    if ent is None:
+        ent = _side[dev.index] = [torch.cuda.Stream(device=dev), False]
+    return ent
+
+
+def _join_side(dev_index):
+    ent = _side[dev_index]
+    ent[1] = False
+    torch.cuda.current_stream(dev_index).wait_stream(ent[0])
+
+
+def wgrad_stream():
+    """The side stream of the current device if weight gradients are in flight on it (the data-parallel
+    all-reduce waits on it too), else None."""
+    ent = _side.get(torch.cuda.current_device())
+    return ent[0] if ent is not None else None
+
+
+class _on_side:
+    """Context: run the enclosed launches on the side stream, after everything enqueued on the current stream so far.
+    The tensors named in `keep` are read there: the caching allocator must not hand their memory to a later main-stream
+    allocation before the side stream is done with them."""
+
+    def __init__(self, *keep):
+        self.keep = [t for t in keep if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        if not WGRAD_SIDE_STREAM or not self.keep or not self.keep[0].is_cuda:
+            return self
+        dev = self.keep[0].device
+        ent = _side_stream(dev)
+        side = ent[0]
+        side.wait_stream(torch.cuda.current_stream(dev))
+        for t in self.keep:
+            t.record_stream(side)
+        if not ent[1]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(lambda i=dev.index: _join_side(i))
+                ent[1] = True
+            except RuntimeError:      # not inside a backward pass: join right after the launch instead
+                ent[1] = None
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        self.ent, self.dev = ent, dev
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            if self.ent[1] is None:
+                _join_side(self.dev.index)
+        return False
+
+
 def _wgrad(x, dy, weight, k, s, p):
     """Weight gradient of conv(x, weight). With the flat optimizer the kernel adds straight into the flat
     gradient buffer (same (Cout,KH,KW,Cin) layout) and autograd gets None; otherwise an OIHW view is returned."""
     sl = getattr(weight, '_das_slot', None)
     cin, cout = _d(x).shape[-1], _d(dy).shape[-1]
     if sl is not None and sl.direct(cin, cout) and sl.cl_shape[1] == k:
-        ops.conv2d_wgrad(x, dy, k, k, s, p, out=sl.grad_cl, accumulate=True)
+        with _on_side(_d(x), _d(dy)):
+            ops.conv2d_wgrad(x, dy, k, k, s, p, out=sl.grad_cl, accumulate=True)
         sl.fired()
         return None
     return _dw_to_oihw(ops.conv2d_wgrad(x, dy, k, k, s, p), weight)
@@ -105,6 +175,8 @@ class ConvBNTrainFn(Function):
             dgamma = dbeta = None
             ga[0].fired()
             ba[0].fired()
+        # (the weight gradient goes out first: on its side stream it waits for draw only, not for the data gradient)
+        dw = _wgrad(x, draw, conv.weight, k, s, p) if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
             if dskip is not None:
@@ -113,7 +185,6 @@ class ConvBNTrainFn(Function):
                                   residual=dskip)
             if dx.shape[-1] != x.shape[-1]:
                 dx = dx[..., :x.shape[-1]]
-        dw = _wgrad(x, draw, conv.weight, k, s, p) if ctx.needs_input_grad[1] else None
         return dx, dw, dgamma, dbeta, dres, None, None, None
 
 
@@ -167,14 +238,14 @@ class ConvFn(Function):
         if dz.dim() == 4 and not dz.is_contiguous():
             dz = dz.contiguous()
         dzr, xr = _wrap(dz, geom), _wrap(x, geom)
+        wp = conv.weight if getattr(conv, 'weight', None) is not None and conv.weight.shape == weight.shape else weight
+        dw = _wgrad(xr, dzr, wp, k, s, p) if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
             hw = None if geom is not None else (x.shape[1], x.shape[2])
             dx = _d(ops.conv2d_dgrad(dzr, packed_weight_dgrad(conv, x.dtype), k, k, s, p, hw))
             if dx.shape[-1] != x.shape[-1]:
                 dx = dx[..., :x.shape[-1]]
-        wp = conv.weight if getattr(conv, 'weight', None) is not None and conv.weight.shape == weight.shape else weight
-        dw = _wgrad(xr, dzr, wp, k, s, p) if ctx.needs_input_grad[1] else None
         db = ops.colsum(dzr)[:weight.shape[0]] if has_bias else None
         return dx, dw, db, None, None, None, None, None
 
@@ -303,7 +374,8 @@ class DcnGemmFn(Function):
         cpad = col.shape[-1] // 9
         if sl is not None and sl.direct(cpad, dy.shape[-1]):
             # (O,3,3,C) channels-last storage == the (O,1,1,9C) GEMM weight: add straight into the flat gradient
-            ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0, out=sl.grad_cl, accumulate=True)
+            with _on_side(col, dy):
+                ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0, out=sl.grad_cl, accumulate=True)
             sl.fired()
             dw = None
         else:
