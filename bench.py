@@ -403,6 +403,9 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=None, help='override the CPU leg\'s thread count')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='run only the CPU leg and print it')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-wgrad-stream', action='store_true', help='A/B: weight gradients on the main stream')
+    ap.add_argument('--no-fused-bn', action='store_true',
+                    help='A/B: one autograd node per conv+BN unit (separate BatchNorm-backward reduction passes)')
     ap.add_argument('--share-gpu', action='store_true',
                     help='testing only: run all ranks on cuda:0 with the gloo transport (not a measurement)')
     args = ap.parse_args()
@@ -441,8 +444,12 @@ def main():
             dist.destroy_process_group()
         return
 
-    from das_amd import ops
+    from das_amd import autograd as ag, backbones, ops
     from das_amd.datasets import SyntheticPoseDataset, collate
+    if args.no_wgrad_stream:
+        ag.WGRAD_SIDE_STREAM = False
+    if args.no_fused_bn:
+        backbones.FUSED_LAYER_BACKWARD = False
     model = build_model(dev, seed=0, dtype=args.dtype, num_stages=stages, train=train)
     ds = SyntheticPoseDataset(num_joints=J, img_shape=(H, W), length=batch * world, seed=0)
     data = collate([ds[rank * batch + i] for i in range(batch)], device=dev)

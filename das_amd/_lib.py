@@ -23,7 +23,9 @@ class DasConvDesc(C.Structure):
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('relu_in', i32), ('relu', i32),
                 ('scale', vp), ('shift', vp), ('residual', vp), ('res_pix_stride', i32), ('stats', vp),
-                ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5), ('in_up', i32), ('stats_slots', i32)]
+                ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5), ('in_up', i32), ('stats_slots', i32),
+                ('bnb_raw', vp), ('bnb_y', vp), ('bnb_mean', vp), ('bnb_invstd', vp), ('bnb_gamma', vp), ('bnb_beta', vp),
+                ('bnb_relu', i32), ('bnb_pix_stride', i32)]
 
 
 class DasPackEntry(C.Structure):
@@ -71,6 +73,7 @@ SIGNATURES = {
     'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
     'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
     'das_bn_train_backward_phase': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i64, vp]),
+    'das_bn_backward_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]),
     'das_groupnorm_backward': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp,
                                      vp, vp, vp]),
     'das_maxpool3x3s2_backward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),

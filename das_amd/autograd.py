@@ -1,8 +1,6 @@
 """torch.autograd.Function wrappers: autograd sequences the backward pass (plumbing), every forward
 and backward body is a HIP kernel from libdas_hip.so. Activations are NHWC tensors or the 2-D `data`
 of an `ops.Ragged`; geometry travels as plain python arguments."""
-import os
-
 import torch
 from torch.autograd import Function
 
@@ -34,7 +32,7 @@ def _dw_to_oihw(dw, weight):
 # its operand dY is ready; the MFMA / LDS-bound weight-gradient kernels then overlap the HBM-bound BatchNorm passes
 # and the under-filled mid-size data-gradient launches of the main stream. The main stream joins the side stream when
 # the backward pass ends (autograd engine callback), before the gradient all-reduce / optimizer step.
-WGRAD_SIDE_STREAM = os.environ.get('DAS_WGRAD_STREAM', '1') != '0'
+WGRAD_SIDE_STREAM = True   # (bench.py --no-wgrad-stream and the tests flip it for A/B runs)
 _side = {}           # device index -> [stream, join callback queued for the running backward?]
 
 
@@ -128,26 +126,34 @@ def _all_reduce(t):
     dist.all_reduce(t)
 
 
+def _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual):
+    """conv (BatchNorm statistics in its epilogue) -> finalize + apply (+ residual, + ReLU). Returns
+    y, raw, mean, invstd, world (number of ranks the statistics span)."""
+    from .nn import bn_stats_buffer, packed_weight, sync_stats
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+    stats = bn_stats_buffer(x, w.shape[0])
+    raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    world = _sync_world(bn)
+    stat_count = 0
+    if world > 1:   # SyncBN: the statistics are those of all ranks' pixels
+        stats = sync_stats(stats, w.shape[0], _all_reduce)
+        stat_count = (raw.numel() // raw.shape[-1]) * world
+    y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,
+                                         residual=residual, relu=relu,
+                                         num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count)
+    bn.__dict__.pop('_das_cache', None)  # running stats changed under the cache's feet (raw-pointer update)
+    return y, raw, mean, invstd, world
+
+
 class ConvBNTrainFn(Function):
     """conv (no bias) -> train-mode BatchNorm (+ residual) (+ ReLU). mspn_mmpose.py:126-157,381-404."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv, bn, relu):
-        from .nn import bn_stats_buffer, packed_weight, sync_stats
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
-        stats = bn_stats_buffer(x, w.shape[0])
-        raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
-        mom = bn.momentum if bn.momentum is not None else 0.1
-        world = _sync_world(bn)
-        stat_count = 0
-        if world > 1:   # SyncBN: the statistics are those of all ranks' pixels
-            stats = sync_stats(stats, w.shape[0], _all_reduce)
-            stat_count = (raw.numel() // raw.shape[-1]) * world
-        y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,
-                                             residual=residual, relu=relu,
-                                             num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count)
-        bn.__dict__.pop('_das_cache', None)  # running stats changed under the cache's feet (raw-pointer update)
+        y, raw, mean, invstd, world = _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual)
         ctx.save_for_backward(x, raw, y if residual is not None else None, mean, invstd, gamma, weight, beta)
         ctx.cfg = (k, s, p, relu, residual is not None, conv, bn)
         ctx.world = world
@@ -204,6 +210,162 @@ class ConvBNTrainSkipFn(Function):
     def backward(ctx, dy, dskip):
         dx, dw, dgamma, dbeta, _, _, _, _ = ConvBNTrainFn.backward(ctx, dy, dskip)
         return dx, dw, dgamma, dbeta, None, None, None
+
+
+class BottleneckChainFn(Function):
+    """A whole ResNet layer (`nn.Sequential` of Bottlenecks, mspn_mmpose.py:17-157,254-275) as ONE autograd node, so
+    that backward can be scheduled by hand: the data-gradient conv that produces the gradient of a BatchNorm layer's
+    output also masks it (ReLU) and reduces [sum dZ | sum dZ * xhat] in its epilogue (DasConvDesc.bnb_*), and the layer
+    is finished by the apply pass alone — the separate reduction pass over (dY, raw) that every BatchNorm backward
+    otherwise needs disappears for bn1 / bn2 of every block and for bn3 of every block but the last (whose gradient
+    arrives from outside). Forward runs the same kernels as the per-unit path. Arithmetic per layer is unchanged
+    (same mask, same sums up to f32 summation order)."""
+
+    @staticmethod
+    def forward(ctx, x, blocks, *params):
+        saved, plan = [x], []
+        it = iter(params)
+        for blk in blocks:
+            xin = x
+            ent = {}
+            w1, g1, b1, w2, g2, b2, w3, g3, b3 = (next(it) for _ in range(9))
+            y1, raw1, m1, i1, _ = _convbn_train_forward(xin, blk.conv1, blk.bn1, g1, b1, True, None)
+            y2, raw2, m2, i2, _ = _convbn_train_forward(y1, blk.conv2, blk.bn2, g2, b2, True, None)
+            if blk.downsample is not None:
+                wd, gd, bd = (next(it) for _ in range(3))
+                ds = blk.downsample
+                idn, rawd, md, idd, _ = _convbn_train_forward(xin, ds.conv, ds.bn, gd, bd, False, None)
+            else:
+                idn = xin
+            y3, raw3, m3, i3, _ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, idn)
+            ent['u'] = len(saved)
+            saved += [raw1, m1, i1, y1, raw2, m2, i2, y2, raw3, m3, i3, y3]
+            if blk.downsample is not None:
+                ent['d'] = len(saved)
+                saved += [rawd, md, idd]
+            plan.append(ent)
+            x = y3
+        ctx.save_for_backward(*saved, *params)
+        ctx.plan, ctx.blocks, ctx.nsaved = plan, blocks, len(saved)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .nn import bn_stats_buffer, packed_weight_dgrad
+        saved, params = ctx.saved_tensors[:ctx.nsaved], ctx.saved_tensors[ctx.nsaved:]
+        blocks, plan = ctx.blocks, ctx.plan
+        grads = [None] * len(params)
+        # parameter offsets per block
+        offs, o = [], 0
+        for blk in blocks:
+            offs.append(o)
+            o += 12 if blk.downsample is not None else 9
+
+        def finish_bn(bn, gamma, beta, pi, dz, raw, mean, invstd, sums):
+            """apply pass of a layer whose dZ and sums are ready; parameter gradients -> flat accumulators or grads[]"""
+            ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
+            direct = ga is not None and ba is not None
+            draw = ops.bn_backward_apply(dz, raw, mean, invstd, gamma, sums,
+                                         dgamma_acc=ga[1] if direct else None, dbeta_acc=ba[1] if direct else None)
+            if direct:
+                ga[0].fired()
+                ba[0].fired()
+            else:
+                C_ = raw.shape[-1]
+                f = sums.view(-1, 2 * C_).sum(0)
+                grads[pi], grads[pi + 1] = f[C_:], f[:C_]
+            return draw
+
+        def classic_bn(bn, gamma, beta, pi, dyv, y, raw, mean, invstd, relu, want_dres):
+            ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
+            direct = ga is not None and ba is not None
+            draw, dres, dgamma, dbeta = ops.bn_train_backward(dyv, y, raw, mean, invstd, gamma, relu, want_dres, beta=beta,
+                                                              dgamma_acc=ga[1] if direct else None,
+                                                              dbeta_acc=ba[1] if direct else None)
+            if direct:
+                ga[0].fired()
+                ba[0].fired()
+            else:
+                grads[pi], grads[pi + 1] = dgamma, dbeta
+            return draw, dres
+
+        def wgrad(conv, pi, xin, draw):
+            k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            grads[pi] = _wgrad(xin, draw, conv.weight, k, s, p)
+
+        def dgrad(conv, draw, xin, residual=None, fuse=None):
+            """data gradient of `conv` wrt xin; fuse = (raw, y, mean, invstd, gamma, beta) of the BatchNorm+ReLU layer
+            that produced xin -> returns (dZ, sums) of that layer instead of the plain gradient"""
+            k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            w = packed_weight_dgrad(conv, xin.dtype)
+            if fuse is None:
+                return ops.conv2d_dgrad(draw, w, k, k, s, p, (xin.shape[1], xin.shape[2]), residual=residual)
+            sums = bn_stats_buffer(xin, xin.shape[-1])
+            dz = ops.conv2d_dgrad(draw, w, k, k, s, p, (xin.shape[1], xin.shape[2]), residual=residual,
+                                  bn_bwd=ops.BnBwd(*fuse, True), stats=sums)
+            return dz, sums
+
+        x0 = saved[0]
+        carry_dy, carry_dz = dy.contiguous(), None     # gradient wrt the current block's output: raw, or (dZ, sums)
+        for bi in range(len(blocks) - 1, -1, -1):
+            blk, ent, po = blocks[bi], plan[bi], offs[bi]
+            raw1, m1, i1, y1, raw2, m2, i2, y2, raw3, m3, i3, y3 = saved[ent['u']:ent['u'] + 12]
+            xin = x0 if bi == 0 else saved[plan[bi - 1]['u'] + 11]
+            w1, g1, b1, w2, g2, b2, w3, g3, b3 = params[po:po + 9]
+            # ---- bn3 (+ identity, ReLU)
+            if carry_dz is None:
+                draw3, dz3 = classic_bn(blk.bn3, g3, b3, po + 7, carry_dy, y3, raw3, m3, i3, True, True)
+            else:
+                dz3, sums3 = carry_dz
+                draw3 = finish_bn(blk.bn3, g3, b3, po + 7, dz3, raw3, m3, i3, sums3)
+            wgrad(blk.conv3, po + 6, y2, draw3)
+            dz2, sums2 = dgrad(blk.conv3, draw3, y2, fuse=(raw2, None, m2, i2, g2, b2))
+            draw2 = finish_bn(blk.bn2, g2, b2, po + 4, dz2, raw2, m2, i2, sums2)
+            wgrad(blk.conv2, po + 3, y1, draw2)
+            dz1, sums1 = dgrad(blk.conv2, draw2, y1, fuse=(raw1, None, m1, i1, g1, b1))
+            draw1 = finish_bn(blk.bn1, g1, b1, po + 1, dz1, raw1, m1, i1, sums1)
+            wgrad(blk.conv1, po, xin, draw1)
+            if blk.downsample is not None:
+                ds = blk.downsample
+                rawd, md, idd = saved[ent['d']:ent['d'] + 3]
+                wd, gd, bd = params[po + 9:po + 12]
+                drawd, _ = classic_bn(ds.bn, gd, bd, po + 10, dz3, None, rawd, md, idd, False, False)
+                wgrad(ds.conv, po + 9, xin, drawd)
+                dx1 = dgrad(blk.conv1, draw1, xin)
+                carry_dy, carry_dz = dgrad(ds.conv, drawd, xin, residual=dx1), None
+            elif bi > 0:   # xin is the previous block's output: mask by it, reduce for its bn3
+                pent, ppo = plan[bi - 1], offs[bi - 1]
+                praw3, pm3, pi3 = saved[pent['u'] + 8:pent['u'] + 11]
+                pg3, pb3 = params[ppo + 7], params[ppo + 8]
+                carry_dy, carry_dz = None, dgrad(blk.conv1, draw1, xin, residual=dz3, fuse=(praw3, xin, pm3, pi3, pg3, pb3))
+            else:
+                carry_dy, carry_dz = dgrad(blk.conv1, draw1, xin, residual=dz3), None
+        assert carry_dz is None
+        return (carry_dy, None) + tuple(grads)
+
+
+def bottleneck_chain(x, blocks):
+    """Run a layer of Bottlenecks through BottleneckChainFn if that applies (training, gradients on, plain BatchNorm —
+    SyncBN layers exchange their sums between the two backward phases and keep the per-unit path); else None."""
+    blocks = list(blocks)
+    bns = []
+    for b in blocks:
+        bns += [b.bn1, b.bn2, b.bn3] + ([b.downsample.bn] if b.downsample is not None else [])
+        if b.downsample is not None and (not getattr(b.downsample, 'norm_name', None) == 'bn' or b.downsample.with_activation):
+            return None
+    if not all(bn.training for bn in bns) or any(_sync_world(bn) > 1 for bn in bns):
+        return None
+    if any(b.downsample is not None for b in blocks[1:]) or x.shape[-1] % 8:
+        return None
+    params = []
+    for b in blocks:
+        params += [b.conv1.weight, b.bn1.weight, b.bn1.bias, b.conv2.weight, b.bn2.weight, b.bn2.bias,
+                   b.conv3.weight, b.bn3.weight, b.bn3.bias]
+        if b.downsample is not None:
+            params += [b.downsample.conv.weight, b.downsample.bn.weight, b.downsample.bn.bias]
+    if not grad_mode(x, *params):
+        return None
+    return BottleneckChainFn.apply(x, blocks, *params)
 
 
 class ConvFn(Function):

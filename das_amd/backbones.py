@@ -19,6 +19,11 @@ from .nn import ConvModule, as_nhwc, conv_bn, to_nchw_view
 from .registry import BACKBONES
 
 
+# training: a layer's Bottlenecks run as one autograd node whose backward folds the BatchNorm-backward reductions into
+# the data-gradient convs (autograd.BottleneckChainFn); False = one node per conv+BN unit (the tests compare both)
+FUSED_LAYER_BACKWARD = True
+
+
 class Bottleneck(nn.Module):
     """ResNet bottleneck, 'pytorch' style (stride on the 3x3), expansion 4 (mspn_mmpose.py:17-157,196-210)."""
     expansion = 4
@@ -74,8 +79,11 @@ class DownsampleModule(nn.Module):
 
     def forward(self, x, skip1, skip2):
         out = []
+        from . import autograd as ag
         for i in range(self.num_units):
-            x = getattr(self, f'layer{i + 1}')(x)
+            layer = getattr(self, f'layer{i + 1}')
+            y = ag.bottleneck_chain(x, layer) if FUSED_LAYER_BACKWARD else None
+            x = layer(x) if y is None else y
             if self.has_skip:
                 x = nnops.add3(x, skip1[i], skip2[i])
             out.append(x)

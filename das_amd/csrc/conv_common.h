@@ -26,6 +26,18 @@ struct ConvP {
               // reads x[t >> up_sh] when t is a multiple of 1 << up_sh, else contributes zero
   int M, K, HoWo, ntiles, nblocks;
   unsigned xbytes;  // addressable bytes of x from its base (0 if >= 4 GiB): range of the buffer descriptor
+  // Fused BatchNorm-backward reduction (data-gradient launches, DasConvDesc.bnb_*): the value about to be stored,
+  // g = conv + residual, is the gradient wrt the OUTPUT of a train-mode BatchNorm (+ReLU) layer whose pre-norm
+  // tensor is bnb_raw. The epilogue stores dZ = g * mask instead and adds [sum dZ | sum dZ * xhat] per channel into
+  // `stats` (same slot scheme as the forward statistics): the separate reduce pass over (dY, raw) disappears.
+  const char* bnb_raw;   // (M, Cout) pre-norm tensor, pixel stride bnb_ps; nullptr = feature off
+  const char* bnb_y;     // (M, Cout) post-ReLU output: mask = y > 0 (needed when a residual entered before the ReLU);
+                         // nullptr with bnb_relu: mask recomputed as bn_affine(raw) > 0
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  int bnb_relu, bnb_ps;
   // ragged multi-level input (stride 1, "same" padding): rows of level l start at lvStart[l]
   int nlev, B;
   int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];
@@ -156,20 +168,42 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   for (int j = 0; j < EPVO; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   OT* yg = reinterpret_cast<OT*>(p.y);
   const OT* rg = reinterpret_cast<const OT*>(p.res);
+  const OT* bxg = reinterpret_cast<const OT*>(p.bnb_raw);   // fused BatchNorm-backward reduction (see ConvP)
+  const OT* byg = reinterpret_cast<const OT*>(p.bnb_y);
   if (n < p.Cout) {
     constexpr int ITERS = BMT / RP, CH = ITERS < 4 ? ITERS : 4;  // rows per thread, processed CH at a time
     static_assert(ITERS % CH == 0, "tile rows per thread must be a multiple of the chunk");
+    float bmu[EPVO], bis[EPVO], bga[EPVO], bbe[EPVO];
+    if (bxg) {
+#pragma unroll
+      for (int j = 0; j < EPVO; ++j) {
+        bmu[j] = p.bnb_mean[n + j]; bis[j] = p.bnb_invstd[n + j];
+        bga[j] = (p.bnb_relu && !byg) ? p.bnb_gamma[n + j] : 0.f;
+        bbe[j] = (p.bnb_relu && !byg) ? p.bnb_beta[n + j] : 0.f;
+      }
+    }
 #pragma unroll 1
     for (int it0 = 0; it0 < ITERS; it0 += CH) {
       // the residual rows of a chunk are requested together, ahead of the LDS reads, so that their
       // memory latency overlaps instead of adding up row by row
-      uint4 rv[CH];
+      uint4 rv[CH], xv[CH], yv[CH];
       if (rg) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
           const int m = m0 + r0 + (it0 + u) * RP;
           rv[u] = make_uint4(0, 0, 0, 0);
           if (m < p.M) rv[u] = *reinterpret_cast<const uint4*>(rg + (long long)m * p.rps + n);
+        }
+      }
+      if (bxg) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int m = m0 + r0 + (it0 + u) * RP;
+          xv[u] = yv[u] = make_uint4(0, 0, 0, 0);
+          if (m < p.M) {
+            xv[u] = *reinterpret_cast<const uint4*>(bxg + (long long)m * p.bnb_ps + n);
+            if (byg) yv[u] = *reinterpret_cast<const uint4*>(byg + (long long)m * p.bnb_ps + n);
+          }
         }
       }
 #pragma unroll
@@ -180,7 +214,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
         const uint4 raw = *reinterpret_cast<const uint4*>(smem + ml * CS + vec * 16);
         float f[EPVO];
         Elem<OT>::unpack(raw, f);
-        if (p.stats) {
+        if (p.stats && !bxg) {
 #pragma unroll
           for (int j = 0; j < EPVO; ++j) { ssum[j] += f[j]; ssq[j] += f[j] * f[j]; }
         }
@@ -194,7 +228,27 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
 #pragma unroll
           for (int j = 0; j < EPVO; ++j) f[j] = fmaxf(f[j], 0.f);
         }
-        *reinterpret_cast<uint4*>(yg + (long long)m * p.yps + n) = (rg || p.relu) ? Elem<OT>::pack(f) : raw;
+        uint4 outv = (rg || p.relu) ? Elem<OT>::pack(f) : raw;
+        if (bxg) {
+          float x[EPVO];
+          Elem<OT>::unpack(xv[u], x);
+          if (p.bnb_relu) {
+            if (byg) {
+              float o[EPVO];
+              Elem<OT>::unpack(yv[u], o);
+#pragma unroll
+              for (int j = 0; j < EPVO; ++j) f[j] = o[j] > 0.f ? f[j] : 0.f;
+            } else {
+#pragma unroll
+              for (int j = 0; j < EPVO; ++j) f[j] = bn_affine(x[j], bmu[j], bis[j], bga[j], bbe[j]) > 0.f ? f[j] : 0.f;
+            }
+          }
+          outv = Elem<OT>::pack(f);
+          Elem<OT>::unpack(outv, f);   // the sums see dZ as stored (what the apply pass will read)
+#pragma unroll
+          for (int j = 0; j < EPVO; ++j) { ssum[j] += f[j]; ssq[j] += f[j] * (x[j] - bmu[j]) * bis[j]; }
+        }
+        *reinterpret_cast<uint4*>(yg + (long long)m * p.yps + n) = outv;
       }
     }
   }

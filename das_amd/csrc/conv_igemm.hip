@@ -624,11 +624,13 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
 // waves 8-9 only issue the DMA, three tiles ahead into four LDS stages, wait with a counted vmcnt and release the
 // others through the workgroup barrier (one barrier per tile).
 // MODE (keeps each variant under the 168 registers that ten waves per workgroup allow): 0 = plain, optional BatchNorm
-// statistics (training forward); 1 = scale / shift, optional ReLU (eval); 2 = residual add, optional ReLU (data gradient).
+// statistics (training forward); 1 = scale / shift, optional ReLU (eval); 2 = residual add, optional ReLU (data gradient);
+// 3 / 4 = data gradient with the fused BatchNorm-backward reduction (ConvP::bnb_*): optional residual, mask from the
+// saved output y (3; no y = no mask) or recomputed from raw with the layer's affine (4), per-channel sums in registers.
 template <int KB, int WN, int MODE>   // K = 32 * KB input channels; WN waves across the 32-channel groups, 8 / WN across pixels
 __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, int ntiles) {
   using T = bf16_t;
-  constexpr bool STATS = MODE == 0, AFF = MODE == 1, RES = MODE == 2;
+  constexpr bool STATS = MODE == 0, AFF = MODE == 1, RES = MODE == 2, BNB = MODE >= 3;
   constexpr int WM = 8 / WN, TM = 64, PB = TM / WM / 16;    // 16-pixel blocks per wave and tile
   constexpr int K = KB * 32, SUBS = (K + 63) / 64;
   constexpr int SUBB = TM * 128, STAGE = SUBS * SUBB;       // bytes
@@ -707,6 +709,116 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
 
   T* yg = reinterpret_cast<T*>(p.y);
+  if constexpr (BNB) {
+    // The epilogue operands (residual = the other gradient of the same tensor, raw, y) are requested when the tile
+    // opens, HB pixel blocks at a time, by hand-issued loads that land while those blocks' MFMAs run; the wait that
+    // follows also drains the previous blocks' stores (one counter for both kinds) — the price of not keeping a second
+    // register set per operand, which this variant has no room for.
+    constexpr int HB = PB > 2 ? 2 : PB;
+    const T* rgb = reinterpret_cast<const T*>(p.res);
+    const T* bx = reinterpret_cast<const T*>(p.bnb_raw);
+    const T* by = MODE == 3 ? reinterpret_cast<const T*>(p.bnb_y) : nullptr;
+    float mu[8], is[8], ga[8], be[8];
+    if constexpr (MODE == 4) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        mu[j] = cok ? p.bnb_mean[c8 + j] : 0.f; is[j] = cok ? p.bnb_invstd[c8 + j] : 0.f;
+        ga[j] = cok ? p.bnb_gamma[c8 + j] : 0.f; be[j] = cok ? p.bnb_beta[c8 + j] : 0.f;
+      }
+    }
+    int st = 0;
+    for (int t = first; t < ntiles; t += tstride) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();    // the loader waves saw tile t land
+      asm volatile("" ::: "memory");
+      const char* sx = smem + st * STAGE;
+#pragma unroll
+      for (int h0 = 0; h0 < PB; h0 += HB) {
+        v4i_t lr[HB], lx[HB], ly[HB];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+          long long m = (long long)t * TM + wm * (TM / WM) + (h0 + h) * 16 + q;
+          m = m < p.M ? m : p.M - 1;
+          const long long eo = m * p.bnb_ps + (cok ? c8 : 0);
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lx[h]) : "v"(bx + eo) : "memory");
+          if (by) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ly[h]) : "v"(by + eo) : "memory");
+          if (rgb) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lr[h]) : "v"(rgb + m * p.rps + (cok ? c8 : 0)) : "memory");
+        }
+        f32x4_t acc0[HB], acc1[HB];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+          const int row = wm * (TM / WM) + (h0 + h) * 16 + q;
+          acc0[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          acc1[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {
+            const int slot = ((kb & 1) * 4 + g4) ^ ((row >> 1) & 7);
+            const uint4 bf = *reinterpret_cast<const uint4*>(sx + (kb >> 1) * SUBB + row * 128 + slot * 16);
+            acc0[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[0][kb]),
+                                                              __builtin_bit_cast(bf16x8_t, bf), acc0[h], 0, 0, 0);
+            acc1[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[1][kb]),
+                                                              __builtin_bit_cast(bf16x8_t, bf), acc1[h], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < HB; ++h)   // (the operands name the destination registers: they stay allocated until here)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[h]), "+v"(ly[h]), "+v"(lr[h])::"memory");
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+          const long long m = (long long)t * TM + wm * (TM / WM) + (h0 + h) * 16 + q;
+          if (m < p.M && cok) {
+            float v[8], x[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = acc0[h][j]; v[4 + j] = acc1[h][j]; }
+            uint4 o = Elem<T>::pack(v);
+            Elem<T>::unpack(o, v);   // the conv result as a tile kernel would have staged it (bf16)
+            if (rgb) {
+              float r[8];
+              Elem<T>::unpack(__builtin_bit_cast(uint4, lr[h]), r);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] += r[j];
+            }
+            Elem<T>::unpack(__builtin_bit_cast(uint4, lx[h]), x);
+            if (MODE == 4) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = bn_affine(x[j], mu[j], is[j], ga[j], be[j]) > 0.f ? v[j] : 0.f;
+            } else if (by) {
+              float yo[8];
+              Elem<T>::unpack(__builtin_bit_cast(uint4, ly[h]), yo);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = yo[j] > 0.f ? v[j] : 0.f;
+            }
+            o = Elem<T>::pack(v);
+            Elem<T>::unpack(o, v);   // dZ as stored
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * x[j]; }   // (sum dZ * raw: centred below)
+            *reinterpret_cast<uint4*>(yg + m * p.yps + c8) = o;
+          }
+        }
+      }
+      st = (st + 1) % NS;
+    }
+    // sum dZ * xhat = invstd * (sum dZ * raw - mean * sum dZ), per workgroup (linear, so the partials may be centred
+    // one by one); then over the 16 pixels (lanes) of a DPP row and one atomic per channel from lane 15 of each row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float m_ = cok ? p.bnb_mean[c8 + j] : 0.f, i_ = cok ? p.bnb_invstd[c8 + j] : 0.f;
+      ssq[j] = i_ * (ssq[j] - m_ * ssum[j]);
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        float v = w ? ssq[j] : ssum[j];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));
+        if (q == 15 && cok) {
+          const int slot = p.stat_slots > 1 ? (int)(blockIdx.x % (unsigned)p.stat_slots) : 0;
+          atomicAdd(p.stats + (slot * 2 + w) * p.Cout + c8 + j, v);
+        }
+      }
+    }
+    return;
+  }
   const T* rg = RES ? reinterpret_cast<const T*>(p.res) : nullptr;
   // Residual rows are fetched one tile ahead by hand-issued loads: if the compiler tracked them it would have to
   // wait with vmcnt(0) (loads and stores mixed in one counter), i.e. for the rows just requested and for every store.
@@ -845,13 +957,19 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
     return true;
   };
   const bool aff = p.scale || p.shift;
-  if ((aff && (p.res || p.stats)) || (p.res && p.stats)) return false;   // (combinations no caller on the path uses)
-  const int mode = p.res ? 2 : (aff ? 1 : 0);
+  const bool bnb = p.bnb_raw != nullptr;
+  if (!bnb && ((aff && (p.res || p.stats)) || (p.res && p.stats))) return false;   // (combinations no caller on the path uses)
+  if (bnb && (p.relu || aff)) return false;
+  const int mode = bnb ? ((p.bnb_relu && !p.bnb_y) ? 4 : 3) : p.res ? 2 : (aff ? 1 : 0);
+  if (mode == 4 && p.res) return false;   // (the recomputed mask is only valid when no residual entered before the ReLU)
 #define DAS_STREAM_CASE(KBV, WNV)                                         \
   if (kb == KBV && wn == WNV) {                                           \
     if (mode == 0) return go(conv1x1_stream_kernel<KBV, WNV, 0>);         \
     if (mode == 1) return go(conv1x1_stream_kernel<KBV, WNV, 1>);         \
-    return go(conv1x1_stream_kernel<KBV, WNV, 2>);                        \
+    if (mode == 2) return go(conv1x1_stream_kernel<KBV, WNV, 2>);         \
+    if (mode == 3) return go(conv1x1_stream_kernel<KBV, WNV, 3>);         \
+    if constexpr (WNV == 2) return go(conv1x1_stream_kernel<KBV, WNV, 4>); \
+    return false;   /* (mode 4 with wide outputs would spill: the tile kernels take those) */ \
   }
   DAS_STREAM_CASE(2, 2) DAS_STREAM_CASE(2, 4) DAS_STREAM_CASE(2, 8)
   DAS_STREAM_CASE(4, 2) DAS_STREAM_CASE(4, 4) DAS_STREAM_CASE(4, 8)
@@ -948,6 +1066,15 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   p.up_sh = d->in_up == 2 ? 1 : 0;
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0;
+  p.bnb_raw = (const char*)d->bnb_raw; p.bnb_y = (const char*)d->bnb_y;
+  p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta;
+  p.bnb_relu = d->bnb_relu; p.bnb_ps = d->bnb_pix_stride;
+  if (p.bnb_raw) {   // fused BatchNorm-backward reduction: see DasConvDesc
+    if (!d->stats || d->out_dtype != d->dtype || d->relu || d->scale || d->shift || !p.bnb_mean || !p.bnb_invstd ||
+        p.bnb_ps < d->Cout || p.bnb_ps % 8)
+      return DAS_ERR_ARG;
+    if (p.bnb_relu && !p.bnb_y && (!p.bnb_gamma || !p.bnb_beta)) return DAS_ERR_ARG;
+  }
   {
     const long long npix = p.nlev > 1 ? M : (long long)d->B * d->H * d->W;
     const long long xb = ((npix - 1) * d->x_pix_stride + d->Cin) * (d->dtype == DAS_BF16 ? 2 : 4);

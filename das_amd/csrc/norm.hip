@@ -25,14 +25,6 @@ __device__ __forceinline__ BnStat bn_stat(const float* __restrict__ stats, int C
   return s;
 }
 
-__global__ void bn_fold_slots_kernel(float* __restrict__ stats, int slots, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float a = stats[i];
-  for (int k = 1; k < slots; ++k) a += stats[k * n + i];
-  stats[i] = a;
-}
-
 // The "finalize" duties, done by workgroup 0 of the apply kernel (no separate launch): publish mean / invstd for
 // the backward pass, update the running statistics (momentum, unbiased variance) and the batch counter.
 __device__ __forceinline__ void bn_publish(const float* __restrict__ stats, long long count, int C, float* running_mean,
@@ -58,7 +50,7 @@ __device__ __forceinline__ void bn_publish(const float* __restrict__ stats, long
 // whole loop and the per-channel constants live in registers (FIXED); two iterations are kept in flight.
 template <typename T, bool FIXED>
 __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long long count, int C,
-                                const float* __restrict__ stats, long long stat_count, float eps,
+                                const float* __restrict__ gstats, int slots, long long stat_count, float eps,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const T* __restrict__ res, int relu, float* running_mean, float* running_var,
                                 float momentum, float* save_mean, float* save_invstd,
@@ -67,6 +59,19 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
   const int VC = C / EPV;
   const long long total = count * VC;
   const long long stride = (long long)gridDim.x * TPB;
+  // The conv epilogue's workgroup slots [slots][2C] are summed by every workgroup into LDS (fixed order; no separate
+  // fold launch — the host caps the grid so that this stays a small fraction of the loads).
+  extern __shared__ float fstat[];   // [2C]
+  const float* stats = gstats;
+  if (slots > 1) {
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) {
+      float a = gstats[i];
+      for (int k = 1; k < slots; ++k) a += gstats[(size_t)k * 2 * C + i];
+      fstat[i] = a;
+    }
+    __syncthreads();
+    stats = fstat;
+  }
   if (blockIdx.x == 0)
     bn_publish(stats, stat_count, C, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                num_batches_tracked);
@@ -202,22 +207,18 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
   if (stat_count != 0 && stat_count < count) return DAS_ERR_ARG;
   if (stats_slots < 0 || stats_slots > 64) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  // the conv epilogue's workgroup slots are folded into slot 0 first (one tiny launch, fixed order): the apply
-  // kernel's 2 M threads each derive their channels' mean / invstd from ONE [2C] array
-  if (stats_slots > 1) {
-    hipLaunchKernelGGL(bn_fold_slots_kernel, dim3((2 * C + TPB - 1) / TPB), dim3(TPB), 0, s, const_cast<float*>(stats),
-                       stats_slots, 2 * C);
-    DAS_CHECK_LAUNCH();
-  }
   const long long nstat = stat_count ? stat_count : count;
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
   // at least eight vectors per thread (the per-thread mean / invstd / gamma / beta set-up is ~60 instructions and 32
   // loads): the mid-size layers ran at 1.7...3 TB/s with one vector per thread (1024 channels at 32x52: 37 -> 22 us)
   const int vpt = std::max(1, (int)dastune::get(dastune::BN_VPT));
-  const int grid = std::max(1, std::min(grid_for(count * vc), (int)((count * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
+  int grid = std::max(1, std::min(grid_for(count * vc), (int)((count * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
+  const int nslots = stats_slots < 1 ? 1 : stats_slots;
+  if (nslots > 1) grid = std::min(grid, 2048);   // (every workgroup folds the slots first)
   const bool fixed = ((long long)grid * TPB) % vc == 0;
+  const size_t sm = nslots > 1 ? 2 * (size_t)C * sizeof(float) : 0;
 #define DAS_BN_APPLY(T, F)                                                                                          \
-  hipLaunchKernelGGL((bn_apply_kernel<T, F>), dim3(grid), dim3(TPB), 0, s, (const T*)x, (T*)y, count, C, stats, nstat, \
+  hipLaunchKernelGGL((bn_apply_kernel<T, F>), dim3(grid), dim3(TPB), sm, s, (const T*)x, (T*)y, count, C, stats, nslots, nstat, \
                      eps, gamma, beta, (const T*)residual, relu, running_mean, running_var, momentum, save_mean,      \
                      save_invstd, num_batches_tracked)
   if (dtype == DAS_BF16) {

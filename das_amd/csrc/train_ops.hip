@@ -661,6 +661,65 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
   }
 }
 
+// The apply pass alone, for a layer whose dZ (already masked) and per-channel sums came out of the epilogue of the
+// data-gradient conv that produced dZ (ConvP::bnb_*): dRaw = gamma*invstd*(dZ - s1/N - xhat*s2/N). `sums` is
+// [slots][2C] (the conv workgroups' slots): every workgroup folds it into LDS first (no separate fold launch; the
+// grid is capped so that this stays a small fraction of the loads). Workgroup 0 also feeds the parameter-gradient
+// accumulators (dbeta += s1, dgamma += s2).
+template <typename T, bool FIXED>
+__global__ void bn_bwd_apply_dz_kernel(const T* __restrict__ dz, const T* __restrict__ raw, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                       const float* __restrict__ sums, int slots, long long rows, int C,
+                                       T* __restrict__ draw, float* __restrict__ dgamma_acc,
+                                       float* __restrict__ dbeta_acc, float inv_n) {
+  constexpr int EPV = Elem<T>::EPV;
+  extern __shared__ float fsum[];   // [2C]
+  for (int i = threadIdx.x; i < 2 * C; i += TPB) {
+    float a = sums[i];
+    for (int k = 1; k < slots; ++k) a += sums[(size_t)k * 2 * C + i];
+    fsum[i] = a;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && dgamma_acc) {
+    for (int c = threadIdx.x; c < C; c += TPB) { dbeta_acc[c] += fsum[c]; dgamma_acc[c] += fsum[C + c]; }
+  }
+  const int VC = C / EPV;
+  const long long total = rows * VC;
+  const long long stride = (long long)gridDim.x * TPB;
+  float mu[EPV], k1[EPV], k2[EPV], k3[EPV];
+  auto load_consts = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const int c = c0 + j;
+      const float is = invstd[c];
+      mu[j] = mean[c]; k1[j] = gamma[c] * is; k2[j] = fsum[c] * inv_n; k3[j] = fsum[C + c] * inv_n * is;
+    }
+  };
+  auto finish = [&](long long i, const uint4& gv, const uint4& xv) {
+    float g[EPV], x[EPV], o[EPV];
+    Elem<T>::unpack(gv, g);
+    Elem<T>::unpack(xv, x);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) o[j] = k1[j] * (g[j] - k2[j] - (x[j] - mu[j]) * k3[j]);
+    *reinterpret_cast<uint4*>(draw + i * EPV) = Elem<T>::pack(o);
+  };
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (FIXED) {
+    if (i < total) load_consts((int)(i % VC) * EPV);
+    for (; i + stride < total; i += 2 * stride) {
+      const long long i1 = i + stride;
+      const uint4 g0 = *reinterpret_cast<const uint4*>(dz + i * EPV), g1 = *reinterpret_cast<const uint4*>(dz + i1 * EPV);
+      const uint4 x0 = *reinterpret_cast<const uint4*>(raw + i * EPV), x1 = *reinterpret_cast<const uint4*>(raw + i1 * EPV);
+      finish(i, g0, x0);
+      finish(i1, g1, x1);
+    }
+  }
+  for (; i < total; i += stride) {
+    if (!FIXED) load_consts((int)(i % VC) * EPV);
+    finish(i, *reinterpret_cast<const uint4*>(dz + i * EPV), *reinterpret_cast<const uint4*>(raw + i * EPV));
+  }
+}
+
 template <typename T, int MASK>
 void launch_bn_backward(const void* dy, const void* y, const void* raw, long long rows, int C, const float* mean,
                         const float* invstd, const float* gamma, const float* beta, void* draw, void* dres,
@@ -759,6 +818,7 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   p.relu_in = p.relu = 0; p.up_sh = 0;
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0; p.xbytes = 0;
+  p.bnb_raw = p.bnb_y = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;
   hipStream_t s = (hipStream_t)stream;
   // second pass: sum the splits of every tile into dW (see wgrad_reduce_kernel)
   auto reduce = [&](auto map, int tiles, int ntiles, long long splits) -> int {
@@ -879,6 +939,35 @@ extern "C" int das_bn_train_backward_phase(const void* dy, const void* y, const 
     if (mask == 0) DAS_BN_BWD(float, 0); else if (mask == 1) DAS_BN_BWD(float, 1); else DAS_BN_BWD(float, 2);
   }
 #undef DAS_BN_BWD
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_bn_backward_apply(const void* dz, const void* raw, int dtype, long long rows, int C, const float* mean,
+                                     const float* invstd, const float* gamma, const float* sums, int sums_slots,
+                                     void* draw, float* dgamma_acc, float* dbeta_acc, long long stat_rows, void* stream) {
+  if (!dz || !raw || !mean || !invstd || !gamma || !sums || !draw || rows <= 0 || C % 8 || C > 2048) return DAS_ERR_ARG;
+  if (sums_slots < 1 || sums_slots > 64 || stat_rows < rows) return DAS_ERR_ARG;
+  if ((dgamma_acc == nullptr) != (dbeta_acc == nullptr)) return DAS_ERR_ARG;
+  if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const float inv_n = 1.f / (float)stat_rows;
+  const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
+  const int vpt = std::max(1, (int)dastune::get(dastune::BN_VPT));
+  // (at most 2048 workgroups: each folds the [slots][2C] sums into LDS before it starts)
+  int grid = std::max(1, std::min(std::min(grid_for(rows * vc), 2048),
+                                  (int)((rows * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
+  const bool fixed = ((long long)grid * TPB) % vc == 0;
+  const size_t sm = 2 * (size_t)C * sizeof(float);
+#define DAS_BN_DZ(T, F)                                                                                                  \
+  hipLaunchKernelGGL((bn_bwd_apply_dz_kernel<T, F>), dim3(grid), dim3(TPB), sm, s, (const T*)dz, (const T*)raw, mean,   \
+                     invstd, gamma, sums, sums_slots, rows, C, (T*)draw, dgamma_acc, dbeta_acc, inv_n)
+  if (dtype == DAS_BF16) {
+    if (fixed) DAS_BN_DZ(bf16_t, true); else DAS_BN_DZ(bf16_t, false);
+  } else {
+    if (fixed) DAS_BN_DZ(float, true); else DAS_BN_DZ(float, false);
+  }
+#undef DAS_BN_DZ
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }

@@ -167,12 +167,40 @@ def pack_conv_weights(flat_src, fwd_dst, dgrad_dst, table_dev, n_entries, total_
                'das_pack_conv_weights')
 
 
-def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw, residual=None):
+def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw, residual=None, bn_bwd=None, stats=None):
     """dX of conv(x, w, stride, pad): a stride-1 conv of the (zero-upsampled) dY with flipped weights.
-    residual: another gradient of the same input, added in the epilogue (x that also feeds a skip path)."""
+    residual: another gradient of the same input, added in the epilogue (x that also feeds a skip path).
+    bn_bwd + stats: x is the output of a train-mode BatchNorm (+ReLU) — see `conv2d`."""
     if isinstance(dy, Ragged):
-        return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, residual=residual)
-    return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, in_up=stride, out_hw=in_hw, residual=residual)
+        return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, residual=residual, bn_bwd=bn_bwd, stats=stats)
+    return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, in_up=stride, out_hw=in_hw, residual=residual, bn_bwd=bn_bwd,
+                  stats=stats)
+
+
+class BnBwd:
+    """What a data-gradient conv needs to fold the BatchNorm-backward reduction of the layer that PRODUCED its output
+    tensor into its epilogue (DasConvDesc.bnb_*): raw = that layer's pre-norm tensor, y = its post-ReLU output (only
+    when a residual entered before the ReLU; None = recompute the mask from raw), per-channel mean / invstd / gamma /
+    beta, relu flag."""
+    __slots__ = ('raw', 'y', 'mean', 'invstd', 'gamma', 'beta', 'relu')
+
+    def __init__(self, raw, y, mean, invstd, gamma, beta, relu):
+        self.raw, self.y, self.mean, self.invstd, self.gamma, self.beta, self.relu = raw, y, mean, invstd, gamma, beta, relu
+
+
+def bn_backward_apply(dz, raw, mean, invstd, gamma, sums, dgamma_acc=None, dbeta_acc=None, stat_rows=0):
+    """BatchNorm backward's apply pass alone (das_bn_backward_apply): dz already masked, sums f32[slots * 2C] from the
+    producing data-gradient conv. Returns d_raw."""
+    _need_gpu(dz, raw, sums)
+    assert dz.is_contiguous() and raw.is_contiguous() and dz.shape == raw.shape and dz.dtype == raw.dtype
+    Cc = raw.shape[-1]
+    rows = raw.numel() // Cc
+    draw = torch.empty_like(raw)
+    _lib.check(_lib.load().das_bn_backward_apply(_ptr(dz), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean), _ptr(invstd),
+                                                 _ptr(gamma), _ptr(sums), sums.numel() // (2 * Cc), _ptr(draw),
+                                                 _ptr(dgamma_acc), _ptr(dbeta_acc), stat_rows or rows, _stream()),
+               'das_bn_backward_apply')
+    return draw
 
 
 def conv2d_wgrad(x, dy, KH, KW, stride, pad, out=None, accumulate=False):
@@ -274,9 +302,11 @@ def bn_train_backward_sync(dy, y, raw, mean, invstd, gamma, relu, want_dres, bet
 
 
 def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, relu_in=False,
-           out_dtype=None, stats=None, out=None, in_up=1, out_hw=None):
+           out_dtype=None, stats=None, out=None, in_up=1, out_hw=None, bn_bwd=None):
     """x (B,H,W,Cin[view]) or Ragged; w packed (Cout,KH,KW,Cin). Returns y (B,Ho,Wo,Cout) / Ragged.
-    in_up / out_hw: data-gradient mode (x zero-upsampled by in_up, explicit output size)."""
+    in_up / out_hw: data-gradient mode (x zero-upsampled by in_up, explicit output size).
+    bn_bwd (BnBwd) + stats: the output (conv + residual) is the gradient wrt a BatchNorm(+ReLU) layer's output; the
+    kernel stores dZ = masked gradient and adds [sum dZ | sum dZ * xhat] into stats (slots as for the forward)."""
     _need_gpu(x, w)
     lib = _lib.load()
     ragged = isinstance(x, Ragged)
@@ -315,6 +345,16 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         residual=rd.data_ptr() if rd is not None else None, res_pix_stride=_ps(residual) if rd is not None else 0,
         stats=stats.data_ptr() if stats is not None else None, num_levels=len(x.sizes) if ragged else 0,
         in_up=in_up, stats_slots=stats.numel() // (2 * Cout) if stats is not None else 0)
+    if bn_bwd is not None:
+        b = bn_bwd
+        assert stats is not None and not relu and scale is None and shift is None and out_dtype == xd.dtype
+        assert b.raw.is_contiguous() and b.raw.shape[-1] == Cout and b.raw.numel() == rows * Cout and b.raw.dtype == out_dtype
+        assert b.y is None or (b.y.is_contiguous() and b.y.shape == b.raw.shape and b.y.dtype == out_dtype)
+        d.bnb_raw, d.bnb_y = b.raw.data_ptr(), (b.y.data_ptr() if b.y is not None else None)
+        d.bnb_mean, d.bnb_invstd = b.mean.data_ptr(), b.invstd.data_ptr()
+        d.bnb_gamma, d.bnb_beta = b.gamma.data_ptr(), b.beta.data_ptr()
+        d.bnb_relu, d.bnb_pix_stride = int(b.relu), Cout
+        _need_gpu(b.raw, b.y, b.mean, b.invstd, b.gamma, b.beta)
     if ragged:
         for l, (h, w_) in enumerate(x.sizes):
             d.lvl_H[l], d.lvl_W[l] = h, w_

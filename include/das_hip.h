@@ -95,6 +95,21 @@ typedef struct {
    * workgroups adding into ONE [2*Cout] array serialise on the same words (~13 ns each: +44 us on the
    * 64-channel convs of the 128 x 208 stage); das_bn_train_apply sums the slots. */
   int stats_slots;
+  /* Fused BatchNorm-backward reduction, for data-gradient launches (bnb_raw != NULL switches it on; needs `stats`,
+   * out_dtype == dtype, no relu). The value about to be stored, g = conv + residual, is then the gradient with respect
+   * to the OUTPUT of a train-mode BatchNorm (+ReLU) layer (mspn_mmpose.py:126-157 under autograd) whose pre-norm
+   * tensor is bnb_raw (same rows / channels as y, pixel stride bnb_pix_stride). The kernel stores dZ = g * mask
+   * (bnb_relu: mask = bnb_y > 0 if bnb_y is given — required when a residual entered before that ReLU — else
+   * bn_affine(raw) > 0 from bnb_mean / invstd / gamma / beta; no bnb_relu: mask = 1) and adds
+   * [sum dZ | sum dZ * (raw - mean) * invstd] per channel into stats[slot][2*Cout]: the separate reduction pass
+   * of das_bn_train_backward over (dY, raw) is not needed, das_bn_backward_apply finishes the layer. */
+  const void* bnb_raw;
+  const void* bnb_y;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  int bnb_relu, bnb_pix_stride;
 } DasConvDesc;
 int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream);
 
@@ -134,6 +149,13 @@ int das_bn_train_backward_phase(const void* dy, const void* y, const void* raw, 
                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 int relu, void* draw, void* dres, float* sums, int sums_prezeroed, float* dgamma_acc,
                                 float* dbeta_acc, int phase, long long stat_rows, void* stream);
+/* The apply pass alone: dZ is already masked and the per-channel sums [sum dZ | sum dZ*xhat] were accumulated into
+ * sums f32[sums_slots][2C] by the data-gradient conv that produced dZ (DasConvDesc.bnb_*), so the layer needs no
+ * reduction pass: draw = gamma*invstd*(dZ - s1/N - xhat*s2/N) with N = stat_rows; dgamma_acc / dbeta_acc (both or
+ * neither) receive s2 / s1. Same autograd semantics as das_bn_train_backward (mspn_mmpose.py:126-157 backward). */
+int das_bn_backward_apply(const void* dz, const void* raw, int dtype, long long rows, int C, const float* mean,
+                          const float* invstd, const float* gamma, const float* sums, int sums_slots, void* draw,
+                          float* dgamma_acc, float* dbeta_acc, long long stat_rows, void* stream);
 
 /* All conv weights of the network packed in one launch, once per optimizer step. flat_src: the optimizer's
  * f32 master buffer, conv weights stored as (Cout,KH,KW,Cin) (the forward operand layout). For every table

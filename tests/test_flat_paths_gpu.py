@@ -140,19 +140,20 @@ def test_flat_optimizer_gradients_equal_autograd_gradients():
 
 def test_wgrad_side_stream_equals_main_stream():
     """Weight gradients launched on the side stream (das_amd/autograd.py `_on_side`) land in the flat gradient exactly
-    as when everything runs on one stream; several iterations so that the caching allocator recycles blocks."""
+    as when everything runs on one stream. f32 compute (a bf16 net amplifies the f32-atomic reordering of the statistics
+    into percent-level gradient differences between ANY two runs, which would hide a race); a second single-stream run
+    gives the run-to-run floor. Later iterations only stress the caching allocator's block reuse."""
     import das_amd
     from das_amd import autograd as ag
     from das_amd.datasets import SyntheticPoseDataset, collate
     from das_amd.optim import FlatSGD, train_iteration
-    from test_model_gpu import tiny_detector_cfg
     res = {}
-    for side in (False, True):
+    for tag, side in (('main', False), ('main2', False), ('side', True)):
         ag.WGRAD_SIDE_STREAM = side
         try:
             torch.manual_seed(0)
             cfg = tiny_detector_cfg()
-            cfg['backbone'].update(num_stages=2, compute_dtype='bf16')
+            cfg['backbone'].update(num_stages=2, compute_dtype='f32')
             model = das_amd.build_model(cfg)
             model.init_weights()
             model.to('cuda').train()
@@ -161,15 +162,15 @@ def test_wgrad_side_stream_equals_main_stream():
             opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, max_grad_norm=35.0)
             out = train_iteration(model, opt, data, 2e-3)
             torch.cuda.synchronize()
-            res[side] = (opt.flat_g.clone(), opt.flat_p.clone(), out['log_vars']['loss'])
-            for _ in range(3):     # (later iterations: replicas drift apart chaotically in bf16; only sanity here)
+            res[tag] = (opt.flat_g.clone(), out['log_vars']['loss'])
+            for _ in range(3):
                 out = train_iteration(model, opt, data, 2e-3)
             assert bool(torch.isfinite(opt.flat_g).all()) and np.isfinite(out['log_vars']['loss'])
         finally:
             ag.WGRAD_SIDE_STREAM = True
-    g0, p0, l0 = res[False]
-    g1, p1, l1 = res[True]
-    assert abs(l0 - l1) <= 1e-3 * abs(l0)
+    g0, l0 = res['main']
     scale = float(g0.abs().max())
-    assert float((g0 - g1).abs().max()) <= 2e-3 * scale      # (f32 atomics of the tiny layers' split reduction reorder)
-    assert float((p0 - p1).abs().max()) <= 1e-4 * float(p0.abs().max())
+    floor = float((g0 - res['main2'][0]).abs().max()) / scale
+    diff = float((g0 - res['side'][0]).abs().max()) / scale
+    assert abs(l0 - res['side'][1]) <= 1e-4 * abs(l0)
+    assert diff <= max(3 * floor, 1e-4), (diff, floor)

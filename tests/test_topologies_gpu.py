@@ -86,7 +86,7 @@ def test_full_width_four_stage_train_step_properties():
     opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0,
                   max_grad_norm=35.0)
     losses = []
-    for it in range(8):
+    for it in range(40):
         out = train_iteration(model, opt, data, 2e-3)
         assert all(np.isfinite(v) for v in out['log_vars'].values()), out['log_vars']
         losses.append(out['log_vars']['loss'])
@@ -97,8 +97,8 @@ def test_full_width_four_stage_train_step_properties():
             allowed = ('multi_stage_mspn.3.upsample.up4', 'flow2d', 'flow3d', 'conv_reg_prevs.0.', 'conv_regs.0.')
             odd = [n for n in dead if not any(a in n for a in allowed) and not n.startswith('bbox_head.scales')]
             assert not odd, odd[:12]
-    # (B = 2 with train-mode BN and momentum 0.9 is noisy step to step: the trend is what is checked)
-    assert min(losses[3:]) < losses[0] and np.mean(losses[4:]) < np.mean(losses[:2]) + 1.0, losses
+    # (B = 2 with train-mode BN and momentum 0.9 is noisy step to step: the trend over 40 steps is what is checked)
+    assert np.mean(losses[-8:]) < np.mean(losses[:8]), losses
     assert len(model.backbone.multi_stage_mspn) == 4
 
 
