@@ -68,6 +68,24 @@ __device__ __forceinline__ float bn_affine(float x, float mean, float invstd, fl
   return __fmaf_rn((x - mean) * invstd, gamma, beta);
 }
 
+// Sum the [slots][n] per-workgroup slot partials into dst[n] (LDS), fixed order. All 16 loads of a value are in flight
+// together: a serial `a += src[k * n + i]` chain costs one L2 round trip per slot at the head of every workgroup
+// (16 us per launch measured on the BatchNorm apply passes). slots <= 64; ends with a workgroup barrier.
+__device__ __forceinline__ void fold_slots_to_lds(const float* __restrict__ src, int slots, int n, float* dst) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float a = 0.f;
+    for (int k0 = 0; k0 < slots; k0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = (k0 + k < slots) ? src[(size_t)(k0 + k) * n + i] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a += v[k];
+    }
+    dst[i] = a;
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -64,12 +64,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
   extern __shared__ float fstat[];   // [2C]
   const float* stats = gstats;
   if (slots > 1) {
-    for (int i = threadIdx.x; i < 2 * C; i += TPB) {
-      float a = gstats[i];
-      for (int k = 1; k < slots; ++k) a += gstats[(size_t)k * 2 * C + i];
-      fstat[i] = a;
-    }
-    __syncthreads();
+    fold_slots_to_lds(gstats, slots, 2 * C, fstat);
     stats = fstat;
   }
   if (blockIdx.x == 0)

@@ -674,12 +674,7 @@ __global__ void bn_bwd_apply_dz_kernel(const T* __restrict__ dz, const T* __rest
                                        float* __restrict__ dbeta_acc, float inv_n) {
   constexpr int EPV = Elem<T>::EPV;
   extern __shared__ float fsum[];   // [2C]
-  for (int i = threadIdx.x; i < 2 * C; i += TPB) {
-    float a = sums[i];
-    for (int k = 1; k < slots; ++k) a += sums[(size_t)k * 2 * C + i];
-    fsum[i] = a;
-  }
-  __syncthreads();
+  fold_slots_to_lds(sums, slots, 2 * C, fsum);
   if (blockIdx.x == 0 && dgamma_acc) {
     for (int c = threadIdx.x; c < C; c += TPB) { dbeta_acc[c] += fsum[c]; dgamma_acc[c] += fsum[C + c]; }
   }
