@@ -404,6 +404,7 @@ def main():
     ap.add_argument('--cpu-baseline-only', action='store_true', help='run only the CPU leg and print it')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-wgrad-stream', action='store_true', help='A/B: weight gradients on the main stream')
+    ap.add_argument('--wgrad-streams', type=int, default=None, help='A/B: number of weight-gradient side streams')
     ap.add_argument('--no-fused-bn', action='store_true',
                     help='A/B: one autograd node per conv+BN unit (separate BatchNorm-backward reduction passes)')
     ap.add_argument('--share-gpu', action='store_true',
@@ -448,6 +449,8 @@ def main():
     from das_amd.datasets import SyntheticPoseDataset, collate
     if args.no_wgrad_stream:
         ag.WGRAD_SIDE_STREAM = False
+    if args.wgrad_streams:
+        ag.set_wgrad_streams(args.wgrad_streams)
     if args.no_fused_bn:
         backbones.FUSED_LAYER_BACKWARD = False
     model = build_model(dev, seed=0, dtype=args.dtype, num_stages=stages, train=train)

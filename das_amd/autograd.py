@@ -33,33 +33,50 @@ def _dw_to_oihw(dw, weight):
 # and the under-filled mid-size data-gradient launches of the main stream. The main stream joins the side stream when
 # the backward pass ends (autograd engine callback), before the gradient all-reduce / optimizer step.
 WGRAD_SIDE_STREAM = True   # (bench.py --no-wgrad-stream and the tests flip it for A/B runs)
-_side = {}           # device index -> [stream, join callback queued for the running backward?]
+# Several weight gradients in flight at once, each on its own stream with a grid of 1 / WGRAD_STREAMS of the chip: the
+# pixel reduction of one op is then split WGRAD_STREAMS times less, and the [split][tile] f32 workspace every split
+# costs (a 256 x 256 tile = 256 KiB written and read back per workgroup: half of an average op's time when 256
+# workgroups share one small Cout x K result) shrinks with it. set_wgrad_streams() sizes the kernels' grids to match.
+WGRAD_STREAMS = 1
+_side = {}           # device index -> [streams, next stream, join callback queued for the running backward?]
 
 
-def _side_stream(dev):
+def set_wgrad_streams(n):
+    """n side streams, weight-gradient grids of 1/n of the chip (das_tuning_set wgrad.blocks / wgrad.pp_blocks)."""
+    global WGRAD_STREAMS
+    from . import _lib
+    lib = _lib.load()
+    WGRAD_STREAMS = max(1, int(n))
+    _lib.check(lib.das_tuning_set(b'wgrad.pp_blocks', 256 // WGRAD_STREAMS), 'das_tuning_set')
+    _lib.check(lib.das_tuning_set(b'wgrad.blocks', 0 if WGRAD_STREAMS == 1 else 768 // WGRAD_STREAMS), 'das_tuning_set')
+    _side.clear()
+
+
+def _side_streams(dev):
     ent = _side.get(dev.index)
-    if ent is None:
-        ent = _side[dev.index] = [torch.cuda.Stream(device=dev), False]
+    if ent is None or len(ent[0]) != WGRAD_STREAMS:
+        ent = _side[dev.index] = [[torch.cuda.Stream(device=dev) for _ in range(WGRAD_STREAMS)], 0, False]
     return ent
 
 
 def _join_side(dev_index):
     ent = _side[dev_index]
-    ent[1] = False
-    torch.cuda.current_stream(dev_index).wait_stream(ent[0])
+    ent[2] = False
+    cur = torch.cuda.current_stream(dev_index)
+    for st in ent[0]:
+        cur.wait_stream(st)
 
 
-def wgrad_stream():
-    """The side stream of the current device if weight gradients are in flight on it (the data-parallel
-    all-reduce waits on it too), else None."""
+def wgrad_streams():
+    """The side streams of the current device (the data-parallel all-reduce waits on them too)."""
     ent = _side.get(torch.cuda.current_device())
-    return ent[0] if ent is not None else None
+    return ent[0] if ent is not None else []
 
 
 class _on_side:
-    """Context: run the enclosed launches on the side stream, after everything enqueued on the current stream so far.
-    The tensors named in `keep` are read there: the caching allocator must not hand their memory to a later main-stream
-    allocation before the side stream is done with them."""
+    """Context: run the enclosed launches on the next side stream, after everything enqueued on the current stream so
+    far. The tensors named in `keep` are read there: the caching allocator must not hand their memory to a later
+    main-stream allocation before the side stream is done with them."""
 
     def __init__(self, *keep):
         self.keep = [t for t in keep if t is not None]
@@ -69,17 +86,18 @@ class _on_side:
         if not WGRAD_SIDE_STREAM or not self.keep or not self.keep[0].is_cuda:
             return self
         dev = self.keep[0].device
-        ent = _side_stream(dev)
-        side = ent[0]
+        ent = _side_streams(dev)
+        side = ent[0][ent[1]]
+        ent[1] = (ent[1] + 1) % len(ent[0])
         side.wait_stream(torch.cuda.current_stream(dev))
         for t in self.keep:
             t.record_stream(side)
-        if not ent[1]:
+        if not ent[2]:
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(lambda i=dev.index: _join_side(i))
-                ent[1] = True
+                ent[2] = True
             except RuntimeError:      # not inside a backward pass: join right after the launch instead
-                ent[1] = None
+                ent[2] = None
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         self.ent, self.dev = ent, dev
@@ -88,7 +106,7 @@ class _on_side:
     def __exit__(self, *exc):
         if self.ctx is not None:
             self.ctx.__exit__(*exc)
-            if self.ent[1] is None:
+            if self.ent[2] is None:
                 _join_side(self.dev.index)
         return False
 

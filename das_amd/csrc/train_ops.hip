@@ -840,7 +840,7 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
       p.xbytes = (unsigned)xb;
       const int ntiles = (p.K + 255) / 256, tiles = ((d->Cout + 255) / 256) * ntiles;
       const long long total_steps = (M + 31) / 32;
-      long long splits = std::max<long long>(1, 256 / tiles);
+      long long splits = std::max<long long>(1, std::max<long long>(1, dastune::get(dastune::WGRAD_PP_BLOCKS)) / tiles);
       long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
       splits = (total_steps + spb - 1) / spb;
       p.y = (char*)wgrad_workspace(s, (size_t)splits * tiles * AccMap256::SLOTS * 16);

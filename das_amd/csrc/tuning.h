@@ -16,7 +16,9 @@ enum Key {
   CONV_GLDS8_MINBLOCKS,  // conv_glds8_kernel (256 x 256 tile, K-steps of 64, 8 phases); 0 disables the kernel
   WGRAD_PP_MINK,         // conv_wgrad_pp_kernel for K >= this (and Cout >= 256); 0 disables the kernel
   WGRAD_BKM,             // pixel rows per step of conv_wgrad_kernel<bf16>: 32 or 64
-  WGRAD_BLOCKS,          // target grid of conv_wgrad_kernel; 0 = by shape
+  WGRAD_BLOCKS,          // target grid of conv_wgrad_kernel; 0 = by shape (768 / 1024: one resident wave of workgroups)
+  WGRAD_PP_BLOCKS,       // target grid of conv_wgrad_pp_kernel (256 = one workgroup per CU); lower it when several
+                         // weight gradients run side by side on different streams
   BN_REDUCE_BLOCKS,      // grid / block size of bn_bwd_reduce_kernel
   BN_REDUCE_THREADS,
   BN_VPT,                // 16-byte vectors per thread of the BatchNorm apply passes

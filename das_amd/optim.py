@@ -208,9 +208,8 @@ class FlatSGD:
         s, e = self.buckets[b]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
-            from .autograd import wgrad_stream
-            side = wgrad_stream()
-            if side is not None:     # weight gradients of this bucket may still be running on the side stream
+            from .autograd import wgrad_streams
+            for side in wgrad_streams():   # weight gradients of this bucket may still be running on a side stream
                 self.comm_stream.wait_stream(side)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(self.flat_g[s:e])
