@@ -218,11 +218,12 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
     torch.cuda.synchronize()
     ag.WGRAD_SIDE_STREAM = side_was
     fam = {}
-    for tag, flops, e0, e1, _shape in ops.PROFILE:
+    for ent in ops.PROFILE:
+        tag, flops, e0, e1 = ent[:4]
         f = fam.setdefault(tag, [0.0, 0.0, 0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3
-        f[2] += 1
+        f[2] += ent[5] if len(ent) > 5 else 1     # (a batched weight-gradient launch counts its ops)
     ops.PROFILE = None
     if not fam:
         return None
@@ -405,6 +406,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-wgrad-stream', action='store_true', help='A/B: weight gradients on the main stream')
     ap.add_argument('--wgrad-streams', type=int, default=None, help='A/B: number of weight-gradient side streams')
+    ap.add_argument('--wgrad-batch', type=int, default=None, help='A/B: weight gradients per batched launch (1 = off)')
     ap.add_argument('--no-fused-bn', action='store_true',
                     help='A/B: one autograd node per conv+BN unit (separate BatchNorm-backward reduction passes)')
     ap.add_argument('--share-gpu', action='store_true',
@@ -451,6 +453,8 @@ def main():
         ag.WGRAD_SIDE_STREAM = False
     if args.wgrad_streams:
         ag.set_wgrad_streams(args.wgrad_streams)
+    if args.wgrad_batch:
+        ag.WGRAD_BATCH = args.wgrad_batch
     if args.no_fused_bn:
         backbones.FUSED_LAYER_BACKWARD = False
     model = build_model(dev, seed=0, dtype=args.dtype, num_stages=stages, train=train)

@@ -111,15 +111,56 @@ class _on_side:
         return False
 
 
+# ---- deferred, batched weight gradients ----------------------------------------------------------------
+# With the flat optimizer a weight gradient only adds into the flat gradient buffer, so backward queues it and hands
+# WGRAD_BATCH of them at a time to das_conv2d_wgrad_batch: ops of one kernel class then share ONE launch, each on a share
+# of the grid (less split workspace per op — see include/das_hip.h). The queue is flushed when the backward pass ends.
+WGRAD_BATCH = 6      # 1 = launch every weight gradient on its own, as it arises
+_pending = []        # [(x, dy, k, k, stride, pad, out, slot)]
+_flush_queued = [False]
+
+
+def flush_wgrads():
+    if not _pending:
+        return
+    items, _pending[:] = list(_pending), []
+    keep = []
+    for it in items:
+        keep += [_d(it[0]), _d(it[1])]
+    with _on_side(*keep):
+        ops.conv2d_wgrad_batch([it[:7] for it in items])
+    for it in items:
+        it[7].fired()
+
+
+def _end_of_backward():
+    _flush_queued[0] = False
+    flush_wgrads()
+
+
 def _wgrad(x, dy, weight, k, s, p):
     """Weight gradient of conv(x, weight). With the flat optimizer the kernel adds straight into the flat
     gradient buffer (same (Cout,KH,KW,Cin) layout) and autograd gets None; otherwise an OIHW view is returned."""
     sl = getattr(weight, '_das_slot', None)
     cin, cout = _d(x).shape[-1], _d(dy).shape[-1]
     if sl is not None and sl.direct(cin, cout) and sl.cl_shape[1] == k:
-        with _on_side(_d(x), _d(dy)):
-            ops.conv2d_wgrad(x, dy, k, k, s, p, out=sl.grad_cl, accumulate=True)
-        sl.fired()
+        if WGRAD_BATCH <= 1:
+            with _on_side(_d(x), _d(dy)):
+                ops.conv2d_wgrad(x, dy, k, k, s, p, out=sl.grad_cl, accumulate=True)
+            sl.fired()
+            return None
+        if any(it[6].data_ptr() == sl.grad_cl.data_ptr() for it in _pending):
+            flush_wgrads()      # (a weight used twice: its two gradients must not meet in one launch)
+        _pending.append((x, dy, k, k, s, p, sl.grad_cl, sl))
+        if not _flush_queued[0]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+                _flush_queued[0] = True
+            except RuntimeError:
+                flush_wgrads()          # not inside a backward pass
+                return None
+        if len(_pending) >= WGRAD_BATCH:
+            flush_wgrads()
         return None
     return _dw_to_oihw(ops.conv2d_wgrad(x, dy, k, k, s, p), weight)
 
@@ -554,6 +595,7 @@ class DcnGemmFn(Function):
         cpad = col.shape[-1] // 9
         if sl is not None and sl.direct(cpad, dy.shape[-1]):
             # (O,3,3,C) channels-last storage == the (O,1,1,9C) GEMM weight: add straight into the flat gradient
+            flush_wgrads()
             with _on_side(col, dy):
                 ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0, out=sl.grad_cl, accumulate=True)
             sl.fired()

@@ -148,43 +148,114 @@ __device__ __forceinline__ void store_partial_tile(float* ws, int split, int til
       if (MAP::wave_n(wave) + b * 16 < n_left) dst[(a * 4 + b) * 64] = acc[a][b];
   }
 }
+// ---- several weight gradients in ONE launch ----
+// A weight gradient has a small result (Cout x K) and a huge reduction (the pixels), so filling 256 CUs means splitting
+// the pixels, and every split costs a round trip of a partial tile through the workspace: with 256 workgroups on a
+// 1024 x 256 result that round trip moves twice the bytes of the operands. Measured on cold operands
+// (tools/dev/wgrad_blocks_bench.py): a quarter of the grid needs only 1.2-2.2x the time of the full grid. So the
+// launcher takes up to WG_MAXOPS ops of one kernel class at a time — backward defers its weight gradients, which feed
+// nothing but the optimizer — and gives each op a share of the grid in proportion to its work: the ops run side by side
+// inside one launch, each split ~n times less. (Streams do not give this: ops issued at backward's pace rarely meet.)
+constexpr int WG_MAXOPS = 8;
+struct WgradOp {
+  const char* x;
+  const char* dy;
+  float* ws;            // this op's region of the partial-tile workspace [split][tile][slot]
+  int H, W, Cin, xps, Ho, Wo, Cout, rps, KH, KW, stride, pad, M, K, HoWo;
+  unsigned xbytes;
+  int nlev, B;
+  int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];
+  int tiles, spb;       // (Cout, K) tiles; pixel steps per workgroup
+  int blk0, nblk;       // first workgroup (a multiple of 8: keeps block % 8 == XCD for xcd_remap) and workgroup count
+};
+struct WgradGroup {
+  int n;
+  WgradOp op[WG_MAXOPS];
+};
+// op of this workgroup (static indices only: a dynamically indexed by-value argument is copied to scratch)
+__device__ __forceinline__ bool wgrad_pick(const WgradGroup& g, int bid, ConvP& p, int& tiles, int& spb, int& local, int& nblk) {
+  int k = -1;
+#pragma unroll
+  for (int i = 0; i < WG_MAXOPS; ++i)
+    if (i < g.n && bid >= g.op[i].blk0 && bid < g.op[i].blk0 + g.op[i].nblk) k = i;
+  if (k < 0) return false;   // padding workgroup between two ops
+  WgradOp o = g.op[0];
+#pragma unroll
+  for (int i = 1; i < WG_MAXOPS; ++i)
+    if (k == i) o = g.op[i];
+  p.x = o.x; p.res = o.dy; p.y = reinterpret_cast<char*>(o.ws); p.w = nullptr;
+  p.scale = p.shift = nullptr; p.stats = nullptr; p.stat_slots = 1;
+  p.H = o.H; p.W = o.W; p.Cin = o.Cin; p.xps = o.xps; p.Ho = o.Ho; p.Wo = o.Wo; p.Cout = o.Cout; p.yps = 0;
+  p.KH = o.KH; p.KW = o.KW; p.stride = o.stride; p.pad = o.pad; p.relu_in = p.relu = 0; p.rps = o.rps; p.up_sh = 0;
+  p.M = o.M; p.K = o.K; p.HoWo = o.HoWo; p.ntiles = p.nblocks = 0; p.xbytes = o.xbytes; p.nlev = o.nlev; p.B = o.B;
+#pragma unroll
+  for (int l = 0; l < MAXLV; ++l) { p.lvH[l] = o.lvH[l]; p.lvW[l] = o.lvW[l]; p.lvStart[l] = o.lvStart[l]; }
+  p.bnb_raw = p.bnb_y = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;
+  tiles = o.tiles; spb = o.spb; local = bid - o.blk0; nblk = o.nblk;
+  return true;
+}
+struct WgradRedOp {
+  const float* ws;
+  float* dw;
+  int tiles, ntiles, splits, Cout, K, accumulate;
+  int groups;           // reduce groups (> 1: atomics into a zeroed / accumulating dW)
+  int blk0, nblk;       // nblk = tiles * (SLOTS / 256) * groups
+};
+struct WgradRedGroup {
+  int n;
+  WgradRedOp op[WG_MAXOPS];
+};
+
 // grid (tiles * SLOTS / 256, groups): every thread owns one float4 slot of one tile and sums it over the splits
 // of its group; one group writes (or adds to) dW directly, several groups (tiny layers: few tiles, hundreds of
 // splits) add atomically into a zeroed / accumulating dW.
 template <typename MAP>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                           int tiles, int ntiles, int splits, int Cout, int K,
-                                                           int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradRedGroup g) {
   constexpr int BPT = MAP::SLOTS / 256;
-  const int tile = blockIdx.x / BPT, slot = (blockIdx.x % BPT) * 256 + threadIdx.x;
+  int k = -1;
+#pragma unroll
+  for (int i = 0; i < WG_MAXOPS; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.op[i].blk0 && (int)blockIdx.x < g.op[i].blk0 + g.op[i].nblk) k = i;
+  if (k < 0) return;
+  WgradRedOp o = g.op[0];
+#pragma unroll
+  for (int i = 1; i < WG_MAXOPS; ++i)
+    if (k == i) o = g.op[i];
+  const int local = blockIdx.x - o.blk0;
+  const int per_group = o.tiles * BPT;
+  const int grp = local / per_group, bx = local % per_group;
+  const int tile = bx / BPT, slot = (bx % BPT) * 256 + threadIdx.x;
   const int lane = slot & 63, b = (slot >> 6) & 3, a = (slot >> 8) % MAP::TA, wave = slot / (MAP::TA * 256);
-  const int o0 = (tile / ntiles) * MAP::TILE + MAP::wave_o(wave) + a * 16 + (lane >> 4) * 4;
-  const int n = (tile % ntiles) * MAP::TILE + MAP::wave_n(wave) + b * 16 + (lane & 15);
-  if ((tile / ntiles) * MAP::TILE + MAP::wave_o(wave) + a * 16 >= Cout || n >= K) return;
-  const int per = (splits + gridDim.y - 1) / gridDim.y;
-  const int s0 = blockIdx.y * per, s1 = min(splits, s0 + per);
-  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(ws) + (size_t)tile * MAP::SLOTS + slot;
-  const size_t stride = (size_t)tiles * MAP::SLOTS;
+  const int o0 = (tile / o.ntiles) * MAP::TILE + MAP::wave_o(wave) + a * 16 + (lane >> 4) * 4;
+  const int n = (tile % o.ntiles) * MAP::TILE + MAP::wave_n(wave) + b * 16 + (lane & 15);
+  if ((tile / o.ntiles) * MAP::TILE + MAP::wave_o(wave) + a * 16 >= o.Cout || n >= o.K) return;
+  const int per = (o.splits + o.groups - 1) / o.groups;
+  const int s0 = grp * per, s1 = min(o.splits, s0 + per);
+  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(o.ws) + (size_t)tile * MAP::SLOTS + slot;
+  const size_t stride = (size_t)o.tiles * MAP::SLOTS;
   f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
-  int s = s0;
-  for (; s + 4 <= s1; s += 4) {
-    const f32x4_t v0 = src[(size_t)s * stride], v1 = src[(size_t)(s + 1) * stride];
-    const f32x4_t v2 = src[(size_t)(s + 2) * stride], v3 = src[(size_t)(s + 3) * stride];
+  int sp = s0;
+  for (; sp + 4 <= s1; sp += 4) {
+    const f32x4_t v0 = src[(size_t)sp * stride], v1 = src[(size_t)(sp + 1) * stride];
+    const f32x4_t v2 = src[(size_t)(sp + 2) * stride], v3 = src[(size_t)(sp + 3) * stride];
     sum += (v0 + v1) + (v2 + v3);
   }
-  for (; s < s1; ++s) sum += src[(size_t)s * stride];
+  for (; sp < s1; ++sp) sum += src[(size_t)sp * stride];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (o0 + j >= Cout) break;
-    float* d = dw + (size_t)(o0 + j) * K + n;
-    if (gridDim.y > 1) atomicAdd(d, sum[j]);
-    else *d = accumulate ? *d + sum[j] : sum[j];
+    if (o0 + j >= o.Cout) break;
+    float* d = o.dw + (size_t)(o0 + j) * o.K + n;
+    if (o.groups > 1) atomicAdd(d, sum[j]);
+    else *d = o.accumulate ? *d + sum[j] : sum[j];
   }
 }
 
 // p.x = forward input X, p.res = dY (pixel stride p.rps), p.y = the workspace the partial tiles are stored to.
 template <typename T, int BKM>   // BKM = pixel rows per step
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_block) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGroup grp_) {
+  ConvP p;
+  int tiles, steps_per_block, lbid, nblk;
+  if (!wgrad_pick(grp_, blockIdx.x, p, tiles, steps_per_block, lbid, nblk)) return;
   constexpr int EPV = Elem<T>::EPV;
   constexpr int ROWB = WG<T>::ROWB, SLOTS = ROWB / 16;
   constexpr int TILE = BKM * ROWB;             // bytes per operand tile
@@ -197,8 +268,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_
   const int ntiles = (p.K + 127) / 128;
   // XCD-aware order: all (Cout, K) tiles of one pixel chunk get consecutive logical ids, i.e. run on the same
   // XCD at the same time, so the chunk's dY / X rows are fetched into ONE L2 instead of eight
-  const int tiles = gridDim.x;
-  const int logical = xcd_remap(blockIdx.x + blockIdx.y * tiles, tiles * gridDim.y);
+  const int logical = xcd_remap(lbid, nblk);
   const int tile = logical % tiles, chunk = logical / tiles;
   const int o0 = (tile / ntiles) * 128, n0 = (tile % ntiles) * 128;
   const int wave_o0 = (wave >> 1) * 64, wave_n0 = (wave & 1) * 64;
@@ -339,7 +409,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvP p, int steps_per_
 // the row pointers, transposing LDS reads of step s into registers) and M (32 MFMAs); waves 4-7 run one
 // interval behind waves 0-3 and wave w / w+4 share a SIMD, so the address walk and the LDS reads of one group
 // hide behind the other group's MFMAs (same scheme as conv_glds4_kernel<PP>).
-__global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(ConvP p, int steps_per_block) {
+__global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WgradGroup grp_) {
+  ConvP p;
+  int tiles, steps_per_block, lbid, nblk;
+  if (!wgrad_pick(grp_, blockIdx.x, p, tiles, steps_per_block, lbid, nblk)) return;
   using T = bf16_t;
   constexpr int EPV = 8, ROWB = 256, SLOTS = 16, BKM = 32;
   constexpr int SUB = BKM * ROWB;                // 8 KiB: 32 rows x 128 channels
@@ -352,8 +425,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(ConvP p, int steps_p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
   const int ntiles = (p.K + 255) / 256;
-  const int tiles = gridDim.x;
-  const int logical = xcd_remap(blockIdx.x + blockIdx.y * tiles, tiles * gridDim.y);
+  const int logical = xcd_remap(lbid, nblk);
   const int tile = logical % tiles, chunk = logical / tiles;
   const int o0 = (tile / ntiles) * 256, n0 = (tile % ntiles) * 256;
   // wave tiles: Cout half = wave & 1 (dY sub-tile), K-column quarter = wave >> 1 (X sub-tile wave >> 2)
@@ -786,111 +858,183 @@ static float* wgrad_workspace(hipStream_t s, size_t bytes) {
   return e->buf;
 }
 
-extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate,
-                                     void* stream) {
+namespace {
+struct HostWgrad {   // one validated op
+  WgradOp o;
+  float* dw;
+  int accumulate, dtype, cls;   // cls: 0 = bf16 ping-pong 256 x 256, 1 = bf16 128 x 128, 2 = f32 128 x 128
+  long long total_steps;
+  double work;
+  int tile;                     // tile edge
+};
+
+int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate, HostWgrad& h) {
   if (!x || !dy || !dw || !d) return DAS_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->x_pix_stride % 8 || d->y_pix_stride % 8) return DAS_ERR_ARG;
   if (d->KH < 1 || d->KW < 1 || d->stride < 1 || d->B < 1 || d->in_up > 1) return DAS_ERR_ARG;
-  ConvP p;
+  if (d->dtype != DAS_BF16 && d->dtype != DAS_F32) return DAS_ERR_ARG;
+  WgradOp& o = h.o;
   long long M = (long long)d->B * d->Ho * d->Wo;
-  p.nlev = d->num_levels;
-  p.B = d->B;
-  if (p.nlev > 1) {
-    if (p.nlev > MAXLV || d->stride != 1 || d->KH != d->KW || d->pad != d->KH / 2) return DAS_ERR_ARG;
+  o.nlev = d->num_levels;
+  o.B = d->B;
+  if (o.nlev > 1) {
+    if (o.nlev > MAXLV || d->stride != 1 || d->KH != d->KW || d->pad != d->KH / 2) return DAS_ERR_ARG;
     M = 0;
-    for (int l = 0; l < p.nlev; ++l) {
-      p.lvH[l] = d->lvl_H[l]; p.lvW[l] = d->lvl_W[l]; p.lvStart[l] = (int)M;
+    for (int l = 0; l < o.nlev; ++l) {
+      o.lvH[l] = d->lvl_H[l]; o.lvW[l] = d->lvl_W[l]; o.lvStart[l] = (int)M;
       M += (long long)d->B * d->lvl_H[l] * d->lvl_W[l];
     }
   }
-  for (int l = (p.nlev > 1 ? p.nlev : 0); l < MAXLV; ++l) { p.lvH[l] = 0; p.lvW[l] = 0; p.lvStart[l] = 0x7fffffff; }
+  for (int l = (o.nlev > 1 ? o.nlev : 0); l < MAXLV; ++l) { o.lvH[l] = 0; o.lvW[l] = 0; o.lvStart[l] = 0x7fffffff; }
   if (M <= 0 || M > 0x7fffff00LL) return DAS_ERR_ARG;   // (the row walker adds a step to a row index in 32 bits)
-  p.x = (const char*)x; p.w = nullptr; p.y = (char*)dw; p.res = (const char*)dy;
-  p.scale = p.shift = nullptr; p.stats = nullptr;
-  p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.xps = d->x_pix_stride;
-  p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.yps = 0; p.rps = d->y_pix_stride;
-  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
-  p.relu_in = p.relu = 0; p.up_sh = 0;
-  p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
-  p.ntiles = p.nblocks = 0; p.xbytes = 0;
-  p.bnb_raw = p.bnb_y = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;
-  hipStream_t s = (hipStream_t)stream;
-  // second pass: sum the splits of every tile into dW (see wgrad_reduce_kernel)
-  auto reduce = [&](auto map, int tiles, int ntiles, long long splits) -> int {
-    using MAP = decltype(map);
-    const int blocks = tiles * (MAP::SLOTS / 256);
-    // tiny layers have few tiles and hundreds of splits: several reduce groups, each adding atomically
-    const int groups = (int)std::max<long long>(1, std::min<long long>(splits / 4, 512 / blocks));
-    if (groups > 1 && !accumulate &&
-        hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->Cout * p.K, s) != hipSuccess)
-      return DAS_ERR_LAUNCH;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<MAP>, dim3(blocks, groups), dim3(256), 0, s, (const float*)p.y, dw, tiles,
-                       ntiles, (int)splits, d->Cout, p.K, accumulate);
-    DAS_CHECK_LAUNCH();
-    return DAS_OK;
-  };
+  o.x = (const char*)x; o.dy = (const char*)dy; o.ws = nullptr;
+  o.H = d->H; o.W = d->W; o.Cin = d->Cin; o.xps = d->x_pix_stride;
+  o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.rps = d->y_pix_stride;
+  o.KH = d->KH; o.KW = d->KW; o.stride = d->stride; o.pad = d->pad;
+  o.M = (int)M; o.K = d->KH * d->KW * d->Cin; o.HoWo = d->Ho * d->Wo;
+  o.xbytes = 0;
+  h.dw = dw; h.accumulate = accumulate; h.dtype = d->dtype;
   // the ping-pong 256 x 256 kernel for the wide layers (K >= 256, Cout >= 256): -5...19 % with cold operands
   // (tools/dev/wgrad_cold_bench.py)
   const int pp_mink = (int)dastune::get(dastune::WGRAD_PP_MINK);   // 0 = off
-  if (d->dtype == DAS_BF16 && pp_mink > 0 && p.K >= pp_mink && d->Cout >= 256) {
-    const long long npix = p.nlev > 1 ? M : (long long)d->B * d->H * d->W;
+  h.cls = d->dtype == DAS_F32 ? 2 : 1;
+  if (d->dtype == DAS_BF16 && pp_mink > 0 && o.K >= pp_mink && d->Cout >= 256) {
+    const long long npix = o.nlev > 1 ? M : (long long)d->B * d->H * d->W;
     const long long xb = ((npix - 1) * d->x_pix_stride + d->Cin) * 2;
     const long long db = ((M - 1) * d->y_pix_stride + d->Cout) * 2;
     if (xb < 0xFFFFFFF0LL && db < 0xFFFFFFE0LL) {
-      p.xbytes = (unsigned)xb;
-      const int ntiles = (p.K + 255) / 256, tiles = ((d->Cout + 255) / 256) * ntiles;
-      const long long total_steps = (M + 31) / 32;
-      long long splits = std::max<long long>(1, std::max<long long>(1, dastune::get(dastune::WGRAD_PP_BLOCKS)) / tiles);
-      long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
-      splits = (total_steps + spb - 1) / spb;
-      p.y = (char*)wgrad_workspace(s, (size_t)splits * tiles * AccMap256::SLOTS * 16);
-      if (!p.y) return DAS_ERR_LAUNCH;
-      const size_t sm = 4 * 4 * 32 * 256;
-      static bool attr_set = false;
-      if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_wgrad_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
-            hipSuccess)
-          return DAS_ERR_LAUNCH;
-        attr_set = true;
-      }
-      dastune::note_kernel("conv_wgrad_pp_kernel");
-      hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3(tiles, (unsigned)splits), dim3(512), sm, s, p, (int)spb);
-      DAS_CHECK_LAUNCH();
-      return reduce(AccMap256{}, tiles, ntiles, splits);
+      o.xbytes = (unsigned)xb;
+      h.cls = 0;
     }
   }
-  const int ntiles = (p.K + 127) / 128, tiles = ((d->Cout + 127) / 128) * ntiles;
-  // bf16: 32 pixel rows per step = 32 KiB of LDS per workgroup, three workgroups resident per CU (register bound):
-  // more independent DMA -> MFMA chains in flight than two workgroups of 64-row steps (+10...14 % measured)
-  const int bkm = d->dtype == DAS_BF16 && dastune::get(dastune::WGRAD_BKM) == 64 ? 64 : 32;
-  const long long total_steps = (M + bkm - 1) / bkm;
-  // Split the pixel reduction so that the whole grid is ONE resident wave of workgroups (3 per CU for bf16 at
-  // 32-row steps, 2 per CU for f32: 64 KiB of LDS each) — a second, partial wave costs a full pass, and every
-  // extra split is one more round of atomics on the same dW words. At least 8 steps per workgroup.
-  // (128 registers -> four workgroups per CU fit; the fourth pays off only on the longest reductions)
-  const int forced_blocks = (int)dastune::get(dastune::WGRAD_BLOCKS);
-  const int target = forced_blocks > 0 ? forced_blocks : (d->dtype == DAS_BF16 && bkm == 32 ? (M >= 262144 ? 1024 : 768) : 512);
-  long long splits = std::max<long long>(1, target / tiles);
-  long long spb = std::max<long long>(8, (total_steps + splits - 1) / splits);
-  splits = (total_steps + spb - 1) / spb;
-  p.y = (char*)wgrad_workspace(s, (size_t)splits * tiles * AccMap128::SLOTS * 16);
-  if (!p.y) return DAS_ERR_LAUNCH;
-  dastune::note_kernel("conv_wgrad_kernel");
-  if (d->dtype == DAS_BF16) {
+  h.tile = h.cls == 0 ? 256 : 128;
+  const int ntiles = (o.K + h.tile - 1) / h.tile;
+  o.tiles = ((d->Cout + h.tile - 1) / h.tile) * ntiles;
+  h.work = (double)M * o.tiles;
+  return DAS_OK;
+}
+
+// Launch up to WG_MAXOPS ops of one class side by side: main kernel, then the split reduction.
+template <typename MAP>
+int wgrad_launch_class(HostWgrad** ops, int n, int cls, hipStream_t s) {
+  // pixel rows per step: bf16 plain kernel 32 (32 KiB of LDS per workgroup, three workgroups resident per CU, register
+  // bound: more independent DMA -> MFMA chains in flight than two workgroups of 64-row steps, +10...14 % measured)
+  const int bkm = cls == 1 && dastune::get(dastune::WGRAD_BKM) == 64 ? 64 : 32;
+  // Grid budget = ONE resident wave of workgroups (ping-pong: 1 per CU; bf16 128 x 128: 3 per CU, a 4th pays only on the
+  // longest reductions; f32: 2 per CU) — a second, partial wave costs a full pass. It is shared by the ops in
+  // proportion to their work; every op keeps at least 8 steps per workgroup.
+  long long budget;
+  if (cls == 0) {
+    budget = std::max<long long>(1, dastune::get(dastune::WGRAD_PP_BLOCKS));
+  } else {
+    const long long forced = dastune::get(dastune::WGRAD_BLOCKS);
+    long long maxM = 0;
+    for (int i = 0; i < n; ++i) maxM = std::max<long long>(maxM, ops[i]->o.M);
+    budget = forced > 0 ? forced : (cls == 1 && bkm == 32 ? (maxM >= 262144 ? 1024 : 768) : 512);
+  }
+  double tot_work = 0;
+  for (int i = 0; i < n; ++i) tot_work += ops[i]->work;
+  WgradGroup g;
+  WgradRedGroup r;
+  g.n = r.n = n;
+  long long blk = 0, rblk = 0;
+  size_t ws_floats = 0;
+  long long splits_of[WG_MAXOPS];
+  for (int i = 0; i < n; ++i) {
+    HostWgrad& h = *ops[i];
+    h.total_steps = ((long long)h.o.M + bkm - 1) / bkm;
+    const long long share = std::max<long long>(h.o.tiles, (long long)(budget * (h.work / tot_work) + 0.5));
+    long long splits = std::max<long long>(1, share / h.o.tiles);
+    long long spb = std::max<long long>(8, (h.total_steps + splits - 1) / splits);
+    splits = (h.total_steps + spb - 1) / spb;
+    splits_of[i] = splits;
+    h.o.spb = (int)spb;
+    h.o.blk0 = (int)blk;
+    h.o.nblk = (int)(splits * h.o.tiles);
+    blk = (blk + h.o.nblk + 7) / 8 * 8;
+    ws_floats += (size_t)splits * h.o.tiles * MAP::SLOTS * 4;
+  }
+  float* ws = wgrad_workspace(s, ws_floats * sizeof(float));
+  if (!ws) return DAS_ERR_LAUNCH;
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    HostWgrad& h = *ops[i];
+    h.o.ws = ws + off;
+    off += (size_t)splits_of[i] * h.o.tiles * MAP::SLOTS * 4;
+    g.op[i] = h.o;
+    WgradRedOp& ro = r.op[i];
+    ro.ws = h.o.ws; ro.dw = h.dw; ro.tiles = h.o.tiles; ro.ntiles = (h.o.K + h.tile - 1) / h.tile;
+    ro.splits = (int)splits_of[i]; ro.Cout = h.o.Cout; ro.K = h.o.K; ro.accumulate = h.accumulate;
+    const int blocks = h.o.tiles * (MAP::SLOTS / 256);
+    // tiny layers have few tiles and hundreds of splits: several reduce groups, each adding atomically
+    ro.groups = (int)std::max<long long>(1, std::min<long long>(splits_of[i] / 4, 512 / blocks));
+    if (ro.groups > 1 && !h.accumulate &&
+        hipMemsetAsync(h.dw, 0, sizeof(float) * (size_t)h.o.Cout * h.o.K, s) != hipSuccess)
+      return DAS_ERR_LAUNCH;
+    ro.blk0 = (int)rblk;
+    ro.nblk = blocks * ro.groups;
+    rblk += ro.nblk;
+  }
+  if (cls == 0) {
+    const size_t sm = 4 * 4 * 32 * 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)conv_wgrad_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) !=
+          hipSuccess)
+        return DAS_ERR_LAUNCH;
+      attr_set = true;
+    }
+    dastune::note_kernel("conv_wgrad_pp_kernel");
+    hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3((unsigned)blk), dim3(512), sm, s, g);
+  } else if (cls == 1) {
+    dastune::note_kernel("conv_wgrad_kernel");
     const size_t sm = 2 * 2 * (size_t)bkm * 256;
     if (bkm == 32) {
-      hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 32>), dim3(tiles, (unsigned)splits), dim3(256), sm, s, p, (int)spb);
+      hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 32>), dim3((unsigned)blk), dim3(256), sm, s, g);
     } else {
-      hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), dim3(tiles, (unsigned)splits), dim3(256), sm, s, p, (int)spb);
+      hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), dim3((unsigned)blk), dim3(256), sm, s, g);
     }
-  } else if (d->dtype == DAS_F32) {
-    const size_t sm = 2 * 2 * 32 * 512;
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, 32>), dim3(tiles, (unsigned)splits), dim3(256), sm, s, p, (int)spb);
   } else {
-    return DAS_ERR_ARG;
+    dastune::note_kernel("conv_wgrad_kernel");
+    const size_t sm = 2 * 2 * 32 * 512;
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, 32>), dim3((unsigned)blk), dim3(256), sm, s, g);
   }
   DAS_CHECK_LAUNCH();
-  return reduce(AccMap128{}, tiles, ntiles, splits);
+  hipLaunchKernelGGL(wgrad_reduce_kernel<MAP>, dim3((unsigned)rblk), dim3(256), 0, s, r);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+}  // namespace
+
+extern "C" int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* const* dys, float* const* dws,
+                                      const DasConvDesc* descs, int accumulate, void* stream) {
+  if (n < 1 || n > 64 || !xs || !dys || !dws || !descs) return DAS_ERR_ARG;
+  HostWgrad ops[64];
+  for (int i = 0; i < n; ++i) {
+    const int rc = wgrad_prepare(xs[i], dys[i], dws[i], &descs[i], accumulate, ops[i]);
+    if (rc != DAS_OK) return rc;
+    for (int j = 0; j < i; ++j)   // two ops adding into one dW inside one launch would race in the reduction
+      if (dws[j] == dws[i]) return DAS_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  for (int cls = 0; cls < 3; ++cls) {
+    HostWgrad* sel[WG_MAXOPS];
+    int k = 0;
+    for (int i = 0; i <= n; ++i) {
+      if (i < n && ops[i].cls == cls) sel[k++] = &ops[i];
+      if (k == WG_MAXOPS || (i == n && k > 0)) {
+        const int rc = cls == 0 ? wgrad_launch_class<AccMap256>(sel, k, cls, s) : wgrad_launch_class<AccMap128>(sel, k, cls, s);
+        if (rc != DAS_OK) return rc;
+        k = 0;
+      }
+    }
+  }
+  return DAS_OK;
+}
+
+extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate,
+                                     void* stream) {
+  return das_conv2d_wgrad_batch(1, &x, &dy, &dw, d, accumulate, stream);
 }
 
 extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream) {

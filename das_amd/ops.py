@@ -242,6 +242,53 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad, out=None, accumulate=False):
     return dw
 
 
+def _wgrad_desc(x, dy, KH, KW, stride, pad):
+    xd, dyd = _data(x), _data(dy)
+    Cin, Cout = xd.shape[-1], dyd.shape[-1]
+    ragged = isinstance(x, Ragged)
+    if ragged:
+        B, (H, W) = x.B, x.sizes[0]
+        Ho, Wo = H, W
+    else:
+        B, H, W, _ = x.shape
+        Ho, Wo = dy.shape[1], dy.shape[2]
+    d = _lib.DasConvDesc(dtype=_DT[xd.dtype], out_dtype=_lib.DAS_F32, B=B, H=H, W=W, Cin=Cin, x_pix_stride=_ps(x),
+                         Ho=Ho, Wo=Wo, Cout=Cout, y_pix_stride=_ps(dy), KH=KH, KW=KW, stride=stride, pad=pad,
+                         num_levels=len(x.sizes) if ragged else 0)
+    if ragged:
+        for l, (h, w_) in enumerate(x.sizes):
+            d.lvl_H[l], d.lvl_W[l] = h, w_
+    assert dyd.dtype == xd.dtype
+    rows = x.rows if ragged else B * Ho * Wo
+    return d, 2.0 * rows * Cout * KH * KW * Cin
+
+
+def conv2d_wgrad_batch(items):
+    """items: [(x, dy, KH, KW, stride, pad, out)], out = f32 (Cout,KH,KW,Cin) buffers (distinct) the results are ADDED
+    to. One das_conv2d_wgrad_batch call: ops of one kernel class share a launch (see include/das_hip.h)."""
+    n = len(items)
+    if n == 0:
+        return
+    descs = (_lib.DasConvDesc * n)()
+    xs, dys, dws = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    flops = 0.0
+    for i, (x, dy, KH, KW, stride, pad, out) in enumerate(items):
+        _need_gpu(x, dy, out)
+        d, fl = _wgrad_desc(x, dy, KH, KW, stride, pad)
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == d.Cout * KH * KW * d.Cin
+        descs[i] = d
+        xs[i], dys[i], dws[i] = _data(x).data_ptr(), _data(dy).data_ptr(), out.data_ptr()
+        flops += fl
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().das_conv2d_wgrad_batch(n, xs, dys, dws, descs, 1, _stream()), 'das_conv2d_wgrad_batch')
+    if PROFILE is not None:
+        e1.record()
+        dt = 'bf16' if _data(items[0][0]).dtype == torch.bfloat16 else 'float'
+        PROFILE.append((f'conv_wgrad_kernel<{dt}>', flops, e0, e1, ('batch', n), n))
+
+
 def colsum(x):
     """f32[C] column sums over all rows of an NHWC tensor / Ragged (bias gradient)."""
     _need_gpu(x)

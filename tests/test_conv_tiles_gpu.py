@@ -254,6 +254,39 @@ def test_wgrad_ragged_real_split():
     np.testing.assert_allclose(got.numpy(), w0.grad.numpy(), rtol=2e-3, atol=2e-3 * float(w0.grad.abs().max()))
 
 
+def test_wgrad_batch_equals_single_launches():
+    """das_conv2d_wgrad_batch: heterogeneous ops (both kernel classes, 3x3 / 1x1 / strided / ragged) sharing launches
+    give what one launch per op gives (same kernels, a different pixel split: f32 summation order only)."""
+    o = ops()
+    items, singles = [], []
+    specs = [(16, 32, 52, 256, 1024, 1, 1, 0), (16, 32, 52, 1024, 256, 1, 1, 0), (16, 32, 52, 256, 256, 3, 1, 1),
+             (8, 64, 104, 128, 512, 1, 1, 0), (16, 16, 26, 512, 512, 3, 1, 1), (4, 64, 104, 128, 128, 3, 2, 1),
+             (2, 128, 208, 64, 64, 3, 1, 1), (8, 64, 104, 256, 512, 1, 2, 0), (16, 16, 26, 512, 2048, 1, 1, 0),
+             (2, 40, 40, 64, 72, 1, 1, 0)]
+    for i, (B, H, W, Cin, Cout, k, s, p) in enumerate(specs):
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        x = torch.randn(B, H, W, Cin, device=DEV, dtype=BF)
+        dy = torch.randn(B, Ho, Wo, Cout, device=DEV, dtype=BF) / (B * Ho * Wo) ** 0.5
+        base = torch.randn(Cout, k, k, Cin, device=DEV)
+        out = base.clone()
+        items.append((x, dy, k, k, s, p, out))
+        singles.append(base + o.conv2d_wgrad(x, dy, k, k, s, p))
+    B, Cc = 4, 256
+    sizes = [(32, 52), (16, 26), (8, 13), (4, 7)]
+    xr = o.Ragged.from_levels([torch.randn(B, h, w, Cc, device=DEV, dtype=BF) for h, w in sizes])
+    dyr = o.Ragged.from_levels([torch.randn(B, h, w, Cc, device=DEV, dtype=BF) / 50 for h, w in sizes])
+    base = torch.zeros(Cc, 3, 3, Cc, device=DEV)
+    items.append((xr, dyr, 3, 3, 1, 1, base.clone()))
+    singles.append(o.conv2d_wgrad(xr, dyr, 3, 3, 1, 1))
+    o.conv2d_wgrad_batch(items)
+    for it, ref in zip(items, singles):
+        got = it[6]
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
+    from das_amd import _lib
+    with pytest.raises(_lib.DasHipError):       # two ops adding into one buffer would race in the reduction
+        o.conv2d_wgrad_batch([items[0], items[0]])
+
+
 def test_tuning_api_rejects_unknown_key():
     from das_amd import _lib
     lib = _lib.load()

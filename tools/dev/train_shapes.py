@@ -22,7 +22,10 @@ for _ in range(R):
     train_iteration(model, opt, data, 2e-3)
 torch.cuda.synchronize()
 agg = {}
-for tag, fl, e0, e1, shape in ops.PROFILE:
+for ent in ops.PROFILE:
+    tag, fl, e0, e1, shape = ent[:5]
+    if shape[0] == 'batch':
+        shape = (0, 0, 0, 0, 0, 0, 0, shape[1])
     a = agg.setdefault((tag, shape), [0.0, 0.0, 0])
     a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
 tot = sum(a[1] for a in agg.values())
