@@ -170,36 +170,32 @@ struct WgradOp {
 };
 struct WgradGroup {
   int n;
+  int blk0[WG_MAXOPS], nblk[WG_MAXOPS];   // (copies of op[i].blk0 / nblk: the pick reads one cache line, not eight)
   WgradOp op[WG_MAXOPS];
 };
-// op of this workgroup. Every field is picked by a chain of scalar selects over statically indexed kernel arguments:
-// a dynamically indexed by-value argument — or a struct-valued select — makes the compiler copy the whole argument block
-// to scratch (1.4 KB per lane; the kernels ran 15 % slower).
-#define WG_SEL(F)                                                                                              \
-  (k == 7 ? g.op[7].F : k == 6 ? g.op[6].F : k == 5 ? g.op[5].F : k == 4 ? g.op[4].F : k == 3 ? g.op[3].F :     \
-   k == 2 ? g.op[2].F : k == 1 ? g.op[1].F : g.op[0].F)
+// op of this workgroup. The argument block lives in HOST memory (every first touch of one of its cache lines is a
+// PCIe round trip, ~2 us), so: the block ranges sit together at the front, and the chosen op's record is read through the
+// kernarg segment pointer with a dynamic offset — plain scalar loads of that ONE record. (Indexing the by-value
+// argument dynamically makes the compiler copy all of it to scratch; a select chain over the eight records reads all
+// eight, one dependent round trip after the other: +20 us per launch measured.)
 __device__ __forceinline__ bool wgrad_pick(const WgradGroup& g, int bid, ConvP& p, int& tiles, int& spb, int& local, int& nblk) {
-  static_assert(WG_MAXOPS == 8, "WG_SEL spells out eight ops");
   int k = -1;
 #pragma unroll
   for (int i = 0; i < WG_MAXOPS; ++i)
-    if (i < g.n && bid >= g.op[i].blk0 && bid < g.op[i].blk0 + g.op[i].nblk) k = i;
+    if (i < g.n && bid >= g.blk0[i] && bid < g.blk0[i] + g.nblk[i]) k = i;
   if (k < 0) return false;   // padding workgroup between two ops
-  p.x = WG_SEL(x); p.res = WG_SEL(dy); p.y = reinterpret_cast<char*>(WG_SEL(ws)); p.w = nullptr;
+  const char* args = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const WgradOp& o = *reinterpret_cast<const WgradOp*>(args + __builtin_offsetof(WgradGroup, op) + (size_t)k * sizeof(WgradOp));
+  p.x = o.x; p.res = o.dy; p.y = reinterpret_cast<char*>(o.ws); p.w = nullptr;
   p.scale = p.shift = nullptr; p.stats = nullptr; p.stat_slots = 1;
-  p.H = WG_SEL(H); p.W = WG_SEL(W); p.Cin = WG_SEL(Cin); p.xps = WG_SEL(xps); p.Ho = WG_SEL(Ho); p.Wo = WG_SEL(Wo);
-  p.Cout = WG_SEL(Cout); p.yps = 0; p.KH = WG_SEL(KH); p.KW = WG_SEL(KW); p.stride = WG_SEL(stride); p.pad = WG_SEL(pad);
-  p.relu_in = p.relu = 0; p.rps = WG_SEL(rps); p.up_sh = 0;
-  p.M = WG_SEL(M); p.K = WG_SEL(K); p.HoWo = WG_SEL(HoWo); p.ntiles = p.nblocks = 0; p.xbytes = WG_SEL(xbytes);
-  p.nlev = WG_SEL(nlev); p.B = WG_SEL(B);
-  p.lvH[0] = WG_SEL(lvH[0]); p.lvH[1] = WG_SEL(lvH[1]); p.lvH[2] = WG_SEL(lvH[2]); p.lvH[3] = WG_SEL(lvH[3]); p.lvH[4] = WG_SEL(lvH[4]);
-  p.lvW[0] = WG_SEL(lvW[0]); p.lvW[1] = WG_SEL(lvW[1]); p.lvW[2] = WG_SEL(lvW[2]); p.lvW[3] = WG_SEL(lvW[3]); p.lvW[4] = WG_SEL(lvW[4]);
-  p.lvStart[0] = WG_SEL(lvStart[0]); p.lvStart[1] = WG_SEL(lvStart[1]); p.lvStart[2] = WG_SEL(lvStart[2]);
-  p.lvStart[3] = WG_SEL(lvStart[3]); p.lvStart[4] = WG_SEL(lvStart[4]);
-  static_assert(MAXLV == 5, "the level arrays are spelled out");
+  p.H = o.H; p.W = o.W; p.Cin = o.Cin; p.xps = o.xps; p.Ho = o.Ho; p.Wo = o.Wo; p.Cout = o.Cout; p.yps = 0;
+  p.KH = o.KH; p.KW = o.KW; p.stride = o.stride; p.pad = o.pad; p.relu_in = p.relu = 0; p.rps = o.rps; p.up_sh = 0;
+  p.M = o.M; p.K = o.K; p.HoWo = o.HoWo; p.ntiles = p.nblocks = 0; p.xbytes = o.xbytes; p.nlev = o.nlev; p.B = o.B;
+#pragma unroll
+  for (int l = 0; l < MAXLV; ++l) { p.lvH[l] = o.lvH[l]; p.lvW[l] = o.lvW[l]; p.lvStart[l] = o.lvStart[l]; }
   p.bnb_raw = p.bnb_y = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;
-  tiles = WG_SEL(tiles); spb = WG_SEL(spb); nblk = WG_SEL(nblk);
-  local = bid - WG_SEL(blk0);
+  tiles = o.tiles; spb = o.spb; nblk = o.nblk;
+  local = bid - o.blk0;
   return true;
 }
 struct WgradRedOp {
@@ -211,6 +207,7 @@ struct WgradRedOp {
 };
 struct WgradRedGroup {
   int n;
+  int blk0[WG_MAXOPS], nblk[WG_MAXOPS];
   WgradRedOp op[WG_MAXOPS];
 };
 
@@ -223,12 +220,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradRedGroup g) {
   int k = -1;
 #pragma unroll
   for (int i = 0; i < WG_MAXOPS; ++i)
-    if (i < g.n && (int)blockIdx.x >= g.op[i].blk0 && (int)blockIdx.x < g.op[i].blk0 + g.op[i].nblk) k = i;
+    if (i < g.n && (int)blockIdx.x >= g.blk0[i] && (int)blockIdx.x < g.blk0[i] + g.nblk[i]) k = i;
   if (k < 0) return;
-  WgradRedOp o;
-  o.ws = WG_SEL(ws); o.dw = WG_SEL(dw); o.tiles = WG_SEL(tiles); o.ntiles = WG_SEL(ntiles); o.splits = WG_SEL(splits);
-  o.Cout = WG_SEL(Cout); o.K = WG_SEL(K); o.accumulate = WG_SEL(accumulate); o.groups = WG_SEL(groups);
-  o.blk0 = WG_SEL(blk0);
+  const char* args = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const WgradRedOp& o = *reinterpret_cast<const WgradRedOp*>(args + __builtin_offsetof(WgradRedGroup, op) + (size_t)k * sizeof(WgradRedOp));
   const int local = blockIdx.x - o.blk0;
   const int per_group = o.tiles * BPT;
   const int grp = local / per_group, bx = local % per_group;
@@ -970,6 +965,7 @@ int wgrad_launch_class(HostWgrad** ops, int n, int cls, hipStream_t s) {
     h.o.ws = ws + off;
     off += (size_t)splits_of[i] * h.o.tiles * MAP::SLOTS * 4;
     g.op[i] = h.o;
+    g.blk0[i] = h.o.blk0; g.nblk[i] = h.o.nblk;
     WgradRedOp& ro = r.op[i];
     ro.ws = h.o.ws; ro.dw = h.dw; ro.tiles = h.o.tiles; ro.ntiles = (h.o.K + h.tile - 1) / h.tile;
     ro.splits = (int)splits_of[i]; ro.Cout = h.o.Cout; ro.K = h.o.K; ro.accumulate = h.accumulate;
@@ -981,6 +977,7 @@ int wgrad_launch_class(HostWgrad** ops, int n, int cls, hipStream_t s) {
       return DAS_ERR_LAUNCH;
     ro.blk0 = (int)rblk;
     ro.nblk = blocks * ro.groups;
+    r.blk0[i] = ro.blk0; r.nblk[i] = ro.nblk;
     rblk += ro.nblk;
   }
   if (cls == 0) {
