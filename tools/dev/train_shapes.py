@@ -36,7 +36,13 @@ for (tag, shape), (fl, sec, n) in agg.items():
     f[0] += fl; f[1] += sec
 for tag, (fl, sec) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print(f'  {sec / R * 1e3:8.3f} ms {fl / sec / 1e12:7.1f} TF  {tag}')
-for (tag, shape), (fl, sec, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+for (tag, shape), (fl, sec, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
     Bb, H, W, Cin, Cout, k, s, nl = shape
-    print(f'{sec / tot * 100:5.1f}% {sec / R * 1e3:7.3f}ms n={n // R:3d} {fl / sec / 1e12:7.1f}TF '
-          f'{tag[5:30]:26s} HxW={H}x{W} Cin={Cin} Cout={Cout} k={k} s={s} lv={nl}')
+    # floors per launch: operands once through HBM at 6.3 TB/s; MFMA at 2.5 PF
+    per = sec / n
+    flop = fl / n
+    rows_out = flop / (2.0 * max(Cout, 1) * k * k * max(Cin, 1)) if Cin else 0
+    hbm = (rows_out * s * s * Cin + rows_out * Cout) * 2 / 6.3e12 if Cin else 0
+    mf = flop / 2.5e15
+    print(f'{sec / tot * 100:5.1f}% {sec / R * 1e3:7.3f}ms n={n // R:3d} {per * 1e6:7.1f}us (hbm {hbm * 1e6:6.1f} mfma {mf * 1e6:6.1f}) '
+          f'{fl / sec / 1e12:7.1f}TF {tag[5:30]:22s} HxW={H}x{W} Cin={Cin} Cout={Cout} k={k} s={s} lv={nl}')
