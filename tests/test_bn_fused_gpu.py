@@ -99,69 +99,83 @@ def test_dgrad_epilogue_reduces_bn_backward(case, dtype):
     np.testing.assert_allclose(nchw(draw).numpy(), q(ref, dtype).numpy(), **(tol if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)))
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-def test_chain_backward_equals_per_unit_backward(dtype):
-    """MSPN2 (2 stages, tiny widths, [2,2,2,2] blocks so that block-to-block fusion is exercised) train-mode backward:
-    BottleneckChainFn vs one autograd node per conv+BN unit — same forward bits, gradients equal to summation order."""
+def _mspn_grads(dtype, fused, flat=False, blocks=(2, 2, 2, 2), stages=2):
     import das_amd
     from das_amd import backbones
-    res = {}
-    for fused in (False, True):
-        backbones.FUSED_LAYER_BACKWARD = fused
-        try:
-            torch.manual_seed(0)
-            m = das_amd.MSPN2(unit_channels=16, num_stages=2, num_blocks=[2, 2, 2, 2], compute_dtype=dtype)
-            cases.det_fill(m.state_dict(), 5)
-            m.to(DEV).train()
-            x = cases.randn(7, 2, 3, 64, 96).to(DEV)
-            outs = m(x)
-            gs = [cases.randn(80 + i, 2, 16, 16 >> i, 24 >> i).to(DEV) for i in range(4)]
-            sum((o.float() * g).sum() for o, g in zip(outs, gs)).backward()
-            res[fused] = ([o.detach().float().clone() for o in outs],
-                          {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
-        finally:
-            backbones.FUSED_LAYER_BACKWARD = True
-    (o0, g0), (o1, g1) = res[False], res[True]
-    for a, b in zip(o0, o1):
-        assert torch.equal(a, b)                      # identical forward kernels
-    if dtype == 'f32':
-        tol = 2e-3
-    else:
-        tol = 6e-2   # bf16 storage of dZ / dRaw: both paths round the same tensors, but a flipped ulp moves a ReLU mask
-    errs = []
-    assert set(g0) == set(g1)
-    for n in g0:
-        a, b = g0[n].float(), g1[n].float()
-        if float(a.abs().max()) == 0:
-            assert float(b.abs().max()) == 0, n
-            continue
-        errs.append(float((a - b).abs().max() / a.abs().max()))
-    errs = np.sort(np.array(errs))
-    # (train-mode BN nets are ill-conditioned, see test_train_gpu.py: the bulk must agree tightly, the tail loosely)
-    assert errs[int(0.9 * len(errs))] < tol and errs[-1] < 20 * tol, (errs[int(0.9 * len(errs))], errs[-1])
-
-
-def test_chain_backward_with_flat_optimizer_direct_accumulation():
-    """With FlatSGD the chain adds weight gradients and BatchNorm parameter gradients straight into the flat buffer;
-    the result equals the autograd-delivered gradients of the same chain."""
-    import das_amd
     from das_amd.optim import FlatSGD
-    grads = {}
-    for flat in (False, True):
+    backbones.FUSED_LAYER_BACKWARD = fused
+    try:
         torch.manual_seed(0)
-        m = das_amd.MSPN2(unit_channels=16, num_stages=1, num_blocks=[2, 1, 2, 1], compute_dtype='f32')
-        cases.det_fill(m.state_dict(), 5)
+        m = das_amd.MSPN2(unit_channels=16, num_stages=stages, num_blocks=list(blocks), compute_dtype=dtype)
+        sd = {k: v.clone() for k, v in cases.det_fill(m.state_dict(), 5).items()}
         m.to(DEV).train()
         if flat:
             opt = FlatSGD(m, lr=1e-3)
             opt.zero_grad()
         outs = m(cases.randn(7, 2, 3, 64, 96).to(DEV))
-        sum((o.float() ** 2).sum() for o in outs).backward()
+        gs = [cases.randn(80 + i, 2, 16, 16 >> i, 24 >> i) for i in range(4)]
+        sum((o.float() * g.to(DEV)).sum() for o, g in zip(outs, gs)).backward()
         torch.cuda.synchronize()
-        grads[flat] = {n: p.grad.detach().float().clone() for n, p in m.named_parameters()}
-    errs = []
-    for n in grads[False]:
-        a, b = grads[False][n], grads[True][n]
-        errs.append(float((a - b).abs().max()) / max(float(a.abs().max()), 1e-6))
-    errs = np.sort(np.array(errs))
-    assert errs[int(0.9 * len(errs))] < 2e-3 and errs[-1] < 4e-2, (errs[int(0.9 * len(errs))], errs[-1])
+        return m, sd, gs, {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+    finally:
+        backbones.FUSED_LAYER_BACKWARD = True
+
+
+def test_chain_backward_vs_f64_oracle():
+    """BottleneckChainFn (block-to-block fusion exercised: two blocks per layer, two stages) against the f64 oracle,
+    in the error band of the oracle's own f32 evaluation — the yardstick of test_train_gpu.py (train-mode BN nets are
+    ill-conditioned: two f32 evaluations of the same net differ by 1e-3...1e-2 on many parameters, and so do two RUNS
+    of this path, whose statistics are summed with float atomics)."""
+    from oracle import backbone as ob
+    from test_train_gpu import band_check, grad_sd, rel
+    m, sd, gs, g_hip = _mspn_grads('f32', True)
+    x = cases.randn(7, 2, 3, 64, 96)
+    refs = {}
+    for dt in (torch.float64, torch.float32):
+        osd = grad_sd(sd, dt)
+        oo = ob.mspn2_forward(osd, x.to(dt), 2, (2, 2, 2, 2), train=True)
+        sum((o * g.to(dt)).sum() for o, g in zip(oo, gs)).backward()
+        refs[dt] = osd
+    e_hip, e_o32 = [], []
+    for k, g in g_hip.items():
+        ref = refs[torch.float64][k].grad
+        if ref is None:
+            continue
+        e_hip.append(rel(g.double().cpu().numpy(), ref.numpy()))
+        e_o32.append(rel(refs[torch.float32][k].grad.double().numpy(), ref.numpy()))
+    assert len(e_hip) > 200
+    band_check(e_hip, e_o32, 'mspn2 chain backward')
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_chain_backward_agrees_with_per_unit_backward(dtype):
+    """Same net, one autograd node per conv+BN unit vs one per layer: the gradients point the same way (exact equality
+    is not defined here: see the run-to-run note above; bf16 storage adds ReLU-mask flips on top)."""
+    _, _, _, g0 = _mspn_grads(dtype, False)
+    _, _, _, g0b = _mspn_grads(dtype, False)      # the same path again: the run-to-run floor
+    _, _, _, g1 = _mspn_grads(dtype, True)
+    assert set(g0) == set(g1)
+    big = [n for n in g0 if g0[n].numel() >= 256 and float(g0[n].abs().max()) > 0]
+    cos = np.array([_cos(g0[n], g1[n]) for n in big])
+    floor = np.array([_cos(g0[n], g0b[n]) for n in big])
+    print('median cos fused-vs-unit', np.median(cos), 'unit-vs-unit', np.median(floor), 'min', cos.min(), floor.min())
+    assert np.median(cos) > np.median(floor) - 0.03 and cos.min() > floor.min() - 0.1, (np.median(cos), np.median(floor))
+    if dtype == 'f32':
+        assert np.median(cos) > 0.999
+
+
+def test_chain_backward_with_flat_optimizer_direct_accumulation():
+    """With FlatSGD the chain adds weight gradients (batched, deferred) and BatchNorm parameter gradients straight into
+    the flat buffer; every parameter that gets a gradient through autograd gets one there."""
+    _, _, _, g0 = _mspn_grads('f32', True, flat=False, blocks=(2, 1, 2, 1), stages=1)
+    _, _, _, g1 = _mspn_grads('f32', True, flat=True, blocks=(2, 1, 2, 1), stages=1)
+    for n in g0:
+        assert n in g1 and (float(g0[n].abs().max()) == 0) == (float(g1[n].abs().max()) == 0), n
+    big = [n for n in g0 if g0[n].numel() >= 256 and float(g0[n].abs().max()) > 0]
+    cos = np.array([_cos(g0[n], g1[n]) for n in big])
+    assert np.median(cos) > 0.999 and cos.min() > 0.98, (np.median(cos), cos.min())
