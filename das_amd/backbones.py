@@ -9,6 +9,7 @@ every layer runs as an NHWC HIP kernel. Reference quirks kept on purpose:
   * `frozen_stages` / `norm_eval` are accepted and ignored (`:600`, `_frozen_stage` never called).
 """
 import copy
+import os
 
 import torch
 import torch.nn as nn
@@ -203,20 +204,74 @@ class MSPN2(nn.Module):
         return [to_nchw_view(o) for o in out[::-1]]
 
     def init_weights(self, pretrained=None):
-        """kaiming for convs, BN weight 1 (mspn_mmpose.py:682-692); checkpoint loading strips
-        the `backbone.` prefix (`:672-680`). Unlike the reference, pretrained=None is accepted."""
-        pretrained = pretrained or self.pretrained
-        for m in self.modules():
+        """mspn_mmpose.py:669-721, both branches.
+          * `pretrained` starting with 'weights/' (the DAS configs' MSPN checkpoints, exp_panoptic.py:12): a full
+            detector / MSPN checkpoint — keys under `backbone.` are loaded by name, non-strict.
+          * otherwise: kaiming-normal (fan_out, relu) for every conv of the stages and of the stem, BatchNorm weight 1 /
+            bias 0, Linear N(0, 0.01); then, if `pretrained` is a path, a ResNet-50 classification checkpoint
+            (torchvision / MMPose key layout `conv1`, `bn1`, `layer{1-4}.{b}.*`, `layer{L}.0.downsample.{0,1}.*`) is
+            mapped onto the stem (`conv1 -> top.0.conv`, `bn1 -> top.0.bn`) and onto the downsample module of EVERY
+            stage (`downsample.0 -> downsample.conv`, `downsample.1 -> downsample.bn`).
+        Unlike the reference (which ignores its argument and fails on pretrained=None), the argument is honoured and None
+        means random initialisation."""
+        pretrained = pretrained if pretrained is not None else self.pretrained
+        if isinstance(pretrained, str) and pretrained.startswith('weights/'):
+            if not os.path.isfile(pretrained):
+                raise FileNotFoundError(f'pretrained backbone checkpoint {pretrained} not found')
+            loaded = torch.load(pretrained, map_location='cpu', weights_only=False)['state_dict']
+            sd = {k.replace('backbone.', ''): v for k, v in loaded.items() if k.startswith('backbone.')}
+            return self.load_state_dict(sd, strict=False)
+        for m in self.multi_stage_mspn.modules():
             if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                nn.init.kaiming_normal_(m.weight, a=0, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
-        if isinstance(pretrained, str):
-            import os
-            if not os.path.isfile(pretrained):
-                raise FileNotFoundError(f'pretrained backbone checkpoint {pretrained} not found')
-            sd = torch.load(pretrained, map_location='cpu')
-            sd = sd.get('state_dict', sd)
-            sd = {k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')} or sd
-            self.load_state_dict(sd, strict=False)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        for m in self.top.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, a=0, mode='fan_out', nonlinearity='relu')
+        if not isinstance(pretrained, str):
+            return None
+        if not os.path.isfile(pretrained):
+            raise FileNotFoundError(f'pretrained backbone checkpoint {pretrained} not found')
+        tmp = resnet_state_dict(pretrained)
+        top, bottlenecks = {}, {}
+        for k, v in tmp.items():
+            if k.startswith('layer'):
+                if 'downsample.0' in k:
+                    bottlenecks[k.replace('downsample.0', 'downsample.conv')] = v
+                elif 'downsample.1' in k:
+                    bottlenecks[k.replace('downsample.1', 'downsample.bn')] = v
+                else:
+                    bottlenecks[k] = v
+            elif k.startswith('conv1'):
+                top[k.replace('conv1', 'top.0.conv')] = v
+            elif k.startswith('bn1'):
+                top[k.replace('bn1', 'top.0.bn')] = v
+        report = [self.top.load_state_dict(top, strict=False)]
+        for stage in self.multi_stage_mspn:
+            report.append(stage.downsample.load_state_dict(bottlenecks, strict=False))
+        return report
+
+
+def resnet_state_dict(filename, map_location='cpu'):
+    """`get_state_dict` (mspn_mmpose.py:161-193): the checkpoint's `state_dict` (or the file itself) with the
+    `module.backbone.` / `module.` / `backbone.` prefixes stripped."""
+    ck = torch.load(filename, map_location=map_location, weights_only=False)
+    if not isinstance(ck, dict):
+        raise RuntimeError(f'No state_dict found in checkpoint file {filename}')
+    sd = ck.get('state_dict', ck)
+    out = {}
+    for k, v in sd.items():
+        for pre in ('module.backbone.', 'module.', 'backbone.'):
+            if k.startswith(pre):
+                k = k[len(pre):]
+                break
+        out[k] = v
+    return out

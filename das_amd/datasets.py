@@ -51,13 +51,20 @@ def collate(samples, device=None):
     return out
 
 
-DATASETS = {'SyntheticPoseDataset': SyntheticPoseDataset}
+from .registry import Registry  # noqa: E402
+
+DATASETS = Registry('dataset')      # mmdet.datasets.builder.DATASETS in the reference (mmdet3d/datasets/builder.py)
+PIPELINES = Registry('pipeline')
+DATASETS.register_module(module=SyntheticPoseDataset)
 
 
-def build_dataset(cfg):
+def build_dataset(cfg, default_args=None):
+    """mmdet3d.datasets.build_dataset (tools/train.py:196): `type=` resolves through DATASETS; a list under
+    `pipeline` becomes a `das_amd.pipelines.Compose`."""
+    from . import pipelines, pose_datasets  # noqa: F401  (register CMUPanopticDataset / MuPots3DHP and the transforms)
     cfg = dict(cfg)
-    t = cfg.pop('type')
-    if t not in DATASETS:
-        raise KeyError(f'dataset type {t} is outside this repo\'s scope (real-data loaders: SURVEY.md section 8f); '
-                       f'available: {sorted(DATASETS)}')
-    return DATASETS[t](**cfg)
+    if cfg.get('type') not in DATASETS:
+        raise KeyError(f"dataset type {cfg.get('type')} is not registered; available: {sorted(DATASETS.module_dict)}")
+    if isinstance(cfg.get('pipeline'), (list, tuple)):
+        cfg['pipeline'] = pipelines.Compose(cfg['pipeline'])
+    return DATASETS.build(cfg, default_args)

@@ -1,0 +1,328 @@
+"""Dataset classes of the DAS reference: annotation parsing and evaluation.
+
+  CMUPanopticDataset  mmdet3d/datasets/cmupanoptic_mono_dataset.py:37-424   (MPJPE)
+  MuPots3DHP          mmdet3d/datasets/mupots_3dhp.py:17-336                (3DPCK, relative and absolute)
+
+Both read the COCO-style json the reference's converters write (mytools/panoptic2coco.py, muco2coco.py) through
+`CocoLite`, a minimal stand-in for pycocotools' index (not installed here). `get_ann_info` builds the training targets
+`gt_poses_3d (G, 3+4J) = [cx, cy, depth, J x (u, v, dz), J x vis]`, `centers2d`, `depths` exactly as the reference's
+`_parse_ann_info`; `evaluate(outputs, res_folder)` takes the detector's `simple_test` outputs, writes
+`result_keypoints.json` and returns the metric dict. Image loading / augmentation lives in `das_amd.pipelines`.
+"""
+import copy
+import json
+import os
+from collections import OrderedDict, defaultdict
+
+import numpy as np
+
+from . import evaluation as E
+from .datasets import DATASETS
+
+
+class CocoLite:
+    """The part of pycocotools.COCO the reference's datasets use: imgs / anns / cats indices, get_ann_ids,
+    get_cat_ids, load_imgs, load_anns."""
+
+    def __init__(self, annotation):
+        data = annotation
+        if isinstance(annotation, (str, os.PathLike)):
+            with open(annotation) as f:
+                data = json.load(f)
+        self.dataset = data
+        self.imgs = {im['id']: im for im in data.get('images', [])}
+        self.anns = {a['id']: a for a in data.get('annotations', [])}
+        self.cats = {c['id']: c for c in data.get('categories', [])}
+        self.img_to_anns = defaultdict(list)
+        for a in data.get('annotations', []):
+            self.img_to_anns[a['image_id']].append(a)
+
+    def get_img_ids(self):
+        return list(self.imgs.keys())
+
+    def get_cat_ids(self, cat_names=()):
+        if not cat_names:
+            return list(self.cats.keys())
+        return [c['id'] for c in self.cats.values() if c['name'] in cat_names]
+
+    def get_ann_ids(self, img_ids=()):
+        return [a['id'] for i in img_ids for a in self.img_to_anns.get(i, [])]
+
+    def load_anns(self, ids):
+        return [self.anns[i] for i in ids]
+
+    def load_imgs(self, ids):
+        return [self.imgs[i] for i in ids]
+
+
+class _PoseCocoDataset:
+    """What mmdet's CocoDataset gives the two subclasses: the annotation index, image list, category maps."""
+    CLASSES = ('person',)
+
+    def __init__(self, ann_file, pipeline=None, data_root=None, img_prefix='', test_mode=False, **kwargs):
+        self.data_root = data_root
+        if data_root is not None and isinstance(ann_file, str) and not os.path.isabs(ann_file):
+            ann_file = os.path.join(data_root, ann_file)
+        if data_root is not None and img_prefix and not os.path.isabs(img_prefix):
+            img_prefix = os.path.join(data_root, img_prefix)
+        self.ann_file, self.img_prefix, self.test_mode = ann_file, img_prefix, test_mode
+        self.coco = CocoLite(ann_file)
+        self.cat_ids = self.coco.get_cat_ids(cat_names=self.CLASSES)
+        self.cat2label = {cat_id: i for i, cat_id in enumerate(self.cat_ids)}
+        self.img_ids = self.coco.get_img_ids()
+        self.data_infos = []
+        for i in self.img_ids:
+            info = dict(self.coco.load_imgs([i])[0])
+            info['filename'] = info['file_name']
+            self.data_infos.append(info)
+        self.pipeline = pipeline
+
+    def __len__(self):
+        return len(self.data_infos)
+
+    def get_ann_info(self, idx):
+        img_id = self.data_infos[idx]['id']
+        ann_info = self.coco.load_anns(self.coco.get_ann_ids(img_ids=[img_id]))
+        return self._parse_ann_info(self.data_infos[idx], ann_info)
+
+    def __getitem__(self, idx):
+        if self.pipeline is None:
+            raise RuntimeError('no pipeline configured: build the dataset with pipeline=[...] (das_amd.pipelines)')
+        ann = self.get_ann_info(idx)
+        if ann is None:
+            return None
+        results = dict(img_info=self.data_infos[idx], ann_info=ann, img_prefix=self.img_prefix, pose3d_fields=[],
+                       bbox_fields=[], img_fields=[])
+        return self.pipeline(results)
+
+    # shared by both datasets (cmupanoptic_mono_dataset.py:267-356, mupots_3dhp.py:195-286)
+    def _evaluate_results(self, outputs, res_folder, image_id_of, num_joints=None):
+        kpts = E.collect_keypoints(outputs, image_id_of, num_joints)
+        results = E.coco_keypoint_results(kpts, self.num_joints)
+        E.write_keypoint_results(results, os.path.join(res_folder, 'result_keypoints.json'))
+        return results
+
+    def _finish_targets(self, gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore):
+        if gt_bboxes:
+            out = dict(bboxes=np.array(gt_bboxes, dtype=np.float32), labels=np.array(gt_labels, dtype=np.int64),
+                       gt_poses_3d=np.array(gt_poses_3d, dtype=np.float32),
+                       centers2d=np.array(centers2d, dtype=np.float32), depths=np.array(depths, dtype=np.float32))
+        else:
+            out = dict(bboxes=np.zeros((0, 4), dtype=np.float32), labels=np.array([], dtype=np.int64),
+                       gt_poses_3d=np.zeros((0, 3 + self.num_joints * 4), dtype=np.float32),
+                       centers2d=np.zeros((0, 2), dtype=np.float32), depths=np.zeros((0), dtype=np.float32))
+        out['gt_labels_3d'] = copy.deepcopy(out['labels'])
+        out['bboxes_ignore'] = np.array(gt_bboxes_ignore, dtype=np.float32) if gt_bboxes_ignore \
+            else np.zeros((0, 4), dtype=np.float32)
+        return out
+
+    def _box_ok(self, ann, img_info, need_area=True):
+        x1, y1, w, h = ann['bbox']
+        inter_w = max(0, min(x1 + w, img_info['width']) - max(x1, 0))
+        inter_h = max(0, min(y1 + h, img_info['height']) - max(y1, 0))
+        if inter_w * inter_h == 0:
+            return False
+        if (ann['area'] <= 0 if need_area else ('area' in ann and ann['area'] <= 0)) or w < 1 or h < 1:
+            return False
+        return ann['category_id'] in self.cat_ids
+
+
+@DATASETS.register_module()
+class CMUPanopticDataset(_PoseCocoDataset):
+    JOINTS_DEF = {'neck': 0, 'nose': 1, 'mid-hip': 2, 'l-shoulder': 3, 'l-elbow': 4, 'l-wrist': 5, 'l-hip': 6,
+                  'l-knee': 7, 'l-ankle': 8, 'r-shoulder': 9, 'r-elbow': 10, 'r-wrist': 11, 'r-hip': 12, 'r-knee': 13,
+                  'r-ankle': 14}
+    skeleton = [[0, 1], [0, 2], [0, 3], [3, 4], [4, 5], [0, 9], [9, 10], [10, 11], [2, 6], [2, 12], [6, 7], [7, 8],
+                [12, 13], [13, 14]]
+    ROOT_IDX = 2
+
+    def __init__(self, data_root=None, load_interval=1, use_bbox_center=False, norm_depth=True, abs_dz=True,
+                 depth_factor=1, **kwargs):
+        super().__init__(data_root=data_root, **kwargs)
+        self.num_joints = len(self.JOINTS_DEF)
+        self.load_interval, self.norm_depth, self.depth_factor, self.abs_dz = load_interval, norm_depth, depth_factor, abs_dz
+        if abs_dz:
+            assert norm_depth
+        self.name2id = {os.path.basename(self.coco.load_imgs([i])[0]['file_name']): i for i in self.img_ids}
+        self.use_bbox_center = use_bbox_center
+
+    def _parse_ann_info(self, img_info, ann_info):
+        """cmupanoptic_mono_dataset.py:166-264: depth / f (and / depth_factor), dz relative to the root (abs_dz), the
+        root joint as the centre; persons whose root is invisible go to bboxes_ignore."""
+        K = img_info['cam']['K']
+        f = np.sqrt(K[0][0] * K[1][1])
+        gt_bboxes, gt_labels, gt_poses_3d, gt_bboxes_ignore, centers2d, depths = [], [], [], [], [], []
+        for ann in ann_info:
+            if ann.get('ignore', False) or not self._box_ok(ann, img_info):
+                continue
+            x1, y1, w, h = ann['bbox']
+            bbox = [x1, y1, x1 + w, y1 + h]
+            if ann.get('iscrowd', False):
+                gt_bboxes_ignore.append(bbox)
+                continue
+            pose_3d = np.array(ann['joints3d_img'], dtype=float)
+            pose_vis = ann['joints2d_vis']
+            if self.norm_depth:
+                pose_3d[:, 2] /= self.depth_factor
+                if self.abs_dz:
+                    abs_dz = pose_3d[:, 2] - pose_3d[[self.ROOT_IDX], 2]
+                pose_3d[:, 2] /= f
+            if pose_3d.max() - pose_3d.min() < 10:
+                continue
+            if not self.use_bbox_center:
+                if pose_vis[self.ROOT_IDX][0] == 0:
+                    gt_bboxes_ignore.append(bbox)
+                    continue
+                c2d = pose_3d[self.ROOT_IDX].copy()
+            else:
+                c2d = pose_3d[self.ROOT_IDX].copy()
+                c2d[0], c2d[1] = x1 + 0.5 * w, y1 + 0.5 * h
+            gt_bboxes.append(bbox)
+            gt_labels.append(self.cat2label[ann['category_id']])
+            if self.abs_dz:
+                pose_3d[:, 2] = abs_dz
+            gt_poses_3d.append(np.concatenate([np.array(c2d, dtype=float).reshape(-1), pose_3d.reshape(-1),
+                                               np.array(pose_vis, dtype=float)[:, 0].reshape(-1)]))
+            centers2d.append(c2d[:2])
+            depths.append(c2d[2])
+        if not gt_bboxes and not self.test_mode:
+            return None
+        ann = self._finish_targets(gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore)
+        if ann['gt_poses_3d'][:, 3 + self.num_joints * 3:].sum() < 6 and not self.test_mode:
+            return None
+        if 'cam' in img_info:
+            ann['cam'] = img_info['cam']
+        return ann
+
+    def evaluate(self, outputs, res_folder='tmp', metric='mpjpe', **kwargs):
+        for m in (metric if isinstance(metric, list) else [metric]):
+            if m.lower() not in ('mpjpe',):
+                raise KeyError(f'metric {m.lower()} is not supported')
+        results = self._evaluate_results(outputs, res_folder, lambda p: self.name2id[os.path.basename(p)])
+        return OrderedDict(self.do_python_keypoint_eval(results))
+
+    def do_python_keypoint_eval(self, results):
+        if isinstance(results, str):
+            if os.path.isdir(results):
+                results = os.path.join(results, 'result_keypoints.json')
+            with open(results) as f:
+                results = json.load(f)
+        images = []
+        for img_id in self.img_ids:
+            img = self.coco.load_imgs([img_id])[0]
+            parsed = self._parse_ann_info(img, self.coco.load_anns(self.coco.get_ann_ids(img_ids=[img_id])))
+            images.append(dict(image_id=img_id, cam=parsed['cam'], gt_poses_3d=parsed['gt_poses_3d']))
+        anns = list(self.coco.anns.values())
+        mpjpe = E.panoptic_mpjpe(results, images, [a['joints3d'] for a in anns], [a['joints3d_vis'] for a in anns],
+                                 self.num_joints, self.ROOT_IDX, self.norm_depth, self.abs_dz, self.depth_factor)
+        return [['MPJPE:', f'{mpjpe:.2f}mm']]
+
+
+@DATASETS.register_module()
+class MuPots3DHP(_PoseCocoDataset):
+    joint_num = 21          # MuCo-3DHP (training) joints; MuPoTS-3D annotates the first 17
+    joints_name = ('Head_top', 'Thorax', 'R_Shoulder', 'R_Elbow', 'R_Wrist', 'L_Shoulder', 'L_Elbow', 'L_Wrist', 'R_Hip',
+                   'R_Knee', 'R_Ankle', 'L_Hip', 'L_Knee', 'L_Ankle', 'Pelvis', 'Spine', 'Head', 'R_Hand', 'L_Hand',
+                   'R_Toe', 'L_Toe')
+    original_joints_name = joints_name[:17]
+    flip_pairs = ((2, 5), (3, 6), (4, 7), (8, 11), (9, 12), (10, 13))
+    JOINTS_DEF = {k: i for i, k in enumerate(original_joints_name)}
+    ROOT_IDX = joints_name.index('Pelvis')
+
+    def __init__(self, use_bbox_center=False, norm_depth=False, abs_dz=False, depth_factor=1, **kwargs):
+        super().__init__(**kwargs)
+        self.num_joints = len(self.JOINTS_DEF)
+        self.name2id = {self.coco.load_imgs([i])[0]['file_name']: i for i in self.img_ids}
+        self.use_bbox_center, self.norm_depth, self.depth_factor, self.abs_dz = use_bbox_center, norm_depth, depth_factor, abs_dz
+        if abs_dz:
+            assert norm_depth
+
+    def _parse_ann_info(self, img_info, ann_info):
+        """mupots_3dhp.py:67-175: pseudo camera from `intrinsic`, joints = [u, v, Z_cam]."""
+        intrinsic = img_info['intrinsic']
+        f, c = intrinsic[:2], intrinsic[2:]
+        cam = dict(K=np.array([[f[0], 0., c[0]], [0., f[1], c[1]]]), R=np.eye(3), t=np.zeros((3, 1)))
+        gt_bboxes, gt_labels, gt_poses_3d, gt_bboxes_ignore, centers2d, depths = [], [], [], [], [], []
+        for ann in ann_info:
+            if ann.get('ignore', False) or not self._box_ok(ann, img_info, need_area=False):
+                continue
+            x1, y1, w, h = ann['bbox']
+            bbox = [x1, y1, x1 + w, y1 + h]
+            if ann.get('iscrowd', False):
+                gt_bboxes_ignore.append(bbox)
+                continue
+            pose_img = np.array(ann['keypoints_img'], dtype=float)
+            pose_cam = np.array(ann['keypoints_cam'], dtype=float)
+            pose_3d = np.concatenate([pose_img, pose_cam[:, 2:]], axis=1)
+            pose_vis = ann['keypoints_vis']
+            if self.norm_depth:
+                pose_3d[:, 2] /= self.depth_factor
+                if self.abs_dz:
+                    abs_dz = pose_3d[:, 2] - pose_3d[[self.ROOT_IDX], 2]
+                pose_3d[:, 2] /= np.sqrt(f[0] * f[1])
+            center = pose_3d[self.ROOT_IDX].copy()
+            if pose_3d.max() - pose_3d.min() < 10:
+                continue
+            if not self.use_bbox_center:
+                if pose_vis[self.ROOT_IDX][0] == 0:
+                    gt_bboxes_ignore.append(bbox)
+                    continue
+                c2d = center
+            else:
+                c2d = center.copy()
+                c2d[0], c2d[1] = x1 + 0.5 * w, y1 + 0.5 * h
+            gt_bboxes.append(bbox)
+            gt_labels.append(self.cat2label[ann['category_id']])
+            if self.abs_dz:
+                pose_3d[:, 2] = abs_dz
+            gt_poses_3d.append(np.concatenate([np.array(c2d, dtype=float).reshape(-1), pose_3d.reshape(-1),
+                                               np.array(pose_vis, dtype=float).reshape(-1)]))
+            centers2d.append(c2d[:2])
+            depths.append(c2d[2])
+        ann = self._finish_targets(gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore)
+        ann['cam'] = cam
+        return ann
+
+    def evaluate(self, outputs, res_folder='tmp', metric='pck', eval_mode='all', **kwargs):
+        for m in (metric if isinstance(metric, list) else [metric]):
+            if m.lower() not in ('pck',):
+                raise KeyError(f'metric {m.lower()} is not supported')
+        root = self.data_root if self.data_root[-1] == '/' else self.data_root + '/'
+        results = self._evaluate_results(outputs, res_folder, lambda p: self.name2id[p.replace(root, '')], self.num_joints)
+        return OrderedDict(self.do_python_keypoint_eval(results, eval_mode=eval_mode))
+
+    def predictions_by_name(self, results):
+        """result records -> file name -> (P, 17, 3) camera-space predictions in mm (mupots_3dhp.py:289-322)."""
+        id2res = defaultdict(list)
+        for r in results:
+            id2res[r['image_id']].append(r)
+        name2pred = {}
+        for img_id in self.img_ids:
+            res = id2res[img_id]
+            img_info = self.coco.imgs[img_id]
+            cam = self._parse_ann_info(img_info, self.coco.load_anns(self.coco.get_ann_ids(img_ids=[img_id])))['cam']
+            f = np.sqrt(cam['K'][0, 0] * cam['K'][1, 1])
+            if len(res) == 0:
+                pred = np.zeros([1, self.num_joints, 3])
+            else:
+                pred_img = np.array([x['keypoints'] for x in res]).reshape(len(res), -1, 3)[:, :self.num_joints]
+                E.denormalise_depth(pred_img, f, self.ROOT_IDX, self.norm_depth, self.abs_dz, self.depth_factor)
+                pred = E.pixel2world(pred_img.reshape(-1, 3).T, cam['K'], cam['R'], cam['t'])[-1].T.reshape(pred_img.shape)
+            name2pred[img_info['file_name']] = pred
+        return name2pred
+
+    def do_python_keypoint_eval(self, results, eval_mode='all', sequences=range(20)):
+        if isinstance(results, str):
+            if os.path.isdir(results):
+                results = os.path.join(results, 'result_keypoints.json')
+            with open(results) as f:
+                results = json.load(f)
+        name2pred = self.predictions_by_name(results)
+        seq_err, seq_err_abs = [], []
+        for ts in sequences:      # (the reference forks one process per sequence; the work is a few ms each)
+            annots = E.load_mupots_annot(os.path.join(self.data_root, 'TS%d/annot.mat' % (ts + 1)))
+            pje, pje_abs = E.eval_mupots_sequence(annots, name2pred, ts, eval_mode)
+            seq_err.append(pje)
+            seq_err_abs.append(pje_abs)
+        pck, pck_abs = E.mupots_pck(seq_err, seq_err_abs)
+        return [('PCK_MEAN:', f'{pck:.2f}'), ('PCK_MEAN_ABS:', f'{pck_abs:.2f}')]

@@ -1,0 +1,77 @@
+"""das_amd's dataset classes / evaluators against fixtures produced by the REFERENCE's own
+dataset classes on the same seeded synthetic annotations and detections (tests/golden/make_golden_eval.py).
+CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import eval_cases as EC
+from das_amd import evaluation as E
+from das_amd.datasets import build_dataset
+from das_amd.pose_datasets import CMUPanopticDataset, MuPots3DHP
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+@pytest.mark.parametrize('tag,kw', [('abs', dict(norm_depth=True, abs_dz=True, depth_factor=1)),
+                                    ('df20', dict(norm_depth=True, abs_dz=False, depth_factor=20))])
+def test_panoptic_parse_and_mpjpe(golden_dir, tmp_path, tag, kw):
+    z = load(golden_dir, f'eval_panoptic_{tag}')
+    ann = EC.panoptic_annotation()
+    ds = CMUPanopticDataset(ann_file=ann, data_root='/data/panoptic', test_mode=True, **kw)
+    parsed = [ds.get_ann_info(i) for i in range(len(ds))]
+    for i, p in enumerate(parsed):          # _parse_ann_info: targets bit-identical to the reference's
+        np.testing.assert_array_equal(p['gt_poses_3d'], z[f'gt{i}'])
+        np.testing.assert_array_equal(p['centers2d'], z[f'c2d{i}'])
+        np.testing.assert_array_equal(p['bboxes_ignore'], z[f'ign{i}'])
+    assert parsed[0]['bboxes_ignore'].shape[0] == 1      # the person with an invisible root
+    outs = EC.panoptic_outputs(ann, [p['gt_poses_3d'] for p in parsed], depth_factor=kw['depth_factor'])
+    res = ds.evaluate(outs, res_folder=str(tmp_path))
+    assert list(res) == ['MPJPE:'] and res['MPJPE:'].endswith('mm')
+    assert abs(float(res['MPJPE:'][:-2]) - float(z['mpjpe'])) <= 0.011      # (the reference prints two decimals)
+    with open(tmp_path / 'result_keypoints.json') as f:
+        rec = json.load(f)
+    assert len(rec) == int(z['n_records'])
+    np.testing.assert_allclose(np.array([r['keypoints'] for r in rec]), z['rec_kpts'], rtol=1e-6)
+    np.testing.assert_allclose(np.array([r['bbox'] for r in rec]), z['rec_bbox'], rtol=1e-6)
+    np.testing.assert_array_equal(np.array([r['image_id'] for r in rec]), z['rec_img'])
+    assert set(rec[0]) == {'image_id', 'category_id', 'keypoints', 'score', 'bbox'}
+    # evaluation from the written file equals evaluation from memory (do_python_keypoint_eval accepts a folder)
+    assert ds.do_python_keypoint_eval(str(tmp_path))[0][1] == res['MPJPE:']
+    with pytest.raises(KeyError):
+        ds.evaluate(outs, res_folder=str(tmp_path), metric='pck')
+
+
+def test_mupots_parse_and_pck(golden_dir, tmp_path):
+    z = load(golden_dir, 'eval_mupots')
+    ann, mats = EC.mupots_annotation()
+    root = str(tmp_path / 'mupots')
+    EC.write_mupots_mats(root, mats)
+    ds = build_dataset(dict(type='MuPots3DHP', ann_file=ann, data_root=root, test_mode=True))
+    assert isinstance(ds, MuPots3DHP) and ds.num_joints == 17 and ds.ROOT_IDX == 14
+    np.testing.assert_array_equal(ds.get_ann_info(0)['gt_poses_3d'], z['gt0'])
+    np.testing.assert_array_equal(ds.get_ann_info(5)['gt_poses_3d'], z['gt5'])
+    outs = EC.mupots_outputs(ann, root)
+    for mode in ('all', 'matched'):
+        res = ds.evaluate(outs, res_folder=str(tmp_path / mode), eval_mode=mode)
+        ref = z[f'pck_{mode}']
+        assert abs(float(res['PCK_MEAN:']) - ref[0]) <= 0.011 and abs(float(res['PCK_MEAN_ABS:']) - ref[1]) <= 0.011, (res, ref)
+
+
+def test_mupots_helpers_vs_reference(golden_dir):
+    z = load(golden_dir, 'eval_mupots')
+    rs = np.random.RandomState(9)
+    a, b = rs.normal(0, 200, (3, 17)), rs.normal(0, 200, (3, 17))
+    np.testing.assert_allclose(E.procrustes(a.copy(), b.copy()), z['procrustes'], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(E.norm_by_bone_length(a.copy(), b.copy(), E.MPII_O1, E.SAFE_TRAVERSAL[1:]), z['bone'],
+                               rtol=1e-12)
+    # camera helpers invert each other (mytools/vis_3d.py)
+    K = np.array([[1400.0, 0, 960.0], [0, 1390.0, 540.0], [0, 0, 1]])
+    R, t = np.eye(3), np.array([[10.0], [-5.0], [300.0]])
+    X = rs.normal(0, 50, (3, 9))
+    back = E.pixel2world(E.world2pixel(X.copy(), K, R, t), K, R, t)[-1]
+    np.testing.assert_allclose(back, X, atol=2e-2)       # (world2pixel divides by z + 1e-5)

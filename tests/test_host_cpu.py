@@ -140,3 +140,70 @@ def test_synthetic_dataset_layout():
     assert float(root_dz.abs().max()) == 0.0
     b = collate([ds[0], ds[1]])
     assert b['img'].shape == (2, 3, 64, 96) and len(b['gt_poses_3d']) == 2
+
+
+def _resnet50_like_checkpoint(seed=0):
+    """A ResNet-50 classification checkpoint in the torchvision / MMPose key layout (conv1, bn1, layerL.b.convK,
+    layerL.0.downsample.{0,1}) with random values."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {'conv1.weight': torch.randn(64, 3, 7, 7, generator=g)}
+    for n in ('weight', 'bias', 'running_mean', 'running_var'):
+        sd[f'bn1.{n}'] = torch.rand(64, generator=g) + 0.5
+    inp = 64
+    for L, (blocks, mid) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512)), 1):
+        for b in range(blocks):
+            cin = inp if b == 0 else mid * 4
+            for name, shape in (('conv1', (mid, cin, 1, 1)), ('conv2', (mid, mid, 3, 3)), ('conv3', (mid * 4, mid, 1, 1))):
+                sd[f'layer{L}.{b}.{name}.weight'] = torch.randn(*shape, generator=g) * 0.05
+            for i, c in ((1, mid), (2, mid), (3, mid * 4)):
+                for n in ('weight', 'bias', 'running_mean', 'running_var'):
+                    sd[f'layer{L}.{b}.bn{i}.{n}'] = torch.rand(c, generator=g) + 0.5
+            if b == 0:
+                sd[f'layer{L}.0.downsample.0.weight'] = torch.randn(mid * 4, cin, 1, 1, generator=g) * 0.05
+                for n in ('weight', 'bias', 'running_mean', 'running_var'):
+                    sd[f'layer{L}.0.downsample.1.{n}'] = torch.rand(mid * 4, generator=g) + 0.5
+        inp = mid * 4
+    sd['fc.weight'] = torch.randn(1000, 2048, generator=g)
+    return sd
+
+
+def test_mspn2_init_weights_resnet_remap(tmp_path):
+    """mspn_mmpose.py:694-721: a ResNet-50 checkpoint lands on the stem and on EVERY stage's downsample module
+    (downsample.0 -> downsample.conv, downsample.1 -> downsample.bn, conv1 -> top.0.conv, bn1 -> top.0.bn), with
+    `module.` / `backbone.` prefixes stripped; the upsample modules keep their kaiming initialisation."""
+    import das_amd
+    sd = _resnet50_like_checkpoint()
+    path = str(tmp_path / 'resnet50.pth')
+    torch.save({'state_dict': {'module.backbone.' + k: v for k, v in sd.items()}}, path)
+    m = das_amd.MSPN2(unit_channels=256, num_stages=2, num_blocks=[3, 4, 6, 3], pretrained=path)
+    report = m.init_weights()
+    assert all(not r.missing_keys for r in report[1:]), report[1].missing_keys[:5]    # every downsample key was covered
+    msd = m.state_dict()
+    assert torch.equal(msd['top.top.0.conv.weight'], sd['conv1.weight'])
+    assert torch.equal(msd['top.top.0.bn.running_var'], sd['bn1.running_var'])
+    for s in range(2):
+        pre = f'multi_stage_mspn.{s}.downsample.'
+        assert torch.equal(msd[pre + 'layer1.0.conv1.weight'], sd['layer1.0.conv1.weight'])
+        assert torch.equal(msd[pre + 'layer3.5.conv2.weight'], sd['layer3.5.conv2.weight'])
+        assert torch.equal(msd[pre + 'layer4.0.downsample.conv.weight'], sd['layer4.0.downsample.0.weight'])
+        assert torch.equal(msd[pre + 'layer2.0.downsample.bn.running_mean'], sd['layer2.0.downsample.1.running_mean'])
+    up = msd['multi_stage_mspn.0.upsample.up1.in_skip.conv.weight']
+    assert abs(float(up.std()) - (2.0 / 256) ** 0.5) < 0.02                  # kaiming fan_out of a 1x1 2048 -> 256 conv
+    with pytest.raises(FileNotFoundError):
+        das_amd.MSPN2(num_stages=1, num_blocks=[1, 1, 1, 1], pretrained='nowhere.pth').init_weights()
+
+
+def test_mspn2_init_weights_detector_checkpoint(tmp_path, monkeypatch):
+    """mspn_mmpose.py:672-680: a `weights/...` path is a detector / MSPN checkpoint whose `backbone.` keys load by name."""
+    import das_amd
+    src = das_amd.MSPN2(unit_channels=16, num_stages=2, num_blocks=[1, 1, 1, 1])
+    src.init_weights()
+    os.makedirs(tmp_path / 'weights')
+    torch.save({'state_dict': {'backbone.' + k: v for k, v in src.state_dict().items()} | {'keypoint_head.x': torch.zeros(1)}},
+               str(tmp_path / 'weights' / 'mspn.pth'))
+    monkeypatch.chdir(tmp_path)
+    dst = das_amd.MSPN2(unit_channels=16, num_stages=2, num_blocks=[1, 1, 1, 1], pretrained='weights/mspn.pth')
+    rep = dst.init_weights()
+    assert not rep.missing_keys and not rep.unexpected_keys
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst.state_dict()[k]), k
