@@ -25,6 +25,7 @@ struct ConvP {
   int up_sh;  // log2 of the input zero-upsampling factor (dgrad of a strided conv): tap coordinate t
               // reads x[t >> up_sh] when t is a multiple of 1 << up_sh, else contributes zero
   int M, K, HoWo, ntiles, nblocks;
+  int m_base;       // first output row of this launch's tile 0 (a conv may be covered by two launches: see launch_bn)
   unsigned xbytes;  // addressable bytes of x from its base (0 if >= 4 GiB): range of the buffer descriptor
   // Fused BatchNorm-backward reduction (data-gradient launches, DasConvDesc.bnb_*): the value about to be stored,
   // g = conv + residual, is the gradient wrt the OUTPUT of a train-mode BatchNorm (+ReLU) layer whose pre-norm

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_reg_kernel(ConvP p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
   const int n0 = (logical % p.ntiles) * BN;
-  const int m0 = (logical / p.ntiles) * BM;
+  const int m0 = p.m_base + (logical / p.ntiles) * BM;
   const int wave_m0 = Tiling<BN>::wave_m0(wave), wave_n0 = Tiling<BN>::wave_n0(wave);
 
   const int srow = tid >> 2, kg = tid & 3;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
   const int n0 = (logical % p.ntiles) * BN;
-  const int m0 = (logical / p.ntiles) * BMT;
+  const int m0 = p.m_base + (logical / p.ntiles) * BMT;
   const int wave_m0 = Tiling<BN, BMT>::wave_m0(wave), wave_n0 = Tiling<BN, BMT>::wave_n0(wave);
 
   // ---- DMA coordinates: chunk c covers LDS rows c*8..c*8+7; lane -> (row, physical slot)
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
   const int n0 = (logical % p.ntiles) * BN;
-  const int m0 = (logical / p.ntiles) * BMT;
+  const int m0 = p.m_base + (logical / p.ntiles) * BMT;
   const int wave_m0 = (wave & 3) * 64, wave_n0 = (wave >> 2) * 64;
 
   // Operands are fetched with `buffer_load_dwordx4 ... offen lds`: 32-bit byte offsets against a buffer
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
   const int n0 = (logical % p.ntiles) * BN;
-  const int m0 = (logical / p.ntiles) * BMT;
+  const int m0 = p.m_base + (logical / p.ntiles) * BMT;
   const int wave_m0 = Tiling<BN, BMT>::wave_m0(wave), wave_n0 = Tiling<BN, BMT>::wave_n0(wave);
 
   const int lrow = lane >> 2, pslot = lane & 3;
@@ -566,19 +566,51 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
 }
 
 // =============================================================== launch
+inline int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = n > 0 ? n : 256;
+  }
+  return cus;
+}
+// The 256-row tile kernels run one workgroup per CU, so a launch is a sequence of rounds of `cus` tiles and a last round
+// that is, e.g., 8 % full (277 tiles on 256 CUs: the B = 8 head convs of the inference workload) costs a whole round.
+// If the last round would be under half full, its pixel rows are left to a second launch on 128-row tiles
+// (4 x the workgroups, two per CU): returns the number of 256-row M tiles the main launch keeps (== mtiles: no split).
+inline long long tail_split_mtiles(long long mtiles, int ntiles, bool allowed) {
+  const long long cus = device_cus(), nb = mtiles * ntiles, rem = nb % cus;
+  if (!allowed || dastune::get(dastune::CONV_TAIL_SPLIT) != 1 || nb <= cus || rem == 0 || rem * 2 > cus) return mtiles;
+  const long long keep = (nb - rem) / ntiles;
+  return keep >= 1 && keep < mtiles ? keep : mtiles;
+}
+
 template <typename T, typename OT, int BN>
-int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
+int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_split = true) {
   ConvP p = p0;
   p.ntiles = (p.Cout + BN - 1) / BN;
   // 256-row tiles (8 waves, weight tile shared by twice the pixels) once they still fill the chip twice over
   // (cold operands, tools/dev/conv_cold_bench.py: 104 tiles of 256 x 128 on 256 CUs still beat 208 of 128 x 128 by
   // 18...22 % on the 3x3 layers of the 32x52 / 16x26 stages — the 3-stage pipeline matters more than the fill)
   const long long mink = dastune::get(dastune::CONV_BIG_MINK), minb = dastune::get(dastune::CONV_BIG_MINBLOCKS);
-  const bool big = glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((p.M + 255) / 256) * p.ntiles >= minb &&
+  const int rows = p.M - p.m_base;   // rows of this launch
+  const bool big = may_split && glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((rows + 255) / 256) * p.ntiles >= minb &&
                    p.K >= mink &&
                    p.xbytes != 0;  // (0 = more than 4 GiB of input: not addressable by 32-bit buffer offsets)
   const int bm = big ? 256 : BM;
-  const int mtiles = (p.M + bm - 1) / bm;
+  int mtiles = (rows + bm - 1) / bm;
+  if (big) {
+    const long long keep = tail_split_mtiles(mtiles, p.ntiles, may_split);
+    if (keep < mtiles) {   // rows of the under-filled last round: 128-row tiles, second launch
+      ConvP tail = p0;
+      tail.m_base = p0.m_base + (int)keep * 256;
+      const int rc = launch<T, OT, BN>(tail, glds, aligned, s, false);
+      if (rc != DAS_OK) return rc;
+      p.M = tail.m_base;
+      mtiles = (int)keep;
+    }
+  }
   p.nblocks = p.ntiles * mtiles;
   const size_t sm_reg = std::max<size_t>(2 * (size_t)(BM + BN) * 64, epilogue_smem_bytes<OT, BN>());
   const size_t sm_glds = std::max<size_t>(2 * (size_t)(BM + BN) * 128, epilogue_smem_bytes<OT, BN>());
@@ -980,7 +1012,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
 
 // 256 x 256 tile kernel: bf16 in / bf16 out, Cout >= 256, Cin % 32 == 0, enough tiles to cover the chip
 template <typename T, typename OT>
-bool try_launch4(const ConvP& p0, hipStream_t s) {
+bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   if constexpr (sizeof(T) == 2 && sizeof(OT) == 2) {
     const long long minblocks = dastune::get(dastune::CONV_GLDS4_MINBLOCKS);  // default: half a chip of 256 x 256 tiles (measured break-even)
     ConvP p = p0;
@@ -988,7 +1020,14 @@ bool try_launch4(const ConvP& p0, hipStream_t s) {
     const long long nb = (long long)((p.M + 255) / 256) * p.ntiles;
     if (minblocks <= 0 || p.Cout < 256 || p.Cin % 32 || p.relu_in || p.up_sh != 0 || p.xbytes == 0 || nb < minblocks)
       return false;
-    p.nblocks = (int)nb;
+    const long long mtiles = (p.M + 255) / 256, keep = tail_split_mtiles(mtiles, p.ntiles, true);
+    if (keep < mtiles) {   // rows of the under-filled last round: 128 x 128 tiles, second launch
+      ConvP tail = p0;
+      tail.m_base = (int)keep * 256;
+      if (launch<T, OT, 128>(tail, glds, aligned, s, false) != DAS_OK) return false;
+      p.M = tail.m_base;
+    }
+    p.nblocks = (int)(keep * p.ntiles);
     const size_t sm4 = std::max<size_t>(4 * (size_t)(256 + 256) * 64, epilogue_smem_bytes<OT, 256, 256>());
     static bool attr_set = false;
     if (!attr_set) {
@@ -1020,7 +1059,7 @@ int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
       return DAS_OK;
     }
   }
-  if (try_launch4<T, OT>(p, s)) {
+  if (try_launch4<T, OT>(p, glds, aligned, s)) {
     DAS_CHECK_LAUNCH();
     return DAS_OK;
   }
@@ -1065,7 +1104,7 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   if (d->in_up == 2 && (d->stride != 1 || p.nlev > 1)) return DAS_ERR_ARG;
   p.up_sh = d->in_up == 2 ? 1 : 0;
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
-  p.ntiles = p.nblocks = 0;
+  p.ntiles = p.nblocks = 0; p.m_base = 0;
   p.bnb_raw = (const char*)d->bnb_raw; p.bnb_y = (const char*)d->bnb_y;
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta;
   p.bnb_relu = d->bnb_relu; p.bnb_ps = d->bnb_pix_stride;

@@ -13,6 +13,8 @@ enum Key {
   CONV_GLDS4_PP,         // -1 = ping-pong schedule for K >= 256, 0 / 1 force the choice
   CONV_STREAM_MINROWS,   // conv1x1_stream_kernel from this many pixel rows up; 0 disables the kernel
   CONV_STREAM_PERCU,     // ... workgroups per CU of its persistent grid
+  CONV_TAIL_SPLIT,       // 1: a 256-row-tile launch whose last round of workgroups would be under half full hands the
+                         // rows of that round to the 128-row tile kernel (second launch)
   CONV_GLDS8_MINBLOCKS,  // conv_glds8_kernel (256 x 256 tile, K-steps of 64, 8 phases); 0 disables the kernel
   WGRAD_PP_MINK,         // conv_wgrad_pp_kernel for K >= this (and Cout >= 256); 0 disables the kernel
   WGRAD_BKM,             // pixel rows per step of conv_wgrad_kernel<bf16>: 32 or 64

@@ -201,6 +201,33 @@ def test_head_ragged_real_size():
     np.testing.assert_allclose(nchw(y.level(0)[-1:]).numpy(), ref0.numpy(), **TOL)
 
 
+def test_tail_split_head_conv_at_inference_batch():
+    """B = 8 head conv: 277 tiles of 256 x 256 on 256 CUs -> the 21 tiles of the second round go to 128-row tiles in a
+    second launch (conv.tail_split). Same values as the single launch; spot-checked against the CPU reference in the rows
+    either launch owns."""
+    o = ops()
+    B, Cc = 8, 256
+    sizes = [(64, 104), (32, 52), (16, 26), (8, 13)]
+    w = cases.randn(190, Cc, Cc, 3, 3) / (9 * Cc) ** 0.5
+    xs = [cases.randn(191 + i, B, Cc, h, ww) for i, (h, ww) in enumerate(sizes)]
+    rag = o.Ragged.from_levels([nhwc(t) for t in xs])
+    assert (rag.rows + 255) // 256 == 277
+    wq = o.pack_weight(w.to(DEV), BF)
+    stats = torch.zeros(16 * 2 * Cc, device=DEV)
+    y = o.conv2d(rag, wq, 3, 3, 1, 1, stats=stats)
+    assert o.last_kernel() == 'conv_glds4_kernel<pp>'
+    with o.tuning(**{'conv.tail_split': 0}):
+        stats1 = torch.zeros(16 * 2 * Cc, device=DEV)
+        y1 = o.conv2d(rag, wq, 3, 3, 1, 1, stats=stats1)
+    np.testing.assert_allclose(y.data.float().cpu().numpy(), y1.data.float().cpu().numpy(), rtol=8e-3, atol=8e-3)
+    np.testing.assert_allclose(stats.view(16, -1).sum(0).cpu().numpy() / rag.rows, stats1.view(16, -1).sum(0).cpu().numpy() / rag.rows,
+                               rtol=1e-3, atol=1e-4)
+    torch.set_num_threads(8)
+    for l in (3, 2, 1):            # levels 1-3 are the last rows: the tail launch owns levels 2, 3 and the end of level 1
+        np.testing.assert_allclose(nchw(y.level(l)).numpy(), conv_ref(xs[l], w, 1, 1).numpy(), **TOL)
+    np.testing.assert_allclose(nchw(y.level(0)[:1]).numpy(), conv_ref(xs[0][:1], w, 1, 1).numpy(), **TOL)
+
+
 WGRAD_REAL = [
     # B, H, W, Cin, Cout, k, stride, pad, expected kernel
     (2, 128, 208, 64, 64, 3, 1, 1, 'conv_wgrad_kernel'),        # 5 tiles x 153 splits = 765 workgroups
