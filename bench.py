@@ -409,6 +409,8 @@ def main():
     ap.add_argument('--wgrad-batch', type=int, default=None, help='A/B: weight gradients per batched launch (1 = off)')
     ap.add_argument('--no-fused-bn', action='store_true',
                     help='A/B: one autograd node per conv+BN unit (separate BatchNorm-backward reduction passes)')
+    ap.add_argument('--tune', nargs='*', default=[], metavar='KEY=VALUE',
+                    help='A/B: dispatch thresholds through das_tuning_set, e.g. conv.tail_split=0')
     ap.add_argument('--share-gpu', action='store_true',
                     help='testing only: run all ranks on cuda:0 with the gloo transport (not a measurement)')
     args = ap.parse_args()
@@ -449,6 +451,10 @@ def main():
 
     from das_amd import autograd as ag, backbones, ops
     from das_amd.datasets import SyntheticPoseDataset, collate
+    for kv in args.tune:
+        k, v = kv.split('=')
+        from das_amd import _lib
+        _lib.check(_lib.load().das_tuning_set(k.encode(), int(v)), f'das_tuning_set({k})')
     if args.no_wgrad_stream:
         ag.WGRAD_SIDE_STREAM = False
     if args.wgrad_streams:

@@ -10,10 +10,40 @@
 namespace {
 constexpr int TPB = 1024;
 constexpr int LDS_KEYS = 16384;  // max locations of one level (128 KiB of u64 keys)
+constexpr int SUP_LDS = 4096;    // suppression flags of the candidates, behind the keys in LDS
+// Greedy OKS-NMS, two ways. Up to PAIR_MAX candidates (the usual case: ~150 pass the score threshold) every pair's
+// "iou > thr" is evaluated up front, one thread per pair — the f64 exp chain of a pair is the cost, 15-21 of them, and
+// evaluating them inside the greedy loop keeps 150 of 1024 threads busy for up to nms_post sequential rounds (250 us of
+// a 458 us launch at B = 8); the loop itself then only ORs one row of a byte matrix per kept pose. More candidates:
+// the round-by-round form (a matrix of cap^2 would not pay).
+constexpr int PAIR_MAX = 768;
 
 __host__ __device__ inline long long ws_bytes_per_image(int cap, int J) {
-  long long per = (long long)cap * 8 + (long long)cap * J * 4 * 3 + (long long)cap * 4 + (long long)cap * 12 + cap;
+  const long long pm = (long long)(cap < PAIR_MAX ? cap : PAIR_MAX);
+  long long per = (long long)cap * 8 + (long long)cap * J * 4 * 3 + (long long)cap * 4 + (long long)cap * 12 + cap + pm * pm;
   return (per + 255) / 256 * 256;
+}
+
+// pose_nms.py:51-90 for one pair: f64 arithmetic as numpy does, the mean rounded to f32 before the compare
+__device__ __forceinline__ bool oks_above(const float* kx, const float* ky, const float* area, int a, int c, int J,
+                                          float thr32) {
+#pragma clang fp contract(off)
+  const double denom = (double)((area[a] + area[c]) / 2.f) + 2.220446049250313e-16;
+  double acc = 0.0;
+  for (int j = 0; j < J; ++j) {
+    const float dx = kx[(size_t)c * J + j] - kx[(size_t)a * J + j];
+    const float dy = ky[(size_t)c * J + j] - ky[(size_t)a * J + j];
+    double var = 0.0256;  // (0.08*2)^2
+    if (J == 17) {
+      const double sg[17] = {.026, .025, .025, .035, .035, .079, .079, .072, .072, .062, .062, .107, .107, .087,
+                             .087, .089, .089};
+      var = (sg[j] * 2) * (sg[j] * 2);
+    }
+    const double e = (double)(dx * dx + dy * dy) / var / denom / 2.0;
+    acc += exp(-e);
+  }
+  const float iou = (float)(acc / (double)J);
+  return !(iou <= thr32);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -52,7 +82,8 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   float* kz = ky + (size_t)cap * J;
   float* area = kz + (size_t)cap * J;
   float* cen = area + cap;
-  unsigned char* sup = reinterpret_cast<unsigned char*>(cen + (size_t)cap * 3);
+  unsigned char* pairm = reinterpret_cast<unsigned char*>(cen + (size_t)cap * 3) + cap;   // [total][total] (<= PAIR_MAX^2)
+  unsigned char* sup = reinterpret_cast<unsigned char*>(smem) + (size_t)LDS_KEYS * 8;          // [cap <= SUP_LDS], LDS
 
   int total = 0, point_base = 0;
   for (int l = 0; l < d.num_levels; ++l) {
@@ -121,8 +152,20 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   if (tid == 0) s_kept = 0;
   __syncthreads();
 
-  // ---- greedy OKS-NMS (pose_nms.py:92-126), f64 arithmetic as numpy does, f32 compare
+  // ---- greedy OKS-NMS (pose_nms.py:92-126)
   const float thr32 = d.nms_thr;
+  const bool pairwise = total <= PAIR_MAX;   // (uniform over the workgroup)
+  if (pairwise && total > 1) {
+    // the upper triangle folded into a (total + 1) / 2 x total rectangle: (r, c > r) as is, (r, c < r) mirrored
+    const int n = total, half = (n + 1) / 2;
+    for (int idx = tid; idx < half * n; idx += TPB) {
+      int r = idx / n, c = idx - r * n;
+      if (c == r) continue;
+      if (c < r) { r = n - 1 - r; c = n - 1 - c; }
+      pairm[(size_t)r * n + c] = oks_above(kx, ky, area, r, c, J, thr32) ? 1 : 0;
+    }
+    __syncthreads();
+  }
   int cur = 0;
   while (true) {
     if (tid == 0) {
@@ -135,25 +178,14 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
     __syncthreads();
     const int sel = s_sel;
     if (sel < 0) break;
-    const float ag = area[sel];
-    for (int c = sel + 1 + tid; c < total; c += TPB) {
-      if (sup[c]) continue;
-      const double denom = (double)((ag + area[c]) / 2.f) + 2.220446049250313e-16;
-      double acc = 0.0;
-      for (int j = 0; j < J; ++j) {
-        const float dx = kx[(size_t)c * J + j] - kx[(size_t)sel * J + j];
-        const float dy = ky[(size_t)c * J + j] - ky[(size_t)sel * J + j];
-        double var = 0.0256;  // (0.08*2)^2
-        if (J == 17) {
-          const double sg[17] = {.026, .025, .025, .035, .035, .079, .079, .072, .072, .062, .062, .107, .107, .087,
-                                 .087, .089, .089};
-          var = (sg[j] * 2) * (sg[j] * 2);
-        }
-        const double e = (double)(dx * dx + dy * dy) / var / denom / 2.0;
-        acc += exp(-e);
+    if (pairwise) {
+      for (int c = sel + 1 + tid; c < total; c += TPB)
+        if (pairm[(size_t)sel * total + c]) sup[c] = 1;
+    } else {
+      for (int c = sel + 1 + tid; c < total; c += TPB) {
+        if (sup[c]) continue;
+        if (oks_above(kx, ky, area, sel, c, J, thr32)) sup[c] = 1;
       }
-      const float iou = (float)(acc / (double)J);
-      if (!(iou <= thr32)) sup[c] = 1;
     }
     cur = sel + 1;
     __syncthreads();
@@ -203,8 +235,8 @@ extern "C" int das_decode(const DasDecodeDesc* d, float* out_scores, float* out_
   for (int l = 0; l < d->num_levels; ++l)
     if (d->H[l] * d->W[l] > LDS_KEYS || !d->cls[l] || !d->ctr[l] || !d->pose[l]) return DAS_ERR_ARG;
   const int cap = das_decode_cap(d);
-  if (cap > LDS_KEYS) return DAS_ERR_ARG;
-  const int lds = LDS_KEYS * 8;
+  if (cap > LDS_KEYS || cap > SUP_LDS) return DAS_ERR_ARG;
+  const int lds = LDS_KEYS * 8 + SUP_LDS;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
