@@ -14,13 +14,13 @@ constexpr int SUP_LDS = 4096;    // suppression flags of the candidates, behind 
 // Greedy OKS-NMS, two ways. Up to PAIR_MAX candidates (the usual case: ~150 pass the score threshold) every pair's
 // "iou > thr" is evaluated up front, one thread per pair — the f64 exp chain of a pair is the cost, 15-21 of them, and
 // evaluating them inside the greedy loop keeps 150 of 1024 threads busy for up to nms_post sequential rounds (250 us of
-// a 458 us launch at B = 8); the loop itself then only ORs one row of a byte matrix per kept pose. More candidates:
-// the round-by-round form (a matrix of cap^2 would not pay).
+// a 458 us launch at B = 8). The result is a bit matrix in LDS, and the greedy walk is done by ONE wave that keeps the
+// suppressed set in registers (a word per lane) and ORs one matrix row per kept pose: no workgroup barrier per round.
+// More candidates: the round-by-round form (a matrix of cap^2 would not pay).
 constexpr int PAIR_MAX = 768;
 
 __host__ __device__ inline long long ws_bytes_per_image(int cap, int J) {
-  const long long pm = (long long)(cap < PAIR_MAX ? cap : PAIR_MAX);
-  long long per = (long long)cap * 8 + (long long)cap * J * 4 * 3 + (long long)cap * 4 + (long long)cap * 12 + cap + pm * pm;
+  long long per = (long long)cap * 8 + (long long)cap * J * 4 * 3 + (long long)cap * 4 + (long long)cap * 12 + cap;
   return (per + 255) / 256 * 256;
 }
 
@@ -82,7 +82,6 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   float* kz = ky + (size_t)cap * J;
   float* area = kz + (size_t)cap * J;
   float* cen = area + cap;
-  unsigned char* pairm = reinterpret_cast<unsigned char*>(cen + (size_t)cap * 3) + cap;   // [total][total] (<= PAIR_MAX^2)
   unsigned char* sup = reinterpret_cast<unsigned char*>(smem) + (size_t)LDS_KEYS * 8;          // [cap <= SUP_LDS], LDS
 
   int total = 0, point_base = 0;
@@ -155,40 +154,70 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   // ---- greedy OKS-NMS (pose_nms.py:92-126)
   const float thr32 = d.nms_thr;
   const bool pairwise = total <= PAIR_MAX;   // (uniform over the workgroup)
-  if (pairwise && total > 1) {
-    // the upper triangle folded into a (total + 1) / 2 x total rectangle: (r, c > r) as is, (r, c < r) mirrored
-    const int n = total, half = (n + 1) / 2;
+  if (pairwise) {
+    // "suppresses" bit matrix in LDS: only keys[0 .. total) are still needed, the rest of the key array is free.
+    // Row r = candidates c > r with oks(r, c) > thr, W words per row.
+    const int n = total, W = (n + 31) >> 5, half = (n + 1) / 2;
+    unsigned* pm = reinterpret_cast<unsigned*>(smem + PAIR_MAX * 8);          // [n][W] <= 768 * 24 * 4 = 72 KiB
+    for (int i = tid; i < n * W; i += TPB) pm[i] = 0u;
+    __syncthreads();
+    // the upper triangle folded into a (n + 1) / 2 x n rectangle: (r, c > r) as is, (r, c < r) mirrored; one thread per
+    // pair evaluates its f64 exp chain (the whole cost of the NMS)
     for (int idx = tid; idx < half * n; idx += TPB) {
       int r = idx / n, c = idx - r * n;
       if (c == r) continue;
-      if (c < r) { r = n - 1 - r; c = n - 1 - c; }
-      pairm[(size_t)r * n + c] = oks_above(kx, ky, area, r, c, J, thr32) ? 1 : 0;
+      const bool mirrored = c < r;
+      if (mirrored) { r = n - 1 - r; c = n - 1 - c; }
+      if (mirrored && (n & 1) && r == half - 1) continue;   // (middle row of an odd n: already covered un-mirrored)
+      if (oks_above(kx, ky, area, r, c, J, thr32)) atomicOr(&pm[r * W + (c >> 5)], 1u << (c & 31));
     }
     __syncthreads();
-  }
-  int cur = 0;
-  while (true) {
-    if (tid == 0) {
-      int s = cur;
-      while (s < total && sup[s]) ++s;
-      s_sel = (s < total && s_kept < d.nms_post) ? s : -1;
-      if (s_sel >= 0) out_index[(size_t)b * d.nms_post + s_kept] = s_sel;  // slot id, remapped below
-      if (s_sel >= 0) ++s_kept;
+    // the greedy walk: ONE wave, no workgroup barriers; lane w keeps word w of the suppressed set
+    if (tid < 64) {
+      unsigned supw = 0u;
+      int kept = 0, cur = 0;
+      while (kept < d.nms_post) {
+        // first candidate >= cur that is not suppressed
+        unsigned avail = 0u;
+        if (tid < W) {
+          avail = ~supw;
+          const int lo = tid << 5;
+          if (cur > lo) avail &= (cur - lo >= 32) ? 0u : ~((1u << (cur - lo)) - 1u);
+          if (lo + 32 > n) avail &= (n - lo <= 0) ? 0u : ((n - lo >= 32) ? ~0u : ((1u << (n - lo)) - 1u));
+        }
+        const unsigned long long has = __ballot(avail != 0u);
+        if (has == 0ull) break;
+        const int wsel = __ffsll((long long)has) - 1;
+        const unsigned aw = (unsigned)__shfl((int)avail, wsel, 64);
+        const int sel = (wsel << 5) + (__ffs((int)aw) - 1);
+        if (tid == 0) out_index[(size_t)b * d.nms_post + kept] = sel;  // slot id, remapped below
+        ++kept;
+        if (tid < W) supw |= pm[sel * W + tid];
+        cur = sel + 1;
+      }
+      if (tid == 0) s_kept = kept;
     }
     __syncthreads();
-    const int sel = s_sel;
-    if (sel < 0) break;
-    if (pairwise) {
-      for (int c = sel + 1 + tid; c < total; c += TPB)
-        if (pairm[(size_t)sel * total + c]) sup[c] = 1;
-    } else {
+  } else {
+    int cur = 0;
+    while (true) {
+      if (tid == 0) {
+        int s = cur;
+        while (s < total && sup[s]) ++s;
+        s_sel = (s < total && s_kept < d.nms_post) ? s : -1;
+        if (s_sel >= 0) out_index[(size_t)b * d.nms_post + s_kept] = s_sel;  // slot id, remapped below
+        if (s_sel >= 0) ++s_kept;
+      }
+      __syncthreads();
+      const int sel = s_sel;
+      if (sel < 0) break;
       for (int c = sel + 1 + tid; c < total; c += TPB) {
         if (sup[c]) continue;
         if (oks_above(kx, ky, area, sel, c, J, thr32)) sup[c] = 1;
       }
+      cur = sel + 1;
+      __syncthreads();
     }
-    cur = sel + 1;
-    __syncthreads();
   }
 
   // ---- emit survivors in kept order
