@@ -121,44 +121,89 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   __syncthreads();
   if (total > 1) bitonic_sort_desc(keys, P);
 
-  // ---- gather + affine per candidate (das_head.py:725-743)
+  // ---- gather + affine per candidate (das_head.py:725-743): 32 lanes per candidate, lane j = joint j (a thread per
+  // candidate walking its joints pays one memory round trip per joint: 40 us of the launch at J = 21)
   const float sx = d.scale_factor[b * 2], sy = d.scale_factor[b * 2 + 1];
   const float zs = sqrtf(sx * sy);
-  for (int c = tid; c < total; c += TPB) {
-    const unsigned flat = ~(unsigned)(keys[c] & 0xffffffffull);
-    int l = 0, base = 0;
-    while (l + 1 < d.num_levels && (int)flat >= base + d.H[l] * d.W[l]) { base += d.H[l] * d.W[l]; ++l; }
-    const int loc = (int)flat - base, Wl = d.W[l];
-    const int st = d.stride[l];
-    const float ptx = (float)((loc % Wl) * st + st / 2), pty = (float)((loc / Wl) * st + st / 2);
-    const float* pp = d.pose[l] + ((size_t)b * d.H[l] * Wl + loc) * d.pose_ps[l];
-    const float depth = pp[2] * zs;
-    cen[c * 3 + 0] = (ptx - pp[0]) / sx;
-    cen[c * 3 + 1] = (pty - pp[1]) / sy;
-    cen[c * 3 + 2] = depth;
-    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-    for (int j = 0; j < J; ++j) {
-      const float x = (pp[3 + 3 * j] + ptx) / sx, y = (pp[4 + 3 * j] + pty) / sy;
-      kx[(size_t)c * J + j] = x;
-      ky[(size_t)c * J + j] = y;
-      kz[(size_t)c * J + j] = pp[5 + 3 * j] + depth;
-      mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
-      mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+  // NMS operands in LDS when they fit behind the keys (the usual ~150 candidates do): keys[0 .. total) | pair bit
+  // matrix [n][W] | x [n][J] | y [n][J] | area [n]
+  const int nW = (total + 31) >> 5;
+  const size_t pm_off = (size_t)PAIR_MAX * 8, xy_off = pm_off + (size_t)total * nW * 4;
+  const bool pairwise = total <= PAIR_MAX && J <= 32 &&
+                        xy_off + (size_t)total * J * 8 + (size_t)total * 4 <= (size_t)LDS_KEYS * 8;   // (uniform)
+  float* skx = reinterpret_cast<float*>(smem + xy_off);
+  float* sky = skx + (size_t)total * J;
+  float* sarea = sky + (size_t)total * J;
+  if (J <= 32) {
+    const int sub = tid & 31;
+    for (int c = tid >> 5; c < total; c += TPB / 32) {
+      const unsigned flat = ~(unsigned)(keys[c] & 0xffffffffull);
+      int l = 0, base = 0;
+      while (l + 1 < d.num_levels && (int)flat >= base + d.H[l] * d.W[l]) { base += d.H[l] * d.W[l]; ++l; }
+      const int loc = (int)flat - base, Wl = d.W[l];
+      const int st = d.stride[l];
+      const float ptx = (float)((loc % Wl) * st + st / 2), pty = (float)((loc / Wl) * st + st / 2);
+      const float* pp = d.pose[l] + ((size_t)b * d.H[l] * Wl + loc) * d.pose_ps[l];
+      const float depth = pp[2] * zs;
+      if (sub < 3) cen[c * 3 + sub] = sub == 0 ? (ptx - pp[0]) / sx : sub == 1 ? (pty - pp[1]) / sy : depth;
+      float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+      if (sub < J) {
+        const float x = (pp[3 + 3 * sub] + ptx) / sx, y = (pp[4 + 3 * sub] + pty) / sy;
+        kx[(size_t)c * J + sub] = x;
+        ky[(size_t)c * J + sub] = y;
+        kz[(size_t)c * J + sub] = pp[5 + 3 * sub] + depth;
+        if (pairwise) { skx[(size_t)c * J + sub] = x; sky[(size_t)c * J + sub] = y; }
+        mnx = mxx = x;
+        mny = mxy = y;
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {   // min / max are exact: any reduction order gives the reference's value
+        mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64));
+        mny = fminf(mny, __shfl_xor(mny, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+      }
+      if (sub == 0) {
+        const float a = (mxx - mnx) * (mxy - mny);
+        area[c] = a;
+        if (pairwise) sarea[c] = a;
+        sup[c] = 0;
+      }
     }
-    area[c] = (mxx - mnx) * (mxy - mny);
-    sup[c] = 0;
+  } else {
+    for (int c = tid; c < total; c += TPB) {
+      const unsigned flat = ~(unsigned)(keys[c] & 0xffffffffull);
+      int l = 0, base = 0;
+      while (l + 1 < d.num_levels && (int)flat >= base + d.H[l] * d.W[l]) { base += d.H[l] * d.W[l]; ++l; }
+      const int loc = (int)flat - base, Wl = d.W[l];
+      const int st = d.stride[l];
+      const float ptx = (float)((loc % Wl) * st + st / 2), pty = (float)((loc / Wl) * st + st / 2);
+      const float* pp = d.pose[l] + ((size_t)b * d.H[l] * Wl + loc) * d.pose_ps[l];
+      const float depth = pp[2] * zs;
+      cen[c * 3 + 0] = (ptx - pp[0]) / sx;
+      cen[c * 3 + 1] = (pty - pp[1]) / sy;
+      cen[c * 3 + 2] = depth;
+      float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+      for (int j = 0; j < J; ++j) {
+        const float x = (pp[3 + 3 * j] + ptx) / sx, y = (pp[4 + 3 * j] + pty) / sy;
+        kx[(size_t)c * J + j] = x;
+        ky[(size_t)c * J + j] = y;
+        kz[(size_t)c * J + j] = pp[5 + 3 * j] + depth;
+        mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
+        mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+      }
+      area[c] = (mxx - mnx) * (mxy - mny);
+      sup[c] = 0;
+    }
   }
   if (tid == 0) s_kept = 0;
   __syncthreads();
 
   // ---- greedy OKS-NMS (pose_nms.py:92-126)
   const float thr32 = d.nms_thr;
-  const bool pairwise = total <= PAIR_MAX;   // (uniform over the workgroup)
   if (pairwise) {
     // "suppresses" bit matrix in LDS: only keys[0 .. total) are still needed, the rest of the key array is free.
     // Row r = candidates c > r with oks(r, c) > thr, W words per row.
-    const int n = total, W = (n + 31) >> 5, half = (n + 1) / 2;
-    unsigned* pm = reinterpret_cast<unsigned*>(smem + PAIR_MAX * 8);          // [n][W] <= 768 * 24 * 4 = 72 KiB
+    const int n = total, W = nW, half = (n + 1) / 2;
+    unsigned* pm = reinterpret_cast<unsigned*>(smem + pm_off);                 // [n][W]
     for (int i = tid; i < n * W; i += TPB) pm[i] = 0u;
     __syncthreads();
     // the upper triangle folded into a (n + 1) / 2 x n rectangle: (r, c > r) as is, (r, c < r) mirrored; one thread per
@@ -169,7 +214,7 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
       const bool mirrored = c < r;
       if (mirrored) { r = n - 1 - r; c = n - 1 - c; }
       if (mirrored && (n & 1) && r == half - 1) continue;   // (middle row of an odd n: already covered un-mirrored)
-      if (oks_above(kx, ky, area, r, c, J, thr32)) atomicOr(&pm[r * W + (c >> 5)], 1u << (c & 31));
+      if (oks_above(skx, sky, sarea, r, c, J, thr32)) atomicOr(&pm[r * W + (c >> 5)], 1u << (c & 31));
     }
     __syncthreads();
     // the greedy walk: ONE wave, no workgroup barriers; lane w keeps word w of the suppressed set
