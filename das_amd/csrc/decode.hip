@@ -25,8 +25,8 @@ __host__ __device__ inline long long ws_bytes_per_image(int cap, int J) {
 }
 
 // pose_nms.py:51-90 for one pair: f64 arithmetic as numpy does, the mean rounded to f32 before the compare
-__device__ __forceinline__ bool oks_above(const float* kx, const float* ky, const float* area, int a, int c, int J,
-                                          float thr32) {
+__device__ __forceinline__ bool oks_above_f64(const float* kx, const float* ky, const float* area, int a, int c, int J,
+                                              float thr32) {
 #pragma clang fp contract(off)
   const double denom = (double)((area[a] + area[c]) / 2.f) + 2.220446049250313e-16;
   double acc = 0.0;
@@ -44,6 +44,28 @@ __device__ __forceinline__ bool oks_above(const float* kx, const float* ky, cons
   }
   const float iou = (float)(acc / (double)J);
   return !(iou <= thr32);
+}
+// The decision "oks > thr" only: an f32 evaluation first (an f64 exp costs ~10x an f32 one and there are 15-21 per
+// pair); its error is below 1e-5 (each term in (0, 1], a few ulp each), so beyond a margin of 1e-3 around the
+// threshold the f32 answer IS the f64 answer; inside the margin the exact f64 form decides.
+__device__ __forceinline__ bool oks_above(const float* kx, const float* ky, const float* area, int a, int c, int J,
+                                          float thr32) {
+  const float denom = (area[a] + area[c]) * 0.5f + 1e-30f;
+  float acc = 0.f;
+  for (int j = 0; j < J; ++j) {
+    const float dx = kx[(size_t)c * J + j] - kx[(size_t)a * J + j];
+    const float dy = ky[(size_t)c * J + j] - ky[(size_t)a * J + j];
+    float var = 0.0256f;
+    if (J == 17) {
+      const float sg[17] = {.026f, .025f, .025f, .035f, .035f, .079f, .079f, .072f, .072f, .062f, .062f, .107f, .107f,
+                            .087f, .087f, .089f, .089f};
+      var = (sg[j] * 2) * (sg[j] * 2);
+    }
+    acc += expf(-(dx * dx + dy * dy) / var / denom * 0.5f);
+  }
+  const float iou = acc / (float)J;
+  if (fabsf(iou - thr32) > 1e-3f && isfinite(iou)) return iou > thr32;
+  return oks_above_f64(kx, ky, area, a, c, J, thr32);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -84,42 +106,108 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   float* cen = area + cap;
   unsigned char* sup = reinterpret_cast<unsigned char*>(smem) + (size_t)LDS_KEYS * 8;          // [cap <= SUP_LDS], LDS
 
-  int total = 0, point_base = 0;
-  for (int l = 0; l < d.num_levels; ++l) {
-    const int npts = d.H[l] * d.W[l];
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    const float* cls = d.cls[l] + (size_t)b * npts * d.cls_ps[l];
-    const float* ctr = d.ctr[l] + (size_t)b * npts * d.ctr_ps[l];
-    for (int i = tid; i < npts; i += TPB) {
-      const float s = sigmoidf_(cls[(size_t)i * d.cls_ps[l]]) * sigmoidf_(ctr[(size_t)i * d.ctr_ps[l]]);
-      if (s > d.score_thr) {
-        const int pos = atomicAdd(&s_n, 1);
-        keys[pos] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(~(unsigned)(point_base + i));
+  // ---- candidates above the score threshold. Usual case: no level has more of them than nms_pre (a few hundred
+  // pass 0.07), so the per-level top-k keeps everything and ONE sweep over all levels' points collects them (their
+  // order is irrelevant: the global sort below defines it). Otherwise: level by level with the top-k sort.
+  __shared__ int s_lv[DAS_MAX_LEVELS];
+  if (tid < DAS_MAX_LEVELS) s_lv[tid] = 0;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  int total = 0;
+  {
+    int npts_all = 0;
+    for (int l = 0; l < d.num_levels; ++l) npts_all += d.H[l] * d.W[l];
+    for (int i0 = 0; i0 < npts_all; i0 += 4 * TPB) {
+      float sc[4];
+      int lv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {     // four points per thread in flight
+        const int i = i0 + u * TPB + tid;
+        sc[u] = -1.f;
+        lv[u] = 0;
+        if (i < npts_all) {
+          int l = 0, base = 0;
+          while (l + 1 < d.num_levels && i >= base + d.H[l] * d.W[l]) { base += d.H[l] * d.W[l]; ++l; }
+          const int loc = i - base, npts = d.H[l] * d.W[l];
+          const float a = d.cls[l][((size_t)b * npts + loc) * d.cls_ps[l]];
+          const float c = d.ctr[l][((size_t)b * npts + loc) * d.ctr_ps[l]];
+          sc[u] = sigmoidf_(a) * sigmoidf_(c);
+          lv[u] = l;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (sc[u] > d.score_thr) {
+          const int pos = atomicAdd(&s_n, 1);
+          atomicAdd(&s_lv[lv[u]], 1);
+          keys[pos] = ((unsigned long long)__float_as_uint(sc[u]) << 32) | (unsigned)(~(unsigned)(i0 + u * TPB + tid));
+        }
       }
     }
     __syncthreads();
-    int n = s_n;
-    if (d.nms_pre > 0 && npts > d.nms_pre && n > d.nms_pre) {
-      int P = 1;
-      while (P < n) P <<= 1;
-      for (int i = n + tid; i < P; i += TPB) keys[i] = 0ull;
+    bool simple = true;
+    for (int l = 0; l < d.num_levels; ++l)
+      if (d.nms_pre > 0 && d.H[l] * d.W[l] > d.nms_pre && s_lv[l] > d.nms_pre) simple = false;   // (uniform)
+    if (simple) {
+      total = s_n;
+      for (int i = tid; i < total; i += TPB) mkeys[i] = keys[i];
       __syncthreads();
-      bitonic_sort_desc(keys, P);
-      n = d.nms_pre;
+    } else {
+      int point_base = 0;
+      for (int l = 0; l < d.num_levels; ++l) {
+        const int npts = d.H[l] * d.W[l];
+        __syncthreads();
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        const float* cls = d.cls[l] + (size_t)b * npts * d.cls_ps[l];
+        const float* ctr = d.ctr[l] + (size_t)b * npts * d.ctr_ps[l];
+        for (int i = tid; i < npts; i += TPB) {
+          const float sv = sigmoidf_(cls[(size_t)i * d.cls_ps[l]]) * sigmoidf_(ctr[(size_t)i * d.ctr_ps[l]]);
+          if (sv > d.score_thr) {
+            const int pos = atomicAdd(&s_n, 1);
+            keys[pos] = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)(~(unsigned)(point_base + i));
+          }
+        }
+        __syncthreads();
+        int n = s_n;
+        if (d.nms_pre > 0 && npts > d.nms_pre && n > d.nms_pre) {
+          int P = 1;
+          while (P < n) P <<= 1;
+          for (int i = n + tid; i < P; i += TPB) keys[i] = 0ull;
+          __syncthreads();
+          bitonic_sort_desc(keys, P);
+          n = d.nms_pre;
+        }
+        for (int i = tid; i < n; i += TPB) mkeys[total + i] = keys[i];
+        total += n;
+        point_base += npts;
+        __syncthreads();
+      }
     }
-    for (int i = tid; i < n; i += TPB) mkeys[total + i] = keys[i];
-    total += n;
-    point_base += npts;
-    __syncthreads();
   }
 
   // ---- global order: score desc, flat index asc
-  int P = 1;
-  while (P < total) P <<= 1;
-  for (int i = tid; i < P; i += TPB) keys[i] = i < total ? mkeys[i] : 0ull;
-  __syncthreads();
-  if (total > 1) bitonic_sort_desc(keys, P);
+  if (total <= TPB) {
+    // rank sort: keys are distinct (the location index is part of them), so a key's position is the number of larger
+    // keys — one pass over the LDS copy per thread, one barrier (the bitonic network needs log^2 of them)
+    unsigned long long mine = 0ull;
+    int rank = 0;
+    if (tid < total) mine = mkeys[tid];
+    __syncthreads();
+    for (int i = tid; i < total; i += TPB) keys[i] = mkeys[i];
+    __syncthreads();
+    if (tid < total)
+      for (int j = 0; j < total; ++j) rank += keys[j] > mine ? 1 : 0;
+    __syncthreads();
+    if (tid < total) keys[rank] = mine;
+    __syncthreads();
+  } else {
+    int P = 1;
+    while (P < total) P <<= 1;
+    for (int i = tid; i < P; i += TPB) keys[i] = i < total ? mkeys[i] : 0ull;
+    __syncthreads();
+    bitonic_sort_desc(keys, P);
+  }
 
   // ---- gather + affine per candidate (das_head.py:725-743): 32 lanes per candidate, lane j = joint j (a thread per
   // candidate walking its joints pays one memory round trip per joint: 40 us of the launch at J = 21)
