@@ -39,6 +39,10 @@ struct ConvP {
   const float* bnb_gamma;
   const float* bnb_beta;
   int bnb_relu, bnb_ps;
+  // split-K (conv_glds_kernel on small-M, long-K layers): blockIdx.y = split s covers K steps [nk*s/ksplit, nk*(s+1)/ksplit)
+  // and stores its raw f32 accumulators to ws[s][M][Cout]; splitk_finish_kernel sums the slabs and runs the epilogue.
+  float* ws;
+  int ksplit;
   // ragged multi-level input (stride 1, "same" padding): rows of level l start at lvStart[l]
   int nlev, B;
   int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];

@@ -22,6 +22,7 @@
 
 #include "conv_common.h"
 #include "tuning.h"
+#include "workspace.h"
 
 using namespace dasconv;
 
@@ -161,6 +162,34 @@ __device__ __forceinline__ void dma16_asm(const void* src, unsigned lds_byte_add
                : "memory");
 }
 
+// ---- split-K (ConvP::ksplit > 1): blockIdx.y = s covers K steps [nk*s/ksplit, nk*(s+1)/ksplit) and stores its raw f32
+// accumulators to slab s of the workspace (float4 = 4 consecutive channels of one pixel); splitk_finish_kernel follows.
+__device__ __forceinline__ void splitk_range(const ConvP& p, int nk, int& kt0, int& kt1) {
+  kt0 = 0; kt1 = nk;
+  if (p.ksplit > 1) {
+    kt0 = (int)((long long)nk * blockIdx.y / p.ksplit);
+    kt1 = (int)((long long)nk * (blockIdx.y + 1) / p.ksplit);
+  }
+}
+// Slab layout = register order: [split][tile][wave][a][b][lane] float4, so that every store / load instruction moves one
+// contiguous KiB per wave (a pixel-major layout would scatter 64-byte pieces over 16 rows).
+template <int BN, int BMT>
+__device__ __forceinline__ size_t splitk_slot(const ConvP& p, int split, int tile) {
+  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN, NW = 2 * BMT / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  return ((((size_t)split * p.nblocks + tile) * NW + wave) * (TN * TM)) * 64 + lane;   // (float4 units; + (a*TM+b)*64)
+}
+template <int BN, int BMT, typename Acc>
+__device__ __forceinline__ void splitk_store(const Acc& acc, const ConvP& p, int tile) {
+  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN;
+  float4* dst = reinterpret_cast<float4*>(p.ws) + splitk_slot<BN, BMT>(p, blockIdx.y, tile);
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+      dst[(a * TM + b) * 64] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+}
+
 template <typename T, typename OT, int BN, int BMT>
 __global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
   constexpr int EPV = Elem<T>::EPV;
@@ -207,7 +236,15 @@ __global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
   for (int j = 0; j < A_INSTR; ++j)
     abase[j] = xg + (rg[j].pix0 + (long long)rg[j].hi0 * rg[j].W + rg[j].wi0) * p.xps + akg[j];
 
-  int f_kh = 0, f_kw = 0, f_ci = 0;
+  int kt0, kt1;
+  splitk_range(p, p.K / BK, kt0, kt1);   // this workgroup's slice of the K steps
+  int f_kh, f_kw, f_ci;
+  {
+    const int e0 = kt0 * BK, tap = e0 / p.Cin;
+    f_ci = e0 - tap * p.Cin;
+    f_kh = tap / p.KW;
+    f_kw = tap - f_kh * p.KW;
+  }
   auto issue = [&](int kt, int buf) {
     char* sA = smem + buf * BUF;
     char* sW = sA + A_BYTES;
@@ -244,13 +281,12 @@ __global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
-  issue(0, 0);
+  issue(kt0, 0);
   __syncthreads();  // vmcnt(0) + barrier: tile 0 landed
   const int frow = lane & 15, fkg = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) issue(kt + 1, buf ^ 1);
     const char* sA = smem + buf * BUF;
     const char* sW = sA + A_BYTES;
 #pragma unroll
@@ -268,6 +304,41 @@ __global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
         for (int b = 0; b < TM; ++b) mma<T>(fa[a], fb[b], acc[a][b]);
     }
     __syncthreads();  // prefetch landed (vmcnt 0) and every wave is done reading `buf`
+  }
+  if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); return; }
+  conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
+}
+
+// Second half of a split-K convolution: same grid and tile map as the tile-kernel launch it follows; every lane sums
+// its accumulator positions over the slabs (fixed order: deterministic) and the shared epilogue does the rest
+// (scale / shift, C tile through LDS, statistics, residual, ReLU, fused BatchNorm-backward sums, 16-byte stores).
+template <typename OT, int BN, int BMT>
+__global__ __launch_bounds__(2 * BMT) void splitk_finish_kernel(ConvP p) {
+  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int logical = xcd_remap(blockIdx.x, p.nblocks);
+  const int n0 = (logical % p.ntiles) * BN;
+  const int m0 = p.m_base + (logical / p.ntiles) * BMT;
+  constexpr int NW = 2 * BMT / 64;
+  const float4* src = reinterpret_cast<const float4*>(p.ws) + splitk_slot<BN, BMT>(p, 0, logical);
+  const size_t slab = (size_t)p.nblocks * NW * (TN * TM) * 64;
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const float4 v = src[(a * TM + b) * 64];
+      acc[a][b] = f32x4_t{v.x, v.y, v.z, v.w};
+    }
+  for (int s = 1; s < p.ksplit; ++s) {   // (one slab at a time: all of its loads are in flight together)
+    src += slab;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const float4 v = src[(a * TM + b) * 64];
+        acc[a][b][0] += v.x; acc[a][b][1] += v.y; acc[a][b][2] += v.z; acc[a][b][3] += v.w;
+      }
   }
   conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
 }
@@ -359,7 +430,20 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
+  int kt0, kt1;
+  splitk_range(p, p.K / BK, kt0, kt1);
+  const int nk = kt1 - kt0;
+  if (kt0) {   // split-K: move the tap walk to this workgroup's first step
+    const int e0 = kt0 * BK, tap = e0 / p.Cin;
+    f_ci = e0 - tap * p.Cin; f_kh = tap / p.KW; f_kw = tap - f_kh * p.KW;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      acur[j] += (unsigned)((((long long)f_kh * aW[j] + f_kw) * p.xps + f_ci) * (long long)E);
+      aok[j] = (unsigned)(ahi[j] + f_kh) < (unsigned)aH[j] && (unsigned)(awi[j] + f_kw) < (unsigned)aW[j];
+    }
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) wcur[j] += (unsigned)e0 * E;
+  }
   issue(0, 0);
   if (nk > 1) issue(1, 1);
   const int frow = lane & 15, fkg = lane >> 4;
@@ -389,6 +473,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
     buf = buf == NBUF - 1 ? 0 : buf + 1;
     nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
   }
+  if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); return; }
   __syncthreads();  // all LDS reads done before the C tile reuses the buffers
   conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
 }
@@ -477,7 +562,20 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
+  int kt0, kt1;
+  splitk_range(p, p.K / BK, kt0, kt1);
+  const int nk = kt1 - kt0;
+  if (kt0) {   // split-K: move the tap walk to this workgroup's first step
+    const int e0 = kt0 * BK, tap = e0 / p.Cin;
+    f_ci = e0 - tap * p.Cin; f_kh = tap / p.KW; f_kw = tap - f_kh * p.KW;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      acur[j] += (unsigned)((((long long)f_kh * aW[j] + f_kw) * p.xps + f_ci) * (long long)E);
+      aok[j] = (unsigned)(ahi[j] + f_kh) < (unsigned)aH[j] && (unsigned)(awi[j] + f_kw) < (unsigned)aW[j];
+    }
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) wcur[j] += (unsigned)e0 * E;
+  }
   issue(0);
   if (nk > 1) issue(1);
   if (nk > 2) issue(2);
@@ -561,6 +659,7 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
     buf = buf == NBUF - 1 ? 0 : buf + 1;
     nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
   }
+  if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); return; }
   __syncthreads();  // all LDS reads done before the C tile reuses the buffers
   conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
 }
@@ -575,6 +674,38 @@ inline int device_cus() {
   }
   return cus;
 }
+// Split-K factor for a tile-kernel launch of `nblocks` workgroups with `nk` K steps (steps of 128 bytes: the 64-byte
+// steps of conv_glds4_kernel are counted in pairs): small-M, long-K layers (the 16x26 / 32x52 stages) have too few
+// tiles to fill the chip, and every K step of a lone workgroup exposes its DMA latency. The K steps are spread over
+// blockIdx.y until there are about conv.splitk_target workgroups per resident slot (`per_cu` of them per CU), each
+// keeping at least conv.splitk_minsteps steps; `bit` selects the kernel in conv.splitk_kernels.
+inline int pick_ksplit(long long nblocks, int nk, int per_cu, int bit, long long out_elems) {
+  const long long mask = dastune::get(dastune::CONV_SPLITK_KERNELS), target = dastune::get(dastune::CONV_SPLITK_TARGET) * per_cu;
+  const long long minsteps = std::max<long long>(1, dastune::get(dastune::CONV_SPLITK_MINSTEPS));
+  if (!(mask & bit) || target <= 0 || nblocks * 2 > target) return 1;
+  long long ks = std::min<long long>({target / nblocks, nk / minsteps, 16});
+  while (ks > 1 && ks * out_elems * 4 > ((long long)128 << 20)) --ks;   // slabs: at most 128 MiB
+  return ks < 2 ? 1 : (int)ks;
+}
+// Launch a tile kernel split over blockIdx.y, then the finishing kernel on the same tile map.
+template <typename OT, int BN, int BMT, typename Kern>
+int launch_splitk(Kern kern, ConvP& p, int ks, size_t sm, hipStream_t s) {
+  p.ws = dasws::get(dasws::CONV_SPLITK, s, (size_t)ks * p.nblocks * BN * BMT * sizeof(float), (size_t)32 << 20);
+  if (!p.ws) return DAS_ERR_LAUNCH;
+  p.ksplit = ks;
+  static bool fin_attr = false;   // (one per instantiation)
+  const size_t sm_fin = epilogue_smem_bytes<OT, BN, BMT>();
+  if (!fin_attr) {
+    (void)hipFuncSetAttribute((const void*)splitk_finish_kernel<OT, BN, BMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_fin);
+    fin_attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.nblocks, ks), dim3(2 * BMT), sm, s, p);
+  DAS_CHECK_LAUNCH();
+  hipLaunchKernelGGL((splitk_finish_kernel<OT, BN, BMT>), dim3(p.nblocks), dim3(2 * BMT), sm_fin, s, p);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
 // The 256-row tile kernels run one workgroup per CU, so a launch is a sequence of rounds of `cus` tiles and a last round
 // that is, e.g., 8 % full (277 tiles on 256 CUs: the B = 8 head convs of the inference workload) costs a whole round.
 // If the last round would be under half full, its pixel rows are left to a second launch on 128-row tiles
@@ -595,12 +726,15 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
   // 18...22 % on the 3x3 layers of the 32x52 / 16x26 stages — the 3-stage pipeline matters more than the fill)
   const long long mink = dastune::get(dastune::CONV_BIG_MINK), minb = dastune::get(dastune::CONV_BIG_MINBLOCKS);
   const int rows = p.M - p.m_base;   // rows of this launch
-  const bool big = may_split && glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && (long long)((rows + 255) / 256) * p.ntiles >= minb &&
+  const int nk128 = (int)((long long)p.K * sizeof(T) / 128);
+  const long long nb3 = (long long)((rows + 255) / 256) * p.ntiles;
+  const int ks3 = (may_split && p.m_base == 0) ? pick_ksplit(nb3, nk128, 1, 2, (long long)p.M * p.Cout) : 1;
+  const bool big = may_split && glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && nb3 * ks3 >= minb &&
                    p.K >= mink &&
                    p.xbytes != 0;  // (0 = more than 4 GiB of input: not addressable by 32-bit buffer offsets)
   const int bm = big ? 256 : BM;
   int mtiles = (rows + bm - 1) / bm;
-  if (big) {
+  if (big && ks3 == 1) {
     const long long keep = tail_split_mtiles(mtiles, p.ntiles, may_split);
     if (keep < mtiles) {   // rows of the under-filled last round: 128-row tiles, second launch
       ConvP tail = p0;
@@ -625,9 +759,20 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
     attr_set = true;
   }
   if (big) {
+    if constexpr (BN == 128 && sizeof(OT) == 2) {
+      if (ks3 > 1) {
+        dastune::note_kernel("conv_glds3_kernel<splitk>");
+        return launch_splitk<OT, 128, 256>(conv_glds3_kernel<T, OT>, p, ks3, sm_big, s);
+      }
+    }
     dastune::note_kernel("conv_glds3_kernel");
     hipLaunchKernelGGL((conv_glds3_kernel<T, OT>), dim3(p.nblocks), dim3(512), sm_big, s, p);
   } else if (glds) {
+    const int ks = (BN >= 64 && p.m_base == 0 && may_split) ? pick_ksplit(p.nblocks, nk128, 2, 1, (long long)p.M * p.Cout) : 1;
+    if (ks > 1) {
+      dastune::note_kernel("conv_glds_kernel<splitk>");
+      return launch_splitk<OT, BN, 128>(conv_glds_kernel<T, OT, BN, 128>, p, ks, sm_glds, s);
+    }
     dastune::note_kernel("conv_glds_kernel");
     hipLaunchKernelGGL((conv_glds_kernel<T, OT, BN, 128>), dim3(p.nblocks), dim3(256), sm_glds, s, p);
   } else if (aligned) {
@@ -658,11 +803,12 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
 // MODE (keeps each variant under the 168 registers that ten waves per workgroup allow): 0 = plain, optional BatchNorm
 // statistics (training forward); 1 = scale / shift, optional ReLU (eval); 2 = residual add, optional ReLU (data gradient);
 // 3 / 4 = data gradient with the fused BatchNorm-backward reduction (ConvP::bnb_*): optional residual, mask from the
-// saved output y (3; no y = no mask) or recomputed from raw with the layer's affine (4), per-channel sums in registers.
+// saved output y (3; no y = no mask) or recomputed from raw with the layer's affine (4), per-channel sums in registers;
+// 5 = scale / shift, then residual add, optional ReLU (the closing 1x1 conv of an eval-mode bottleneck).
 template <int KB, int WN, int MODE>   // K = 32 * KB input channels; WN waves across the 32-channel groups, 8 / WN across pixels
 __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, int ntiles) {
   using T = bf16_t;
-  constexpr bool STATS = MODE == 0, AFF = MODE == 1, RES = MODE == 2, BNB = MODE >= 3;
+  constexpr bool STATS = MODE == 0, AFF = MODE == 1 || MODE == 5, RES = MODE == 2 || MODE == 5, BNB = MODE == 3 || MODE == 4;
   constexpr int WM = 8 / WN, TM = 64, PB = TM / WM / 16;    // 16-pixel blocks per wave and tile
   constexpr int K = KB * 32, SUBS = (K + 63) / 64;
   constexpr int SUBB = TM * 128, STAGE = SUBS * SUBB;       // bytes
@@ -990,9 +1136,9 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
   };
   const bool aff = p.scale || p.shift;
   const bool bnb = p.bnb_raw != nullptr;
-  if (!bnb && ((aff && (p.res || p.stats)) || (p.res && p.stats))) return false;   // (combinations no caller on the path uses)
+  if (!bnb && p.stats && (aff || p.res)) return false;   // (combinations no caller on the path uses)
   if (bnb && (p.relu || aff)) return false;
-  const int mode = bnb ? ((p.bnb_relu && !p.bnb_y) ? 4 : 3) : p.res ? 2 : (aff ? 1 : 0);
+  const int mode = bnb ? ((p.bnb_relu && !p.bnb_y) ? 4 : 3) : p.res ? (aff ? 5 : 2) : (aff ? 1 : 0);
   if (mode == 4 && p.res) return false;   // (the recomputed mask is only valid when no residual entered before the ReLU)
 #define DAS_STREAM_CASE(KBV, WNV)                                         \
   if (kb == KBV && wn == WNV) {                                           \
@@ -1000,6 +1146,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
     if (mode == 1) return go(conv1x1_stream_kernel<KBV, WNV, 1>);         \
     if (mode == 2) return go(conv1x1_stream_kernel<KBV, WNV, 2>);         \
     if (mode == 3) return go(conv1x1_stream_kernel<KBV, WNV, 3>);         \
+    if (mode == 5) return go(conv1x1_stream_kernel<KBV, WNV, 5>);         \
     if constexpr (WNV == 2) return go(conv1x1_stream_kernel<KBV, WNV, 4>); \
     return false;   /* (mode 4 with wide outputs would spill: the tile kernels take those) */ \
   }
@@ -1018,9 +1165,10 @@ bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
     ConvP p = p0;
     p.ntiles = (p.Cout + 255) / 256;
     const long long nb = (long long)((p.M + 255) / 256) * p.ntiles;
-    if (minblocks <= 0 || p.Cout < 256 || p.Cin % 32 || p.relu_in || p.up_sh != 0 || p.xbytes == 0 || nb < minblocks)
+    const int ks4 = pick_ksplit(nb, p.K / 64, 1, 4, (long long)p.M * p.Cout);
+    if (minblocks <= 0 || p.Cout < 256 || p.Cin % 32 || p.relu_in || p.up_sh != 0 || p.xbytes == 0 || nb * ks4 < minblocks)
       return false;
-    const long long mtiles = (p.M + 255) / 256, keep = tail_split_mtiles(mtiles, p.ntiles, true);
+    const long long mtiles = (p.M + 255) / 256, keep = ks4 > 1 ? mtiles : tail_split_mtiles(mtiles, p.ntiles, true);
     if (keep < mtiles) {   // rows of the under-filled last round: 128 x 128 tiles, second launch
       ConvP tail = p0;
       tail.m_base = (int)keep * 256;
@@ -1039,6 +1187,12 @@ bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
     // HBM-bound K = 64 / 128 layers that finish in two or four steps)
     const long long force_pp = dastune::get(dastune::CONV_GLDS4_PP);
     const bool pp = force_pp >= 0 ? force_pp == 1 : p.K >= 256;
+    if (ks4 > 1) {
+      dastune::note_kernel("conv_glds4_kernel<splitk>");
+      const int rc = pp ? launch_splitk<OT, 256, 256>(conv_glds4_kernel<T, OT, true>, p, ks4, sm4, s)
+                        : launch_splitk<OT, 256, 256>(conv_glds4_kernel<T, OT, false>, p, ks4, sm4, s);
+      return rc == DAS_OK;
+    }
     dastune::note_kernel(pp ? "conv_glds4_kernel<pp>" : "conv_glds4_kernel");
     if (pp) {
       hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true>), dim3(p.nblocks), dim3(512), sm4, s, p);
@@ -1105,6 +1259,7 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   p.up_sh = d->in_up == 2 ? 1 : 0;
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0; p.m_base = 0;
+  p.ws = nullptr; p.ksplit = 1;
   p.bnb_raw = (const char*)d->bnb_raw; p.bnb_y = (const char*)d->bnb_y;
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta;
   p.bnb_relu = d->bnb_relu; p.bnb_ps = d->bnb_pix_stride;

@@ -14,6 +14,7 @@
 
 #include "conv_common.h"
 #include "tuning.h"
+#include "workspace.h"
 
 using namespace dasconv;
 
@@ -824,41 +825,10 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
 }
 }  // namespace
 
-// Workspace of the weight gradient's partial tiles: one buffer per (device, stream) — launches on one stream are
-// ordered, so consecutive layers reuse it — 64 MiB covers every grid the launcher below picks (1024 workgroups
-// x 64 KiB, or 256 x 256 KiB); a larger request (tuning overrides) grows it after draining the stream.
+// Workspace of the weight gradient's partial tiles (workspace.h: one buffer per device and stream): 64 MiB covers every
+// grid the launcher below picks (1024 workgroups x 64 KiB, or 256 x 256 KiB); tuning overrides may grow it.
 static float* wgrad_workspace(hipStream_t s, size_t bytes) {
-  struct Entry { int dev; hipStream_t s; float* buf; size_t bytes; bool used; };
-  static Entry table[16];
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  Entry* e = nullptr;
-  for (Entry& t : table)
-    if (t.used && t.dev == dev && t.s == s) { e = &t; break; }
-  if (!e) {
-    for (Entry& t : table)
-      if (!t.used) { e = &t; break; }
-    if (!e) {   // table full (streams that came and went): take over the first entry's buffer
-      e = &table[0];
-      if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-      if (e->dev != dev && e->buf) { (void)hipFree(e->buf); e->buf = nullptr; e->bytes = 0; }
-      e->dev = dev; e->s = s;
-    } else {
-      *e = Entry{dev, s, nullptr, 0, true};
-    }
-  }
-  if (e->bytes < bytes) {
-    if (e->buf) {
-      if (hipStreamSynchronize(s) != hipSuccess || hipFree(e->buf) != hipSuccess) return nullptr;
-      e->buf = nullptr; e->bytes = 0;
-    }
-    const size_t want = std::max<size_t>(bytes, (size_t)64 << 20);
-    if (hipMalloc(reinterpret_cast<void**>(&e->buf), want) != hipSuccess) { e->buf = nullptr; return nullptr; }
-    e->bytes = want;
-  }
-  return e->buf;
+  return dasws::get(dasws::WGRAD, s, bytes, (size_t)64 << 20);
 }
 
 namespace {

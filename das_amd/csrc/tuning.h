@@ -15,7 +15,11 @@ enum Key {
   CONV_STREAM_PERCU,     // ... workgroups per CU of its persistent grid
   CONV_TAIL_SPLIT,       // 1: a 256-row-tile launch whose last round of workgroups would be under half full hands the
                          // rows of that round to the 128-row tile kernel (second launch)
-  CONV_GLDS8_MINBLOCKS,  // conv_glds8_kernel (256 x 256 tile, K-steps of 64, 8 phases); 0 disables the kernel
+  CONV_SPLITK_TARGET,    // tile-kernel launches with at most half this many workgroups (x 2 for the 128-row kernel, two
+                         // per CU) split their K loop over blockIdx.y up to about this many (+ splitk_finish_kernel);
+                         // 0 disables split-K
+  CONV_SPLITK_MINSTEPS,  // ... keeping at least this many K steps (of 128 bytes) per split
+  CONV_SPLITK_KERNELS,   // bit mask of the kernels that may split: 1 conv_glds_kernel, 2 conv_glds3_kernel, 4 conv_glds4_kernel
   WGRAD_PP_MINK,         // conv_wgrad_pp_kernel for K >= this (and Cout >= 256); 0 disables the kernel
   WGRAD_BKM,             // pixel rows per step of conv_wgrad_kernel<bf16>: 32 or 64
   WGRAD_BLOCKS,          // target grid of conv_wgrad_kernel; 0 = by shape (768 / 1024: one resident wave of workgroups)

@@ -1,6 +1,6 @@
 """Parity of the tile kernels the benchmark actually runs — conv_glds3_kernel (256 x 128, 3 stages),
-conv_glds4_kernel (256 x 256, 4 stages; plain and ping-pong schedule), conv_glds8_kernel (256 x 256, 8 phases),
-conv1x1_stream_kernel, conv_wgrad_kernel / conv_wgrad_pp_kernel at their production split — against
+conv_glds4_kernel (256 x 256, 4 stages; plain and ping-pong schedule), conv_glds_kernel with its K loop split
+over workgroups, conv1x1_stream_kernel, conv_wgrad_kernel / conv_wgrad_pp_kernel at their production split — against
 F.conv2d on bf16-rounded operands ("what's weak" #1).
 
 Two kinds of cases:
@@ -47,13 +47,12 @@ def conv_ref(x, w, s, p):
 
 
 FORCE = {
-    'conv_glds3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.glds8_minblocks': 0,
+    'conv_glds3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.splitk_target': 0,
                           'conv.stream_minrows': 0},
-    'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.glds8_minblocks': 0,
+    'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.splitk_target': 0,
                           'conv.stream_minrows': 0},
-    'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.glds8_minblocks': 0,
+    'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.splitk_target': 0,
                               'conv.stream_minrows': 0},
-    'conv_glds8_kernel': {'conv.glds8_minblocks': 1, 'conv.stream_minrows': 0},
 }
 
 # B, H, W, Cin, Cout, k, stride, pad
@@ -156,6 +155,95 @@ def test_tile_dgrad_forced(kernel):
         dx = o.conv2d_dgrad(nhwc(dy), o.pack_weight_dgrad(w.to(DEV), BF), 3, 3, 1, 1, (H, W), residual=nhwc(other))
         assert o.last_kernel() == kernel
     np.testing.assert_allclose(nchw(dx).numpy(), q(q(x.grad) + q(other)).numpy(), **TOL)
+
+
+# ---------------------------------------------------------------- split-K (small M, long K)
+SPLITK = {
+    # kernel: (tuning that routes the case to it, bit in conv.splitk_kernels, cases B, H, W, Cin, Cout, k, stride, pad)
+    'conv_glds_kernel': ({'conv.big_minblocks': 1 << 30, 'conv.glds4_minblocks': 0, 'conv.stream_minrows': 0,
+                          'conv.splitk_target': 0}, 1, [
+        (2, 16, 26, 512, 512, 3, 1, 1),    # layer4-like 3x3: 7 x 4 tiles, 72 K steps
+        (1, 9, 13, 2048, 136, 1, 1, 0),    # 1x1, K = 2048, M and N overhang
+        (2, 32, 52, 256, 256, 3, 2, 1),    # stride 2
+        (3, 7, 5, 192, 64, 3, 1, 1),       # BN = 64 tile, several images per M tile, odd split boundaries (27 steps)
+    ]),
+    'conv_glds3_kernel': (FORCE['conv_glds3_kernel'], 2, [
+        (2, 16, 26, 512, 512, 3, 1, 1), (1, 9, 13, 2048, 136, 1, 1, 0), (2, 32, 52, 256, 256, 3, 2, 1),
+        (3, 7, 5, 192, 128, 3, 1, 1),      # splits start in the middle of a tap (192 channels = 3 steps per tap)
+    ]),
+    'conv_glds4_kernel': (FORCE['conv_glds4_kernel'], 4, [
+        (2, 16, 26, 512, 512, 3, 1, 1), (1, 9, 13, 2048, 264, 1, 1, 0), (3, 7, 5, 96, 256, 3, 1, 1),
+    ]),
+    'conv_glds4_kernel<pp>': (FORCE['conv_glds4_kernel<pp>'], 4, [
+        (2, 16, 26, 512, 512, 3, 1, 1), (2, 32, 52, 256, 256, 3, 2, 1), (3, 7, 5, 96, 256, 3, 1, 1),
+    ]),
+}
+
+
+@pytest.mark.parametrize('kernel,idx', [(k, i) for k, v in SPLITK.items() for i in range(len(v[2]))])
+def test_splitk_matches_unsplit(kernel, idx):
+    """Each tile kernel with its K loop split over blockIdx.y + splitk_finish_kernel, against F.conv2d and against the
+    same kernel unsplit."""
+    o = ops()
+    force, bit, shapes = SPLITK[kernel]
+    B, H, W, Cin, Cout, k, s, p = shapes[idx]
+    x = cases.randn(201, B, Cin, H, W)
+    w = cases.randn(202, Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    xd, wd = nhwc(x), o.pack_weight(w.to(DEV), BF)
+    with o.tuning(**force):
+        y1 = o.conv2d(xd, wd, k, k, s, p)
+        assert o.last_kernel() == kernel, o.last_kernel()
+    with o.tuning(**{**force, 'conv.splitk_target': 512, 'conv.splitk_minsteps': 2, 'conv.splitk_kernels': bit}):
+        y2 = o.conv2d(xd, wd, k, k, s, p)
+        assert o.last_kernel() == kernel.replace('<pp>', '') + '<splitk>', o.last_kernel()
+    np.testing.assert_allclose(nchw(y2).numpy(), conv_ref(x, w, s, p).numpy(), **TOL)
+    # f32 partial sums regrouped: equal up to one bf16 rounding of the result
+    np.testing.assert_allclose(nchw(y2).numpy(), nchw(y1).numpy(), rtol=8e-3, atol=2e-3)
+
+
+def test_splitk_epilogues_and_default_dispatch():
+    """The layer4 3x3 at B=8 takes split-K by default; every epilogue runs in the finishing kernel."""
+    o = ops()
+    B, H, W, Cin, Cout = 8, 16, 26, 512, 512
+    x, w = cases.randn(211, B, Cin, H, W), cases.randn(212, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
+    scale, shift = cases.randn(213, Cout).abs() + 0.5, cases.randn(214, Cout)
+    res = cases.randn(215, B, Cout, H, W)
+    torch.set_num_threads(8)
+    conv = conv_ref(x, w, 1, 1)
+    xd, wd = nhwc(x), o.pack_weight(w.to(DEV), BF)
+    y = o.conv2d(xd, wd, 3, 3, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), residual=nhwc(res), relu=True)
+    assert o.last_kernel().endswith('<splitk>'), o.last_kernel()
+    aff_q = q(conv * scale[None, :, None, None] + shift[None, :, None, None])
+    np.testing.assert_allclose(nchw(y).numpy(), F.relu(aff_q + q(res)).numpy(), **TOL)
+    stats = torch.zeros(2 * Cout, device=DEV)
+    y = o.conv2d(xd, wd, 3, 3, 1, 1, stats=stats)
+    assert o.last_kernel().endswith('<splitk>'), o.last_kernel()
+    yq = nchw(y)
+    n = B * H * W
+    s_ref = torch.cat([yq.sum((0, 2, 3)), (yq ** 2).sum((0, 2, 3))])
+    np.testing.assert_allclose(stats.cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
+    # data gradient of a stride-2 3x3 (zero-upsampled dY) through the split path
+    dy = cases.randn(216, B, Cout, H // 2, W // 2)
+    xr = cases.randn(217, B, Cin, H, W).requires_grad_(True)
+    F.conv2d(xr, q(w), None, 2, 1).backward(q(dy))
+    dx = o.conv2d_dgrad(nhwc(dy), o.pack_weight_dgrad(w.to(DEV), BF), 3, 3, 2, 1, (H, W))
+    assert o.last_kernel() == 'conv_glds_kernel<splitk>', o.last_kernel()
+    np.testing.assert_allclose(nchw(dx).numpy(), q(xr.grad).numpy(), **TOL)
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 256), (128, 512), (256, 64)])
+def test_stream_affine_residual(cin, cout):
+    """conv1x1_stream_kernel mode 5: the closing 1x1 of an eval-mode bottleneck (folded BN, + identity, ReLU)."""
+    o = ops()
+    B, H, W = 2, 64, 130
+    x, w = cases.randn(221, B, cin, H, W), cases.randn(222, cout, cin, 1, 1) / cin ** 0.5
+    scale, shift = cases.randn(223, cout).abs() + 0.5, cases.randn(224, cout)
+    res = cases.randn(225, B, cout, H, W)
+    y = o.conv2d(nhwc(x), o.pack_weight(w.to(DEV), BF), 1, 1, 1, 0, scale=scale.to(DEV), shift=shift.to(DEV),
+                 residual=nhwc(res), relu=True)
+    assert o.last_kernel() == 'conv1x1_stream_kernel', o.last_kernel()
+    aff_q = q(conv_ref(x, w, 1, 0) * scale[None, :, None, None] + shift[None, :, None, None])
+    np.testing.assert_allclose(nchw(y).numpy(), F.relu(aff_q + q(res)).numpy(), **TOL)
 
 
 # ---------------------------------------------------------------- production sizes, default dispatch

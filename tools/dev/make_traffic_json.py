@@ -24,31 +24,37 @@ def family(fetch, write, match):
     return dict(fetch_mb=round(f, 2), write_mb=round(w, 2), hbm_mb_per_launch=round(f + w, 2), dispatches=n)
 
 
+WGRAD_OPS = 279 * 2     # tools/dev/wgrad_mix.py: 279 ops per replay of the step's batches, warm-up + timed replay
+
+
 def main(d, out):
     wf, ww, cf, cw, inf, infw = (load(d, n) for n in ('wf', 'ww', 'cf', 'cw', 'inf', 'infw'))
     fam = {}
-    # weight gradient = main kernel (128 x 128 or ping-pong 256 x 256) + split reduction per op: all bytes of the
-    # weight-gradient kernels divided by the number of ops (= dispatches of the reduce kernels)
-    nops = sum(v['dispatches'] for k, v in wf.items() if 'wgrad_reduce' in k)
-    f = sum(v['dispatches'] * v.get('fetch_mb', 0) for k, v in wf.items() if 'wgrad' in k) / nops
-    w = sum(v['dispatches'] * v.get('write_size_mb', 0) for k, v in ww.items() if 'wgrad' in k) / nops
+    # weight gradient: grouped launches (several ops per dispatch) of conv_wgrad_pp_kernel (256 x 256 ping-pong) and
+    # conv_wgrad_kernel (128 x 128) + one wgrad_reduce_kernel per group: all their bytes / the number of ops replayed
+    f = sum(v['dispatches'] * v.get('fetch_mb', 0) for k, v in wf.items() if 'wgrad' in k) / WGRAD_OPS
+    w = sum(v['dispatches'] * v.get('write_size_mb', 0) for k, v in ww.items() if 'wgrad' in k) / WGRAD_OPS
     fam['conv_wgrad_kernel<bf16>'] = dict(train=dict(
-        fetch_mb=round(f, 2), write_mb=round(w, 2), hbm_mb_per_launch=round(f + w, 2),
-        source=PASSES + ' over tools/dev/wgrad_mix.py: the 30 most expensive weight-gradient shapes of the train '
-                        'step with their per-step counts, B=16; conv_wgrad_kernel + wgrad_reduce_kernel per op'))
-    e = family(cf, cw, lambda k: k.startswith('conv_glds4_kernel<bf16, bf16'))
-    e['source'] = PASSES + (' over tools/dev/conv_mix.py: the conv_glds4_kernel shapes (forward + data-gradient) of '
-                            'the train step with their per-step counts, B=16')
-    fam['conv_glds4_kernel<bf16, bf16>'] = dict(train=e)
+        fetch_mb=round(f, 2), write_mb=round(w, 2), hbm_mb_per_launch=round(f + w, 2), ops=WGRAD_OPS,
+        source=PASSES + ' over tools/dev/wgrad_mix.py: the 279 weight-gradient ops of one train step (B=16) replayed in '
+                        'the 50 batches backward issues them in; conv_wgrad_pp_kernel + conv_wgrad_kernel + '
+                        'wgrad_reduce_kernel bytes per op (algorithmic 123.66 MB per op)'))
+    src_mix = PASSES + (' over tools/dev/conv_mix.py: the conv shapes (forward + data-gradient) of the train step with '
+                        'their per-step counts, B=16')
     src_inf = PASSES + ' over `bench.py --workload infer --steps 3 --warmup 1` (B=8, forward launches)'
-    for prefix, tag in (('conv_glds4_kernel<bf16, bf16', 'conv_glds4_kernel<bf16, bf16>'),
-                        ('conv_glds3_kernel<bf16, bf16', 'conv_glds3_kernel<bf16, bf16>'),
-                        ('conv_glds_kernel<bf16, bf16, 128, 128>', 'conv_glds_kernel<bf16, bf16, 128, 128>'),
-                        ('conv_glds_kernel<bf16, bf16, 64, 128>', 'conv_glds_kernel<bf16, bf16, 64, 128>')):
-        e = family(inf, infw, lambda k, p=prefix: k.startswith(p))
-        if e:
-            e['source'] = src_inf
-            fam.setdefault(tag, {})['infer'] = e
+    # bench.py tags a launch with das_last_kernel(): map each tag to the rocprof kernel names of that family
+    tags = (('conv_glds4_kernel<pp>', lambda k: k.startswith('conv_glds4_kernel<') and k.endswith('true>')),
+            ('conv_glds4_kernel', lambda k: k.startswith('conv_glds4_kernel<') and k.endswith('false>')),
+            ('conv_glds3_kernel', lambda k: k.startswith('conv_glds3_kernel<')),
+            ('conv_glds_kernel', lambda k: k.startswith('conv_glds_kernel<')),
+            ('conv1x1_stream_kernel', lambda k: k.startswith('conv1x1_stream_kernel<')),
+            ('conv_reg_kernel', lambda k: k.startswith('conv_reg_kernel<')))
+    for tag, match in tags:
+        for wl, (fe, wr, src) in (('train', (cf, cw, src_mix)), ('infer', (inf, infw, src_inf))):
+            e = family(fe, wr, match)
+            if e:
+                e['source'] = src
+                fam.setdefault(tag, {})[wl] = e
     json.dump(dict(note='HBM MB per launch: FETCH_SIZE KiB x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB, '
                         'means over the dispatches of the named run',
                    families=fam), open(out, 'w'), indent=1, sort_keys=True)

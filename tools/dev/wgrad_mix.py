@@ -9,6 +9,16 @@ import torch
 from das_amd import ops
 
 batches = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wgrad_batches.json')))
+args = [a for a in sys.argv[1:]]
+for a in args:
+    if a.startswith('batch='):       # re-chunk the op sequence (A/B of the batch size)
+        nb = int(a[6:])
+        flat = [o for b in batches for o in b]
+        batches = [flat[i:i + nb] for i in range(0, len(flat), nb)]
+    else:                            # key=value -> das_tuning_set
+        from das_amd import _lib
+        k, v = a.split('=')
+        _lib.check(_lib.load().das_tuning_set(k.encode(), int(v)), k)
 pool = {}
 
 
