@@ -110,12 +110,13 @@ __device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4
 // then shared by twice as many pixel rows, which is what relieves the L2 -> LDS path on the big layers).
 template <int BN, int BMT = 128>
 struct Tiling {
-  static constexpr int NT = BMT * 2;               // threads per workgroup
-  static constexpr int TM = (BN == 256) ? 8 : (BN == 128) ? 4 : 2;   // 16-row pixel tiles per wave
-  static constexpr int TN = (BN >= 64) ? 4 : 2;                      // 16-row channel tiles per wave
-  // BN = 256 (with BMT = 256): 2 x 4 waves of 128 pixels x 64 channels
+  // threads per workgroup: 2 per pixel row, except the 288-row variant of the 256-channel tile (8 waves x 144 x 64)
+  static constexpr int NT = (BN == 256) ? 512 : BMT * 2;
+  static constexpr int TM = (BN == 256) ? BMT / 32 : (BN == 128) ? 4 : 2;   // 16-row pixel tiles per wave
+  static constexpr int TN = (BN >= 64) ? 4 : 2;                             // 16-row channel tiles per wave
+  // BN = 256 (BMT = 256 or 288): 2 x 4 waves of BMT / 2 pixels x 64 channels
   static __device__ __forceinline__ int wave_m0(int wave) {
-    return BN == 256 ? (wave & 1) * 128 : BMT == 256 ? (wave & 3) * 64 : ((BN == 128) ? (wave & 1) * 64 : wave * 32);
+    return BN == 256 ? (wave & 1) * (BMT / 2) : BMT == 256 ? (wave & 3) * 64 : ((BN == 128) ? (wave & 1) * 64 : wave * 32);
   }
   static __device__ __forceinline__ int wave_n0(int wave) {
     return BN == 256 ? (wave >> 1) * 64 : BMT == 256 ? (wave >> 2) * 64 : ((BN == 128) ? (wave >> 1) * 64 : 0);
@@ -125,7 +126,7 @@ struct Tiling {
 template <typename OT, int BN, int BMT = 128>
 constexpr size_t epilogue_smem_bytes() {
   size_t ctile = (size_t)BMT * (BN * sizeof(OT) + 16);
-  size_t red = 2 * (size_t)(2 * BMT / (BN * sizeof(OT) / 16)) * BN * 4;
+  size_t red = 2 * (size_t)(Tiling<BN, BMT>::NT / (BN * sizeof(OT) / 16)) * BN * 4;
   return ctile > red ? ctile : red;
 }
 
@@ -176,7 +177,9 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   const OT* bxg = reinterpret_cast<const OT*>(p.bnb_raw);   // fused BatchNorm-backward reduction (see ConvP)
   const OT* byg = reinterpret_cast<const OT*>(p.bnb_y);
   if (n < p.Cout) {
-    constexpr int ITERS = BMT / RP, CH = ITERS < 4 ? ITERS : 4;  // rows per thread, processed CH at a time
+    constexpr int ITERS = BMT / RP;  // rows per thread, processed CH at a time
+    constexpr int CH = ITERS % 4 == 0 ? 4 : ITERS % 3 == 0 ? 3 : ITERS % 2 == 0 ? 2 : 1;
+    static_assert(BMT % RP == 0, "tile rows must be a multiple of the rows per pass");
     static_assert(ITERS % CH == 0, "tile rows per thread must be a multiple of the chunk");
     float bmu[EPVO], bis[EPVO], bga[EPVO], bbe[EPVO];
     if (bxg) {

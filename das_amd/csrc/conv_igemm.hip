@@ -175,7 +175,7 @@ __device__ __forceinline__ void splitk_range(const ConvP& p, int nk, int& kt0, i
 // contiguous KiB per wave (a pixel-major layout would scatter 64-byte pieces over 16 rows).
 template <int BN, int BMT>
 __device__ __forceinline__ size_t splitk_slot(const ConvP& p, int split, int tile) {
-  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN, NW = 2 * BMT / 64;
+  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN, NW = Tiling<BN, BMT>::NT / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   return ((((size_t)split * p.nblocks + tile) * NW + wave) * (TN * TM)) * 64 + lane;   // (float4 units; + (a*TM+b)*64)
 }
@@ -313,13 +313,13 @@ __global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
 // its accumulator positions over the slabs (fixed order: deterministic) and the shared epilogue does the rest
 // (scale / shift, C tile through LDS, statistics, residual, ReLU, fused BatchNorm-backward sums, 16-byte stores).
 template <typename OT, int BN, int BMT>
-__global__ __launch_bounds__(2 * BMT) void splitk_finish_kernel(ConvP p) {
+__global__ __launch_bounds__((BN == 256 ? 512 : 2 * BMT)) void splitk_finish_kernel(ConvP p) {
   constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
   const int n0 = (logical % p.ntiles) * BN;
   const int m0 = p.m_base + (logical / p.ntiles) * BMT;
-  constexpr int NW = 2 * BMT / 64;
+  constexpr int NW = Tiling<BN, BMT>::NT / 64;
   const float4* src = reinterpret_cast<const float4*>(p.ws) + splitk_slot<BN, BMT>(p, 0, logical);
   const size_t slab = (size_t)p.nblocks * NW * (TN * TM) * 64;
   f32x4_t acc[TN][TM];
@@ -485,14 +485,22 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
 // stages fit (128 KiB) and the DMAs run three steps ahead; each wave owns 128 pixels x 64 channels (8 x 4
 // MFMA tiles, 128 accumulator registers). Wait / barrier scheme as in conv_glds3_kernel with 4 DMAs per wave
 // and stage. Needs Cin % 32 == 0; used for Cout >= 256.
-template <typename T, typename OT, bool PP>
+// BMT = 288 (nine 16-row MFMA tiles per wave instead of eight): for launches whose tile count at 256 rows spills a few
+// tiles into another round of the one-workgroup-per-CU grid (277 tiles on 256 CUs: the B = 8 head convs). The pixel
+// tile then needs 18 DMA instructions per stage: every wave issues a third one, waves 0-1 for rows 256..287, the others
+// for an out-of-range offset into a scratch KiB (zero fill, no memory traffic), so that the vmcnt arithmetic stays
+// wave-uniform.
+template <typename T, typename OT, bool PP, int BMT = 256>
 __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
-  constexpr int BN = 256, BMT = 256, NBUF = 4;
+  constexpr int BN = 256, NBUF = 4;
+  static_assert(BMT == 256 || BMT == 288, "pixel tile: 256 or 288 rows");
   constexpr int EPV = Elem<T>::EPV;
   constexpr int BK = 4 * EPV;  // 64-byte rows
   constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN;
   constexpr int A_BYTES = BMT * 64, W_BYTES = BN * 64, BUF = A_BYTES + W_BYTES;
-  constexpr int A_INSTR = 2, W_INSTR = 2;  // 16 rows x 64 B per wave-instruction
+  constexpr int A_INSTR = BMT == 256 ? 2 : 3, W_INSTR = 2;  // 16 rows x 64 B per wave-instruction
+  constexpr int DPS = A_INSTR + W_INSTR;                    // DMAs per wave and stage
+  constexpr int SCRATCH = NBUF * BUF;                       // (BMT = 288) landing KiB of the padding DMAs
   constexpr unsigned E = sizeof(T);
   constexpr unsigned OOB = 0xFFFFFFF0u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -510,10 +518,13 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   unsigned acur[A_INSTR], arowstep[A_INSTR];
   int ahi[A_INSTR], awi[A_INSTR], aH[A_INSTR], aW[A_INSTR];
   bool aok[A_INSTR];
+  // instruction j of wave w stages LDS rows arow(j) .. + 15; the third one (BMT = 288) is real on waves 0-1 only
+  auto arow = [&](int j) { return j < 2 ? (wave * 2 + j) * 16 : 256 + wave * 16; };
+  const bool a3 = wave < 2;
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
-    const int row = (wave * A_INSTR + j) * 16 + lrow;
-    const RowGeom g = row_geom(p, m0 + row);
+    const int row = arow(j) + lrow;
+    const RowGeom g = row_geom(p, (j < 2 || a3) ? m0 + row : p.M);
     const int akg = (pslot ^ ((-(row >> 2)) & 3)) * EPV;   // logical k-group stored at this physical slot
     acur[j] = (unsigned)(((g.pix0 + (long long)g.hi0 * g.W + g.wi0) * p.xps + akg) * (long long)E);
     arowstep[j] = (unsigned)g.W * (unsigned)p.xps * E;
@@ -534,7 +545,8 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   auto issue = [&](int buf) {
     const unsigned sA = lds0 + buf * BUF, sW = sA + A_BYTES;
 #pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) dma16_buf(aok[j] ? acur[j] : OOB, xrs, sA + (wave * A_INSTR + j) * 1024);
+    for (int j = 0; j < A_INSTR; ++j)
+      dma16_buf(aok[j] ? acur[j] : OOB, xrs, (j < 2 || a3) ? sA + (unsigned)arow(j) * 64u : lds0 + SCRATCH);
 #pragma unroll
     for (int j = 0; j < W_INSTR; ++j) {
       dma16_buf(wcur[j], wrs, sW + (wave * W_INSTR + j) * 1024);
@@ -590,17 +602,17 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
     const int grp = wave >> 2;
     auto wait_next = [&](int kt) {   // this wave's DMAs of tile kt+1 (tiles kt+2, kt+3 may still fly: 4 DMAs each)
       if (kt + 3 < nk) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");
       } else if (kt + 2 < nk) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     };
     if (nk > 2) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");
     } else if (nk > 1) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -637,9 +649,9 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt landed; the (up to two) younger tiles, 4 DMAs per wave each, may still fly
     if (kt + 2 < nk) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");
     } else if (kt + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -679,9 +691,10 @@ inline int device_cus() {
 // tiles to fill the chip, and every K step of a lone workgroup exposes its DMA latency. The K steps are spread over
 // blockIdx.y until there are about conv.splitk_target workgroups per resident slot (`per_cu` of them per CU), each
 // keeping at least conv.splitk_minsteps steps; `bit` selects the kernel in conv.splitk_kernels.
-inline int pick_ksplit(long long nblocks, int nk, int per_cu, int bit, long long out_elems) {
+inline int pick_ksplit(long long nblocks, int nk, int per_cu, int bit, long long out_elems, bool tail = false) {
   const long long mask = dastune::get(dastune::CONV_SPLITK_KERNELS), target = dastune::get(dastune::CONV_SPLITK_TARGET) * per_cu;
-  const long long minsteps = std::max<long long>(1, dastune::get(dastune::CONV_SPLITK_MINSTEPS));
+  // (the tail launch of a tail-split conv is pure overhead on top of the full rounds: split it as finely as is sane)
+  const long long minsteps = tail ? 4 : std::max<long long>(1, dastune::get(dastune::CONV_SPLITK_MINSTEPS));
   if (!(mask & bit) || target <= 0 || nblocks * 2 > target) return 1;
   long long ks = std::min<long long>({target / nblocks, nk / minsteps, 16});
   while (ks > 1 && ks * out_elems * 4 > ((long long)128 << 20)) --ks;   // slabs: at most 128 MiB
@@ -699,9 +712,10 @@ int launch_splitk(Kern kern, ConvP& p, int ks, size_t sm, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)splitk_finish_kernel<OT, BN, BMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_fin);
     fin_attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.nblocks, ks), dim3(2 * BMT), sm, s, p);
+  constexpr int NT = Tiling<BN, BMT>::NT;
+  hipLaunchKernelGGL(kern, dim3(p.nblocks, ks), dim3(NT), sm, s, p);
   DAS_CHECK_LAUNCH();
-  hipLaunchKernelGGL((splitk_finish_kernel<OT, BN, BMT>), dim3(p.nblocks), dim3(2 * BMT), sm_fin, s, p);
+  hipLaunchKernelGGL((splitk_finish_kernel<OT, BN, BMT>), dim3(p.nblocks), dim3(NT), sm_fin, s, p);
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }
@@ -728,8 +742,9 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
   const int rows = p.M - p.m_base;   // rows of this launch
   const int nk128 = (int)((long long)p.K * sizeof(T) / 128);
   const long long nb3 = (long long)((rows + 255) / 256) * p.ntiles;
-  const int ks3 = (may_split && p.m_base == 0) ? pick_ksplit(nb3, nk128, 1, 2, (long long)p.M * p.Cout) : 1;
-  const bool big = may_split && glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && nb3 * ks3 >= minb &&
+  const bool tail = !may_split;   // this launch covers the rows a 256-row-tile launch left over (see tail_split_mtiles)
+  const int ks3 = pick_ksplit(nb3, nk128, 1, 2, (long long)rows * p.Cout, tail);
+  const bool big = (may_split || ks3 > 1) && glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && nb3 * ks3 >= minb &&
                    p.K >= mink &&
                    p.xbytes != 0;  // (0 = more than 4 GiB of input: not addressable by 32-bit buffer offsets)
   const int bm = big ? 256 : BM;
@@ -768,7 +783,7 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
     dastune::note_kernel("conv_glds3_kernel");
     hipLaunchKernelGGL((conv_glds3_kernel<T, OT>), dim3(p.nblocks), dim3(512), sm_big, s, p);
   } else if (glds) {
-    const int ks = (BN >= 64 && p.m_base == 0 && may_split) ? pick_ksplit(p.nblocks, nk128, 2, 1, (long long)p.M * p.Cout) : 1;
+    const int ks = BN >= 64 ? pick_ksplit(p.nblocks, nk128, 2, 1, (long long)rows * p.Cout, tail) : 1;
     if (ks > 1) {
       dastune::note_kernel("conv_glds_kernel<splitk>");
       return launch_splitk<OT, BN, 128>(conv_glds_kernel<T, OT, BN, 128>, p, ks, sm_glds, s);
@@ -1164,40 +1179,56 @@ bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
     const long long minblocks = dastune::get(dastune::CONV_GLDS4_MINBLOCKS);  // default: half a chip of 256 x 256 tiles (measured break-even)
     ConvP p = p0;
     p.ntiles = (p.Cout + 255) / 256;
-    const long long nb = (long long)((p.M + 255) / 256) * p.ntiles;
+    const long long mtiles = (p.M + 255) / 256, nb = mtiles * p.ntiles;
     const int ks4 = pick_ksplit(nb, p.K / 64, 1, 4, (long long)p.M * p.Cout);
     if (minblocks <= 0 || p.Cout < 256 || p.Cin % 32 || p.relu_in || p.up_sh != 0 || p.xbytes == 0 || nb * ks4 < minblocks)
       return false;
-    const long long mtiles = (p.M + 255) / 256, keep = ks4 > 1 ? mtiles : tail_split_mtiles(mtiles, p.ntiles, true);
-    if (keep < mtiles) {   // rows of the under-filled last round: 128 x 128 tiles, second launch
+    // ping-pong schedule for the MFMA-bound shapes (+12...15 % at K >= 512, neutral at 256, a loss for the
+    // HBM-bound K = 64 / 128 layers that finish in two or four steps)
+    const long long force_pp = dastune::get(dastune::CONV_GLDS4_PP);
+    const bool pp = force_pp >= 0 ? force_pp == 1 : p.K >= 256;
+    const size_t sm4 = std::max<size_t>(4 * (size_t)(256 + 256) * 64, epilogue_smem_bytes<OT, 256, 256>());
+    const size_t sm4x = std::max<size_t>(4 * (size_t)(288 + 256) * 64 + 1024, epilogue_smem_bytes<OT, 256, 288>());
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true, 288>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4x);
+      attr_set = true;
+    }
+    if (ks4 > 1) {
+      p.nblocks = (int)nb;
+      dastune::note_kernel("conv_glds4_kernel<splitk>");
+      const int rc = pp ? launch_splitk<OT, 256, 256>(conv_glds4_kernel<T, OT, true, 256>, p, ks4, sm4, s)
+                        : launch_splitk<OT, 256, 256>(conv_glds4_kernel<T, OT, false, 256>, p, ks4, sm4, s);
+      return rc == DAS_OK;
+    }
+    // One workgroup per CU: the launch runs in rounds of `cus` tiles. Three ways to cover M (cost in 32-row slabs per
+    // CU): 256-row tiles, all rounds (8 each); 256-row tiles with the under-filled last round handed to a split-K tail
+    // launch (measured ~4 on top of the full rounds); 288-row tiles (9 per round, fewer tiles).
+    const long long cus = device_cus(), keep = tail_split_mtiles(mtiles, p.ntiles, true);
+    const long long nb288 = (long long)((p.M + 287) / 288) * p.ntiles;
+    const long long cost256 = keep < mtiles ? (nb / cus) * 8 + 4 : ((nb + cus - 1) / cus) * 8;
+    const long long cost288 = ((nb288 + cus - 1) / cus) * 9;
+    const long long mf = dastune::get(dastune::CONV_GLDS4_MF);   // 0 = by cost, 8 / 9 force the tile height
+    if (pp && (mf == 9 || (mf == 0 && cost288 < cost256))) {
+      p.nblocks = (int)nb288;
+      dastune::note_kernel("conv_glds4_kernel<pp,288>");
+      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 288>), dim3(p.nblocks), dim3(512), sm4x, s, p);
+      return true;
+    }
+    if (keep < mtiles) {   // rows of the under-filled last round: second launch (128-row tiles, split-K)
       ConvP tail = p0;
       tail.m_base = (int)keep * 256;
       if (launch<T, OT, 128>(tail, glds, aligned, s, false) != DAS_OK) return false;
       p.M = tail.m_base;
     }
     p.nblocks = (int)(keep * p.ntiles);
-    const size_t sm4 = std::max<size_t>(4 * (size_t)(256 + 256) * 64, epilogue_smem_bytes<OT, 256, 256>());
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
-      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
-      attr_set = true;
-    }
-    // ping-pong schedule for the MFMA-bound shapes (+12...15 % at K >= 512, neutral at 256, a loss for the
-    // HBM-bound K = 64 / 128 layers that finish in two or four steps)
-    const long long force_pp = dastune::get(dastune::CONV_GLDS4_PP);
-    const bool pp = force_pp >= 0 ? force_pp == 1 : p.K >= 256;
-    if (ks4 > 1) {
-      dastune::note_kernel("conv_glds4_kernel<splitk>");
-      const int rc = pp ? launch_splitk<OT, 256, 256>(conv_glds4_kernel<T, OT, true>, p, ks4, sm4, s)
-                        : launch_splitk<OT, 256, 256>(conv_glds4_kernel<T, OT, false>, p, ks4, sm4, s);
-      return rc == DAS_OK;
-    }
     dastune::note_kernel(pp ? "conv_glds4_kernel<pp>" : "conv_glds4_kernel");
     if (pp) {
-      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true>), dim3(p.nblocks), dim3(512), sm4, s, p);
+      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 256>), dim3(p.nblocks), dim3(512), sm4, s, p);
     } else {
-      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, false>), dim3(p.nblocks), dim3(512), sm4, s, p);
+      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, false, 256>), dim3(p.nblocks), dim3(512), sm4, s, p);
     }
     return true;
   } else {

@@ -11,6 +11,7 @@ enum Key {
   CONV_BIG_MINK,         // ... and K at least this
   CONV_GLDS4_MINBLOCKS,  // conv_glds4_kernel (256 x 256 tile) from this many tiles up; 0 disables the kernel
   CONV_GLDS4_PP,         // -1 = ping-pong schedule for K >= 256, 0 / 1 force the choice
+  CONV_GLDS4_MF,         // conv_glds4_kernel pixel-tile height in 32-row units: 0 = by round count, 8 = 256 rows, 9 = 288 rows
   CONV_STREAM_MINROWS,   // conv1x1_stream_kernel from this many pixel rows up; 0 disables the kernel
   CONV_STREAM_PERCU,     // ... workgroups per CU of its persistent grid
   CONV_TAIL_SPLIT,       // 1: a 256-row-tile launch whose last round of workgroups would be under half full hands the

@@ -37,10 +37,10 @@ CASES = [
     ('conv1x1_stream_kernel', 2, 91, 93, 128, 512, 1, False),   # mode 3 without y: no ReLU on the producing layer
 ]
 FORCE = {
-    'conv_glds_kernel': {'conv.big_minblocks': 1 << 30, 'conv.glds4_minblocks': 0, 'conv.stream_minrows': 0},
-    'conv_glds3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.stream_minrows': 0},
-    'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.stream_minrows': 0},
-    'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.stream_minrows': 0},
+    'conv_glds_kernel': {'conv.big_minblocks': 1 << 30, 'conv.glds4_minblocks': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0},
+    'conv_glds3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0},
+    'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
+    'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
     'conv1x1_stream_kernel': {},
 }
 
@@ -164,7 +164,10 @@ def test_chain_backward_agrees_with_per_unit_backward(dtype):
     cos = np.array([_cos(g0[n], g1[n]) for n in big])
     floor = np.array([_cos(g0[n], g0b[n]) for n in big])
     print('median cos fused-vs-unit', np.median(cos), 'unit-vs-unit', np.median(floor), 'min', cos.min(), floor.min())
-    assert np.median(cos) > np.median(floor) - 0.03 and cos.min() > floor.min() - 0.1, (np.median(cos), np.median(floor))
+    # (bf16: the floor is itself one draw of a chaotic process — median cosine about 0.3 between two runs of the SAME
+    # path — so the comparison only has to rule out a systematically different gradient; f32 is the sharp check)
+    slack, slack_min = (0.03, 0.1) if dtype == 'f32' else (0.12, 0.3)
+    assert np.median(cos) > np.median(floor) - slack and cos.min() > floor.min() - slack_min, (np.median(cos), np.median(floor))
     if dtype == 'f32':
         assert np.median(cos) > 0.999
 

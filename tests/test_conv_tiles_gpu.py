@@ -49,10 +49,12 @@ def conv_ref(x, w, s, p):
 FORCE = {
     'conv_glds3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.splitk_target': 0,
                           'conv.stream_minrows': 0},
-    'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.splitk_target': 0,
+    'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8,
                           'conv.stream_minrows': 0},
     'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.splitk_target': 0,
-                              'conv.stream_minrows': 0},
+                              'conv.glds4_mf': 8, 'conv.stream_minrows': 0},
+    'conv_glds4_kernel<pp,288>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.splitk_target': 0,
+                                  'conv.glds4_mf': 9, 'conv.stream_minrows': 0},
 }
 
 # B, H, W, Cin, Cout, k, stride, pad
@@ -90,14 +92,14 @@ def test_glds3_forced(case):
     np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds4_kernel', 'conv_glds4_kernel<pp>'])
+@pytest.mark.parametrize('kernel', ['conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 @pytest.mark.parametrize('case', SHAPES4)
 def test_glds4_forced(kernel, case):
     x, w, y = _run_forced(kernel, case)
     np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_epilogues_forced(kernel):
     """scale / shift / residual / ReLU, then the BatchNorm statistics of the stored values (in slots)."""
     o = ops()
@@ -122,7 +124,7 @@ def test_tile_epilogues_forced(kernel):
     np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_ragged_levels_forced(kernel):
     """The head's mode: four FPN levels in one launch, shared 3x3 weights (das_head.py:176-178)."""
     o = ops()
@@ -140,7 +142,7 @@ def test_tile_ragged_levels_forced(kernel):
         np.testing.assert_allclose(nchw(y.level(l)).numpy(), ref.numpy(), **TOL)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel<pp>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_dgrad_forced(kernel):
     """Data gradient of a stride-1 3x3 conv on the tile kernels (flipped weights), with a second gradient of the
     same tensor added in the epilogue."""
@@ -280,7 +282,8 @@ def test_head_ragged_real_size():
     xs = [cases.randn(151 + i, B, Cc, h, ww) for i, (h, ww) in enumerate(sizes)]
     rag = o.Ragged.from_levels([nhwc(t) for t in xs])
     y = o.conv2d(rag, o.pack_weight(w.to(DEV), BF), 3, 3, 1, 1)
-    assert o.last_kernel() == 'conv_glds4_kernel<pp>', o.last_kernel()
+    # 553 tiles of 256 rows = 3 rounds on 256 CUs; 492 tiles of 288 rows = 2 rounds: the launcher takes the taller tile
+    assert o.last_kernel() == 'conv_glds4_kernel<pp,288>', o.last_kernel()
     torch.set_num_threads(8)
     for l in (3, 2, 1):      # (level 0 alone is 106k rows x 2304 x 256: skipped on the CPU side, levels share the code path)
         np.testing.assert_allclose(nchw(y.level(l)).numpy(), conv_ref(xs[l], w, 1, 1).numpy(), **TOL)
@@ -290,9 +293,9 @@ def test_head_ragged_real_size():
 
 
 def test_tail_split_head_conv_at_inference_batch():
-    """B = 8 head conv: 277 tiles of 256 x 256 on 256 CUs -> the 21 tiles of the second round go to 128-row tiles in a
-    second launch (conv.tail_split). Same values as the single launch; spot-checked against the CPU reference in the rows
-    either launch owns."""
+    """B = 8 head conv: 277 tiles of 256 x 256 on 256 CUs. Default: 246 tiles of 288 rows (one round). With the tile
+    height pinned to 256 the 21 tiles of the second round go to a split-K tail launch (conv.tail_split). Same values
+    as the single launch; spot-checked against the CPU reference in the rows either launch owns."""
     o = ops()
     B, Cc = 8, 256
     sizes = [(64, 104), (32, 52), (16, 26), (8, 13)]
@@ -301,15 +304,20 @@ def test_tail_split_head_conv_at_inference_batch():
     rag = o.Ragged.from_levels([nhwc(t) for t in xs])
     assert (rag.rows + 255) // 256 == 277
     wq = o.pack_weight(w.to(DEV), BF)
-    stats = torch.zeros(16 * 2 * Cc, device=DEV)
-    y = o.conv2d(rag, wq, 3, 3, 1, 1, stats=stats)
-    assert o.last_kernel() == 'conv_glds4_kernel<pp>'
-    with o.tuning(**{'conv.tail_split': 0}):
+    stats9 = torch.zeros(16 * 2 * Cc, device=DEV)
+    y9 = o.conv2d(rag, wq, 3, 3, 1, 1, stats=stats9)
+    assert o.last_kernel() == 'conv_glds4_kernel<pp,288>', o.last_kernel()
+    with o.tuning(**{'conv.glds4_mf': 8}):
+        stats = torch.zeros(16 * 2 * Cc, device=DEV)
+        y = o.conv2d(rag, wq, 3, 3, 1, 1, stats=stats)
+        assert o.last_kernel() == 'conv_glds4_kernel<pp>'
+    with o.tuning(**{'conv.tail_split': 0, 'conv.glds4_mf': 8}):
         stats1 = torch.zeros(16 * 2 * Cc, device=DEV)
         y1 = o.conv2d(rag, wq, 3, 3, 1, 1, stats=stats1)
-    np.testing.assert_allclose(y.data.float().cpu().numpy(), y1.data.float().cpu().numpy(), rtol=8e-3, atol=8e-3)
-    np.testing.assert_allclose(stats.view(16, -1).sum(0).cpu().numpy() / rag.rows, stats1.view(16, -1).sum(0).cpu().numpy() / rag.rows,
-                               rtol=1e-3, atol=1e-4)
+    for ya, sa in ((y, stats), (y9, stats9)):
+        np.testing.assert_allclose(ya.data.float().cpu().numpy(), y1.data.float().cpu().numpy(), rtol=8e-3, atol=8e-3)
+        np.testing.assert_allclose(sa.view(16, -1).sum(0).cpu().numpy() / rag.rows, stats1.view(16, -1).sum(0).cpu().numpy() / rag.rows,
+                                   rtol=1e-3, atol=1e-4)
     torch.set_num_threads(8)
     for l in (3, 2, 1):            # levels 1-3 are the last rows: the tail launch owns levels 2, 3 and the end of level 1
         np.testing.assert_allclose(nchw(y.level(l)).numpy(), conv_ref(xs[l], w, 1, 1).numpy(), **TOL)
