@@ -123,41 +123,82 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
 }
 
 // ---- GroupNorm: pass 1 = per-(level, image, group) sum / sumsq; pass 2 = normalise (+ReLU)
-template <typename T>
-__global__ void gn_stats_kernel(const T* __restrict__ x, DasLevels lv, int C, int ps, int G, int pix_per_block,
-                                float* __restrict__ stats) {
+// Both passes use one decomposition: blockIdx.y = segment (level, image), blockIdx.x = a run of `pix_per_block` pixels of
+// it; a thread keeps one 16-byte channel vector (its groups' constants stay in registers) and walks the run's pixels
+// TPB / VC apart, four loads in flight. (Levels are picked with static indices: a dynamically indexed by-value
+// argument would be copied to scratch.)
+constexpr int GN_NT = 1024;   // threads per workgroup of the GroupNorm passes (16 waves: loads in flight per CU)
+struct GnSeg {
+  int HW;
+  long long row0;
+};
+__device__ __forceinline__ GnSeg gn_segment(const DasLevels& lv, int seg) {
+  const int l = seg / lv.B, b = seg - l * lv.B;
+  GnSeg g{0, 0};
+  long long start = 0;
+#pragma unroll
+  for (int i = 0; i < DAS_MAX_LEVELS; ++i) {
+    const int hw = i < lv.num_levels ? lv.H[i] * lv.W[i] : 0;
+    if (i == l) { g.HW = hw; g.row0 = start + (long long)b * hw; }
+    start += (long long)lv.B * hw;
+  }
+  return g;
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, DasLevels lv, int C, int ps, int G,
+                                                      int pix_per_block, float* __restrict__ stats) {
   constexpr int EPV = Elem<T>::EPV;
   extern __shared__ float sred[];  // [2*C]
-  const int seg = blockIdx.y, l = seg / lv.B, b = seg % lv.B;
-  const int HW = lv.H[l] * lv.W[l];
+  const int seg = blockIdx.y;
+  const GnSeg sg = gn_segment(lv, seg);
   const int p0 = blockIdx.x * pix_per_block;
-  if (p0 >= HW) return;  // block-uniform
-  long long row0 = (long long)b * HW;
-  for (int i = 0; i < l; ++i) row0 += (long long)lv.B * lv.H[i] * lv.W[i];
-  const int VC = C / EPV;
-  for (int i = threadIdx.x; i < 2 * C; i += TPB) sred[i] = 0.f;
+  if (p0 >= sg.HW) return;  // block-uniform
+  const int VC = C / EPV, cpg = C / G;
+  for (int i = threadIdx.x; i < 2 * C; i += NT) sred[i] = 0.f;
   __syncthreads();
-  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = TPB / VC;
+  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = NT / VC;
   float s[EPV], q[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) { s[j] = 0.f; q[j] = 0.f; }
   if (pl < PL) {
-    const int p1 = min(p0 + pix_per_block, HW);
-    for (int p = p0 + pl; p < p1; p += PL) {
+    const int p1 = min(p0 + pix_per_block, sg.HW);
+    const T* base = x + sg.row0 * ps + v * EPV;
+    int p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {
+      uint4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(base + (long long)(p + u * PL) * ps);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[EPV];
+        Elem<T>::unpack(r[u], f);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+      }
+    }
+    for (; p < p1; p += PL) {
       float f[EPV];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (row0 + p) * ps + v * EPV), f);
+      Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + (long long)p * ps), f);
 #pragma unroll
       for (int j = 0; j < EPV; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
     }
+    if (cpg % EPV == 0) {   // the vector lies inside one group: one pair of LDS atomics per thread (slot = first channel)
+      float a = 0.f, c = 0.f;
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) {
-      atomicAdd(&sred[v * EPV + j], s[j]);
-      atomicAdd(&sred[C + v * EPV + j], q[j]);
+      for (int j = 0; j < EPV; ++j) { a += s[j]; c += q[j]; }
+      atomicAdd(&sred[v * EPV], a);
+      atomicAdd(&sred[C + v * EPV], c);
+    } else {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) {
+        atomicAdd(&sred[v * EPV + j], s[j]);
+        atomicAdd(&sred[C + v * EPV + j], q[j]);
+      }
     }
   }
   __syncthreads();
-  const int cpg = C / G;
-  for (int g = threadIdx.x; g < G; g += TPB) {
+  for (int g = threadIdx.x; g < G; g += NT) {
     float a = 0.f, c = 0.f;
     for (int j = 0; j < cpg; ++j) { a += sred[g * cpg + j]; c += sred[C + g * cpg + j]; }
     atomicAdd(&stats[((long long)seg * G + g) * 2], a);
@@ -165,30 +206,51 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, DasLevels lv, int C, in
   }
 }
 
-template <typename T>
-__global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, DasLevels lv, int C, int ps, int G,
-                                const float* __restrict__ stats, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float eps, int relu, long long total) {
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, DasLevels lv, int C, int ps,
+                                                      int G, int pix_per_block, const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, int relu) {
   constexpr int EPV = Elem<T>::EPV;
+  const int seg = blockIdx.y;
+  const GnSeg sg = gn_segment(lv, seg);
+  const int p0 = blockIdx.x * pix_per_block;
+  if (p0 >= sg.HW) return;
   const int VC = C / EPV, cpg = C / G;
-  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    const int v = (int)(i % VC);
-    const long long pix = i / VC;
-    const LvGeom g = lv_geom(lv, pix);
-    const long long seg = (long long)g.l * lv.B + g.b;
-    const float inv_n = 1.f / ((float)(g.H * g.W) * (float)cpg);
+  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = NT / VC;
+  if (pl >= PL) return;
+  const float inv_n = 1.f / ((float)sg.HW * (float)cpg);
+  float mean[EPV], rstd[EPV], ga[EPV], be[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int c = v * EPV + j, gi = c / cpg;
+    mean[j] = stats[((long long)seg * G + gi) * 2] * inv_n;
+    const float var = fmaxf(stats[((long long)seg * G + gi) * 2 + 1] * inv_n - mean[j] * mean[j], 0.f);
+    rstd[j] = rsqrtf(var + eps);
+    ga[j] = gamma[c]; be[j] = beta[c];
+  }
+  const int p1 = min(p0 + pix_per_block, sg.HW);
+  const long long off = sg.row0 * ps + v * EPV;
+  auto norm = [&](uint4 r) {
     float f[EPV];
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + pix * ps + v * EPV), f);
+    Elem<T>::unpack(r, f);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-      const int c = v * EPV + j, gi = c / cpg;
-      const float mean = stats[(seg * G + gi) * 2] * inv_n;
-      const float var = fmaxf(stats[(seg * G + gi) * 2 + 1] * inv_n - mean * mean, 0.f);
-      const float o = (f[j] - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
+      const float o = (f[j] - mean[j]) * rstd[j] * ga[j] + be[j];
       f[j] = relu ? fmaxf(o, 0.f) : o;
     }
-    *reinterpret_cast<uint4*>(y + pix * ps + v * EPV) = Elem<T>::pack(f);
+    return Elem<T>::pack(f);
+  };
+  int p = p0 + pl;
+  for (; p + 3 * PL < p1; p += 4 * PL) {
+    uint4 r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(x + off + (long long)(p + u * PL) * ps);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4*>(y + off + (long long)(p + u * PL) * ps) = norm(r[u]);
   }
+  for (; p < p1; p += PL)
+    *reinterpret_cast<uint4*>(y + off + (long long)p * ps) = norm(*reinterpret_cast<const uint4*>(x + off + (long long)p * ps));
 }
 }  // namespace
 
@@ -232,7 +294,7 @@ extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLe
   if (!x || !y || !gamma || !beta || !stats_ws || !lv_valid(lv) || C % 8 || C % G || pix_stride % 8 || C > 2048)
     return DAS_ERR_ARG;
   const int epv = dtype == DAS_BF16 ? 8 : 4;
-  if ((C / epv) > TPB) return DAS_ERR_ARG;
+  if ((C / epv) > GN_NT) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nseg = lv->num_levels * lv->B;
   if (hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
@@ -245,17 +307,16 @@ extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLe
   const int ppb_min = (int)dastune::get(dastune::GN_PPB);   // minimum pixels per workgroup
   if (ppb < ppb_min) ppb = ppb_min;
   chunks = (maxhw + ppb - 1) / ppb;
-  const long long total = lv_total_rows(*lv) * (C / epv);
   if (dtype == DAS_BF16) {
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(chunks, nseg), dim3(TPB), 2 * C * sizeof(float), s,
+    hipLaunchKernelGGL((gn_stats_kernel<bf16_t, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 2 * C * sizeof(float), s,
                        (const bf16_t*)x, *lv, C, pix_stride, G, ppb, stats_ws);
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, s, (const bf16_t*)x, (bf16_t*)y,
-                       *lv, C, pix_stride, G, stats_ws, gamma, beta, eps, relu, total);
+    hipLaunchKernelGGL((gn_apply_kernel<bf16_t, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 0, s, (const bf16_t*)x, (bf16_t*)y,
+                       *lv, C, pix_stride, G, ppb, stats_ws, gamma, beta, eps, relu);
   } else if (dtype == DAS_F32) {
-    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(chunks, nseg), dim3(TPB), 2 * C * sizeof(float), s,
+    hipLaunchKernelGGL((gn_stats_kernel<float, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 2 * C * sizeof(float), s,
                        (const float*)x, *lv, C, pix_stride, G, ppb, stats_ws);
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, s, (const float*)x, (float*)y,
-                       *lv, C, pix_stride, G, stats_ws, gamma, beta, eps, relu, total);
+    hipLaunchKernelGGL((gn_apply_kernel<float, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 0, s, (const float*)x, (float*)y,
+                       *lv, C, pix_stride, G, ppb, stats_ws, gamma, beta, eps, relu);
   } else {
     return DAS_ERR_ARG;
   }
