@@ -25,7 +25,8 @@ class DasConvDesc(C.Structure):
                 ('scale', vp), ('shift', vp), ('residual', vp), ('res_pix_stride', i32), ('stats', vp),
                 ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5), ('in_up', i32), ('stats_slots', i32),
                 ('bnb_raw', vp), ('bnb_y', vp), ('bnb_mean', vp), ('bnb_invstd', vp), ('bnb_gamma', vp), ('bnb_beta', vp),
-                ('bnb_relu', i32), ('bnb_pix_stride', i32)]
+                ('bnb_relu', i32), ('bnb_pix_stride', i32),
+                ('out_sub', i32), ('out_ph', i32), ('out_pw', i32), ('out_H', i32), ('out_W', i32)]
 
 
 class DasPackEntry(C.Structure):

@@ -220,7 +220,7 @@ class ConvBNTrainFn(Function):
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
-        from .nn import packed_weight_dgrad
+        from .nn import packed_weight_dgrad, packed_weight_dgrad_s2
         x, raw, y, mean, invstd, gamma, weight, beta = ctx.saved_tensors
         k, s, p, relu, has_res, conv, bn = ctx.cfg
         dy = dy.contiguous()
@@ -247,7 +247,7 @@ class ConvBNTrainFn(Function):
             if dskip is not None:
                 dskip = dskip.contiguous()
             dx = ops.conv2d_dgrad(draw, packed_weight_dgrad(conv, x.dtype), k, k, s, p, (x.shape[1], x.shape[2]),
-                                  residual=dskip)
+                                  residual=dskip, w_classes=packed_weight_dgrad_s2(conv, x.dtype))
             if dx.shape[-1] != x.shape[-1]:
                 dx = dx[..., :x.shape[-1]]
         return dx, dw, dgamma, dbeta, dres, None, None, None
@@ -310,7 +310,7 @@ class BottleneckChainFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from .nn import bn_stats_buffer, packed_weight_dgrad
+        from .nn import bn_stats_buffer, packed_weight_dgrad, packed_weight_dgrad_s2
         saved, params = ctx.saved_tensors[:ctx.nsaved], ctx.saved_tensors[ctx.nsaved:]
         blocks, plan = ctx.blocks, ctx.plan
         grads = [None] * len(params)
@@ -352,16 +352,19 @@ class BottleneckChainFn(Function):
             k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
             grads[pi] = _wgrad(xin, draw, conv.weight, k, s, p)
 
-        def dgrad(conv, draw, xin, residual=None, fuse=None):
+        def dgrad(conv, draw, xin, residual=None, fuse=None, accumulate=None):
             """data gradient of `conv` wrt xin; fuse = (raw, y, mean, invstd, gamma, beta) of the BatchNorm+ReLU layer
-            that produced xin -> returns (dZ, sums) of that layer instead of the plain gradient"""
+            that produced xin -> returns (dZ, sums) of that layer instead of the plain gradient; accumulate = a tensor
+            already holding another gradient of xin, added to in place"""
             k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
             w = packed_weight_dgrad(conv, xin.dtype)
+            wc = packed_weight_dgrad_s2(conv, xin.dtype)
             if fuse is None:
-                return ops.conv2d_dgrad(draw, w, k, k, s, p, (xin.shape[1], xin.shape[2]), residual=residual)
+                return ops.conv2d_dgrad(draw, w, k, k, s, p, (xin.shape[1], xin.shape[2]), residual=residual, w_classes=wc,
+                                        accumulate=accumulate)
             sums = bn_stats_buffer(xin, xin.shape[-1])
             dz = ops.conv2d_dgrad(draw, w, k, k, s, p, (xin.shape[1], xin.shape[2]), residual=residual,
-                                  bn_bwd=ops.BnBwd(*fuse, True), stats=sums)
+                                  bn_bwd=ops.BnBwd(*fuse, True), stats=sums, w_classes=wc)
             return dz, sums
 
         x0 = saved[0]
@@ -391,7 +394,7 @@ class BottleneckChainFn(Function):
                 drawd, _ = classic_bn(ds.bn, gd, bd, po + 10, dz3, None, rawd, md, idd, False, False)
                 wgrad(ds.conv, po + 9, xin, drawd)
                 dx1 = dgrad(blk.conv1, draw1, xin)
-                carry_dy, carry_dz = dgrad(ds.conv, drawd, xin, residual=dx1), None
+                carry_dy, carry_dz = dgrad(ds.conv, drawd, xin, accumulate=dx1), None
             elif bi > 0:   # xin is the previous block's output: mask by it, reduce for its bn3
                 pent, ppo = plan[bi - 1], offs[bi - 1]
                 praw3, pm3, pi3 = saved[pent['u'] + 8:pent['u'] + 11]
@@ -448,7 +451,7 @@ class ConvFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from .nn import packed_weight_dgrad
+        from .nn import packed_weight_dgrad, packed_weight_dgrad_s2
         x, weight, y = ctx.saved_tensors
         k, s, p, relu, geom, conv, has_bias = ctx.cfg
         if relu:
@@ -464,7 +467,8 @@ class ConvFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             hw = None if geom is not None else (x.shape[1], x.shape[2])
-            dx = _d(ops.conv2d_dgrad(dzr, packed_weight_dgrad(conv, x.dtype), k, k, s, p, hw))
+            dx = _d(ops.conv2d_dgrad(dzr, packed_weight_dgrad(conv, x.dtype), k, k, s, p, hw,
+                                     w_classes=packed_weight_dgrad_s2(conv, x.dtype)))
             if dx.shape[-1] != x.shape[-1]:
                 dx = dx[..., :x.shape[-1]]
         db = ops.colsum(dzr)[:weight.shape[0]] if has_bias else None

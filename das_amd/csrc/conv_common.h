@@ -43,6 +43,9 @@ struct ConvP {
   // and stores its raw f32 accumulators to ws[s][M][Cout]; splitk_finish_kernel sums the slabs and runs the epilogue.
   float* ws;
   int ksplit;
+  // sub-grid output (DasConvDesc.out_sub): output pixel (b, i, j) is row (b * oH + 2 i + oph) * oW + 2 j + opw of y,
+  // of the residual and of the bnb_* tensors
+  int osub, oph, opw, oH, oW;
   // ragged multi-level input (stride 1, "same" padding): rows of level l start at lvStart[l]
   int nlev, B;
   int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];
@@ -173,6 +176,13 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
 #pragma unroll
   for (int j = 0; j < EPVO; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   OT* yg = reinterpret_cast<OT*>(p.y);
+  // row of y / residual / bnb tensors that conv output row m goes to
+  auto orow = [&](int m) -> long long {
+    if (!p.osub) return m;
+    const int b = m / p.HoWo, rem = m - b * p.HoWo;
+    const int i = rem / p.Wo, j = rem - i * p.Wo;
+    return ((long long)b * p.oH + 2 * i + p.oph) * p.oW + 2 * j + p.opw;
+  };
   const OT* rg = reinterpret_cast<const OT*>(p.res);
   const OT* bxg = reinterpret_cast<const OT*>(p.bnb_raw);   // fused BatchNorm-backward reduction (see ConvP)
   const OT* byg = reinterpret_cast<const OT*>(p.bnb_y);
@@ -195,12 +205,18 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
       // the residual rows of a chunk are requested together, ahead of the LDS reads, so that their
       // memory latency overlaps instead of adding up row by row
       uint4 rv[CH], xv[CH], yv[CH];
+      long long om[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int m = m0 + r0 + (it0 + u) * RP;
+        om[u] = m < p.M ? orow(m) : 0;
+      }
       if (rg) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
           const int m = m0 + r0 + (it0 + u) * RP;
           rv[u] = make_uint4(0, 0, 0, 0);
-          if (m < p.M) rv[u] = *reinterpret_cast<const uint4*>(rg + (long long)m * p.rps + n);
+          if (m < p.M) rv[u] = *reinterpret_cast<const uint4*>(rg + om[u] * p.rps + n);
         }
       }
       if (bxg) {
@@ -209,8 +225,8 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
           const int m = m0 + r0 + (it0 + u) * RP;
           xv[u] = yv[u] = make_uint4(0, 0, 0, 0);
           if (m < p.M) {
-            xv[u] = *reinterpret_cast<const uint4*>(bxg + (long long)m * p.bnb_ps + n);
-            if (byg) yv[u] = *reinterpret_cast<const uint4*>(byg + (long long)m * p.bnb_ps + n);
+            xv[u] = *reinterpret_cast<const uint4*>(bxg + om[u] * p.bnb_ps + n);
+            if (byg) yv[u] = *reinterpret_cast<const uint4*>(byg + om[u] * p.bnb_ps + n);
           }
         }
       }
@@ -256,7 +272,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
 #pragma unroll
           for (int j = 0; j < EPVO; ++j) { ssum[j] += f[j]; ssq[j] += f[j] * (x[j] - bmu[j]) * bis[j]; }
         }
-        *reinterpret_cast<uint4*>(yg + (long long)m * p.yps + n) = outv;
+        *reinterpret_cast<uint4*>(yg + om[u] * p.yps + n) = outv;
       }
     }
   }

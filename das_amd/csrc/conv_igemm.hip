@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
 inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
   const long long min_rows = dastune::get(dastune::CONV_STREAM_MINROWS);   // 0 disables
   if (min_rows <= 0 || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.up_sh != 0 || p.relu_in ||
-      p.xbytes == 0 || p.M < min_rows)
+      p.xbytes == 0 || p.M < min_rows || p.osub)
     return false;
   if (p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
   if (p.Cout != 64 && p.Cout != 128 && p.Cout % 256 != 0) return false;
@@ -1291,6 +1291,12 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0; p.m_base = 0;
   p.ws = nullptr; p.ksplit = 1;
+  p.osub = d->out_sub ? 1 : 0; p.oph = d->out_ph; p.opw = d->out_pw; p.oH = d->out_H; p.oW = d->out_W;
+  if (p.osub) {   // sub-grid output: see DasConvDesc
+    if (p.nlev > 1 || d->stride != 1 || (unsigned)p.oph > 1u || (unsigned)p.opw > 1u || d->Ho < 1 || d->Wo < 1 ||
+        2 * (d->Ho - 1) + p.oph >= p.oH || 2 * (d->Wo - 1) + p.opw >= p.oW)
+      return DAS_ERR_ARG;
+  }
   p.bnb_raw = (const char*)d->bnb_raw; p.bnb_y = (const char*)d->bnb_y;
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta;
   p.bnb_relu = d->bnb_relu; p.bnb_ps = d->bnb_pix_stride;

@@ -97,6 +97,16 @@ def packed_weight_dgrad(conv, dtype):
     return _cache_of(conv).get(('wd', dtype), (conv.weight,), lambda: ops.pack_weight_dgrad(conv.weight, dtype))
 
 
+def packed_weight_dgrad_s2(conv, dtype):
+    """The flipped weights of a stride-2 conv split by output parity (ops.dgrad_s2_weights), or None when the conv's
+    data gradient does not take that path."""
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    if s != 2 or conv.kernel_size[0] != conv.kernel_size[1] or not ops.s2_decomposable(k, p):
+        return None
+    return _cache_of(conv).get(('wd2', dtype), (conv.weight,),
+                               lambda: ops.dgrad_s2_weights(packed_weight_dgrad(conv, dtype), k, p))
+
+
 def _pad8(v, n, fill=0.0):
     out = torch.full(((n + 7) // 8 * 8,), fill, dtype=torch.float32, device=v.device)
     out[:n] = v.detach().float()

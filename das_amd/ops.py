@@ -167,12 +167,78 @@ def pack_conv_weights(flat_src, fwd_dst, dgrad_dst, table_dev, n_entries, total_
                'das_pack_conv_weights')
 
 
-def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw, residual=None, bn_bwd=None, stats=None):
+def _s2_classes(k, pad):
+    """Stride-2 data gradient by output parity. With the flipped weights Wf (pad' = k-1-pad), dX[h] sums
+    dY_up[h - pad' + a] * Wf[a] over the taps a whose dY_up sample is not an inserted zero: a = a0, a0 + 2, ... with
+    a0 = (h + pad') % 2, reading dY[i + a' + c] for h = 2 i + ph, a = a0 + 2 a'. Per parity: (a0, taps, pad = -c)."""
+    padp, out = k - 1 - pad, []
+    for ph in (0, 1):
+        a0 = (ph + padp) % 2
+        nt = max(0, (k - a0 + 1) // 2)
+        c2 = ph - padp + a0
+        assert c2 % 2 == 0
+        out.append((a0, nt, -(c2 // 2)))
+    return out
+
+
+def dgrad_s2_weights(w_dgrad, k, pad):
+    """The flipped weights (Cin, k, k, Cout) of a stride-2 conv split by output parity: {(ph, pw): (Cin, nth, ntw, Cout)
+    contiguous} for the classes that have taps (see _s2_classes)."""
+    cls, out = _s2_classes(k, pad), {}
+    for ph, (ah, nh, _) in enumerate(cls):
+        for pw, (aw, nw, _) in enumerate(cls):
+            if nh and nw:
+                out[(ph, pw)] = w_dgrad if (k == 1) else w_dgrad[:, ah::2, aw::2, :].contiguous()
+    return out
+
+
+def s2_decomposable(k, pad):
+    """stride-2 data gradient through the parity classes: taps exist for some class, non-negative class padding"""
+    cls = _s2_classes(k, pad)
+    return any(n for _, n, _ in cls) and all(p >= 0 for _, n, p in cls if n) and len({p for _, n, p in cls if n}) == 1
+
+
+def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw, residual=None, bn_bwd=None, stats=None, w_classes=None,
+                 accumulate=None):
     """dX of conv(x, w, stride, pad): a stride-1 conv of the (zero-upsampled) dY with flipped weights.
     residual: another gradient of the same input, added in the epilogue (x that also feeds a skip path).
-    bn_bwd + stats: x is the output of a train-mode BatchNorm (+ReLU) — see `conv2d`."""
+    bn_bwd + stats: x is the output of a train-mode BatchNorm (+ReLU) — see `conv2d`.
+    Stride 2: one launch per output parity over the taps that hit dY samples (a quarter of the multiplies of the
+    zero-upsampled form); w_classes = dgrad_s2_weights(...) if the caller caches them.
+    accumulate: a tensor of dX's shape that already holds another gradient of x; the result is added into it in place
+    (only the parities that have taps are touched: a stride-2 1x1 conv reaches a quarter of the pixels)."""
     if isinstance(dy, Ragged):
+        assert accumulate is None
         return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, residual=residual, bn_bwd=bn_bwd, stats=stats)
+    if stride == 2 and KH == KW and s2_decomposable(KH, pad):
+        cls = _s2_classes(KH, pad)
+        every = all(n for _, n, _ in cls)
+        if every or (bn_bwd is None and stats is None):
+            H, W = in_hw
+            B, Cx = dy.shape[0], w_dgrad.shape[0]
+            if accumulate is not None:
+                assert residual is None and accumulate.shape == (B, H, W, Cx) and accumulate.is_contiguous()
+                out, residual = accumulate, accumulate
+            else:
+                out = torch.empty(B, H, W, Cx, dtype=dy.dtype, device=dy.device)
+            wc = w_classes if w_classes is not None else dgrad_s2_weights(w_dgrad, KH, pad)
+            for ph, (ah, nh, padc) in enumerate(cls):
+                for pw, (aw, nw, _) in enumerate(cls):
+                    hs, ws = (H - ph + 1) // 2, (W - pw + 1) // 2
+                    if hs < 1 or ws < 1:
+                        continue
+                    if nh and nw:
+                        conv2d(dy, wc[(ph, pw)], nh, nw, 1, padc, residual=residual, bn_bwd=bn_bwd, stats=stats, out=out,
+                               out_hw=(hs, ws), out_sub=(ph, pw))
+                    elif residual is not out:   # no tap reaches this parity: the other gradient alone, or zero
+                        if residual is not None:
+                            out[:, ph::2, pw::2] = residual[:, ph::2, pw::2]
+                        else:
+                            out[:, ph::2, pw::2] = 0
+            return out
+    if accumulate is not None:
+        assert residual is None
+        residual = accumulate
     return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, in_up=stride, out_hw=in_hw, residual=residual, bn_bwd=bn_bwd,
                   stats=stats)
 
@@ -349,11 +415,13 @@ def bn_train_backward_sync(dy, y, raw, mean, invstd, gamma, relu, want_dres, bet
 
 
 def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, relu_in=False,
-           out_dtype=None, stats=None, out=None, in_up=1, out_hw=None, bn_bwd=None):
+           out_dtype=None, stats=None, out=None, in_up=1, out_hw=None, bn_bwd=None, out_sub=None):
     """x (B,H,W,Cin[view]) or Ragged; w packed (Cout,KH,KW,Cin). Returns y (B,Ho,Wo,Cout) / Ragged.
     in_up / out_hw: data-gradient mode (x zero-upsampled by in_up, explicit output size).
     bn_bwd (BnBwd) + stats: the output (conv + residual) is the gradient wrt a BatchNorm(+ReLU) layer's output; the
-    kernel stores dZ = masked gradient and adds [sum dZ | sum dZ * xhat] into stats (slots as for the forward)."""
+    kernel stores dZ = masked gradient and adds [sum dZ | sum dZ * xhat] into stats (slots as for the forward).
+    out_sub = (ph, pw): `out` (required), residual and the bn_bwd tensors are (B, oH, oW, Cout); conv output pixel
+    (i, j) of the out_hw grid lands on their pixel (2 i + ph, 2 j + pw) (DasConvDesc.out_sub)."""
     _need_gpu(x, w)
     lib = _lib.load()
     ragged = isinstance(x, Ragged)
@@ -378,9 +446,14 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         else:
             Ho = (H + 2 * pad - KH) // stride + 1
             Wo = (W + 2 * pad - KW) // stride + 1
-        if out is None:
-            out = torch.empty(B, Ho, Wo, Cout, dtype=out_dtype, device=x.device)
-        assert out.shape == (B, Ho, Wo, Cout) and out.dtype == out_dtype
+        if out_sub is not None:
+            assert out is not None and out.is_contiguous() and out.shape[0] == B and out.shape[3] == Cout and stride == 1
+            full_rows = out.shape[0] * out.shape[1] * out.shape[2]
+        else:
+            if out is None:
+                out = torch.empty(B, Ho, Wo, Cout, dtype=out_dtype, device=x.device)
+            assert out.shape == (B, Ho, Wo, Cout)
+        assert out.dtype == out_dtype
         rows = B * Ho * Wo
     od, rd = _data(out), _data(residual) if residual is not None else None
     for t in (scale, shift):
@@ -392,10 +465,14 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         residual=rd.data_ptr() if rd is not None else None, res_pix_stride=_ps(residual) if rd is not None else 0,
         stats=stats.data_ptr() if stats is not None else None, num_levels=len(x.sizes) if ragged else 0,
         in_up=in_up, stats_slots=stats.numel() // (2 * Cout) if stats is not None else 0)
+    if out_sub is not None:
+        assert not ragged
+        d.out_sub, d.out_ph, d.out_pw, d.out_H, d.out_W = 1, out_sub[0], out_sub[1], out.shape[1], out.shape[2]
     if bn_bwd is not None:
         b = bn_bwd
         assert stats is not None and not relu and scale is None and shift is None and out_dtype == xd.dtype
-        assert b.raw.is_contiguous() and b.raw.shape[-1] == Cout and b.raw.numel() == rows * Cout and b.raw.dtype == out_dtype
+        assert b.raw.is_contiguous() and b.raw.shape[-1] == Cout and b.raw.dtype == out_dtype
+        assert b.raw.numel() == (full_rows if out_sub is not None else rows) * Cout
         assert b.y is None or (b.y.is_contiguous() and b.y.shape == b.raw.shape and b.y.dtype == out_dtype)
         d.bnb_raw, d.bnb_y = b.raw.data_ptr(), (b.y.data_ptr() if b.y is not None else None)
         d.bnb_mean, d.bnb_invstd = b.mean.data_ptr(), b.invstd.data_ptr()

@@ -110,6 +110,12 @@ typedef struct {
   const float* bnb_gamma;
   const float* bnb_beta;
   int bnb_relu, bnb_pix_stride;
+  /* Sub-grid output (out_sub = 1; single level, stride 1): conv output pixel (b, i, j), i < Ho, j < Wo, is row
+   * (b * out_H + 2 i + out_ph) * out_W + 2 j + out_pw of y — and of residual, bnb_raw, bnb_y, which are tensors of the
+   * full B x out_H x out_W grid. The data gradient of a stride-2 conv is four such launches, one per output parity
+   * (ph, pw), each over only the taps that land on dY samples — das_conv2d_nhwc with in_up = 2 multiplies three zeros
+   * for every sample (torch: conv_transpose / cuDNN dgrad behind mspn_mmpose.py's stride-2 Bottlenecks). */
+  int out_sub, out_ph, out_pw, out_H, out_W;
 } DasConvDesc;
 int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream);
 

@@ -248,6 +248,62 @@ def test_stream_affine_residual(cin, cout):
     np.testing.assert_allclose(nchw(y).numpy(), F.relu(aff_q + q(res)).numpy(), **TOL)
 
 
+# ---------------------------------------------------------------- stride-2 data gradient by output parity
+S2 = [
+    # B, H, W, Cin, Cout, k, pad
+    (2, 32, 52, 128, 128, 3, 1),     # the Bottleneck's 3x3 stride 2
+    (2, 32, 52, 256, 512, 1, 0),     # the downsample branch: only the even-even pixels receive a gradient
+    (1, 17, 23, 64, 72, 3, 1),       # odd sizes: the four sub-grids differ in size
+    (3, 9, 6, 64, 64, 1, 0),
+]
+
+
+@pytest.mark.parametrize('case', S2)
+def test_dgrad_stride2_parity_classes(case):
+    """conv2d_dgrad(stride 2) = one sub-grid launch per output parity (DasConvDesc.out_sub) against autograd, against the
+    zero-upsampled form (in_up = 2), with a second gradient added, and accumulating in place."""
+    o = ops()
+    B, H, W, Cin, Cout, k, p = case
+    x = cases.randn(230, B, Cin, H, W).requires_grad_(True)
+    w = cases.randn(231, Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    Ho, Wo = (H + 2 * p - k) // 2 + 1, (W + 2 * p - k) // 2 + 1
+    dy = cases.randn(232, B, Cout, Ho, Wo)
+    other = cases.randn(233, B, Cin, H, W)
+    F.conv2d(x, q(w), None, 2, p).backward(q(dy))
+    wd = o.pack_weight_dgrad(w.to(DEV), BF)
+    dx = o.conv2d_dgrad(nhwc(dy), wd, k, k, 2, p, (H, W))
+    np.testing.assert_allclose(nchw(dx).numpy(), q(x.grad).numpy(), **TOL)
+    old = o.conv2d(nhwc(dy), wd, k, k, 1, k - 1 - p, in_up=2, out_hw=(H, W))
+    np.testing.assert_allclose(nchw(dx).numpy(), nchw(old).numpy(), rtol=8e-3, atol=2e-3)
+    dx2 = o.conv2d_dgrad(nhwc(dy), wd, k, k, 2, p, (H, W), residual=nhwc(other))
+    np.testing.assert_allclose(nchw(dx2).numpy(), q(q(x.grad) + q(other)).numpy(), **TOL)
+    acc = nhwc(other).clone()
+    dx3 = o.conv2d_dgrad(nhwc(dy), wd, k, k, 2, p, (H, W), accumulate=acc)
+    assert dx3.data_ptr() == acc.data_ptr()
+    np.testing.assert_allclose(nchw(dx3).numpy(), nchw(dx2).numpy(), rtol=0, atol=0)
+
+
+def test_dgrad_stride2_fused_bn_backward():
+    """The 3x3 stride-2 data gradient with the BatchNorm-backward reduction folded in: same dZ and the same sums as the
+    zero-upsampled launch."""
+    o = ops()
+    B, H, W, Cin, Cout = 2, 32, 52, 128, 128
+    w = cases.randn(241, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
+    dy = nhwc(cases.randn(242, B, Cout, H // 2, W // 2))
+    raw = nhwc(cases.randn(243, B, Cin, H, W))
+    mean, invstd = cases.randn(244, Cin).to(DEV) * 0.1, (cases.randn(245, Cin).abs() + 0.5).to(DEV)
+    gamma, beta = (cases.randn(246, Cin).abs() + 0.5).to(DEV), (cases.randn(247, Cin) * 0.2).to(DEV)
+    wd = o.pack_weight_dgrad(w.to(DEV), BF)
+    fuse = o.BnBwd(raw, None, mean, invstd, gamma, beta, True)
+    s_new, s_old = torch.zeros(2 * Cin, device=DEV), torch.zeros(2 * Cin, device=DEV)
+    dz_new = o.conv2d_dgrad(dy, wd, 3, 3, 2, 1, (H, W), bn_bwd=fuse, stats=s_new)
+    dz_old = o.conv2d(dy, wd, 3, 3, 1, 1, in_up=2, out_hw=(H, W), bn_bwd=fuse, stats=s_old)
+    np.testing.assert_allclose(dz_new.float().cpu().numpy(), dz_old.float().cpu().numpy(), rtol=8e-3, atol=2e-3)
+    n = B * H * W
+    np.testing.assert_allclose(s_new.cpu().numpy() / n, s_old.cpu().numpy() / n, rtol=2e-3, atol=2e-4)
+    assert float((dz_new == 0).float().mean()) > 0.2      # the mask is in effect
+
+
 # ---------------------------------------------------------------- production sizes, default dispatch
 REAL = [
     # B, H, W, Cin, Cout, k, stride, pad, expected kernel
