@@ -49,9 +49,15 @@ class DAS(nn.Module):
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_poses_3d, gt_labels_3d, centers2d, depths,
                       gt_bboxes_ignore=None):
+        # the ground-truth half of the loss goes first: its host synchronisation then costs a few small kernels' latency,
+        # and everything after it (backbone, head, losses) is queued without another one
+        hw = tuple(img.shape[-2:])
+        prepare = getattr(self.bbox_head, 'prepare_targets', None)
+        targets = prepare(hw, img.shape[0], img.device, gt_poses_3d, centers2d, depths) if prepare else None
         x = self.extract_feat(img)
+        extra = dict(targets=targets, input_hw=hw) if prepare else {}
         return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_poses_3d, gt_labels_3d, centers2d,
-                                            depths, gt_bboxes_ignore)
+                                            depths, gt_bboxes_ignore, **extra)
 
     def simple_test(self, img, img_metas, rescale=False, **kwargs):
         x = self.extract_feat(img)

@@ -155,91 +155,117 @@ def _pack_centers(centers2d, depths, n, device):
                       for c, d in zip(centers2d, depths)]).contiguous()
 
 
-def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d, centers2d=None, depths=None):
+def das_head_targets(head, B, sizes, device, gt_poses_3d, centers2d=None, depths=None):
+    """Everything of DASHead.loss (das_head.py:283-478) that depends on the ground truth and the feature-map geometry
+    only: target assignment, the positive rows, the 2-D / 3-D split, the RLE targets and weights, and the host-side
+    branch conditions (counts). The detector calls this BEFORE the backbone runs (the one device-to-host copy below then
+    waits for a few small kernels instead of draining a queued forward pass), the prediction-dependent half
+    (`das_head_loss_rows`) runs without any host synchronisation."""
+    J = head.num_joints
+    geom = Ragged(torch.empty(sum(B * h * w for h, w in sizes), 0, device=device), B, sizes)
+    gt_rows, gt_start = _pack_gt(gt_poses_3d, device)
+    labels, targets, ctr_t = T.assign_targets(geom, head.strides, head.regress_ranges, gt_rows, gt_start, J,
+                                              head.center_sample_radius, head.centerness_alpha, head.background_label,
+                                              centers=_pack_centers(centers2d, depths, gt_rows.shape[0], device))
+    prep = dict(B=B, sizes=[tuple(s) for s in sizes], labels=labels)
+    is_pos = labels == 0
+    row_stride = torch.cat([torch.full((geom.starts[l + 1] - geom.starts[l],), float(s), device=device)
+                            for l, s in enumerate(head.strides)])
+    # counts first (one copy): positives, 3-D positives, visible joints
+    vis_all = (targets[:, 3 + 3 * J:] * is_pos[:, None]).sum() * (2 if head.prev_loss else 1)
+    is3d_all = is_pos & ~(targets[:, 5:3 + 3 * J:3] == 0).all(1)
+    npos, n3d, nvis_host = torch.stack([is_pos.sum().float(), is3d_all.sum().float(), vis_all]).tolist()
+    npos, n3d = int(npos), int(n3d)
+    prep.update(npos=npos, n3d=n3d, nvis_host=nvis_host)
+    if npos == 0:
+        return prep
+    pos = torch.nonzero_static(is_pos, size=npos).reshape(-1)
+    pt, pct, ps = targets[pos], ctr_t[pos], row_stride[pos]
+    gt_uvd = pt[:, 3:3 + 3 * J]
+    is2d = (gt_uvd[:, 2::3] == 0).all(1)
+    idx3d = torch.nonzero_static(~is2d, size=n3d).reshape(-1)
+    idx2d = torch.nonzero_static(is2d, size=npos - n3d).reshape(-1)
+    keep3 = (~is2d).to(pt.dtype)[:, None, None]                       # zero the z column of 2-D-only samples
+    zcol = pt.new_tensor([0.0, 0.0, 1.0])
+    root = torch.cat([pt[:, :2] * ps[:, None], torch.zeros_like(pt[:, :1])], 1)
+    real = gt_uvd.reshape(npos, J, 3) - root[:, None]
+    real = torch.cat([real[..., :2] / ps[:, None, None], real[..., 2:] / head.z_norm], -1)
+    vis_w = pt[:, 3 + 3 * J:].reshape(npos, J, 1).expand(npos, J, 3)
+    if head.prev_loss:
+        real2, vis2 = real.repeat(1, 2, 1), vis_w.repeat(1, 2, 1)
+    else:
+        real2, vis2 = real, vis_w.contiguous()
+    prep.update(pos=pos, ctr_t=pct, idx3d=idx3d, idx2d=idx2d, kill=1 - (1 - keep3) * zcol, sig_add=(1 - keep3) * zcol,
+                depth_t=pt.index_select(0, idx3d)[:, 2] * head.depth_factor if n3d else None,
+                real2=real2, vis2=vis2, nvis=vis2[..., 0].sum())
+    return prep
+
+
+def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d, centers2d=None, depths=None, prep=None):
     """cls (rows,1), pose (rows,3+6J), ctr (rows,1), aux = refined uvd (rows,3J): Ragged f32, rows ordered
     level-major / image / (h,w) exactly like the reference's flatten-and-concat (das_head.py:306-333).
-    gt_poses_3d: list per image of (G, 3+4J) [cx,cy,depth, J x (u,v,dz), J x vis]."""
+    gt_poses_3d: list per image of (G, 3+4J) [cx,cy,depth, J x (u,v,dz), J x vis].
+    prep: das_head_targets(...) of the same batch and geometry if the caller computed it ahead of the forward pass."""
     J, B, dev = head.num_joints, cls.B, cls.device
-    gt_rows, gt_start = _pack_gt(gt_poses_3d, dev)
-    labels, targets, ctr_t = T.assign_targets(cls, head.strides, head.regress_ranges, gt_rows, gt_start, J,
-                                              head.center_sample_radius, head.centerness_alpha, head.background_label,
-                                              centers=_pack_centers(centers2d, depths, gt_rows.shape[0], dev))
-    pos = (labels == 0).nonzero().reshape(-1)
-    npos = int(pos.numel())
+    if prep is None or prep['B'] != B or prep['sizes'] != [tuple(s) for s in cls.sizes]:
+        prep = das_head_targets(head, B, cls.sizes, dev, gt_poses_3d, centers2d, depths)
+    npos, n3d = prep['npos'], prep['n3d']
     if npos == 0:  # das_head.py:473-478
         z = (cls.data[0, 0] - cls.data[0, 0]).clone()
         return dict(loss_cls=z, loss_depth=z, loss_pose=z, loss_centerness=z)
 
     lc = head.loss_cls
-    loss_cls = T.FocalLossSumFn.apply(cls.data, labels, lc.gamma, lc.alpha) * (lc.loss_weight / (npos + B))
+    loss_cls = T.FocalLossSumFn.apply(cls.data, prep['labels'], lc.gamma, lc.alpha) * (lc.loss_weight / (npos + B))
 
-    row_stride = torch.cat([torch.full((cls.starts[l + 1] - cls.starts[l],), float(s), device=dev)
-                            for l, s in enumerate(head.strides)])
-    pp, pc, paux = pose.data[pos], ctr.data[pos, 0], aux.data[pos]
-    pt, pct, ps = targets[pos], ctr_t[pos], row_stride[pos]
-    cw = pp.new_tensor(head.train_cfg['code_weight']) if head.train_cfg and head.train_cfg.get('code_weight') \
-        else pp.new_ones(3 + 6 * J)
+    pos = prep['pos']
+    # (index_select: its backward is an atomic index_add; boolean / advanced indexing would sort and synchronise)
+    pp, pc, paux = pose.data.index_select(0, pos), ctr.data.index_select(0, pos)[:, 0], aux.data.index_select(0, pos)
+    cw = [float(v) for v in head.train_cfg['code_weight']] if head.train_cfg and head.train_cfg.get('code_weight') \
+        else [1.0] * (3 + 6 * J)
 
-    gt_uvd = pt[:, 3:3 + 3 * J]
-    is2d = (gt_uvd[:, 2::3] == 0).all(1)
-    is3d = ~is2d
-    # the host-side branch conditions of this function (3-D positives, 2-D-only positives, visible joints)
-    # depend on the targets only: one device-to-host copy for all of them
-    vis_sum = pt[:, 3 + 3 * J:].sum() * (2 if head.prev_loss else 1)
-    n3d, nvis_host = torch.stack([is3d.sum().float(), vis_sum]).tolist()
-    n3d = int(n3d)
     if n3d > 0:
         lr = head.loss_reg
-        loss_depth = T.SmoothL1SumFn.apply(pp[is3d, 2], pt[is3d, 2] * head.depth_factor, lr.beta) * \
-            (float(cw[2]) * lr.loss_weight / n3d)
+        loss_depth = T.SmoothL1SumFn.apply(pp.index_select(0, prep['idx3d'])[:, 2], prep['depth_t'], lr.beta) * \
+            (cw[2] * lr.loss_weight / n3d)
     else:
         loss_depth = pp[0, 2] - pp[0, 2]
 
-    keep3 = (~is2d).to(pp.dtype)[:, None, None]                       # zero the z column of 2-D-only samples
-    zcol = pp.new_tensor([0.0, 0.0, 1.0])
-    uvd = pp[:, 3:3 + 3 * J].reshape(npos, J, 3)
-    upd = paux.reshape(npos, J, 3)
-    sig = pp[:, 3 + 3 * J:].reshape(npos, J, 3)
-    kill = 1 - (1 - keep3) * zcol
-    uvd, upd = uvd * kill, upd * kill
-    sig = sig * kill + (1 - keep3) * zcol                              # sigma logit := 1 for those
-    root = torch.cat([pt[:, :2] * ps[:, None], torch.zeros_like(pt[:, :1])], 1)
-    real = gt_uvd.reshape(npos, J, 3) - root[:, None]
-    real = torch.cat([real[..., :2] / ps[:, None, None], real[..., 2:] / head.z_norm], -1)
-    vis_w = pt[:, 3 + 3 * J:].reshape(npos, J, 1).expand(npos, J, 3)
+    kill = prep['kill']
+    uvd = pp[:, 3:3 + 3 * J].reshape(npos, J, 3) * kill
+    upd = paux.reshape(npos, J, 3) * kill
+    sig = pp[:, 3 + 3 * J:].reshape(npos, J, 3) * kill + prep['sig_add']    # sigma logit := 1 for 2-D-only samples' z
     sig = sig.sigmoid() + 1e-9
+    real2, vis2 = prep['real2'], prep['vis2']
     if head.prev_loss:
-        pred = torch.cat([upd, uvd], 1)
-        real2, sig2, vis2 = real.repeat(1, 2, 1), sig.repeat(1, 2, 1), vis_w.repeat(1, 2, 1)
+        pred, sig2 = torch.cat([upd, uvd], 1), sig.repeat(1, 2, 1)
         flows = [('_update', slice(0, J)), ('', slice(J, 2 * J))]
     else:
-        pred, real2, sig2, vis2 = upd, real, sig, vis_w
+        pred, sig2 = upd, sig
         flows = [('', slice(0, J))]
     bar = (pred - real2) / sig2
-    two_d = (real2[..., 2] == 0).all(1)   # == is2d: the root's z is 0, so real z == 0 <=> gt dz == 0
-    log_phi = bar.new_zeros(npos, bar.size(1))
-    n2d = npos - n3d
     # per dimension ONE forward (and one backward) launch covers the flows of both prediction sets
-    for D, sel, name, n in ((2, two_d, 'flow2d', n2d), (3, ~two_d, 'flow3d', npos - n2d)):
+    parts = [None] * len(flows)
+    for D, idx, name, n in ((2, prep['idx2d'], 'flow2d', npos - n3d), (3, prep['idx3d'], 'flow3d', n3d)):
         if n == 0:
             continue
-        idx = sel.nonzero().reshape(-1)
-        rows = bar[sel]
+        rows = bar.index_select(0, idx)
         outs = T.realnvp_log_prob_multi([(getattr(head, name + suffix), rows[:, sl, :D].reshape(-1, D))
                                          for suffix, sl in flows])
-        for (suffix, sl), v in zip(flows, outs):
-            log_phi = log_phi.index_put((idx[:, None], torch.arange(sl.start, sl.stop, device=dev)[None]), v.view(-1, J))
+        for f, v in enumerate(outs):
+            full = bar.new_zeros(npos, J).index_copy(0, idx, v.view(-1, J))
+            parts[f] = full if parts[f] is None else parts[f] + full
+    log_phi = torch.cat(parts, 1)
     nf = torch.log(sig2) - log_phi[..., None]
     lp = head.loss_pose
-    nvis = vis2[..., 0].sum()
-    if nvis_host < 1:  # residual_log_likelihood_loss.py:24-25
+    nvis = prep['nvis']
+    if prep['nvis_host'] < 1:  # residual_log_likelihood_loss.py:24-25
         loss_pose = nvis
     else:
         q = (torch.log(sig2 / lp.amp) + (real2 - pred).abs() / (math.sqrt(2) * sig2 + 1e-9)) * vis2
-        loss_pose = ((nf * vis2 + q) * float(cw[3])).sum() / nvis
+        loss_pose = ((nf * vis2 + q) * cw[3]).sum() / nvis
 
     lctr = head.loss_centerness
-    loss_ctr = T.BCELogitsSumFn.apply(pc, pct) * (lctr.loss_weight / npos)
+    loss_ctr = T.BCELogitsSumFn.apply(pc, prep['ctr_t']) * (lctr.loss_weight / npos)
     return dict(loss_cls=loss_cls, loss_depth=loss_depth, loss_pose=loss_pose, loss_centerness=loss_ctr)
 
 

@@ -265,6 +265,7 @@ class DASHead(nn.Module):
         self.conv_centerness_prev = self._init_branch(self.centerness_branch, (1,) * len(self.centerness_branch))
         self.conv_centerness = nn.Conv2d(self.centerness_branch[-1], 1, 1)
         self.scales = nn.ModuleList([nn.ModuleList([Scale(1.0) for _ in self.group_reg_dims]) for _ in self.strides])
+        self._level_sizes = {}   # input (H, W) -> feature-map sizes per level, learnt from the first forward pass
         self.biases = nn.ModuleList([Bias(0.0, use_bias=False) for _ in self.strides])
 
     def init_weights(self):
@@ -414,7 +415,20 @@ class DASHead(nn.Module):
         dtype = self.compute_dtype or x[0].dtype
         rows = ops.Ragged.from_levels([as_nhwc(f, dtype) for f in x])
         cls, pose, ctr, ref = self.forward_rows(rows, list(range(len(x))))
-        return das_head_loss_rows(self, cls, pose, ctr, ref, gt_poses_3d, centers2d, depths)
+        prep = kwargs.get('targets')
+        if 'input_hw' in kwargs:   # remembered for prepare_targets: the level sizes this input size leads to
+            self._level_sizes[tuple(kwargs['input_hw'])] = [tuple(s) for s in rows.sizes]
+        return das_head_loss_rows(self, cls, pose, ctr, ref, gt_poses_3d, centers2d, depths, prep=prep)
+
+    def prepare_targets(self, input_hw, batch, device, gt_poses_3d, centers2d=None, depths=None):
+        """The ground-truth half of the loss (losses.das_head_targets), computed before the backbone runs so that its
+        device-to-host copy of the counts does not drain a queued forward pass. Needs the level sizes of this input
+        size: known from the second step on (None before — the loss then computes its targets itself)."""
+        from .losses import das_head_targets
+        sizes = self._level_sizes.get(tuple(input_hw))
+        if sizes is None or not self.training:
+            return None
+        return das_head_targets(self, batch, sizes, device, gt_poses_3d, centers2d, depths)
 
     def loss(self, cls_scores, pose_preds, centernesses, aux_pose_preds, gt_bboxes, gt_labels, gt_poses_3d,
              gt_labels_3d, centers2d, depths, img_metas, gt_bboxes_ignore=None):

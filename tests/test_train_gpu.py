@@ -47,14 +47,15 @@ def grad_sd(sd, dt=torch.float32):
     return out
 
 
-def band_check(e_hip, e_o32, what):
-    """HIP-vs-f64 errors must sit in the same band as oracle-f32-vs-f64 errors."""
+def band_check(e_hip, e_o32, what, slack=1.0):
+    """HIP-vs-f64 errors must sit in the same band as oracle-f32-vs-f64 errors. (slack > 1: deep train-mode nets whose
+    HIP result itself varies from run to run — f32 atomics in the BatchNorm statistics reorder the sums.)"""
     e_hip, e_o32 = np.sort(np.array(e_hip)), np.sort(np.array(e_o32))
     med = lambda e: e[len(e) // 2]
     p90 = lambda e: e[int(len(e) * 0.9)]
-    assert med(e_hip) < max(3 * med(e_o32), 2e-4), (what, 'median', med(e_hip), med(e_o32))
-    assert p90(e_hip) < max(3 * p90(e_o32), 1e-3), (what, 'p90', p90(e_hip), p90(e_o32))
-    assert e_hip[-1] < max(6 * e_o32[-1], 2e-2), (what, 'max', e_hip[-1], e_o32[-1])
+    assert med(e_hip) < max(3 * slack * med(e_o32), 2e-4), (what, 'median', med(e_hip), med(e_o32))
+    assert p90(e_hip) < max(3 * slack * p90(e_o32), 1e-3), (what, 'p90', p90(e_hip), p90(e_o32))
+    assert e_hip[-1] < max(6 * slack * e_o32[-1], 2e-2), (what, 'max', e_hip[-1], e_o32[-1])
 
 
 def param_errors(module, o64, o32, skip=()):
