@@ -409,6 +409,8 @@ def main():
     ap.add_argument('--wgrad-batch', type=int, default=None, help='A/B: weight gradients per batched launch (1 = off)')
     ap.add_argument('--no-fused-bn', action='store_true',
                     help='A/B: one autograd node per conv+BN unit (separate BatchNorm-backward reduction passes)')
+    ap.add_argument('--no-early-targets', action='store_true',
+                    help='A/B: target assignment inside the loss (after the forward pass) instead of ahead of the backbone')
     ap.add_argument('--tune', nargs='*', default=[], metavar='KEY=VALUE',
                     help='A/B: dispatch thresholds through das_tuning_set, e.g. conv.tail_split=0')
     ap.add_argument('--share-gpu', action='store_true',
@@ -463,6 +465,9 @@ def main():
         ag.WGRAD_BATCH = args.wgrad_batch
     if args.no_fused_bn:
         backbones.FUSED_LAYER_BACKWARD = False
+    if args.no_early_targets:
+        from das_amd import detectors
+        detectors.EARLY_TARGETS = False
     model = build_model(dev, seed=0, dtype=args.dtype, num_stages=stages, train=train)
     ds = SyntheticPoseDataset(num_joints=J, img_shape=(H, W), length=batch * world, seed=0)
     data = collate([ds[rank * batch + i] for i in range(batch)], device=dev)

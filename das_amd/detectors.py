@@ -11,6 +11,18 @@ import torch.nn as nn
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
+# A/B switch (bench.py --no-early-targets): compute the loss's ground-truth half beside the backbone (side stream)
+EARLY_TARGETS = True
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 @DETECTORS.register_module()
 class DAS(nn.Module):
     def __init__(self, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None):
@@ -49,12 +61,27 @@ class DAS(nn.Module):
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_poses_3d, gt_labels_3d, centers2d, depths,
                       gt_bboxes_ignore=None):
-        # the ground-truth half of the loss goes first: its host synchronisation then costs a few small kernels' latency,
-        # and everything after it (backbone, head, losses) is queued without another one
+        # The ground-truth half of the loss (target assignment, positive rows, counts) needs one device-to-host copy. It
+        # runs on a side stream AFTER the backbone has been queued: the copy waits for those few small kernels only, the
+        # main stream keeps executing the backbone meanwhile, and everything after it (head, losses) is queued without
+        # another synchronisation.
         hw = tuple(img.shape[-2:])
-        prepare = getattr(self.bbox_head, 'prepare_targets', None)
-        targets = prepare(hw, img.shape[0], img.device, gt_poses_3d, centers2d, depths) if prepare else None
+        prepare = getattr(self.bbox_head, 'prepare_targets', None) if EARLY_TARGETS else None
+        targets = None
+        if prepare and img.is_cuda:
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)                  # (the ground truth was put on the device by the main stream)
         x = self.extract_feat(img)
+        if prepare and img.is_cuda:
+            side = _side_stream(img.device)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                targets = prepare(hw, img.shape[0], img.device, gt_poses_3d, centers2d, depths)
+            main.wait_stream(side)
+            for t in (targets or {}).values():
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
         extra = dict(targets=targets, input_hw=hw) if prepare else {}
         return self.bbox_head.forward_train(x, img_metas, gt_bboxes, gt_labels, gt_poses_3d, gt_labels_3d, centers2d,
                                             depths, gt_bboxes_ignore, **extra)

@@ -17,6 +17,12 @@ def short(n):
 def main(db, skip=0):
     c = sqlite3.connect(db)
     rows = c.execute('select name, start, end from kernels order by start').fetchall()[int(skip):]
+    # steady state only: the window between the first and the last optimizer step (sgd_kernel launches of > 100 us) if
+    # the run has several, so that model construction and the first (allocating) steps stay out of the numbers
+    sgd = [i for i, (n, s, e) in enumerate(rows) if 'sgd_kernel' in n and e - s > 100000]
+    if len(sgd) >= 4:
+        rows = rows[sgd[1] + 1:sgd[-1] + 1]
+        print(f'steady-state window: {len(sgd) - 2} optimizer steps')
     busy = sum(e - s for _, s, e in rows)
     span = rows[-1][2] - rows[0][1]
     gaps = []
@@ -33,6 +39,12 @@ def main(db, skip=0):
     for g, i in gaps:
         k = by_next[short(rows[i][0])]
         k[0] += g; k[1] += 1
+    hist = defaultdict(lambda: [0, 0])
+    for g, _ in gaps:
+        b = 2 if g < 2000 else 5 if g < 5000 else 10 if g < 10000 else 20 if g < 20000 else 100 if g < 100000 else 1000
+        hist[b][0] += g; hist[b][1] += 1
+    print('-- gap histogram (bucket upper bound us: count, total ms): ' +
+          ', '.join(f'<{b}: {hist[b][1]}, {hist[b][0] / 1e6:.2f}' for b in sorted(hist)))
     print('-- idle time by the kernel that follows the gap')
     for n, (t, cnt) in sorted(by_next.items(), key=lambda kv: -kv[1][0])[:25]:
         print(f'  {t / 1e6:8.3f} ms  {cnt:6d} gaps  avg {t / cnt / 1e3:7.1f} us  {n}')
