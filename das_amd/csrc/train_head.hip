@@ -4,6 +4,10 @@
 // hands zeroed f32 buffers.
 #include "common.h"
 
+#ifndef DAS_DCN_TG
+#define DAS_DCN_TG 3   // taps per load group of deform_col2im_kernel (1, 3 or 9)
+#endif
+
 namespace {
 constexpr int TPB = 256;
 inline int grid_for(long long n, int cap = 16384) {
@@ -81,15 +85,26 @@ __global__ __launch_bounds__(TPB) void deform_col2im_gather_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       unsigned long long hits = __ballot(coef[r] != 0.f);
+      // four hits per trip: their dcol vectors are requested together (one load in flight per wave left this kernel
+      // latency bound). A missing hit repeats the last one with coefficient 0; the summation order is unchanged.
       while (hits) {
-        const int l = __builtin_ctzll(hits);
-        hits &= hits - 1;
-        const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef[r]), l));
-        const int dr = __builtin_amdgcn_readlane(drow[r], l);
+        float cf[4];
+        int dr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int l = hits ? __builtin_ctzll(hits) : 0;
+          cf[u] = hits ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef[r]), l)) : 0.f;
+          dr[u] = hits ? __builtin_amdgcn_readlane(drow[r], l) : (u ? dr[u - 1] : 0);
+          hits &= hits - 1;
+        }
         if (ch < C) {
-          float v[4];
-          load4(dcol + (long long)dr * C + ch, v);
-          a0 += cf * v[0]; a1 += cf * v[1]; a2 += cf * v[2]; a3 += cf * v[3];
+          float v[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) load4(dcol + (long long)dr[u] * C + ch, v[u]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (cf[u] != 0.f) { a0 += cf[u] * v[u][0]; a1 += cf[u] * v[u][1]; a2 += cf[u] * v[u][2]; a3 += cf[u] * v[u][3]; }
+          }
         }
       }
     }
@@ -116,71 +131,129 @@ __device__ __forceinline__ float wave_sum63(float v) {
 // gradients, one wave reduction per tap written once, and the corner scatters of the irregular pairs as f32
 // atomics (lane = one channel there, so that a wave's atomics are contiguous). Measured: fetching the nine taps'
 // dcol vectors up front and batching the 27 reductions costs more in registers than it hides in latency.
+// (raw 4-channel vectors: kept packed while in flight, 2 registers for bf16)
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+  using type = float4;
+  static __device__ __forceinline__ void unpack(const float4& t, float* v) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+};
+template <> struct Raw4<bf16_t> {
+  using type = uint2;
+  static __device__ __forceinline__ void unpack(const uint2& t, float* v) {
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+};
+
+// One WAVE = one pixel: the offset / mask gradients (one wave reduction per tap, written once) and the corner scatters
+// of the irregular pairs as f32 atomics (lane = one channel there, so that a wave's atomics are contiguous).
+// The per-tap geometry (sigmoid, floor, bilinear weights, corner rows) is computed ONCE, by lane k for tap k, and
+// handed to the channel loop through readlane (scalar registers): computed per tap in every lane it made the kernel
+// VALU bound (2150 vector instructions per pixel, SQ_INSTS_VALU; 0.5 ms of the 0.7).
+__device__ __forceinline__ float rl_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 template <typename T>
 __global__ __launch_bounds__(TPB) void deform_col2im_kernel(const T* __restrict__ x, const float* __restrict__ om,
                                                             const T* __restrict__ dcol, float* __restrict__ dx,
                                                             float* __restrict__ dom, DasLevels lv, int C, int xps,
                                                             int omps, int domps, long long rows) {
 #pragma clang fp contract(off)
+  using R4 = typename Raw4<T>::type;
+  constexpr int TG = DAS_DCN_TG;   // taps whose 5 vectors (dcol + 4 corners, kept packed) are requested together
+  static_assert(9 % TG == 0, "tap groups");
   const int lane = threadIdx.x & 63;
   const long long m = ((long long)blockIdx.x * TPB + threadIdx.x) >> 6;
   if (m >= rows) return;
   const LvGeom g = lv_geom(lv, m);
   const int H = g.H, W = g.W;
-  const float ov = lane < 27 ? om[m * omps + lane] : 0.f;
+  // ---- lane k < 9: tap k
+  const int kk = lane < 9 ? lane : 0;
+  const float* o = om + m * omps;
+  const float ody = o[2 * kk], odx = o[2 * kk + 1], logit = o[18 + kk];
+  const float vmask = 1.f / (1.f + expf(-logit));
+  const float py = (float)(g.h - 1 + kk / 3) + ody;
+  const float px = (float)(g.w - 1 + kk % 3) + odx;
+  const bool vlive = py > -1.f && px > -1.f && py < (float)H && px < (float)W;
+  const float fy = floorf(py), fx = floorf(px);
+  const int vy0 = vlive ? (int)fy : 0, vx0 = vlive ? (int)fx : 0;
+  const float vly = py - fy, vlx = px - fx;
+  int vok = vlive ? 16 : 0;     // bit c = corner c inside the plane, bit 4 = tap live, bit 5 = irregular pair
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int yy = vy0 + (c >> 1), xx = vx0 + (c & 1);
+    if (vlive && yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1) vok |= 1 << c;
+  }
+  if (vlive && !dcn_regular(vy0, vx0, g.h, g.w)) vok |= 32;
+  const int vrow = (int)(g.plane0 + (long long)vy0 * W + vx0);   // pixel row of corner 0 (rows < 2^31: checked by the host)
+
   const T* dc = dcol + m * 9 * C;
   float* d = dom + m * domps;
 #pragma unroll 1
-  for (int k = 0; k < 9; ++k) {
-    const float ody = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ov), 2 * k));
-    const float odx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ov), 2 * k + 1));
-    const float logit = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ov), 18 + k));
-    const float mask = 1.f / (1.f + expf(-logit));
-    const float py = (float)(g.h - 1 + k / 3) + ody;
-    const float px = (float)(g.w - 1 + k % 3) + odx;
-    if (!(py > -1.f && px > -1.f && py < (float)H && px < (float)W)) continue;  // wave-uniform
-    const float fy = floorf(py), fx = floorf(px);
-    const int y0 = (int)fy, x0 = (int)fx;
-    const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
-    const float wts[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
-    const float wy[4] = {-hx, -lx, hx, lx};   // d(weight)/d(py)
-    const float wx[4] = {-hy, hy, -ly, ly};   // d(weight)/d(px)
-    float val = 0.f, gpy = 0.f, gpx = 0.f;
+  for (int k0 = 0; k0 < 9; k0 += TG) {
+    float val[TG], gpy[TG], gpx[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) { val[t] = 0.f; gpy[t] = 0.f; gpx[t] = 0.f; }
     for (int c0 = 0; c0 < C; c0 += 256) {
       const int ch = c0 + lane * 4;
       if (ch >= C) break;
-      float gc[4];
-      load4(dc + k * C + ch, gc);
+      R4 gr[TG], fr[TG][4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
-        if (yy < 0 || yy > H - 1 || xx < 0 || xx > W - 1) continue;  // wave-uniform
-        const long long pix = g.plane0 + (long long)yy * W + xx;
-        float f[4];
-        load4(x + pix * xps + ch, f);
-        const float dot = (gc[0] * f[0] + gc[1] * f[1]) + (gc[2] * f[2] + gc[3] * f[3]);
-        val += wts[c] * dot;
-        gpy += wy[c] * dot;
-        gpx += wx[c] * dot;
+      for (int t = 0; t < TG; ++t) {
+        const int ok = __builtin_amdgcn_readlane(vok, k0 + t), row = __builtin_amdgcn_readlane(vrow, k0 + t);
+        gr[t] = *reinterpret_cast<const R4*>(dc + (k0 + t) * C + ch);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {   // (a corner outside the plane re-reads this pixel's own row: never used)
+          const long long pix = (ok >> c & 1) ? (long long)row + (c >> 1) * W + (c & 1) : m;
+          fr[t][c] = *reinterpret_cast<const R4*>(x + pix * xps + ch);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        const int ok = __builtin_amdgcn_readlane(vok, k0 + t);
+        const float ly = rl_f(vly, k0 + t), lx = rl_f(vlx, k0 + t);
+        float gc[4];
+        Raw4<T>::unpack(gr[t], gc);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float wts[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+        const float wy[4] = {-hx, -lx, hx, lx};     // d(weight)/d(py)
+        const float wx[4] = {-hy, hy, -ly, ly};     // d(weight)/d(px)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (!(ok >> c & 1)) continue;   // wave-uniform
+          float f[4];
+          Raw4<T>::unpack(fr[t][c], f);
+          const float dot = (gc[0] * f[0] + gc[1] * f[1]) + (gc[2] * f[2] + gc[3] * f[3]);
+          val[t] += wts[c] * dot;
+          gpy[t] += wy[c] * dot;
+          gpx[t] += wx[c] * dot;
+        }
       }
     }
-    if (!dcn_regular(y0, x0, g.h, g.w)) {   // (regular pairs: dx comes from the gather kernel)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
-        // a corner with zero bilinear weight adds exactly 0.0: skip the atomics (wave-uniform)
-        if (yy < 0 || yy > H - 1 || xx < 0 || xx > W - 1 || wts[c] == 0.f) continue;
-        float* dst = dx + (g.plane0 + (long long)yy * W + xx) * C;
-        for (int ch = lane; ch < C; ch += 64) atomicAdd(dst + ch, Elem<T>::load(dc + k * C + ch) * mask * wts[c]);
+    for (int t = 0; t < TG; ++t) {
+      const int k = k0 + t;
+      const int ok = __builtin_amdgcn_readlane(vok, k);
+      if (!(ok & 16)) continue;   // wave-uniform: the outputs of a dead tap stay as the caller zeroed them
+      const float mask = rl_f(vmask, k);
+      if (ok & 32) {   // irregular pair (regular pairs: dx comes from the gather kernel)
+        const float ly = rl_f(vly, k), lx = rl_f(vlx, k), hy = 1.f - ly, hx = 1.f - lx;
+        const float wts[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+        const int row = __builtin_amdgcn_readlane(vrow, k);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          // a corner with zero bilinear weight adds exactly 0.0: skip the atomics (wave-uniform)
+          if (!(ok >> c & 1) || wts[c] == 0.f) continue;
+          float* dst = dx + ((long long)row + (c >> 1) * W + (c & 1)) * C;
+          for (int ch = lane; ch < C; ch += 64) atomicAdd(dst + ch, Elem<T>::load(dc + k * C + ch) * mask * wts[c]);
+        }
       }
-    }
-    val = wave_sum63(val);
-    gpy = wave_sum63(gpy);
-    gpx = wave_sum63(gpx);
-    if (lane == 63) {
-      d[2 * k] = gpy * mask;
-      d[2 * k + 1] = gpx * mask;
-      d[18 + k] = val * mask * (1.f - mask);
+      const float v = wave_sum63(val[t]), py_ = wave_sum63(gpy[t]), px_ = wave_sum63(gpx[t]);
+      if (lane == 63) {
+        d[2 * k] = py_ * mask;
+        d[2 * k + 1] = px_ * mask;
+        d[18 + k] = v * mask * (1.f - mask);
+      }
     }
   }
 }
