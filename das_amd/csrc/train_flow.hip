@@ -4,27 +4,40 @@
 //   log_prob(x): for i = L-1..0:  z_ = m_i z;  s = snet_i(z_) (1-m_i);  t = tnet_i(z_) (1-m_i);
 //                                 z = (1-m_i) (z - t) exp(-s) + z_;  logdet -= sum s
 //                log p = -|z|^2/2 - D/2 log 2pi + logdet
-// The reference runs this as ~1000 tiny torch kernels per step; here it is two kernels (forward, backward)
-// over N = positives x joints rows:
-//   forward : one thread per row, activations in registers; every lane uses the same weights, so they are
-//             fetched with scalar loads (wave-uniform addresses) and the FMAs read them from SGPRs.
+// The reference runs this as ~1000 tiny torch kernels per step; here it is two kernels (forward, backward) over
+// N = positives x joints rows. N is small (about 10^4): with one thread per row the launch is 176 waves on 1024 SIMDs,
+// each walking 80 000 (forward) / 180 000 (backward) dependent instructions alone on its SIMD — 0.65 / 1.45 ms. So a
+// row is spread over a GROUP OF 16 LANES (one DPP row): lane q owns hidden units 4q..4q+3 of both hidden layers.
+//   layer 1 (D -> 64)   : 4 x D FMAs per lane
+//   layer 2 (64 -> 64)  : the 64 inputs are gathered from the group (ds_bpermute), the lane's 4 x 64 weights come from
+//                         LDS as one 16-byte read per input (W2 staged transposed: conflict-free)
+//   layer 3 (64 -> D)   : 4 partial products per lane and output, summed over the group (4 xor-shuffles)
+// A block is 1024 threads = 64 rows; a net's parameters are staged in LDS once per block. 16 x the waves and a
+// sixteenth of the instructions per wave: latency is hidden by the other waves of the SIMD.
 //   backward: the coupling layers are invertible, so nothing but the final z is saved — each layer's input is
-//             recovered from its output while walking back. Per net: a row phase (thread = row: recompute the
-//             MLP, back-propagate) alternates with a weight phase (thread = 16 weights of W2, or one weight of
-//             W1 / W3: reduce  sum_r delta[r] (x) h[r]  over the block's 256 rows from LDS) — no per-row
-//             atomics, one atomic per weight per block.
+//             recovered from its output while walking back. Per net the row phase above is re-run and back-propagated
+//             (delta2, delta1 per lane: its 4 hidden units), alternating with weight phases in which the block's 64
+//             rows of (delta, activation) pairs, parked in LDS, are reduced per weight: one atomic per weight per block.
 // params per flow (f32): layer i = [t-net | s-net], net = W1[64][D] b1[64] W2[64][64] b2[64] W3[D][64] b3[D].
 #include "common.h"
 
 namespace {
-constexpr int FH = 64;        // hidden width
-constexpr int FR = 256;       // rows per block = threads per block
+constexpr int FH = 64;          // hidden width
+constexpr int FR = 256;         // job row ranges are aligned to this (python pads)
+constexpr int GL = 16;          // lanes per row
+constexpr int NT = 1024;        // threads per block
+constexpr int RPB = NT / GL;    // rows per block
 constexpr float SLOPE = 0.01f;  // nn.LeakyReLU default
 
 template <int D>
 struct Net {
   static constexpr int W1 = 0, B1 = W1 + FH * D, W2 = B1 + FH, B2 = W2 + FH * FH, W3 = B2 + FH, B3 = W3 + D * FH,
                        SIZE = B3 + D;
+};
+// LDS image of one net (floats): W1 rows padded to 4, W2 both ways (row-major for the backward's W2^T delta)
+struct Lds {
+  static constexpr int W1 = 0, B1 = W1 + FH * 4, W2T = B1 + FH, W2 = W2T + FH * FH, B2 = W2 + FH * FH, W3 = B2 + FH,
+                       B3 = W3 + 4 * FH, SIZE = B3 + 4;
 };
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : SLOPE * v; }
@@ -36,69 +49,91 @@ struct FlowJobs {
   DasFlowJob j[DAS_FLOW_MAX_JOBS];
 };
 __device__ __forceinline__ DasFlowJob job_of_block(const FlowJobs& jobs) {
-  const int row0 = blockIdx.x * FR;
+  const int row0 = blockIdx.x * RPB;
   int ji = 0;
   for (int q = 1; q < DAS_FLOW_MAX_JOBS; ++q)
     if (q < jobs.n && row0 >= jobs.j[q].row_start) ji = q;
   return jobs.j[ji];
 }
 
-// a1 -> h1 -> a2 -> h2 -> out for one row; w = the net's parameters in LDS. zin: masked input (D values).
+// value of lane `src` (0..15) of this lane's group
+__device__ __forceinline__ float grp(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((threadIdx.x & ~(GL - 1) & 63) + src) << 2,
+                                                                __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((threadIdx.x & 63) ^ m) << 2, __builtin_bit_cast(int, v)));
+  return v;
+}
+
+// global -> LDS image of one net (all threads of the block; callers put barriers around it)
 template <int D>
-__device__ __forceinline__ void mlp_forward(const float* __restrict__ w, const float* zin, float* h1, float* h2,
+__device__ __forceinline__ void stage_net(const float* __restrict__ w, float* __restrict__ sw, bool with_rowmajor) {
+  const int t = threadIdx.x;
+  {   // W2: thread t brings W2[o][i0..i0+3], o = t >> 4, i0 = (t & 15) * 4
+    const int o = t >> 4, i0 = (t & 15) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(w + Net<D>::W2 + o * FH + i0);
+    sw[Lds::W2T + (i0 + 0) * FH + o] = v.x; sw[Lds::W2T + (i0 + 1) * FH + o] = v.y;
+    sw[Lds::W2T + (i0 + 2) * FH + o] = v.z; sw[Lds::W2T + (i0 + 3) * FH + o] = v.w;
+    if (with_rowmajor) *reinterpret_cast<float4*>(sw + Lds::W2 + o * FH + i0) = v;
+  }
+  if (t < FH) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) sw[Lds::W1 + t * 4 + d] = d < D ? w[Net<D>::W1 + t * D + (d < D ? d : 0)] : 0.f;
+    sw[Lds::B1 + t] = w[Net<D>::B1 + t];
+    sw[Lds::B2 + t] = w[Net<D>::B2 + t];
+#pragma unroll
+    for (int c = 0; c < D; ++c) sw[Lds::W3 + c * FH + t] = w[Net<D>::W3 + c * FH + t];
+    if (t < D) sw[Lds::B3 + t] = w[Net<D>::B3 + t];
+  }
+}
+
+// One row per group of 16 lanes; lane q holds hidden units 4q..4q+3. zin: the masked input (the same in all lanes of
+// the group). Returns h1[4], h2[4] (this lane's units) and out[D] (replicated).
+template <int D>
+__device__ __forceinline__ void mlp_forward(const float* __restrict__ sw, const float* zin, float* h1, float* h2,
                                             float* out) {
+  const int q = threadIdx.x & (GL - 1);
 #pragma unroll
-  for (int k = 0; k < FH; ++k) {
-    float a = w[Net<D>::B1 + k];
-#pragma unroll
-    for (int d = 0; d < D; ++d) a += w[Net<D>::W1 + k * D + d] * zin[d];
-    h1[k] = lrelu(a);
-    if ((k & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+  for (int oo = 0; oo < 4; ++oo) {
+    const float4 w1 = *reinterpret_cast<const float4*>(sw + Lds::W1 + (4 * q + oo) * 4);
+    float a = sw[Lds::B1 + 4 * q + oo];
+    a += w1.x * zin[0];
+    a += w1.y * zin[1];
+    if (D > 2) a += w1.z * zin[D > 2 ? 2 : 0];
+    h1[oo] = lrelu(a);
   }
-  // Fully unrolled on purpose: h1/h2 live in registers, which only works with compile-time indices. The
-  // weight row of output o+1 is requested from LDS before the 64 FMAs of output o; the scheduling barrier
-  // per output keeps the compiler from hoisting hundreds of LDS loads (and spilling).
-  float4 wrow[2][FH / 4];
+  const float4 b2 = *reinterpret_cast<const float4*>(sw + Lds::B2 + 4 * q);
+  float acc[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll 2
+  for (int s = 0; s < GL; ++s) {   // (not fully unrolled: the compiler would hoist all 64 LDS reads and spill)
 #pragma unroll
-  for (int i4 = 0; i4 < FH / 4; ++i4) wrow[0][i4] = reinterpret_cast<const float4*>(w + Net<D>::W2)[i4];
-#pragma unroll
-  for (int o = 0; o < FH; ++o) {
-    if (o + 1 < FH) {
-#pragma unroll
-      for (int i4 = 0; i4 < FH / 4; ++i4)
-        wrow[(o + 1) & 1][i4] = reinterpret_cast<const float4*>(w + Net<D>::W2 + (o + 1) * FH)[i4];
+    for (int v = 0; v < 4; ++v) {
+      const float hv = grp(h1[v], s);
+      const float4 w = *reinterpret_cast<const float4*>(sw + Lds::W2T + (4 * s + v) * FH + 4 * q);
+      acc[0] += w.x * hv; acc[1] += w.y * hv; acc[2] += w.z * hv; acc[3] += w.w * hv;
     }
-    float a = w[Net<D>::B2 + o];
-#pragma unroll
-    for (int i4 = 0; i4 < FH / 4; ++i4) {
-      const float4 v = wrow[o & 1][i4];
-      a += v.x * h1[i4 * 4] + v.y * h1[i4 * 4 + 1] + v.z * h1[i4 * 4 + 2] + v.w * h1[i4 * 4 + 3];
-    }
-    h2[o] = lrelu(a);
-    __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int oo = 0; oo < 4; ++oo) h2[oo] = lrelu(acc[oo]);
 #pragma unroll
   for (int c = 0; c < D; ++c) {
-    float a = w[Net<D>::B3 + c];
-    const float4* row = reinterpret_cast<const float4*>(w + Net<D>::W3 + c * FH);
-#pragma unroll
-    for (int i4 = 0; i4 < FH / 4; ++i4) {
-      const float4 v = row[i4];
-      a += v.x * h2[i4 * 4] + v.y * h2[i4 * 4 + 1] + v.z * h2[i4 * 4 + 2] + v.w * h2[i4 * 4 + 3];
-    }
-    out[c] = a;
-    __builtin_amdgcn_sched_barrier(0);
+    const float4 w3 = *reinterpret_cast<const float4*>(sw + Lds::W3 + c * FH + 4 * q);
+    out[c] = grp_sum(w3.x * h2[0] + w3.y * h2[1] + w3.z * h2[2] + w3.w * h2[3]) + sw[Lds::B3 + c];
   }
 }
 
 // ------------------------------------------------------------------ forward
 template <int D>
-__global__ __launch_bounds__(FR) void realnvp_fwd_kernel(const float* __restrict__ x, FlowJobs jobs, int layers,
+__global__ __launch_bounds__(NT) void realnvp_fwd_kernel(const float* __restrict__ x, FlowJobs jobs, int layers,
                                                          unsigned mask_bits, float* __restrict__ logp,
                                                          float* __restrict__ zout) {
+  __shared__ __attribute__((aligned(16))) float sw[Lds::SIZE];
   const DasFlowJob job = job_of_block(jobs);
   const float* __restrict__ params = job.params;
-  const int r = blockIdx.x * FR + threadIdx.x;
+  const int r = blockIdx.x * RPB + (threadIdx.x >> 4);
   const bool live = r >= job.row_start && r < job.row_end;
   float z[D], logdet = 0.f;
 #pragma unroll
@@ -108,11 +143,12 @@ __global__ __launch_bounds__(FR) void realnvp_fwd_kernel(const float* __restrict
     float zin[D], s[D], t[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) zin[d] = ((m >> d) & 1u) ? z[d] : 0.f;
-    for (int which = 1; which >= 0; --which) {   // s-net, then t-net (one inlined copy of the MLP code)
-      float h1[FH], h2[FH], out[D];
-      // every lane uses the same weights: wave-uniform addresses -> scalar loads, the FMAs take them from SGPRs
-      const float* w = params + (size_t)(i * 2 + which) * Net<D>::SIZE;
-      mlp_forward<D>(w, zin, h1, h2, out);
+    for (int which = 1; which >= 0; --which) {   // s-net, then t-net
+      float h1[4], h2[4], out[D];
+      __syncthreads();   // the previous net's image is no longer read
+      stage_net<D>(params + (size_t)(i * 2 + which) * Net<D>::SIZE, sw, false);
+      __syncthreads();
+      mlp_forward<D>(sw, zin, h1, h2, out);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if (which == 1) s[d] = out[d]; else t[d] = out[d];
@@ -127,7 +163,7 @@ __global__ __launch_bounds__(FR) void realnvp_fwd_kernel(const float* __restrict
       }
     }
   }
-  if (live) {
+  if (live && (threadIdx.x & (GL - 1)) == 0) {
     float q = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) { q += z[d] * z[d]; zout[(size_t)r * D + d] = z[d]; }
@@ -136,32 +172,8 @@ __global__ __launch_bounds__(FR) void realnvp_fwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------ backward
-// Weight phase: dW2[o][i] (+db2), dW1[k][d] (+db1), dW3[c][k] (+db3) of one net from the block's rows in LDS.
-//   bufH: [FR][FH] left factor rows, bufD: [FR][FH] right factor rows.
-__device__ __forceinline__ void reduce_w2(const float* __restrict__ H1, const float* __restrict__ D2, float* dW2,
-                                          float* db2) {
-  const int t = threadIdx.x, o = t >> 2, i0 = (t & 3) * 16;
-  float acc[16], bsum = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-#pragma unroll 2
-  for (int r = 0; r < FR; ++r) {
-    const float dv = D2[r * FH + o];
-    const float4* h = reinterpret_cast<const float4*>(H1 + r * FH + i0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = h[q];
-      acc[q * 4] += dv * v.x; acc[q * 4 + 1] += dv * v.y; acc[q * 4 + 2] += dv * v.z; acc[q * 4 + 3] += dv * v.w;
-    }
-    bsum += dv;
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) atomicAdd(dW2 + o * FH + i0 + j, acc[j]);
-  if ((t & 3) == 0) atomicAdd(db2 + o, bsum);
-}
-
 template <int D>
-__global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict__ zfin, const float* __restrict__ glogp,
+__global__ __launch_bounds__(NT) void realnvp_bwd_kernel(const float* __restrict__ zfin, const float* __restrict__ glogp,
                                                          FlowJobs jobs, int layers, unsigned mask_bits,
                                                          float* __restrict__ dx) {
   const DasFlowJob job = job_of_block(jobs);
@@ -169,12 +181,13 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
   float* __restrict__ dparams = job.dparams;
   float* const* __restrict__ dst_table = job.dst_table;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* buf0 = sm;                       // [FR][FH]
-  float* buf1 = buf0 + FR * FH;           // [FR][FH]
-  float* sm3 = buf1 + FR * FH;            // [FR][4] delta3 rows
-  float* smz = sm3 + FR * 4;              // [FR][4] masked inputs
-  const int tid = threadIdx.x;
-  const int r = blockIdx.x * FR + tid;
+  float* sw = sm;                         // Lds image of the net
+  float* bufA = sw + Lds::SIZE;           // [RPB][FH] activations (h2, then h1, then delta1)
+  float* bufD = bufA + RPB * FH;          // [RPB][FH] delta2
+  float* sm3 = bufD + RPB * FH;           // [RPB][4] delta3 rows
+  float* smz = sm3 + RPB * 4;             // [RPB][4] masked inputs
+  const int tid = threadIdx.x, q = tid & (GL - 1), rg = tid >> 4;
+  const int r = blockIdx.x * RPB + rg;
   const bool live = r >= job.row_start && r < job.row_end;
   const float g = live ? glogp[r] : 0.f;
   float z[D], dz[D];
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
   }
   for (int i = 0; i < layers; ++i) {      // forward went L-1..0, so walk 0..L-1
     const unsigned m = (mask_bits >> (i * D)) & ((1u << D) - 1u);
-    float zin[D], sraw[D], tval[D];
+    float zin[D], tval[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) zin[d] = ((m >> d) & 1u) ? z[d] : 0.f;
     float dzin_m[D];                      // gradient reaching the masked inputs through the two nets
@@ -194,15 +207,14 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
     float sd[D], es[D];
     // two passes: s-net first (its output is needed to invert the layer), then t-net
     for (int which = 1; which >= 0; --which) {
-      float A[FH], Bv[FH], out[D], d3[D];
-      // the net's weights: wave-uniform global addresses -> scalar loads (no LDS staging)
-      const float* wl = params + (size_t)(i * 2 + which) * Net<D>::SIZE;
-      __syncthreads();   // the previous net's weight phase has finished reading buf0 / smz
-      mlp_forward<D>(wl, zin, A, Bv, out);       // A = h1, Bv = h2
+      float h1[4], h2[4], out[D], d3[D];
+      __syncthreads();   // the previous net's weight phase has finished reading the image / bufA / smz
+      stage_net<D>(params + (size_t)(i * 2 + which) * Net<D>::SIZE, sw, true);
+      __syncthreads();
+      mlp_forward<D>(sw, zin, h1, h2, out);
       if (which == 1) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          sraw[d] = out[d];
           sd[d] = ((m >> d) & 1u) ? 0.f : tanhf(out[d]);
           es[d] = expf(-sd[d]);
           // ds = -dz * z_out - g on the transformed dims; through tanh
@@ -229,95 +241,89 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
       float* gB2 = tb ? tb[3] : gp + Net<D>::B2;
       float* gW3 = tb ? tb[4] : gp + Net<D>::W3;
       float* gB3 = tb ? tb[5] : gp + Net<D>::B3;
-      // ---- layer 3: dW3 = sum_r d3 (x) h2
+      // delta2 = (W3^T d3) * lrelu'(a2)   (sign(a2) = sign(h2)); delta1 = (W2^T delta2) * lrelu'(a1)
+      float d2[4], d1[4];
 #pragma unroll
-      for (int k = 0; k < FH; ++k) buf1[tid * FH + k] = Bv[k];
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        sm3[tid * 4 + d] = d < D ? d3[d < D ? d : 0] : 0.f;
-        smz[tid * 4 + d] = d < D ? zin[d < D ? d : 0] : 0.f;
-      }
-      __syncthreads();
-      if (tid < D * FH) {
-        const int c = tid / FH, k = tid - c * FH;
-        float acc = 0.f;
-        for (int rr = 0; rr < FR; ++rr) acc += sm3[rr * 4 + c] * buf1[rr * FH + k];
-        atomicAdd(gW3 + c * FH + k, acc);
-      } else if (tid < D * FH + D) {
-        const int c = tid - D * FH;
-        float acc = 0.f;
-        for (int rr = 0; rr < FR; ++rr) acc += sm3[rr * 4 + c];
-        atomicAdd(gB3 + c, acc);
-      }
-      // delta2 = (W3^T d3) * lrelu'(a2)   (sign(a2) = sign(h2)), overwriting h2
-#pragma unroll
-      for (int k = 0; k < FH; ++k) {
+      for (int oo = 0; oo < 4; ++oo) {
         float a = 0.f;
 #pragma unroll
-        for (int c = 0; c < D; ++c) a += wl[Net<D>::W3 + c * FH + k] * d3[c];
-        Bv[k] = a * (Bv[k] > 0.f ? 1.f : SLOPE);
+        for (int c = 0; c < D; ++c) a += sw[Lds::W3 + c * FH + 4 * q + oo] * d3[c];
+        d2[oo] = a * (h2[oo] > 0.f ? 1.f : SLOPE);
+        d1[oo] = 0.f;
       }
-      __syncthreads();   // buf1 (h2) no longer read
-      // ---- layer 2: dW2 = sum_r delta2 (x) h1
+#pragma unroll 2
+      for (int s = 0; s < GL; ++s) {
 #pragma unroll
-      for (int k = 0; k < FH; ++k) { buf0[tid * FH + k] = A[k]; buf1[tid * FH + k] = Bv[k]; }
-      __syncthreads();
-      reduce_w2(buf0, buf1, gW2, gB2);
-      // delta1 = (W2^T delta2) * lrelu'(a1), overwriting h1
-      unsigned long long pos = 0ull;
-#pragma unroll
-      for (int k = 0; k < FH; ++k) pos |= (A[k] > 0.f ? 1ull : 0ull) << k;
-#pragma unroll
-      for (int k = 0; k < FH; ++k) A[k] = 0.f;
-      {
-        float4 wrow[2][FH / 4];
-#pragma unroll
-        for (int i4 = 0; i4 < FH / 4; ++i4) wrow[0][i4] = reinterpret_cast<const float4*>(wl + Net<D>::W2)[i4];
-#pragma unroll
-        for (int o = 0; o < FH; ++o) {
-          if (o + 1 < FH) {
-#pragma unroll
-            for (int i4 = 0; i4 < FH / 4; ++i4)
-              wrow[(o + 1) & 1][i4] = reinterpret_cast<const float4*>(wl + Net<D>::W2 + (o + 1) * FH)[i4];
-          }
-          const float dv = Bv[o];
-#pragma unroll
-          for (int i4 = 0; i4 < FH / 4; ++i4) {
-            const float4 v = wrow[o & 1][i4];
-            A[i4 * 4] += v.x * dv; A[i4 * 4 + 1] += v.y * dv; A[i4 * 4 + 2] += v.z * dv; A[i4 * 4 + 3] += v.w * dv;
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int v = 0; v < 4; ++v) {
+          const float dv = grp(d2[v], s);   // delta2 of hidden unit o = 4 s + v
+          const float4 w = *reinterpret_cast<const float4*>(sw + Lds::W2 + (4 * s + v) * FH + 4 * q);
+          d1[0] += w.x * dv; d1[1] += w.y * dv; d1[2] += w.z * dv; d1[3] += w.w * dv;
         }
       }
 #pragma unroll
-      for (int k = 0; k < FH; ++k) A[k] *= ((pos >> k) & 1ull) ? 1.f : SLOPE;
-      __syncthreads();   // buf0 / buf1 no longer read by reduce_w2
-      // ---- layer 1: dW1 = sum_r delta1 (x) z_;  dz_ = W1^T delta1
-#pragma unroll
-      for (int k = 0; k < FH; ++k) buf0[tid * FH + k] = A[k];
-      __syncthreads();
-      if (tid < FH * D) {
-        const int k = tid / D, d = tid - k * D;
-        float acc = 0.f;
-        for (int rr = 0; rr < FR; ++rr) acc += buf0[rr * FH + k] * smz[rr * 4 + d];
-        atomicAdd(gW1 + k * D + d, acc);
-      } else if (tid < FH * D + FH) {
-        const int k = tid - FH * D;
-        float acc = 0.f;
-        for (int rr = 0; rr < FR; ++rr) acc += buf0[rr * FH + k];
-        atomicAdd(gB1 + k, acc);
-      }
+      for (int oo = 0; oo < 4; ++oo) d1[oo] *= h1[oo] > 0.f ? 1.f : SLOPE;
+      // gradient wrt the masked inputs: W1^T delta1, summed over the group
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if ((m >> d) & 1u) {
           float a = 0.f;
 #pragma unroll
-          for (int k = 0; k < FH; ++k) a += wl[Net<D>::W1 + k * D + d] * A[k];
-          dzin_m[d] += a;
+          for (int oo = 0; oo < 4; ++oo) a += sw[Lds::W1 + (4 * q + oo) * 4 + d] * d1[oo];
+          dzin_m[d] += grp_sum(a);
         }
       }
+      // ---- weight phases. Layer 3: dW3 = sum_r d3 (x) h2; layer 2: dW2 = sum_r delta2 (x) h1
+      *reinterpret_cast<float4*>(bufA + rg * FH + 4 * q) = make_float4(h2[0], h2[1], h2[2], h2[3]);
+      *reinterpret_cast<float4*>(bufD + rg * FH + 4 * q) = make_float4(d2[0], d2[1], d2[2], d2[3]);
+      if (q < 4) {
+        sm3[rg * 4 + q] = q < D ? d3[q < D ? q : 0] : 0.f;
+        smz[rg * 4 + q] = q < D ? zin[q < D ? q : 0] : 0.f;
+      }
+      __syncthreads();
+      if (tid < D * FH) {
+        const int c = tid / FH, k = tid - c * FH;
+        float acc = 0.f;
+        for (int rr = 0; rr < RPB; ++rr) acc += sm3[rr * 4 + c] * bufA[rr * FH + k];
+        atomicAdd(gW3 + c * FH + k, acc);
+      } else if (tid < D * FH + D) {
+        const int c = tid - D * FH;
+        float acc = 0.f;
+        for (int rr = 0; rr < RPB; ++rr) acc += sm3[rr * 4 + c];
+        atomicAdd(gB3 + c, acc);
+      }
+      __syncthreads();   // bufA (h2) no longer read
+      *reinterpret_cast<float4*>(bufA + rg * FH + 4 * q) = make_float4(h1[0], h1[1], h1[2], h1[3]);
+      __syncthreads();
+      {   // thread t: dW2[o][i0..i0+3], o = t >> 4, i0 = (t & 15) * 4
+        const int o = tid >> 4, i0 = (tid & 15) * 4;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, bs = 0.f;
+#pragma unroll 4
+        for (int rr = 0; rr < RPB; ++rr) {
+          const float dv = bufD[rr * FH + o];
+          const float4 h = *reinterpret_cast<const float4*>(bufA + rr * FH + i0);
+          a0 += dv * h.x; a1 += dv * h.y; a2 += dv * h.z; a3 += dv * h.w;
+          bs += dv;
+        }
+        atomicAdd(gW2 + o * FH + i0, a0); atomicAdd(gW2 + o * FH + i0 + 1, a1);
+        atomicAdd(gW2 + o * FH + i0 + 2, a2); atomicAdd(gW2 + o * FH + i0 + 3, a3);
+        if ((tid & 15) == 0) atomicAdd(gB2 + o, bs);
+      }
+      __syncthreads();   // bufA (h1) no longer read
+      // ---- layer 1: dW1 = sum_r delta1 (x) z_
+      *reinterpret_cast<float4*>(bufA + rg * FH + 4 * q) = make_float4(d1[0], d1[1], d1[2], d1[3]);
+      __syncthreads();
+      if (tid < FH * D) {
+        const int k = tid / D, d = tid - k * D;
+        float acc = 0.f;
+        for (int rr = 0; rr < RPB; ++rr) acc += bufA[rr * FH + k] * smz[rr * 4 + d];
+        atomicAdd(gW1 + k * D + d, acc);
+      } else if (tid < FH * D + FH) {
+        const int k = tid - FH * D;
+        float acc = 0.f;
+        for (int rr = 0; rr < RPB; ++rr) acc += bufA[rr * FH + k];
+        atomicAdd(gB1 + k, acc);
+      }
     }
-    (void)sraw;
     // invert the layer and pass the gradient to its input
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
       }
     }
   }
-  if (live) {
+  if (live && q == 0) {
 #pragma unroll
     for (int d = 0; d < D; ++d) dx[(size_t)r * D + d] = dz[d];
   }
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(FR) void realnvp_bwd_kernel(const float* __restrict
 
 template <int D>
 constexpr size_t bwd_smem() {
-  return (size_t)(2 * FR * FH + 2 * FR * 4) * sizeof(float);
+  return (size_t)(Lds::SIZE + 2 * RPB * FH + 2 * RPB * 4) * sizeof(float);
 }
 
 }  // namespace
@@ -360,12 +366,12 @@ extern "C" int das_realnvp_log_prob_multi(const float* x, int rows_total, int D,
   FlowJobs fj;
   fj.n = njobs;
   for (int q = 0; q < DAS_FLOW_MAX_JOBS; ++q) fj.j[q] = jobs[q < njobs ? q : 0];
-  const int blocks = (rows_total + FR - 1) / FR;
+  const int blocks = (rows_total + RPB - 1) / RPB;
   if (D == 3) {
-    hipLaunchKernelGGL(realnvp_fwd_kernel<3>, dim3(blocks), dim3(FR), 0, (hipStream_t)stream, x, fj, layers, mask_bits,
+    hipLaunchKernelGGL(realnvp_fwd_kernel<3>, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, fj, layers, mask_bits,
                        logp, z_out);
   } else {
-    hipLaunchKernelGGL(realnvp_fwd_kernel<2>, dim3(blocks), dim3(FR), 0, (hipStream_t)stream, x, fj, layers, mask_bits,
+    hipLaunchKernelGGL(realnvp_fwd_kernel<2>, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, fj, layers, mask_bits,
                        logp, z_out);
   }
   DAS_CHECK_LAUNCH();
@@ -382,7 +388,7 @@ extern "C" int das_realnvp_log_prob_multi_backward(const float* z_final, const f
   FlowJobs fj;
   fj.n = njobs;
   for (int q = 0; q < DAS_FLOW_MAX_JOBS; ++q) fj.j[q] = jobs[q < njobs ? q : 0];
-  const int blocks = (rows_total + FR - 1) / FR;
+  const int blocks = (rows_total + RPB - 1) / RPB;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)realnvp_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -395,10 +401,10 @@ extern "C" int das_realnvp_log_prob_multi_backward(const float* z_final, const f
   for (int q = 0; q < njobs; ++q)
     if (jobs[q].dparams && hipMemsetAsync(jobs[q].dparams, 0, psize, s) != hipSuccess) return DAS_ERR_LAUNCH;
   if (D == 3) {
-    hipLaunchKernelGGL(realnvp_bwd_kernel<3>, dim3(blocks), dim3(FR), bwd_smem<3>(), s, z_final, grad_logp, fj, layers,
+    hipLaunchKernelGGL(realnvp_bwd_kernel<3>, dim3(blocks), dim3(NT), bwd_smem<3>(), s, z_final, grad_logp, fj, layers,
                        mask_bits, dx);
   } else {
-    hipLaunchKernelGGL(realnvp_bwd_kernel<2>, dim3(blocks), dim3(FR), bwd_smem<2>(), s, z_final, grad_logp, fj, layers,
+    hipLaunchKernelGGL(realnvp_bwd_kernel<2>, dim3(blocks), dim3(NT), bwd_smem<2>(), s, z_final, grad_logp, fj, layers,
                        mask_bits, dx);
   }
   DAS_CHECK_LAUNCH();

@@ -7,7 +7,7 @@ from das_amd.train_ops import realnvp_log_prob
 
 for dim, cls in ((3, RealNVP), (2, RealNVP2D)):
     flow = cls().cuda()
-    for N in (256, 4096, 65536, 262144):
+    for N in ([int(a) for a in sys.argv[1:]] or (256, 4096, 65536, 262144)):
         x = torch.randn(N, dim, device='cuda', requires_grad=True)
         g = torch.randn(N, device='cuda')
         for _ in range(2):
