@@ -327,6 +327,11 @@ __global__ void offset_sample_bwd_kernel(const float* __restrict__ uvd, const fl
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const int j = (int)(i % J);
     const long long pix = i / J;
+    {   // The loss reaches this op at the positive locations only (a fraction of a percent of the pixels): where the
+        // upstream gradient of a (pixel, joint) is zero, every term below is zero and the outputs keep the caller's zeros
+      const float* g0 = gout + pix * gout_ps + j * 3;
+      if (g0[0] == 0.f && g0[1] == 0.f && g0[2] == 0.f) continue;
+    }
     const LvGeom gm = lv_geom(lv, pix);
     const int H = gm.H, W = gm.W, px = gm.w, py = gm.h;
     const float* uvd_b = uvd + gm.plane0 * (long long)uvd_ps;
