@@ -60,6 +60,93 @@ __global__ void deform_im2col_kernel(const T* __restrict__ x, const float* __res
   }
 }
 
+// Wave-level variant (C / EPV in {16, 32, 64} channel vectors per pixel): a wave covers 64 / VC pixels. The tap geometry
+// (sigmoid, floor, bilinear fractions, corner validity, corner row) is computed ONCE per (pixel, tap) — by lane
+// p * 9 + k — and fetched by the lanes that need it with ds_bpermute; computed per channel vector, as above, it made the
+// pass VALU bound (2500 vector instructions per wave against a 652 MB store stream, SQ_INSTS_VALU). Corner vectors of
+// three taps are in flight together.
+template <typename T, int VC>
+__global__ __launch_bounds__(256) void deform_im2col_wave_kernel(const T* __restrict__ x, const float* __restrict__ om,
+                                                                 T* __restrict__ col, DasLevels lv, int C, int xps,
+                                                                 int omps, long long rows) {
+#pragma clang fp contract(off)
+  constexpr int EPV = Elem<T>::EPV, PPW = 64 / VC, TG = 3;
+  const int lane = threadIdx.x & 63;
+  const long long m0 = (((long long)blockIdx.x * 256 + threadIdx.x) >> 6) * PPW;
+  if (m0 >= rows) return;
+  // ---- producer role: lane p * 9 + k
+  float vmask, vly, vlx;
+  int vok = 0, vrow = 0, vW = 1;
+  {
+    const int gp = lane < PPW * 9 ? lane / 9 : 0, gk = lane < PPW * 9 ? lane % 9 : 0;
+    const long long gm = m0 + gp < rows ? m0 + gp : rows - 1;
+    const LvGeom g = lv_geom(lv, gm);
+    const float* o = om + gm * omps;
+    const float dy = o[2 * gk], dx = o[2 * gk + 1];
+    vmask = 1.f / (1.f + expf(-o[18 + gk]));
+    const float py = (float)(g.h - 1 + gk / 3) + dy;
+    const float px = (float)(g.w - 1 + gk % 3) + dx;
+    const bool live = py > -1.f && px > -1.f && py < (float)g.H && px < (float)g.W;
+    const float fy = floorf(py), fx = floorf(px);
+    const int y0 = live ? (int)fy : 0, x0 = live ? (int)fx : 0;
+    vly = py - fy; vlx = px - fx;
+    vok = live ? 16 : 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
+      if (live && yy >= 0 && yy <= g.H - 1 && xx >= 0 && xx <= g.W - 1) vok |= 1 << c;
+    }
+    vrow = (int)(g.plane0 + (long long)y0 * g.W + x0);   // (row counts < 2^31: checked by the host)
+    vW = g.W;
+  }
+  // ---- consumer role: channel vector v of pixel mp
+  const int mp = lane / VC, v = lane - mp * VC;
+  const long long m = m0 + mp;
+  const bool valid = m < rows;
+  const long long msafe = valid ? m : rows - 1;
+  auto from = [&](int val, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, val); };
+  auto fromf = [&](float val, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, val))); };
+  const int W = from(vW, mp * 9);
+  const T* xb = x + v * EPV;
+#pragma unroll 1
+  for (int k0 = 0; k0 < 9; k0 += TG) {
+    uint4 fr[TG][4];
+    int ok[TG];
+    float ly[TG], lx[TG], mk[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      const int src = mp * 9 + k0 + t;
+      ok[t] = from(vok, src);
+      const int row = from(vrow, src);
+      ly[t] = fromf(vly, src); lx[t] = fromf(vlx, src); mk[t] = fromf(vmask, src);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {   // (a corner outside the plane re-reads this pixel's own row: weight 0)
+        const long long pix = (ok[t] >> c & 1) ? (long long)row + (c >> 1) * W + (c & 1) : msafe;
+        fr[t][c] = *reinterpret_cast<const uint4*>(xb + pix * xps);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      const float hy = 1.f - ly[t], hx = 1.f - lx[t];
+      const float wts[4] = {hy * hx, hy * lx[t], ly[t] * hx, ly[t] * lx[t]};
+      float out[EPV];
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) out[j] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (!(ok[t] >> c & 1)) continue;
+        float f[EPV];
+        Elem<T>::unpack(fr[t][c], f);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) out[j] += wts[c] * f[j];
+      }
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) out[j] = (ok[t] & 16) ? out[j] * mk[t] : 0.f;
+      if (valid) *reinterpret_cast<uint4*>(col + (m * 9 + k0 + t) * C + v * EPV) = Elem<T>::pack(out);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ grid_sample helper
 // torch grid_sample(bilinear, zeros, align_corners=False) on an NHWC f32 map, NCH channels
 // starting at `c`, evaluated at normalised location loc in [0,1] units (grid = 2*loc-1).
@@ -236,16 +323,29 @@ extern "C" int das_deform_im2col3x3(const void* x, const float* om, void* col, i
                                     int x_pix_stride, int om_pix_stride, void* stream) {
   if (!x || !om || !col || !lv_valid(lv) || C % 8 || x_pix_stride % 8 || om_pix_stride < 27) return DAS_ERR_ARG;
   const long long npix = lv_total_rows(*lv);
-  if (dtype == DAS_BF16) {
+  if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
+  const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
+  hipStream_t s = (hipStream_t)stream;
+  if ((vc == 16 || vc == 32 || vc == 64) && npix < 0x7fffffffLL) {   // wave-level kernel: 64 / vc pixels per wave
+    const long long waves = (npix + 64 / vc - 1) / (64 / vc);
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+#define DAS_IM2COL_CASE(TT, VCV)                                                                                   \
+    hipLaunchKernelGGL((deform_im2col_wave_kernel<TT, VCV>), dim3(blocks), dim3(256), 0, s, (const TT*)x, om, (TT*)col, \
+                       *lv, C, x_pix_stride, om_pix_stride, npix)
+    if (dtype == DAS_BF16) {
+      if (vc == 16) DAS_IM2COL_CASE(bf16_t, 16); else if (vc == 32) DAS_IM2COL_CASE(bf16_t, 32); else DAS_IM2COL_CASE(bf16_t, 64);
+    } else {
+      if (vc == 16) DAS_IM2COL_CASE(float, 16); else if (vc == 32) DAS_IM2COL_CASE(float, 32); else DAS_IM2COL_CASE(float, 64);
+    }
+#undef DAS_IM2COL_CASE
+  } else if (dtype == DAS_BF16) {
     const long long total = npix * (C / 8);
-    hipLaunchKernelGGL(deform_im2col_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(deform_im2col_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, s,
                        (const bf16_t*)x, om, (bf16_t*)col, *lv, C, x_pix_stride, om_pix_stride, total);
-  } else if (dtype == DAS_F32) {
-    const long long total = npix * (C / 4);
-    hipLaunchKernelGGL(deform_im2col_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
-                       (const float*)x, om, (float*)col, *lv, C, x_pix_stride, om_pix_stride, total);
   } else {
-    return DAS_ERR_ARG;
+    const long long total = npix * (C / 4);
+    hipLaunchKernelGGL(deform_im2col_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, s,
+                       (const float*)x, om, (float*)col, *lv, C, x_pix_stride, om_pix_stride, total);
   }
   DAS_CHECK_LAUNCH();
   return DAS_OK;
