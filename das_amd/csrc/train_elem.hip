@@ -17,25 +17,46 @@ inline int grid_for(long long n, int cap = 8192) {
 // ------------------------------------------------------------------ GroupNorm backward
 // pass 1: per channel a[c] = sum dZ, b[c] = sum dZ*xhat over the block's pixels of one (level,image)
 // segment; dgamma/dbeta get them directly, the group sums s1 = sum gamma*a, s2 = sum gamma*b per segment.
+// Both passes: blockIdx.y = segment (level, image), blockIdx.x = a run of pix_per_block pixels; a thread keeps one 16-byte
+// channel vector (its groups' constants in registers) and walks the run TPB / VC pixels apart, two pixels' three
+// operands in flight (as the forward passes, norm.hip: no per-element geometry, levels picked with static indices).
+constexpr int GN_NT = 1024;
+struct GnSeg {
+  int HW;
+  long long row0;
+};
+__device__ __forceinline__ GnSeg gn_segment(const DasLevels& lv, int seg) {
+  const int l = seg / lv.B, b = seg - l * lv.B;
+  GnSeg g{0, 0};
+  long long start = 0;
+#pragma unroll
+  for (int i = 0; i < DAS_MAX_LEVELS; ++i) {
+    const int hw = i < lv.num_levels ? lv.H[i] * lv.W[i] : 0;
+    if (i == l) { g.HW = hw; g.row0 = start + (long long)b * hw; }
+    start += (long long)lv.B * hw;
+  }
+  return g;
+}
+
 template <typename T>
-__global__ void gn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
-                                     DasLevels lv, int C, int ps, int G, int pix_per_block,
-                                     const float* __restrict__ fstats, const float* __restrict__ gamma, float eps,
-                                     int relu, float* __restrict__ gsums, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta) {
-  constexpr int EPV = Elem<T>::EPV;
+__global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                              const T* __restrict__ x, DasLevels lv, int C, int ps, int G,
+                                                              int pix_per_block, const float* __restrict__ fstats,
+                                                              const float* __restrict__ gamma, float eps, int relu,
+                                                              float* __restrict__ gsums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  constexpr int EPV = Elem<T>::EPV, NT = GN_NT;
   extern __shared__ float sred[];  // [2C]
-  const int seg = blockIdx.y, l = seg / lv.B, b = seg % lv.B;
-  const int HW = lv.H[l] * lv.W[l];
+  const int seg = blockIdx.y;
+  const GnSeg sg = gn_segment(lv, seg);
+  const int HW = sg.HW;
   const int p0 = blockIdx.x * pix_per_block;
   if (p0 >= HW) return;
-  long long row0 = (long long)b * HW;
-  for (int i = 0; i < l; ++i) row0 += (long long)lv.B * lv.H[i] * lv.W[i];
   const int VC = C / EPV, cpg = C / G;
   const float inv_n = 1.f / ((float)HW * (float)cpg);
-  for (int i = threadIdx.x; i < 2 * C; i += TPB) sred[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * C; i += NT) sred[i] = 0.f;
   __syncthreads();
-  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = TPB / VC;
+  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = NT / VC;
   if (pl < PL) {
     float a[EPV], bb[EPV], mu[EPV], rs[EPV];
 #pragma unroll
@@ -46,31 +67,69 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
       mu[j] = m; rs[j] = rsqrtf(var + eps); a[j] = 0.f; bb[j] = 0.f;
     }
     const int p1 = min(p0 + pix_per_block, HW);
-    for (int p = p0 + pl; p < p1; p += PL) {
+    const long long off = sg.row0 * ps + v * EPV;
+    auto acc = [&](const uint4& rg, const uint4& rx, const uint4& ry) {
       float g[EPV], xx[EPV];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + (row0 + p) * ps + v * EPV), g);
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + (row0 + p) * ps + v * EPV), xx);
+      Elem<T>::unpack(rg, g);
+      Elem<T>::unpack(rx, xx);
       if (relu) {
         float o[EPV];
-        Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + (row0 + p) * ps + v * EPV), o);
+        Elem<T>::unpack(ry, o);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < EPV; ++j) { a[j] += g[j]; bb[j] += g[j] * (xx[j] - mu[j]) * rs[j]; }
-    }
+    };
+    int p = p0 + pl;
+    for (; p + PL < p1; p += 2 * PL) {
+      uint4 rg[2], rx[2], ry[2];
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) {
-      atomicAdd(&sred[v * EPV + j], a[j]);
-      atomicAdd(&sred[C + v * EPV + j], bb[j]);
+      for (int u = 0; u < 2; ++u) {
+        const long long o = off + (long long)(p + u * PL) * ps;
+        rg[u] = *reinterpret_cast<const uint4*>(dy + o);
+        rx[u] = *reinterpret_cast<const uint4*>(x + o);
+        ry[u] = relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc(rg[u], rx[u], ry[u]);
+    }
+    for (; p < p1; p += PL) {
+      const long long o = off + (long long)p * ps;
+      acc(*reinterpret_cast<const uint4*>(dy + o), *reinterpret_cast<const uint4*>(x + o),
+          relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0));
+    }
+    if (64 % VC == 0) {
+      // the 64 / VC pixel lanes of a wave that share this channel vector: xor-shuffles, then ONE lane per vector adds
+      // the wave's sums (16 waves per address instead of 16 x 64 / VC threads)
+      for (int m = VC; m < 64; m <<= 1) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          a[j] += __shfl_xor(a[j], m);
+          bb[j] += __shfl_xor(bb[j], m);
+        }
+      }
+      if ((threadIdx.x & 63) < VC) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          atomicAdd(&sred[v * EPV + j], a[j]);
+          atomicAdd(&sred[C + v * EPV + j], bb[j]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) {
+        atomicAdd(&sred[v * EPV + j], a[j]);
+        atomicAdd(&sred[C + v * EPV + j], bb[j]);
+      }
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += TPB) {
+  for (int c = threadIdx.x; c < C; c += NT) {
     atomicAdd(dbeta + c, sred[c]);
     atomicAdd(dgamma + c, sred[C + c]);
   }
-  for (int g = threadIdx.x; g < G; g += TPB) {
+  for (int g = threadIdx.x; g < G; g += NT) {
     float s1 = 0.f, s2 = 0.f;
     for (int j = 0; j < cpg; ++j) { s1 += gamma[g * cpg + j] * sred[g * cpg + j]; s2 += gamma[g * cpg + j] * sred[C + g * cpg + j]; }
     atomicAdd(&gsums[((long long)seg * G + g) * 2], s1);
@@ -79,37 +138,67 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
 }
 
 template <typename T>
-__global__ void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
-                                    T* __restrict__ dx, DasLevels lv, int C, int ps, int G,
-                                    const float* __restrict__ fstats, const float* __restrict__ gsums,
-                                    const float* __restrict__ gamma, float eps, int relu, long long total) {
-  constexpr int EPV = Elem<T>::EPV;
+__global__ __launch_bounds__(GN_NT) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                             const T* __restrict__ x, T* __restrict__ dx, DasLevels lv,
+                                                             int C, int ps, int G, int pix_per_block,
+                                                             const float* __restrict__ fstats,
+                                                             const float* __restrict__ gsums,
+                                                             const float* __restrict__ gamma, float eps, int relu) {
+  constexpr int EPV = Elem<T>::EPV, NT = GN_NT;
+  const int seg = blockIdx.y;
+  const GnSeg sg = gn_segment(lv, seg);
+  const int p0 = blockIdx.x * pix_per_block;
+  if (p0 >= sg.HW) return;
   const int VC = C / EPV, cpg = C / G;
-  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    const int v = (int)(i % VC);
-    const long long pix = i / VC;
-    const LvGeom gm = lv_geom(lv, pix);
-    const long long seg = (long long)gm.l * lv.B + gm.b;
-    const float inv_n = 1.f / ((float)(gm.H * gm.W) * (float)cpg);
+  const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = NT / VC;
+  if (pl >= PL) return;
+  const float inv_n = 1.f / ((float)sg.HW * (float)cpg);
+  float mu[EPV], rs[EPV], ga[EPV], k1[EPV], k2[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int c = v * EPV + j, gi = c / cpg;
+    const float m = fstats[((long long)seg * G + gi) * 2] * inv_n;
+    const float var = fmaxf(fstats[((long long)seg * G + gi) * 2 + 1] * inv_n - m * m, 0.f);
+    mu[j] = m; rs[j] = rsqrtf(var + eps); ga[j] = gamma[c];
+    k1[j] = gsums[((long long)seg * G + gi) * 2] * inv_n;
+    k2[j] = gsums[((long long)seg * G + gi) * 2 + 1] * inv_n;
+  }
+  const int p1 = min(p0 + pix_per_block, sg.HW);
+  const long long off = sg.row0 * ps + v * EPV;
+  auto one = [&](const uint4& rg, const uint4& rx, const uint4& ry) {
     float g[EPV], xx[EPV], o[EPV];
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + pix * ps + v * EPV), g);
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + pix * ps + v * EPV), xx);
+    Elem<T>::unpack(rg, g);
+    Elem<T>::unpack(rx, xx);
     if (relu) {
       float yy[EPV];
-      Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + pix * ps + v * EPV), yy);
+      Elem<T>::unpack(ry, yy);
 #pragma unroll
       for (int j = 0; j < EPV; ++j) g[j] = yy[j] > 0.f ? g[j] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-      const int c = v * EPV + j, gi = c / cpg;
-      const float m = fstats[(seg * G + gi) * 2] * inv_n;
-      const float var = fmaxf(fstats[(seg * G + gi) * 2 + 1] * inv_n - m * m, 0.f);
-      const float rs = rsqrtf(var + eps);
-      const float xhat = (xx[j] - m) * rs;
-      o[j] = rs * (g[j] * gamma[c] - gsums[(seg * G + gi) * 2] * inv_n - xhat * gsums[(seg * G + gi) * 2 + 1] * inv_n);
+      const float xhat = (xx[j] - mu[j]) * rs[j];
+      o[j] = rs[j] * (g[j] * ga[j] - k1[j] - xhat * k2[j]);
     }
-    *reinterpret_cast<uint4*>(dx + pix * ps + v * EPV) = Elem<T>::pack(o);
+    return Elem<T>::pack(o);
+  };
+  int p = p0 + pl;
+  for (; p + PL < p1; p += 2 * PL) {
+    uint4 rg[2], rx[2], ry[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long o = off + (long long)(p + u * PL) * ps;
+      rg[u] = *reinterpret_cast<const uint4*>(dy + o);
+      rx[u] = *reinterpret_cast<const uint4*>(x + o);
+      ry[u] = relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<uint4*>(dx + off + (long long)(p + u * PL) * ps) = one(rg[u], rx[u], ry[u]);
+  }
+  for (; p < p1; p += PL) {
+    const long long o = off + (long long)p * ps;
+    *reinterpret_cast<uint4*>(dx + o) = one(*reinterpret_cast<const uint4*>(dy + o), *reinterpret_cast<const uint4*>(x + o),
+                                            relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0));
   }
 }
 
@@ -271,7 +360,7 @@ extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void*
   if (!dy || !x || !dx || !fwd_stats || !gamma || !gsums_ws || !dgamma || !dbeta || !lv_valid(lv)) return DAS_ERR_ARG;
   if (C % 8 || C % G || pix_stride % 8 || C > 2048 || (relu && !y)) return DAS_ERR_ARG;
   const int epv = dtype == DAS_BF16 ? 8 : 4;
-  if ((C / epv) > TPB) return DAS_ERR_ARG;
+  if ((C / epv) > GN_NT) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nseg = lv->num_levels * lv->B;
   if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
@@ -282,13 +371,12 @@ extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void*
   int chunks = (256 * 4 + lv->B - 1) / lv->B;
   int ppb = std::max((int)dastune::get(dastune::GN_PPB), (maxhw + chunks - 1) / chunks);   // (see norm.hip)
   chunks = (maxhw + ppb - 1) / ppb;
-  const long long total = lv_total_rows(*lv) * (C / epv);
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3(chunks, nseg), dim3(TPB), 2 * C * sizeof(float), s, (const T*)dy,
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3(chunks, nseg), dim3(GN_NT), 2 * C * sizeof(float), s, (const T*)dy,
                        (const T*)y, (const T*)x, *lv, C, pix_stride, G, ppb, fwd_stats, gamma, eps, relu, gsums_ws,
                        dgamma, dbeta);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
-                       (const T*)x, (T*)dx, *lv, C, pix_stride, G, fwd_stats, gsums_ws, gamma, eps, relu, total);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks, nseg), dim3(GN_NT), 0, s, (const T*)dy, (const T*)y,
+                       (const T*)x, (T*)dx, *lv, C, pix_stride, G, ppb, fwd_stats, gsums_ws, gamma, eps, relu);
   });
   DAS_CHECK_LAUNCH();
   return DAS_OK;
