@@ -52,6 +52,12 @@ class DasTargetDesc(C.Structure):
                 ('radius', f32), ('alpha', f32)]
 
 
+class DasPhotometric(C.Structure):
+    _fields_ = [('use_brightness', i32), ('use_contrast', i32), ('contrast_first', i32), ('use_saturation', i32),
+                ('use_hue', i32), ('brightness', f32), ('contrast', f32), ('saturation', f32), ('hue', f32),
+                ('perm', i32 * 3)]
+
+
 class DasDecodeDesc(C.Structure):
     _fields_ = [('B', i32), ('J', i32), ('num_levels', i32),
                 ('H', i32 * DAS_MAX_LEVELS), ('W', i32 * DAS_MAX_LEVELS), ('stride', i32 * DAS_MAX_LEVELS),
@@ -68,6 +74,11 @@ SIGNATURES = {
     'das_tuning_get': (i32, [C.c_char_p, C.POINTER(i64)]),
     'das_tuning_reset': (i32, []),
     'das_last_kernel': (C.c_char_p, []),
+    'das_img_resize_bilinear': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'das_img_flip_horizontal': (i32, [vp, vp, i32, i32, i32, vp]),
+    'das_img_photometric': (i32, [vp, i32, i32, C.POINTER(DasPhotometric), vp]),
+    'das_img_warp_affine': (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(f32), vp]),
+    'das_img_normalize_pad_chw': (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), i32, vp]),
     'das_conv2d_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), vp]),
     'das_conv2d_wgrad_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), i32, vp]),
     'das_conv2d_wgrad_batch': (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(DasConvDesc), i32, vp]),

@@ -42,10 +42,20 @@ class SyntheticPoseDataset:
 
 
 def collate(samples, device=None):
-    """Batch a list of samples the way mmcv's collate + scatter would hand them to `model(**data)`."""
+    """Batch a list of samples the way mmcv's collate + scatter would hand them to `model(**data)`: images of
+    different (padded) sizes are zero-padded bottom / right to the largest one (mmcv.parallel.collate on stacked
+    DataContainers), annotations stay per-image lists."""
     def dev(t):
         return t.to(device, non_blocking=True) if device is not None else t
-    out = dict(img=dev(torch.stack([s['img'] for s in samples])), img_metas=[s['img_metas'] for s in samples])
+    imgs = [s['img'] for s in samples]
+    if len({tuple(i.shape) for i in imgs}) == 1:
+        img = torch.stack(imgs)
+    else:
+        hm, wm = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
+        img = imgs[0].new_zeros((len(imgs), imgs[0].shape[0], hm, wm))
+        for b, i in enumerate(imgs):
+            img[b, :, :i.shape[-2], :i.shape[-1]] = i
+    out = dict(img=dev(img), img_metas=[s['img_metas'] for s in samples])
     for k in ('gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths'):
         out[k] = [dev(s[k]) for s in samples]
     return out

@@ -1,0 +1,72 @@
+"""Python side of the image kernels of the pose data pipeline (das_amd/csrc/augment.hip, C ABI in include/das_hip.h):
+f32 HWC (BGR) CUDA tensors in, CUDA tensors out. No CPU fallback: a CPU tensor raises."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .ops import _need_gpu, _ptr, _stream
+
+
+def _hwc(img):
+    _need_gpu(img)
+    assert img.dim() == 3 and img.dtype == torch.float32 and img.is_contiguous(), (img.shape, img.dtype)
+    return img.shape
+
+
+def resize_bilinear(img, size):
+    """cv2.resize(img, (Wd, Hd), INTER_LINEAR) on a float image (mmcv.imresize / imrescale, ResizePose)."""
+    H, W, Cc = _hwc(img)
+    Wd, Hd = int(size[0]), int(size[1])
+    out = torch.empty(Hd, Wd, Cc, dtype=torch.float32, device=img.device)
+    _lib.check(_lib.load().das_img_resize_bilinear(_ptr(img), _ptr(out), H, W, Hd, Wd, Cc, _stream()), 'das_img_resize_bilinear')
+    return out
+
+
+def flip_horizontal(img):
+    H, W, Cc = _hwc(img)
+    out = torch.empty_like(img)
+    _lib.check(_lib.load().das_img_flip_horizontal(_ptr(img), _ptr(out), H, W, Cc, _stream()), 'das_img_flip_horizontal')
+    return out
+
+
+def photometric_(img, brightness=None, contrast=None, contrast_first=True, saturation=None, hue=None, perm=None):
+    """mmdet PhotoMetricDistortion with the drawn parameters (None = step not applied), in place."""
+    H, W, Cc = _hwc(img)
+    assert Cc == 3
+    p = _lib.DasPhotometric(use_brightness=int(brightness is not None), use_contrast=int(contrast is not None),
+                            contrast_first=int(bool(contrast_first)), use_saturation=int(saturation is not None),
+                            use_hue=int(hue is not None), brightness=float(brightness or 0.0),
+                            contrast=float(contrast if contrast is not None else 1.0),
+                            saturation=float(saturation if saturation is not None else 1.0), hue=float(hue or 0.0))
+    for c, v in enumerate(perm if perm is not None else (0, 1, 2)):
+        p.perm[c] = int(v)
+    _lib.check(_lib.load().das_img_photometric(_ptr(img), H, W, C.byref(p), _stream()), 'das_img_photometric')
+    return img
+
+
+def warp_affine(img, M, size, border):
+    """cv2.warpAffine(img, M (forward 2x3, f64), (Wd, Hd), INTER_LINEAR, BORDER_CONSTANT, borderValue=border)."""
+    H, W, Cc = _hwc(img)
+    assert Cc == 3
+    Wd, Hd = int(size[0]), int(size[1])
+    out = torch.empty(Hd, Wd, 3, dtype=torch.float32, device=img.device)
+    m = (C.c_double * 6)(*[float(v) for v in list(M[0]) + list(M[1])])
+    b = (C.c_float * 3)(*[float(v) for v in border])
+    _lib.check(_lib.load().das_img_warp_affine(_ptr(img), _ptr(out), H, W, Hd, Wd, m, b, _stream()), 'das_img_warp_affine')
+    return out
+
+
+def normalize_pad_chw(img, mean, std, to_rgb, pad_hw=None, out=None):
+    """mmcv.imnormalize + zero pad to pad_hw + HWC -> CHW in one pass; `out` may be a (3, Hp, Wp) slice of a batch."""
+    H, W, Cc = _hwc(img)
+    assert Cc == 3
+    Hp, Wp = pad_hw if pad_hw is not None else (H, W)
+    if out is None:
+        out = torch.empty(3, Hp, Wp, dtype=torch.float32, device=img.device)
+    assert out.shape == (3, Hp, Wp) and out.is_contiguous() and out.dtype == torch.float32
+    m = (C.c_double * 3)(*[float(v) for v in mean])
+    s = (C.c_double * 3)(*[float(v) for v in std])
+    _lib.check(_lib.load().das_img_normalize_pad_chw(_ptr(img), _ptr(out), H, W, Hp, Wp, m, s, int(bool(to_rgb)), _stream()),
+               'das_img_normalize_pad_chw')
+    return out

@@ -1,5 +1,27 @@
-"""Data pipeline pieces: `Compose` and the registry the dataset configs resolve their
-`pipeline=[dict(type=...)]` entries through (mmdet.datasets.pipelines.Compose / PIPELINES in the reference)."""
+"""Pose data pipeline as a GPU-side augmentation stage.
+
+The reference's train pipeline (configs/das/exp_panoptic.py:59-98) is a CPU chain of numpy / OpenCV transforms:
+LoadImageFromFile, LoadAnnotationsPose3D (loading.py:671-736), ResizePose (transforms_3d.py:19-61), RandomFlipPose3D
+(:235-356), PhotoMetricDistortion (mmdet), GlobalRotScaleTransPose (:901-1129), Normalize, Pad (mmdet),
+DefaultFormatBundlePose3D (formating.py:383-442), Collect3D (:83-...). The classes here keep those registry names,
+constructor keywords, `results` keys and random-number call order, with the work split in two:
+
+  * annotations (a few persons x (3 + 4 J) floats): numpy on the host — the reference's own arithmetic, restated
+    line by line and pinned bit-exactly against the imported reference (tests/golden/pipeline_*.npz);
+  * the image: a float32 HWC (BGR) CUDA tensor from the decoded frame on, transformed by the HIP kernels of
+    das_amd/csrc/augment.hip (das_amd.image_ops), which restate the OpenCV / mmcv ops the reference calls.
+    `Normalize` and `Pad` only record their parameters; `DefaultFormatBundlePose3D` runs them with the HWC -> CHW
+    transpose as ONE pass (das_img_normalize_pad_chw), optionally straight into a slot of the batch tensor.
+
+Random draws use numpy's global generator in the reference's order, so a seeded run draws the same augmentation
+parameters as the reference pipeline would.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
 from .datasets import PIPELINES
 from .registry import build_from_cfg
 
@@ -15,4 +37,480 @@ class Compose:
             data = t(data)
             if data is None:
                 return None
+        return data
+
+
+def _img_ops():
+    from . import image_ops
+    return image_ops
+
+
+def _is_dev(img):
+    return isinstance(img, torch.Tensor) and img.is_cuda
+
+
+# ---------------------------------------------------------------------------------------------- loading
+@PIPELINES.register_module()
+class LoadImageFromFile:
+    """mmdet LoadImageFromFile(to_float32=True): BGR HWC. The decoded frame goes to the device at once (`device`,
+    default 'cuda'); `.npy` files hold an HWC BGR array, anything else is decoded with PIL (OpenCV is not in this image)."""
+
+    def __init__(self, to_float32=False, color_type='color', file_client_args=None, device='cuda'):
+        self.to_float32, self.device = to_float32, device
+
+    def __call__(self, results):
+        if results.get('img_prefix') is not None:
+            filename = os.path.join(results['img_prefix'], results['img_info']['filename'])
+        else:
+            filename = results['img_info']['filename']
+        if filename.endswith('.npy'):
+            img = np.load(filename)
+        else:
+            from PIL import Image
+            img = np.asarray(Image.open(filename).convert('RGB'))[..., ::-1]
+        img = np.ascontiguousarray(img)
+        t = torch.from_numpy(img).to(self.device)
+        if self.to_float32:
+            t = t.float()
+        results['filename'] = filename
+        results['ori_filename'] = results['img_info']['filename']
+        results['img'] = t.contiguous()
+        results['img_shape'] = tuple(img.shape)
+        results['ori_shape'] = tuple(img.shape)
+        results['img_fields'] = ['img']
+        return results
+
+
+@PIPELINES.register_module()
+class LoadAnnotationsPose3D:
+    """loading.py:671-736 (+ mmdet LoadAnnotations for bboxes / labels)."""
+
+    def __init__(self, with_pose_3d=True, with_label_3d=True, with_bbox=False, with_label=False, poly2mask=True,
+                 file_client_args=None):
+        self.with_pose_3d, self.with_label_3d, self.with_bbox, self.with_label = with_pose_3d, with_label_3d, with_bbox, with_label
+
+    def __call__(self, results):
+        ann = results['ann_info']
+        if self.with_bbox:
+            results['gt_bboxes'] = ann['bboxes'].copy()
+            if ann.get('bboxes_ignore') is not None:
+                results['gt_bboxes_ignore'] = ann['bboxes_ignore'].copy()
+                results.setdefault('bbox_fields', []).append('gt_bboxes_ignore')
+            results.setdefault('bbox_fields', []).append('gt_bboxes')
+        if self.with_label:
+            results['gt_labels'] = ann['labels'].copy()
+        if self.with_pose_3d:
+            results['centers2d'] = ann['centers2d']
+            results['depths'] = ann['depths']
+            results['gt_poses_3d'] = ann['gt_poses_3d']
+        if self.with_label_3d:
+            results['gt_labels_3d'] = ann['gt_labels_3d']
+        if 'cam' in ann:
+            results['cam'] = ann['cam']
+        return results
+
+
+# ---------------------------------------------------------------------------------------------- resize
+def resize_pose(results, scale_depth, abs_dz):
+    """ResizePose._resize_pose (transforms_3d.py:32-56), in place on `results`."""
+    scale_factor = results['scale_factor'][:2]     # w, h
+    num_joints = (results['gt_poses_3d'].shape[-1] - 3) // 4
+    centers2d = results['centers2d']
+    depths = results['depths']
+    assert (centers2d == results['gt_poses_3d'][:, :2]).all()
+    assert (depths == results['gt_poses_3d'][:, 2]).all()
+    joints = results['gt_poses_3d'][:, 3:3 + num_joints * 3].reshape(-1, num_joints, 3)
+    joints_vis = results['gt_poses_3d'][:, 3 + num_joints * 3:].reshape(-1, num_joints)
+    centers2d = centers2d * scale_factor
+    joints[..., :2] = joints[..., :2] * scale_factor
+    if scale_depth:
+        depth_scale = np.sqrt(scale_factor.prod())
+        depths = depths / depth_scale
+        if not abs_dz:
+            joints[..., 2] = joints[..., 2] / depth_scale
+    results['centers2d'] = centers2d
+    results['depths'] = depths
+    results['gt_poses_3d'] = np.concatenate(
+        [centers2d, depths.reshape(-1, 1), joints.reshape(-1, num_joints * 3), joints_vis], axis=-1)
+
+
+@PIPELINES.register_module()
+class ResizePose:
+    """transforms_3d.py:19-61 over mmdet's Resize (multiscale_mode 'range' / 'value', keep_ratio)."""
+
+    def __init__(self, scale_depth=False, abs_dz=False, img_scale=None, multiscale_mode='range', ratio_range=None,
+                 keep_ratio=True, bbox_clip_border=True, backend='cv2', override=False):
+        self.scale_depth, self.abs_dz = scale_depth, abs_dz
+        if abs_dz:
+            assert scale_depth
+        self.img_scale = None if img_scale is None else (img_scale if isinstance(img_scale, list) else [img_scale])
+        assert multiscale_mode in ('value', 'range') and ratio_range is None, 'as the DAS configs use it'
+        self.multiscale_mode, self.keep_ratio, self.bbox_clip_border = multiscale_mode, keep_ratio, bbox_clip_border
+
+    def _random_scale(self, results):
+        if len(self.img_scale) == 1:
+            scale = tuple(self.img_scale[0])
+        elif self.multiscale_mode == 'range':      # mmdet Resize.random_sample
+            longs, shorts = [max(s) for s in self.img_scale], [min(s) for s in self.img_scale]
+            long_edge = np.random.randint(min(longs), max(longs) + 1)
+            short_edge = np.random.randint(min(shorts), max(shorts) + 1)
+            scale = (long_edge, short_edge)
+        else:                                      # random_select
+            scale = tuple(self.img_scale[np.random.randint(len(self.img_scale))])
+        results['scale'] = scale
+
+    def __call__(self, results):
+        if 'scale' not in results:
+            self._random_scale(results)
+        img = results['img']
+        h, w = results['img_shape'][:2]
+        if self.keep_ratio:                        # mmcv.imrescale
+            s = results['scale']
+            f = min(max(s) / max(h, w), min(s) / min(h, w))
+            new_w, new_h = int(w * float(f) + 0.5), int(h * float(f) + 0.5)
+        else:
+            new_w, new_h = results['scale']
+        results['img'] = _img_ops().resize_bilinear(img, (new_w, new_h))
+        w_scale, h_scale = new_w / w, new_h / h
+        results['scale_factor'] = np.array([w_scale, h_scale, w_scale, h_scale], dtype=np.float32)
+        results['img_shape'] = (new_h, new_w, 3)
+        results['pad_shape'] = (new_h, new_w, 3)
+        results['keep_ratio'] = self.keep_ratio
+        for key in results.get('bbox_fields', []):  # mmdet Resize._resize_bboxes
+            b = results[key] * results['scale_factor']
+            if self.bbox_clip_border:
+                b[:, 0::2] = np.clip(b[:, 0::2], 0, new_w)
+                b[:, 1::2] = np.clip(b[:, 1::2], 0, new_h)
+            results[key] = b
+        resize_pose(results, self.scale_depth, self.abs_dz)
+        return results
+
+
+# ---------------------------------------------------------------------------------------------- flip
+def flip_pose(results, num_joints, flip_pairs):
+    """RandomFlipPose3D.random_flip_data_3d, 'gt_poses_3d' branch (transforms_3d.py:293-318), in place."""
+    w = results['img_shape'][1]
+    centers2d = results['centers2d']
+    depths = results['depths']
+    joints = results['gt_poses_3d'][:, 3:3 + num_joints * 3].reshape(-1, num_joints, 3)
+    joints_vis = results['gt_poses_3d'][:, 3 + num_joints * 3:].reshape(-1, num_joints)
+    centers2d[..., 0] = w - centers2d[..., 0] - 1
+    joints[:, :, 0] = w - joints[:, :, 0] - 1
+    for pair in flip_pairs:
+        joints[:, pair[0]], joints[:, pair[1]] = joints[:, pair[1]], joints[:, pair[0]].copy()
+        joints_vis[:, pair[0]], joints_vis[:, pair[1]] = joints_vis[:, pair[1]], joints_vis[:, pair[0]].copy()
+    results['centers2d'] = centers2d
+    results['gt_poses_3d'] = np.concatenate(
+        [centers2d, depths.reshape(-1, 1), joints.reshape(-1, num_joints * 3), joints_vis], axis=-1)
+
+
+@PIPELINES.register_module()
+class RandomFlipPose3D:
+    """transforms_3d.py:235-356 over mmdet's RandomFlip (horizontal)."""
+
+    def __init__(self, sync_2d=True, flip_ratio_bev_horizontal=0.0, flip_ratio_bev_vertical=0.0, num_joints=15,
+                 flip_pairs=None, direction='horizontal'):
+        assert sync_2d and flip_ratio_bev_vertical == 0 and direction == 'horizontal'
+        self.flip_ratio, self.num_joints, self.flip_pairs = flip_ratio_bev_horizontal, num_joints, flip_pairs or []
+
+    def __call__(self, results):
+        if 'flip' not in results:                  # mmdet RandomFlip.__call__
+            cur_dir = np.random.choice(['horizontal', None], p=[self.flip_ratio, 1 - self.flip_ratio])
+            results['flip'] = cur_dir is not None
+        results.setdefault('flip_direction', 'horizontal' if results['flip'] else None)
+        if results['flip']:
+            results['img'] = _img_ops().flip_horizontal(results['img'])
+            w = results['img_shape'][1]
+            for key in results.get('bbox_fields', []):   # mmdet bbox_flip
+                b = results[key]
+                flipped = b.copy()
+                flipped[..., 0::4] = w - b[..., 2::4]
+                flipped[..., 2::4] = w - b[..., 0::4]
+                results[key] = flipped
+        results['pcd_horizontal_flip'] = results['flip']
+        results['pcd_vertical_flip'] = False
+        results.setdefault('transformation_3d_flow', [])
+        if results['pcd_horizontal_flip']:
+            if 'gt_poses_3d' in results:
+                flip_pose(results, self.num_joints, self.flip_pairs)
+            results['transformation_3d_flow'].extend(['HF'])
+        return results
+
+
+# ---------------------------------------------------------------------------------------------- colour
+@PIPELINES.register_module()
+class PhotoMetricDistortion:
+    """mmdet PhotoMetricDistortion: the draws (numpy.random, this order) on the host, the pixels in one kernel pass."""
+
+    def __init__(self, brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18):
+        self.brightness_delta = brightness_delta
+        self.contrast_lower, self.contrast_upper = contrast_range
+        self.saturation_lower, self.saturation_upper = saturation_range
+        self.hue_delta = hue_delta
+
+    def draw(self):
+        r = np.random
+        p = dict(brightness=None, contrast=None, saturation=None, hue=None, perm=None)
+        if r.randint(2):
+            p['brightness'] = r.uniform(-self.brightness_delta, self.brightness_delta)
+        mode = r.randint(2)
+        p['contrast_first'] = mode == 1
+        if mode == 1 and r.randint(2):
+            p['contrast'] = r.uniform(self.contrast_lower, self.contrast_upper)
+        if r.randint(2):
+            p['saturation'] = r.uniform(self.saturation_lower, self.saturation_upper)
+        if r.randint(2):
+            p['hue'] = r.uniform(-self.hue_delta, self.hue_delta)
+        if mode == 0 and r.randint(2):
+            p['contrast'] = r.uniform(self.contrast_lower, self.contrast_upper)
+        if r.randint(2):
+            p['perm'] = r.permutation(3)
+        return p
+
+    def __call__(self, results):
+        p = results['photometric'] = self.draw()
+        _img_ops().photometric_(results['img'], **p)
+        return results
+
+
+# ---------------------------------------------------------------------------------------------- rot / scale / trans
+def get_3rd_point(a, b):
+    direct = a - b
+    return b + np.array([-direct[1], direct[0]], dtype=np.float32)
+
+
+def get_dir(src_point, rot_rad):
+    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
+    return [src_point[0] * cs - src_point[1] * sn, src_point[0] * sn + src_point[1] * cs]
+
+
+def affine_from_points(src, dst):
+    """cv2.getAffineTransform: the 2x3 map taking three points to three points (f64 solve)."""
+    A = np.zeros((6, 6))
+    b = np.zeros(6)
+    for i in range(3):
+        A[i, :3] = [src[i][0], src[i][1], 1]
+        A[i + 3, 3:] = [src[i][0], src[i][1], 1]
+        b[i], b[i + 3] = dst[i][0], dst[i][1]
+    return np.linalg.solve(A, b).reshape(2, 3)
+
+
+def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0], dtype=np.float32), inv=0):
+    """transforms_3d.py:864-898."""
+    if not isinstance(scale, np.ndarray) and not isinstance(scale, list):
+        scale = np.array([scale, scale])
+    scale_tmp = scale
+    src_w = scale_tmp[0]
+    dst_w, dst_h = output_size[0], output_size[1]
+    rot_rad = np.pi * rot / 180
+    src_dir = get_dir([0, src_w * -0.5], rot_rad)
+    dst_dir = np.array([0, dst_w * -0.5], np.float32)
+    src = np.zeros((3, 2), dtype=np.float32)
+    dst = np.zeros((3, 2), dtype=np.float32)
+    src[0, :] = center + scale_tmp * shift
+    src[1, :] = center + src_dir + scale_tmp * shift
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir
+    src[2:, :] = get_3rd_point(src[0, :], src[1, :])
+    dst[2:, :] = get_3rd_point(dst[0, :], dst[1, :])
+    if inv:
+        return affine_from_points(np.float32(dst), np.float32(src))
+    return affine_from_points(np.float32(src), np.float32(dst))
+
+
+def warp_annotations(results, trans, scale, num_joints, scale_depth, abs_dz, use_bbox_center):
+    """The annotation half of GlobalRotScaleTransPose._transform (transforms_3d.py:988-1058): returns the updated
+    results, or None when fewer than two persons keep their root inside the image."""
+    h, w, _ = results['img_shape']
+    joints = results['gt_poses_3d'][:, :3 + num_joints * 3]
+    batch = len(joints)
+    joints_vis = results['gt_poses_3d'][:, 3 + num_joints * 3:].reshape(batch, num_joints)
+    joints = joints.reshape(batch, num_joints + 1, 3)
+    joints_depth = joints[..., [2]]
+    if scale_depth:
+        if not abs_dz:
+            joints_depth = joints_depth * scale
+        else:
+            joints_depth[0] = joints_depth[0] * scale
+    new_joints = joints.copy()
+    new_joints[..., 2] = 1
+    new_joints = new_joints.reshape(-1, 3)
+    new_joints = np.dot(new_joints, trans.T)
+    new_joints = new_joints.reshape(batch, -1, 2)
+    new_joints = np.concatenate([new_joints, joints_depth], axis=-1)
+    gt_poses_3d = np.concatenate([new_joints.reshape(batch, -1), joints_vis], axis=-1).astype(np.float32)
+    assert ((0 <= joints_vis) & (joints_vis <= 1)).all()
+
+    gt_bboxes = results['gt_bboxes']
+    new_gt_bboxes = gt_bboxes.reshape(batch, 2, 2)
+    new_gt_bboxes_rev = new_gt_bboxes.copy()
+    new_gt_bboxes_rev[..., 1] = new_gt_bboxes[..., 1][:, ::-1]
+    new_gt_bboxes = np.concatenate([new_gt_bboxes, new_gt_bboxes_rev], axis=1)
+    new_gt_bboxes = np.concatenate([new_gt_bboxes, np.ones([batch, 4, 1])], axis=-1).reshape(-1, 3)
+    new_gt_bboxes = np.dot(new_gt_bboxes, trans.T)[:, :2].reshape(batch, 4, 2)
+    xmin_ymin = new_gt_bboxes.min(axis=1)
+    xmax_ymax = new_gt_bboxes.max(axis=1)
+    new_gt_bboxes = np.concatenate([xmin_ymin, xmax_ymax], axis=-1)
+    new_gt_bboxes[:, 0::2] = new_gt_bboxes[:, 0::2].clip(0, w - 1)
+    new_gt_bboxes[:, 1::2] = new_gt_bboxes[:, 1::2].clip(0, h - 1)
+    results['gt_bboxes'] = new_gt_bboxes
+    results['centers2d'] = gt_poses_3d[:, :2]
+    results['depths'] = gt_poses_3d[:, 3]
+    results['gt_poses_3d'] = gt_poses_3d
+
+    out_of_bound = (new_joints[..., 0] < 0) | (new_joints[..., 0] > w - 1) | \
+                   (new_joints[..., 1] < 0) | (new_joints[..., 1] > h - 1)
+    joints_vis[out_of_bound[:, 1:]] = 0
+    if not use_bbox_center:
+        valid = ~out_of_bound[:, 0]
+        gt_poses_3d = np.concatenate([new_joints.reshape(batch, -1), joints_vis], axis=-1).astype(np.float32)
+        if valid.sum() < 2:
+            return None
+    else:
+        new_centers = np.stack([new_gt_bboxes[:, 0::2].mean(-1), new_gt_bboxes[:, 1::2].mean(-1),
+                                new_joints[:, 0, -1]], axis=-1)
+        gt_poses_3d = np.concatenate([new_centers, new_joints[:, 1:].reshape(batch, -1), joints_vis],
+                                     axis=-1).astype(np.float32)
+        valid = (joints_vis.sum(-1) >= 3) & ((gt_bboxes[:, 2:] - gt_bboxes[:, :2]).prod() > 64)
+    results['gt_poses_3d'] = gt_poses_3d[valid].copy()
+    results['gt_bboxes'] = new_gt_bboxes[valid]
+    results['centers2d'] = gt_poses_3d[:, :2][valid].copy()
+    results['depths'] = gt_poses_3d[:, 2][valid].copy()
+    results['gt_labels'] = results['gt_labels'][valid]
+    results['gt_labels_3d'] = results['gt_labels_3d'][valid]
+    results['transform_mat'] = trans
+    return results
+
+
+@PIPELINES.register_module()
+class GlobalRotScaleTransPose:
+    """transforms_3d.py:901-1129: one random (rotation, scale, translation) affine map for image and annotations."""
+
+    def __init__(self, rot_range=[-0.78539816, 0.78539816], scale_ratio_range=[0.95, 1.05], translation_std=[0, 0, 0],
+                 shift_height=False, num_joints=None, scale_depth=False, abs_dz=False, img_norm_cfg=None,
+                 use_bbox_center=False):
+        if not isinstance(rot_range, (list, tuple, np.ndarray)):
+            rot_range = [-rot_range, rot_range]
+        if not isinstance(translation_std, (list, tuple, np.ndarray)):
+            translation_std = [translation_std] * 3
+        assert all(std >= 0 for std in translation_std)
+        self.rot_range, self.scale_ratio_range, self.translation_std = rot_range, scale_ratio_range, translation_std
+        self.num_joints, self.scale_depth, self.abs_dz, self.use_bbox_center = num_joints, scale_depth, abs_dz, use_bbox_center
+        if abs_dz:
+            assert scale_depth
+        if img_norm_cfg is not None:
+            self.img_mean = img_norm_cfg['mean']
+            if img_norm_cfg['to_rgb']:
+                self.img_mean = self.img_mean[::-1]
+        else:
+            self.img_mean = [127.5, 127.5, 127.5]
+
+    def draw(self, results):
+        """_rot_points, _random_scale, _trans_points: in this order (transforms_3d.py:1112-1116)."""
+        noise_rotation = np.random.uniform(self.rot_range[0], self.rot_range[1])
+        rot_sin, rot_cos = np.sin(noise_rotation), np.cos(noise_rotation)
+        results['pcd_rotation'] = np.array([[rot_cos, -rot_sin, 0], [rot_sin, rot_cos, 0], [0, 0, 1]]).T
+        results['pcd_rot'] = noise_rotation / math.pi * 180
+        assert 'pcd_scale_factor' not in results
+        results['pcd_scale_factor'] = np.random.uniform(self.scale_ratio_range[0], self.scale_ratio_range[1])
+        results['pcd_trans'] = np.random.normal(scale=np.array(self.translation_std, dtype=np.float32), size=2).T
+
+    def matrix(self, results):
+        h, w, _ = results['img_shape']
+        center = np.array([w / 2, h / 2], dtype=float) * (1 + results['pcd_trans'])
+        new_scale = np.array([w, h], dtype=float) * results['pcd_scale_factor']
+        return get_affine_transform(center, new_scale, results['pcd_rot'], [w, h])
+
+    def __call__(self, results):
+        results.setdefault('transformation_3d_flow', [])
+        self.draw(results)
+        trans = self.matrix(results)
+        h, w, _ = results['img_shape']
+        for key in results.get('img_fields', ['img']):
+            img = results[key]
+            assert tuple(img.shape[:2]) == (h, w)
+            results[key] = _img_ops().warp_affine(img, trans, (int(w), int(h)), self.img_mean)
+        results = warp_annotations(results, trans, results['pcd_scale_factor'], self.num_joints, self.scale_depth,
+                                   self.abs_dz, self.use_bbox_center)
+        if results is None:
+            return None
+        results['transformation_3d_flow'].extend(['R', 'S', 'T'])
+        return results
+
+
+# ---------------------------------------------------------------------------------------------- normalize / pad / format
+@PIPELINES.register_module()
+class Normalize:
+    """mmdet Normalize: records the parameters; the arithmetic runs in DefaultFormatBundlePose3D's single pass."""
+
+    def __init__(self, mean, std, to_rgb=True):
+        self.mean, self.std, self.to_rgb = np.array(mean, dtype=np.float32), np.array(std, dtype=np.float32), to_rgb
+
+    def __call__(self, results):
+        results['img_norm_cfg'] = dict(mean=self.mean, std=self.std, to_rgb=self.to_rgb)
+        results['_pending_normalize'] = True
+        return results
+
+
+@PIPELINES.register_module()
+class Pad:
+    """mmdet Pad(size / size_divisor, pad_val=0): records the padded shape (see Normalize)."""
+
+    def __init__(self, size=None, size_divisor=None, pad_val=0):
+        assert (size is None) != (size_divisor is None) and pad_val == 0
+        self.size, self.size_divisor = size, size_divisor
+
+    def __call__(self, results):
+        h, w = results['img_shape'][:2]
+        if self.size is not None:
+            ph, pw = self.size
+        else:
+            d = self.size_divisor
+            ph, pw = int(np.ceil(h / d)) * d, int(np.ceil(w / d)) * d
+        results['pad_shape'] = (ph, pw, 3)
+        results['pad_fixed_size'] = self.size
+        results['pad_size_divisor'] = self.size_divisor
+        return results
+
+
+def materialize_image(results, out=None):
+    """Normalize + Pad + HWC -> CHW of results['img'] in one kernel pass; `out` = a (3, Hp, Wp) slot of a batch tensor."""
+    cfg = results.get('img_norm_cfg') if results.pop('_pending_normalize', False) else None
+    mean = cfg['mean'] if cfg is not None else (0.0, 0.0, 0.0)
+    std = cfg['std'] if cfg is not None else (1.0, 1.0, 1.0)
+    ph, pw = results.get('pad_shape', results['img_shape'])[:2]
+    return _img_ops().normalize_pad_chw(results['img'], mean, std, bool(cfg is not None and cfg['to_rgb']), (ph, pw), out=out)
+
+
+@PIPELINES.register_module()
+class DefaultFormatBundlePose3D:
+    """formating.py:383-442: image to a CHW tensor (here: with the pending Normalize / Pad, on the device), annotation
+    arrays to tensors. (mmcv's DataContainer is the collate protocol of mmcv's dataloader; plain tensors here.)"""
+
+    def __init__(self, class_names, with_gt=True, with_label=True):
+        self.class_names, self.with_gt, self.with_label = class_names, with_gt, with_label
+
+    def __call__(self, results):
+        if 'img' in results:
+            results['img'] = materialize_image(results)
+        for key in ['gt_bboxes', 'gt_bboxes_ignore', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths',
+                    'transform_mat']:
+            if key in results:
+                results[key] = torch.from_numpy(np.ascontiguousarray(results[key]))
+        return results
+
+
+@PIPELINES.register_module()
+class Collect3D:
+    """formating.py:83-...: the keys the detector takes plus `img_metas` (the meta keys the model reads)."""
+
+    def __init__(self, keys, meta_keys=('filename', 'ori_shape', 'img_shape', 'pad_shape', 'scale_factor', 'flip',
+                                        'flip_direction', 'img_norm_cfg', 'transformation_3d_flow', 'pcd_scale_factor',
+                                        'pcd_rot', 'pcd_trans', 'transform_mat'), debug=False, num_joints=15):
+        self.keys, self.meta_keys = keys, meta_keys
+
+    def __call__(self, results):
+        data = {'img_metas': {k: results[k] for k in self.meta_keys if k in results}}
+        for k in self.keys:
+            data[k] = results[k]
         return data

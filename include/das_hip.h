@@ -407,6 +407,38 @@ long long das_decode_ws_bytes(int B, int cap, int J);
 int das_decode(const DasDecodeDesc* d, float* out_scores, float* out_poses, float* out_centers, int* out_index,
                int* out_count, void* ws, void* stream);
 
+/* ---- Image half of the pose data pipeline as a GPU-side augmentation stage: f32 HWC images,
+ * BGR as mmcv loads them. Each entry restates the OpenCV / mmcv op the reference pipeline calls
+ * (mmdet3d/datasets/pipelines/transforms_3d.py, configs/das/exp_panoptic.py:59-98):
+ *   das_img_resize_bilinear     mmcv.imrescale / imresize -> cv2.resize(INTER_LINEAR) on float images (ResizePose :19-61)
+ *   das_img_flip_horizontal     mmcv.imflip (RandomFlipPose3D :235-356)
+ *   das_img_photometric         mmdet PhotoMetricDistortion (brightness, contrast first / last, saturation and hue
+ *                               through OpenCV's float BGR<->HSV, channel permutation), in place, C = 3
+ *   das_img_warp_affine         cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT, borderValue) with the FORWARD 2x3 map M
+ *                               (GlobalRotScaleTransPose :973-986), C = 3
+ *   das_img_normalize_pad_chw   mmcv.imnormalize (BGR->RGB, cv2.subtract / cv2.multiply with f64 scalars) + Pad(0) +
+ *                               HWC->CHW (Normalize, Pad, DefaultFormatBundlePose3D formating.py:383-442) */
+typedef struct {
+  int use_brightness, use_contrast, contrast_first, use_saturation, use_hue;
+  float brightness, contrast, saturation, hue;
+  int perm[3]; /* output channel c takes channel perm[c] */
+} DasPhotometric;
+typedef struct {
+  double inv[6];
+  float border[3];
+} DasAffine; /* (internal) */
+typedef struct {
+  double mean[3], stdinv[3];
+  int to_rgb, mean_f64, std_f64;
+} DasNormalize; /* (internal) */
+int das_img_resize_bilinear(const float* src, float* dst, int Hs, int Ws, int Hd, int Wd, int C, void* stream);
+int das_img_flip_horizontal(const float* src, float* dst, int H, int W, int C, void* stream);
+int das_img_photometric(float* img, int H, int W, const DasPhotometric* p, void* stream);
+int das_img_warp_affine(const float* src, float* dst, int Hs, int Ws, int Hd, int Wd, const double* M, const float* border,
+                        void* stream);
+int das_img_normalize_pad_chw(const float* src, float* dst, int H, int W, int Hp, int Wp, const double* mean,
+                              const double* std, int to_rgb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
