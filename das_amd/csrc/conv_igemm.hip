@@ -348,7 +348,7 @@ __global__ __launch_bounds__((BN == 256 ? 512 : 2 * BMT)) void splitk_finish_ker
 // K-steps ahead of the MFMAs: per step  s_waitcnt vmcnt(one tile's DMAs still in flight) -> s_barrier ->
 // issue tile k+2 into the buffer freed by step k-1 -> MFMAs on tile k. Counted vmcnt + raw s_barrier
 // (a __syncthreads() would drain the DMA queue, cdna guide section 5).
-template <typename T, typename OT>
+template <typename T, typename OT, bool PP = false>
 __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   constexpr int BN = 128, BMT = 256, NBUF = 3;
   constexpr int EPV = Elem<T>::EPV;
@@ -448,6 +448,58 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   if (nk > 1) issue(1, 1);
   const int frow = lane & 15, fkg = lane >> 4;
   int buf = 0, nbuf = 2;  // buffer of tile kt, buffer tile kt+2 goes to
+  if constexpr (PP) {
+    // Ping-pong schedule (as conv_glds4_kernel<PP>): every K-step is two barrier intervals, R (issue tile kt+2, read
+    // the 16 fragments of tile kt) and M (the 32 MFMAs); waves 4-7 run one interval behind waves 0-3 and wave w / w+4
+    // share a SIMD, so one of them holds the matrix pipe while the other reads LDS and issues DMA. Tile kt+1 must
+    // have landed before the barrier that opens the leading group's R of step kt+1.
+    const int grp = wave >> 2;
+    auto wait_next = [&](int kt) {   // this wave's DMAs of tile kt+1 (tile kt+2 may still fly: 6 DMAs)
+      if (kt + 2 < nk) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    if (nk > 1) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                 // tile 0 landed
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // trailing group: one interval behind
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---- R
+      if (kt + 2 < nk) issue(kt + 2, nbuf);
+      const char* sA = smem + buf * BUF;
+      const char* sW = sA + A_BYTES;
+      uint4 fb[2][TM], fa[2][TN];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fa[t][i] = *reinterpret_cast<const uint4*>(sW + slot128(wave_n0 + i * 16 + frow, t * 4 + fkg));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fb[t][i] = *reinterpret_cast<const uint4*>(sA + slot128(wave_m0 + i * 16 + frow, t * 4 + fkg));
+      }
+      if (grp == 1) wait_next(kt);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- M
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) mma<T>(fa[t][a], fb[t][b], acc[a][b]);
+      __builtin_amdgcn_s_setprio(0);
+      if (grp == 0) wait_next(kt);
+      __builtin_amdgcn_s_barrier();
+      buf = buf == NBUF - 1 ? 0 : buf + 1;
+      nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // leading group: match the trailing group's extra interval
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) {
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile kt landed; tile kt+1 (6 DMAs per wave) may fly
@@ -770,18 +822,29 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
     (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
     (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
     (void)hipFuncSetAttribute((const void*)conv_glds_kernel<T, OT, BN, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_glds);
-    if (BN == 128) (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+    if (BN == 128) {
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+    }
     attr_set = true;
   }
   if (big) {
+    // ping-pong schedule from conv.glds3_pp_mink K on (-1: never)
+    const long long ppk = dastune::get(dastune::CONV_GLDS3_PP_MINK);
+    const bool pp3 = ppk >= 0 && p.K >= ppk;
     if constexpr (BN == 128 && sizeof(OT) == 2) {
       if (ks3 > 1) {
         dastune::note_kernel("conv_glds3_kernel<splitk>");
-        return launch_splitk<OT, 128, 256>(conv_glds3_kernel<T, OT>, p, ks3, sm_big, s);
+        return pp3 ? launch_splitk<OT, 128, 256>(conv_glds3_kernel<T, OT, true>, p, ks3, sm_big, s)
+                   : launch_splitk<OT, 128, 256>(conv_glds3_kernel<T, OT, false>, p, ks3, sm_big, s);
       }
     }
-    dastune::note_kernel("conv_glds3_kernel");
-    hipLaunchKernelGGL((conv_glds3_kernel<T, OT>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+    dastune::note_kernel(pp3 ? "conv_glds3_kernel<pp>" : "conv_glds3_kernel");
+    if (pp3) {
+      hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+    } else {
+      hipLaunchKernelGGL((conv_glds3_kernel<T, OT, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+    }
   } else if (glds) {
     const int ks = BN >= 64 ? pick_ksplit(p.nblocks, nk128, 2, 1, (long long)rows * p.Cout, tail) : 1;
     if (ks > 1) {

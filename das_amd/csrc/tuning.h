@@ -9,6 +9,8 @@ namespace dastune {
 enum Key {
   CONV_BIG_MINBLOCKS,    // conv_glds3_kernel (256 x 128 tile) from this many tiles up
   CONV_BIG_MINK,         // ... and K at least this
+  CONV_GLDS3_PP_MINK,    // conv_glds3_kernel runs its ping-pong schedule for K >= this (+4...8 % from K = 1024 up,
+                         // neutral to -2 % at K = 512 / 576); -1 = never
   CONV_GLDS4_MINBLOCKS,  // conv_glds4_kernel (256 x 256 tile) from this many tiles up; 0 disables the kernel
   CONV_GLDS4_PP,         // -1 = ping-pong schedule for K >= 256, 0 / 1 force the choice
   CONV_GLDS4_MF,         // conv_glds4_kernel pixel-tile height in 32-row units: 0 = by round count, 8 = 256 rows, 9 = 288 rows

@@ -14,7 +14,8 @@ struct Entry {
 };
 // (defaults: break-even points measured with cold operands, tools/dev/conv_cold_bench.py / wgrad_cold_bench.py)
 constexpr Entry kTable[N_KEYS] = {
-    {"conv.big_minblocks", 100},  {"conv.big_mink", 0},       {"conv.glds4_minblocks", 128}, {"conv.glds4_pp", -1},      {"conv.glds4_mf", 0},
+    {"conv.big_minblocks", 100},  {"conv.big_mink", 0},       {"conv.glds3_pp_mink", 1024},
+    {"conv.glds4_minblocks", 128}, {"conv.glds4_pp", -1},      {"conv.glds4_mf", 0},
     {"conv.stream_minrows", 16384}, {"conv.stream_percu", 2}, {"conv.tail_split", 1},        {"conv.splitk_target", 256},
     {"conv.splitk_minsteps", 12}, {"conv.splitk_kernels", 3},  {"wgrad.pp_mink", 256},
     {"wgrad.bkm", 32},            {"wgrad.blocks", 0},        {"wgrad.pp_blocks", 256},      {"bn.reduce_blocks", 256},     {"bn.reduce_threads", 256},

@@ -38,7 +38,7 @@ CASES = [
 ]
 FORCE = {
     'conv_glds_kernel': {'conv.big_minblocks': 1 << 30, 'conv.glds4_minblocks': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0},
-    'conv_glds3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0},
+    'conv_glds3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds3_pp_mink': -1},
     'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
     'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
     'conv1x1_stream_kernel': {},

@@ -48,7 +48,9 @@ def conv_ref(x, w, s, p):
 
 FORCE = {
     'conv_glds3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.splitk_target': 0,
-                          'conv.stream_minrows': 0},
+                          'conv.glds3_pp_mink': -1, 'conv.stream_minrows': 0},
+    'conv_glds3_kernel<pp>': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.splitk_target': 0,
+                              'conv.glds3_pp_mink': 0, 'conv.stream_minrows': 0},
     'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8,
                           'conv.stream_minrows': 0},
     'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.splitk_target': 0,
@@ -86,9 +88,10 @@ def _run_forced(kernel, case, **kw):
     return x, w, y
 
 
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>'])
 @pytest.mark.parametrize('case', SHAPES3)
-def test_glds3_forced(case):
-    x, w, y = _run_forced('conv_glds3_kernel', case)
+def test_glds3_forced(kernel, case):
+    x, w, y = _run_forced(kernel, case)
     np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
 
 
@@ -99,7 +102,7 @@ def test_glds4_forced(kernel, case):
     np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_epilogues_forced(kernel):
     """scale / shift / residual / ReLU, then the BatchNorm statistics of the stored values (in slots)."""
     o = ops()
@@ -124,7 +127,7 @@ def test_tile_epilogues_forced(kernel):
     np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_ragged_levels_forced(kernel):
     """The head's mode: four FPN levels in one launch, shared 3x3 weights (das_head.py:176-178)."""
     o = ops()
@@ -142,7 +145,7 @@ def test_tile_ragged_levels_forced(kernel):
         np.testing.assert_allclose(nchw(y.level(l)).numpy(), ref.numpy(), **TOL)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_dgrad_forced(kernel):
     """Data gradient of a stride-1 3x3 conv on the tile kernels (flipped weights), with a second gradient of the
     same tensor added in the epilogue."""
@@ -168,6 +171,9 @@ SPLITK = {
         (1, 9, 13, 2048, 136, 1, 1, 0),    # 1x1, K = 2048, M and N overhang
         (2, 32, 52, 256, 256, 3, 2, 1),    # stride 2
         (3, 7, 5, 192, 64, 3, 1, 1),       # BN = 64 tile, several images per M tile, odd split boundaries (27 steps)
+    ]),
+    'conv_glds3_kernel<pp>': (FORCE['conv_glds3_kernel<pp>'], 2, [
+        (2, 16, 26, 512, 512, 3, 1, 1), (3, 7, 5, 192, 128, 3, 1, 1),
     ]),
     'conv_glds3_kernel': (FORCE['conv_glds3_kernel'], 2, [
         (2, 16, 26, 512, 512, 3, 1, 1), (1, 9, 13, 2048, 136, 1, 1, 0), (2, 32, 52, 256, 256, 3, 2, 1),
@@ -310,8 +316,8 @@ REAL = [
     (2, 128, 208, 256, 256, 3, 1, 1, 'conv_glds4_kernel<pp>'),      # 208 tiles of 256 x 256, K = 2304
     (2, 128, 208, 64, 256, 3, 1, 1, 'conv_glds4_kernel<pp>'),       # K = 576
     (16, 16, 26, 2048, 2048, 1, 1, 0, 'conv_glds4_kernel<pp>'),     # out_skip1 of the coarsest unit: 26 x 8 tiles
-    (4, 128, 208, 128, 128, 3, 1, 1, 'conv_glds3_kernel'),          # layer2-like 3x3 on a large map
-    (16, 32, 52, 1024, 128, 1, 1, 0, 'conv_glds3_kernel'),          # 104 tiles, K = 1024
+    (4, 128, 208, 128, 128, 3, 1, 1, 'conv_glds3_kernel<pp>'),      # layer2-like 3x3 on a large map (K = 1152: ping-pong)
+    (16, 32, 52, 1024, 128, 1, 1, 0, 'conv_glds3_kernel<pp>'),      # 104 tiles, K = 1024
     (2, 128, 208, 256, 64, 1, 1, 0, 'conv1x1_stream_kernel'),
 ]
 
