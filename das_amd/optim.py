@@ -288,17 +288,28 @@ class FlatSGD:
             self._learn()
         self._reset_iteration()
 
-    def step(self, lr):
+    @property
+    def param_groups(self):
+        """torch.optim-style view for LR hooks (mmcv's LrUpdaterHook writes `group['lr']`): one dict per flat group;
+        `step()` without an argument applies the lr stored here (group lr = base lr x its lr_mult)."""
+        if not hasattr(self, '_param_groups'):
+            self._param_groups = [dict(lr=self.base_lr * g['lr_mult'], initial_lr=self.base_lr * g['lr_mult'],
+                                       momentum=self.momentum, weight_decay=g['wd'], lr_mult=g['lr_mult'])
+                                  for g in self.groups]
+        return self._param_groups
+
+    def step(self, lr=None):
         self._check_grad_aliasing()
         scale = 1.0 / self.world
         sumsq = None
         if self.max_grad_norm > 0:
             sumsq = T.grad_sumsq(self.flat_g, self.sumsq)
-        for g in self.groups:
+        for gi, g in enumerate(self.groups):
             if g['end'] == g['start']:
                 continue
             s, e = g['start'], g['end']
-            T.sgd_momentum_step(self.flat_p[s:e], self.flat_g[s:e], self.flat_m[s:e], lr * g['lr_mult'], self.momentum,
+            glr = lr * g['lr_mult'] if lr is not None else self.param_groups[gi]['lr']
+            T.sgd_momentum_step(self.flat_p[s:e], self.flat_g[s:e], self.flat_m[s:e], glr, self.momentum,
                                 g['wd'], grad_scale=scale, max_norm=self.max_grad_norm, grad_sumsq_t=sumsq,
                                 first_step=self.steps == 0)
         self.steps += 1

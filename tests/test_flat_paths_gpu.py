@@ -174,3 +174,25 @@ def test_wgrad_side_stream_equals_main_stream():
     diff = float((g0 - res['side'][0]).abs().max()) / scale
     assert abs(l0 - res['side'][1]) <= 1e-4 * abs(l0)
     assert diff <= max(3 * floor, 1e-4), (diff, floor)
+
+
+def test_flat_sgd_param_groups_shim():
+    """LR hooks of the reference write `optimizer.param_groups[i]['lr']` (mmcv LrUpdaterHook); `step()` without an
+    argument applies those, and equals `step(lr)` with the same base lr."""
+    import torch.nn as nn
+    from das_amd.optim import FlatSGD
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(0)
+        return nn.Sequential(nn.Conv2d(8, 8, 3, bias=True), nn.BatchNorm2d(8)).to('cuda')
+    a, b = make(), make()
+    oa = FlatSGD(a, lr=0.1, bias_lr_mult=2.0, bias_decay_mult=0.0)
+    ob = FlatSGD(b, lr=0.1, bias_lr_mult=2.0, bias_decay_mult=0.0)
+    g = torch.randn_like(oa.flat_g)
+    oa.flat_g.copy_(g); ob.flat_g.copy_(g)
+    assert [round(pg['lr'], 6) for pg in oa.param_groups] == [0.1, 0.2]
+    for pg in oa.param_groups:
+        pg['lr'] = pg['initial_lr'] * 0.5          # what a hook does
+    oa.step()
+    ob.step(0.05)
+    assert torch.equal(oa.flat_p, ob.flat_p)
