@@ -2,6 +2,7 @@
 the loss function (target assignment + four losses), parse/sum, backward, optimizer."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import time
 import torch
 import bench
 from das_amd import losses, pose_heads
@@ -17,10 +18,14 @@ opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0,
 ev = {}
 
 
+cpu = {}
+
+
 def mark(name):
     e = torch.cuda.Event(enable_timing=True)
     e.record()
     ev.setdefault(name, []).append(e)
+    cpu.setdefault(name, []).append(time.perf_counter())
 
 
 orig = losses.das_head_loss_rows
@@ -34,11 +39,10 @@ def timed_loss(*a, **k):
 
 
 losses.das_head_loss_rows = timed_loss
-import time
 N = 8
 for it in range(3 + N):
     if it == 3:
-        ev.clear()
+        ev.clear(); cpu.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
     mark('start')
@@ -55,4 +59,5 @@ print(f'wall ms/step {(time.perf_counter() - t0) / N * 1e3:.2f}')
 names = ['start', 'loss_in', 'loss_out', 'fwd_done', 'bwd_done', 'end']
 for a, b in zip(names, names[1:]):
     ms = sum(x.elapsed_time(y) for x, y in zip(ev[a], ev[b])) / N
-    print(f'{a:9s} -> {b:9s} {ms:8.3f} ms')
+    cms = sum(y - x for x, y in zip(cpu[a], cpu[b])) / N * 1e3
+    print(f'{a:9s} -> {b:9s} GPU timeline {ms:8.3f} ms   CPU issue time {cms:8.3f} ms')

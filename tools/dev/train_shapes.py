@@ -9,6 +9,8 @@ from das_amd.datasets import SyntheticPoseDataset, collate
 from das_amd.optim import FlatSGD, train_iteration
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+from das_amd import autograd as _ag
+_ag.WGRAD_SIDE_STREAM = False   # kernels one at a time: per-shape times are not stretched by overlapped weight gradients
 dev = torch.device('cuda', 0)
 model = bench.build_model(dev, num_stages=4, train=True)
 ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=B, seed=0)
@@ -42,7 +44,7 @@ for (tag, shape), (fl, sec, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[
     per = sec / n
     flop = fl / n
     rows_out = flop / (2.0 * max(Cout, 1) * k * k * max(Cin, 1)) if Cin else 0
-    hbm = (rows_out * s * s * Cin + rows_out * Cout) * 2 / 6.3e12 if Cin else 0
+    hbm = (rows_out * (Cin if k == 1 and s == 1 else min(s * s, k * k) * Cin / (s * s) if False else Cin) + rows_out * Cout) * 2 / 6.3e12 if Cin else 0
     mf = flop / 2.5e15
     print(f'{sec / tot * 100:5.1f}% {sec / R * 1e3:7.3f}ms n={n // R:3d} {per * 1e6:7.1f}us (hbm {hbm * 1e6:6.1f} mfma {mf * 1e6:6.1f}) '
           f'{fl / sec / 1e12:7.1f}TF {tag[5:30]:22s} HxW={H}x{W} Cin={Cin} Cout={Cout} k={k} s={s} lv={nl}')
