@@ -68,10 +68,30 @@ PIPELINES = Registry('pipeline')
 DATASETS.register_module(module=SyntheticPoseDataset)
 
 
+class ConcatDataset:
+    """mmdet.datasets.ConcatDataset: the datasets back to back (Panoptic + COCO keypoints in the reference's train set)."""
+
+    def __init__(self, datasets):
+        self.datasets = list(datasets)
+        self.cumulative_sizes = list(np.cumsum([len(d) for d in self.datasets]))
+        self.CLASSES = getattr(self.datasets[0], 'CLASSES', None)
+
+    def __len__(self):
+        return int(self.cumulative_sizes[-1]) if self.datasets else 0
+
+    def __getitem__(self, idx):
+        if idx < 0:
+            idx += len(self)
+        d = int(np.searchsorted(self.cumulative_sizes, idx, side='right'))
+        return self.datasets[d][idx - (int(self.cumulative_sizes[d - 1]) if d else 0)]
+
+
 def build_dataset(cfg, default_args=None):
     """mmdet3d.datasets.build_dataset (tools/train.py:196): `type=` resolves through DATASETS; a list under
     `pipeline` becomes a `das_amd.pipelines.Compose`."""
     from . import pipelines, pose_datasets  # noqa: F401  (register CMUPanopticDataset / MuPots3DHP and the transforms)
+    if isinstance(cfg, (list, tuple)):      # mmdet: a list of dataset configs is their concatenation (exp_panoptic.py:161-184)
+        return ConcatDataset([build_dataset(c, default_args) for c in cfg])
     cfg = dict(cfg)
     if cfg.get('type') not in DATASETS:
         raise KeyError(f"dataset type {cfg.get('type')} is not registered; available: {sorted(DATASETS.module_dict)}")

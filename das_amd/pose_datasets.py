@@ -326,3 +326,152 @@ class MuPots3DHP(_PoseCocoDataset):
             seq_err_abs.append(pje_abs)
         pck, pck_abs = E.mupots_pck(seq_err, seq_err_abs)
         return [('PCK_MEAN:', f'{pck:.2f}'), ('PCK_MEAN_ABS:', f'{pck_abs:.2f}')]
+
+
+@DATASETS.register_module()
+class MuCo3DHPDataset(_PoseCocoDataset):
+    """muco_3dhp.py: the MuCo-3DHP training set of the exp_mupots config (21 joints, root = Pelvis, pseudo camera from
+    the per-image focal length `f` and principal point `c`)."""
+    muco_joint_num = 21
+    muco_joints_name = MuPots3DHP.joints_name
+    muco_flip_pairs = ((2, 5), (3, 6), (4, 7), (8, 11), (9, 12), (10, 13), (17, 18), (19, 20))
+    JOINTS_DEF = {k: i for i, k in enumerate(muco_joints_name)}
+    ROOT_IDX = muco_joints_name.index('Pelvis')
+
+    def __init__(self, ann_file, pipeline=None, use_bbox_center=False, norm_depth=False, depth_factor=1, abs_dz=False,
+                 **kwargs):
+        if abs_dz:
+            assert norm_depth
+        super().__init__(ann_file, pipeline, **kwargs)
+        self.norm_depth, self.depth_factor, self.abs_dz, self.use_bbox_center = norm_depth, depth_factor, abs_dz, use_bbox_center
+        self.num_joints = len(self.JOINTS_DEF)
+        self.name2id = {os.path.basename(self.coco.load_imgs([i])[0]['file_name']): i for i in self.img_ids}
+        if self.test_mode:            # muco_3dhp.py:63-66: every fourth image that has annotations
+            keep = [i for i, info in enumerate(self.data_infos) if self.coco.get_ann_ids(img_ids=[info['id']])][::4]
+            self.data_infos = [self.data_infos[i] for i in keep]
+
+    def _parse_ann_info(self, img_info, ann_info):
+        """muco_3dhp.py:124-246: joints = [u, v, Z_cam], depth / sqrt(fx fy) (and / depth_factor), dz relative to the
+        root with abs_dz; persons whose root is invisible go to bboxes_ignore."""
+        f, c = img_info['f'], img_info['c']
+        cam = dict(K=np.array([[f[0], 0., c[0]], [0., f[1], c[1]]]),
+                   R=np.array([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]]), t=np.array([[0.], [0.], [0.]]))
+        gt_bboxes, gt_labels, gt_poses_3d, gt_bboxes_ignore, centers2d, depths = [], [], [], [], [], []
+        for ann in ann_info:
+            if ann.get('ignore', False) or not self._box_ok(ann, img_info, need_area=False):
+                continue
+            x1, y1, w, h = ann['bbox']
+            bbox = [x1, y1, x1 + w, y1 + h]
+            if ann.get('iscrowd', False):
+                gt_bboxes_ignore.append(bbox)
+                continue
+            pose_img = np.array(ann['keypoints_img'], dtype=float)
+            pose_cam = np.array(ann['keypoints_cam'], dtype=float)
+            pose_3d = np.concatenate([pose_img, pose_cam[:, 2:]], axis=1)
+            pose_vis = ann['keypoints_vis']
+            if self.norm_depth:
+                pose_3d[:, 2] /= self.depth_factor
+                if self.abs_dz:
+                    abs_dz = pose_3d[:, 2] - pose_3d[[self.ROOT_IDX], 2]
+                pose_3d[:, 2] /= np.sqrt(f[0] * f[1])
+            center = pose_3d[self.ROOT_IDX].copy()
+            if pose_3d.max() - pose_3d.min() < 10:
+                continue
+            if not self.use_bbox_center:
+                if pose_vis[self.ROOT_IDX] == 0:
+                    gt_bboxes_ignore.append(bbox)
+                    continue
+                c2d = pose_3d[self.ROOT_IDX].copy()
+            else:
+                c2d = center.copy()
+                c2d[0], c2d[1] = x1 + 0.5 * w, y1 + 0.5 * h
+            gt_bboxes.append(bbox)
+            gt_labels.append(self.cat2label[ann['category_id']])
+            if self.abs_dz:
+                pose_3d[:, 2] = abs_dz
+            gt_poses_3d.append(np.concatenate([np.array(c2d, dtype=float).reshape(-1), pose_3d.reshape(-1),
+                                               np.array(pose_vis, dtype=float).reshape(-1)]))
+            centers2d.append(c2d[:2])
+            depths.append(c2d[2])
+        if not gt_bboxes and not self.test_mode:
+            return None
+        out = self._finish_targets(gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore)
+        if out['gt_poses_3d'][:, 3 + self.num_joints * 3:].sum() < 6 and not self.test_mode:
+            return None
+        out['cam'] = cam
+        return out
+
+    def evaluate(self, *a, **k):
+        raise NotImplementedError      # (as in the reference, muco_3dhp.py:248-249)
+
+
+@DATASETS.register_module()
+class COCOKeypointsDataset(_PoseCocoDataset):
+    """coco_keypoints_dataset.py: COCO person keypoints as 2-D-only training samples (all dz = 0, which is what routes
+    them to the 2-D flows of the RLE loss), re-indexed into the target joint set (`convert_ids`: 'muco' 21 joints,
+    'panoptic' 15 joints, :229-271)."""
+    JOINTS_DEF = {k: i for i, k in enumerate((
+        'nose', 'left_eye', 'right_eye', 'left_ear', 'right_ear', 'left_shoulder', 'right_shoulder', 'left_elbow',
+        'right_elbow', 'left_wrist', 'right_wrist', 'left_hip', 'right_hip', 'left_knee', 'right_knee', 'left_ankle',
+        'right_ankle'))}
+    CONVERT = {'muco': [-1, -1, 6, 8, 10, 5, 7, 9, 12, 14, 16, 11, 13, 15, -1, -1, -1, -1, -1, -1, -1],
+               'panoptic': [-1, 0, -1, 5, 7, 9, 11, 13, 15, 6, 8, 10, 12, 14, 16]}
+
+    def __init__(self, data_root=None, load_interval=1, use_nms=False, use_bbox_center=False, convert_ids=None, **kwargs):
+        super().__init__(data_root=data_root, **kwargs)
+        assert convert_ids in (None, 'muco', 'panoptic')
+        self.num_joints = len(self.JOINTS_DEF)
+        self.load_interval, self.convert_ids, self.use_nms, self.use_bbox_center = load_interval, convert_ids, use_nms, use_bbox_center
+        self.name2id = {os.path.basename(self.coco.load_imgs([i])[0]['file_name']): i for i in self.img_ids}
+
+    def _parse_ann_info(self, img_info, ann_info):
+        """coco_keypoints_dataset.py:133-287."""
+        gt_bboxes, gt_labels, gt_poses_3d, gt_bboxes_ignore, centers2d, depths = [], [], [], [], [], []
+        for ann in ann_info:
+            if ann.get('ignore', False) or not self._box_ok(ann, img_info):
+                continue
+            x1, y1, w, h = ann['bbox']
+            bbox = [x1, y1, x1 + w, y1 + h]
+            if ann.get('iscrowd', False):
+                gt_bboxes_ignore.append(bbox)
+                continue
+            keypoints = np.array(ann['keypoints']).reshape(self.num_joints, 3)
+            pose_vis = (keypoints[..., 2] > 0).astype(float)
+            bbox_np = np.array(bbox, dtype=float).reshape(2, 2)
+            bbox_np[:, 0] = bbox_np[:, 0].clip(0, img_info['width'] - 1)
+            bbox_np[:, 1] = bbox_np[:, 1].clip(0, img_info['height'] - 1)
+            bbox_wh = bbox_np[1, :] - bbox_np[0, :]
+            if (bbox_wh < 2).any() or bbox_wh.prod() < 64:
+                continue
+            pose_3d = keypoints.copy()
+            pose_3d[..., 2] = 0
+            if not self.use_bbox_center:
+                if pose_vis[11] == 0 or pose_vis[12] == 0:      # both hips must be annotated (:186-194)
+                    continue
+                c2d = 0.5 * (pose_3d[11] + pose_3d[12])
+            else:
+                c2d = np.zeros(3, dtype=float)
+                c2d[:2] = bbox_np.mean(0)
+            gt_bboxes.append(bbox)
+            gt_labels.append(self.cat2label[ann['category_id']])
+            gt_poses_3d.append(np.concatenate([np.array(c2d, dtype=float).reshape(-1),
+                                               np.array(pose_3d, dtype=float).reshape(-1), np.array(pose_vis, dtype=float)]))
+            centers2d.append(c2d[:2])
+            depths.append(c2d[2])
+        if not gt_bboxes:
+            return None
+        out = self._finish_targets(gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore)
+        if self.convert_ids is not None:
+            cids = np.array(self.CONVERT[self.convert_ids], dtype=np.int64)
+            g = out['gt_poses_3d']
+            uvd = g[:, 3:3 + self.num_joints * 3].reshape(-1, self.num_joints, 3)
+            vis = g[:, 3 + self.num_joints * 3:]
+            n = uvd.shape[0]
+            e_uvd = np.zeros((n, len(cids), 3), dtype=np.float32)
+            e_vis = np.zeros((n, len(cids)), dtype=np.float32)
+            e_uvd[:, cids >= 0] = uvd[:, cids[cids >= 0]]
+            e_vis[:, cids >= 0] = vis[:, cids[cids >= 0]]
+            out['gt_poses_3d'] = np.concatenate([g[:, :3], e_uvd.reshape(n, -1), e_vis], axis=1).astype(np.float32)
+            if e_vis.sum() < 6:
+                return None
+        return out
