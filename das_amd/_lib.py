@@ -75,6 +75,7 @@ SIGNATURES = {
     'das_tuning_reset': (i32, []),
     'das_last_kernel': (C.c_char_p, []),
     'das_img_resize_bilinear': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'das_img_resize_bilinear_u8': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_img_flip_horizontal': (i32, [vp, vp, i32, i32, i32, vp]),
     'das_img_photometric': (i32, [vp, i32, i32, C.POINTER(DasPhotometric), vp]),
     'das_img_warp_affine': (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(f32), vp]),

@@ -42,6 +42,36 @@ __global__ void img_resize_kernel(const float* __restrict__ src, float* __restri
   }
 }
 
+// cv2.resize(INTER_LINEAR) on 8-bit images (the test pipeline resizes the decoded uint8 frame): OpenCV's fixed-point path —
+// 11-bit coefficients (saturate_cast<short>(f * 2048)), horizontal pass in int32, vertical pass
+// ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+__global__ void img_resize_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int Hs, int Ws,
+                                     int Hd, int Wd, int C, double scale_x, double scale_y) {
+#pragma clang fp contract(off)
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= (long long)Hd * Wd) return;
+  const int dy = (int)(i / Wd), dx = (int)(i - (long long)dy * Wd);
+  float fx = (float)((dx + 0.5) * scale_x - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= Ws - 1) { fx = 0.f; sx = Ws - 1; }
+  float fy = (float)((dy + 0.5) * scale_y - 0.5);
+  int sy = (int)floorf(fy);
+  fy -= (float)sy;
+  if (sy < 0) { fy = 0.f; sy = 0; }
+  if (sy >= Hs - 1) { fy = 0.f; sy = Hs - 1; }
+  const int sx1 = sx + 1 < Ws ? sx + 1 : sx, sy1 = sy + 1 < Hs ? sy + 1 : sy;
+  auto coef = [](float v) { const int r = (int)rintf(v * 2048.f); return r > 32767 ? 32767 : r < -32768 ? -32768 : r; };
+  const int a0 = coef(1.f - fx), a1 = coef(fx), b0 = coef(1.f - fy), b1 = coef(fy);
+  for (int c = 0; c < C; ++c) {
+    const int r0 = (int)src[((long long)sy * Ws + sx) * C + c] * a0 + (int)src[((long long)sy * Ws + sx1) * C + c] * a1;
+    const int r1 = (int)src[((long long)sy1 * Ws + sx) * C + c] * a0 + (int)src[((long long)sy1 * Ws + sx1) * C + c] * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    dst[i * C + c] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v);
+  }
+}
+
 __global__ void img_flip_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C) {
   const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= (long long)H * W) return;
@@ -151,6 +181,16 @@ extern "C" int das_img_resize_bilinear(const float* src, float* dst, int Hs, int
   const double sx = 1.0 / ((double)Wd / Ws), sy = 1.0 / ((double)Hd / Hs);   // (as cv2.resize forms them)
   hipLaunchKernelGGL(img_resize_kernel, dim3(blocks_for((long long)Hd * Wd)), dim3(TPB), 0, (hipStream_t)stream, src, dst,
                      Hs, Ws, Hd, Wd, C, sx, sy);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_img_resize_bilinear_u8(const unsigned char* src, unsigned char* dst, int Hs, int Ws, int Hd, int Wd, int C,
+                                          void* stream) {
+  if (!src || !dst || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1 || C < 1) return DAS_ERR_ARG;
+  const double sx = 1.0 / ((double)Wd / Ws), sy = 1.0 / ((double)Hd / Hs);
+  hipLaunchKernelGGL(img_resize_u8_kernel, dim3(blocks_for((long long)Hd * Wd)), dim3(TPB), 0, (hipStream_t)stream, src,
+                     dst, Hs, Ws, Hd, Wd, C, sx, sy);
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }

@@ -15,9 +15,18 @@ def _hwc(img):
 
 
 def resize_bilinear(img, size):
-    """cv2.resize(img, (Wd, Hd), INTER_LINEAR) on a float image (mmcv.imresize / imrescale, ResizePose)."""
-    H, W, Cc = _hwc(img)
+    """cv2.resize(img, (Wd, Hd), INTER_LINEAR) (mmcv.imresize / imrescale): float32 images (train pipeline, ResizePose)
+    or uint8 images (test pipeline: OpenCV's fixed-point path)."""
     Wd, Hd = int(size[0]), int(size[1])
+    if img.dtype == torch.uint8:
+        _need_gpu(img)
+        assert img.dim() == 3 and img.is_contiguous()
+        H, W, Cc = img.shape
+        out = torch.empty(Hd, Wd, Cc, dtype=torch.uint8, device=img.device)
+        _lib.check(_lib.load().das_img_resize_bilinear_u8(_ptr(img), _ptr(out), H, W, Hd, Wd, Cc, _stream()),
+                   'das_img_resize_bilinear_u8')
+        return out
+    H, W, Cc = _hwc(img)
     out = torch.empty(Hd, Wd, Cc, dtype=torch.float32, device=img.device)
     _lib.check(_lib.load().das_img_resize_bilinear(_ptr(img), _ptr(out), H, W, Hd, Wd, Cc, _stream()), 'das_img_resize_bilinear')
     return out
@@ -59,6 +68,8 @@ def warp_affine(img, M, size, border):
 
 def normalize_pad_chw(img, mean, std, to_rgb, pad_hw=None, out=None):
     """mmcv.imnormalize + zero pad to pad_hw + HWC -> CHW in one pass; `out` may be a (3, Hp, Wp) slice of a batch."""
+    if img.dtype == torch.uint8:      # (mmcv.imnormalize: img.astype(np.float32) first; exact)
+        img = img.float()
     H, W, Cc = _hwc(img)
     assert Cc == 3
     Hp, Wp = pad_hw if pad_hw is not None else (H, W)

@@ -186,6 +186,70 @@ class ResizePose:
         return results
 
 
+@PIPELINES.register_module()
+class Resize(ResizePose):
+    """mmdet Resize (the test pipeline's `dict(type='Resize', keep_ratio=True)` inside MultiScaleFlipAug): image and
+    boxes only."""
+
+    def __init__(self, **kwargs):
+        super().__init__(scale_depth=False, abs_dz=False, **kwargs)
+
+    def __call__(self, results):
+        pose = {k: results.pop(k) for k in ('gt_poses_3d', 'centers2d', 'depths') if k in results}
+        try:
+            # (ResizePose's image / box half; the pose half is skipped: plain Resize leaves those keys alone)
+            if 'scale' not in results:
+                self._random_scale(results)
+            h, w = results['img_shape'][:2]
+            if self.keep_ratio:
+                sc = results['scale']
+                f = min(max(sc) / max(h, w), min(sc) / min(h, w))
+                new_w, new_h = int(w * float(f) + 0.5), int(h * float(f) + 0.5)
+            else:
+                new_w, new_h = results['scale']
+            results['img'] = _img_ops().resize_bilinear(results['img'], (new_w, new_h))
+            w_scale, h_scale = new_w / w, new_h / h
+            results['scale_factor'] = np.array([w_scale, h_scale, w_scale, h_scale], dtype=np.float32)
+            results['img_shape'] = results['pad_shape'] = (new_h, new_w, 3)
+            results['keep_ratio'] = self.keep_ratio
+            for key in results.get('bbox_fields', []):
+                b = results[key] * results['scale_factor']
+                if self.bbox_clip_border:
+                    b[:, 0::2] = np.clip(b[:, 0::2], 0, new_w)
+                    b[:, 1::2] = np.clip(b[:, 1::2], 0, new_h)
+                results[key] = b
+        finally:
+            results.update(pose)
+        return results
+
+
+@PIPELINES.register_module()
+class MultiScaleFlipAug:
+    """mmdet MultiScaleFlipAug: the wrapped transforms once per (scale, flip) combination; the outputs' values are
+    gathered into lists per key (one entry per augmentation: the DAS configs use a single scale, no flip)."""
+
+    def __init__(self, transforms, img_scale=None, scale_factor=None, flip=False, flip_direction='horizontal'):
+        assert (img_scale is None) != (scale_factor is None)
+        self.transforms = Compose(transforms)
+        self.img_scale = img_scale if isinstance(img_scale, list) else [img_scale] if img_scale is not None else \
+            (scale_factor if isinstance(scale_factor, list) else [scale_factor])
+        self.scale_key = 'scale' if img_scale is not None else 'scale_factor'
+        self.flip = flip
+        self.flip_direction = flip_direction if isinstance(flip_direction, list) else [flip_direction]
+
+    def __call__(self, results):
+        import copy
+        aug = []
+        flips = [(False, None)] + ([(True, d) for d in self.flip_direction] if self.flip else [])
+        for scale in self.img_scale:
+            for flip, direction in flips:
+                r = copy.copy(results)
+                r[self.scale_key] = scale
+                r['flip'], r['flip_direction'] = flip, direction
+                aug.append(self.transforms(r))
+        return {k: [a[k] for a in aug] for k in aug[0]}
+
+
 # ---------------------------------------------------------------------------------------------- flip
 def flip_pose(results, num_joints, flip_pairs):
     """RandomFlipPose3D.random_flip_data_3d, 'gt_poses_3d' branch (transforms_3d.py:293-318), in place."""
@@ -506,7 +570,7 @@ class Collect3D:
 
     def __init__(self, keys, meta_keys=('filename', 'ori_shape', 'img_shape', 'pad_shape', 'scale_factor', 'flip',
                                         'flip_direction', 'img_norm_cfg', 'transformation_3d_flow', 'pcd_scale_factor',
-                                        'pcd_rot', 'pcd_trans', 'transform_mat'), debug=False, num_joints=15):
+                                        'pcd_rot', 'pcd_trans', 'transform_mat', 'cam'), debug=False, num_joints=15):
         self.keys, self.meta_keys = keys, meta_keys
 
     def __call__(self, results):

@@ -432,6 +432,8 @@ typedef struct {
   int to_rgb, mean_f64, std_f64;
 } DasNormalize; /* (internal) */
 int das_img_resize_bilinear(const float* src, float* dst, int Hs, int Ws, int Hd, int Wd, int C, void* stream);
+int das_img_resize_bilinear_u8(const unsigned char* src, unsigned char* dst, int Hs, int Ws, int Hd, int Wd, int C,
+                               void* stream); /* 8-bit images: OpenCV's fixed-point INTER_LINEAR (test pipeline) */
 int das_img_flip_horizontal(const float* src, float* dst, int H, int W, int C, void* stream);
 int das_img_photometric(float* img, int H, int W, const DasPhotometric* p, void* stream);
 int das_img_warp_affine(const float* src, float* dst, int Hs, int Ws, int Hd, int Wd, const double* M, const float* border,

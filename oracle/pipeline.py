@@ -41,6 +41,33 @@ def resize_bilinear(img, size):
     return (r0 * b0 + r1 * b1).astype(F32)
 
 
+def resize_bilinear_u8(img, size):
+    """cv2.resize(INTER_LINEAR) on uint8: 11-bit fixed-point coefficients, int32 horizontal pass, the vertical pass
+    (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2."""
+    Hs, Ws = img.shape[:2]
+    Wd, Hd = size
+    scale_x, scale_y = 1.0 / (float(Wd) / Ws), 1.0 / (float(Hd) / Hs)
+
+    def axis(n_dst, n_src, scale):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(F32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(F32)).astype(F32)
+        lo = s < 0
+        f[lo], s[lo] = 0, 0
+        hi = s >= n_src - 1
+        f[hi], s[hi] = 0, n_src - 1
+        c0 = np.clip(np.rint((F32(1) - f) * F32(2048)), -32768, 32767).astype(np.int64)
+        c1 = np.clip(np.rint(f * F32(2048)), -32768, 32767).astype(np.int64)
+        return s, np.minimum(s + 1, n_src - 1), c0, c1
+    sx, sx1, a0, a1 = axis(Wd, Ws, scale_x)
+    sy, sy1, b0, b1 = axis(Hd, Hs, scale_y)
+    im = img.astype(np.int64)
+    r0 = im[sy][:, sx] * a0[None, :, None] + im[sy][:, sx1] * a1[None, :, None]
+    r1 = im[sy1][:, sx] * a0[None, :, None] + im[sy1][:, sx1] * a1[None, :, None]
+    v = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
 def rescale_size(w, h, scale):
     """mmcv.rescale_size for a (long, short) tuple: new (w, h) and the factor."""
     f = min(max(scale) / max(h, w), min(scale) / min(h, w))

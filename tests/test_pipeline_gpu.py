@@ -182,3 +182,47 @@ def test_pipeline_output_feeds_a_train_step(tmp_path):
     model = bench.build_model(torch.device(DEV), seed=0, dtype='f32', num_stages=1, train=True)
     res = model.train_step(data, None)
     assert np.isfinite(float(res['loss'].detach())) and res['num_samples'] == 2
+
+
+@pytest.mark.parametrize('hw,size', [((37, 53), (41, 29)), ((540, 960), (1138, 640)), ((64, 48), (48, 64))])
+def test_resize_uint8_bit_exact(hw, size):
+    """the test pipeline resizes the decoded 8-bit frame: OpenCV's fixed-point INTER_LINEAR"""
+    from das_amd import image_ops as I
+    from oracle import pipeline as O
+    img = np.random.RandomState(11).randint(0, 256, hw + (3,)).astype(np.uint8)
+    got = I.resize_bilinear(dev(img), size).cpu().numpy()
+    assert got.dtype == np.uint8 and np.array_equal(got, O.resize_bilinear_u8(img, size))
+
+
+def test_test_pipeline_chain(tmp_path):
+    """configs/das/exp_panoptic.py:138-155: MultiScaleFlipAug(img_scale, flip=False)[Resize, RandomFlipPose3D(0),
+    Normalize, Pad, DefaultFormatBundlePose3D, Collect3D] on an 8-bit frame."""
+    from das_amd import pipelines as P
+    from oracle import pipeline as O
+    h, w = 270, 480
+    img = np.random.RandomState(12).randint(0, 256, (h, w, 3)).astype(np.uint8)
+    np.save(tmp_path / 'frame.npy', img)
+    ann = PC.annotations(22, n=3, h=h, w=w)
+    pipe = P.Compose([
+        dict(type='LoadImageFromFile'),
+        dict(type='LoadAnnotationsPose3D', with_pose_3d=True, with_label_3d=False),
+        dict(type='MultiScaleFlipAug', img_scale=(667, 320), flip=False, transforms=[
+            dict(type='Resize', keep_ratio=True),
+            dict(type='RandomFlipPose3D', flip_ratio_bev_horizontal=0.0, flip_pairs=PC.FLIP_PAIRS, num_joints=PC.J),
+            dict(type='Normalize', **PC.IMG_NORM),
+            dict(type='Pad', size_divisor=32),
+            dict(type='DefaultFormatBundlePose3D', class_names=['person'], with_label=False),
+            dict(type='Collect3D', keys=['img', 'gt_poses_3d', 'depths']),
+        ])])
+    out = pipe(dict(img_info=dict(filename=str(tmp_path / 'frame.npy')), img_prefix=None,
+                    ann_info=dict(centers2d=ann['centers2d'], depths=ann['depths'], gt_poses_3d=ann['gt_poses_3d'],
+                                  cam=dict(K=np.eye(3)))))
+    assert isinstance(out['img'], list) and len(out['img']) == 1
+    meta = out['img_metas'][0]
+    nw, nh = O.rescale_size(w, h, (667, 320))
+    assert tuple(meta['img_shape'][:2]) == (nh, nw) and not meta['flip'] and 'cam' in meta
+    ref = O.resize_bilinear_u8(img, (nw, nh)).astype(np.float32)
+    ref = O.pad_to_multiple(O.normalize(ref, np.float32(PC.IMG_NORM['mean']), np.float32(PC.IMG_NORM['std']), True), 32)
+    got = out['img'][0].cpu().numpy()
+    assert np.array_equal(got, ref.transpose(2, 0, 1))
+    assert np.array_equal(out['gt_poses_3d'][0].numpy(), ann['gt_poses_3d'])      # plain Resize leaves the poses alone
