@@ -69,3 +69,95 @@ def test_bench_self_launches_two_ranks():
         line = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
         assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0, line
         assert line['config']['parallelism'] in ('dp2', 'replicas2')
+
+
+def test_test_cli_on_a_real_dataset_class_with_pipeline_and_evaluator(tmp_path):
+    """tools/test.py end to end on the non-synthetic path: CMUPanopticDataset over a COCO-style annotation file,
+    the reference's test pipeline (MultiScaleFlipAug / Resize / Normalize / Pad ...) on the GPU, `--eval mpjpe`."""
+    import json
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import eval_cases as EC
+    ann = EC.panoptic_annotation(n_img=3)
+    root = tmp_path / 'panoptic'
+    rs = np.random.RandomState(0)
+    for im in ann['images']:
+        f = root / im['file_name']
+        f.parent.mkdir(parents=True, exist_ok=True)
+        Image.fromarray(rs.randint(0, 256, (im['height'], im['width'], 3)).astype(np.uint8)).save(f, quality=60)
+    (root / 'annotations').mkdir()
+    with open(root / 'annotations/val.json', 'w') as f:
+        json.dump(ann, f)
+    cfg = tmp_path / 'cfg.py'
+    cfg.write_text(f"""
+_base_ = ['{ROOT}/configs/das/exp_panoptic.py']
+img_norm_cfg = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+test_pipeline = [
+    dict(type='LoadImageFromFile'),
+    dict(type='LoadAnnotationsPose3D', with_pose_3d=True, with_label_3d=False),
+    dict(type='MultiScaleFlipAug', img_scale=(667, 320), flip=False, transforms=[
+        dict(type='Resize', keep_ratio=True),
+        dict(type='RandomFlipPose3D', flip_ratio_bev_horizontal=0.0,
+             flip_pairs=[[3, 9], [4, 10], [5, 11], [6, 12], [7, 13], [8, 14]], num_joints=15),
+        dict(type='Normalize', **img_norm_cfg),
+        dict(type='Pad', size_divisor=32),
+        dict(type='DefaultFormatBundlePose3D', class_names=['person'], with_label=False),
+        dict(type='Collect3D', keys=['img', 'gt_poses_3d', 'depths']),
+    ])]
+data = dict(samples_per_gpu=1, test=dict(_delete_=True, type='CMUPanopticDataset', data_root='{root}/',
+                                         ann_file='{root}/annotations/val.json', img_prefix='{root}/', pipeline=test_pipeline,
+                                         test_mode=True, use_bbox_center=False, abs_dz=True, norm_depth=True, depth_factor=1))
+""")
+    out = run('tools/test.py', str(cfg), 'none', '--eval', 'mpjpe', '--cfg-options', 'model.backbone.num_stages=1',
+              'model.test_cfg.score_thr=0.0', 'model.test_cfg.nms_post=5')
+    assert '3 images' in out and 'MPJPE' in out, out[-800:]
+
+
+def test_train_cli_on_a_real_dataset_class_with_the_train_pipeline(tmp_path):
+    """tools/train.py on CMUPanopticDataset + the reference's train pipeline (multi-scale resize, flip, photometric
+    distortion, rotation / scale / translation, normalize, pad) running on the GPU; samples the augmentation drops are
+    replaced, images of different sizes are padded to a common batch shape."""
+    import json
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import eval_cases as EC
+    ann = EC.panoptic_annotation(n_img=6)
+    root = tmp_path / 'panoptic'
+    rs = np.random.RandomState(1)
+    for im in ann['images']:
+        f = root / im['file_name']
+        f.parent.mkdir(parents=True, exist_ok=True)
+        Image.fromarray(rs.randint(0, 256, (im['height'], im['width'], 3)).astype(np.uint8)).save(f, quality=60)
+    (root / 'annotations').mkdir()
+    with open(root / 'annotations/train.json', 'w') as f:
+        json.dump(ann, f)
+    cfg = tmp_path / 'cfg.py'
+    cfg.write_text(f"""
+_base_ = ['{ROOT}/configs/das/exp_panoptic.py']
+img_norm_cfg = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+train_pipeline = [
+    dict(type='LoadImageFromFile', to_float32=True),
+    dict(type='LoadAnnotationsPose3D', with_bbox=True, with_label=True),
+    dict(type='ResizePose', scale_depth=True, abs_dz=True, img_scale=[(480, 256), (480, 288)], multiscale_mode='range',
+         keep_ratio=True),
+    dict(type='RandomFlipPose3D', flip_ratio_bev_horizontal=0.5,
+         flip_pairs=[[3, 9], [4, 10], [5, 11], [6, 12], [7, 13], [8, 14]], num_joints=15),
+    dict(type='PhotoMetricDistortion', brightness_delta=32, contrast_range=(0.7, 1.3), saturation_range=(0.7, 1.3),
+         hue_delta=18),
+    dict(type='GlobalRotScaleTransPose', scale_depth=True, abs_dz=True, rot_range=[-0.0, 0.0], scale_ratio_range=[0.9, 1.1],
+         translation_std=[0.02, 0.02], num_joints=15, img_norm_cfg=img_norm_cfg, use_bbox_center=False),
+    dict(type='Normalize', **img_norm_cfg),
+    dict(type='Pad', size_divisor=32),
+    dict(type='DefaultFormatBundlePose3D', class_names=['person']),
+    dict(type='Collect3D', keys=['img', 'gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths']),
+]
+data = dict(samples_per_gpu=2, train=dict(_delete_=True, type='CMUPanopticDataset', data_root='{root}/',
+                                          ann_file='{root}/annotations/train.json', img_prefix='{root}/',
+                                          pipeline=train_pipeline, use_bbox_center=False, abs_dz=True, norm_depth=True,
+                                          depth_factor=1))
+""")
+    out = run('tools/train.py', str(cfg), '--work-dir', str(tmp_path / 'w'), '--max-iters', '3', '--cfg-options',
+              'model.backbone.num_stages=1', 'runner.max_epochs=1', 'log_config.interval=1')
+    assert 'loss_pose' in out and 'nan' not in out.lower(), out[-800:]

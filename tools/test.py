@@ -73,8 +73,14 @@ def main():
     if args.max_batches:
         idxs = idxs[:args.max_batches]
     for i in idxs:  # samples_per_gpu=1 as in the reference (tools/test.py:160-166)
-        data = collate([dataset[i]], device='cuda')
-        out = model(return_loss=False, rescale=True, img=[data['img']], img_metas=[data['img_metas']])
+        sample = dataset[i]
+        if isinstance(sample['img'], (list, tuple)):   # MultiScaleFlipAug: one entry per test-time augmentation
+            imgs = [t.unsqueeze(0).cuda() for t in sample['img']]
+            metas = [[m] for m in sample['img_metas']]
+        else:
+            data = collate([sample], device='cuda')
+            imgs, metas = [data['img']], [data['img_metas']]
+        out = model(return_loss=False, rescale=True, img=imgs, img_metas=metas)
         for r in out:
             results.append({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in r.items()})
     if distributed:
@@ -88,8 +94,14 @@ def main():
             with open(args.out, 'wb') as f:
                 pickle.dump(results, f)
         if args.eval:
-            print(f'--eval {args.eval}: task metrics need the real datasets, which are out of scope here '
-                  f'(SURVEY.md section 8f); results were {"written to " + args.out if args.out else "not saved"}')
+            if hasattr(dataset, 'evaluate'):   # CMUPanopticDataset (mpjpe) / MuPots3DHP (pck): das_amd/evaluation.py
+                kw = {}
+                for kv in args.eval_options or []:     # k=v pairs, as mmcv's DictAction parses them
+                    k, v = kv.split('=', 1)
+                    kw[k] = v
+                print(dataset.evaluate(results, metric=args.eval[0] if len(args.eval) == 1 else args.eval, **kw))
+            else:
+                print(f'--eval {args.eval}: {type(dataset).__name__} has no evaluator (synthetic data)')
 
 
 if __name__ == '__main__':

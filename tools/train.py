@@ -96,7 +96,14 @@ def main():
         order = order[rank::world]
         t0 = time.time()
         for b in range(0, len(order), spg):
-            data = collate([dataset[i] for i in order[b:b + spg]], device='cuda')
+            samples = []
+            for i in order[b:b + spg]:
+                smp, tries = dataset[i], 0
+                while smp is None and tries < 100:   # the pipeline dropped the sample (no valid person after augmentation):
+                    i = (i + 1) % len(dataset)       # take another one, as mmdet's CustomDataset._rand_another does
+                    smp, tries = dataset[i], tries + 1
+                samples.append(smp)
+            data = collate(samples, device='cuda')
             lr = step_lr(opt.base_lr, epoch, it, steps=lrc.get('step', (16, 20)), warmup_iters=lrc.get('warmup_iters', 0),
                          warmup_ratio=lrc.get('warmup_ratio', 1.0))
             out = train_iteration(model, opt, data, lr)
