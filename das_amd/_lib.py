@@ -63,7 +63,7 @@ class DasDecodeDesc(C.Structure):
                 ('H', i32 * DAS_MAX_LEVELS), ('W', i32 * DAS_MAX_LEVELS), ('stride', i32 * DAS_MAX_LEVELS),
                 ('cls', vp * DAS_MAX_LEVELS), ('ctr', vp * DAS_MAX_LEVELS), ('pose', vp * DAS_MAX_LEVELS),
                 ('cls_ps', i32 * DAS_MAX_LEVELS), ('ctr_ps', i32 * DAS_MAX_LEVELS), ('pose_ps', i32 * DAS_MAX_LEVELS),
-                ('nms_pre', i32), ('nms_post', i32), ('score_thr', f32), ('nms_thr', f32), ('scale_factor', vp)]
+                ('nms_pre', i32), ('nms_post', i32), ('score_thr', f32), ('nms_thr', f32), ('scale_factor', vp), ('nms_soft', i32)]
 
 
 # name -> (restype, argtypes); must list every function include/das_hip.h declares
@@ -150,7 +150,7 @@ def load():
         except AttributeError as e:
             raise DasHipError(f'libdas_hip.so does not export {name}') from e
         fn.restype, fn.argtypes = res, args
-    if lib.das_abi_version() != 1:
+    if lib.das_abi_version() != 2:
         raise DasHipError('libdas_hip.so ABI version mismatch')
     _lib = lib
     return lib

@@ -1,5 +1,5 @@
 // Fused per-image decode: sigmoid scores -> threshold -> per-level top-k -> gather + affine
-// -> stable descending sort -> greedy OKS-NMS -> first nms_post survivors.
+// -> stable descending sort -> greedy OKS-NMS (or soft OKS-NMS) -> first nms_post survivors.
 // (das_head.py:690-796 `_get_poses_single`, pose_nms.py:51-126.) One 1024-thread workgroup per
 // image; candidate keys live in LDS (128 KiB). Integer/ordering work is exact:
 // key = (score bits << 32) | ~flat_index, so "higher score first, then lower flat index".
@@ -25,8 +25,7 @@ __host__ __device__ inline long long ws_bytes_per_image(int cap, int J) {
 }
 
 // pose_nms.py:51-90 for one pair: f64 arithmetic as numpy does, the mean rounded to f32 before the compare
-__device__ __forceinline__ bool oks_above_f64(const float* kx, const float* ky, const float* area, int a, int c, int J,
-                                              float thr32) {
+__device__ __forceinline__ float oks_value_f64(const float* kx, const float* ky, const float* area, int a, int c, int J) {
 #pragma clang fp contract(off)
   const double denom = (double)((area[a] + area[c]) / 2.f) + 2.220446049250313e-16;
   double acc = 0.0;
@@ -42,8 +41,11 @@ __device__ __forceinline__ bool oks_above_f64(const float* kx, const float* ky, 
     const double e = (double)(dx * dx + dy * dy) / var / denom / 2.0;
     acc += exp(-e);
   }
-  const float iou = (float)(acc / (double)J);
-  return !(iou <= thr32);
+  return (float)(acc / (double)J);
+}
+__device__ __forceinline__ bool oks_above_f64(const float* kx, const float* ky, const float* area, int a, int c, int J,
+                                              float thr32) {
+  return !(oks_value_f64(kx, ky, area, a, c, J) <= thr32);
 }
 // The decision "oks > thr" only: an f32 evaluation first (an f64 exp costs ~10x an f32 one and there are 15-21 per
 // pair); its error is below 1e-5 (each term in (0, 1], a few ulp each), so beyond a margin of 1e-3 around the
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   // matrix [n][W] | x [n][J] | y [n][J] | area [n]
   const int nW = (total + 31) >> 5;
   const size_t pm_off = (size_t)PAIR_MAX * 8, xy_off = pm_off + (size_t)total * nW * 4;
-  const bool pairwise = total <= PAIR_MAX && J <= 32 &&
+  const bool pairwise = !d.nms_soft && total <= PAIR_MAX && J <= 32 &&
                         xy_off + (size_t)total * J * 8 + (size_t)total * 4 <= (size_t)LDS_KEYS * 8;   // (uniform)
   float* skx = reinterpret_cast<float*>(smem + xy_off);
   float* sky = skx + (size_t)total * J;
@@ -287,7 +289,50 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
 
   // ---- greedy OKS-NMS (pose_nms.py:92-126)
   const float thr32 = d.nms_thr;
-  if (pairwise) {
+  if (d.nms_soft) {
+    // Soft OKS-NMS (pose_nms.py:128-194, the `nms_type != 'hard'` branch of das_head.py:784-790): nothing is dropped;
+    // each round takes the best remaining candidate and rescales every other remaining score by exp(-oks^2 / thr)
+    // (f32 arithmetic on the f32 oks values, as numpy does with these arrays), until nms_post are taken. The
+    // reference re-sorts the remaining scores every round; only their maximum matters for the next round, so a
+    // workgroup-wide arg-max replaces the sort (ties: the candidate that came first in the initial order).
+    float* ssc = reinterpret_cast<float*>(smem + (size_t)LDS_KEYS * 8 - (size_t)SUP_LDS * 4);   // [total <= SUP_LDS]
+    __shared__ unsigned long long s_red[TPB / 64];
+    for (int c = tid; c < total; c += TPB) ssc[c] = __uint_as_float((unsigned)(keys[c] >> 32));
+    __syncthreads();
+    const int maxd = total < d.nms_post ? total : d.nms_post;
+    int kept = 0;
+    while (kept < maxd) {
+      unsigned long long best = 0ull;   // (score bits << 32) | ~slot: the scores are >= 0, so bit order is value order
+      for (int c = tid; c < total; c += TPB)
+        if (!sup[c]) {
+          const unsigned long long k = ((unsigned long long)__float_as_uint(ssc[c]) << 32) | (unsigned)(~(unsigned)c);
+          best = k > best ? k : best;
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+      }
+      if ((tid & 63) == 0) s_red[tid >> 6] = best;
+      __syncthreads();
+      best = s_red[0];
+#pragma unroll
+      for (int i = 1; i < TPB / 64; ++i) best = s_red[i] > best ? s_red[i] : best;
+      const int sel = (int)~(unsigned)(best & 0xffffffffull);
+      if (tid == 0) out_index[(size_t)b * d.nms_post + kept] = sel;   // slot id, remapped below
+      ++kept;
+      for (int c = tid; c < total; c += TPB) {
+        if (c == sel || sup[c]) continue;
+        const float iou = oks_value_f64(kx, ky, area, sel, c, J);
+        ssc[c] = ssc[c] * (float)exp((double)(-(iou * iou) / thr32));
+      }
+      __syncthreads();
+      if (tid == 0) sup[sel] = 1;
+      __syncthreads();
+    }
+    if (tid == 0) s_kept = kept;
+    __syncthreads();
+  } else if (pairwise) {
     // "suppresses" bit matrix in LDS: only keys[0 .. total) are still needed, the rest of the key array is free.
     // Row r = candidates c > r with oks(r, c) > thr, W words per row.
     const int n = total, W = nW, half = (n + 1) / 2;

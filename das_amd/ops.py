@@ -771,16 +771,17 @@ def head_assemble_backward(raw, d_pose, d_uvd, desc):
     return d_raw, d_scale
 
 
-def decode(cls_list, ctr_list, pose_list, strides, scale_factors, J, nms_pre, nms_post, score_thr, nms_thr):
+def decode(cls_list, ctr_list, pose_list, strides, scale_factors, J, nms_pre, nms_post, score_thr, nms_thr, nms_soft=False):
     """Eval-mode head outputs per level, NHWC f32: cls/ctr (B,H,W,c>=1) logits in channel 0,
     pose (B,H,W,>=3+3J). scale_factors: (B,2) f32 device tensor. Returns dict of device tensors:
-    count (B,), scores (B,nms_post), poses (B,nms_post,J,3), centers (B,nms_post,3), index (B,nms_post)."""
+    count (B,), scores (B,nms_post), poses (B,nms_post,J,3), centers (B,nms_post,3), index (B,nms_post).
+    nms_soft: soft OKS-NMS (`nms_type='soft'`, pose_nms.py:128-194) instead of the greedy one."""
     _need_gpu(*cls_list, *ctr_list, *pose_list, scale_factors)
     lib = _lib.load()
     B = cls_list[0].shape[0]
     L = len(cls_list)
     d = _lib.DasDecodeDesc(B=B, J=J, num_levels=L, nms_pre=nms_pre, nms_post=nms_post, score_thr=score_thr,
-                           nms_thr=nms_thr, scale_factor=scale_factors.data_ptr())
+                           nms_thr=nms_thr, scale_factor=scale_factors.data_ptr(), nms_soft=1 if nms_soft else 0)
     for l in range(L):
         d.H[l], d.W[l], d.stride[l] = cls_list[l].shape[1], cls_list[l].shape[2], strides[l]
         d.cls[l], d.ctr[l], d.pose[l] = cls_list[l].data_ptr(), ctr_list[l].data_ptr(), pose_list[l].data_ptr()

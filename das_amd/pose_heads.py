@@ -390,9 +390,9 @@ class DASHead(nn.Module):
         sf = torch.tensor(np.stack([np.asarray(m['scale_factor'], dtype=np.float32)[:2] for m in img_metas]),
                           dtype=f32, device=dev)
         nms_post = cfg.get('nms_post', 100)
-        assert cfg.get('nms_type', 'hard') == 'hard', 'soft OKS-NMS is not on the DAS configs\' path'
         out = ops.decode(cls, ctr, pose, self.strides, sf, J, cfg.get('nms_pre', -1), nms_post,
-                         cfg.get('score_thr', 0.), cfg.get('nms_thr', 0.9))
+                         cfg.get('score_thr', 0.), cfg.get('nms_thr', 0.9),
+                         nms_soft=cfg.get('nms_type', 'hard') != 'hard')   # (das_head.py:784-790)
         counts = out['count'].cpu().tolist()
         results = []
         for b, meta in enumerate(img_metas):

@@ -36,7 +36,7 @@ typedef struct {
   int H[5], W[5];
 } DasLevels;
 
-/* Library/ABI version and the code object's target, for the loader's sanity check. */
+/* Library/ABI version (2: round-2 descriptor layouts) and the code object's target, for the loader's sanity check. */
 int das_abi_version(void);
 const char* das_target_arch(void);
 
@@ -400,6 +400,9 @@ typedef struct {
   int nms_pre, nms_post;
   float score_thr, nms_thr;
   const float* scale_factor; /* device f32[B*2]: (sx, sy) per image */
+  int nms_soft; /* != 0: soft OKS-NMS (pose_nms.py:128-194 soft_oks_nms, the nms_type != 'hard' branch of
+                 * das_head.py:784-790): nms_post rounds of "take the best remaining score, multiply every other
+                 * remaining score by exp(-oks^2 / nms_thr)"; the scores returned are the original ones */
 } DasDecodeDesc;
 /* candidate capacity per image = sum over levels of min(H*W, nms_pre) */
 int das_decode_cap(const DasDecodeDesc* d);

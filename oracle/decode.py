@@ -2,7 +2,7 @@
 
 Follows /root/reference/mmdet3d/models/pose_heads/das_head.py get_poses :653-688,
 _get_poses_single :690-796 and /root/reference/mmdet3d/core/post_processing/pose_nms.py
-oks_iou :51-89, oks_nms :92-126.
+oks_iou :51-89, oks_nms :92-126, _rescore / soft_oks_nms :128-194.
 
 Tie-break: the reference's `torch.topk` / `np.argsort()[::-1]` leave equal scores in an
 undefined order; the oracle defines "higher score first, then lower flat index" (stable
@@ -46,6 +46,28 @@ def oks_nms(scores, kpts, areas, thr):
     return np.array(keep, dtype=np.int64)
 
 
+def soft_oks_nms(scores, kpts, areas, thr, max_dets=20):
+    """pose_nms.py:128-194 (`_rescore` gaussian + `soft_oks_nms`): float32 arithmetic as numpy does with these arrays.
+    The reference re-sorts the rescored scores every round with an unstable argsort; the oracle defines ties as
+    "the candidate that came first in the initial (score desc, index asc) order", which coincides on tie-free input."""
+    if len(scores) == 0:
+        return np.zeros((0,), dtype=np.int64)
+    order = np.argsort(-scores.astype(np.float64), kind='stable')
+    sc = scores[order].astype(np.float32)
+    pos = np.arange(len(order))      # position in the initial order (the tie rule)
+    keep = []
+    while len(order) > 0 and len(keep) < max_dets:
+        i = order[0]
+        ovr = oks_iou(kpts[i], kpts[order[1:]], areas[i], areas[order[1:]])
+        order, pos = order[1:], pos[1:]
+        sc = sc[1:] * np.exp(-ovr ** 2 / thr)
+        assert sc.dtype == np.float32
+        tmp = np.lexsort((pos, -sc.astype(np.float64)))
+        order, pos, sc = order[tmp], pos[tmp], sc[tmp]
+        keep.append(i)
+    return np.array(keep, dtype=np.int64)
+
+
 def decode_single(cls_scores, pose_preds, centernesses, points, scale_factor, J, test_cfg, return_index=False):
     """Per image: lists over levels of (1,h,w), (3+6J,h,w), (1,h,w) eval-mode head outputs."""
     nms_pre = test_cfg.get('nms_pre', -1)
@@ -82,8 +104,12 @@ def decode_single(cls_scores, pose_preds, centernesses, points, scale_factor, J,
     if nms_post > 0 and len(nms_scores) > 0:
         area = (P[..., :2].max(1)[0] - P[..., :2].min(1)[0]).prod(-1)
         kp = torch.cat([P[..., :2], vis[..., None]], -1).reshape(len(P), -1)
-        keep = oks_nms(nms_scores[:, 0].numpy(), kp.numpy(), area.numpy(), test_cfg.get('nms_thr', 0.9))
-        keep = torch.from_numpy(keep[:test_cfg.get('nms_post', 100)])
+        if test_cfg.get('nms_type', 'hard') == 'hard':
+            keep = oks_nms(nms_scores[:, 0].numpy(), kp.numpy(), area.numpy(), test_cfg.get('nms_thr', 0.9))
+            keep = torch.from_numpy(keep[:test_cfg.get('nms_post', 100)])
+        else:
+            keep = torch.from_numpy(soft_oks_nms(nms_scores[:, 0].numpy(), kp.numpy(), area.numpy(),
+                                                 test_cfg.get('nms_thr', 0.9), max_dets=test_cfg.get('nms_post', 100)))
         nms_scores, P, C, vis, I = nms_scores[keep], P[keep], C[keep], vis[keep], I[keep]
     if return_index:
         return nms_scores, P, vis, C, I

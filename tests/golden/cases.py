@@ -124,6 +124,15 @@ def mupots_gts(counts=(2, 3), seed=6):
     return dict(gt_labels_3d=labels, gt_poses_3d=poses, centers2d=c2d, depths=dep)
 
 
+# soft OKS-NMS cases (nms_type != 'hard'): the default threshold, and a low one (strong rescoring: the order of the
+# remaining candidates changes from round to round) with a small cap
+SOFT_DECODE_CFGS = {
+    'a': dict(FULL_TEST_CFG, nms_type='soft'),
+    'b': dict(FULL_TEST_CFG, nms_type='soft', nms_thr=0.05, nms_post=20),
+}
+SOFT_DECODE_INPUTS = {'a': dict(), 'b': dict(seed=91, bias=-3.5)}
+
+
 def full_decode_inputs(seed=21, B=2, Jn=FULL_J, sizes=FULL_SIZES, bias=-4.0):
     """Tie-free random eval-mode head outputs at the full 512x832 level sizes."""
     cls, pose, ctr = [], [], []

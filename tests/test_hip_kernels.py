@@ -311,7 +311,7 @@ def _decode_hip(cls, pose, ctr, sf, J, strides, cfg):
     o = ops()
     out = o.decode([nhwc(c) for c in cls], [nhwc(c) for c in ctr], [nhwc(p) for p in pose], strides,
                    torch.tensor(sf, dtype=torch.float32, device=DEV), J, cfg['nms_pre'], cfg['nms_post'],
-                   cfg['score_thr'], cfg['nms_thr'])
+                   cfg['score_thr'], cfg['nms_thr'], nms_soft=cfg.get('nms_type', 'hard') != 'hard')
     return {k: v.cpu() for k, v in out.items()}
 
 
@@ -341,6 +341,35 @@ def test_decode_full_size_vs_oracle_and_reference_fixture(golden_dir):
     out = _check_decode_vs_oracle(cls, pose, ctr, [(1.3, 1.3), (1.0, 1.0)], cases.FULL_J, cases.FULL_STRIDES,
                                   cases.FULL_TEST_CFG, golden=z)
     assert int(out['count'].min()) > 20
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_decode_soft_nms_vs_oracle_and_reference_fixture(golden_dir, tag):
+    """nms_type='soft' (pose_nms.py:128-194): kept indices bit-exact vs the oracle, values vs the reference fixture."""
+    import os
+    z = np.load(os.path.join(golden_dir, 'decode_soft.npz'))
+    cfg = cases.SOFT_DECODE_CFGS[tag]
+    cls, pose, ctr = cases.full_decode_inputs(**cases.SOFT_DECODE_INPUTS[tag])
+    out = _check_decode_vs_oracle(cls, pose, ctr, [(1.3, 1.3), (1.0, 1.0)], cases.FULL_J, cases.FULL_STRIDES, cfg,
+                                  golden={k[2:]: z[k] for k in z.files if k.startswith(tag + '_')})
+    assert out['count'].tolist() == [cfg['nms_post']] * 2
+
+
+def test_decode_soft_nms_edge_cases():
+    # fewer candidates than nms_post (everything is kept, in rescored order), the nms_pre truncation path, J = 21, none
+    cfg = dict(cases.FULL_TEST_CFG, nms_type='soft', nms_thr=0.2)
+    cls, pose, ctr = cases.full_decode_inputs(seed=5, B=1, bias=-5.0)
+    out = _check_decode_vs_oracle(cls, pose, ctr, [(1.0, 1.0)], cases.FULL_J, cases.FULL_STRIDES, cfg)
+    assert 0 < int(out['count'][0]) < cfg['nms_post']
+    cls, pose, ctr = cases.full_decode_inputs(seed=77, B=1, bias=1.0)
+    _check_decode_vs_oracle(cls, pose, ctr, [(1.0, 1.0)], cases.FULL_J, cases.FULL_STRIDES,
+                            dict(cfg, nms_pre=300, nms_post=50))
+    sizes = [(96, 128), (48, 64), (24, 32), (12, 16)]
+    cls, pose, ctr = cases.full_decode_inputs(seed=6, B=1, Jn=21, sizes=sizes, bias=-4.5)
+    _check_decode_vs_oracle(cls, pose, ctr, [(0.8, 0.8)], 21, cases.FULL_STRIDES, cfg)
+    cls, pose, ctr = cases.full_decode_inputs(seed=78, B=2, bias=-20.0)
+    out = _decode_hip(cls, pose, ctr, [(1.0, 1.0)] * 2, cases.FULL_J, cases.FULL_STRIDES, cfg)
+    assert out['count'].tolist() == [0, 0]
 
 
 def test_decode_topk_truncation_and_empty():

@@ -135,6 +135,28 @@ def test_dashead_decode_vs_reference_fixture(golden_dir):
         assert r['image_paths'] == [metas[b]['filename']]
 
 
+def test_dashead_decode_soft_nms_cfg(golden_dir):
+    """`test_cfg.nms_type='soft'` through the head's own `get_poses` (das_head.py:784-790) against the oracle."""
+    from oracle import decode as od
+    ze = load(golden_dir, 'head_eval')
+    head = build_head().to(DEV).eval()
+    cfg = dict(head.test_cfg, nms_type='soft', nms_thr=0.3, nms_post=12)
+    cls = [torch.from_numpy(ze[f'cls{i}']) + 1.0 for i in range(2)]
+    ctr = [torch.from_numpy(ze[f'ctr{i}']) + 1.0 for i in range(2)]
+    pose = [torch.from_numpy(ze[f'pose{i}']) for i in range(2)]
+    metas = [dict(scale_factor=np.array([1.3, 1.1, 1.3, 1.1], dtype=np.float32), filename='a'),
+             dict(scale_factor=np.array([1., 1., 1., 1.], dtype=np.float32), filename='b')]
+    ref = od.get_poses(cls, pose, ctr, metas, head.num_joints, head.strides, cfg)
+    res = head.get_poses([t.to(DEV) for t in cls], [t.to(DEV) for t in pose], [t.to(DEV) for t in ctr], metas, cfg=cfg)
+    hard = head.get_poses([t.to(DEV) for t in cls], [t.to(DEV) for t in pose], [t.to(DEV) for t in ctr], metas,
+                          cfg=dict(cfg, nms_type='hard'))
+    for r, m, h in zip(ref, res, hard):
+        assert m['poses'].shape == r['poses'].shape and m['poses'].shape[0] > 0
+        np.testing.assert_allclose(np.array(m['scores'], dtype=np.float32), np.array(r['scores'], dtype=np.float32), rtol=1e-6)
+        np.testing.assert_allclose(m['poses'].cpu().numpy(), r['poses'].numpy(), rtol=1e-4, atol=1e-4)
+        assert m['scores'][0] == h['scores'][0]   # both start from the best candidate
+
+
 def tiny_detector_cfg(J=15):
     return dict(
         type='DAS', pretrained=None,

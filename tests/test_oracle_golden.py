@@ -162,6 +162,21 @@ def test_decode_full_size(golden_dir):
     _check_decode(z, res)
 
 
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_decode_soft_nms(golden_dir, tag):
+    """nms_type='soft' (das_head.py:784-790, pose_nms.py:128-194) against the reference's own output."""
+    z = load(golden_dir, 'decode_soft')
+    cls, pose, ctr = cases.full_decode_inputs(**cases.SOFT_DECODE_INPUTS[tag])
+    metas = [dict(scale_factor=np.array([1.3, 1.3, 1.3, 1.3], dtype=np.float32), filename='a'),
+             dict(scale_factor=np.array([1., 1., 1., 1.], dtype=np.float32), filename='b')]
+    res = od.get_poses(cls, pose, ctr, metas, cases.FULL_J, cases.FULL_STRIDES, cases.SOFT_DECODE_CFGS[tag])
+    for b, r in enumerate(res):
+        assert r['poses'].shape[0] == cases.SOFT_DECODE_CFGS[tag]['nms_post']
+        np.testing.assert_array_equal(np.array(r['scores'], dtype=np.float32), z[f'{tag}_scores{b}'])
+        np.testing.assert_allclose(r['poses'].numpy(), z[f'{tag}_poses{b}'], **TOL)
+        np.testing.assert_allclose(r['centers'].numpy(), z[f'{tag}_centers{b}'], **TOL)
+
+
 def test_decode_empty():
     cls, pose, ctr = cases.full_decode_inputs(bias=-20.0)
     metas = [dict(scale_factor=np.ones(4, dtype=np.float32), filename='a')] * 2

@@ -89,3 +89,21 @@ def test_oks_nms_live(R):
         mine = od.oks_nms(scores, kp.reshape(n, -1), areas, thr)
         assert ref.tolist() == mine.tolist()
         assert 0 < len(mine) <= n
+
+
+def test_soft_oks_nms_live(R):
+    """pose_nms.py:128-194 against the restatement: same kept indices in the same order, several thresholds / caps."""
+    from mmdet3d.core.post_processing import pose_nms as ref_nms
+    rs = np.random.RandomState(1)
+    for n, J in ((60, 15), (90, 17), (40, 21)):
+        kp = rs.uniform(0, 200, (n, J, 3)).astype(np.float32)
+        kp[n // 2:] = kp[:n // 2] + rs.normal(0, 3.0, (n - n // 2, J, 3)).astype(np.float32)  # near-duplicates
+        kp[..., 2] = 1
+        scores = rs.uniform(0.1, 1, n).astype(np.float32)
+        areas = (kp[..., 0].max(1) - kp[..., 0].min(1)) * (kp[..., 1].max(1) - kp[..., 1].min(1))
+        db = [dict(score=np.array(scores[i]), keypoints=kp[i], area=np.array(areas[i])) for i in range(n)]
+        for thr, cap in ((0.9, 20), (0.5, 100), (0.1, 7)):
+            ref = ref_nms.soft_oks_nms(db, thr, max_dets=cap)
+            mine = od.soft_oks_nms(scores, kp.reshape(n, -1), areas, thr, max_dets=cap)
+            assert ref.tolist() == mine.tolist()
+            assert len(mine) == min(n, cap)
