@@ -393,13 +393,15 @@ class DASHead(nn.Module):
         out = ops.decode(cls, ctr, pose, self.strides, sf, J, cfg.get('nms_pre', -1), nms_post,
                          cfg.get('score_thr', 0.), cfg.get('nms_thr', 0.9),
                          nms_soft=cfg.get('nms_type', 'hard') != 'hard')   # (das_head.py:784-790)
-        counts = out['count'].cpu().tolist()
+        # ONE device-to-host copy per batch (counts and scores together): a copy per image is a host sync per image
+        host = torch.cat([out['count'].to(f32).unsqueeze(1), out['scores']], 1).cpu().numpy()
+        vis = torch.ones(len(img_metas), nms_post, J, dtype=f32, device=dev)
         results = []
         for b, meta in enumerate(img_metas):
-            K = counts[b]
-            r = {'poses': out['poses'][b, :K], 'vis': torch.ones(K, J, dtype=f32, device=dev),
+            K = int(host[b, 0])
+            r = {'poses': out['poses'][b, :K], 'vis': vis[b, :K],
                  'centers': out['centers'][b, :K], 'image_paths': [meta.get('filename')],
-                 'scores': out['scores'][b, :K].cpu().numpy().tolist()}
+                 'scores': host[b, 1:1 + K].tolist()}
             if return_index:
                 r['index'] = out['index'][b, :K]
             results.append(r)
