@@ -281,7 +281,8 @@ class BottleneckChainFn(Function):
     (same mask, same sums up to f32 summation order)."""
 
     @staticmethod
-    def forward(ctx, x, blocks, *params):
+    def forward(ctx, x, blocks, skip_through, *params):
+        x_in = x
         saved, plan = [x], []
         it = iter(params)
         for blk in blocks:
@@ -306,11 +307,15 @@ class BottleneckChainFn(Function):
             x = y3
         ctx.save_for_backward(*saved, *params)
         ctx.plan, ctx.blocks, ctx.nsaved = plan, blocks, len(saved)
-        return x
+        # skip_through: the layer's input is handed through as a second output (see ConvBNTrainSkipFn): its other
+        # consumers take it from there, and their gradient arrives here as `dskip`, added in a data-gradient epilogue
+        return (x, x_in) if skip_through else x
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         from .nn import bn_stats_buffer, packed_weight_dgrad, packed_weight_dgrad_s2
+        if dskip is not None:
+            dskip = dskip.contiguous()
         saved, params = ctx.saved_tensors[:ctx.nsaved], ctx.saved_tensors[ctx.nsaved:]
         blocks, plan = ctx.blocks, ctx.plan
         grads = [None] * len(params)
@@ -393,8 +398,10 @@ class BottleneckChainFn(Function):
                 wd, gd, bd = params[po + 9:po + 12]
                 drawd, _ = classic_bn(ds.bn, gd, bd, po + 10, dz3, None, rawd, md, idd, False, False)
                 wgrad(ds.conv, po + 9, xin, drawd)
-                dx1 = dgrad(blk.conv1, draw1, xin)
+                dx1 = dgrad(blk.conv1, draw1, xin, residual=dskip if bi == 0 else None)
                 carry_dy, carry_dz = dgrad(ds.conv, drawd, xin, accumulate=dx1), None
+                if bi == 0:
+                    dskip = None
             elif bi > 0:   # xin is the previous block's output: mask by it, reduce for its bn3
                 pent, ppo = plan[bi - 1], offs[bi - 1]
                 praw3, pm3, pi3 = saved[pent['u'] + 8:pent['u'] + 11]
@@ -403,12 +410,15 @@ class BottleneckChainFn(Function):
             else:
                 carry_dy, carry_dz = dgrad(blk.conv1, draw1, xin, residual=dz3), None
         assert carry_dz is None
-        return (carry_dy, None) + tuple(grads)
+        if dskip is not None:   # (first block without a downsample branch: its epilogue's residual slot is taken)
+            carry_dy = carry_dy + dskip
+        return (carry_dy, None, None) + tuple(grads)
 
 
-def bottleneck_chain(x, blocks):
+def bottleneck_chain(x, blocks, skip_through=False):
     """Run a layer of Bottlenecks through BottleneckChainFn if that applies (training, gradients on, plain BatchNorm —
-    SyncBN layers exchange their sums between the two backward phases and keep the per-unit path); else None."""
+    SyncBN layers exchange their sums between the two backward phases and keep the per-unit path); else None.
+    skip_through: returns (y, x) with x routed through the node for its other consumers."""
     blocks = list(blocks)
     bns = []
     for b in blocks:
@@ -427,7 +437,7 @@ def bottleneck_chain(x, blocks):
             params += [b.downsample.conv.weight, b.downsample.bn.weight, b.downsample.bn.bias]
     if not grad_mode(x, *params):
         return None
-    return BottleneckChainFn.apply(x, blocks, *params)
+    return BottleneckChainFn.apply(x, blocks, skip_through, *params)
 
 
 class ConvFn(Function):

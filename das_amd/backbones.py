@@ -83,8 +83,15 @@ class DownsampleModule(nn.Module):
         from . import autograd as ag
         for i in range(self.num_units):
             layer = getattr(self, f'layer{i + 1}')
-            y = ag.bottleneck_chain(x, layer) if FUSED_LAYER_BACKWARD else None
-            x = layer(x) if y is None else y
+            # x (for i > 0) also feeds the upsample module: it is handed THROUGH the layer's autograd node, so that
+            # the gradient of those consumers arrives there and is added in a data-gradient epilogue (no separate add)
+            y = ag.bottleneck_chain(x, layer, skip_through=i > 0) if FUSED_LAYER_BACKWARD else None
+            if y is None:
+                x = layer(x)
+            elif i > 0:
+                x, out[-1] = y
+            else:
+                x = y
             if self.has_skip:
                 x = nnops.add3(x, skip1[i], skip2[i])
             out.append(x)
@@ -109,19 +116,28 @@ class UpsampleUnit(nn.Module):
             self.cross_conv = ConvModule(unit_channels, out_channels, 1, norm_cfg=norm_cfg)
 
     def forward(self, x, up_x):
+        # x and out each feed several convs: all but the last consumer hand the tensor through their autograd node
+        # (conv_bn(skip_through=True)), so the gradients meet in data-gradient epilogues instead of elementwise adds
+        thru = self.gen_skip
         if self.ind > 0:
-            lat = self.in_skip(x)
+            lat = conv_bn(x, self.in_skip.conv, self.in_skip.bn, skip_through=thru)
+            if thru:
+                lat, x = lat
             up = nnops.upsample_bilinear(up_x, x.shape[1], x.shape[2])
             # relu(in_skip(x) + up_conv(up)): add + ReLU fused into up_conv's epilogue
             out = conv_bn(up, self.up_conv.conv, self.up_conv.bn, relu=True, residual=lat)
         else:
-            out = conv_bn(x, self.in_skip.conv, self.in_skip.bn, relu=True)
+            out = conv_bn(x, self.in_skip.conv, self.in_skip.bn, relu=True, skip_through=thru)
+            if thru:
+                out, x = out
         skip1 = skip2 = cross = None
         if self.gen_skip:
             skip1 = self.out_skip1(x)
-            skip2 = self.out_skip2(out)
+            m = self.out_skip2
+            skip2, out = conv_bn(out, m.conv, m.norm, relu=m.with_activation, skip_through=True)
         if self.ind == self.num_units - 1 and self.gen_cross_conv:
-            cross = self.cross_conv(out)
+            m = self.cross_conv
+            cross, out = conv_bn(out, m.conv, m.norm, relu=m.with_activation, skip_through=True)
         return out, skip1, skip2, cross
 
 
