@@ -83,6 +83,7 @@ SIGNATURES = {
     'das_conv2d_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), vp]),
     'das_conv2d_wgrad_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), i32, vp]),
     'das_conv2d_wgrad_batch': (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(DasConvDesc), i32, vp]),
+    'das_wgrad_last_plan': (i32, [C.POINTER(i64), i32]),
     'das_pack_conv_weights': (i32, [vp, vp, vp, i32, vp, i32, i32, vp]),
     'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
     'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),

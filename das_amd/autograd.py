@@ -115,7 +115,7 @@ class _on_side:
 # With the flat optimizer a weight gradient only adds into the flat gradient buffer, so backward queues it and hands
 # WGRAD_BATCH of them at a time to das_conv2d_wgrad_batch: ops of one kernel class then share ONE launch, each on a share
 # of the grid (less split workspace per op — see include/das_hip.h). The queue is flushed when the backward pass ends.
-WGRAD_BATCH = 6      # 1 = launch every weight gradient on its own, as it arises
+WGRAD_BATCH = 32     # 1 = launch every weight gradient on its own, as it arises (at most 64 per launch)
 _pending = []        # [(x, dy, k, k, stride, pad, out, slot)]
 _flush_queued = [False]
 

@@ -9,8 +9,13 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
+#include <string>
 #include <type_traits>
+#include <vector>
 
 #include "conv_common.h"
 #include "tuning.h"
@@ -149,45 +154,53 @@ __device__ __forceinline__ void store_partial_tile(float* ws, int split, int til
       if (MAP::wave_n(wave) + b * 16 < n_left) dst[(a * 4 + b) * 64] = acc[a][b];
   }
 }
-// ---- several weight gradients in ONE launch ----
-// A weight gradient has a small result (Cout x K) and a huge reduction (the pixels), so filling 256 CUs means splitting
-// the pixels, and every split costs a round trip of a partial tile through the workspace: with 256 workgroups on a
-// 1024 x 256 result that round trip moves twice the bytes of the operands. Measured on cold operands
-// (tools/dev/wgrad_blocks_bench.py): a quarter of the grid needs only 1.2-2.2x the time of the full grid. So the
-// launcher takes up to WG_MAXOPS ops of one kernel class at a time — backward defers its weight gradients, which feed
-// nothing but the optimizer — and gives each op a share of the grid in proportion to its work: the ops run side by side
-// inside one launch, each split ~n times less. (Streams do not give this: ops issued at backward's pace rarely meet.)
-constexpr int WG_MAXOPS = 8;
-struct WgradOp {
-  const char* x;
-  const char* dy;
-  float* ws;            // this op's region of the partial-tile workspace [split][tile][slot]
+// ---- many weight gradients in ONE persistent launch, scheduled on the host ----
+// A weight gradient has a small result (Cout x K) and a huge reduction (the pixels). Filling 256 CUs with ONE op means
+// splitting the pixels, and every split costs a round trip of a partial tile through the workspace (with 256 workgroups
+// on a 1024 x 256 result that round trip moves twice the bytes of the operands); sharing a launch between a few ops by
+// grid shares (the previous scheme) leaves whole-number effects: an op with 9 tiles and a share of 14 workgroups runs
+// 9 of them 1.5x longer than planned while the others idle. Backward defers its weight gradients — they feed nothing
+// but the optimizer — so the launcher sees dozens of ops at a time and schedules them like a job shop:
+//   * unit = (op, tile, run of pixel steps). A tile whose whole reduction fits under the per-workgroup quota is ONE
+//     unit: its accumulators go straight into dW, no workspace, no reduction pass. Longer tiles are cut into equal
+//     runs whose partial tiles pass through the workspace (contiguous per tile) and are summed by wgrad_reduce_kernel.
+//   * the grid is one resident wave of workgroups; every workgroup walks a LIST of units (longest first). Lists are
+//     built by longest-processing-time-first packing per XCD: the units of one (op, run) — all (Cout, K) tiles over
+//     the same pixel rows, which share dY and the X rows — go to workgroups of the same XCD (block b runs on XCD
+//     b % 8) with near-equal start times, so the rows are fetched into ONE L2.
+// The schedule depends on the shapes only: it is cached per op-list signature together with its device copy; operand
+// pointers travel in the kernel argument.
+constexpr int WG_MAXOPS = 64;
+struct WgradOpS {        // geometry of one op (device table)
   int H, W, Cin, xps, Ho, Wo, Cout, rps, KH, KW, stride, pad, M, K, HoWo;
   unsigned xbytes;
   int nlev, B;
   int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];
-  int tiles, spb;       // (Cout, K) tiles; pixel steps per workgroup
-  int blk0, nblk;       // first workgroup (a multiple of 8: keeps block % 8 == XCD for xcd_remap) and workgroup count
+  int tiles;
 };
-struct WgradGroup {
-  int n;
-  int blk0[WG_MAXOPS], nblk[WG_MAXOPS];   // (copies of op[i].blk0 / nblk: the pick reads one cache line, not eight)
-  WgradOp op[WG_MAXOPS];
+struct WgradUnit {
+  int op, tile;
+  int step0, nsteps;    // pixel steps [step0, step0 + nsteps) of BKM rows
+  int dest;             // >= 0: partial tile number in the workspace; -1: straight into dW
+  int pad_[3];
 };
-// op of this workgroup. The argument block lives in HOST memory (every first touch of one of its cache lines is a
-// PCIe round trip, ~2 us), so: the block ranges sit together at the front, and the chosen op's record is read through the
-// kernarg segment pointer with a dynamic offset — plain scalar loads of that ONE record. (Indexing the by-value
-// argument dynamically makes the compiler copy all of it to scratch; a select chain over the eight records reads all
-// eight, one dependent round trip after the other: +20 us per launch measured.)
-__device__ __forceinline__ bool wgrad_pick(const WgradGroup& g, int bid, ConvP& p, int& tiles, int& spb, int& local, int& nblk) {
-  int k = -1;
-#pragma unroll
-  for (int i = 0; i < WG_MAXOPS; ++i)
-    if (i < g.n && bid >= g.blk0[i] && bid < g.blk0[i] + g.nblk[i]) k = i;
-  if (k < 0) return false;   // padding workgroup between two ops
+struct WgradPtrs { const char* x; const char* dy; float* dw; };
+struct WgradSched {
+  const WgradUnit* units;
+  const int* first;     // [grid + 1]: units of workgroup b = units[first[b] .. first[b + 1])
+  const WgradOpS* ops;
+  float* ws;
+  int accumulate;
+  WgradPtrs ptr[WG_MAXOPS];
+};
+// The argument block lives in HOST memory (every first touch of one of its cache lines is a PCIe round trip, ~2 us):
+// a workgroup reads the ONE pointer record it needs through the kernarg segment pointer with a dynamic offset.
+// (Indexing the by-value argument dynamically makes the compiler copy all of it to scratch.)
+__device__ __forceinline__ void wgrad_load_unit(const WgradSched& g, const WgradUnit& u, ConvP& p, float*& dw) {
   const char* args = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-  const WgradOp& o = *reinterpret_cast<const WgradOp*>(args + __builtin_offsetof(WgradGroup, op) + (size_t)k * sizeof(WgradOp));
-  p.x = o.x; p.res = o.dy; p.y = reinterpret_cast<char*>(o.ws); p.w = nullptr;
+  const WgradPtrs& pt = *reinterpret_cast<const WgradPtrs*>(args + __builtin_offsetof(WgradSched, ptr) + (size_t)u.op * sizeof(WgradPtrs));
+  const WgradOpS& o = g.ops[u.op];
+  p.x = pt.x; p.res = pt.dy; p.y = nullptr; p.w = nullptr; dw = pt.dw;
   p.scale = p.shift = nullptr; p.stats = nullptr; p.stat_slots = 1;
   p.H = o.H; p.W = o.W; p.Cin = o.Cin; p.xps = o.xps; p.Ho = o.Ho; p.Wo = o.Wo; p.Cout = o.Cout; p.yps = 0;
   p.KH = o.KH; p.KW = o.KW; p.stride = o.stride; p.pad = o.pad; p.relu_in = p.relu = 0; p.rps = o.rps; p.up_sh = 0;
@@ -195,48 +208,88 @@ __device__ __forceinline__ bool wgrad_pick(const WgradGroup& g, int bid, ConvP& 
 #pragma unroll
   for (int l = 0; l < MAXLV; ++l) { p.lvH[l] = o.lvH[l]; p.lvW[l] = o.lvW[l]; p.lvStart[l] = o.lvStart[l]; }
   p.bnb_raw = p.bnb_y = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;
-  tiles = o.tiles; spb = o.spb; nblk = o.nblk;
-  local = bid - o.blk0;
-  return true;
 }
-struct WgradRedOp {
-  const float* ws;
-  float* dw;
-  int tiles, ntiles, splits, Cout, K, accumulate;
+// accumulators of a whole reduction -> dW (row-major Cout x K), same element map as wgrad_reduce_kernel. A wave tile
+// inside the result (the common case, wave-uniform test) runs without per-element tests: the old values of an
+// accumulating store are fetched sixteen at a time (written with early-outs per element the compiler serialises
+// 128 load -> wait -> add -> store round trips per lane); wave tiles that overhang Cout / K take the per-element path.
+template <typename MAP, int TA>
+__device__ __forceinline__ void store_direct_tile(float* dw, int K, int Cout, int o0, int n0, int wave, int lane,
+                                                  int accumulate, const f32x4_t (&acc)[TA][4]) {
+  const int q = lane & 15, g4 = lane >> 4;
+  const int wo = o0 + MAP::wave_o(wave), wn = n0 + MAP::wave_n(wave);
+  if (wo + TA * 16 <= Cout && wn + 64 <= K) {
+    float* base = dw + (size_t)(wo + g4 * 4) * K + wn + q;
+#pragma unroll
+    for (int a = 0; a < TA; ++a) {
+      float* r = base + (size_t)a * 16 * K;
+      constexpr int JB = TA >= 8 ? 4 : 2;   // rows per batch (the 128 x 128 kernel has no registers to spare)
+#pragma unroll
+      for (int j0 = 0; j0 < 4; j0 += JB) {
+        float old[JB][4];
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) old[j][b] = accumulate ? r[(size_t)(j0 + j) * K + b * 16] : 0.f;
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) r[(size_t)(j0 + j) * K + b * 16] = old[j][b] + acc[a][b][j0 + j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < TA; ++a) {
+    const int ob = wo + a * 16 + g4 * 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int n = wn + b * 16 + q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (n < K && ob + j < Cout) {
+          float* d = dw + (size_t)(ob + j) * K + n;
+          *d = accumulate ? *d + acc[a][b][j] : acc[a][b][j];
+        }
+      }
+    }
+  }
+}
+struct WgradRedJob {
+  int op, o0, n0;       // tile origin
+  int base, splits;     // partial tiles base .. base + splits of the workspace
   int groups;           // reduce groups (> 1: atomics into a zeroed / accumulating dW)
-  int blk0, nblk;       // nblk = tiles * (SLOTS / 256) * groups
+  int pad_[2];
 };
-struct WgradRedGroup {
-  int n;
-  int blk0[WG_MAXOPS], nblk[WG_MAXOPS];
-  WgradRedOp op[WG_MAXOPS];
+struct WgradRedArgs {
+  const WgradRedJob* jobs;
+  const WgradOpS* ops;
+  const float* ws;
+  int accumulate;
+  float* dw[WG_MAXOPS];
 };
 
-// grid (tiles * SLOTS / 256, groups): every thread owns one float4 slot of one tile and sums it over the splits
-// of its group; one group writes (or adds to) dW directly, several groups (tiny layers: few tiles, hundreds of
+// grid (SLOTS / 256 * max groups, jobs): every thread owns one float4 slot of one tile and sums it over the splits of
+// its group in a fixed order; one group writes (or adds to) dW directly, several groups (one small result, hundreds of
 // splits) add atomically into a zeroed / accumulating dW.
 template <typename MAP>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradRedGroup g) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradRedArgs g) {
   constexpr int BPT = MAP::SLOTS / 256;
-  int k = -1;
-#pragma unroll
-  for (int i = 0; i < WG_MAXOPS; ++i)
-    if (i < g.n && (int)blockIdx.x >= g.blk0[i] && (int)blockIdx.x < g.blk0[i] + g.nblk[i]) k = i;
-  if (k < 0) return;
+  const WgradRedJob& jb = g.jobs[blockIdx.y];
+  const int grp = blockIdx.x / BPT, bx = blockIdx.x % BPT;
+  if (grp >= jb.groups) return;
   const char* args = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-  const WgradRedOp& o = *reinterpret_cast<const WgradRedOp*>(args + __builtin_offsetof(WgradRedGroup, op) + (size_t)k * sizeof(WgradRedOp));
-  const int local = blockIdx.x - o.blk0;
-  const int per_group = o.tiles * BPT;
-  const int grp = local / per_group, bx = local % per_group;
-  const int tile = bx / BPT, slot = (bx % BPT) * 256 + threadIdx.x;
+  float* dw = *reinterpret_cast<float* const*>(args + __builtin_offsetof(WgradRedArgs, dw) + (size_t)jb.op * sizeof(float*));
+  const int Cout = g.ops[jb.op].Cout, K = g.ops[jb.op].K;
+  const int slot = bx * 256 + threadIdx.x;
   const int lane = slot & 63, b = (slot >> 6) & 3, a = (slot >> 8) % MAP::TA, wave = slot / (MAP::TA * 256);
-  const int o0 = (tile / o.ntiles) * MAP::TILE + MAP::wave_o(wave) + a * 16 + (lane >> 4) * 4;
-  const int n = (tile % o.ntiles) * MAP::TILE + MAP::wave_n(wave) + b * 16 + (lane & 15);
-  if ((tile / o.ntiles) * MAP::TILE + MAP::wave_o(wave) + a * 16 >= o.Cout || n >= o.K) return;
-  const int per = (o.splits + o.groups - 1) / o.groups;
-  const int s0 = grp * per, s1 = min(o.splits, s0 + per);
-  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(o.ws) + (size_t)tile * MAP::SLOTS + slot;
-  const size_t stride = (size_t)o.tiles * MAP::SLOTS;
+  const int o0 = jb.o0 + MAP::wave_o(wave) + a * 16 + (lane >> 4) * 4;
+  const int n = jb.n0 + MAP::wave_n(wave) + b * 16 + (lane & 15);
+  if (jb.o0 + MAP::wave_o(wave) + a * 16 >= Cout || n >= K) return;
+  const int per = (jb.splits + jb.groups - 1) / jb.groups;
+  const int s0 = grp * per, s1 = min(jb.splits, s0 + per);
+  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(g.ws) + (size_t)jb.base * MAP::SLOTS + slot;
+  const size_t stride = MAP::SLOTS;
   f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
   int sp = s0;
   for (; sp + 4 <= s1; sp += 4) {
@@ -247,19 +300,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradRedGroup g) {
   for (; sp < s1; ++sp) sum += src[(size_t)sp * stride];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (o0 + j >= o.Cout) break;
-    float* d = o.dw + (size_t)(o0 + j) * o.K + n;
-    if (o.groups > 1) atomicAdd(d, sum[j]);
-    else *d = o.accumulate ? *d + sum[j] : sum[j];
+    if (o0 + j >= Cout) break;
+    float* d = dw + (size_t)(o0 + j) * K + n;
+    if (jb.groups > 1) atomicAdd(d, sum[j]);
+    else *d = g.accumulate ? *d + sum[j] : sum[j];
   }
 }
 
 // p.x = forward input X, p.res = dY (pixel stride p.rps), p.y = the workspace the partial tiles are stored to.
 template <typename T, int BKM>   // BKM = pixel rows per step
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGroup grp_) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSched sch_) {
+  const int u_end = sch_.first[blockIdx.x + 1];
+  for (int ui = sch_.first[blockIdx.x]; ui < u_end; ++ui) {   // (body indented as the single-unit kernel it grew from)
+  const WgradUnit& un = sch_.units[ui];
   ConvP p;
-  int tiles, steps_per_block, lbid, nblk;
-  if (!wgrad_pick(grp_, blockIdx.x, p, tiles, steps_per_block, lbid, nblk)) return;
+  float* dw;
+  wgrad_load_unit(sch_, un, p, dw);
   constexpr int EPV = Elem<T>::EPV;
   constexpr int ROWB = WG<T>::ROWB, SLOTS = ROWB / 16;
   constexpr int TILE = BKM * ROWB;             // bytes per operand tile
@@ -270,13 +326,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGroup grp_) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = (p.K + 127) / 128;
-  // XCD-aware order: all (Cout, K) tiles of one pixel chunk get consecutive logical ids, i.e. run on the same
-  // XCD at the same time, so the chunk's dY / X rows are fetched into ONE L2 instead of eight
-  const int logical = xcd_remap(lbid, nblk);
-  const int tile = logical % tiles, chunk = logical / tiles;
+  const int tile = un.tile;
   const int o0 = (tile / ntiles) * 128, n0 = (tile % ntiles) * 128;
   const int wave_o0 = (wave >> 1) * 64, wave_n0 = (wave & 1) * 64;
-  const long long m_begin = (long long)chunk * steps_per_block * BKM;
+  const long long m_begin = (long long)un.step0 * BKM;
 
   const T* xg = reinterpret_cast<const T*>(p.x);
   const T* dyg = reinterpret_cast<const T*>(p.res);
@@ -336,13 +389,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGroup grp_) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const long long m_left = (long long)p.M - m_begin;
-  const int nsteps = (int)std::min<long long>(steps_per_block, (m_left + BKM - 1) / BKM);
-  if (nsteps <= 0) {   // (the host sizes the grid so that this does not happen; the reduction reads every split)
-    store_partial_tile<AccMap128>(reinterpret_cast<float*>(p.y), chunk, tiles, tile, wave, lane, p.Cout - o0, p.K - n0,
-                                  acc);
-    return;
-  }
+  const int nsteps = un.nsteps;   // >= 1, inside the tensor (host schedule)
   issue(0);
   __syncthreads();
   const int g4 = lane >> 4, q = lane & 15;
@@ -400,8 +447,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGroup grp_) {
     __syncthreads();
   }
 
-  store_partial_tile<AccMap128>(reinterpret_cast<float*>(p.y), chunk, tiles, tile, wave, lane, p.Cout - o0, p.K - n0,
-                                  acc);
+  if (un.dest >= 0) {
+    store_partial_tile<AccMap128>(sch_.ws, un.dest, 1, 0, wave, lane, p.Cout - o0, p.K - n0, acc);
+  } else {
+    store_direct_tile<AccMap128>(dw, p.K, p.Cout, o0, n0, wave, lane, sch_.accumulate, acc);
+  }
+  }   // next unit (every wave is past the last step's barrier: the LDS buffers are free)
 }
 
 // Ping-pong variant for bf16 with Cout >= 256 and K >= 256: 256 (Cout) x 256 (K columns) tile, 8 waves (2 x 4),
@@ -413,10 +464,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradGroup grp_) {
 // the row pointers, transposing LDS reads of step s into registers) and M (32 MFMAs); waves 4-7 run one
 // interval behind waves 0-3 and wave w / w+4 share a SIMD, so the address walk and the LDS reads of one group
 // hide behind the other group's MFMAs (same scheme as conv_glds4_kernel<PP>).
-__global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WgradGroup grp_) {
+__global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WgradSched sch_) {
+  const int u_end = sch_.first[blockIdx.x + 1];
+  for (int ui = sch_.first[blockIdx.x]; ui < u_end; ++ui) {   // (body indented as the single-unit kernel it grew from)
+  const WgradUnit& un = sch_.units[ui];
   ConvP p;
-  int tiles, steps_per_block, lbid, nblk;
-  if (!wgrad_pick(grp_, blockIdx.x, p, tiles, steps_per_block, lbid, nblk)) return;
+  float* dw;
+  wgrad_load_unit(sch_, un, p, dw);
   using T = bf16_t;
   constexpr int EPV = 8, ROWB = 256, SLOTS = 16, BKM = 32;
   constexpr int SUB = BKM * ROWB;                // 8 KiB: 32 rows x 128 channels
@@ -429,12 +483,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WgradGroup grp_) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
   const int ntiles = (p.K + 255) / 256;
-  const int logical = xcd_remap(lbid, nblk);
-  const int tile = logical % tiles, chunk = logical / tiles;
+  const int tile = un.tile;
   const int o0 = (tile / ntiles) * 256, n0 = (tile % ntiles) * 256;
   // wave tiles: Cout half = wave & 1 (dY sub-tile), K-column quarter = wave >> 1 (X sub-tile wave >> 2)
   const int wave_dsub = wave & 1, wave_xsub = wave >> 2, wave_n0 = ((wave >> 1) & 1) * 64;
-  const long long m_begin = (long long)chunk * steps_per_block * BKM;
+  const long long m_begin = (long long)un.step0 * BKM;
 
   const v4i_t xrs = make_rsrc(p.x, p.xbytes);
   const v4i_t drs = make_rsrc(p.res, (unsigned)(((long long)(p.M - 1) * p.rps + p.Cout) * 2));
@@ -495,13 +548,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WgradGroup grp_) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const long long m_left = (long long)p.M - m_begin;
-  const int nsteps = (int)std::min<long long>(steps_per_block, (m_left + BKM - 1) / BKM);
-  if (nsteps <= 0) {   // (the host sizes the grid so that this does not happen; the reduction reads every split)
-    store_partial_tile<AccMap256>(reinterpret_cast<float*>(p.y), chunk, tiles, tile, wave, lane, p.Cout - o0, p.K - n0,
-                                  acc);
-    return;
-  }
+  const int nsteps = un.nsteps;   // >= 1, inside the tensor (host schedule)
   // each wave has 4 DMAs in flight per staged step
   auto wait_steps = [&](int ahead) {   // ... until at most `ahead` staged steps of this wave are still in flight
     if (ahead >= 2) {
@@ -573,8 +620,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WgradGroup grp_) {
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();   // leading group: match the trailing group's extra interval
 
-  store_partial_tile<AccMap256>(reinterpret_cast<float*>(p.y), chunk, tiles, tile, wave, lane, p.Cout - o0, p.K - n0,
-                                  acc);
+  if (un.dest >= 0) {
+    store_partial_tile<AccMap256>(sch_.ws, un.dest, 1, 0, wave, lane, p.Cout - o0, p.K - n0, acc);
+  } else {
+    store_direct_tile<AccMap256>(dw, p.K, p.Cout, o0, n0, wave, lane, sch_.accumulate, acc);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's counted waits assume only its own DMAs are in flight
+  }   // next unit (both wave groups are past their last interval: every LDS stage is free)
 }
 
 // ------------------------------------------------------------------ column sums (bias gradient)
@@ -833,20 +885,21 @@ static float* wgrad_workspace(hipStream_t s, size_t bytes) {
 
 namespace {
 struct HostWgrad {   // one validated op
-  WgradOp o;
+  WgradOpS o;
+  const char* x;
+  const char* dy;
   float* dw;
-  int accumulate, dtype, cls;   // cls: 0 = bf16 ping-pong 256 x 256, 1 = bf16 128 x 128, 2 = f32 128 x 128
-  long long total_steps;
-  double work;
-  int tile;                     // tile edge
+  int dtype, cls;   // cls: 0 = bf16 ping-pong 256 x 256, 1 = bf16 128 x 128, 2 = f32 128 x 128
+  int tile;         // tile edge
 };
 
-int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate, HostWgrad& h) {
+int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d, HostWgrad& h) {
   if (!x || !dy || !dw || !d) return DAS_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->x_pix_stride % 8 || d->y_pix_stride % 8) return DAS_ERR_ARG;
   if (d->KH < 1 || d->KW < 1 || d->stride < 1 || d->B < 1 || d->in_up > 1) return DAS_ERR_ARG;
   if (d->dtype != DAS_BF16 && d->dtype != DAS_F32) return DAS_ERR_ARG;
-  WgradOp& o = h.o;
+  std::memset(&h.o, 0, sizeof(h.o));   // (the record is part of the schedule cache key: no indeterminate padding)
+  WgradOpS& o = h.o;
   long long M = (long long)d->B * d->Ho * d->Wo;
   o.nlev = d->num_levels;
   o.B = d->B;
@@ -860,13 +913,13 @@ int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d
   }
   for (int l = (o.nlev > 1 ? o.nlev : 0); l < MAXLV; ++l) { o.lvH[l] = 0; o.lvW[l] = 0; o.lvStart[l] = 0x7fffffff; }
   if (M <= 0 || M > 0x7fffff00LL) return DAS_ERR_ARG;   // (the row walker adds a step to a row index in 32 bits)
-  o.x = (const char*)x; o.dy = (const char*)dy; o.ws = nullptr;
+  h.x = (const char*)x; h.dy = (const char*)dy;
   o.H = d->H; o.W = d->W; o.Cin = d->Cin; o.xps = d->x_pix_stride;
   o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.rps = d->y_pix_stride;
   o.KH = d->KH; o.KW = d->KW; o.stride = d->stride; o.pad = d->pad;
   o.M = (int)M; o.K = d->KH * d->KW * d->Cin; o.HoWo = d->Ho * d->Wo;
   o.xbytes = 0;
-  h.dw = dw; h.accumulate = accumulate; h.dtype = d->dtype;
+  h.dw = dw; h.dtype = d->dtype;
   // the ping-pong 256 x 256 kernel for the wide layers (K >= 256, Cout >= 256): -5...19 % with cold operands
   // (tools/dev/wgrad_cold_bench.py)
   const int pp_mink = (int)dastune::get(dastune::WGRAD_PP_MINK);   // 0 = off
@@ -883,73 +936,232 @@ int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d
   h.tile = h.cls == 0 ? 256 : 128;
   const int ntiles = (o.K + h.tile - 1) / h.tile;
   o.tiles = ((d->Cout + h.tile - 1) / h.tile) * ntiles;
-  h.work = (double)M * o.tiles;
   return DAS_OK;
 }
 
-// Launch up to WG_MAXOPS ops of one class side by side: main kernel, then the split reduction.
+// ---- the schedule of one launch (see the comment above WgradSched) ----
+struct WgradPlan {
+  std::vector<WgradUnit> units;
+  std::vector<int> first;          // [grid + 1]
+  std::vector<WgradRedJob> jobs;
+  int grid = 0, partials = 0, max_groups = 1;
+  std::vector<int> zero_ops;       // ops whose dW must be zeroed first (atomic reduce groups into a fresh result)
+  // device copy
+  char* dev = nullptr;
+  size_t off_units = 0, off_first = 0, off_ops = 0, off_jobs = 0;
+};
+
+// Longest-processing-time-first packing of the units onto `grid` workgroups, XCD by XCD. `bkm` pixel rows per step.
+// Cost model (in steps): a unit costs its steps plus a constant for prologue / epilogue; a partial tile costs more
+// (its workspace round trip competes with the operand stream and feeds the reduction pass).
+void wgrad_schedule(const HostWgrad* const* ops, int n, int grid, int bkm, WgradPlan& plan) {
+  constexpr double C_UNIT = 3.0, C_PARTIAL = 10.0;
+  const int nx = grid >= 8 ? 8 : 1;             // XCDs (block b runs on XCD b % 8)
+  std::vector<long long> steps(n);
+  double total = 0;
+  for (int i = 0; i < n; ++i) {
+    steps[i] = ((long long)ops[i]->o.M + bkm - 1) / bkm;
+    total += (double)steps[i] * ops[i]->o.tiles;
+  }
+  struct Group { int op; long long step0; int nsteps; bool partial; };   // the tiles of one op over one run of steps
+  std::vector<Group> best_groups;
+  std::vector<int> best_splits;
+  double best_cost = 1e300;
+  std::vector<double> load_x, load_s;
+  auto pack = [&](const std::vector<Group>& gs, std::vector<std::vector<int>>* lists, std::vector<int>* unit_group,
+                  std::vector<int>* unit_tile) -> double {
+    // order: longest units first
+    std::vector<int> order(gs.size());
+    for (size_t i = 0; i < gs.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gs[a].nsteps > gs[b].nsteps; });
+    load_x.assign(nx, 0.0);
+    load_s.assign(grid, 0.0);
+    for (int gi : order) {
+      const Group& g = gs[gi];
+      const int tiles = ops[g.op]->o.tiles;
+      const double c = g.nsteps + (g.partial ? C_PARTIAL : C_UNIT);
+      // (a result with more tiles than an XCD has workgroups goes to several XCDs, a run of consecutive tiles each:
+      // those share the dY columns of a Cout row of tiles)
+      const int per_x = std::max(1, grid / nx);
+      for (int t0 = 0; t0 < tiles; t0 += per_x) {
+        const int t1 = std::min(tiles, t0 + per_x);
+        int x = 0;
+        for (int k = 1; k < nx; ++k)
+          if (load_x[k] < load_x[x]) x = k;
+        load_x[x] += c * (t1 - t0);
+        for (int t = t0; t < t1; ++t) {
+          int sl = x;                              // least loaded workgroup of this XCD
+          for (int b = x; b < grid; b += nx)
+            if (load_s[b] < load_s[sl]) sl = b;
+          load_s[sl] += c;
+          if (lists) {
+            (*lists)[sl].push_back((int)unit_group->size());
+            unit_group->push_back(gi);
+            unit_tile->push_back(t);
+          }
+        }
+      }
+    }
+    double mk = 0;
+    for (int b = 0; b < grid; ++b) mk = std::max(mk, load_s[b]);
+    return mk;
+  };
+  // candidate cut lengths: a tile longer than alpha x (the per-workgroup quota) is cut into equal runs
+  const double quota = std::max(1.0, total / grid);
+  for (double alpha : {1.0, 0.7, 0.5, 0.35, 0.25}) {
+    const long long lmax = std::max<long long>(8, (long long)(quota * alpha + 0.5));
+    std::vector<Group> gs;
+    std::vector<int> splits(n);
+    double npart = 0;
+    for (int i = 0; i < n; ++i) {
+      long long sp = (steps[i] + lmax - 1) / lmax;
+      const long long spb = (steps[i] + sp - 1) / sp;
+      sp = (steps[i] + spb - 1) / spb;
+      splits[i] = (int)sp;
+      for (long long c = 0; c < sp; ++c)
+        gs.push_back(Group{i, c * spb, (int)std::min<long long>(spb, steps[i] - c * spb), sp > 1});
+      if (sp > 1) npart += (double)sp * ops[i]->o.tiles;
+    }
+    // makespan + the reduction pass (it reads every partial tile once: ~2 steps' worth of chip time per 256 of them)
+    const double cost = pack(gs, nullptr, nullptr, nullptr) + 2.0 * npart / grid;
+    if (cost < best_cost) { best_cost = cost; best_groups = gs; best_splits = splits; }
+  }
+  std::vector<std::vector<int>> lists(grid);
+  std::vector<int> unit_group, unit_tile;
+  pack(best_groups, &lists, &unit_group, &unit_tile);
+  // partial tiles: contiguous per (op, tile)
+  std::vector<int> base(n, -1);
+  plan.partials = 0;
+  plan.jobs.clear();
+  plan.zero_ops.clear();
+  plan.max_groups = 1;
+  for (int i = 0; i < n; ++i) {
+    if (best_splits[i] <= 1) continue;
+    base[i] = plan.partials;
+    const int tile_edge = ops[i]->tile, ntiles = (ops[i]->o.K + tile_edge - 1) / tile_edge;
+    // one small result with hundreds of splits: several reduce groups, each adding atomically
+    const int groups = std::max(1, std::min(best_splits[i] / 8, 256 / std::max(1, ops[i]->o.tiles * 16)));
+    if (groups > 1) plan.zero_ops.push_back(i);
+    plan.max_groups = std::max(plan.max_groups, groups);
+    for (int t = 0; t < ops[i]->o.tiles; ++t) {
+      WgradRedJob jb{};
+      jb.op = i; jb.o0 = (t / ntiles) * tile_edge; jb.n0 = (t % ntiles) * tile_edge;
+      jb.base = plan.partials + t * best_splits[i]; jb.splits = best_splits[i]; jb.groups = groups;
+      plan.jobs.push_back(jb);
+    }
+    plan.partials += ops[i]->o.tiles * best_splits[i];
+  }
+  plan.grid = grid;
+  plan.units.clear();
+  plan.first.assign(grid + 1, 0);
+  for (int b = 0; b < grid; ++b) {
+    plan.first[b] = (int)plan.units.size();
+    for (int ui : lists[b]) {
+      const Group& g = best_groups[unit_group[ui]];
+      WgradUnit u{};
+      u.op = g.op; u.tile = unit_tile[ui]; u.step0 = (int)g.step0; u.nsteps = g.nsteps;
+      if (g.partial) {
+        const long long spb = (steps[g.op] + best_splits[g.op] - 1) / best_splits[g.op];
+        u.dest = base[g.op] + u.tile * best_splits[g.op] + (int)(g.step0 / spb);
+      } else {
+        u.dest = -1;
+      }
+      plan.units.push_back(u);
+    }
+  }
+  plan.first[grid] = (int)plan.units.size();
+}
+
+thread_local long long g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+// schedules by op-list signature (shapes, class, grid): a training step repeats the same few lists
+struct PlanCache {
+  std::mutex mu;
+  std::map<std::string, std::unique_ptr<WgradPlan>> plans;
+};
+PlanCache& plan_cache() {
+  static PlanCache c;
+  return c;
+}
+
+// Launch the ops of one class: main kernel (persistent, one resident wave of workgroups), then the reduction of the
+// tiles that were cut.
 template <typename MAP>
-int wgrad_launch_class(HostWgrad** ops, int n, int cls, hipStream_t s) {
+int wgrad_launch_class(HostWgrad** ops, int n, int cls, int accumulate, hipStream_t s) {
   // pixel rows per step: bf16 plain kernel 32 (32 KiB of LDS per workgroup, three workgroups resident per CU, register
   // bound: more independent DMA -> MFMA chains in flight than two workgroups of 64-row steps, +10...14 % measured)
   const int bkm = cls == 1 && dastune::get(dastune::WGRAD_BKM) == 64 ? 64 : 32;
-  // Grid budget = ONE resident wave of workgroups (ping-pong: 1 per CU; bf16 128 x 128: 3 per CU, a 4th pays only on the
-  // longest reductions; f32: 2 per CU) — a second, partial wave costs a full pass. It is shared by the ops in
-  // proportion to their work; every op keeps at least 8 steps per workgroup.
-  long long budget;
+  // grid = ONE resident wave of workgroups (ping-pong: 1 per CU; bf16 128 x 128: 3 per CU; f32: 2 per CU)
+  long long grid;
   if (cls == 0) {
-    budget = std::max<long long>(1, dastune::get(dastune::WGRAD_PP_BLOCKS));
+    grid = std::max<long long>(1, dastune::get(dastune::WGRAD_PP_BLOCKS));
   } else {
     const long long forced = dastune::get(dastune::WGRAD_BLOCKS);
-    long long maxM = 0;
-    for (int i = 0; i < n; ++i) maxM = std::max<long long>(maxM, ops[i]->o.M);
-    budget = forced > 0 ? forced : (cls == 1 && bkm == 32 ? (maxM >= 262144 ? 1024 : 768) : 512);
+    grid = forced > 0 ? forced : (cls == 1 && bkm == 32 ? 768 : 512);
   }
-  double tot_work = 0;
-  for (int i = 0; i < n; ++i) tot_work += ops[i]->work;
-  WgradGroup g;
-  WgradRedGroup r;
-  g.n = r.n = n;
-  long long blk = 0, rblk = 0;
-  size_t ws_floats = 0;
-  long long splits_of[WG_MAXOPS];
-  for (int i = 0; i < n; ++i) {
-    HostWgrad& h = *ops[i];
-    h.total_steps = ((long long)h.o.M + bkm - 1) / bkm;
-    const long long share = std::max<long long>(h.o.tiles, (long long)(budget * (h.work / tot_work) + 0.5));
-    long long splits = std::max<long long>(1, share / h.o.tiles);
-    long long spb = std::max<long long>(8, (h.total_steps + splits - 1) / splits);
-    splits = (h.total_steps + spb - 1) / spb;
-    splits_of[i] = splits;
-    h.o.spb = (int)spb;
-    h.o.blk0 = (int)blk;
-    h.o.nblk = (int)(splits * h.o.tiles);
-    blk = (blk + h.o.nblk + 7) / 8 * 8;
-    ws_floats += (size_t)splits * h.o.tiles * MAP::SLOTS * 4;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return DAS_ERR_LAUNCH;
+  std::string key;
+  key.reserve(32 + (size_t)n * sizeof(WgradOpS));
+  const int head[4] = {dev, cls, (int)grid, bkm};
+  key.append(reinterpret_cast<const char*>(head), sizeof(head));
+  for (int i = 0; i < n; ++i) key.append(reinterpret_cast<const char*>(&ops[i]->o), sizeof(WgradOpS));
+  WgradPlan* plan = nullptr;
+  {
+    PlanCache& pc = plan_cache();
+    std::lock_guard<std::mutex> lock(pc.mu);
+    auto it = pc.plans.find(key);
+    if (it == pc.plans.end()) {
+      if (pc.plans.size() >= 512) {   // (shape sweeps: drop everything; launches in flight keep running off their copies only
+        if (hipDeviceSynchronize() != hipSuccess) return DAS_ERR_LAUNCH;   //  until they finish, so drain first)
+        for (auto& kv : pc.plans)
+          if (kv.second->dev) (void)hipFree(kv.second->dev);
+        pc.plans.clear();
+      }
+      std::unique_ptr<WgradPlan> np(new WgradPlan);
+      wgrad_schedule(ops, n, (int)grid, bkm, *np);
+      auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+      np->off_units = 0;
+      np->off_first = al(np->units.size() * sizeof(WgradUnit));
+      np->off_ops = np->off_first + al(np->first.size() * sizeof(int));
+      np->off_jobs = np->off_ops + al((size_t)n * sizeof(WgradOpS));
+      const size_t bytes = np->off_jobs + al(np->jobs.size() * sizeof(WgradRedJob)) + 256;
+      std::vector<char> host(bytes, 0);
+      std::memcpy(host.data() + np->off_units, np->units.data(), np->units.size() * sizeof(WgradUnit));
+      std::memcpy(host.data() + np->off_first, np->first.data(), np->first.size() * sizeof(int));
+      for (int i = 0; i < n; ++i) std::memcpy(host.data() + np->off_ops + (size_t)i * sizeof(WgradOpS), &ops[i]->o, sizeof(WgradOpS));
+      if (!np->jobs.empty())
+        std::memcpy(host.data() + np->off_jobs, np->jobs.data(), np->jobs.size() * sizeof(WgradRedJob));
+      if (hipMalloc(reinterpret_cast<void**>(&np->dev), bytes) != hipSuccess) return DAS_ERR_LAUNCH;
+      if (hipMemcpy(np->dev, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return DAS_ERR_LAUNCH;
+      it = pc.plans.emplace(std::move(key), std::move(np)).first;
+    }
+    plan = it->second.get();
   }
-  float* ws = wgrad_workspace(s, ws_floats * sizeof(float));
-  if (!ws) return DAS_ERR_LAUNCH;
-  size_t off = 0;
-  for (int i = 0; i < n; ++i) {
-    HostWgrad& h = *ops[i];
-    h.o.ws = ws + off;
-    off += (size_t)splits_of[i] * h.o.tiles * MAP::SLOTS * 4;
-    g.op[i] = h.o;
-    g.blk0[i] = h.o.blk0; g.nblk[i] = h.o.nblk;
-    WgradRedOp& ro = r.op[i];
-    ro.ws = h.o.ws; ro.dw = h.dw; ro.tiles = h.o.tiles; ro.ntiles = (h.o.K + h.tile - 1) / h.tile;
-    ro.splits = (int)splits_of[i]; ro.Cout = h.o.Cout; ro.K = h.o.K; ro.accumulate = h.accumulate;
-    const int blocks = h.o.tiles * (MAP::SLOTS / 256);
-    // tiny layers have few tiles and hundreds of splits: several reduce groups, each adding atomically
-    ro.groups = (int)std::max<long long>(1, std::min<long long>(splits_of[i] / 4, 512 / blocks));
-    if (ro.groups > 1 && !h.accumulate &&
-        hipMemsetAsync(h.dw, 0, sizeof(float) * (size_t)h.o.Cout * h.o.K, s) != hipSuccess)
-      return DAS_ERR_LAUNCH;
-    ro.blk0 = (int)rblk;
-    ro.nblk = blocks * ro.groups;
-    r.blk0[i] = ro.blk0; r.nblk[i] = ro.nblk;
-    rblk += ro.nblk;
+  {   // das_wgrad_last_plan
+    long long direct = 0, longest = 0;
+    for (const WgradUnit& u : plan->units) direct += u.dest < 0;
+    for (int b = 0; b < plan->grid; ++b) longest = std::max<long long>(longest, plan->first[b + 1] - plan->first[b]);
+    const long long st[8] = {cls, plan->grid, (long long)plan->units.size(), direct, plan->partials, (long long)plan->jobs.size(),
+                             longest, plan->max_groups};
+    std::memcpy(g_last_plan, st, sizeof(st));
   }
+  float* ws = nullptr;
+  if (plan->partials > 0) {
+    ws = wgrad_workspace(s, (size_t)plan->partials * MAP::SLOTS * 4 * sizeof(float));
+    if (!ws) return DAS_ERR_LAUNCH;
+  }
+  WgradSched g;
+  g.units = reinterpret_cast<const WgradUnit*>(plan->dev + plan->off_units);
+  g.first = reinterpret_cast<const int*>(plan->dev + plan->off_first);
+  g.ops = reinterpret_cast<const WgradOpS*>(plan->dev + plan->off_ops);
+  g.ws = ws;
+  g.accumulate = accumulate;
+  for (int i = 0; i < n; ++i) g.ptr[i] = WgradPtrs{ops[i]->x, ops[i]->dy, ops[i]->dw};
+  if (!accumulate)
+    for (int i : plan->zero_ops)
+      if (hipMemsetAsync(ops[i]->dw, 0, sizeof(float) * (size_t)ops[i]->o.Cout * ops[i]->o.K, s) != hipSuccess)
+        return DAS_ERR_LAUNCH;
   if (cls == 0) {
     const size_t sm = 4 * 4 * 32 * 256;
     static bool attr_set = false;
@@ -960,50 +1172,63 @@ int wgrad_launch_class(HostWgrad** ops, int n, int cls, hipStream_t s) {
       attr_set = true;
     }
     dastune::note_kernel("conv_wgrad_pp_kernel");
-    hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3((unsigned)blk), dim3(512), sm, s, g);
+    hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3((unsigned)grid), dim3(512), sm, s, g);
   } else if (cls == 1) {
     dastune::note_kernel("conv_wgrad_kernel");
     const size_t sm = 2 * 2 * (size_t)bkm * 256;
     if (bkm == 32) {
-      hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 32>), dim3((unsigned)blk), dim3(256), sm, s, g);
+      hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 32>), dim3((unsigned)grid), dim3(256), sm, s, g);
     } else {
-      hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), dim3((unsigned)blk), dim3(256), sm, s, g);
+      hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64>), dim3((unsigned)grid), dim3(256), sm, s, g);
     }
   } else {
     dastune::note_kernel("conv_wgrad_kernel");
     const size_t sm = 2 * 2 * 32 * 512;
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, 32>), dim3((unsigned)blk), dim3(256), sm, s, g);
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, 32>), dim3((unsigned)grid), dim3(256), sm, s, g);
   }
   DAS_CHECK_LAUNCH();
-  hipLaunchKernelGGL(wgrad_reduce_kernel<MAP>, dim3((unsigned)rblk), dim3(256), 0, s, r);
-  DAS_CHECK_LAUNCH();
+  if (!plan->jobs.empty()) {
+    WgradRedArgs r;
+    r.jobs = reinterpret_cast<const WgradRedJob*>(plan->dev + plan->off_jobs);
+    r.ops = g.ops;
+    r.ws = ws;
+    r.accumulate = accumulate;
+    for (int i = 0; i < n; ++i) r.dw[i] = ops[i]->dw;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<MAP>, dim3((unsigned)(MAP::SLOTS / 256 * plan->max_groups), (unsigned)plan->jobs.size()),
+                       dim3(256), 0, s, r);
+    DAS_CHECK_LAUNCH();
+  }
   return DAS_OK;
 }
 }  // namespace
 
 extern "C" int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* const* dys, float* const* dws,
                                       const DasConvDesc* descs, int accumulate, void* stream) {
-  if (n < 1 || n > 64 || !xs || !dys || !dws || !descs) return DAS_ERR_ARG;
-  HostWgrad ops[64];
+  if (n < 1 || n > WG_MAXOPS || !xs || !dys || !dws || !descs) return DAS_ERR_ARG;
+  HostWgrad ops[WG_MAXOPS];
   for (int i = 0; i < n; ++i) {
-    const int rc = wgrad_prepare(xs[i], dys[i], dws[i], &descs[i], accumulate, ops[i]);
+    const int rc = wgrad_prepare(xs[i], dys[i], dws[i], &descs[i], ops[i]);
     if (rc != DAS_OK) return rc;
-    for (int j = 0; j < i; ++j)   // two ops adding into one dW inside one launch would race in the reduction
+    for (int j = 0; j < i; ++j)   // two ops adding into one dW inside one launch would race
       if (dws[j] == dws[i]) return DAS_ERR_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
   for (int cls = 0; cls < 3; ++cls) {
     HostWgrad* sel[WG_MAXOPS];
     int k = 0;
-    for (int i = 0; i <= n; ++i) {
-      if (i < n && ops[i].cls == cls) sel[k++] = &ops[i];
-      if (k == WG_MAXOPS || (i == n && k > 0)) {
-        const int rc = cls == 0 ? wgrad_launch_class<AccMap256>(sel, k, cls, s) : wgrad_launch_class<AccMap128>(sel, k, cls, s);
-        if (rc != DAS_OK) return rc;
-        k = 0;
-      }
-    }
+    for (int i = 0; i < n; ++i)
+      if (ops[i].cls == cls) sel[k++] = &ops[i];
+    if (k == 0) continue;
+    const int rc = cls == 0 ? wgrad_launch_class<AccMap256>(sel, k, cls, accumulate, s)
+                            : wgrad_launch_class<AccMap128>(sel, k, cls, accumulate, s);
+    if (rc != DAS_OK) return rc;
   }
+  return DAS_OK;
+}
+
+extern "C" int das_wgrad_last_plan(long long* out, int n) {
+  if (!out || n < 1) return DAS_ERR_ARG;
+  for (int i = 0; i < n; ++i) out[i] = i < 8 ? g_last_plan[i] : 0;
   return DAS_OK;
 }
 

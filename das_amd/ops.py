@@ -45,6 +45,14 @@ def last_kernel():
     return _lib.load().das_last_kernel().decode()
 
 
+def last_wgrad_plan():
+    """Schedule of this thread's last weight-gradient launch (das_wgrad_last_plan): dict of kernel class, grid, units,
+    direct (units stored straight into dW), partial (tiles through the workspace), reduced, longest list, groups."""
+    out = (C.c_longlong * 8)()
+    _lib.check(_lib.load().das_wgrad_last_plan(out, 8), 'das_wgrad_last_plan')
+    return dict(zip(('cls', 'grid', 'units', 'direct', 'partial', 'reduced', 'longest', 'groups'), list(out)))
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -329,9 +337,10 @@ def _wgrad_desc(x, dy, KH, KW, stride, pad):
     return d, 2.0 * rows * Cout * KH * KW * Cin
 
 
-def conv2d_wgrad_batch(items):
+def conv2d_wgrad_batch(items, accumulate=True):
     """items: [(x, dy, KH, KW, stride, pad, out)], out = f32 (Cout,KH,KW,Cin) buffers (distinct) the results are ADDED
-    to. One das_conv2d_wgrad_batch call: ops of one kernel class share a launch (see include/das_hip.h)."""
+    to (accumulate=False: written). One das_conv2d_wgrad_batch call: the ops of one kernel class share a persistent,
+    host-scheduled launch (see include/das_hip.h)."""
     n = len(items)
     if n == 0:
         return
@@ -348,7 +357,8 @@ def conv2d_wgrad_batch(items):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.load().das_conv2d_wgrad_batch(n, xs, dys, dws, descs, 1, _stream()), 'das_conv2d_wgrad_batch')
+    _lib.check(_lib.load().das_conv2d_wgrad_batch(n, xs, dys, dws, descs, 1 if accumulate else 0, _stream()),
+               'das_conv2d_wgrad_batch')
     if PROFILE is not None:
         e1.record()
         dt = 'bf16' if _data(items[0][0]).dtype == torch.bfloat16 else 'float'

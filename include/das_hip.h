@@ -133,14 +133,21 @@ int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d,
  */
 int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate,
                           void* stream);
-/* n (<= 64) weight gradients at once: ops of one kernel class run side by side in ONE launch, each on a share of the
- * grid in proportion to its work, so each is split over fewer workgroups and moves proportionally fewer partial tiles
- * through the split workspace than n separate calls would (a quarter of the grid needs 1.2-2.2x the time of the full
- * grid, not 4x). xs / dys / dws / descs: arrays of n entries with the meaning of das_conv2d_wgrad_nhwc; the dws must
- * be distinct. Backward may defer its weight gradients to collect such batches: nothing but the optimizer reads them
- * (torch autograd runs them inside each conv's backward node; the reference has no counterpart). */
+/* n (<= 64) weight gradients at once: the ops of one kernel class share ONE persistent launch (one resident wave of
+ * workgroups) that the host schedules like a job shop. A (Cout, K) tile whose whole pixel reduction fits under the
+ * per-workgroup quota is one unit: its accumulators go straight into dw (no workspace, no reduction pass); longer
+ * tiles are cut into equal runs whose partial tiles pass through the workspace and a reduction kernel. Every workgroup
+ * walks a list of units, lists are packed longest-first per XCD (the tiles of one op over the same pixel rows share
+ * an L2). The schedule depends on the shapes only and is cached per op list. xs / dys / dws / descs: arrays of n
+ * entries with the meaning of das_conv2d_wgrad_nhwc; the dws must be distinct. Backward may defer its weight
+ * gradients to collect such batches: nothing but the optimizer reads them (torch autograd runs them inside each
+ * conv's backward node; the reference has no counterpart). */
 int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* const* dys, float* const* dws,
                            const DasConvDesc* descs, int accumulate, void* stream);
+/* Schedule of the calling thread's last weight-gradient launch (tests, tuning): out[0..7] = kernel class (0 ping-pong
+ * 256 x 256, 1 bf16 128 x 128, 2 f32), grid, units, units stored straight into dw, partial tiles through the workspace,
+ * reduced tiles, longest unit list of a workgroup, reduce groups. */
+int das_wgrad_last_plan(long long* out, int n);
 /* out f32[C] (zeroed by the call) = column sums of x (rows, C) — bias gradients. */
 int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream);
 /* Train-mode BatchNorm (+ReLU, + residual) backward. dZ = dY * (y > 0) when relu; with y == NULL (allowed

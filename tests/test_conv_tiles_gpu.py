@@ -472,6 +472,61 @@ def test_wgrad_batch_equals_single_launches():
         o.conv2d_wgrad_batch([items[0], items[0]])
 
 
+def test_wgrad_schedule_direct_units():
+    """A launch with more tiles than workgroups: the host schedule gives most tiles their whole pixel reduction as ONE
+    unit whose accumulators go straight into dW (no workspace, no reduction pass), several units per workgroup.
+    Checked against F.conv2d's weight gradient (CPU), written (accumulate = 0) and added (accumulate = 1)."""
+    o = ops()
+    specs = [(4, 16, 26, 512, 2048, 1, 1, 0), (4, 16, 26, 2048, 512, 1, 1, 0), (4, 16, 26, 512, 512, 3, 1, 1),
+             (4, 16, 26, 2048, 2048, 1, 1, 0), (4, 32, 52, 256, 1024, 1, 1, 0), (4, 32, 52, 1024, 256, 1, 1, 0),
+             (4, 32, 52, 256, 256, 3, 1, 1), (4, 16, 26, 1024, 2048, 1, 2, 0), (4, 16, 26, 512, 2040, 1, 1, 0)]
+    items, refs = [], []
+    torch.set_num_threads(8)
+    for i, (B, H, W, Cin, Cout, k, s, p) in enumerate(specs):
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        x = cases.randn(301 + i, B, Cin, H, W)
+        dy = cases.randn(331 + i, B, Cout, Ho, Wo) / (B * Ho * Wo) ** 0.5
+        w0 = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+        F.conv2d(q(x), w0, None, s, p).backward(q(dy))
+        refs.append(w0.grad.permute(0, 2, 3, 1))
+        items.append((nhwc(x), nhwc(dy), k, k, s, p, torch.full((Cout, k, k, Cin), 7.0, device=DEV)))
+    with o.tuning(**{'wgrad.pp_blocks': 32}):                    # 197 tiles on 32 workgroups (a step's deferred ops have
+        o.conv2d_wgrad_batch(items, accumulate=False)            # that ratio on 256)
+        plan = o.last_wgrad_plan()
+        assert o.last_kernel() == 'conv_wgrad_pp_kernel' and plan['cls'] == 0 and plan['grid'] == 32
+        assert plan['longest'] >= 4 and plan['direct'] >= 0.9 * plan['units'], plan   # (the longest tiles may be cut)
+        for it, ref in zip(items, refs):
+            np.testing.assert_allclose(it[6].cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+        first = [it[6].clone() for it in items]
+        o.conv2d_wgrad_batch(items)                              # same shapes: cached schedule, added this time
+        for it, f in zip(items, first):
+            np.testing.assert_allclose(it[6].cpu().numpy(), 2 * f.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    o.conv2d_wgrad_batch(items, accumulate=False)                # full grid: most tiles cut in two, same result
+    plan = o.last_wgrad_plan()
+    assert plan['grid'] == 256 and plan['partial'] > 0, plan
+    for it, ref in zip(items, refs):
+        np.testing.assert_allclose(it[6].cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+
+
+def test_wgrad_schedule_cut_tile_atomic_groups():
+    """One small result with a long reduction alone in a launch: the tile is cut into hundreds of runs, the reduction
+    pass sums them in several groups that add atomically (into a zeroed dW when accumulate = 0)."""
+    o = ops()
+    B, H, W, Cin, Cout = 4, 128, 208, 64, 64
+    x, dy = cases.randn(361, B, Cin, H, W), cases.randn(362, B, Cout, H, W) / (B * H * W) ** 0.5
+    torch.set_num_threads(8)
+    w0 = torch.zeros(Cout, Cin, 1, 1, requires_grad=True)
+    F.conv2d(q(x), w0, None, 1, 0).backward(q(dy))
+    ref = w0.grad.permute(0, 2, 3, 1)
+    out = torch.full((Cout, 1, 1, Cin), 3.0, device=DEV)
+    o.conv2d_wgrad_batch([(nhwc(x), nhwc(dy), 1, 1, 1, 0, out)], accumulate=False)
+    plan = o.last_wgrad_plan()
+    assert plan['cls'] == 1 and plan['direct'] == 0 and plan['partial'] >= 64 and plan['groups'] > 1, plan
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    o.conv2d_wgrad_batch([(nhwc(x), nhwc(dy), 1, 1, 1, 0, out)])
+    np.testing.assert_allclose(out.cpu().numpy(), 2 * ref.numpy(), rtol=2e-3, atol=4e-3 * float(ref.abs().max()))
+
+
 def test_tuning_api_rejects_unknown_key():
     from das_amd import _lib
     lib = _lib.load()
