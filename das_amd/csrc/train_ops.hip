@@ -955,7 +955,7 @@ struct WgradPlan {
 // Cost model (in steps): a unit costs its steps plus a constant for prologue / epilogue; a partial tile costs more
 // (its workspace round trip competes with the operand stream and feeds the reduction pass).
 void wgrad_schedule(const HostWgrad* const* ops, int n, int grid, int bkm, WgradPlan& plan) {
-  constexpr double C_UNIT = 3.0, C_PARTIAL = 10.0;
+  constexpr double C_UNIT = 8.0, C_PARTIAL = 10.0;   // (a 256 KiB tile stored, or read-modified-written, per unit)
   const int nx = grid >= 8 ? 8 : 1;             // XCDs (block b runs on XCD b % 8)
   std::vector<long long> steps(n);
   double total = 0;
@@ -990,9 +990,12 @@ void wgrad_schedule(const HostWgrad* const* ops, int n, int grid, int bkm, Wgrad
           if (load_x[k] < load_x[x]) x = k;
         load_x[x] += c * (t1 - t0);
         for (int t = t0; t < t1; ++t) {
-          int sl = x;                              // least loaded workgroup of this XCD
+          int sl = x, sg = 0;                      // least loaded workgroup of this XCD / of the chip
           for (int b = x; b < grid; b += nx)
             if (load_s[b] < load_s[sl]) sl = b;
+          for (int b = 1; b < grid; ++b)
+            if (load_s[b] < load_s[sg]) sg = b;
+          if (load_s[sl] > load_s[sg] + 0.5 * c) sl = sg;   // (balance first: the XCD is a preference)
           load_s[sl] += c;
           if (lists) {
             (*lists)[sl].push_back((int)unit_group->size());
@@ -1006,10 +1009,31 @@ void wgrad_schedule(const HostWgrad* const* ops, int n, int grid, int bkm, Wgrad
     for (int b = 0; b < grid; ++b) mk = std::max(mk, load_s[b]);
     return mk;
   };
-  // candidate cut lengths: a tile longer than alpha x (the per-workgroup quota) is cut into equal runs
+  // candidate cut lengths lmax (a tile longer than lmax steps is cut into equal runs): fractions of the per-workgroup
+  // quota, and for r = 1, 2, ... rounds the shortest lmax whose units still fit r per workgroup (a launch of 261
+  // units on 256 workgroups takes two rounds: whole-number effects decide small launches)
+  auto units_at = [&](long long lmax) {
+    long long u = 0;
+    for (int i = 0; i < n; ++i) u += (long long)ops[i]->o.tiles * ((steps[i] + lmax - 1) / lmax);
+    return u;
+  };
   const double quota = std::max(1.0, total / grid);
-  for (double alpha : {1.0, 0.7, 0.5, 0.35, 0.25}) {
-    const long long lmax = std::max<long long>(8, (long long)(quota * alpha + 0.5));
+  long long max_steps = 8;
+  for (int i = 0; i < n; ++i) max_steps = std::max(max_steps, steps[i]);
+  std::vector<long long> cands;
+  for (double alpha : {1.0, 0.7, 0.5, 0.35, 0.25}) cands.push_back(std::max<long long>(8, (long long)(quota * alpha + 0.5)));
+  for (int r : {1, 2, 3, 4, 6, 8}) {
+    long long lo = 8, hi = max_steps;          // smallest lmax in [8, max_steps] with units_at(lmax) <= r * grid
+    if (units_at(hi) > (long long)r * grid) continue;
+    while (lo < hi) {
+      const long long mid = (lo + hi) / 2;
+      if (units_at(mid) <= (long long)r * grid) hi = mid; else lo = mid + 1;
+    }
+    cands.push_back(lo);
+  }
+  std::sort(cands.begin(), cands.end());
+  cands.erase(std::unique(cands.begin(), cands.end()), cands.end());
+  for (long long lmax : cands) {
     std::vector<Group> gs;
     std::vector<int> splits(n);
     double npart = 0;
@@ -1022,8 +1046,8 @@ void wgrad_schedule(const HostWgrad* const* ops, int n, int grid, int bkm, Wgrad
         gs.push_back(Group{i, c * spb, (int)std::min<long long>(spb, steps[i] - c * spb), sp > 1});
       if (sp > 1) npart += (double)sp * ops[i]->o.tiles;
     }
-    // makespan + the reduction pass (it reads every partial tile once: ~2 steps' worth of chip time per 256 of them)
-    const double cost = pack(gs, nullptr, nullptr, nullptr) + 2.0 * npart / grid;
+    // makespan + the reduction pass (a launch, and every partial tile read once: ~10 steps of chip time per `grid`)
+    const double cost = pack(gs, nullptr, nullptr, nullptr) + (npart > 0 ? 4.0 + 10.0 * npart / grid : 0.0);
     if (cost < best_cost) { best_cost = cost; best_groups = gs; best_splits = splits; }
   }
   std::vector<std::vector<int>> lists(grid);
