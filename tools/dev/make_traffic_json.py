@@ -37,7 +37,7 @@ def main(d, out):
     fam['conv_wgrad_kernel<bf16>'] = dict(train=dict(
         fetch_mb=round(f, 2), write_mb=round(w, 2), hbm_mb_per_launch=round(f + w, 2), ops=WGRAD_OPS,
         source=PASSES + ' over tools/dev/wgrad_mix.py: the 279 weight-gradient ops of one train step (B=16) replayed in '
-                        'the 50 batches backward issues them in; conv_wgrad_pp_kernel + conv_wgrad_kernel + '
+                        'the 13 launches (<= 32 deferred ops each) backward issues them in; conv_wgrad_pp_kernel + conv_wgrad_kernel + '
                         'wgrad_reduce_kernel bytes per op (algorithmic 123.66 MB per op)'))
     src_mix = PASSES + (' over tools/dev/conv_mix.py: the conv shapes (forward + data-gradient) of the train step with '
                         'their per-step counts, B=16')

@@ -1,5 +1,5 @@
 """Dev tool: the weight gradients of one training bench step (B=16), replayed batch by batch as backward hands them to
-das_conv2d_wgrad_batch (tools/dev/wgrad_batches.json, recorded by tools/dev/dump_wgrad_batches.py: 50 batches, 279 ops;
+das_conv2d_wgrad_batch (tools/dev/wgrad_batches.json, recorded by tools/dev/dump_wgrad_batches.py: 13 batches of <= 32 deferred ops, 279 ops;
 the DCNv2 GEMM weight gradients go out alone) on random operands. Run under `rocprofv3 --pmc ...` (one counter set per
 pass) for the HBM traffic / MFMA counters of conv_wgrad_kernel + conv_wgrad_pp_kernel + wgrad_reduce_kernel per op
 behind bench.py's roofline.traffic, or bare for a time per step."""
