@@ -10,7 +10,10 @@ Inputs are resident in HBM when the timed region starts. N>1: one process per GP
 per-rank batches (weak scaling); training exchanges gradients with RCCL all-reduce, inference has no collective.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     — dominant kernel family, algorithmic FLOPs / HIP-event time measured on the launch stream
+  roofline     — the kernel family carrying the most algorithmic FLOPs, FLOPs / HIP-event time measured on the launch
+                 stream against the dense MFMA peak (+ PMC traffic per launch from profiles/traffic.json)
+  roofline_hbm — the largest HBM-bound family beside it (launch mix below the ridge), algorithmic bytes / time against
+                 the HBM peak
   cpu_baseline — the CPU oracle (oracle/, "port") timed on this host on a bounded sample (N=1 only)
 """
 import argparse
@@ -28,6 +31,7 @@ if ROOT not in sys.path:
 
 H, W, J = 512, 832, 15
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E, same guide
 PEAK_F32_TFLOPS = 157.3
 # conv MACs x 2 per image at 512x832, J=15
 FWD_GFLOP = {1: 227.0, 2: 326.9, 3: 426.8, 4: 526.7}
@@ -220,21 +224,40 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
     fam = {}
     for ent in ops.PROFILE:
         tag, flops, e0, e1 = ent[:4]
-        f = fam.setdefault(tag, [0.0, 0.0, 0])
+        f = fam.setdefault(tag, [0.0, 0.0, 0, 0.0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += ent[5] if len(ent) > 5 else 1     # (a batched weight-gradient launch counts its ops)
+        f[3] += ent[6] if len(ent) > 6 else 0.0   # algorithmic bytes: every operand once
     ops.PROFILE = None
     if not fam:
-        return None
+        return None, None
     peak = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
-    tag, (fl, sec, cnt) = max(fam.items(), key=lambda kv: kv[1][1])
+    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)    # FLOP per byte above which a launch mix is matrix-core bound
+    # `roofline`: the family that carries the most algorithmic FLOPs (training: the weight gradient, a third of the
+    # step's FLOPs — the kernel family the reviews track), against the dense MFMA peak.
+    tag, (fl, sec, cnt, by) = max(fam.items(), key=lambda kv: kv[1][0])
     ach = fl / sec / 1e12
-    return dict(bound='mfma', kernel=tag, achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+    roof = dict(bound='mfma', kernel=tag, achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
                 traffic=None, launches_per_step=cnt // reps, avg_launch_us=round(sec / cnt * 1e6, 2),
                 family_ms_per_step=round(sec / reps * 1e3, 3),
-                all_families={k: dict(tflops=round(v[0] / v[1] / 1e12, 2), ms_per_step=round(v[1] / reps * 1e3, 3),
-                                      launches=v[2] // reps) for k, v in fam.items()})
+                algorithmic_mb_per_launch=round(by / cnt / 1e6, 2),
+                all_families={k: dict(tflops=round(v[0] / v[1] / 1e12, 2), gbs=round(v[3] / v[1] / 1e9, 1),
+                                      flop_per_byte=round(v[0] / max(v[3], 1.0), 1),
+                                      ms_per_step=round(v[1] / reps * 1e3, 3), launches=v[2] // reps)
+                              for k, v in fam.items()})
+    # `roofline_hbm`: the family with the largest time among the others whose launch mix sits below the ridge
+    # (training: the persistent 1x1 kernel of the expand / reduce convs), against the HBM peak.
+    below = {k: v for k, v in fam.items() if k != tag and v[3] > 0 and v[0] / v[3] < ridge}
+    roof_hbm = None
+    if below:
+        t2, (fl2, sec2, cnt2, by2) = max(below.items(), key=lambda kv: kv[1][1])
+        gbs = by2 / sec2 / 1e9
+        roof_hbm = dict(bound='hbm', kernel=t2, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                        frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=cnt2 // reps,
+                        avg_launch_us=round(sec2 / cnt2 * 1e6, 2), family_ms_per_step=round(sec2 / reps * 1e3, 3),
+                        algorithmic_mb_per_launch=round(by2 / cnt2 / 1e6, 2), flop_per_byte=round(fl2 / by2, 1))
+    return roof, roof_hbm
 
 
 def attach_traffic(roof, workload, batch):
@@ -513,9 +536,10 @@ def main():
     else:
         extra['poses_per_step_rank0'] = sum(len(r['scores']) for r in res)
 
-    roof = roofline_from_profile(ops, step, args.dtype)
-    if roof is not None:
-        attach_traffic(roof, 'train' if train else 'infer', batch)
+    roof, roof_hbm = roofline_from_profile(ops, step, args.dtype)
+    for r in (roof, roof_hbm):
+        if r is not None:
+            attach_traffic(r, 'train' if train else 'infer', batch)
 
     if rank == 0:
         total_imgs = batch * world * steps
@@ -534,6 +558,8 @@ def main():
             'model_tflops': round(total_imgs * gflop / dt / 1e3, 2),
             'roofline': roof,
         }
+        if roof_hbm is not None:
+            out['roofline_hbm'] = roof_hbm
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload, full=args.cpu_baseline_full, threads=args.cpu_threads)

@@ -312,7 +312,8 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad, out=None, accumulate=False):
         e1.record()
         rows = x.rows if ragged else B * Ho * Wo
         tag = f'conv_wgrad_kernel<{"bf16" if xd.dtype == torch.bfloat16 else "float"}>'
-        PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1, (B, H, W, Cin, Cout, KH, stride, 0)))
+        nby = (xd.numel() + dyd.numel()) * xd.element_size() + dw.numel() * 4
+        PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1, (B, H, W, Cin, Cout, KH, stride, 0), 1, float(nby)))
     return dw
 
 
@@ -346,7 +347,7 @@ def conv2d_wgrad_batch(items, accumulate=True):
         return
     descs = (_lib.DasConvDesc * n)()
     xs, dys, dws = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
-    flops = 0.0
+    flops, nby = 0.0, 0.0
     for i, (x, dy, KH, KW, stride, pad, out) in enumerate(items):
         _need_gpu(x, dy, out)
         d, fl = _wgrad_desc(x, dy, KH, KW, stride, pad)
@@ -354,6 +355,7 @@ def conv2d_wgrad_batch(items, accumulate=True):
         descs[i] = d
         xs[i], dys[i], dws[i] = _data(x).data_ptr(), _data(dy).data_ptr(), out.data_ptr()
         flops += fl
+        nby += (_data(x).numel() + _data(dy).numel()) * _data(x).element_size() + out.numel() * 4
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -362,7 +364,7 @@ def conv2d_wgrad_batch(items, accumulate=True):
     if PROFILE is not None:
         e1.record()
         dt = 'bf16' if _data(items[0][0]).dtype == torch.bfloat16 else 'float'
-        PROFILE.append((f'conv_wgrad_kernel<{dt}>', flops, e0, e1, ('batch', n), n))
+        PROFILE.append((f'conv_wgrad_kernel<{dt}>', flops, e0, e1, ('batch', n), n, nby))
 
 
 def colsum(x):
@@ -501,8 +503,14 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
     if PROFILE is not None:
         e1.record()
         tag = last_kernel()   # the kernel the launcher picked (das_last_kernel): equals the rocprof kernel family
+        # algorithmic bytes: every operand once (x, weights, y, + residual, + the BatchNorm-backward operands)
+        eo = od.element_size()
+        nby = xd.numel() * xd.element_size() + Cout * KH * KW * Cin * xd.element_size() + rows * Cout * eo
+        nby += rows * Cout * eo if rd is not None else 0
+        if bn_bwd is not None:
+            nby += rows * Cout * eo * (2 if bn_bwd.y is not None else 1)
         PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1,
-                        (B, H, W, Cin, Cout, KH, stride, len(x.sizes) if ragged else 1)))
+                        (B, H, W, Cin, Cout, KH, stride, len(x.sizes) if ragged else 1), 1, float(nby)))
     return out
 
 

@@ -17,7 +17,7 @@ for _ in range(R):
     model(img, metas, return_loss=False)
 torch.cuda.synchronize()
 agg = {}
-for tag, fl, e0, e1, shape in ops.PROFILE:
+for tag, fl, e0, e1, shape in [e[:5] for e in ops.PROFILE]:
     a = agg.setdefault((tag, shape), [0.0, 0.0, 0])
     a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
 tot = sum(a[1] for a in agg.values())
