@@ -69,6 +69,13 @@ def test_bench_self_launches_two_ranks():
         line = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
         assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0, line
         assert line['config']['parallelism'] in ('dp2', 'replicas2')
+        for key in ('roofline', 'roofline_hbm'):    # the measurement objects of the contract (roofline_hbm: conv workloads)
+            r = line.get(key)
+            if key == 'roofline_hbm' and wl == 'decode':
+                continue
+            assert r is not None, (wl, key)
+            assert r['bound'] in ('hbm', 'mfma') and r['unit'] == ('GB/s' if r['bound'] == 'hbm' else 'TFLOP/s')
+            assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 'traffic' in r
 
 
 def test_test_cli_on_a_real_dataset_class_with_pipeline_and_evaluator(tmp_path):
