@@ -7,6 +7,7 @@
 //                         fragments are single dwords, so no transpose is needed.
 //   BatchNorm (train) backward, GroupNorm backward, column sums (bias gradients).
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1097,6 +1098,7 @@ void wgrad_schedule(const HostWgrad* const* ops, int n, int grid, int bkm, Wgrad
 }
 
 thread_local long long g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+std::atomic<long long> g_plan_misses{0};   // schedules built so far (process-wide): a steady training loop stops adding to it
 
 // schedules by op-list signature (shapes, class, grid): a training step repeats the same few lists
 struct PlanCache {
@@ -1142,6 +1144,7 @@ int wgrad_launch_class(HostWgrad** ops, int n, int cls, int accumulate, hipStrea
           if (kv.second->dev) (void)hipFree(kv.second->dev);
         pc.plans.clear();
       }
+      g_plan_misses.fetch_add(1, std::memory_order_relaxed);
       std::unique_ptr<WgradPlan> np(new WgradPlan);
       wgrad_schedule(ops, n, (int)grid, bkm, *np);
       auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -1252,7 +1255,7 @@ extern "C" int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* 
 
 extern "C" int das_wgrad_last_plan(long long* out, int n) {
   if (!out || n < 1) return DAS_ERR_ARG;
-  for (int i = 0; i < n; ++i) out[i] = i < 8 ? g_last_plan[i] : 0;
+  for (int i = 0; i < n; ++i) out[i] = i < 8 ? g_last_plan[i] : (i == 8 ? g_plan_misses.load(std::memory_order_relaxed) : 0);
   return DAS_OK;
 }
 

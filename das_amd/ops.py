@@ -48,9 +48,9 @@ def last_kernel():
 def last_wgrad_plan():
     """Schedule of this thread's last weight-gradient launch (das_wgrad_last_plan): dict of kernel class, grid, units,
     direct (units stored straight into dW), partial (tiles through the workspace), reduced, longest list, groups."""
-    out = (C.c_longlong * 8)()
-    _lib.check(_lib.load().das_wgrad_last_plan(out, 8), 'das_wgrad_last_plan')
-    return dict(zip(('cls', 'grid', 'units', 'direct', 'partial', 'reduced', 'longest', 'groups'), list(out)))
+    out = (C.c_longlong * 9)()
+    _lib.check(_lib.load().das_wgrad_last_plan(out, 9), 'das_wgrad_last_plan')
+    return dict(zip(('cls', 'grid', 'units', 'direct', 'partial', 'reduced', 'longest', 'groups', 'schedules_built'), list(out)))
 
 
 def _stream():

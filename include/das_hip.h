@@ -146,7 +146,8 @@ int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* const* dys,
                            const DasConvDesc* descs, int accumulate, void* stream);
 /* Schedule of the calling thread's last weight-gradient launch (tests, tuning): out[0..7] = kernel class (0 ping-pong
  * 256 x 256, 1 bf16 128 x 128, 2 f32), grid, units, units stored straight into dw, partial tiles through the workspace,
- * reduced tiles, longest unit list of a workgroup, reduce groups. */
+ * reduced tiles, longest unit list of a workgroup, reduce groups; out[8] = schedules built by this process so far (a
+ * steady training loop stops adding to it: schedules are cached per op list). */
 int das_wgrad_last_plan(long long* out, int n);
 /* out f32[C] (zeroed by the call) = column sums of x (rows, C) — bias gradients. */
 int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream);

@@ -24,4 +24,9 @@ for i in range(n):
     train_iteration(model, opt, data, 2e-3)
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t) * 1e3)
+    if i in (2, 5):
+        from das_amd import ops as _o
+        print('after step', i, 'schedules built', _o.last_wgrad_plan()['schedules_built'])
 print(' '.join(f'{v:.1f}' for v in ts))
+from das_amd import ops
+print('schedules built', ops.last_wgrad_plan()['schedules_built'])
