@@ -23,6 +23,17 @@ def _side_stream(device):
     return _SIDE[key]
 
 
+class LazyLogVars:
+    """The step's log variables still on the device (names + one stacked tensor, already averaged over the ranks);
+    `resolve()` copies them to the host once and returns the OrderedDict of floats `_parse_losses` returns eagerly."""
+
+    def __init__(self, names, vals):
+        self.names, self.vals = names, vals
+
+    def resolve(self):
+        return OrderedDict(zip(self.names, self.vals.tolist()))
+
+
 @DETECTORS.register_module()
 class DAS(nn.Module):
     def __init__(self, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None):
@@ -111,8 +122,10 @@ class DAS(nn.Module):
             return self.forward_test(img, img_metas, **kwargs)
 
     @staticmethod
-    def _parse_losses(losses):
-        """Sum of every entry whose key contains 'loss'; log vars averaged over ranks."""
+    def _parse_losses(losses, lazy=False):
+        """Sum of every entry whose key contains 'loss'; log vars averaged over ranks.
+        lazy: log_vars come back as a LazyLogVars — the device-to-host copy (a host synchronisation that drains the
+        launch queue in the middle of the step, right before backward has to be queued) happens when it is resolved."""
         log_vars = OrderedDict()
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):
@@ -128,13 +141,15 @@ class DAS(nn.Module):
         vals = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(vals.div_(dist.get_world_size()))
+        if lazy:
+            return loss, LazyLogVars(list(log_vars), vals)
         for name, v in zip(list(log_vars), vals.tolist()):
             log_vars[name] = v
         return loss, log_vars
 
-    def train_step(self, data, optimizer=None):
+    def train_step(self, data, optimizer=None, lazy_log=False):
         losses = self(**data)
-        loss, log_vars = self._parse_losses(losses)
+        loss, log_vars = self._parse_losses(losses, lazy=lazy_log)
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
 
     def val_step(self, data, optimizer=None):

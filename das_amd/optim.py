@@ -374,8 +374,13 @@ def train_iteration(model, optimizer, data, lr):
     """One optimisation step: forward + losses + backward (HIP kernels under autograd), gradient
     all-reduce over RCCL, fused clip + SGD. Returns the detector's `train_step` dict."""
     optimizer.zero_grad()
-    out = model.train_step(data, None)
+    # the log variables stay on the device until the whole step has been queued: read back right after the forward
+    # pass (as mmdet's `_parse_losses` does) they drain the launch queue, and backward then starts from an empty one
+    lazy = 'lazy_log' in getattr(getattr(model.train_step, '__code__', None), 'co_varnames', ())
+    out = model.train_step(data, None, lazy_log=True) if lazy else model.train_step(data, None)
     out['loss'].backward()
     optimizer.all_reduce_grads()
     optimizer.step(lr)
+    if hasattr(out['log_vars'], 'resolve'):
+        out['log_vars'] = out['log_vars'].resolve()
     return out
