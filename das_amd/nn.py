@@ -8,7 +8,6 @@ NHWC/K-contiguous layout the HIP kernels want (cache keyed on parameter version)
 libdas_hip.so through `das_amd.ops`.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -202,8 +201,8 @@ def zeroed_stats(n, device):
     return _STATS_ARENA.take(n, device)[:n]
 
 
-_SLOT_ROWS = int(os.environ.get('DAS_DEV_STAT_SLOT_ROWS', 16384))   # tuning only
-_WIDE_SLOT_ROWS = int(os.environ.get('DAS_DEV_STAT_WIDE_SLOT_ROWS', 262144))   # tuning only
+_SLOT_ROWS = 16384          # rows from which the statistics of a conv epilogue are spread over 16 slots
+_WIDE_SLOT_ROWS = 262144    # ... and over 64 slots on the layers with <= 128 output channels
 
 
 def bn_stats_buffer(x, cout):
