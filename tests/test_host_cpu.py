@@ -207,3 +207,19 @@ def test_mspn2_init_weights_detector_checkpoint(tmp_path, monkeypatch):
     assert not rep.missing_keys and not rep.unexpected_keys
     for k, v in src.state_dict().items():
         assert torch.equal(v, dst.state_dict()[k]), k
+
+
+def test_lazy_log_vars_equal_the_eager_ones():
+    """`_parse_losses(lazy=True)` (what train_iteration uses: the read-back happens after the whole step has been queued)
+    resolves to the same loss and the same log variables as the eager form the reference's `_parse_losses` has
+    (mmdet BaseDetector._parse_losses: sum of the entries whose key contains 'loss', lists summed entry by entry)."""
+    import torch
+    from das_amd.detectors import DAS, LazyLogVars
+    losses = {'loss_cls': torch.tensor([0.25, 0.75]), 'loss_pose': [torch.tensor(1.5), torch.tensor([2.0, 4.0])],
+              'acc': torch.tensor(0.5), 'loss_depth': torch.tensor(3.0)}
+    loss_e, lv_e = DAS._parse_losses(losses)
+    loss_l, lv_l = DAS._parse_losses(losses, lazy=True)
+    assert isinstance(lv_l, LazyLogVars) and torch.equal(loss_e, loss_l)
+    assert float(loss_e) == 0.5 + (1.5 + 3.0) + 3.0
+    got = lv_l.resolve()
+    assert list(got) == list(lv_e) == ['loss_cls', 'loss_pose', 'acc', 'loss_depth', 'loss'] and got == lv_e
