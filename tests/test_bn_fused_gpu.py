@@ -156,20 +156,34 @@ def _cos(a, b):
 def test_chain_backward_agrees_with_per_unit_backward(dtype):
     """Same net, one autograd node per conv+BN unit vs one per layer: the gradients point the same way (exact equality
     is not defined here: see the run-to-run note above; bf16 storage adds ReLU-mask flips on top)."""
-    _, _, _, g0 = _mspn_grads(dtype, False)
-    _, _, _, g0b = _mspn_grads(dtype, False)      # the same path again: the run-to-run floor
-    _, _, _, g1 = _mspn_grads(dtype, True)
-    assert set(g0) == set(g1)
-    big = [n for n in g0 if g0[n].numel() >= 256 and float(g0[n].abs().max()) > 0]
-    cos = np.array([_cos(g0[n], g1[n]) for n in big])
-    floor = np.array([_cos(g0[n], g0b[n]) for n in big])
-    print('median cos fused-vs-unit', np.median(cos), 'unit-vs-unit', np.median(floor), 'min', cos.min(), floor.min())
-    # (bf16: the floor is itself one draw of a chaotic process — median cosine about 0.3 between two runs of the SAME
-    # path — so the comparison only has to rule out a systematically different gradient; f32 is the sharp check)
-    slack, slack_min = (0.03, 0.1) if dtype == 'f32' else (0.12, 0.3)
-    assert np.median(cos) > np.median(floor) - slack and cos.min() > floor.min() - slack_min, (np.median(cos), np.median(floor))
-    if dtype == 'f32':
+    if dtype == 'f32':   # the sharp check
+        _, _, _, g0 = _mspn_grads(dtype, False)
+        _, _, _, g0b = _mspn_grads(dtype, False)      # the same path again: the run-to-run floor
+        _, _, _, g1 = _mspn_grads(dtype, True)
+        assert set(g0) == set(g1)
+        big = [n for n in g0 if g0[n].numel() >= 256 and float(g0[n].abs().max()) > 0]
+        cos = np.array([_cos(g0[n], g1[n]) for n in big])
+        floor = np.array([_cos(g0[n], g0b[n]) for n in big])
+        print('median cos fused-vs-unit', np.median(cos), 'unit-vs-unit', np.median(floor), 'min', cos.min(), floor.min())
+        assert np.median(cos) > np.median(floor) - 0.03 and cos.min() > floor.min() - 0.1, (np.median(cos), np.median(floor))
         assert np.median(cos) > 0.999
+        return
+    # bf16: two runs of the SAME path have a median cosine of about 0.3 (0.17 ... 0.42 from draw to draw: the reordered
+    # float atomics of the statistics flip ReLU masks, and the flips cascade), so one draw against one draw of the floor
+    # fails one time in ten. Several draws of both: the mean median-cosine between the paths must not sit below the mean
+    # between runs of the unit path — a systematically different gradient would put it near zero.
+    units = [_mspn_grads(dtype, False)[3] for _ in range(3)]
+    fused = [_mspn_grads(dtype, True)[3] for _ in range(2)]
+    assert set(units[0]) == set(fused[0])
+    big = [n for n in units[0] if units[0][n].numel() >= 256 and float(units[0][n].abs().max()) > 0]
+
+    def med(a, b):
+        return float(np.median([_cos(a[n], b[n]) for n in big]))
+
+    cross = np.mean([med(u, f) for u in units for f in fused])
+    floor = np.mean([med(units[i], units[j]) for i in range(3) for j in range(i + 1, 3)])
+    print('mean median cos fused-vs-unit', cross, 'unit-vs-unit', floor)
+    assert cross > floor - 0.15 and cross > 0.1, (cross, floor)
 
 
 def test_chain_backward_with_flat_optimizer_direct_accumulation():
