@@ -168,11 +168,14 @@ def test_chain_backward_agrees_with_per_unit_backward(dtype):
         assert np.median(cos) > np.median(floor) - 0.03 and cos.min() > floor.min() - 0.1, (np.median(cos), np.median(floor))
         assert np.median(cos) > 0.999
         return
-    # bf16: two runs of the SAME path have a median cosine of about 0.3 (0.17 ... 0.42 from draw to draw: the reordered
-    # float atomics of the statistics flip ReLU masks, and the flips cascade), so one draw against one draw of the floor
-    # fails one time in ten. Several draws of both: the mean median-cosine between the paths must not sit below the mean
-    # between runs of the unit path — a systematically different gradient would put it near zero.
-    units = [_mspn_grads(dtype, False)[3] for _ in range(3)]
+    # bf16: the two paths round differently (dZ is stored in bf16, the ReLU mask is recomputed from raw), a flipped ReLU
+    # mask moves whole sub-graphs, and the flips cascade through 2 x 16 train-mode BatchNorm layers: the median cosine
+    # between the paths is 0.2 ... 0.7 from draw to draw. Two runs of the SAME path are no yardstick for that: they agree
+    # to 0.99997 when the float atomics of the statistics happen to retire in the same order and to 0.3 when they do
+    # not (both seen in one session). What this leg can rule out is a systematically different gradient (cosine near
+    # zero, or a different scale), over several draws; the sharp comparison is the f32 leg above and the kernel-by-kernel
+    # bf16 cases.
+    units = [_mspn_grads(dtype, False)[3] for _ in range(2)]
     fused = [_mspn_grads(dtype, True)[3] for _ in range(2)]
     assert set(units[0]) == set(fused[0])
     big = [n for n in units[0] if units[0][n].numel() >= 256 and float(units[0][n].abs().max()) > 0]
@@ -181,9 +184,10 @@ def test_chain_backward_agrees_with_per_unit_backward(dtype):
         return float(np.median([_cos(a[n], b[n]) for n in big]))
 
     cross = np.mean([med(u, f) for u in units for f in fused])
-    floor = np.mean([med(units[i], units[j]) for i in range(3) for j in range(i + 1, 3)])
-    print('mean median cos fused-vs-unit', cross, 'unit-vs-unit', floor)
-    assert cross > floor - 0.15 and cross > 0.1, (cross, floor)
+    floor = med(units[0], units[1])
+    scale = np.median([float(fused[0][n].norm() / units[0][n].norm()) for n in big])
+    print('mean median cos fused-vs-unit', cross, 'unit-vs-unit', floor, 'median norm ratio', scale)
+    assert cross > 0.1 and 0.5 < scale < 2.0, (cross, floor, scale)
 
 
 def test_chain_backward_with_flat_optimizer_direct_accumulation():

@@ -176,7 +176,10 @@ def test_wgrad_side_stream_equals_main_stream():
     floor = max(float((a - b).abs().max()) for i, a in enumerate(mains) for b in mains[i + 1:]) / scale
     diff = float((g0 - res['side'][0]).abs().max()) / scale
     assert abs(l0 - res['side'][1]) <= 1e-4 * abs(l0)
-    assert diff <= max(6 * floor, 1e-4), (diff, floor)
+    # (the absolute term: when the three single-stream runs happen to retire their atomics in the same order the floor
+    # is ~1e-7 while a differently timed run still lands 5e-3 away; a lost or doubled weight gradient is O(1), and the
+    # sharp race check is test_wgrad_batch_on_side_stream_bit_exact below)
+    assert diff <= max(6 * floor, 2e-2), (diff, floor)
 
 
 def test_wgrad_batch_on_side_stream_bit_exact():
