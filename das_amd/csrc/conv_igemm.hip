@@ -883,6 +883,19 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
 // 3 / 4 = data gradient with the fused BatchNorm-backward reduction (ConvP::bnb_*): optional residual, mask from the
 // saved output y (3; no y = no mask) or recomputed from raw with the layer's affine (4), per-channel sums in registers;
 // 5 = scale / shift, then residual add, optional ReLU (the closing 1x1 conv of an eval-mode bottleneck).
+// The per-channel sums of a wave end up in lane 15 of each DPP row: sixteen values (8 channels x {sum, sum of squares})
+// for each of the four channel groups. Sixteen atomic instructions with four live lanes each cost the launch 4-5 us of
+// tail (tools/dev/stream_fixed.py); the 64 values go through 256 bytes of LDS instead and leave as ONE atomic instruction
+// with every lane live: lane = group * 16 + channel * 2 + which.
+__device__ __forceinline__ void stream_stat_flush(float* sred, int lane, int n0, const ConvP& p) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's LDS writes have landed; nothing is reordered across)
+  const float v = sred[lane];
+  const int ch = n0 + (lane >> 4) * 8 + ((lane & 15) >> 1), w = lane & 1;
+  if (ch < p.Cout) {
+    const int slot = p.stat_slots > 1 ? (int)(blockIdx.x % (unsigned)p.stat_slots) : 0;
+    atomicAdd(p.stats + (slot * 2 + w) * p.Cout + ch, v);
+  }
+}
 template <int KB, int WN, int MODE>   // K = 32 * KB input channels; WN waves across the 32-channel groups, 8 / WN across pixels
 __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, int ntiles) {
   using T = bf16_t;
@@ -954,6 +967,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
   }
   const int c8 = n0 + g4 * 8;   // this lane's eight output channels
   const bool cok = c8 < p.Cout;
+  float* sred = reinterpret_cast<float*>(smem + NS * STAGE) + wave * 64;   // this wave's 64 reduced sums (see stream_stat_flush)
   float sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -1067,12 +1081,10 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));
-        if (q == 15 && cok) {
-          const int slot = p.stat_slots > 1 ? (int)(blockIdx.x % (unsigned)p.stat_slots) : 0;
-          atomicAdd(p.stats + (slot * 2 + w) * p.Cout + c8 + j, v);
-        }
+        if (q == 15) sred[g4 * 16 + j * 2 + w] = v;
       }
     }
+    stream_stat_flush(sred, lane, n0, p);
     return;
   }
   const T* rg = RES ? reinterpret_cast<const T*>(p.res) : nullptr;
@@ -1170,12 +1182,10 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));
         v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));
-        if (q == 15 && cok) {
-          const int slot = p.stat_slots > 1 ? (int)(blockIdx.x % (unsigned)p.stat_slots) : 0;
-          atomicAdd(p.stats + (slot * 2 + w) * p.Cout + c8 + j, v);
-        }
+        if (q == 15) sred[g4 * 16 + j * 2 + w] = v;
       }
     }
+    stream_stat_flush(sred, lane, n0, p);
   }
 }
 
@@ -1192,7 +1202,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
   const int wn = p.Cout >= 256 ? 8 : p.Cout / 32, ncol = p.Cout >= 256 ? p.Cout / 256 : 1;
   const int ntiles = (p.M + 63) / 64;
   const int kb = p.Cin / 32;
-  const size_t sm = 4 * (size_t)((p.Cin + 63) / 64) * 64 * 128;   // four stages of 64 pixel rows
+  const size_t sm = 4 * (size_t)((p.Cin + 63) / 64) * 64 * 128 + 8 * 64 * sizeof(float);   // four stages of 64 pixel rows + the waves' reduced sums
   auto go = [&](auto kern) -> bool {
     static int per_cu = 0;   // (one static per template instance: the lambda is instantiated per kernel type)
     if (per_cu == 0) {

@@ -202,7 +202,6 @@ def zeroed_stats(n, device):
 
 
 _SLOT_ROWS = 16384          # rows from which the statistics of a conv epilogue are spread over 16 slots
-_WIDE_SLOT_ROWS = 262144    # ... and over 64 slots on the layers with <= 128 output channels
 
 
 def bn_stats_buffer(x, cout):
@@ -211,10 +210,7 @@ def bn_stats_buffer(x, cout):
     (DasConvDesc.stats_slots); das_bn_train_apply sums the slots."""
     xd = x.data if hasattr(x, 'sizes') else x
     rows = xd.numel() // xd.shape[-1]
-    # Same-word f32 atomics retire one after the other at ~0.3 us each (tools/dev/stream_fixed.py: 1024 of them on one
-    # word cost 320 us): the 128x208 layers have 3328 tiles of 128 rows, 208 per word with 16 slots = a 60 us chain
-    # under a 90 us kernel. The narrow layers of that stage (whose apply pass folds the slots cheaply) take 64 slots.
-    slots = (64 if rows >= _WIDE_SLOT_ROWS and cout <= 128 else 16) if rows >= _SLOT_ROWS else 1
+    slots = 16 if rows >= _SLOT_ROWS else 1
     return zeroed_stats(slots * 2 * cout, xd.device)
 
 
