@@ -202,7 +202,8 @@ def zeroed_stats(n, device):
 
 
 _SLOT_ROWS = 16384          # rows from which the statistics of a conv epilogue are spread over slots:
-_FULL_SLOT_ROWS = 65536     # 16 from here up,
+_FULL_SLOT_ROWS = 65536     # _FULL_SLOTS from here up,
+_FULL_SLOTS = 8             # (8 cost the apply passes 0.2 ms per step less than 16 and no conv kernel more)
 _MID_SLOTS = 4              # this many in between (the 32x52 stage: the apply pass folds the slots in every workgroup,
                             # 7 us for 16 slots x 1024 channels, while 4 slots already cut the atomic chain to 16 per line)
 
@@ -213,7 +214,7 @@ def bn_stats_buffer(x, cout):
     (DasConvDesc.stats_slots); das_bn_train_apply sums the slots."""
     xd = x.data if hasattr(x, 'sizes') else x
     rows = xd.numel() // xd.shape[-1]
-    slots = (16 if rows >= _FULL_SLOT_ROWS else _MID_SLOTS) if rows >= _SLOT_ROWS else 1
+    slots = (_FULL_SLOTS if rows >= _FULL_SLOT_ROWS else _MID_SLOTS) if rows >= _SLOT_ROWS else 1
     return zeroed_stats(slots * 2 * cout, xd.device)
 
 
