@@ -363,9 +363,14 @@ extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void*
   if ((C / epv) > GN_NT) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nseg = lv->num_levels * lv->B;
-  if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
-  if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
-  if (hipMemsetAsync(dbeta, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  // (one fill when the caller laid the three accumulators out back to back: a fill is a ~4 us launch of its own)
+  if (dgamma == gsums_ws + 2 * nseg * G && dbeta == dgamma + C) {
+    if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * (2 * (size_t)nseg * G + 2 * (size_t)C), s) != hipSuccess) return DAS_ERR_LAUNCH;
+  } else {
+    if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
+    if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+    if (hipMemsetAsync(dbeta, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  }
   int maxhw = 0;
   for (int l = 0; l < lv->num_levels; ++l) maxhw = std::max(maxhw, lv->H[l] * lv->W[l]);
   int chunks = (256 * 4 + lv->B - 1) / lv->B;

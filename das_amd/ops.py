@@ -608,9 +608,10 @@ def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True):
     Cc = xd.shape[-1]
     dx = _empty_like_rows(x, Cc, xd.dtype)
     assert _ps(dy) == _ps(x) == _ps(dx) and (yd is None or _ps(y) == _ps(x)), 'operands must share the pixel stride'
-    gs = torch.empty(lv.num_levels * lv.B * G * 2, dtype=torch.float32, device=xd.device)
-    dgamma = torch.empty(Cc, dtype=torch.float32, device=xd.device)
-    dbeta = torch.empty_like(dgamma)
+    # (the three accumulators back to back: the call zeroes them with one fill)
+    ngs = lv.num_levels * lv.B * G * 2
+    acc = torch.empty(ngs + 2 * Cc, dtype=torch.float32, device=xd.device)
+    gs, dgamma, dbeta = acc[:ngs], acc[ngs:ngs + Cc], acc[ngs + Cc:]
     _lib.check(_lib.load().das_groupnorm_backward(_ptr(dyd), _ptr(yd), _ptr(xd), _ptr(_data(dx)), _DT[xd.dtype],
                                                   C.byref(lv), Cc, _ps(x), G, _ptr(fwd_stats), _ptr(gamma), eps,
                                                   int(relu), _ptr(gs), _ptr(dgamma), _ptr(dbeta), _stream()),
