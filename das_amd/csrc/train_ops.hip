@@ -878,10 +878,11 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
 }
 }  // namespace
 
-// Workspace of the weight gradient's partial tiles (workspace.h: one buffer per device and stream): 64 MiB covers every
-// grid the launcher below picks (1024 workgroups x 64 KiB, or 256 x 256 KiB); tuning overrides may grow it.
+// Workspace of the weight gradient's partial tiles (workspace.h: one buffer per device and stream): 256 MiB covers every
+// schedule of the train step (a few hundred cut tiles of 256 KiB per launch) — growing it later means draining the
+// stream, a free and an allocation in the middle of a step.
 static float* wgrad_workspace(hipStream_t s, size_t bytes) {
-  return dasws::get(dasws::WGRAD, s, bytes, (size_t)64 << 20);
+  return dasws::get(dasws::WGRAD, s, bytes, (size_t)256 << 20);
 }
 
 namespace {
