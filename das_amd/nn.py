@@ -107,8 +107,14 @@ def packed_weight_dgrad_s2(conv, dtype):
 
 
 def _pad8(v, n, fill=0.0):
+    """f32 vector of n values padded to a multiple of 8 (the kernels read per-channel constants in vectors of 8). A
+    vector that already is f32, contiguous and a multiple of 8 long is used as it is: padding it anyway cost two small
+    launches per biased conv and step (the parameters change every step, so nothing here can be cached across steps)."""
+    vd = v.detach()
+    if n % 8 == 0 and vd.numel() == n and vd.dtype == torch.float32 and vd.is_contiguous():
+        return vd
     out = torch.full(((n + 7) // 8 * 8,), fill, dtype=torch.float32, device=v.device)
-    out[:n] = v.detach().float()
+    out[:n] = vd.float()
     return out
 
 
