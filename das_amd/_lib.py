@@ -58,6 +58,11 @@ class DasPhotometric(C.Structure):
                 ('perm', i32 * 3)]
 
 
+class DasRleDesc(C.Structure):
+    _fields_ = [('J', i32), ('sets', i32), ('npos', i32), ('pose_ps', i32), ('aux_ps', i32), ('stride2', i32),
+                ('stride3', i32), ('amp', f32), ('beta', f32)]
+
+
 class DasDecodeDesc(C.Structure):
     _fields_ = [('B', i32), ('J', i32), ('num_levels', i32),
                 ('H', i32 * DAS_MAX_LEVELS), ('W', i32 * DAS_MAX_LEVELS), ('stride', i32 * DAS_MAX_LEVELS),
@@ -121,6 +126,10 @@ SIGNATURES = {
     'das_realnvp_log_prob_multi': (i32, [vp, i32, i32, C.POINTER(DasFlowJob), i32, i32, C.c_uint, vp, vp, vp]),
     'das_realnvp_log_prob_multi_backward': (i32, [vp, vp, i32, i32, C.POINTER(DasFlowJob), i32, i32, C.c_uint, vp, vp]),
     'das_realnvp_log_prob_backward': (i32, [vp, vp, i32, i32, vp, i32, C.c_uint, vp, vp, vp, vp]),
+    'das_rle_blocks': (i32, [C.POINTER(DasRleDesc)]),
+    'das_rle_prepare': (i32, [vp, vp, vp, vp, vp, vp, vp, C.POINTER(DasRleDesc), vp, vp, vp, vp, vp]),
+    'das_rle_loss': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(DasRleDesc), vp, vp]),
+    'das_rle_backward': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(DasRleDesc), vp, vp, vp]),
     'das_grad_sumsq': (i32, [vp, i64, vp, i32, vp]),
     'das_sgd_momentum_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]),
     'das_decode_cap': (i32, [C.POINTER(DasDecodeDesc)]),
@@ -151,7 +160,7 @@ def load():
         except AttributeError as e:
             raise DasHipError(f'libdas_hip.so does not export {name}') from e
         fn.restype, fn.argtypes = res, args
-    if lib.das_abi_version() != 2:
+    if lib.das_abi_version() != 3:
         raise DasHipError('libdas_hip.so ABI version mismatch')
     _lib = lib
     return lib

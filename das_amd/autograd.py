@@ -138,6 +138,33 @@ def _end_of_backward():
     flush_wgrads()
 
 
+def finish_backward():
+    """Launch whatever weight gradients are still queued and make the current stream wait for the side streams.
+    The autograd engine's end-of-backward callbacks normally did both already; the engine skips them when backward
+    raises, so the consumers of the gradients (FlatSGD.all_reduce_grads / step) call this unconditionally."""
+    flush_wgrads()
+    for dev_index, ent in _side.items():
+        ent[2] = False
+        cur = torch.cuda.current_stream(dev_index)
+        for st in ent[0]:
+            cur.wait_stream(st)
+
+
+def reset_step_state():
+    """Start of an optimisation step (FlatSGD.zero_grad): forget everything a previous backward left behind. After a
+    backward that raised (out of memory, an assert inside a Function) the queue still holds that step's weight-gradient
+    operands and the 'callback queued' flags are still set; launched now, those stale operands would add into the next
+    step's gradient, and with the flags set no later backward would flush or join again."""
+    _pending.clear()
+    _flush_queued[0] = False
+    for dev_index, ent in _side.items():
+        if ent[2]:
+            cur = torch.cuda.current_stream(dev_index)
+            for st in ent[0]:
+                cur.wait_stream(st)
+        ent[2] = False
+
+
 def _wgrad(x, dy, weight, k, s, p):
     """Weight gradient of conv(x, weight). With the flat optimizer the kernel adds straight into the flat
     gradient buffer (same (Cout,KH,KW,Cin) layout) and autograd gets None; otherwise an OIHW view is returned."""

@@ -17,17 +17,16 @@ typedef uint16_t bf16_t;  // raw bfloat16 bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN kept quiet
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-
+// f32 -> bf16, round-to-nearest-even, NaN kept quiet: gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR; the
+// integer sequence it replaces — NaN test, rounding add, shift, merge — was ~8 VALU instructions per element and made
+// the C-tile staging of the conv epilogues VALU-bound: 5.4 us of a 256 x 256 tile's 11.5 us epilogue, in-kernel stamps).
+typedef __bf16 das_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float das_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const das_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, das_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // Element traits: T is the storage type of activations / weights.
 template <typename T>

@@ -4,6 +4,20 @@
 #pragma once
 #include "common.h"
 
+// Dev builds (make stamps -> libdas_hip_stamps.so, never loaded by the product): thread 0 of every workgroup of the
+// tile kernels records the 100 MHz wall clock at up to eight points (entry, main loop, epilogue phases, exit) into a
+// host-provided buffer, 8 x u64 per workgroup: tools/dev/conv_stamps.py / t2_bench.py split a launch into prologue /
+// K loop / epilogue phases from them.
+#ifdef DAS_STAMPS
+static __device__ unsigned long long* g_das_stamps;
+#define DAS_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    if (g_das_stamps && threadIdx.x == 0) g_das_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define DAS_STAMP(i) do {} while (0)
+#endif
+
 namespace dasconv {
 
 constexpr int BM = 128;
@@ -126,22 +140,22 @@ struct Tiling {
   }
 };
 
-template <typename OT, int BN, int BMT = 128>
+template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>>
 constexpr size_t epilogue_smem_bytes() {
   size_t ctile = (size_t)BMT * (BN * sizeof(OT) + 16);
-  size_t red = 2 * (size_t)(Tiling<BN, BMT>::NT / (BN * sizeof(OT) / 16)) * BN * 4;
+  size_t red = 2 * (size_t)(TL::NT / (BN * sizeof(OT) / 16)) * BN * 4;
   return ctile > red ? ctile : red;
 }
 
 // acc[a][b][j]: channel n0 + wave_n0 + a*16 + (lane>>4)*4 + j, pixel m0 + wave_m0 + b*16 + (lane&15).
 // Must be entered after a barrier that ends all LDS reads of the main loop.
-template <typename OT, int BN, int BMT = 128, typename Acc>
+template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, typename Acc>
 __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* smem, int m0, int n0) {
-  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN, NT = Tiling<BN, BMT>::NT;
+  constexpr int TM = TL::TM, TN = TL::TN, NT = TL::NT;
   constexpr int EPVO = 16 / (int)sizeof(OT);
   constexpr int CS = BN * (int)sizeof(OT) + 16;  // padded C-tile row stride in bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_m0 = Tiling<BN, BMT>::wave_m0(wave), wave_n0 = Tiling<BN, BMT>::wave_n0(wave);
+  const int wave_m0 = TL::wave_m0(wave), wave_n0 = TL::wave_n0(wave);
   const int ch4 = (lane >> 4) * 4;
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
@@ -167,6 +181,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
     }
   }
   __syncthreads();
+  DAS_STAMP(5);
 
   constexpr int VR = BN * (int)sizeof(OT) / 16;  // 16-B vectors per C row
   constexpr int RP = NT / VR;                    // rows per pass
@@ -276,8 +291,10 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
       }
     }
   }
+  DAS_STAMP(6);
   if (p.stats) {
     __syncthreads();
+    DAS_STAMP(7);
     float* red = reinterpret_cast<float*>(smem);  // [2][RP][BN]
 #pragma unroll
     for (int j = 0; j < EPVO; ++j) {
@@ -285,8 +302,8 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
       red[(RP + r0) * BN + vec * EPVO + j] = ssq[j];
     }
     __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, c = tid % BN;
+    for (int i = tid; i < 2 * BN; i += NT) {   // (one pass unless the workgroup has fewer than 2 * BN threads)
+      const int which = i / BN, c = i % BN;
       if (n0 + c < p.Cout) {
         float s = 0.f;
         for (int r = 0; r < RP; ++r) s += red[(which * RP + r) * BN + c];

@@ -28,6 +28,12 @@ using namespace dasconv;
 
 __device__ uint4 g_das_zero_page[8];  // 128 B of zeros: source of every out-of-bounds DMA
 
+#ifdef DAS_STAMPS
+extern "C" int das_dev_set_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_das_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 2;
+}
+#endif
+
 namespace {
 
 // =============================================================== generic register-staged kernel
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   constexpr int A_BYTES = BMT * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
   constexpr int A_INSTR = 4, W_INSTR = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  DAS_STAMP(0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -444,6 +451,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < W_INSTR; ++j) wcur[j] += (unsigned)e0 * E;
   }
+  DAS_STAMP(1);
   issue(0, 0);
   if (nk > 1) issue(1, 1);
   const int frow = lane & 15, fkg = lane >> 4;
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                 // tile 0 landed
+    DAS_STAMP(2);
     if (grp == 1) __builtin_amdgcn_s_barrier();   // trailing group: one interval behind
     for (int kt = 0; kt < nk; ++kt) {
       // ---- R
@@ -525,9 +534,11 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
     buf = buf == NBUF - 1 ? 0 : buf + 1;
     nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
   }
-  if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); return; }
+  DAS_STAMP(3);
+  if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); DAS_STAMP(4); return; }
   __syncthreads();  // all LDS reads done before the C tile reuses the buffers
   conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
+  DAS_STAMP(4);
 }
 
 // =============================================================== 4-stage pipeline, 256 x 256 tile, 8 waves
@@ -556,6 +567,7 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   constexpr unsigned E = sizeof(T);
   constexpr unsigned OOB = 0xFFFFFFF0u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  DAS_STAMP(0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -640,6 +652,7 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < W_INSTR; ++j) wcur[j] += (unsigned)e0 * E;
   }
+  DAS_STAMP(1);
   issue(0);
   if (nk > 1) issue(1);
   if (nk > 2) issue(2);
@@ -669,6 +682,7 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                 // tile 0 landed
+    DAS_STAMP(2);
     if (grp == 1) __builtin_amdgcn_s_barrier();   // trailing group: one interval behind
     for (int kt = 0; kt < nk; ++kt) {
       // ---- R
@@ -723,9 +737,11 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
     buf = buf == NBUF - 1 ? 0 : buf + 1;
     nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
   }
-  if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); return; }
+  DAS_STAMP(3);
+  if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); DAS_STAMP(4); return; }
   __syncthreads();  // all LDS reads done before the C tile reuses the buffers
   conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
+  DAS_STAMP(4);
 }
 
 // =============================================================== launch

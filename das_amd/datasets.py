@@ -98,3 +98,18 @@ def build_dataset(cfg, default_args=None):
     if isinstance(cfg.get('pipeline'), (list, tuple)):
         cfg['pipeline'] = pipelines.Compose(cfg['pipeline'])
     return DATASETS.build(cfg, default_args)
+
+
+def collect_results(parts, size=None):
+    """Results of a multi-rank test run back in dataset order. Rank r evaluated samples r, r + world, r + 2 * world, ...
+    (`parts[r]`, in that order), so the dataset order is the round-robin interleave of the parts; ranks at the tail of a
+    dataset whose length is not a multiple of the world size hold one result fewer, and every result is kept. The
+    reference (tools/test.py:205-206 -> mmdet `multi_gpu_test` / `collect_results`) pads the sampler so that all parts
+    are equally long, interleaves with zip and trims to `len(dataset)`: the same list. `size` trims likewise."""
+    out = []
+    longest = max((len(part) for part in parts), default=0)
+    for i in range(longest):
+        for part in parts:
+            if i < len(part):
+                out.append(part[i])
+    return out if size is None else out[:size]

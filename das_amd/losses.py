@@ -181,23 +181,19 @@ def das_head_targets(head, B, sizes, device, gt_poses_3d, centers2d=None, depths
         return prep
     pos = torch.nonzero_static(is_pos, size=npos).reshape(-1)
     pt, pct, ps = targets[pos], ctr_t[pos], row_stride[pos]
-    gt_uvd = pt[:, 3:3 + 3 * J]
-    is2d = (gt_uvd[:, 2::3] == 0).all(1)
-    idx3d = torch.nonzero_static(~is2d, size=n3d).reshape(-1)
-    idx2d = torch.nonzero_static(is2d, size=npos - n3d).reshape(-1)
-    keep3 = (~is2d).to(pt.dtype)[:, None, None]                       # zero the z column of 2-D-only samples
-    zcol = pt.new_tensor([0.0, 0.0, 1.0])
+    gt_uvd = pt[:, 3:3 + 3 * J].reshape(npos, J, 3)
+    is2d = (gt_uvd[..., 2] == 0).all(1)                              # sample without depth annotation (das_head.py:388)
+    # pixel-to-joint targets: image offsets in units of the level's stride, depth in units of z_norm (:393-409)
     root = torch.cat([pt[:, :2] * ps[:, None], torch.zeros_like(pt[:, :1])], 1)
-    real = gt_uvd.reshape(npos, J, 3) - root[:, None]
-    real = torch.cat([real[..., :2] / ps[:, None, None], real[..., 2:] / head.z_norm], -1)
-    vis_w = pt[:, 3 + 3 * J:].reshape(npos, J, 1).expand(npos, J, 3)
-    if head.prev_loss:
-        real2, vis2 = real.repeat(1, 2, 1), vis_w.repeat(1, 2, 1)
-    else:
-        real2, vis2 = real, vis_w.contiguous()
-    prep.update(pos=pos, ctr_t=pct, idx3d=idx3d, idx2d=idx2d, kill=1 - (1 - keep3) * zcol, sig_add=(1 - keep3) * zcol,
-                depth_t=pt.index_select(0, idx3d)[:, 2] * head.depth_factor if n3d else None,
-                real2=real2, vis2=vis2, nvis=vis2[..., 0].sum())
+    real = gt_uvd - root[:, None]
+    real = torch.cat([real[..., :2] / ps[:, None, None], real[..., 2:] / head.z_norm], -1).contiguous()
+    vis = pt[:, 3 + 3 * J:].contiguous()
+    kind = is2d.to(torch.int32)
+    # rank of every positive among the positives of its kind: its block of J rows in the flows' input
+    slot = torch.where(is2d, torch.cumsum(kind, 0), torch.cumsum(1 - kind, 0)).to(torch.int32) - 1
+    prep.update(pos=pos, ctr_t=pct, real=real, vis=vis, is2d=kind, slot=slot,
+                depth_t=(pt[:, 2] * head.depth_factor).contiguous(),
+                nvis=vis.sum() * (2 if head.prev_loss else 1))
     return prep
 
 
@@ -218,51 +214,24 @@ def das_head_loss_rows(head, cls, pose, ctr, aux, gt_poses_3d, centers2d=None, d
     loss_cls = T.FocalLossSumFn.apply(cls.data, prep['labels'], lc.gamma, lc.alpha) * (lc.loss_weight / (npos + B))
 
     pos = prep['pos']
-    # (index_select: its backward is an atomic index_add; boolean / advanced indexing would sort and synchronise)
-    pp, pc, paux = pose.data.index_select(0, pos), ctr.data.index_select(0, pos)[:, 0], aux.data.index_select(0, pos)
     cw = [float(v) for v in head.train_cfg['code_weight']] if head.train_cfg and head.train_cfg.get('code_weight') \
         else [1.0] * (3 + 6 * J)
-
-    if n3d > 0:
-        lr = head.loss_reg
-        loss_depth = T.SmoothL1SumFn.apply(pp.index_select(0, prep['idx3d'])[:, 2], prep['depth_t'], lr.beta) * \
-            (cw[2] * lr.loss_weight / n3d)
-    else:
-        loss_depth = pp[0, 2] - pp[0, 2]
-
-    kill = prep['kill']
-    uvd = pp[:, 3:3 + 3 * J].reshape(npos, J, 3) * kill
-    upd = paux.reshape(npos, J, 3) * kill
-    sig = pp[:, 3 + 3 * J:].reshape(npos, J, 3) * kill + prep['sig_add']    # sigma logit := 1 for 2-D-only samples' z
-    sig = sig.sigmoid() + 1e-9
-    real2, vis2 = prep['real2'], prep['vis2']
-    if head.prev_loss:
-        pred, sig2 = torch.cat([upd, uvd], 1), sig.repeat(1, 2, 1)
-        flows = [('_update', slice(0, J)), ('', slice(J, 2 * J))]
-    else:
-        pred, sig2 = upd, sig
-        flows = [('', slice(0, J))]
-    bar = (pred - real2) / sig2
-    # per dimension ONE forward (and one backward) launch covers the flows of both prediction sets
-    parts = [None] * len(flows)
-    for D, idx, name, n in ((2, prep['idx2d'], 'flow2d', npos - n3d), (3, prep['idx3d'], 'flow3d', n3d)):
-        if n == 0:
-            continue
-        rows = bar.index_select(0, idx)
-        outs = T.realnvp_log_prob_multi([(getattr(head, name + suffix), rows[:, sl, :D].reshape(-1, D))
-                                         for suffix, sl in flows])
-        for f, v in enumerate(outs):
-            full = bar.new_zeros(npos, J).index_copy(0, idx, v.view(-1, J))
-            parts[f] = full if parts[f] is None else parts[f] + full
-    log_phi = torch.cat(parts, 1)
-    nf = torch.log(sig2) - log_phi[..., None]
-    lp = head.loss_pose
+    # depth term and RLE pose loss of the positive rows: three elementwise kernels around the two RealNVP launches
+    # (train_ops.RLEPoseLossFn), forward and backward; the gradients land in the positives' rows of dense zero tensors
+    lr, lp = head.loss_reg, head.loss_pose
+    sets = 2 if head.prev_loss else 1
+    meta = dict(J=J, sets=sets, n2d=npos - n3d, n3d=n3d, amp=float(lp.amp), beta=float(lr.beta),
+                flows={D: ([getattr(head, f'flow{D}d_update')] if sets == 2 else []) + [getattr(head, f'flow{D}d')]
+                       for D in (2, 3)},
+                **{k: prep[k] for k in ('pos', 'real', 'vis', 'is2d', 'slot', 'depth_t')})
+    sums = T.rle_pose_loss_sums(pose.data, aux.data, meta)
+    loss_depth = sums[1] * (cw[2] * lr.loss_weight / n3d) if n3d > 0 else sums[1] * 0.0
     nvis = prep['nvis']
     if prep['nvis_host'] < 1:  # residual_log_likelihood_loss.py:24-25
         loss_pose = nvis
     else:
-        q = (torch.log(sig2 / lp.amp) + (real2 - pred).abs() / (math.sqrt(2) * sig2 + 1e-9)) * vis2
-        loss_pose = ((nf * vis2 + q) * cw[3]).sum() / nvis
+        loss_pose = sums[0] * cw[3] / nvis
+    pc = ctr.data.index_select(0, pos)[:, 0]
 
     lctr = head.loss_centerness
     loss_ctr = T.BCELogitsSumFn.apply(pc, prep['ctr_t']) * (lctr.loss_weight / npos)

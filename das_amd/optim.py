@@ -190,6 +190,10 @@ class FlatSGD:
     def zero_grad(self):
         """Clears the flat gradient. Also the once-per-iteration guard of the packed weight copies: an in-place
         parameter edit since the last call invalidates them (they are keyed on PARAM_EPOCH only)."""
+        from .autograd import reset_step_state
+        reset_step_state()          # (a backward that raised leaves queued weight gradients and sticky flags behind)
+        if self.world > 1 and any(self._pfires):
+            self._reset_iteration()
         self.flat_g.zero_()
         sig = self._param_signature()
         if sig != self._sig:
@@ -267,6 +271,8 @@ class FlatSGD:
     def all_reduce_grads(self):
         """Finish the gradient sum over ranks (the mean is folded into the step's grad_scale): launch the
         buckets that backward did not complete (unused parameters, first iteration), then wait."""
+        from .autograd import finish_backward
+        finish_backward()           # queued weight gradients launched, side streams joined — whatever backward did
         if self.world == 1:
             return
         if self._late:
@@ -299,6 +305,8 @@ class FlatSGD:
         return self._param_groups
 
     def step(self, lr=None):
+        from .autograd import finish_backward
+        finish_backward()
         self._check_grad_aliasing()
         scale = 1.0 / self.world
         sumsq = None

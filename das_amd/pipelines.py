@@ -111,27 +111,40 @@ class LoadAnnotationsPose3D:
 
 
 # ---------------------------------------------------------------------------------------------- resize
+class PoseTable:
+    """Column groups of a `gt_poses_3d` matrix, one row per person:
+    [root u, root v, root depth | J x (u, v, dz) | J x visibility]  (4 J + 3 columns, cmupanoptic_mono_dataset.py:171-207).
+    `joints` and `vis` are private copies the transforms edit; `pack` writes a matrix in the same layout."""
+
+    def __init__(self, rows, num_joints=None):
+        self.n = len(rows)
+        self.J = (rows.shape[-1] - 3) // 4 if num_joints is None else num_joints
+        split = 3 + 3 * self.J
+        self.root, self.depth = rows[:, :2], rows[:, 2]
+        self.joints = np.array(rows[:, 3:split]).reshape(self.n, self.J, 3)
+        self.vis = np.array(rows[:, split:]).reshape(self.n, self.J)
+
+    def pack(self, root, depth):
+        return np.concatenate([root, depth.reshape(-1, 1), self.joints.reshape(self.n, -1), self.vis], axis=-1)
+
+
 def resize_pose(results, scale_depth, abs_dz):
-    """ResizePose._resize_pose (transforms_3d.py:32-56), in place on `results`."""
-    scale_factor = results['scale_factor'][:2]     # w, h
-    num_joints = (results['gt_poses_3d'].shape[-1] - 3) // 4
-    centers2d = results['centers2d']
-    depths = results['depths']
-    assert (centers2d == results['gt_poses_3d'][:, :2]).all()
-    assert (depths == results['gt_poses_3d'][:, 2]).all()
-    joints = results['gt_poses_3d'][:, 3:3 + num_joints * 3].reshape(-1, num_joints, 3)
-    joints_vis = results['gt_poses_3d'][:, 3 + num_joints * 3:].reshape(-1, num_joints)
-    centers2d = centers2d * scale_factor
-    joints[..., :2] = joints[..., :2] * scale_factor
+    """Annotation half of ResizePose (what transforms_3d.py:32-56 computes), in place on `results`: image coordinates
+    follow the (w, h) scale factors; with `scale_depth` the root depth shrinks by the geometric mean of the two
+    (a resized image looks like the same scene seen from further away), and so do the joints' relative depths
+    unless they are absolute (`abs_dz`)."""
+    wh = results['scale_factor'][:2]
+    table = PoseTable(results['gt_poses_3d'])
+    assert np.array_equal(results['centers2d'], table.root) and np.array_equal(results['depths'], table.depth)
+    root, depth = results['centers2d'] * wh, results['depths']
+    table.joints[..., :2] *= wh
     if scale_depth:
-        depth_scale = np.sqrt(scale_factor.prod())
-        depths = depths / depth_scale
+        shrink = np.sqrt(wh.prod())
+        depth = depth / shrink
         if not abs_dz:
-            joints[..., 2] = joints[..., 2] / depth_scale
-    results['centers2d'] = centers2d
-    results['depths'] = depths
-    results['gt_poses_3d'] = np.concatenate(
-        [centers2d, depths.reshape(-1, 1), joints.reshape(-1, num_joints * 3), joints_vis], axis=-1)
+            table.joints[..., 2] /= shrink
+    results['centers2d'], results['depths'] = root, depth
+    results['gt_poses_3d'] = table.pack(root, depth)
 
 
 @PIPELINES.register_module()
@@ -252,20 +265,18 @@ class MultiScaleFlipAug:
 
 # ---------------------------------------------------------------------------------------------- flip
 def flip_pose(results, num_joints, flip_pairs):
-    """RandomFlipPose3D.random_flip_data_3d, 'gt_poses_3d' branch (transforms_3d.py:293-318), in place."""
-    w = results['img_shape'][1]
-    centers2d = results['centers2d']
-    depths = results['depths']
-    joints = results['gt_poses_3d'][:, 3:3 + num_joints * 3].reshape(-1, num_joints, 3)
-    joints_vis = results['gt_poses_3d'][:, 3 + num_joints * 3:].reshape(-1, num_joints)
-    centers2d[..., 0] = w - centers2d[..., 0] - 1
-    joints[:, :, 0] = w - joints[:, :, 0] - 1
-    for pair in flip_pairs:
-        joints[:, pair[0]], joints[:, pair[1]] = joints[:, pair[1]], joints[:, pair[0]].copy()
-        joints_vis[:, pair[0]], joints_vis[:, pair[1]] = joints_vis[:, pair[1]], joints_vis[:, pair[0]].copy()
-    results['centers2d'] = centers2d
-    results['gt_poses_3d'] = np.concatenate(
-        [centers2d, depths.reshape(-1, 1), joints.reshape(-1, num_joints * 3), joints_vis], axis=-1)
+    """Annotation half of a horizontal flip (the 'gt_poses_3d' branch of transforms_3d.py:293-318), in place: columns
+    mirror about the image (x -> w - x - 1) and left / right joints trade places."""
+    width = results['img_shape'][1]
+    table = PoseTable(results['gt_poses_3d'], num_joints)
+    order = np.arange(num_joints)            # joint j of the flipped person is joint order[j] of the original
+    for left, right in flip_pairs:
+        order[[left, right]] = order[[right, left]]
+    table.joints, table.vis = table.joints[:, order], table.vis[:, order]
+    root = results['centers2d']
+    for x in (root[..., 0], table.joints[..., 0]):
+        x[...] = width - x - 1
+    results['gt_poses_3d'] = table.pack(root, results['depths'])
 
 
 @PIPELINES.register_module()
@@ -338,16 +349,6 @@ class PhotoMetricDistortion:
 
 
 # ---------------------------------------------------------------------------------------------- rot / scale / trans
-def get_3rd_point(a, b):
-    direct = a - b
-    return b + np.array([-direct[1], direct[0]], dtype=np.float32)
-
-
-def get_dir(src_point, rot_rad):
-    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
-    return [src_point[0] * cs - src_point[1] * sn, src_point[0] * sn + src_point[1] * cs]
-
-
 def affine_from_points(src, dst):
     """cv2.getAffineTransform: the 2x3 map taking three points to three points (f64 solve)."""
     A = np.zeros((6, 6))
@@ -359,89 +360,82 @@ def affine_from_points(src, dst):
     return np.linalg.solve(A, b).reshape(2, 3)
 
 
-def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0], dtype=np.float32), inv=0):
-    """transforms_3d.py:864-898."""
-    if not isinstance(scale, np.ndarray) and not isinstance(scale, list):
-        scale = np.array([scale, scale])
-    scale_tmp = scale
-    src_w = scale_tmp[0]
-    dst_w, dst_h = output_size[0], output_size[1]
-    rot_rad = np.pi * rot / 180
-    src_dir = get_dir([0, src_w * -0.5], rot_rad)
-    dst_dir = np.array([0, dst_w * -0.5], np.float32)
-    src = np.zeros((3, 2), dtype=np.float32)
-    dst = np.zeros((3, 2), dtype=np.float32)
-    src[0, :] = center + scale_tmp * shift
-    src[1, :] = center + src_dir + scale_tmp * shift
-    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
-    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir
-    src[2:, :] = get_3rd_point(src[0, :], src[1, :])
-    dst[2:, :] = get_3rd_point(dst[0, :], dst[1, :])
-    if inv:
-        return affine_from_points(np.float32(dst), np.float32(src))
-    return affine_from_points(np.float32(src), np.float32(dst))
+def _corner_triangle(origin, spoke):
+    """Three f32 points that pin a similarity: `origin`, `origin + spoke`, and the spoke turned a quarter turn about its
+    tip (what the reference's point construction yields, transforms_3d.py:864-898: its third point is
+    tip + perp(origin - tip))."""
+    tri = np.zeros((3, 2), dtype=np.float32)
+    tri[0] = origin
+    tri[1] = origin + spoke
+    back = tri[0] - tri[1]
+    tri[2] = tri[1] + np.array([-back[1], back[0]], dtype=np.float32)
+    return tri
+
+
+def window_to_frame_affine(center, extent, rot_deg, frame_wh, inverse=False):
+    """2x3 affine that shows the source window (centre `center`, width `extent[0]`, turned by `rot_deg` degrees) in an
+    output frame of `frame_wh` pixels. As in the reference (transforms_3d.py:864-898) the map is pinned by three point
+    pairs rounded to f32 and solved the way cv2.getAffineTransform does, so the matrix — and every annotation moved
+    with it — is bit-identical to the reference's."""
+    extent = np.asarray(extent, dtype=float) * np.ones(2)
+    fw, fh = frame_wh[0], frame_wh[1]
+    turn = np.pi * rot_deg / 180
+    reach = extent[0] * -0.5                          # half a window width, "up" in image coordinates
+    window = _corner_triangle(np.asarray(center, dtype=float),
+                              np.array([-(reach * np.sin(turn)), reach * np.cos(turn)]))
+    frame = _corner_triangle(np.array([fw * 0.5, fh * 0.5]), np.array([0, fw * -0.5], dtype=np.float32))
+    return affine_from_points(frame, window) if inverse else affine_from_points(window, frame)
+
+
+def _move_points(xy, affine):
+    """(N, 2) points through a 2x3 affine, in f64 as one (N, 3) x (3, 2) product."""
+    homog = np.concatenate([xy, np.ones((len(xy), 1))], axis=-1)
+    return np.dot(homog, affine.T)
 
 
 def warp_annotations(results, trans, scale, num_joints, scale_depth, abs_dz, use_bbox_center):
-    """The annotation half of GlobalRotScaleTransPose._transform (transforms_3d.py:988-1058): returns the updated
-    results, or None when fewer than two persons keep their root inside the image."""
-    h, w, _ = results['img_shape']
-    joints = results['gt_poses_3d'][:, :3 + num_joints * 3]
-    batch = len(joints)
-    joints_vis = results['gt_poses_3d'][:, 3 + num_joints * 3:].reshape(batch, num_joints)
-    joints = joints.reshape(batch, num_joints + 1, 3)
-    joints_depth = joints[..., [2]]
+    """Annotation half of GlobalRotScaleTransPose (what transforms_3d.py:988-1058 computes): roots, joints and boxes
+    move with the image's affine map `trans`; joints that leave the image become invisible; persons whose root leaves
+    it (or, with `use_bbox_center`, that keep fewer than three visible joints) are dropped. Returns the updated
+    results, or None when fewer than two persons remain (the sample is redrawn)."""
+    height, width, _ = results['img_shape']
+    rows = results['gt_poses_3d']
+    n, split = len(rows), 3 + 3 * num_joints
+    points = np.array(rows[:, :split]).reshape(n, num_joints + 1, 3)       # root first, then the joints
+    vis = np.array(rows[:, split:]).reshape(n, num_joints)
+    assert ((0 <= vis) & (vis <= 1)).all()
+    depth = points[..., 2:]
     if scale_depth:
-        if not abs_dz:
-            joints_depth = joints_depth * scale
+        if abs_dz:
+            depth[0] = depth[0] * scale      # (first person only: the reference indexes the person axis here)
         else:
-            joints_depth[0] = joints_depth[0] * scale
-    new_joints = joints.copy()
-    new_joints[..., 2] = 1
-    new_joints = new_joints.reshape(-1, 3)
-    new_joints = np.dot(new_joints, trans.T)
-    new_joints = new_joints.reshape(batch, -1, 2)
-    new_joints = np.concatenate([new_joints, joints_depth], axis=-1)
-    gt_poses_3d = np.concatenate([new_joints.reshape(batch, -1), joints_vis], axis=-1).astype(np.float32)
-    assert ((0 <= joints_vis) & (joints_vis <= 1)).all()
+            depth = depth * scale
+    moved = np.concatenate([_move_points(points[..., :2].reshape(-1, 2), trans).reshape(n, -1, 2), depth], axis=-1)
 
-    gt_bboxes = results['gt_bboxes']
-    new_gt_bboxes = gt_bboxes.reshape(batch, 2, 2)
-    new_gt_bboxes_rev = new_gt_bboxes.copy()
-    new_gt_bboxes_rev[..., 1] = new_gt_bboxes[..., 1][:, ::-1]
-    new_gt_bboxes = np.concatenate([new_gt_bboxes, new_gt_bboxes_rev], axis=1)
-    new_gt_bboxes = np.concatenate([new_gt_bboxes, np.ones([batch, 4, 1])], axis=-1).reshape(-1, 3)
-    new_gt_bboxes = np.dot(new_gt_bboxes, trans.T)[:, :2].reshape(batch, 4, 2)
-    xmin_ymin = new_gt_bboxes.min(axis=1)
-    xmax_ymax = new_gt_bboxes.max(axis=1)
-    new_gt_bboxes = np.concatenate([xmin_ymin, xmax_ymax], axis=-1)
-    new_gt_bboxes[:, 0::2] = new_gt_bboxes[:, 0::2].clip(0, w - 1)
-    new_gt_bboxes[:, 1::2] = new_gt_bboxes[:, 1::2].clip(0, h - 1)
-    results['gt_bboxes'] = new_gt_bboxes
-    results['centers2d'] = gt_poses_3d[:, :2]
-    results['depths'] = gt_poses_3d[:, 3]
-    results['gt_poses_3d'] = gt_poses_3d
+    boxes = results['gt_bboxes']
+    corners = boxes[:, [[0, 1], [2, 3], [0, 3], [2, 1]]]                   # (n, 4, 2)
+    corners = _move_points(corners.reshape(-1, 2), trans).reshape(n, 4, 2)
+    hull = np.concatenate([corners.min(axis=1), corners.max(axis=1)], axis=-1)
+    hull[:, 0::2] = hull[:, 0::2].clip(0, width - 1)
+    hull[:, 1::2] = hull[:, 1::2].clip(0, height - 1)
 
-    out_of_bound = (new_joints[..., 0] < 0) | (new_joints[..., 0] > w - 1) | \
-                   (new_joints[..., 1] < 0) | (new_joints[..., 1] > h - 1)
-    joints_vis[out_of_bound[:, 1:]] = 0
-    if not use_bbox_center:
-        valid = ~out_of_bound[:, 0]
-        gt_poses_3d = np.concatenate([new_joints.reshape(batch, -1), joints_vis], axis=-1).astype(np.float32)
-        if valid.sum() < 2:
-            return None
+    outside = (moved[..., 0] < 0) | (moved[..., 0] > width - 1) | (moved[..., 1] < 0) | (moved[..., 1] > height - 1)
+    vis[outside[:, 1:]] = 0
+    if use_bbox_center:
+        root = np.stack([hull[:, 0::2].mean(-1), hull[:, 1::2].mean(-1), moved[:, 0, -1]], axis=-1)
+        keep = (vis.sum(-1) >= 3) & ((boxes[:, 2:] - boxes[:, :2]).prod() > 64)
     else:
-        new_centers = np.stack([new_gt_bboxes[:, 0::2].mean(-1), new_gt_bboxes[:, 1::2].mean(-1),
-                                new_joints[:, 0, -1]], axis=-1)
-        gt_poses_3d = np.concatenate([new_centers, new_joints[:, 1:].reshape(batch, -1), joints_vis],
-                                     axis=-1).astype(np.float32)
-        valid = (joints_vis.sum(-1) >= 3) & ((gt_bboxes[:, 2:] - gt_bboxes[:, :2]).prod() > 64)
-    results['gt_poses_3d'] = gt_poses_3d[valid].copy()
-    results['gt_bboxes'] = new_gt_bboxes[valid]
-    results['centers2d'] = gt_poses_3d[:, :2][valid].copy()
-    results['depths'] = gt_poses_3d[:, 2][valid].copy()
-    results['gt_labels'] = results['gt_labels'][valid]
-    results['gt_labels_3d'] = results['gt_labels_3d'][valid]
+        root = moved[:, 0]
+        keep = ~outside[:, 0]
+        if keep.sum() < 2:
+            return None
+    table = np.concatenate([root, moved[:, 1:].reshape(n, -1), vis], axis=-1).astype(np.float32)
+    results['gt_poses_3d'] = table[keep].copy()
+    results['gt_bboxes'] = hull[keep]
+    results['centers2d'] = table[:, :2][keep].copy()
+    results['depths'] = table[:, 2][keep].copy()
+    results['gt_labels'] = results['gt_labels'][keep]
+    results['gt_labels_3d'] = results['gt_labels_3d'][keep]
     results['transform_mat'] = trans
     return results
 
@@ -483,7 +477,7 @@ class GlobalRotScaleTransPose:
         h, w, _ = results['img_shape']
         center = np.array([w / 2, h / 2], dtype=float) * (1 + results['pcd_trans'])
         new_scale = np.array([w, h], dtype=float) * results['pcd_scale_factor']
-        return get_affine_transform(center, new_scale, results['pcd_rot'], [w, h])
+        return window_to_frame_affine(center, new_scale, results['pcd_rot'], [w, h])
 
     def __call__(self, results):
         results.setdefault('transformation_3d_flow', [])

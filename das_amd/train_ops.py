@@ -227,6 +227,120 @@ class RealNVPLogProbFn(Function):
         return (dx, None, None, None) + tuple(grads)
 
 
+class RLEPoseLossFn(Function):
+    """[sum of vis * (log sigma - log_phi + logQ) over (positive, joint, prediction set, dim) | smooth-L1 sum of the
+    depth term] of the positive rows — the RLE pose loss and the depth loss before code weights and normalisers
+    (das_head.py:375-381, 385-466; residual_log_likelihood_loss.py:17-37) — as three elementwise kernels
+    (das_rle_prepare / das_rle_loss / das_rle_backward) around the two RealNVP launches, forward and backward.
+    pose (rows, >= 3 + 6J) and aux (rows, >= 3J): the head's dense f32 outputs. meta: dict with the ground-truth half
+    (losses.das_head_targets): pos, real, vis, is2d, slot, depth_t, J, sets, n2d, n3d, amp, beta and
+    flows = {2: [flow of set 0, (set 1)], 3: [...]}. The flows' parameters also come in as inputs so that autograd can
+    deliver their gradients when the flat optimizer's tables are not in use."""
+
+    @staticmethod
+    def forward(ctx, pose, aux, meta, *flat_plist):
+        _need_gpu(pose, aux)
+        assert pose.dtype == aux.dtype == torch.float32 and pose.stride(1) == 1 and aux.stride(1) == 1
+        dev, J, sets = pose.device, meta['J'], meta['sets']
+        d = _lib.DasRleDesc()
+        d.J, d.sets, d.npos, d.pose_ps, d.aux_ps = J, sets, meta['pos'].numel(), pose.stride(0), aux.stride(0)
+        d.amp, d.beta = meta['amp'], meta['beta']
+        count = {2: meta['n2d'], 3: meta['n3d']}
+        stride = {D: -(-count[D] * J // _FLOW_ALIGN) * _FLOW_ALIGN for D in (2, 3)}
+        d.stride2, d.stride3 = stride[2], stride[3]
+        x, w, logp, z, jobs = {}, {}, {}, {}, {}
+        for D in (2, 3):
+            rows = sets * stride[D]
+            x[D] = torch.zeros(rows, D, dtype=torch.float32, device=dev) if rows else None
+            w[D] = torch.zeros(rows, dtype=torch.float32, device=dev) if rows else None
+        lib = _lib.load()
+        gt = [meta[k] for k in ('pos', 'real', 'vis', 'is2d', 'slot')]
+        _lib.check(lib.das_rle_prepare(_ptr(pose), _ptr(aux), *[_ptr(t) for t in gt], C.byref(d), _ptr(x[2]), _ptr(w[2]),
+                                       _ptr(x[3]), _ptr(w[3]), _stream()), 'das_rle_prepare')
+        for D in (2, 3):
+            if x[D] is None:
+                continue
+            flows = meta['flows'][D]
+            jobs[D] = []
+            for q, f in enumerate(flows):
+                c, table = _flow_state(f, dev)
+                jobs[D].append((q * stride[D], q * stride[D] + count[D] * J, c['packed'], table, c['plist']))
+            arr = (_lib.DasFlowJob * sets)()
+            for q, (r0, r1, packed, table, plist) in enumerate(jobs[D]):
+                arr[q].params, arr[q].dparams, arr[q].dst_table = packed.data_ptr(), None, None
+                arr[q].row_start, arr[q].row_end = r0, r1
+            rows = sets * stride[D]
+            logp[D] = torch.zeros(rows, dtype=torch.float32, device=dev)
+            z[D] = torch.zeros(rows, D, dtype=torch.float32, device=dev)
+            c0, _ = _flow_state(flows[0], dev)
+            _lib.check(lib.das_realnvp_log_prob_multi(_ptr(x[D]), rows, D, arr, sets, len(flows[0].t), c0['bits'],
+                                                      _ptr(logp[D]), _ptr(z[D]), _stream()), 'das_realnvp_log_prob_multi')
+        partials = torch.empty(lib.das_rle_blocks(C.byref(d)), 2, dtype=torch.float32, device=dev)
+        _lib.check(lib.das_rle_loss(_ptr(pose), _ptr(aux), *[_ptr(t) for t in gt], _ptr(meta['depth_t']),
+                                    _ptr(logp.get(2)), _ptr(logp.get(3)), C.byref(d), _ptr(partials), _stream()), 'das_rle_loss')
+        ctx.cfg = (d, meta, jobs, w, z)
+        ctx.save_for_backward(pose, aux)
+        return partials.sum(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        d, meta, jobs, w, z = ctx.cfg
+        pose, aux = ctx.saved_tensors
+        g = g.contiguous().float()
+        lib = _lib.load()
+        dx, outs = {}, {}
+        for D in (2, 3):
+            if D not in jobs:
+                continue
+            sets, rows = len(jobs[D]), z[D].shape[0]
+            dx[D] = torch.zeros_like(z[D])
+            arr = (_lib.DasFlowJob * sets)()
+            outs[D] = []
+            for q, (r0, r1, packed, table, plist) in enumerate(jobs[D]):
+                arr[q].params, arr[q].row_start, arr[q].row_end = packed.data_ptr(), r0, r1
+                if table is not None:   # the optimizer's flat gradient: the kernel adds every tensor's gradient in place
+                    arr[q].dparams, arr[q].dst_table = None, table.data_ptr()
+                    outs[D].append(None)
+                else:
+                    dp = torch.empty_like(packed)
+                    arr[q].dparams, arr[q].dst_table = dp.data_ptr(), None
+                    outs[D].append(dp)
+            f0 = meta['flows'][D][0]
+            _lib.check(lib.das_realnvp_log_prob_multi_backward(_ptr(z[D]), _ptr(w[D] * g[0]), rows, D, arr, sets, len(f0.t),
+                                                               _flow_state(f0, pose.device)[0]['bits'], _ptr(dx[D]), _stream()),
+                       'das_realnvp_log_prob_multi_backward')
+        dpose, daux = torch.zeros_like(pose), torch.zeros_like(aux)
+        gt = [meta[k] for k in ('pos', 'real', 'vis', 'is2d', 'slot')]
+        _lib.check(lib.das_rle_backward(_ptr(pose), _ptr(aux), *[_ptr(t) for t in gt], _ptr(meta['depth_t']), _ptr(dx.get(2)),
+                                        _ptr(dx.get(3)), _ptr(g), C.byref(d), _ptr(dpose), _ptr(daux), _stream()),
+                   'das_rle_backward')
+        grads = []
+        for D in (2, 3):
+            for (r0, r1, packed, table, plist), dp in zip(jobs.get(D, []), outs.get(D, [])):
+                if dp is None:
+                    for p in plist:
+                        p._das_slot.fired()
+                    grads += [None] * len(plist)
+                else:
+                    off = 0
+                    for p in plist:
+                        n = p.numel()
+                        grads.append(dp[off:off + n].view(p.shape))
+                        off += n
+        return (dpose, daux, None) + tuple(grads)
+
+
+def rle_pose_loss_sums(pose, aux, meta):
+    """-> tensor [pose sum, depth sum] (see RLEPoseLossFn); the flows' parameters are threaded through autograd."""
+    flat = []
+    for D in (2, 3):
+        if meta['n2d' if D == 2 else 'n3d'] > 0:
+            for f in meta['flows'][D]:
+                flat += _flow_state(f, pose.device)[0]['plist']
+    # (dense rows: the gradient tensors share the inputs' row strides)
+    return RLEPoseLossFn.apply(pose.contiguous(), aux.contiguous(), meta, *flat)
+
+
 def realnvp_log_prob_multi(pairs):
     """[(flow, x (N_i, D)), ...] with one common D -> [log p_i (N_i)]: RealNVP.log_prob (real_nvp.py:60-80) of
     every pair in one forward (and one backward) launch."""

@@ -377,6 +377,42 @@ int das_realnvp_log_prob_backward(const float* z_final, const float* grad_logp, 
                                   int layers, unsigned mask_bits, float* dx, float* dparams,
                                   float* const* dst_table, void* stream);
 
+/* The RLE pose loss around the flows and the depth term, on the positive locations only (replaces the tensor algebra of
+ * mmdet3d/models/pose_heads/das_head.py:375-381 (depth: SmoothL1 on the root depth of the 3-D positives) and :385-466
+ * (pose) with mmdet3d/models/losses/residual_log_likelihood_loss.py:17-37 (`RLELoss3D.forward`, `logQ`)).
+ * pose f32[rows][pose_ps] = [root offset 2 | depth | J x uvd | J x sigma logits] and aux f32[rows][aux_ps] = the refined
+ * J x uvd of the recursive-update branch are the head's dense outputs; pos i64[npos] the rows of the positives (distinct);
+ * real f32[npos][J][3] the normalised pixel-to-joint targets, vis f32[npos][J], is2d i32[npos] (1 = sample without
+ * depth: its z offsets count as 0 and its z sigma logit as 1, :388-391), slot i32[npos] = rank of the positive among
+ * the positives of its kind, depth_t f32[npos] the depth targets. Prediction set 0 = aux, set 1 (sets == 2, `prev_loss`)
+ * = pose's own uvd. The flow inputs are written in the layout das_realnvp_log_prob_multi reads: x2 f32[sets*stride2][2]
+ * for the 2-D samples and x3 f32[sets*stride3][3] for the 3-D ones, row = set * stride + slot * J + j (strides:
+ * multiples of 256), with w2 / w3 f32[...] = -3 * vis, the row's weight in the loss (d loss / d log_phi before the
+ * upstream scalar); rows no positive owns are left untouched (the caller zeroes the buffers).
+ * das_rle_loss: partials f32[das_rle_blocks(d)][2] = per-workgroup sums of vis * (log sigma - log_phi + logQ) over
+ * (positive, joint, set, dim) and of the depth term's smooth-L1 values; the caller adds them up in index order and
+ * applies code weights / normalisers (the loss value is then independent of the launch).
+ * das_rle_backward: g_sums f32[2] (device) = upstream gradients of the two sums; dx2 / dx3 = the flows' input
+ * gradients for grad_logp = w * g_sums[0]; writes the positives' rows of dpose / daux (same strides; every element
+ * written once, the caller provides zeroed buffers for the other rows). */
+typedef struct {
+  int J, sets, npos;
+  int pose_ps, aux_ps;
+  int stride2, stride3;
+  float amp;    /* RLELoss3D.amp = 1 / sqrt(2 pi) */
+  float beta;   /* SmoothL1Loss.beta of the depth term */
+} DasRleDesc;
+int das_rle_blocks(const DasRleDesc* d);
+int das_rle_prepare(const float* pose, const float* aux, const long long* pos, const float* real, const float* vis,
+                    const int* is2d, const int* slot, const DasRleDesc* d, float* x2, float* w2, float* x3, float* w3,
+                    void* stream);
+int das_rle_loss(const float* pose, const float* aux, const long long* pos, const float* real, const float* vis,
+                 const int* is2d, const int* slot, const float* depth_t, const float* logp2, const float* logp3,
+                 const DasRleDesc* d, float* partials, void* stream);
+int das_rle_backward(const float* pose, const float* aux, const long long* pos, const float* real, const float* vis,
+                     const int* is2d, const int* slot, const float* depth_t, const float* dx2, const float* dx3,
+                     const float* g_sums, const DasRleDesc* d, float* dpose, float* daux, void* stream);
+
 /* out (+)= sum g^2 over a flat f32 gradient buffer (global-norm clipping, exp_panoptic.py:204-205). */
 int das_grad_sumsq(const float* g, long long n, float* out, int zero_first, void* stream);
 /* torch.optim.SGD step (momentum, weight decay) on flat f32 buffers with the clip coefficient

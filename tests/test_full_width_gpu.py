@@ -1,0 +1,209 @@
+"""Numeric parity at the BENCHMARKED topologies and sizes: the real MSPN-50 widths
+(channels up to 2048, six-block chains, the multi-stage skip seams), full 512 x 832 / 768 x 1024 frames — HIP against
+the CPU oracle (itself pinned bit-exact against the reference, tests/test_oracle_vs_reference.py):
+
+  (i)   configs[1]: 1-stage MSPN-50 + FPN + DASHead, eval, B = 1: f32 head maps within 2e-4 of the map range, decode
+        kept indices identical (mspn_mmpose.py:657-667, das_head.py:232-267, 653-796);
+  (ii)  configs[2]: 4-stage train step, B = 2: the four losses f32 vs oracle within 1e-3, bf16 vs f32 within a stated
+        band; bf16 vs f32 decode overlap at full size;
+  (iii) configs[4]: exp_mupots topology (3 stages, J = 21, root 14, two recursive-update layers), 768 x 1024, B = 1:
+        f32 head maps and decode against the oracle.
+The CPU side costs a few seconds per case (it is the `cpu_baseline` leg of bench.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def split_sd(model):
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    return ({k[9:]: v for k, v in sd.items() if k.startswith('backbone.')},
+            {k[5:]: v for k, v in sd.items() if k.startswith('neck.')},
+            {k[10:]: v for k, v in sd.items() if k.startswith('bbox_head.')})
+
+
+def oracle_hcfg(cfg):
+    h = cfg['bbox_head']
+    ru = h['recursive_update']
+    return dict(num_joints=h['num_joints'], root_idx=h['root_idx'], depth_factor=h['depth_factor'], z_norm=h['z_norm'],
+                strides=h['strides'], stacked_convs=h['stacked_convs'], num_heads=ru['num_heads'],
+                num_layers=ru['num_layers'], regress_ranges=h['regress_ranges'],
+                code_weight=cfg['train_cfg']['code_weight'], prev_loss=ru['prev_loss'])
+
+
+def build(cfg, seed=0):
+    import das_amd
+    torch.manual_seed(seed)
+    model = das_amd.build_model(cfg)
+    model.init_weights()
+    with torch.no_grad():   # (as bench.build_model: spread in the sampling / regression convs, a trained net has it)
+        for n, p in model.bbox_head.named_parameters():
+            if 'conv_offset.weight' in n or 'sampling_offset.weight' in n or 'conv_poses.0.weight' in n:
+                p.normal_(0, 0.02)
+    return model
+
+
+def calibrate_cpu(hsd, cls, ctr, target):
+    """Shift conv_cls.bias so that ~target locations per image pass score_thr; returns the shift."""
+    cc = torch.cat([t.reshape(t.shape[0], -1) for t in cls], 1)
+    kk = torch.cat([t.reshape(t.shape[0], -1) for t in ctr], 1)
+    lo, hi = -20.0, 20.0
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        n = ((torch.sigmoid(cc + mid) * torch.sigmoid(kk)) > 0.07).float().sum().item() / cc.shape[0]
+        lo, hi = (mid, hi) if n < target else (lo, mid)
+    return 0.5 * (lo + hi)
+
+
+def eval_case(cfg, stages, H, W, seed, target=150):
+    """f32 HIP forward + decode against the CPU oracle on the same weights and frame."""
+    from oracle import backbone as ob, decode as od, head as oh
+    J = cfg['bbox_head']['num_joints']
+    hcfg = oracle_hcfg(cfg)
+    model = build(cfg, seed)
+    bsd, nsd, hsd = split_sd(model)
+    g = torch.Generator().manual_seed(seed + 100)
+    img = torch.randn(1, 3, H, W, generator=g)
+    metas = [dict(scale_factor=np.ones(4, dtype=np.float32), filename='x')]
+    blocks = tuple(cfg['backbone']['num_blocks'])
+    with torch.no_grad():
+        feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img, stages, blocks))
+        c, p, k = oh.head_forward(hsd, feats, hcfg, '', False)
+        shift = calibrate_cpu(hsd, c, k, target)
+        hsd['conv_cls.bias'] += shift
+        c, p, k = oh.head_forward(hsd, feats, hcfg, '', False)
+        ref = od.get_poses(c, p, k, metas, J, hcfg['strides'], cfg['test_cfg'], return_index=True)
+    with torch.no_grad():
+        model.bbox_head.conv_cls.bias.add_(shift)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        hc, hp, hk = model.bbox_head(model.extract_feat(img.to(DEV)))
+        out = model.bbox_head.get_poses(hc, hp, hk, metas, return_index=True)
+    return (c, p, k), ref, (hc, hp, hk), out
+
+
+def check_maps_and_decode(refmaps, ref, maps, out, tol):
+    for name, rl, hl in zip(('cls', 'pose', 'ctr'), refmaps, maps):
+        for lvl, (r, h) in enumerate(zip(rl, hl)):
+            assert tuple(r.shape) == tuple(h.shape), (name, lvl)
+            e = rel(h.float().cpu().numpy(), r.numpy())
+            assert e < tol, (name, lvl, e)
+    r, o = ref[0], out[0]
+    ri, oi = r['index'].numpy(), o['index'].cpu().numpy()
+    assert len(ri) > 20, len(ri)
+    np.testing.assert_array_equal(oi, ri)
+    np.testing.assert_allclose(o['poses'].cpu().numpy(), r['poses'].numpy(), rtol=2e-3, atol=2e-2)
+    np.testing.assert_allclose(np.asarray(o['scores']), np.asarray(r['scores']), rtol=2e-3)
+
+
+def test_one_stage_full_width_eval_f32_maps_and_decode_match_the_oracle():
+    import bench
+    cfg = bench.model_cfg(1, 'f32')
+    refmaps, ref, maps, out = eval_case(cfg, 1, bench.H, bench.W, seed=0)
+    check_maps_and_decode(refmaps, ref, maps, out, 2e-4)
+
+
+def mupots_cfg(dtype):
+    import bench
+    J = 21
+    cfg = bench.model_cfg(3, dtype)
+    cfg['bbox_head'].update(num_joints=J, root_idx=14, depth_factor=1)
+    cfg['bbox_head']['recursive_update'].update(num_layers=2, num_joints=J)
+    cfg['train_cfg'] = dict(code_weight=[1.0, 1.0, 1] + [2] * J * 6)
+    return cfg
+
+
+def test_mupots_three_stage_full_width_eval_f32_maps_and_decode_match_the_oracle():
+    refmaps, ref, maps, out = eval_case(mupots_cfg('f32'), 3, 768, 1024, seed=1, target=120)
+    assert sum(c.shape[-2] * c.shape[-1] for c in maps[0]) == 16320
+    check_maps_and_decode(refmaps, ref, maps, out, 2e-4)
+
+
+def test_four_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
+    """One train-mode forward + the four losses at B = 2 (batch statistics over two frames): f32 HIP against the
+    oracle, bf16 HIP against f32 HIP. Yardstick for f32 (as in test_train_gpu.py): the oracle evaluated in f64 is
+    the truth, and the oracle's OWN f32 evaluation shows how far f32 rounding moves a loss through ~200 train-mode
+    BatchNorm layers at these widths; the HIP f32 path must sit in that band (x4, floor 1e-3 relative).
+    Band for bf16: activations are rounded to 8 bits of mantissa after every layer; the loss values are sums over
+    ~10^5 locations and move by far less than that."""
+    import bench
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    from oracle import backbone as ob, head as oh, loss as ol
+    cfg = bench.model_cfg(4, 'f32')
+    hcfg = oracle_hcfg(cfg)
+    model = build(cfg, 0)
+    ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=2, seed=0)
+    ss = [ds[i] for i in range(2)]
+    img = torch.stack([s['img'] for s in ss])
+    gts = {k: [s[k] for s in ss] for k in ('gt_labels_3d', 'gt_poses_3d', 'centers2d', 'depths')}
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        bsd, nsd, hsd = [{k: (v.to(dt) if v.is_floating_point() else v) for k, v in d.items()} for d in split_sd(model)]
+        g = {k: [t.to(dt) if t.is_floating_point() else t for t in v] for k, v in gts.items()}
+        with torch.no_grad():
+            feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img.to(dt), 4, (3, 4, 6, 3), train=True), train=True)
+            outs = oh.head_forward(hsd, feats, hcfg, '', True)
+            ref[dt] = {k: float(v) for k, v in ol.head_loss(hsd, '', *outs, g, hcfg).items()}
+    data = collate(ss, device=DEV)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    with torch.no_grad():
+        l32 = {k: float(v) for k, v in model.train_step(data)['log_vars'].items()}
+    report = {k: (l32[k], ref[torch.float32][k], ref[torch.float64][k]) for k in ref[torch.float64]}
+    for k, truth in ref[torch.float64].items():
+        band = max(4 * abs(ref[torch.float32][k] - truth), 1e-3 * abs(truth)) + 1e-5
+        assert abs(l32[k] - truth) <= band, (k, report)
+    cfgb = bench.model_cfg(4, 'bf16')
+    mb = build(cfgb, 0)
+    mb.load_state_dict(sd0)
+    mb.to(DEV).train()
+    with torch.no_grad():
+        lbf = {k: float(v) for k, v in mb.train_step(data)['log_vars'].items()}
+    print('full-width 4-stage losses  hip f32 / oracle f32 / oracle f64:', report, ' hip bf16:', lbf)
+    for k in ref[torch.float64]:
+        assert abs(lbf[k] - l32[k]) <= 3e-2 * abs(l32[k]) + 1e-3, (k, lbf[k], l32[k])
+
+
+def test_bf16_decode_overlaps_f32_at_full_size():
+    """Same weights, same frames, 1-stage eval at 512 x 832: the poses the benchmarked bf16 path keeps are the poses
+    the f32 path keeps. bf16 rounding moves scores by ~1e-2 relative, so candidates near score_thr and near-duplicate
+    neighbours (OKS around nms_thr) may trade places: at least 90 % of the kept location indices must be shared
+    and the shared detections' joints agree within a few pixels."""
+    import bench
+    cfg32, cfgbf = bench.model_cfg(1, 'f32'), bench.model_cfg(1, 'bf16')
+    m32 = build(cfg32, 0)
+    sd0 = {k: v.clone() for k, v in m32.state_dict().items()}
+    mbf = build(cfgbf, 0)
+    mbf.load_state_dict(sd0)
+    m32.to(DEV).eval()
+    mbf.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(2, 3, bench.H, bench.W, generator=g).to(DEV)
+    metas = [dict(scale_factor=np.ones(4, dtype=np.float32), filename=str(i)) for i in range(2)]
+    bench.calibrate_scores(m32, img, metas, target=150)
+    with torch.no_grad():
+        mbf.bbox_head.conv_cls.bias.copy_(m32.bbox_head.conv_cls.bias)
+        res = []
+        for m in (m32, mbf):
+            c, p, k = m.bbox_head(m.extract_feat(img))
+            res.append(m.bbox_head.get_poses(c, p, k, metas, return_index=True))
+    shared = total = 0
+    for a, b in zip(*res):
+        ia, ib = a['index'].cpu().numpy().tolist(), b['index'].cpu().numpy().tolist()
+        assert len(ia) > 20
+        common = set(ia) & set(ib)
+        shared += len(common)
+        total += len(ia)
+        pa, pb = a['poses'].cpu().numpy(), b['poses'].cpu().numpy()
+        for idx in common:
+            d = np.abs(pa[ia.index(idx)][:, :2] - pb[ib.index(idx)][:, :2]).max()
+            assert d < 8.0, (idx, d)   # pixels, on 832 x 512 frames
+    assert shared >= 0.9 * total, (shared, total)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.das_abi_version() == 2 and lib.das_target_arch() == b'gfx950'
+    assert lib.das_abi_version() == 3 and lib.das_target_arch() == b'gfx950'
 
 
 def test_ops_refuse_cpu_tensors():
@@ -223,3 +223,16 @@ def test_lazy_log_vars_equal_the_eager_ones():
     assert float(loss_e) == 0.5 + (1.5 + 3.0) + 3.0
     got = lv_l.resolve()
     assert list(got) == list(lv_e) == ['loss_cls', 'loss_pose', 'acc', 'loss_depth', 'loss'] and got == lv_e
+
+
+@pytest.mark.parametrize('n,world', [(10, 4), (8, 4), (3, 4), (7, 2), (1, 3), (0, 2)])
+def test_multi_rank_result_collection_keeps_the_tail(n, world):
+    """tools/test.py: rank r evaluates samples r, r + world, ...; the collected list is the dataset order and keeps
+    every result also when len(dataset) % world != 0 (the reference pads the sampler and trims: tools/test.py:205-206)."""
+    from das_amd.datasets import collect_results
+    parts = [[dict(idx=i) for i in range(r, n, world)] for r in range(world)]
+    got = collect_results(parts, n)
+    assert [r['idx'] for r in got] == list(range(n))
+    # a sampler padded the reference's way (indices repeated up to a multiple of world) is trimmed to the dataset size
+    padded = [[dict(idx=i % max(n, 1)) for i in range(r, -(-n // world) * world, world)] for r in range(world)] if n else parts
+    assert [r['idx'] for r in collect_results(padded, n)] == list(range(n))

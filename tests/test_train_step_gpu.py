@@ -59,3 +59,71 @@ def test_bf16_and_f32_losses_agree():
         lbf = mbf.train_step(data)['log_vars']
     for k in l32:
         assert abs(l32[k] - lbf[k]) <= 0.08 * abs(l32[k]) + 0.05, (k, l32[k], lbf[k])
+
+
+def test_backward_that_raises_does_not_poison_the_next_step():
+    """A backward pass that raises half way (out of memory, an assert inside a Function) skips the autograd engine's
+    end-of-backward callbacks; the deferred weight-gradient queue and the 'callback queued' flags must not survive into
+    the next step (FlatSGD.zero_grad resets them, all_reduce_grads / step flush and join unconditionally): the step
+    after the failure produces the gradients of a clean run."""
+    from das_amd import autograd as ag
+    from das_amd.optim import FlatSGD
+    kw = dict(lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=35.0)
+    ref_model, data = make('f32')
+    ref = FlatSGD(ref_model, **kw)
+    ref.zero_grad()
+    ref_model.train_step(data, None)['loss'].backward()
+    ref.all_reduce_grads()
+    torch.cuda.synchronize()
+    g_ref = ref.flat_g.clone()
+    assert float(g_ref.abs().max()) > 0
+
+    model, _ = make('f32')
+    model.load_state_dict(ref_model.state_dict())
+    opt = FlatSGD(model, **kw)
+    opt.zero_grad()
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+
+    # fail in the middle of backward: the head's gradients (incl. queued weight gradients) are out, the backbone's are not
+    feats = model.extract_feat(data['img'])
+    feats = tuple(Boom.apply(f) for f in feats)
+    losses = model.bbox_head.forward_train(feats, data['img_metas'], *[data[k] for k in (
+        'gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths')])
+    loss = sum(v for k, v in losses.items() if 'loss' in k)
+    with pytest.raises(RuntimeError, match='boom'):
+        loss.backward()
+    assert ag._pending or ag._flush_queued[0] or any(e[2] for e in ag._side.values()), \
+        'the failed backward left nothing behind: the test no longer exercises the reset'
+    del feats, losses, loss
+
+    opt.zero_grad()
+    assert not ag._pending and not ag._flush_queued[0]
+    model.train_step(data, None)['loss'].backward()
+    opt.all_reduce_grads()
+    torch.cuda.synchronize()
+    assert not ag._pending
+    # run-to-run floor of a clean step (float atomics in the BatchNorm statistics reorder sums): a second clean model
+    clean, _ = make('f32')
+    clean.load_state_dict(ref_model.state_dict())
+    copt = FlatSGD(clean, **kw)
+    copt.zero_grad()
+    clean.train_step(data, None)['loss'].backward()
+    copt.all_reduce_grads()
+    torch.cuda.synchronize()
+    scale = float(g_ref.abs().max())
+    floor = float((copt.flat_g - g_ref).abs().max()) / scale
+    err = float((opt.flat_g - g_ref).abs().max()) / scale
+    # (stale weight-gradient operands added into this step would double the head's gradients: an O(1) error)
+    assert err < max(10 * floor, 2e-3), (err, floor)
+    # and the running statistics / parameters can still step
+    opt.step(2e-3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(opt.flat_p).all()

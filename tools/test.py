@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import das_amd  # noqa: E402
 from das_amd.config import parse_cfg_options  # noqa: E402
-from das_amd.datasets import build_dataset, collate  # noqa: E402
+from das_amd.datasets import build_dataset, collate, collect_results  # noqa: E402
 
 
 def parse_args():
@@ -86,7 +86,7 @@ def main():
     if distributed:
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, results)
-        results = [r for part in zip(*gathered) for r in part] if world > 1 else results
+        results = collect_results(gathered, len(dataset)) if world > 1 else results
     if rank == 0:
         n = sum(len(r['scores']) for r in results)
         print(f'{len(results)} images, {n} poses')
