@@ -69,3 +69,105 @@ def test_two_ranks_one_gpu_stay_in_lockstep():
     assert all(torch.isfinite(torch.tensor(l0))) and l0 == l1   # log vars are rank-averaged: identical
     torch.testing.assert_close(p0, p1, rtol=0, atol=0)  # same averaged gradients -> bit-identical parameters
     torch.testing.assert_close(b0, b1, rtol=0, atol=0)  # SyncBN layers normalised with the same (global) statistics
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Equivalence, not only consistency: the 2-rank step against a single process that owns BOTH ranks' samples.
+def _equiv_cfg():
+    from test_model_gpu import tiny_detector_cfg
+    cfg = tiny_detector_cfg()
+    cfg['backbone']['compute_dtype'] = 'f32'
+    cfg['backbone']['norm_cfg'] = dict(type='SyncBN')
+    cfg['neck']['norm_cfg'] = dict(type='SyncBN')
+    return cfg
+
+
+_LR = 1.0    # (with the clip at 0.05 the step has norm 0.05: far above the f32 resolution of the parameters)
+_OPT = dict(lr=_LR, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=0.05,
+            bucket_mb=1, overlap=True)   # (max_grad_norm far below the gradient norm: the clip is ACTIVE)
+
+
+def _equiv_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        probe = torch.ones(4, device='cuda')
+        dist.all_reduce(probe)
+    except Exception as e:
+        ret[rank] = ('skip', repr(e))
+        dist.destroy_process_group()
+        return
+    import das_amd
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    from das_amd.optim import FlatSGD, train_iteration
+    torch.manual_seed(0)
+    model = das_amd.build_model(_equiv_cfg())
+    model.init_weights()
+    model.to('cuda').train()
+    opt = FlatSGD(model, **_OPT)
+    ds = SyntheticPoseDataset(num_joints=15, img_shape=(128, 192), length=8, seed=3, max_persons=3)
+    data = collate([ds[rank * 2 + i] for i in range(2)], device='cuda')
+    train_iteration(model, opt, data, _LR)
+    torch.cuda.synchronize()
+    names = [n for n, _ in model.named_parameters()]
+    ret[rank] = ('ok', {n: p.detach().cpu() for n, p in model.named_parameters()},
+                 {n: b.detach().cpu() for n, b in model.named_buffers() if 'running' in n}, names)
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_the_single_process_step_on_the_concatenated_batch():
+    """Data parallelism must be invisible: rank r takes samples 2r, 2r + 1 (SyncBN everywhere, gradient mean folded
+    into the fused SGD kernel, global-norm clip ACTIVE on the averaged gradient, buckets overlapped with backward).
+    One process then runs the same four samples: backbone + neck on the whole batch (plain BatchNorm over 4 samples
+    == SyncBN over 2 x 2), the head's loss per half (the loss normalisers — positives, visible joints — are per rank
+    in data-parallel training, reference and here alike), mean of the two. Parameters after the step and the
+    SyncBN running statistics agree to f32 rounding."""
+    mp.set_start_method('spawn', force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 32500 + os.getpid() % 1000
+    mp.spawn(_equiv_worker, args=(2, port, ret), nprocs=2, join=True)
+    if ret[0][0] == 'skip':
+        pytest.skip('gloo cannot all-reduce device tensors in this build: ' + ret[0][1])
+    import das_amd
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    from das_amd.optim import FlatSGD
+    torch.manual_seed(0)
+    model = das_amd.build_model(_equiv_cfg())
+    model.init_weights()
+    model.to('cuda').train()
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    assert bns and all(getattr(m, '_das_sync', False) for m in bns), 'a BatchNorm layer of this config is not SyncBN'
+    init = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt = FlatSGD(model, **{**_OPT, 'overlap': False})
+    ds = SyntheticPoseDataset(num_joints=15, img_shape=(128, 192), length=8, seed=3, max_persons=3)
+    samples = [ds[i] for i in range(4)]
+    whole = collate(samples, device='cuda')
+    opt.zero_grad()
+    feats = model.extract_feat(whole['img'])
+    total = 0
+    for half in (slice(0, 2), slice(2, 4)):
+        part = collate(samples[half], device='cuda')
+        losses = model.bbox_head.forward_train(tuple(f[half] for f in feats), part['img_metas'], *[part[k] for k in (
+            'gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths')])
+        total = total + sum(v for k, v in losses.items() if 'loss' in k)
+    (total / 2).backward()
+    opt.all_reduce_grads()
+    opt.step(_LR)
+    torch.cuda.synchronize()
+    (_, p0, b0, names), (_, p1, b1, _) = ret[0], ret[1]
+    rows, step = [], 0.0
+    for n, p in model.named_parameters():
+        assert torch.equal(p0[n], p1[n]), n
+        moved = float((p.detach() - init[n]).abs().max())
+        err = float((p.detach().cpu() - p0[n]).abs().max())
+        step = max(step, moved)
+        rows.append((err, moved, n))
+    # (relative to how far the step moved the tensor — floor: 1 % of the largest move of any tensor; f32 summation
+    # order of statistics and gradients differs between the two runs)
+    bad = sorted(((e / max(m, 1e-2 * step), e, m, n) for e, m, n in rows), reverse=True)[:6]
+    assert bad[0][0] < 2e-2, bad
+    for n, b in model.named_buffers():
+        if 'running' in n:
+            torch.testing.assert_close(b.detach().cpu(), b0[n], rtol=1e-4, atol=1e-6)
