@@ -9,7 +9,6 @@ Both read the COCO-style json the reference's converters write (mytools/panoptic
 `_parse_ann_info`; `evaluate(outputs, res_folder)` takes the detector's `simple_test` outputs, writes
 `result_keypoints.json` and returns the metric dict. Image loading / augmentation lives in `das_amd.pipelines`.
 """
-import copy
 import json
 import os
 from collections import OrderedDict, defaultdict
@@ -102,19 +101,61 @@ class _PoseCocoDataset:
         E.write_keypoint_results(results, os.path.join(res_folder, 'result_keypoints.json'))
         return results
 
-    def _finish_targets(self, gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore):
-        if gt_bboxes:
-            out = dict(bboxes=np.array(gt_bboxes, dtype=np.float32), labels=np.array(gt_labels, dtype=np.int64),
-                       gt_poses_3d=np.array(gt_poses_3d, dtype=np.float32),
-                       centers2d=np.array(centers2d, dtype=np.float32), depths=np.array(depths, dtype=np.float32))
-        else:
-            out = dict(bboxes=np.zeros((0, 4), dtype=np.float32), labels=np.array([], dtype=np.int64),
-                       gt_poses_3d=np.zeros((0, 3 + self.num_joints * 4), dtype=np.float32),
-                       centers2d=np.zeros((0, 2), dtype=np.float32), depths=np.zeros((0), dtype=np.float32))
-        out['gt_labels_3d'] = copy.deepcopy(out['labels'])
-        out['bboxes_ignore'] = np.array(gt_bboxes_ignore, dtype=np.float32) if gt_bboxes_ignore \
-            else np.zeros((0, 4), dtype=np.float32)
-        return out
+    IGNORE = 'ignore'     # a record that only marks a region (crowd, root joint not annotated)
+
+    def _collect_persons(self, img_info, ann_info, person_of, need_area=True):
+        """One pass over an image's annotation records -> the target arrays of the sample. `person_of(ann, xywh)` is
+        the dataset's reading of one record: None (not a training person), IGNORE (its box goes to bboxes_ignore) or
+        (root (3,), joints (J, 3), vis (J,)) with root = [u, v, depth] of the person's centre. A row of gt_poses_3d is
+        [root | J x (u, v, dz) | J x vis] — the layout DASHead's target assignment reads (das_head.py:488-650);
+        centers2d / depths are the root's columns."""
+        boxes, labels, rows, ignored = [], [], [], []
+        for ann in ann_info:
+            if ann.get('ignore', False) or not self._box_ok(ann, img_info, need_area):
+                continue
+            x, y, w, h = ann['bbox']
+            person = self.IGNORE if ann.get('iscrowd', False) else person_of(ann, (x, y, w, h))
+            if person is None:
+                continue
+            if isinstance(person, str):
+                ignored.append([x, y, x + w, y + h])
+                continue
+            boxes.append([x, y, x + w, y + h])
+            labels.append(self.cat2label[ann['category_id']])
+            rows.append(np.concatenate([np.asarray(part, dtype=float).reshape(-1) for part in person]))
+        table = np.array(rows, dtype=np.float32).reshape(len(rows), 3 + self.num_joints * 4)
+        labels = np.array(labels, dtype=np.int64)
+        return dict(bboxes=np.array(boxes, dtype=np.float32).reshape(len(rows), 4), labels=labels,
+                    gt_poses_3d=table, centers2d=table[:, :2].copy(), depths=table[:, 2].copy(),
+                    gt_labels_3d=labels.copy(), bboxes_ignore=np.array(ignored, dtype=np.float32).reshape(len(ignored), 4))
+
+    def _camera_person(self, joints, vis, focal, xywh):
+        """A person annotated in camera space, joints = (J, 3) [u, v, Z] (edited in place), for the 3-D datasets:
+        Z / depth_factor / focal length (`norm_depth`: depth in units of the focal length, so that it survives image
+        resizing), joint depths relative to the root (`abs_dz`), the root joint — or the box centre — as the person's
+        centre. Degenerate annotations (all coordinates within 10 units) are dropped, a person whose root joint is
+        not annotated only marks its box as ignored."""
+        depth, rel = joints[:, 2], None
+        if self.norm_depth:
+            depth /= self.depth_factor
+            if self.abs_dz:
+                rel = depth - depth[[self.ROOT_IDX]]
+            depth /= focal
+        if joints.max() - joints.min() < 10:
+            return None
+        root = joints[self.ROOT_IDX].copy()
+        if self.use_bbox_center:
+            x, y, w, h = xywh
+            root[0], root[1] = x + 0.5 * w, y + 0.5 * h
+        elif vis[self.ROOT_IDX] == 0:
+            return self.IGNORE
+        if rel is not None:
+            joints[:, 2] = rel
+        return root, joints, vis
+
+    def _enough_visible(self, ann):
+        """training samples need six visible joints over all persons (the reference's datasets re-draw otherwise)"""
+        return ann['gt_poses_3d'][:, 3 + self.num_joints * 3:].sum() >= 6
 
     def _box_ok(self, ann, img_info, need_area=True):
         x1, y1, w, h = ann['bbox']
@@ -147,48 +188,16 @@ class CMUPanopticDataset(_PoseCocoDataset):
         self.use_bbox_center = use_bbox_center
 
     def _parse_ann_info(self, img_info, ann_info):
-        """cmupanoptic_mono_dataset.py:166-264: depth / f (and / depth_factor), dz relative to the root (abs_dz), the
-        root joint as the centre; persons whose root is invisible go to bboxes_ignore."""
+        """Targets of one frame (what cmupanoptic_mono_dataset.py:166-264 computes): joints3d_img = [u, v, Z_cam], focal
+        length = geometric mean of fx, fy; see `_camera_person`."""
         K = img_info['cam']['K']
-        f = np.sqrt(K[0][0] * K[1][1])
-        gt_bboxes, gt_labels, gt_poses_3d, gt_bboxes_ignore, centers2d, depths = [], [], [], [], [], []
-        for ann in ann_info:
-            if ann.get('ignore', False) or not self._box_ok(ann, img_info):
-                continue
-            x1, y1, w, h = ann['bbox']
-            bbox = [x1, y1, x1 + w, y1 + h]
-            if ann.get('iscrowd', False):
-                gt_bboxes_ignore.append(bbox)
-                continue
-            pose_3d = np.array(ann['joints3d_img'], dtype=float)
-            pose_vis = ann['joints2d_vis']
-            if self.norm_depth:
-                pose_3d[:, 2] /= self.depth_factor
-                if self.abs_dz:
-                    abs_dz = pose_3d[:, 2] - pose_3d[[self.ROOT_IDX], 2]
-                pose_3d[:, 2] /= f
-            if pose_3d.max() - pose_3d.min() < 10:
-                continue
-            if not self.use_bbox_center:
-                if pose_vis[self.ROOT_IDX][0] == 0:
-                    gt_bboxes_ignore.append(bbox)
-                    continue
-                c2d = pose_3d[self.ROOT_IDX].copy()
-            else:
-                c2d = pose_3d[self.ROOT_IDX].copy()
-                c2d[0], c2d[1] = x1 + 0.5 * w, y1 + 0.5 * h
-            gt_bboxes.append(bbox)
-            gt_labels.append(self.cat2label[ann['category_id']])
-            if self.abs_dz:
-                pose_3d[:, 2] = abs_dz
-            gt_poses_3d.append(np.concatenate([np.array(c2d, dtype=float).reshape(-1), pose_3d.reshape(-1),
-                                               np.array(pose_vis, dtype=float)[:, 0].reshape(-1)]))
-            centers2d.append(c2d[:2])
-            depths.append(c2d[2])
-        if not gt_bboxes and not self.test_mode:
-            return None
-        ann = self._finish_targets(gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore)
-        if ann['gt_poses_3d'][:, 3 + self.num_joints * 3:].sum() < 6 and not self.test_mode:
+        focal = np.sqrt(K[0][0] * K[1][1])
+
+        def person_of(ann, xywh):
+            return self._camera_person(np.array(ann['joints3d_img'], dtype=float),
+                                       np.array(ann['joints2d_vis'], dtype=float)[:, 0], focal, xywh)
+        ann = self._collect_persons(img_info, ann_info, person_of)
+        if not self.test_mode and (len(ann['labels']) == 0 or not self._enough_visible(ann)):
             return None
         if 'cam' in img_info:
             ann['cam'] = img_info['cam']
@@ -238,49 +247,17 @@ class MuPots3DHP(_PoseCocoDataset):
             assert norm_depth
 
     def _parse_ann_info(self, img_info, ann_info):
-        """mupots_3dhp.py:67-175: pseudo camera from `intrinsic`, joints = [u, v, Z_cam]."""
-        intrinsic = img_info['intrinsic']
-        f, c = intrinsic[:2], intrinsic[2:]
-        cam = dict(K=np.array([[f[0], 0., c[0]], [0., f[1], c[1]]]), R=np.eye(3), t=np.zeros((3, 1)))
-        gt_bboxes, gt_labels, gt_poses_3d, gt_bboxes_ignore, centers2d, depths = [], [], [], [], [], []
-        for ann in ann_info:
-            if ann.get('ignore', False) or not self._box_ok(ann, img_info, need_area=False):
-                continue
-            x1, y1, w, h = ann['bbox']
-            bbox = [x1, y1, x1 + w, y1 + h]
-            if ann.get('iscrowd', False):
-                gt_bboxes_ignore.append(bbox)
-                continue
-            pose_img = np.array(ann['keypoints_img'], dtype=float)
-            pose_cam = np.array(ann['keypoints_cam'], dtype=float)
-            pose_3d = np.concatenate([pose_img, pose_cam[:, 2:]], axis=1)
-            pose_vis = ann['keypoints_vis']
-            if self.norm_depth:
-                pose_3d[:, 2] /= self.depth_factor
-                if self.abs_dz:
-                    abs_dz = pose_3d[:, 2] - pose_3d[[self.ROOT_IDX], 2]
-                pose_3d[:, 2] /= np.sqrt(f[0] * f[1])
-            center = pose_3d[self.ROOT_IDX].copy()
-            if pose_3d.max() - pose_3d.min() < 10:
-                continue
-            if not self.use_bbox_center:
-                if pose_vis[self.ROOT_IDX][0] == 0:
-                    gt_bboxes_ignore.append(bbox)
-                    continue
-                c2d = center
-            else:
-                c2d = center.copy()
-                c2d[0], c2d[1] = x1 + 0.5 * w, y1 + 0.5 * h
-            gt_bboxes.append(bbox)
-            gt_labels.append(self.cat2label[ann['category_id']])
-            if self.abs_dz:
-                pose_3d[:, 2] = abs_dz
-            gt_poses_3d.append(np.concatenate([np.array(c2d, dtype=float).reshape(-1), pose_3d.reshape(-1),
-                                               np.array(pose_vis, dtype=float).reshape(-1)]))
-            centers2d.append(c2d[:2])
-            depths.append(c2d[2])
-        ann = self._finish_targets(gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore)
-        ann['cam'] = cam
+        """Targets of one frame (what mupots_3dhp.py:67-175 computes): pseudo camera from `intrinsic` = (fx, fy, cx, cy),
+        joints = [u, v, Z_cam] from keypoints_img / keypoints_cam."""
+        f, c = img_info['intrinsic'][:2], img_info['intrinsic'][2:]
+        focal = np.sqrt(f[0] * f[1])
+
+        def person_of(ann, xywh):
+            uv, cam_xyz = np.array(ann['keypoints_img'], dtype=float), np.array(ann['keypoints_cam'], dtype=float)
+            return self._camera_person(np.concatenate([uv, cam_xyz[:, 2:]], axis=1),
+                                       np.array(ann['keypoints_vis'], dtype=float).reshape(-1), focal, xywh)
+        ann = self._collect_persons(img_info, ann_info, person_of, need_area=False)
+        ann['cam'] = dict(K=np.array([[f[0], 0., c[0]], [0., f[1], c[1]]]), R=np.eye(3), t=np.zeros((3, 1)))
         return ann
 
     def evaluate(self, outputs, res_folder='tmp', metric='pck', eval_mode='all', **kwargs):
@@ -351,55 +328,21 @@ class MuCo3DHPDataset(_PoseCocoDataset):
             self.data_infos = [self.data_infos[i] for i in keep]
 
     def _parse_ann_info(self, img_info, ann_info):
-        """muco_3dhp.py:124-246: joints = [u, v, Z_cam], depth / sqrt(fx fy) (and / depth_factor), dz relative to the
-        root with abs_dz; persons whose root is invisible go to bboxes_ignore."""
+        """Targets of one composited frame (what muco_3dhp.py:124-246 computes): pseudo camera from the per-image focal
+        length `f` and principal point `c` (axes: MuCo's y-up world), joints = [u, v, Z_cam]."""
         f, c = img_info['f'], img_info['c']
-        cam = dict(K=np.array([[f[0], 0., c[0]], [0., f[1], c[1]]]),
-                   R=np.array([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]]), t=np.array([[0.], [0.], [0.]]))
-        gt_bboxes, gt_labels, gt_poses_3d, gt_bboxes_ignore, centers2d, depths = [], [], [], [], [], []
-        for ann in ann_info:
-            if ann.get('ignore', False) or not self._box_ok(ann, img_info, need_area=False):
-                continue
-            x1, y1, w, h = ann['bbox']
-            bbox = [x1, y1, x1 + w, y1 + h]
-            if ann.get('iscrowd', False):
-                gt_bboxes_ignore.append(bbox)
-                continue
-            pose_img = np.array(ann['keypoints_img'], dtype=float)
-            pose_cam = np.array(ann['keypoints_cam'], dtype=float)
-            pose_3d = np.concatenate([pose_img, pose_cam[:, 2:]], axis=1)
-            pose_vis = ann['keypoints_vis']
-            if self.norm_depth:
-                pose_3d[:, 2] /= self.depth_factor
-                if self.abs_dz:
-                    abs_dz = pose_3d[:, 2] - pose_3d[[self.ROOT_IDX], 2]
-                pose_3d[:, 2] /= np.sqrt(f[0] * f[1])
-            center = pose_3d[self.ROOT_IDX].copy()
-            if pose_3d.max() - pose_3d.min() < 10:
-                continue
-            if not self.use_bbox_center:
-                if pose_vis[self.ROOT_IDX] == 0:
-                    gt_bboxes_ignore.append(bbox)
-                    continue
-                c2d = pose_3d[self.ROOT_IDX].copy()
-            else:
-                c2d = center.copy()
-                c2d[0], c2d[1] = x1 + 0.5 * w, y1 + 0.5 * h
-            gt_bboxes.append(bbox)
-            gt_labels.append(self.cat2label[ann['category_id']])
-            if self.abs_dz:
-                pose_3d[:, 2] = abs_dz
-            gt_poses_3d.append(np.concatenate([np.array(c2d, dtype=float).reshape(-1), pose_3d.reshape(-1),
-                                               np.array(pose_vis, dtype=float).reshape(-1)]))
-            centers2d.append(c2d[:2])
-            depths.append(c2d[2])
-        if not gt_bboxes and not self.test_mode:
+        focal = np.sqrt(f[0] * f[1])
+
+        def person_of(ann, xywh):
+            uv, cam_xyz = np.array(ann['keypoints_img'], dtype=float), np.array(ann['keypoints_cam'], dtype=float)
+            return self._camera_person(np.concatenate([uv, cam_xyz[:, 2:]], axis=1),
+                                       np.array(ann['keypoints_vis'], dtype=float).reshape(-1), focal, xywh)
+        ann = self._collect_persons(img_info, ann_info, person_of, need_area=False)
+        if not self.test_mode and (len(ann['labels']) == 0 or not self._enough_visible(ann)):
             return None
-        out = self._finish_targets(gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore)
-        if out['gt_poses_3d'][:, 3 + self.num_joints * 3:].sum() < 6 and not self.test_mode:
-            return None
-        out['cam'] = cam
-        return out
+        ann['cam'] = dict(K=np.array([[f[0], 0., c[0]], [0., f[1], c[1]]]),
+                          R=np.array([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]]), t=np.array([[0.], [0.], [0.]]))
+        return ann
 
     def evaluate(self, *a, **k):
         raise NotImplementedError      # (as in the reference, muco_3dhp.py:248-249)
@@ -425,53 +368,45 @@ class COCOKeypointsDataset(_PoseCocoDataset):
         self.name2id = {os.path.basename(self.coco.load_imgs([i])[0]['file_name']): i for i in self.img_ids}
 
     def _parse_ann_info(self, img_info, ann_info):
-        """coco_keypoints_dataset.py:133-287."""
-        gt_bboxes, gt_labels, gt_poses_3d, gt_bboxes_ignore, centers2d, depths = [], [], [], [], [], []
-        for ann in ann_info:
-            if ann.get('ignore', False) or not self._box_ok(ann, img_info):
-                continue
-            x1, y1, w, h = ann['bbox']
-            bbox = [x1, y1, x1 + w, y1 + h]
-            if ann.get('iscrowd', False):
-                gt_bboxes_ignore.append(bbox)
-                continue
-            keypoints = np.array(ann['keypoints']).reshape(self.num_joints, 3)
-            pose_vis = (keypoints[..., 2] > 0).astype(float)
-            bbox_np = np.array(bbox, dtype=float).reshape(2, 2)
-            bbox_np[:, 0] = bbox_np[:, 0].clip(0, img_info['width'] - 1)
-            bbox_np[:, 1] = bbox_np[:, 1].clip(0, img_info['height'] - 1)
-            bbox_wh = bbox_np[1, :] - bbox_np[0, :]
-            if (bbox_wh < 2).any() or bbox_wh.prod() < 64:
-                continue
-            pose_3d = keypoints.copy()
-            pose_3d[..., 2] = 0
-            if not self.use_bbox_center:
-                if pose_vis[11] == 0 or pose_vis[12] == 0:      # both hips must be annotated (:186-194)
-                    continue
-                c2d = 0.5 * (pose_3d[11] + pose_3d[12])
+        """Targets of one COCO image (what coco_keypoints_dataset.py:133-287 computes): 2-D-only persons (every depth
+        0), centre = midpoint of the hips (both must be annotated) or the clipped box centre; boxes under 2 px a side
+        or 64 px2 are dropped; optionally re-indexed into the MuCo / Panoptic joint set."""
+        lim = np.array([img_info['width'] - 1, img_info['height'] - 1], dtype=float)
+        L_HIP, R_HIP = self.JOINTS_DEF['left_hip'], self.JOINTS_DEF['right_hip']
+
+        def person_of(ann, xywh):
+            x, y, w, h = xywh
+            kp = np.array(ann['keypoints']).reshape(self.num_joints, 3)
+            vis = (kp[..., 2] > 0).astype(float)
+            corners = np.array([x, y, x + w, y + h], dtype=float).reshape(2, 2)
+            corners[:, 0] = corners[:, 0].clip(0, lim[0])
+            corners[:, 1] = corners[:, 1].clip(0, lim[1])
+            side = corners[1] - corners[0]
+            if (side < 2).any() or side.prod() < 64:
+                return None
+            joints = kp.copy()
+            joints[..., 2] = 0
+            if self.use_bbox_center:
+                root = np.zeros(3, dtype=float)
+                root[:2] = corners.mean(0)
+            elif vis[L_HIP] == 0 or vis[R_HIP] == 0:
+                return None
             else:
-                c2d = np.zeros(3, dtype=float)
-                c2d[:2] = bbox_np.mean(0)
-            gt_bboxes.append(bbox)
-            gt_labels.append(self.cat2label[ann['category_id']])
-            gt_poses_3d.append(np.concatenate([np.array(c2d, dtype=float).reshape(-1),
-                                               np.array(pose_3d, dtype=float).reshape(-1), np.array(pose_vis, dtype=float)]))
-            centers2d.append(c2d[:2])
-            depths.append(c2d[2])
-        if not gt_bboxes:
+                root = 0.5 * (joints[L_HIP] + joints[R_HIP])
+            return root, joints, vis
+        out = self._collect_persons(img_info, ann_info, person_of)
+        if len(out['labels']) == 0:
             return None
-        out = self._finish_targets(gt_bboxes, gt_labels, gt_poses_3d, centers2d, depths, gt_bboxes_ignore)
         if self.convert_ids is not None:
-            cids = np.array(self.CONVERT[self.convert_ids], dtype=np.int64)
-            g = out['gt_poses_3d']
-            uvd = g[:, 3:3 + self.num_joints * 3].reshape(-1, self.num_joints, 3)
+            src = np.array(self.CONVERT[self.convert_ids], dtype=np.int64)    # target joint -> COCO joint, -1 = none
+            have = src >= 0
+            g, n = out['gt_poses_3d'], len(out['labels'])
+            uvd = g[:, 3:3 + self.num_joints * 3].reshape(n, self.num_joints, 3)
             vis = g[:, 3 + self.num_joints * 3:]
-            n = uvd.shape[0]
-            e_uvd = np.zeros((n, len(cids), 3), dtype=np.float32)
-            e_vis = np.zeros((n, len(cids)), dtype=np.float32)
-            e_uvd[:, cids >= 0] = uvd[:, cids[cids >= 0]]
-            e_vis[:, cids >= 0] = vis[:, cids[cids >= 0]]
-            out['gt_poses_3d'] = np.concatenate([g[:, :3], e_uvd.reshape(n, -1), e_vis], axis=1).astype(np.float32)
-            if e_vis.sum() < 6:
+            new_uvd = np.zeros((n, len(src), 3), dtype=np.float32)
+            new_vis = np.zeros((n, len(src)), dtype=np.float32)
+            new_uvd[:, have], new_vis[:, have] = uvd[:, src[have]], vis[:, src[have]]
+            out['gt_poses_3d'] = np.concatenate([g[:, :3], new_uvd.reshape(n, -1), new_vis], axis=1).astype(np.float32)
+            if new_vis.sum() < 6:
                 return None
         return out
