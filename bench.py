@@ -86,8 +86,8 @@ def calibrate_scores(model, img, metas, target=150):
 
 def host_cpu_info():
     """(threads to use, description): physical cores this process may run on — logical CPUs in the affinity mask,
-    capped by the cgroup CPU quota, divided by the SMT width — and the lscpu model name."""
-    import subprocess
+    capped by the cgroup CPU quota, divided by the SMT width — and the CPU model name. Read from /proc and /sys: this
+    runs after the process has initialised the GPU, where starting a child process (lscpu) is not something to risk."""
     logical = len(os.sched_getaffinity(0))
     quota = None
     try:
@@ -99,12 +99,23 @@ def host_cpu_info():
         pass
     model, tpc = 'unknown CPU', 1
     try:
-        for line in subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout.splitlines():
-            if line.startswith('Model name:'):
-                model = line.split(':', 1)[1].strip()
-            elif line.startswith('Thread(s) per core:'):
-                tpc = max(1, int(line.split(':', 1)[1]))
-    except (OSError, ValueError, subprocess.SubprocessError):
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        cpu0 = min(os.sched_getaffinity(0))
+        with open(f'/sys/devices/system/cpu/cpu{cpu0}/topology/thread_siblings_list') as f:
+            sib = f.read().strip()
+        n = 0
+        for part in sib.split(','):       # "0,128" or "0-1"
+            lo, _, hi = part.partition('-')
+            n += int(hi or lo) - int(lo) + 1
+        tpc = max(1, n)
+    except (OSError, ValueError):
         pass
     cores = max(1, logical // tpc)
     if quota is not None:
@@ -210,7 +221,15 @@ def cpu_baseline(workload, budget_s=30.0, full=False, threads=None):
 
 
 def roofline_from_profile(ops, run_step, dtype, reps=2):
-    """HIP events around every conv-family launch (forward, data-grad, weight-grad), on the launch stream."""
+    """HIP events around every launch of the conv families (forward, data gradient, the two weight-gradient kernel
+    classes) and of the BatchNorm passes, on the launch stream. Returns (roofline, roofline_mfma, roofline_hbm,
+    roofline_bn):
+      roofline       the family with the LARGEST TIME in the step (selection rule stated in the object), priced against
+                     the roof its own launch mix sits under: FLOP per algorithmic byte above the ridge
+                     (peak FLOP/s / peak B/s = 312 for bf16) -> dense MFMA peak, below -> HBM peak;
+      roofline_mfma  the family that carries the most algorithmic FLOPs among those above the ridge;
+      roofline_hbm   the conv family with the largest time among those below the ridge;
+      roofline_bn    the BatchNorm passes together (apply, backward apply, backward reduce + apply), HBM-bound."""
     # Kernel quality is measured with the kernels running one at a time: the weight gradients' side stream (which
     # overlaps them with the main stream in the timed region) is switched off for these passes, otherwise a launch's
     # event-to-event time would include whatever ran beside it.
@@ -225,40 +244,50 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
     fam = {}
     for ent in ops.PROFILE:
         tag, flops, e0, e1 = ent[:4]
-        f = fam.setdefault(tag, [0.0, 0.0, 0, 0.0])
+        f = fam.setdefault(tag, [0.0, 0.0, 0, 0.0, 0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3
-        f[2] += ent[5] if len(ent) > 5 else 1     # (a batched weight-gradient launch counts its ops)
+        f[2] += ent[5] if len(ent) > 5 else 1     # ops (a batched weight-gradient launch covers several)
         f[3] += ent[6] if len(ent) > 6 else 0.0   # algorithmic bytes: every operand once
+        f[4] += ent[7] if len(ent) > 7 else 1     # kernel launches
     ops.PROFILE = None
     if not fam:
-        return None, None
+        return None, None, None, None
     peak = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
     ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)    # FLOP per byte above which a launch mix is matrix-core bound
-    # `roofline`: the family that carries the most algorithmic FLOPs (training: the weight gradient, a third of the
-    # step's FLOPs — the kernel family the reviews track), against the dense MFMA peak.
-    tag, (fl, sec, cnt, by) = max(fam.items(), key=lambda kv: kv[1][0])
-    ach = fl / sec / 1e12
-    roof = dict(bound='mfma', kernel=tag, achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                traffic=None, launches_per_step=cnt // reps, avg_launch_us=round(sec / cnt * 1e6, 2),
-                family_ms_per_step=round(sec / reps * 1e3, 3),
-                algorithmic_mb_per_launch=round(by / cnt / 1e6, 2),
-                all_families={k: dict(tflops=round(v[0] / v[1] / 1e12, 2), gbs=round(v[3] / v[1] / 1e9, 1),
-                                      flop_per_byte=round(v[0] / max(v[3], 1.0), 1),
-                                      ms_per_step=round(v[1] / reps * 1e3, 3), launches=v[2] // reps)
-                              for k, v in fam.items()})
-    # `roofline_hbm`: the family with the largest time among the others whose launch mix sits below the ridge
-    # (training: the persistent 1x1 kernel of the expand / reduce convs), against the HBM peak.
-    below = {k: v for k, v in fam.items() if k != tag and v[3] > 0 and v[0] / v[3] < ridge}
-    roof_hbm = None
+
+    def entry(tag, v, rule):
+        fl, sec, nops, by, nl = v
+        mfma = by > 0 and fl / by >= ridge
+        ach = fl / sec / 1e12 if mfma else by / sec / 1e9
+        pk = peak if mfma else PEAK_HBM_GBS
+        return dict(bound='mfma' if mfma else 'hbm', kernel=tag, achieved=round(ach, 2 if mfma else 1), peak=pk,
+                    unit='TFLOP/s' if mfma else 'GB/s', frac=round(ach / pk, 4), traffic=None, selection=rule,
+                    launches_per_step=nl // reps, ops_per_step=nops // reps, avg_launch_us=round(sec / max(nl, 1) * 1e6, 2),
+                    family_ms_per_step=round(sec / reps * 1e3, 3), algorithmic_mb_per_launch=round(by / max(nl, 1) / 1e6, 2),
+                    flop_per_byte=round(fl / max(by, 1.0), 1), ridge_flop_per_byte=round(ridge, 1),
+                    tflops=round(fl / sec / 1e12, 2), gbs=round(by / sec / 1e9, 1))
+    conv = {k: v for k, v in fam.items() if v[0] > 0}
+    bn = {k: v for k, v in fam.items() if v[0] == 0}
+    tag, v = max(fam.items(), key=lambda kv: kv[1][1])
+    roof = entry(tag, v, 'largest time per step among the conv families and the BatchNorm passes')
+    roof['all_families'] = {k: dict(tflops=round(x[0] / x[1] / 1e12, 2), gbs=round(x[3] / x[1] / 1e9, 1),
+                                    flop_per_byte=round(x[0] / max(x[3], 1.0), 1), ms_per_step=round(x[1] / reps * 1e3, 3),
+                                    launches=x[4] // reps, ops=x[2] // reps) for k, x in fam.items()}
+    above = {k: x for k, x in conv.items() if x[3] > 0 and x[0] / x[3] >= ridge}
+    below = {k: x for k, x in conv.items() if x[3] > 0 and x[0] / x[3] < ridge}
+    roof_mfma = roof_hbm = roof_bn = None
+    if above:
+        t, x = max(above.items(), key=lambda kv: kv[1][0])
+        roof_mfma = entry(t, x, 'most algorithmic FLOPs among the families above the ridge')
     if below:
-        t2, (fl2, sec2, cnt2, by2) = max(below.items(), key=lambda kv: kv[1][1])
-        gbs = by2 / sec2 / 1e9
-        roof_hbm = dict(bound='hbm', kernel=t2, achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                        frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, launches_per_step=cnt2 // reps,
-                        avg_launch_us=round(sec2 / cnt2 * 1e6, 2), family_ms_per_step=round(sec2 / reps * 1e3, 3),
-                        algorithmic_mb_per_launch=round(by2 / cnt2 / 1e6, 2), flop_per_byte=round(fl2 / by2, 1))
-    return roof, roof_hbm
+        t, x = max(below.items(), key=lambda kv: kv[1][1])
+        roof_hbm = entry(t, x, 'largest time among the conv families below the ridge')
+    if bn:
+        tot = [sum(x[i] for x in bn.values()) for i in range(5)]
+        roof_bn = entry(' + '.join(sorted(bn)), tot, 'all BatchNorm passes of the step (forward apply, backward apply, '
+                        'backward reduce + apply); algorithmic bytes = every operand of every pass once')
+    return roof, roof_mfma, roof_hbm, roof_bn
 
 
 def attach_traffic(roof, workload, batch):
@@ -537,8 +566,8 @@ def main():
     else:
         extra['poses_per_step_rank0'] = sum(len(r['scores']) for r in res)
 
-    roof, roof_hbm = roofline_from_profile(ops, step, args.dtype)
-    for r in (roof, roof_hbm):
+    roof, roof_mfma, roof_hbm, roof_bn = roofline_from_profile(ops, step, args.dtype)
+    for r in (roof, roof_mfma, roof_hbm, roof_bn):
         if r is not None:
             attach_traffic(r, 'train' if train else 'infer', batch)
 
@@ -559,8 +588,9 @@ def main():
             'model_tflops': round(total_imgs * gflop / dt / 1e3, 2),
             'roofline': roof,
         }
-        if roof_hbm is not None:
-            out['roofline_hbm'] = roof_hbm
+        for key, r in (('roofline_mfma', roof_mfma), ('roofline_hbm', roof_hbm), ('roofline_bn', roof_bn)):
+            if r is not None:
+                out[key] = r
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload, full=args.cpu_baseline_full, threads=args.cpu_threads)

@@ -352,8 +352,32 @@ class BottleneckChainFn(Function):
             offs.append(o)
             o += 12 if blk.downsample is not None else 9
 
+        def deliver(bn, pi, dgamma, dbeta):
+            """LOCAL parameter gradients of a SyncBN layer (the gradient all-reduce sums the ranks' contributions)"""
+            ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
+            if ga is not None and ba is not None:
+                ga[1].add_(dgamma)
+                ba[1].add_(dbeta)
+                ga[0].fired()
+                ba[0].fired()
+            else:
+                grads[pi], grads[pi + 1] = dgamma, dbeta
+
         def finish_bn(bn, gamma, beta, pi, dz, raw, mean, invstd, sums):
             """apply pass of a layer whose dZ and sums are ready; parameter gradients -> flat accumulators or grads[]"""
+            world = _sync_world(bn)
+            if world > 1:
+                # SyncBN: the data-gradient epilogue reduced this rank's [sum dZ | sum dZ * xhat] (xhat from the global
+                # statistics); the apply pass needs the sums over ALL ranks' rows (what torch's SyncBatchNorm does with
+                # its all_reduce of sum_dy / sum_dy_xmu), the parameter gradients are the local sums
+                C_ = raw.shape[-1]
+                local = sums.view(-1, 2 * C_).sum(0)
+                glob = local.clone()
+                _all_reduce(glob)
+                rows = raw.numel() // C_
+                draw = ops.bn_backward_apply(dz, raw, mean, invstd, gamma, glob, stat_rows=rows * world)
+                deliver(bn, pi, local[C_:], local[:C_])
+                return draw
             ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
             direct = ga is not None and ba is not None
             draw = ops.bn_backward_apply(dz, raw, mean, invstd, gamma, sums,
@@ -368,6 +392,12 @@ class BottleneckChainFn(Function):
             return draw
 
         def classic_bn(bn, gamma, beta, pi, dyv, y, raw, mean, invstd, relu, want_dres):
+            world = _sync_world(bn)
+            if world > 1:
+                draw, dres, dgamma, dbeta = ops.bn_train_backward_sync(dyv, y, raw, mean, invstd, gamma, relu, want_dres,
+                                                                       beta, _all_reduce, world)
+                deliver(bn, pi, dgamma, dbeta)
+                return draw, dres
             ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
             direct = ga is not None and ba is not None
             draw, dres, dgamma, dbeta = ops.bn_train_backward(dyv, y, raw, mean, invstd, gamma, relu, want_dres, beta=beta,
@@ -443,8 +473,9 @@ class BottleneckChainFn(Function):
 
 
 def bottleneck_chain(x, blocks, skip_through=False):
-    """Run a layer of Bottlenecks through BottleneckChainFn if that applies (training, gradients on, plain BatchNorm —
-    SyncBN layers exchange their sums between the two backward phases and keep the per-unit path); else None.
+    """Run a layer of Bottlenecks through BottleneckChainFn if that applies (training, gradients on); else None.
+    SyncBN layers (any mix with plain ones: the reference's `_make_layer` makes only a layer's first block SyncBN) run
+    the same fused backward: the sums a data-gradient epilogue reduced are all-reduced before their apply pass.
     skip_through: returns (y, x) with x routed through the node for its other consumers."""
     blocks = list(blocks)
     bns = []
@@ -452,7 +483,7 @@ def bottleneck_chain(x, blocks, skip_through=False):
         bns += [b.bn1, b.bn2, b.bn3] + ([b.downsample.bn] if b.downsample is not None else [])
         if b.downsample is not None and (not getattr(b.downsample, 'norm_name', None) == 'bn' or b.downsample.with_activation):
             return None
-    if not all(bn.training for bn in bns) or any(_sync_world(bn) > 1 for bn in bns):
+    if not all(bn.training for bn in bns):
         return None
     if any(b.downsample is not None for b in blocks[1:]) or x.shape[-1] % 8:
         return None

@@ -1,0 +1,130 @@
+"""Batches prepared ahead of the trainer.
+
+The reference trains with `workers_per_gpu=4` (configs/das/exp_panoptic.py:159-160 -> mmdet `build_dataloader`: worker
+processes decode and augment on the CPU). Here augmentation already runs on the GPU (das_amd/pipelines.py), so what is
+left on the host is the JPEG decode and the annotation arithmetic; `PrefetchLoader` moves both off the training thread:
+
+  * `workers` background THREADS (PIL's decoder and the host-to-device copy release the GIL) build whole batches, each
+    on its own HIP stream: `dataset[i]` for every index of the batch — the pipeline's GPU kernels are queued on that
+    stream and run beside the training step —, `collate`, then an event;
+  * batches are handed over strictly in order; the consumer's current stream waits for the batch's event and the
+    tensors are registered with it (`record_stream`), so that the caching allocator cannot recycle them early;
+  * a sample the pipeline dropped (no valid person left after augmentation -> None) is replaced by the next index, as
+    mmdet's `CustomDataset._rand_another` re-draws;
+  * an exception in a worker is re-raised by the consumer at the batch it belongs to.
+
+With `workers=0` the same batches are built synchronously on the calling thread (what tools/train.py did before).
+Random draws come from the process-wide numpy / torch generators: with one worker the sample sequence is the
+synchronous one, with several it depends on thread timing (as it depends on worker seeds in the reference).
+"""
+import queue
+import threading
+
+import torch
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors(v)
+
+
+class PrefetchLoader:
+    def __init__(self, dataset, batches, collate_fn, device='cuda', workers=1, depth=2, max_redraws=100):
+        self.dataset, self.batches, self.collate_fn = dataset, [list(b) for b in batches], collate_fn
+        self.device = torch.device(device)
+        self.workers, self.depth, self.max_redraws = max(0, int(workers)), max(1, int(depth)), max_redraws
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _build(self, indices):
+        samples = []
+        for i in indices:
+            smp, tries = self.dataset[i], 0
+            while smp is None and tries < self.max_redraws:
+                i = (i + 1) % len(self.dataset)
+                smp, tries = self.dataset[i], tries + 1
+            if smp is None:
+                raise RuntimeError(f'no valid sample within {self.max_redraws} re-draws after index {i}')
+            samples.append(smp)
+        return self.collate_fn(samples, device=self.device)
+
+    def __iter__(self):
+        if self.workers == 0:
+            for b in self.batches:
+                yield self._build(b)
+            return
+        cuda = self.device.type == 'cuda'
+        if cuda and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        n = len(self.batches)
+        fatal = []          # an exception that killed a worker outside a batch (consumer re-raises it)
+        slots = [queue.Queue(maxsize=1) for _ in range(n)]       # one hand-over cell per batch: order is by index
+        ticket = iter(range(n))
+        lock, stop = threading.Lock(), threading.Event()
+        window = threading.Semaphore(self.workers + self.depth)   # batches built but not yet consumed
+
+        def work():
+            try:
+                run()
+            except BaseException as e:   # noqa: BLE001 — a dead worker must not leave the consumer waiting for ever
+                fatal.append(e)
+
+        def run():
+            if cuda:
+                torch.cuda.set_device(self.device)
+            stream = torch.cuda.Stream(device=self.device) if cuda else None
+            while not stop.is_set():
+                window.acquire()
+                if stop.is_set():
+                    return
+                with lock:
+                    k = next(ticket, None)
+                if k is None:
+                    return
+                try:
+                    if cuda:
+                        with torch.cuda.stream(stream):
+                            data = self._build(self.batches[k])
+                            ready = torch.cuda.Event()
+                            ready.record(stream)
+                    else:
+                        data, ready = self._build(self.batches[k]), None
+                    slots[k].put((data, ready, None))
+                except BaseException as e:   # noqa: BLE001 — handed to the consumer, which re-raises it
+                    slots[k].put((None, None, e))
+
+        threads = [threading.Thread(target=work, daemon=True, name=f'das-prefetch-{t}') for t in range(self.workers)]
+        for t in threads:
+            t.start()
+        try:
+            for k in range(n):
+                while True:
+                    try:
+                        data, ready, err = slots[k].get(timeout=0.2)
+                        break
+                    except queue.Empty:
+                        if fatal:
+                            raise RuntimeError('a prefetch worker died') from fatal[0]
+                        if not any(t.is_alive() for t in threads) and slots[k].empty():
+                            raise RuntimeError(f'all prefetch workers exited before batch {k} was built')
+                window.release()
+                if err is not None:
+                    raise err
+                if ready is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ready)
+                    for t in _tensors(data):
+                        if t.is_cuda:
+                            t.record_stream(cur)
+                yield data
+        finally:
+            stop.set()
+            for _ in threads:
+                window.release()

@@ -18,6 +18,26 @@ _DT = {torch.float32: _lib.DAS_F32, torch.bfloat16: _lib.DAS_BF16}
 PROFILE = None
 
 
+class _timed:
+    """bench.py's per-launch record for the non-conv families (BatchNorm passes): HIP events on the launch stream
+    around the call, when PROFILE is a list. nbytes = algorithmic bytes of the op (every operand of every pass once)."""
+
+    def __init__(self, tag, nbytes, launches=1):
+        self.tag, self.nbytes, self.launches = tag, float(nbytes), launches
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None and exc[0] is None:
+            self.e1.record()
+            PROFILE.append((self.tag, 0.0, self.e0, self.e1, ('bn',), 1, self.nbytes, self.launches))
+        return False
+
+
 class tuning:
     """Context manager over das_tuning_set: `with ops.tuning(**{'conv.glds4_minblocks': 1}): ...` (tests, A/B runs)."""
 
@@ -270,10 +290,11 @@ def bn_backward_apply(dz, raw, mean, invstd, gamma, sums, dgamma_acc=None, dbeta
     Cc = raw.shape[-1]
     rows = raw.numel() // Cc
     draw = torch.empty_like(raw)
-    _lib.check(_lib.load().das_bn_backward_apply(_ptr(dz), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean), _ptr(invstd),
-                                                 _ptr(gamma), _ptr(sums), sums.numel() // (2 * Cc), _ptr(draw),
-                                                 _ptr(dgamma_acc), _ptr(dbeta_acc), stat_rows or rows, _stream()),
-               'das_bn_backward_apply')
+    with _timed('bn_bwd_apply_dz_kernel', 3 * raw.numel() * raw.element_size()):     # dZ, raw -> d raw
+        _lib.check(_lib.load().das_bn_backward_apply(_ptr(dz), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean), _ptr(invstd),
+                                                     _ptr(gamma), _ptr(sums), sums.numel() // (2 * Cc), _ptr(draw),
+                                                     _ptr(dgamma_acc), _ptr(dbeta_acc), stat_rows or rows, _stream()),
+                   'das_bn_backward_apply')
     return draw
 
 
@@ -338,6 +359,15 @@ def _wgrad_desc(x, dy, KH, KW, stride, pad):
     return d, 2.0 * rows * Cout * KH * KW * Cin
 
 
+def _is_pp_wgrad(x, dy, KH, KW):
+    """Kernel class das_conv2d_wgrad_batch will pick for this op (csrc/train_ops.hip `classify`): the 256 x 256
+    ping-pong kernel for bf16 ops with K >= wgrad.pp_mink and Cout >= 256, the 128 x 128 kernel otherwise."""
+    mink = C.c_longlong()
+    _lib.load().das_tuning_get(b'wgrad.pp_mink', C.byref(mink))
+    xd, dyd = _data(x), _data(dy)
+    return xd.dtype == torch.bfloat16 and mink.value > 0 and KH * KW * xd.shape[-1] >= mink.value and dyd.shape[-1] >= 256
+
+
 def conv2d_wgrad_batch(items, accumulate=True):
     """items: [(x, dy, KH, KW, stride, pad, out)], out = f32 (Cout,KH,KW,Cin) buffers (distinct) the results are ADDED
     to (accumulate=False: written). One das_conv2d_wgrad_batch call: the ops of one kernel class share a persistent,
@@ -345,6 +375,15 @@ def conv2d_wgrad_batch(items, accumulate=True):
     n = len(items)
     if n == 0:
         return
+    if PROFILE is not None:
+        # measuring: one call per kernel class, so that the event pair around it times that kernel (+ its reduce pass)
+        # alone; the launches themselves are the ones the single call would have made
+        pp = [it for it in items if _is_pp_wgrad(it[0], it[1], it[2], it[3])]
+        rest = [it for it in items if not _is_pp_wgrad(it[0], it[1], it[2], it[3])]
+        if pp and rest:
+            conv2d_wgrad_batch(pp, accumulate)
+            conv2d_wgrad_batch(rest, accumulate)
+            return
     descs = (_lib.DasConvDesc * n)()
     xs, dys, dws = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
     flops, nby = 0.0, 0.0
@@ -363,8 +402,12 @@ def conv2d_wgrad_batch(items, accumulate=True):
                'das_conv2d_wgrad_batch')
     if PROFILE is not None:
         e1.record()
-        dt = 'bf16' if _data(items[0][0]).dtype == torch.bfloat16 else 'float'
-        PROFILE.append((f'conv_wgrad_kernel<{dt}>', flops, e0, e1, ('batch', n), n, nby))
+        x0, dy0, KH0, KW0 = items[0][:4]
+        dt = 'bf16' if _data(x0).dtype == torch.bfloat16 else 'float'
+        tag = 'conv_wgrad_pp_kernel' if _is_pp_wgrad(x0, dy0, KH0, KW0) else f'conv_wgrad_kernel<{dt}>'
+        plan = last_wgrad_plan()
+        # (tag, flops, events, shape key, ops in the launch, algorithmic bytes, kernel launches: + the reduce pass)
+        PROFILE.append((tag, flops, e0, e1, ('batch', n), n, nby, 1 + (1 if plan['partial'] > 0 else 0)))
 
 
 def colsum(x):
@@ -397,10 +440,15 @@ def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta=Non
     else:
         sums, prezeroed = torch.empty(2 * Cc, dtype=torch.float32, device=raw.device), 0
     assert not (relu and y is None and want_dres), 'the recomputed mask ignores a residual'
-    _lib.check(_lib.load().das_bn_train_backward(_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean),
-                                                 _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _ptr(draw),
-                                                 _ptr(dres), _ptr(sums), prezeroed, _ptr(dgamma_acc),
-                                                 _ptr(dbeta_acc), _stream()), 'das_bn_train_backward')
+    # two passes (the sums must be complete before anything can be applied): reduce reads dY, raw (, y); apply reads them
+    # again and writes d raw (, d residual)
+    nin = 3 if y is not None else 2
+    with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', (2 * nin + 1 + (1 if want_dres else 0)) * raw.numel() *
+                raw.element_size(), launches=2):
+        _lib.check(_lib.load().das_bn_train_backward(_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean),
+                                                     _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _ptr(draw),
+                                                     _ptr(dres), _ptr(sums), prezeroed, _ptr(dgamma_acc),
+                                                     _ptr(dbeta_acc), _stream()), 'das_bn_train_backward')
     return draw, dres, sums[Cc:], sums[:Cc]
 
 
@@ -590,12 +638,13 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     mean, invstd = mi[0], mi[1]
     if num_batches_tracked is not None:
         assert num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda
-    _lib.check(_lib.load().das_bn_train_apply(_ptr(x), _ptr(y), _DT[x.dtype], count, Cc, _ptr(stats), _ptr(gamma),
-                                              _ptr(beta), _ptr(running_mean), _ptr(running_var), momentum, eps,
-                                              _ptr(residual), int(relu), _ptr(mean), _ptr(invstd),
-                                              _ptr(num_batches_tracked), int(stat_count),
-                                              stats.numel() // (2 * Cc), _stream()),
-               'das_bn_train_apply')
+    with _timed('bn_apply_kernel', (3 if residual is not None else 2) * x.numel() * x.element_size()):
+        _lib.check(_lib.load().das_bn_train_apply(_ptr(x), _ptr(y), _DT[x.dtype], count, Cc, _ptr(stats), _ptr(gamma),
+                                                  _ptr(beta), _ptr(running_mean), _ptr(running_var), momentum, eps,
+                                                  _ptr(residual), int(relu), _ptr(mean), _ptr(invstd),
+                                                  _ptr(num_batches_tracked), int(stat_count),
+                                                  stats.numel() // (2 * Cc), _stream()),
+                   'das_bn_train_apply')
     return y, mean, invstd
 
 

@@ -325,32 +325,70 @@ class FlatSGD:
         bump_param_epoch()  # packed bf16 weight copies are rebuilt on the next forward
 
     # ------------------------------------------------------------------ checkpointing
-    def state_dict(self):
-        """Momentum buffers as dense tensors in the parameters' own (OIHW) shapes, keyed by parameter name, plus
-        the step count — enough to resume exactly (mmcv's checkpoint carries `optimizer` the same way,
-        tools/train.py:200-210 / CheckpointHook)."""
-        mom = {}
+    def _dense_momentum(self):
+        """name -> momentum buffer as a dense tensor of the parameter's own (OIHW) shape, on the host"""
+        out = {}
         for n, p, sl in zip(self._names, self._params, self.slots):
             m = self.flat_m[sl.off:sl.off + sl.numel]
             if sl.cl_shape is not None:
                 O, KH, KW, I = sl.cl_shape
                 m = m.view(O, KH, KW, I).permute(0, 3, 1, 2)
-            mom[n] = m.reshape(p.shape).detach().contiguous().cpu()
-        return dict(momentum_buffer=mom, steps=self.steps, base_lr=self.base_lr)
+            out[n] = m.reshape(p.shape).detach().contiguous().cpu()
+        return out
+
+    def state_dict(self):
+        """The layout `torch.optim.SGD.state_dict()` has for the reference's optimizer — mmcv's
+        DefaultOptimizerConstructor with `paramwise_cfg` makes one param group PER parameter, in
+        `model.named_parameters()` order — so that a checkpoint written here resumes upstream
+        (`runner.resume` -> `optimizer.load_state_dict`, tools/train.py:200-210) and an upstream checkpoint resumes here:
+        state[i]['momentum_buffer'] dense OIHW, param_groups[i] = lr / momentum / dampening / weight_decay / nesterov.
+        The step count and base lr ride along under `das_*` keys (torch ignores unknown top-level keys)."""
+        mom = self._dense_momentum()
+        order = [n for n, p in self.model.named_parameters() if p.requires_grad]
+        group_of = {}
+        for g in self.groups:
+            for n, sl in zip(self._names, self.slots):
+                if g['start'] <= sl.off < g['end']:
+                    group_of[n] = g
+        state, pgs = {}, []
+        for i, n in enumerate(order):
+            g = group_of[n]
+            if self.steps > 0:
+                state[i] = dict(momentum_buffer=mom[n])
+            pgs.append(dict(lr=self.base_lr * g['lr_mult'], initial_lr=self.base_lr * g['lr_mult'], momentum=self.momentum,
+                            dampening=0, weight_decay=g['wd'], nesterov=False, params=[i]))
+        return dict(state=state, param_groups=pgs, das_steps=self.steps, das_base_lr=self.base_lr, das_names=order)
 
     def load_state_dict(self, sd):
-        mom = sd['momentum_buffer']
+        """Accepts this class's layout, the reference's (torch SGD: `state` / `param_groups`, one group per parameter or
+        one group for all) and the round-2 layout of this repo (`momentum_buffer` by parameter name)."""
+        if 'momentum_buffer' in sd:
+            mom, steps = sd['momentum_buffer'], int(sd.get('steps', 1))
+        else:
+            order = [n for n, p in self.model.named_parameters() if p.requires_grad]
+            flat_ids = [i for g in sd['param_groups'] for i in g['params']]
+            if len(flat_ids) != len(order):
+                raise ValueError(f'optimizer state holds {len(flat_ids)} parameters, the model has {len(order)}')
+            mom = {}
+            for n, i in zip(order, flat_ids):
+                st = sd['state'].get(i, sd['state'].get(str(i)))
+                if st is not None and st.get('momentum_buffer') is not None:
+                    mom[n] = st['momentum_buffer']
+            steps = int(sd.get('das_steps', 1 if mom else 0))
         for n, p, sl in zip(self._names, self._params, self.slots):
-            if n not in mom:
-                raise KeyError(f'optimizer state has no momentum buffer for {n}')
-            m = mom[n].to(self.flat_m.device, torch.float32)
             dst = self.flat_m[sl.off:sl.off + sl.numel]
+            if n not in mom:
+                if 'momentum_buffer' in sd:
+                    raise KeyError(f'optimizer state has no momentum buffer for {n}')
+                dst.zero_()        # (torch creates a buffer at a parameter's first gradient: never stepped = none)
+                continue
+            m = mom[n].to(self.flat_m.device, torch.float32)
             if sl.cl_shape is not None:
                 O, KH, KW, I = sl.cl_shape
                 dst.view(O, KH, KW, I).copy_(m.permute(0, 2, 3, 1))
             else:
                 dst.copy_(m.reshape(-1))
-        self.steps = int(sd.get('steps', 1))
+        self.steps = steps
 
     def grad_norm(self):
         return float(torch.sqrt(T.grad_sumsq(self.flat_g)).item()) / self.world

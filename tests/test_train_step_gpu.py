@@ -127,3 +127,36 @@ def test_backward_that_raises_does_not_poison_the_next_step():
     opt.step(2e-3)
     torch.cuda.synchronize()
     assert torch.isfinite(opt.flat_p).all()
+
+
+def test_optimizer_state_is_torch_sgd_layout_both_ways():
+    """FlatSGD.state_dict() is what torch.optim.SGD (built the reference's way: mmcv paramwise_cfg -> one param group per
+    parameter, named_parameters order) loads, and what torch writes FlatSGD loads: checkpoints resume across the two
+    (the reference's `runner.resume` -> `optimizer.load_state_dict`)."""
+    from das_amd.optim import FlatSGD, train_iteration
+    kw = dict(lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=35.0)
+    model, data = make('f32')
+    opt = FlatSGD(model, **kw)
+    for _ in range(2):
+        train_iteration(model, opt, data, 2e-3)
+    torch.cuda.synchronize()
+    sd = opt.state_dict()
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    clones = [torch.nn.Parameter(p.detach().clone().contiguous()) for _, p in named]
+    topt = torch.optim.SGD([dict(params=[c]) for c in clones], lr=2e-3, momentum=0.9)
+    topt.load_state_dict(dict(state=sd['state'], param_groups=sd['param_groups']))
+    for i, ((n, p), c) in enumerate(zip(named, clones)):
+        buf = topt.state[c]['momentum_buffer']
+        assert buf.shape == p.shape, n
+        assert torch.equal(buf.cpu(), sd['state'][i]['momentum_buffer']), n
+    g = topt.param_groups[[n for n, _ in named].index('backbone.top.top.0.bn.bias')]
+    assert abs(g['lr'] - 4e-3) < 1e-12 and g['weight_decay'] == 0.0        # bias_lr_mult = 2, bias_decay_mult = 0
+    # ... and back: what torch writes, a fresh FlatSGD reads
+    model2, _ = make('f32')
+    opt2 = FlatSGD(model2, **kw)
+    opt2.load_state_dict(topt.state_dict())
+    assert torch.equal(opt2.flat_m, opt.flat_m)
+    # the round-2 layout of this repo still loads
+    opt3 = FlatSGD(make('f32')[0], **kw)
+    opt3.load_state_dict(dict(momentum_buffer=opt._dense_momentum(), steps=2, base_lr=2e-3))
+    assert torch.equal(opt3.flat_m, opt.flat_m) and opt3.steps == 2

@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import das_amd  # noqa: E402
 from das_amd.config import parse_cfg_options  # noqa: E402
-from das_amd.datasets import build_dataset, collate  # noqa: E402
+from das_amd.datasets import build_dataset, collate, collect_results  # noqa: E402
+from das_amd.loader import PrefetchLoader  # noqa: E402
 from das_amd.optim import build_optimizer, step_lr, train_iteration  # noqa: E402
 
 
@@ -37,6 +38,39 @@ def parse_args():
     p.add_argument('--autoscale-lr', action='store_true')
     p.add_argument('--max-iters', type=int, default=None, help='stop after this many iterations (smoke runs)')
     return p.parse_args()
+
+
+def validate(model, dataset, cfg, rank, world, work_dir):
+    """mmcv's (Dist)EvalHook as the reference wires it (tools/train.py:218 `validate=not args.no_validate` ->
+    mmdet `train_detector`; `evaluation = dict(interval=1)`, exp_panoptic.py:218): the validation set through the test
+    pipeline one image at a time, rank r taking samples r, r + world, ..., results collected in dataset order on
+    rank 0 and scored by the dataset's own evaluator (MPJPE / PCK, das_amd/evaluation.py)."""
+    was_training = model.training
+    model.eval()
+    results = []
+    with torch.no_grad():
+        for i in range(rank, len(dataset), world):
+            sample = dataset[i]
+            if isinstance(sample['img'], (list, tuple)):   # MultiScaleFlipAug: one entry per test-time augmentation
+                imgs = [t.unsqueeze(0).cuda() for t in sample['img']]
+                metas = [[m] for m in sample['img_metas']]
+            else:
+                data = collate([sample], device='cuda')
+                imgs, metas = [data['img']], [data['img_metas']]
+            for r in model(return_loss=False, rescale=True, img=imgs, img_metas=metas):
+                results.append({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in r.items()})
+    model.train(was_training)
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, results)
+        results = collect_results(gathered, len(dataset))
+    if rank != 0:
+        return None
+    ev = dict(cfg.get('evaluation', {}))
+    ev.pop('interval', None)
+    if hasattr(dataset, 'evaluate'):
+        return dataset.evaluate(results, res_folder=os.path.join(work_dir, 'val'), **ev)
+    return dict(images=len(results), poses=sum(len(r['scores']) for r in results))
 
 
 def main():
@@ -81,7 +115,14 @@ def main():
         start_epoch = ck.get('meta', {}).get('epoch', 0)
         it = ck.get('meta', {}).get('iter', 0)
 
+    val_dataset = None
+    eval_every = cfg.get('evaluation', {}).get('interval', 1)
+    if not args.no_validate and cfg.data.get('val') is not None:
+        val_cfg = dict(cfg.data.val)
+        val_cfg['test_mode'] = True
+        val_dataset = build_dataset(val_cfg)
     spg = cfg.data.get('samples_per_gpu', 4)
+    workers = cfg.data.get('workers_per_gpu', 0)
     lrc = cfg.get('lr_config', {})
     max_epochs = cfg.get('runner', {}).get('max_epochs', 12)
     log_every = cfg.get('log_config', {}).get('interval', 50)
@@ -95,15 +136,11 @@ def main():
         order = (order * (total // max(len(order), 1) + 1))[:total]
         order = order[rank::world]
         t0 = time.time()
-        for b in range(0, len(order), spg):
-            samples = []
-            for i in order[b:b + spg]:
-                smp, tries = dataset[i], 0
-                while smp is None and tries < 100:   # the pipeline dropped the sample (no valid person after augmentation):
-                    i = (i + 1) % len(dataset)       # take another one, as mmdet's CustomDataset._rand_another does
-                    smp, tries = dataset[i], tries + 1
-                samples.append(smp)
-            data = collate(samples, device='cuda')
+        # decode + GPU-side augmentation + collate run `workers_per_gpu` threads ahead of the training thread
+        loader = PrefetchLoader(dataset, [order[b:b + spg] for b in range(0, len(order), spg)], collate, device='cuda',
+                                workers=workers)
+        for bi, data in enumerate(loader):
+            b = bi * spg
             lr = step_lr(opt.base_lr, epoch, it, steps=lrc.get('step', (16, 20)), warmup_iters=lrc.get('warmup_iters', 0),
                          warmup_ratio=lrc.get('warmup_ratio', 1.0))
             out = train_iteration(model, opt, data, lr)
@@ -122,6 +159,10 @@ def main():
                             meta=dict(epoch=epoch + 1, iter=it, config=cfg.text, CLASSES=model.CLASSES,
                                       das_amd_version=das_amd.__version__)),
                        os.path.join(work_dir, f'epoch_{epoch + 1}.pth'))
+        if val_dataset is not None and (epoch + 1) % eval_every == 0:
+            metrics = validate(model, val_dataset, cfg, rank, world, work_dir)
+            if rank == 0:
+                print(f'Epoch(val) [{epoch + 1}] {metrics}', flush=True)
         if args.max_iters and it >= args.max_iters:
             break
     if distributed:
