@@ -149,8 +149,11 @@ def test_optimizer_state_is_torch_sgd_layout_both_ways():
         buf = topt.state[c]['momentum_buffer']
         assert buf.shape == p.shape, n
         assert torch.equal(buf.cpu(), sd['state'][i]['momentum_buffer']), n
+    # bias_lr_mult = 2 / bias_decay_mult = 0 reach conv biases, not the norm layers' (mmcv DefaultOptimizerConstructor)
+    g = topt.param_groups[[n for n, _ in named].index('bbox_head.conv_cls.bias')]
+    assert abs(g['lr'] - 4e-3) < 1e-12 and g['weight_decay'] == 0.0
     g = topt.param_groups[[n for n, _ in named].index('backbone.top.top.0.bn.bias')]
-    assert abs(g['lr'] - 4e-3) < 1e-12 and g['weight_decay'] == 0.0        # bias_lr_mult = 2, bias_decay_mult = 0
+    assert abs(g['lr'] - 2e-3) < 1e-12 and abs(g['weight_decay'] - 1e-4) < 1e-12
     # ... and back: what torch writes, a fresh FlatSGD reads
     model2, _ = make('f32')
     opt2 = FlatSGD(model2, **kw)

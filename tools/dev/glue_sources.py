@@ -26,17 +26,29 @@ want = ('aten::fill_', 'aten::zero_', 'aten::copy_', 'aten::add', 'aten::add_', 
         'aten::zeros', 'aten::clone', 'aten::contiguous', 'aten::_to_copy', 'aten::sum', 'aten::div', 'aten::sub')
 cnt = collections.Counter()
 nost = 0
+nostack = collections.Counter()
+stacks = {}
 for ev in prof.events():
     if ev.name not in want:
         continue
     st = ev.stack or []
     if not st:
         nost += 1
+        nostack[ev.name] += 1
         continue
     src = next((f for f in st if 'das_amd/' in f), None)
     if src is None:
         src = st[0]
     cnt[(ev.name, src.split('das_amd/')[-1][:80])] += 1
+    stacks.setdefault((ev.name, src.split('das_amd/')[-1][:80]), st)
 print('events without a stack:', nost)
 for (name, src), n in cnt.most_common(45):
     print(f'{n:4d}  {name:18s} {src}')
+print('--- events without a stack (the autograd engine thread), by op:')
+for name, n in nostack.most_common(12):
+    print(f'{n:4d}  {name}')
+print('--- full stacks of the top entries')
+for (name, src), n in cnt.most_common(8):
+    print(f'== {n} x {name} @ {src}')
+    for f in stacks[(name, src)][:14]:
+        print('     ', f[-110:])

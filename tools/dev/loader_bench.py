@@ -91,7 +91,7 @@ def main():
     order = [i % len(ds) for i in range(args.batches * args.spg)]
     batches = [order[b:b + args.spg] for b in range(0, len(order), args.spg)]
     np.random.seed(0)
-    one = collate([ds[0]], device='cuda')
+    one = next(iter(PrefetchLoader(ds, [[0]], collate, workers=0)))     # (re-draws when the augmentation drops the sample)
     print('sample image', tuple(one['img'].shape), flush=True)
 
     for workers in (0, 1, 2, 4, 8):
