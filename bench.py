@@ -457,6 +457,8 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=None, help='override the CPU leg\'s thread count')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='run only the CPU leg and print it')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-graphs', action='store_true',
+                    help='A/B: queue every launch of the backbone + neck instead of replaying their two hipGraphs (train, 1 GPU)')
     ap.add_argument('--no-wgrad-stream', action='store_true', help='A/B: weight gradients on the main stream')
     ap.add_argument('--wgrad-streams', type=int, default=None, help='A/B: number of weight-gradient side streams')
     ap.add_argument('--wgrad-batch', type=int, default=None, help='A/B: weight gradients per batched launch (1 = off)')
@@ -548,7 +550,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(warmup):
+    graphs = None
+    if train and world == 1 and not args.no_graphs:
+        # (one eager step first: the optimizer's packed-weight buffers, the weight-gradient schedules and the kernels'
+        # attributes exist before anything is captured; it counts as one of the warm-up steps)
+        res = step()
+        from das_amd.graphs import enable_trunk_graphs
+        graphs = enable_trunk_graphs(model, opt, data['img'])
+        extra['hip_graphs'] = 'backbone + neck: forward graph, backward graph (das_amd/graphs.py); head and losses eager'
+    else:
+        extra['hip_graphs'] = 'off'
+    for _ in range(warmup - (1 if graphs is not None else 0)):
         res = step()
     sync_all()
     t0 = time.perf_counter()
@@ -556,6 +568,8 @@ def main():
         res = step()
     sync_all()
     dt = time.perf_counter() - t0
+    if graphs is not None:     # the per-launch measurement passes below need every launch queued by hand
+        model._graphed_trunk = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -83,7 +83,12 @@ class DAS(nn.Module):
             main = torch.cuda.current_stream()
             ready = torch.cuda.Event()
             ready.record(main)                  # (the ground truth was put on the device by the main stream)
-        x = self.extract_feat(img)
+        # backbone + neck: two hipGraph replays when the trunk was captured for this batch shape (das_amd/graphs.py)
+        trunk = getattr(self, '_graphed_trunk', None)
+        if trunk is not None and self.training and torch.is_grad_enabled() and trunk.matches(img):
+            x = trunk(img)
+        else:
+            x = self.extract_feat(img)
         if prepare and img.is_cuda:
             side = _side_stream(img.device)
             side.wait_event(ready)

@@ -1,0 +1,137 @@
+"""HIP graphs for the static part of the training step.
+
+The train step issues ~2700 kernel launches; the host needs 60-90 ms to queue them, about as long as the GPU needs to
+run them, and every Python thread beside the trainer (the prefetching loader) makes it slower. Two thirds of those
+launches belong to the backbone + neck, whose shapes, addresses and launch parameters do not depend on the data: the
+forward pass of that trunk is captured once into one hipGraph and its backward pass into a second one (the same
+kernels, launched by the same code — capture only records them), and a step then replays two graphs instead of
+queueing ~2000 launches. The head, the losses and their backward depend on the number of positive locations and
+stay eager; their launches are queued while the trunk's graph runs.
+
+What makes the capture legal:
+  * nothing in the trunk synchronises with the host or allocates device memory through HIP once warm: workspaces
+    (per stream: the warm-up runs on the capture stream), kernel attributes, weight-gradient schedules are set up by
+    two eager warm-up iterations; tensors come from the graph's private pool of the caching allocator;
+  * Python-side state that decides WHAT is launched is pinned for the capture: the per-step caches of packed weights
+    are invalidated first (so the packing launches are part of the graph and run at every replay), the zero-filled
+    statistics arena is a private one whose memset is the graph's first node, the weight gradients' side stream is
+    off (everything on the capture stream);
+  * gradients of the trunk's parameters are added into the optimizer's flat gradient buffer by the captured kernels
+    themselves (fixed addresses); the Python completion hooks that drive the overlapped all-reduce do not run at
+    replay, so graphs are a single-process feature (world size 1) — with several ranks the eager path overlaps the
+    gradient all-reduce with backward instead.
+The warm-up's side effects (BatchNorm running statistics, gradients) are undone after the capture."""
+import torch
+
+from . import autograd as ag
+from . import nn as dnn
+
+
+class _Replay(torch.autograd.Function):
+    """Forward graph now, backward graph when the feature maps' gradients arrive. `anchor` is a dummy input that
+    requires grad: the image does not, and without a differentiable input autograd would not call backward."""
+
+    @staticmethod
+    def forward(ctx, img, anchor, trunk):
+        ctx.trunk = trunk
+        trunk.x.copy_(img)
+        trunk.fwd.replay()
+        trunk.mark_packed()
+        return tuple(o.detach() for o in trunk.outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        trunk = ctx.trunk
+        for dst, g in zip(trunk.gouts, gouts):
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g)
+        trunk.bwd.replay()
+        return None, None, None
+
+
+class GraphedTrunk:
+    """model.extract_feat (backbone + neck) in training mode as two hipGraphs. `trunk(img)` returns the feature maps
+    (autograd-connected: their gradients trigger the backward graph); None if `img` does not match the captured
+    batch (the caller runs the eager path)."""
+
+    def __init__(self, model, optimizer, img, warmup=2):
+        assert model.training and img.is_cuda
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and \
+            torch.distributed.is_initialized() else 1
+        if world != 1:
+            raise RuntimeError('GraphedTrunk: the captured backward cannot drive the overlapped gradient all-reduce; '
+                               'use the eager path with several ranks')
+        self.model, self.opt = model, optimizer
+        self.shape, self.dtype = tuple(img.shape), img.dtype
+        dev = img.device
+        params = [p for m in (model.backbone, model.neck) if m is not None for p in m.parameters()]
+        self._dtypes = set()
+        # state the warm-up iterations would leave behind
+        buffers = [b for m in (model.backbone, model.neck) if m is not None for b in m.buffers()]
+        keep_buf = [b.detach().clone() for b in buffers]
+        keep_g = optimizer.flat_g.detach().clone()
+        side_was, ag.WGRAD_SIDE_STREAM = ag.WGRAD_SIDE_STREAM, False
+        arena_was = dnn._STATS_ARENA
+        self.arena = dnn._ZeroArena()
+        self.x = img.detach().clone()
+        self.anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self.stream = torch.cuda.Stream(device=dev)
+        try:
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self.stream):
+                for _ in range(warmup):
+                    outs = model.extract_feat(self.x)
+                    torch.autograd.backward(outs, [torch.full_like(o, 1e-3) for o in outs])
+                    del outs
+            torch.cuda.current_stream(dev).wait_stream(self.stream)
+            torch.cuda.synchronize(dev)
+            dnn._STATS_ARENA = self.arena
+            self.arena.take(64, dev)              # (allocates the arena's buffer outside the capture)
+            dnn.bump_param_epoch()               # every packed-weight cache misses: the packing is part of the graph
+            self.fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.fwd, stream=self.stream):
+                self.arena.reset()
+                self.outs = model.extract_feat(self.x)
+            self.gouts = [torch.zeros_like(o) for o in self.outs]
+            self.bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.bwd, pool=self.fwd.pool(), stream=self.stream):
+                self.arena.reset()
+                torch.autograd.backward(self.outs, self.gouts)
+        finally:
+            ag.WGRAD_SIDE_STREAM = side_was
+            dnn._STATS_ARENA = arena_was
+        self._epoch_dtypes = [dt for dt, ep in optimizer._packed_epoch.items() if ep == dnn.PARAM_EPOCH[0]]
+        with torch.no_grad():
+            for b, k in zip(buffers, keep_buf):
+                b.copy_(k)
+            optimizer.flat_g.copy_(keep_g)
+        for p in params:     # (the capture ran no kernel: nothing was accumulated, but autograd may have created .grad)
+            assert p.grad is not None
+        dnn.bump_param_epoch()                   # caches filled during the capture describe graph memory: not for eager use
+        torch.cuda.synchronize(dev)
+
+    def mark_packed(self):
+        """The forward graph has just repacked every conv weight of the flat buffer for the current parameters: the
+        eager head must not do it again."""
+        for dt in self._epoch_dtypes:
+            self.opt._packed_epoch[dt] = dnn.PARAM_EPOCH[0]
+
+    def matches(self, img):
+        return tuple(img.shape) == self.shape and img.dtype == self.dtype and img.is_cuda
+
+    def __call__(self, img):
+        return _Replay.apply(img, self.anchor, self)
+
+
+def enable_trunk_graphs(model, optimizer, example_img):
+    """Capture the trunk for batches shaped like `example_img`; the detector's training forward uses it from now on.
+    Returns the GraphedTrunk (None when capture is not applicable: several ranks)."""
+    world = torch.distributed.get_world_size() if torch.distributed.is_available() and \
+        torch.distributed.is_initialized() else 1
+    if world != 1:
+        return None
+    trunk = GraphedTrunk(model, optimizer, example_img)
+    model._graphed_trunk = trunk
+    return trunk

@@ -199,6 +199,11 @@ class _ZeroArena:
         self.off += n
         return s
 
+    def reset(self):
+        """Zero the whole buffer and start over (the first node of a captured graph: das_amd/graphs.py)."""
+        self.buf.zero_()
+        self.off = 0
+
 
 _STATS_ARENA = _ZeroArena()
 

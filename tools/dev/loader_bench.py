@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--batches', type=int, default=10)
     ap.add_argument('--spg', type=int, default=16)
     ap.add_argument('--no-train', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='queue the trunk launch by launch instead of replaying its hipGraphs')
     args = ap.parse_args()
     root = tempfile.mkdtemp(prefix='das_loader_')
     t0 = time.time()
@@ -108,6 +109,11 @@ def main():
     opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=35.0)
     first = next(iter(PrefetchLoader(ds, batches[:1], collate, workers=0)))
     for _ in range(3):
+        train_iteration(model, opt, first, 2e-3)
+    if not args.no_graphs:
+        from das_amd.graphs import enable_trunk_graphs
+        enable_trunk_graphs(model, opt, first['img'])
+        print('trunk captured as hipGraphs', flush=True)
         train_iteration(model, opt, first, 2e-3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
