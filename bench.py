@@ -555,6 +555,7 @@ def main():
         # (one eager step first: the optimizer's packed-weight buffers, the weight-gradient schedules and the kernels'
         # attributes exist before anything is captured; it counts as one of the warm-up steps)
         res = step()
+        del res
         from das_amd.graphs import enable_trunk_graphs
         graphs = enable_trunk_graphs(model, opt, data['img'])
         extra['hip_graphs'] = 'backbone + neck: forward graph, backward graph (das_amd/graphs.py); head and losses eager'

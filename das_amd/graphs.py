@@ -66,8 +66,7 @@ class GraphedTrunk:
         self.model, self.opt = model, optimizer
         self.shape, self.dtype = tuple(img.shape), img.dtype
         dev = img.device
-        params = [p for m in (model.backbone, model.neck) if m is not None for p in m.parameters()]
-        self._dtypes = set()
+        params = [p for m in (model.backbone, model.neck) if m is not None for p in m.parameters() if p.requires_grad]
         # state the warm-up iterations would leave behind
         buffers = [b for m in (model.backbone, model.neck) if m is not None for b in m.buffers()]
         keep_buf = [b.detach().clone() for b in buffers]
@@ -80,11 +79,20 @@ class GraphedTrunk:
         self.stream = torch.cuda.Stream(device=dev)
         try:
             self.stream.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self.stream):
+            import warnings
+            with torch.cuda.stream(self.stream), warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter('always')
                 for _ in range(warmup):
                     outs = model.extract_feat(self.x)
-                    torch.autograd.backward(outs, [torch.full_like(o, 1e-3) for o in outs])
+                    self._backward(outs, [torch.full_like(o, 1e-3) for o in outs], params)
                     del outs
+            if any('AccumulateGrad' in str(w.message) for w in caught):
+                # An autograd graph of an earlier step is still referenced somewhere (a kept loss tensor is enough): the
+                # parameters' gradient accumulators then stay bound to the training stream, backward on the capture
+                # stream has to synchronise with it, and that cannot be captured (the HIP runtime crashes at end-capture).
+                raise RuntimeError('GraphedTrunk: drop every reference to earlier losses / outputs (anything with a '
+                                   'grad_fn) before capturing: their autograd graph pins the parameters\' gradient '
+                                   'accumulators to the training stream')
             torch.cuda.current_stream(dev).wait_stream(self.stream)
             torch.cuda.synchronize(dev)
             dnn._STATS_ARENA = self.arena
@@ -98,7 +106,7 @@ class GraphedTrunk:
             self.bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.bwd, pool=self.fwd.pool(), stream=self.stream):
                 self.arena.reset()
-                torch.autograd.backward(self.outs, self.gouts)
+                self._backward(self.outs, self.gouts, params)
         finally:
             ag.WGRAD_SIDE_STREAM = side_was
             dnn._STATS_ARENA = arena_was
@@ -111,6 +119,19 @@ class GraphedTrunk:
             assert p.grad is not None
         dnn.bump_param_epoch()                   # caches filled during the capture describe graph memory: not for eager use
         torch.cuda.synchronize(dev)
+
+    @staticmethod
+    def _backward(outs, gouts, params):
+        """Backward of the trunk WITHOUT autograd's AccumulateGrad nodes: those are per-parameter objects bound to the
+        stream they were first used on (the training stream) and stay alive as long as any earlier autograd graph does
+        (a kept loss tensor is enough); run from the capture stream they synchronise the two streams, which is illegal
+        inside a capture. torch.autograd.grad returns the gradients instead; the few that autograd delivers (most are
+        added into the flat gradient by the kernels themselves and come back as None) are added by hand."""
+        grads = torch.autograd.grad(outs, params, gouts, allow_unused=True)
+        with torch.no_grad():
+            for p, g in zip(params, grads):
+                if g is not None:
+                    p.grad.add_(g)
 
     def mark_packed(self):
         """The forward graph has just repacked every conv weight of the flat buffer for the current parameters: the
