@@ -22,8 +22,8 @@ class _timed:
     """bench.py's per-launch record for the non-conv families (BatchNorm passes): HIP events on the launch stream
     around the call, when PROFILE is a list. nbytes = algorithmic bytes of the op (every operand of every pass once)."""
 
-    def __init__(self, tag, nbytes, launches=1):
-        self.tag, self.nbytes, self.launches = tag, float(nbytes), launches
+    def __init__(self, tag, nbytes, launches=1, shape=()):
+        self.tag, self.nbytes, self.launches, self.shape = tag, float(nbytes), launches, ('bn',) + tuple(shape)
 
     def __enter__(self):
         if PROFILE is not None:
@@ -34,7 +34,7 @@ class _timed:
     def __exit__(self, *exc):
         if PROFILE is not None and exc[0] is None:
             self.e1.record()
-            PROFILE.append((self.tag, 0.0, self.e0, self.e1, ('bn',), 1, self.nbytes, self.launches))
+            PROFILE.append((self.tag, 0.0, self.e0, self.e1, self.shape, 1, self.nbytes, self.launches))
         return False
 
 
@@ -290,7 +290,7 @@ def bn_backward_apply(dz, raw, mean, invstd, gamma, sums, dgamma_acc=None, dbeta
     Cc = raw.shape[-1]
     rows = raw.numel() // Cc
     draw = torch.empty_like(raw)
-    with _timed('bn_bwd_apply_dz_kernel', 3 * raw.numel() * raw.element_size()):     # dZ, raw -> d raw
+    with _timed('bn_bwd_apply_dz_kernel', 3 * raw.numel() * raw.element_size(), shape=(rows, Cc)):     # dZ, raw -> d raw
         _lib.check(_lib.load().das_bn_backward_apply(_ptr(dz), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean), _ptr(invstd),
                                                      _ptr(gamma), _ptr(sums), sums.numel() // (2 * Cc), _ptr(draw),
                                                      _ptr(dgamma_acc), _ptr(dbeta_acc), stat_rows or rows, _stream()),
@@ -444,7 +444,7 @@ def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta=Non
     # again and writes d raw (, d residual)
     nin = 3 if y is not None else 2
     with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', (2 * nin + 1 + (1 if want_dres else 0)) * raw.numel() *
-                raw.element_size(), launches=2):
+                raw.element_size(), launches=2, shape=(rows, Cc, nin, int(bool(want_dres)))):
         _lib.check(_lib.load().das_bn_train_backward(_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean),
                                                      _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _ptr(draw),
                                                      _ptr(dres), _ptr(sums), prezeroed, _ptr(dgamma_acc),
@@ -638,7 +638,8 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     mean, invstd = mi[0], mi[1]
     if num_batches_tracked is not None:
         assert num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda
-    with _timed('bn_apply_kernel', (3 if residual is not None else 2) * x.numel() * x.element_size()):
+    with _timed('bn_apply_kernel', (3 if residual is not None else 2) * x.numel() * x.element_size(),
+                shape=(count, Cc, int(residual is not None))):
         _lib.check(_lib.load().das_bn_train_apply(_ptr(x), _ptr(y), _DT[x.dtype], count, Cc, _ptr(stats), _ptr(gamma),
                                                   _ptr(beta), _ptr(running_mean), _ptr(running_var), momentum, eps,
                                                   _ptr(residual), int(relu), _ptr(mean), _ptr(invstd),

@@ -1,4 +1,4 @@
-"""Dev tool: the conv_glds4_kernel launches (forward and data-gradient) of one training bench step (B=16; shapes and
+"""Dev tool: the tile-kernel and stream-kernel launches (forward and data-gradient) of one training bench step (B=16; shapes and
 per-step counts from tools/dev/train_shapes.py; the stride-2 data-gradient shapes, 4 launches, are left out), each
 launched `count` times. Run under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) for the HBM
 traffic per launch behind bench.py's roofline.traffic, or bare for a time per step."""
@@ -14,6 +14,9 @@ SHAPES = [
     (10, 64, 104, 256, 256, 1), (6, 32, 52, 1024, 1024, 1), (4, 128, 208, 128, 256, 1), (6, 16, 26, 2048, 2048, 1),
     (2, 64, 104, 256, 256, 3), (16, 0, 0, 256, 256, 3), (4, 0, 0, 256, 2304, 1), (4, 0, 0, 2304, 256, 1),
     (4, 0, 0, 32, 256, 3),
+    # the 256 x 128 tile (conv_glds3_kernel, plain / ping-pong / split over K) and 128 x 64 tile (conv_glds_kernel) shapes
+    (42, 32, 52, 256, 256, 3), (51, 32, 52, 1024, 256, 1), (24, 64, 104, 128, 128, 3), (28, 64, 104, 512, 128, 1),
+    (16, 16, 26, 512, 512, 3), (20, 16, 26, 2048, 512, 1), (24, 128, 208, 64, 64, 3),
 ]
 LEVELS = [(64, 104), (32, 52), (16, 26), (8, 13)]
 B = 16
