@@ -262,8 +262,7 @@ class RLEPoseLossFn(Function):
                 continue
             flows = meta['flows'][D]
             jobs[D] = []
-            for q, f in enumerate(flows):
-                c, table = _flow_state(f, dev)
+            for q, (c, table) in enumerate(meta['flow_states'][D]):   # (prepared outside: see rle_pose_loss_sums)
                 jobs[D].append((q * stride[D], q * stride[D] + count[D] * J, c['packed'], table, c['plist']))
             arr = (_lib.DasFlowJob * sets)()
             for q, (r0, r1, packed, table, plist) in enumerate(jobs[D]):
@@ -272,7 +271,7 @@ class RLEPoseLossFn(Function):
             rows = sets * stride[D]
             logp[D] = torch.zeros(rows, dtype=torch.float32, device=dev)
             z[D] = torch.zeros(rows, D, dtype=torch.float32, device=dev)
-            c0, _ = _flow_state(flows[0], dev)
+            c0 = meta['flow_states'][D][0][0]
             _lib.check(lib.das_realnvp_log_prob_multi(_ptr(x[D]), rows, D, arr, sets, len(flows[0].t), c0['bits'],
                                                       _ptr(logp[D]), _ptr(z[D]), _stream()), 'das_realnvp_log_prob_multi')
         partials = torch.empty(lib.das_rle_blocks(C.byref(d)), 2, dtype=torch.float32, device=dev)
@@ -307,7 +306,7 @@ class RLEPoseLossFn(Function):
                     outs[D].append(dp)
             f0 = meta['flows'][D][0]
             _lib.check(lib.das_realnvp_log_prob_multi_backward(_ptr(z[D]), _ptr(w[D] * g[0]), rows, D, arr, sets, len(f0.t),
-                                                               _flow_state(f0, pose.device)[0]['bits'], _ptr(dx[D]), _stream()),
+                                                               meta['flow_states'][D][0][0]['bits'], _ptr(dx[D]), _stream()),
                        'das_realnvp_log_prob_multi_backward')
         dpose, daux = torch.zeros_like(pose), torch.zeros_like(aux)
         gt = [meta[k] for k in ('pos', 'real', 'vis', 'is2d', 'slot')]
@@ -332,11 +331,15 @@ class RLEPoseLossFn(Function):
 
 def rle_pose_loss_sums(pose, aux, meta):
     """-> tensor [pose sum, depth sum] (see RLEPoseLossFn); the flows' parameters are threaded through autograd."""
+    # the flows' packed parameters and — with the flat optimizer — the device tables of their gradient destinations are
+    # looked up HERE: inside Function.forward grad mode is off, _flow_state would hand out no table, and the backward
+    # kernel's parameter gradients would come back through autograd (one AccumulateGrad add per tensor: ~290 per step)
     flat = []
+    meta = dict(meta, flow_states={D: [_flow_state(f, pose.device) for f in meta['flows'][D]] for D in (2, 3)})
     for D in (2, 3):
         if meta['n2d' if D == 2 else 'n3d'] > 0:
-            for f in meta['flows'][D]:
-                flat += _flow_state(f, pose.device)[0]['plist']
+            for c, _ in meta['flow_states'][D]:
+                flat += c['plist']
     # (dense rows: the gradient tensors share the inputs' row strides)
     return RLEPoseLossFn.apply(pose.contiguous(), aux.contiguous(), meta, *flat)
 
