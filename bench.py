@@ -371,8 +371,25 @@ def decode_workload(args, rank, world, dev):
         return
     kern_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / steps     # events bracket the launch on its stream
     nloc = sum(h * w for h, w in HW)
-    bytes_img = nloc * (1 + 1 + 3 + 3 * Jm) * 4                        # every logit / pose value read once
+    # Bytes the path REQUIRES per image: the class and centerness logit of every location (the pose maps are only
+    # gathered at the candidates that pass the threshold: 3 + 6 J floats each), and the kept poses written. SURVEY 8(d)'s
+    # figure (every pose value of every location, 3.36 MB at J = 15) is what the reference's dense tensor code touches,
+    # not what the decode needs: priced on it this latency-bound kernel looked like 79 % of the HBM peak.
+    cand = int(out['ncand'].float().mean().item()) if 'ncand' in out else 150
     poses = int(out['count'].sum().item())
+    bytes_img = nloc * 2 * 4 + cand * (3 + 6 * Jm) * 4 + (poses / B) * (3 * Jm + 3 + 1) * 4
+    # the kernel is one workgroup per image (a sort / NMS latency chain): per-image time at a batch that fills the chip
+    # (B) and at the serving batch of configs[1] (8 images: 8 of 256 CUs busy)
+    small = [t[:8] for t in cls], [t[:8] for t in ctr], [t[:8] for t in pose]
+    for _ in range(3):
+        ops.decode(small[0], small[1], small[2], strides, sf[:8], Jm, 1000, 100, 0.07, 0.9)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.decode(small[0], small[1], small[2], strides, sf[:8], Jm, 1000, 100, 0.07, 0.9)
+    e1.record()
+    torch.cuda.synchronize()
+    us_b8 = e0.elapsed_time(e1) / 20 * 1e3
     line = {
         'metric': 'imgs/sec decode', 'value': round(B * world * steps / dt, 1), 'unit': 'img/s', 'n_gpus': world,
         'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True,
@@ -383,8 +400,11 @@ def decode_workload(args, rank, world, dev):
         'poses_per_sec': round(poses * world * steps / dt, 1), 'poses_per_step_rank0': poses,
         'roofline': {'bound': 'hbm', 'kernel': 'decode_kernel', 'achieved': round(bytes_img * B / kern_s / 1e9, 1),
                      'peak': 8000.0, 'unit': 'GB/s', 'frac': round(bytes_img * B / kern_s / 8e12, 4), 'traffic': None,
-                     'avg_launch_us': round(kern_s * 1e6, 1),
-                     'note': 'one 1024-thread workgroup per image: a sort / NMS latency chain, not a streaming kernel'},
+                     'avg_launch_us': round(kern_s * 1e6, 1), 'required_bytes_per_img': int(bytes_img),
+                     'us_per_img': round(kern_s * 1e6 / B, 3), 'launch_us_at_batch_8': round(us_b8, 1),
+                     'us_per_img_at_batch_8': round(us_b8 / 8, 2),
+                     'note': 'one 1024-thread workgroup per image: a sort / NMS latency chain, not a streaming kernel; '
+                             'bytes = 2 logits per location + the gathered candidates + the kept poses'},
     }
     if world == 1 and not args.no_cpu_baseline:
         from oracle import decode as OD
