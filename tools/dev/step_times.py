@@ -1,5 +1,5 @@
-"""Dev tool: per-step wall time of the train bench's step in a fresh process (is the first run on a fresh box slow
-because of its first steps, or as a whole?). usage: step_times.py [steps]"""
+"""Dev tool: per-step wall time and host (launch-queueing) time of the train bench's step in a fresh process; with
+`graphs` as second argument the trunk is captured as hipGraphs after step 3. usage: step_times.py [steps] [graphs]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -29,6 +29,10 @@ def _resolve(self):
 detectors.LazyLogVars.resolve = _resolve
 ts, hs = [], []
 for i in range(n):
+    if i == 3 and len(sys.argv) > 2 and sys.argv[2] == 'graphs':
+        from das_amd.graphs import enable_trunk_graphs
+        enable_trunk_graphs(model, opt, data['img'])
+        print('trunk captured as hipGraphs before step 3')
     torch.cuda.synchronize()
     t = time.perf_counter()
     train_iteration(model, opt, data, 2e-3)
