@@ -138,3 +138,117 @@ class PrefetchLoader:
             for _ in threads:
                 window.release()
             sys.setswitchinterval(interval)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Worker PROCESSES: the reference's dataloader model (mmdet build_dataloader -> torch DataLoader workers), with the
+# augmentation on the GPU. Threads share the trainer's interpreter lock: ~2.5 ms of Python per sample in the pipeline's
+# stages, 16 samples per step, beside a trainer that has to stay ahead of the GPU through ~700 eager launches per step —
+# measured: the trainer alone 162 img/s, beside 2-8 loader threads 105-120 img/s (tools/dev/loader_bench.py --probe: the
+# same threads doing nothing cost 0 %, decode only 9 %, the full pipeline 27 %). Each worker process has its own
+# interpreter and its own HIP context on the same GPU, builds whole batches there and hands the collated CUDA tensors over
+# by IPC handle (torch.multiprocessing reductions; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver).
+def _process_worker(wid, dataset_cfg, device_index, seed, max_redraws, task_q, result_q):
+    import traceback
+    import numpy as np
+    try:
+        torch.cuda.set_device(device_index)
+        from .datasets import build_dataset, collate
+        np.random.seed(seed + wid)
+        torch.manual_seed(seed + wid)
+        dataset = build_dataset(dataset_cfg)
+        builder = PrefetchLoader(dataset, [], collate, device=f'cuda:{device_index}', workers=0, max_redraws=max_redraws)
+        result_q.put(('ready', wid, len(dataset)))
+    except BaseException:   # noqa: BLE001
+        result_q.put(('fatal', wid, traceback.format_exc()))
+        return
+    held = []            # the last batches sent: kept alive here until the consumer had time to map them
+    while True:
+        task = task_q.get()
+        if task is None:
+            return
+        k, indices = task
+        try:
+            data = builder._build(indices)
+            torch.cuda.synchronize()          # the consumer's stream knows nothing of this process's streams
+            result_q.put(('ok', k, data))
+            held.append(data)
+            del held[:-4]
+        except BaseException:   # noqa: BLE001 — reported to the consumer, which raises at that batch
+            result_q.put(('err', k, traceback.format_exc()))
+
+
+class ProcessLoader:
+    """`workers` processes building batches of `build_dataset(dataset_cfg)` on GPU `device`; `batches(list of index
+    lists)` yields the collated batches in order. The pool lives until `close()` (start-up costs a few seconds per
+    worker: interpreter, torch import, HIP context), so one loader serves every epoch."""
+
+    def __init__(self, dataset_cfg, device='cuda', workers=4, depth=2, seed=0, max_redraws=100, start_timeout=300):
+        import torch.multiprocessing as mp
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.workers, self.depth = max(1, int(workers)), max(1, int(depth))
+        ctx = mp.get_context('spawn')
+        self.task_q, self.result_q = ctx.Queue(), ctx.Queue()
+        self.procs = [ctx.Process(target=_process_worker, daemon=True, name=f'das-loader-{w}',
+                                  args=(w, dataset_cfg, self.device.index, seed, max_redraws, self.task_q, self.result_q))
+                      for w in range(self.workers)]
+        for p in self.procs:
+            p.start()
+        self.length = None
+        for _ in self.procs:
+            kind, wid, info = self._get(start_timeout)
+            if kind != 'ready':
+                self.close()
+                raise RuntimeError(f'loader worker {wid} failed to start:\n{info}')
+            self.length = info
+
+    def _get(self, timeout):
+        import queue as _q
+        waited = 0.0
+        while True:
+            try:
+                return self.result_q.get(timeout=0.5)
+            except _q.Empty:
+                waited += 0.5
+                dead = [p.name for p in self.procs if not p.is_alive()]
+                if dead:
+                    raise RuntimeError(f'loader worker process(es) died: {dead}')
+                if waited >= timeout:
+                    raise RuntimeError(f'no batch from the loader workers within {timeout} s')
+
+    def batches(self, batches, timeout=600):
+        batches = [list(b) for b in batches]
+        n, sent, ready = len(batches), 0, {}
+        window = self.workers + self.depth
+        for k in range(n):
+            while sent < n and sent < k + window:
+                self.task_q.put((sent, batches[sent]))
+                sent += 1
+            while k not in ready:
+                kind, kk, data = self._get(timeout)
+                if kind == 'err':
+                    raise RuntimeError(f'loader worker failed on batch {kk}:\n{data}')
+                if kind == 'fatal':
+                    raise RuntimeError(f'loader worker died:\n{data}')
+                ready[kk] = data
+            yield ready.pop(k)
+
+    def close(self):
+        for _ in self.procs:
+            try:
+                self.task_q.put(None)
+            except Exception:   # noqa: BLE001
+                pass
+        for p in self.procs:
+            p.join(5)
+            if p.is_alive():
+                p.terminate()
+        self.procs = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass

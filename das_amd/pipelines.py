@@ -71,7 +71,10 @@ class LoadImageFromFile:
             # byte copy of 11 ms that holds the GIL (the JPEG decode itself, 10 ms, releases it) — with it, eight
             # loader threads beside the trainer delivered 108 img/s; the frame goes up as decoded and is flipped there
             from PIL import Image
-            img = np.array(Image.open(filename).convert('RGB'))
+            pil = Image.open(filename)
+            if pil.mode != 'RGB':           # (convert() copies the frame even when there is nothing to convert: 1.2 ms)
+                pil = pil.convert('RGB')
+            img = np.array(pil)
             t = torch.from_numpy(img).to(self.device).flip(-1)
         if self.to_float32:
             t = t.float()

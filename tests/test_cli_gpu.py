@@ -177,3 +177,27 @@ data = dict(samples_per_gpu=2, train=dict(_delete_=True, type='CMUPanopticDatase
     out = run('tools/train.py', str(cfg), '--work-dir', str(tmp_path / 'w'), '--max-iters', '3', '--no-validate',
               '--cfg-options', 'model.backbone.num_stages=1', 'runner.max_epochs=1', 'log_config.interval=1')
     assert 'loss_pose' in out and 'nan' not in out.lower(), out[-800:]
+
+
+def test_process_loader_hands_device_batches_over_in_order():
+    """das_amd.loader.ProcessLoader: worker processes (own interpreter, own HIP context on the same GPU) build the batches,
+    the collated CUDA tensors arrive here by IPC handle, in batch order, and a failing batch raises here."""
+    from das_amd.loader import ProcessLoader
+    cfg = dict(type='SyntheticPoseDataset', num_joints=15, img_shape=(128, 192), length=12, seed=3, max_persons=3)
+    pl = ProcessLoader(cfg, device='cuda:0', workers=2)
+    try:
+        assert pl.length == 12
+        batches = [[0, 1], [2, 3], [4, 5], [6, 7], [8, 9]]
+        got = list(pl.batches(batches))
+        assert len(got) == 5
+        from das_amd.datasets import SyntheticPoseDataset, collate
+        ds = SyntheticPoseDataset(num_joints=15, img_shape=(128, 192), length=12, seed=3, max_persons=3)
+        for b, data in zip(batches, got):
+            ref = collate([ds[i] for i in b], device='cuda')
+            assert data['img'].is_cuda and torch.equal(data['img'], ref['img'])
+            assert all(torch.equal(x, y) for x, y in zip(data['gt_poses_3d'], ref['gt_poses_3d']))
+        with pytest.raises(RuntimeError, match='loader worker failed on batch 0'):
+            list(pl.batches([['not an index']]))
+        del got, data
+    finally:
+        pl.close()

@@ -23,7 +23,7 @@ import bench  # noqa: E402
 import das_amd  # noqa: E402,F401
 import eval_cases as EC  # noqa: E402
 from das_amd.datasets import build_dataset, collate  # noqa: E402
-from das_amd.loader import PrefetchLoader  # noqa: E402
+from das_amd.loader import PrefetchLoader, ProcessLoader  # noqa: E402
 from das_amd.optim import FlatSGD, train_iteration  # noqa: E402
 
 
@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--batches', type=int, default=10)
     ap.add_argument('--spg', type=int, default=16)
     ap.add_argument('--no-train', action='store_true')
+    ap.add_argument('--probe', action='store_true', help='diagnostics: trainer on a resident batch beside the loader variants')
     ap.add_argument('--no-graphs', action='store_true', help='queue the trunk launch by launch instead of replaying its hipGraphs')
     args = ap.parse_args()
     root = tempfile.mkdtemp(prefix='das_loader_')
@@ -122,6 +123,33 @@ def main():
     torch.cuda.synchronize()
     print(f'train step alone (resident batch {tuple(first["img"].shape)}): {len(order) / (time.perf_counter() - t0):7.1f} img/s',
           flush=True)
+    if args.probe:
+        # what slows the trainer down beside the loader? (a) the full loader, its batches discarded; (b) decode only
+        # (no GPU-side stages); (c) threads that only sleep
+        import copy
+        cfg_dec = dataset_cfg(root)
+        cfg_dec['pipeline'] = cfg_dec['pipeline'][:1]
+        ds_dec = build_dataset(cfg_dec)
+
+        class Sleepy:
+            def __len__(self):
+                return len(ds)
+
+            def __getitem__(self, i):
+                time.sleep(0.004)
+                return dict(idx=i)
+        variants = (('full pipeline, batches discarded', ds, collate), ('decode + upload only', ds_dec, lambda smp, device=None: smp),
+                    ('sleeping threads', Sleepy(), lambda smp, device=None: smp))
+        for name, dset, coll in variants:
+            for workers in (2, 4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in PrefetchLoader(dset, batches, coll, workers=workers):
+                    train_iteration(model, opt, first, 2e-3)
+                torch.cuda.synchronize()
+                print(f'trainer on a resident batch beside [{name}], workers={workers}: {len(order) / (time.perf_counter() - t0):7.1f} img/s',
+                      flush=True)
+        return
     for workers in (0, 2, 4, 8):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -129,7 +157,26 @@ def main():
             train_iteration(model, opt, data, 2e-3)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f'loader + 4-stage train step, workers={workers}: {len(order) / dt:7.1f} img/s', flush=True)
+        print(f'loader threads + 4-stage train step, workers={workers}: {len(order) / dt:7.1f} img/s', flush=True)
+    for workers in (4, 8):
+        t0 = time.perf_counter()
+        pl = ProcessLoader(dataset_cfg(root), workers=workers)
+        print(f'{workers} worker processes up in {time.perf_counter() - t0:.1f} s', flush=True)
+        for data in pl.batches(batches[:3]):      # (warm: allocator pools, kernels)
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for data in pl.batches(batches):
+            pass
+        torch.cuda.synchronize()
+        print(f'loader processes alone, workers={workers}: {len(order) / (time.perf_counter() - t0):7.1f} img/s', flush=True)
+        t0 = time.perf_counter()
+        for data in pl.batches(batches):
+            train_iteration(model, opt, data, 2e-3)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f'loader processes + 4-stage train step, workers={workers}: {len(order) / dt:7.1f} img/s', flush=True)
+        pl.close()
 
 
 if __name__ == '__main__':

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import das_amd  # noqa: E402
 from das_amd.config import parse_cfg_options  # noqa: E402
 from das_amd.datasets import build_dataset, collate, collect_results  # noqa: E402
-from das_amd.loader import PrefetchLoader  # noqa: E402
+from das_amd.loader import PrefetchLoader, ProcessLoader  # noqa: E402
 from das_amd.optim import build_optimizer, step_lr, train_iteration  # noqa: E402
 
 
@@ -123,6 +123,11 @@ def main():
         val_dataset = build_dataset(val_cfg)
     spg = cfg.data.get('samples_per_gpu', 4)
     workers = cfg.data.get('workers_per_gpu', 0)
+    # data.worker_mode: 'thread' (default: threads of this process, das_amd.loader.PrefetchLoader) or 'process' (the
+    # reference's model: worker processes, each with its own interpreter and HIP context, batches handed over by IPC)
+    pool = None
+    if workers > 0 and cfg.data.get('worker_mode', 'thread') == 'process':
+        pool = ProcessLoader(cfg.data.train, device=f'cuda:{local_rank}', workers=workers, seed=args.seed + 1000 * rank)
     lrc = cfg.get('lr_config', {})
     max_epochs = cfg.get('runner', {}).get('max_epochs', 12)
     log_every = cfg.get('log_config', {}).get('interval', 50)
@@ -137,8 +142,9 @@ def main():
         order = order[rank::world]
         t0 = time.time()
         # decode + GPU-side augmentation + collate run `workers_per_gpu` threads ahead of the training thread
-        loader = PrefetchLoader(dataset, [order[b:b + spg] for b in range(0, len(order), spg)], collate, device='cuda',
-                                workers=workers)
+        index_batches = [order[b:b + spg] for b in range(0, len(order), spg)]
+        loader = pool.batches(index_batches) if pool is not None else \
+            PrefetchLoader(dataset, index_batches, collate, device='cuda', workers=workers)
         for bi, data in enumerate(loader):
             b = bi * spg
             lr = step_lr(opt.base_lr, epoch, it, steps=lrc.get('step', (16, 20)), warmup_iters=lrc.get('warmup_iters', 0),
@@ -165,6 +171,8 @@ def main():
                 print(f'Epoch(val) [{epoch + 1}] {metrics}', flush=True)
         if args.max_iters and it >= args.max_iters:
             break
+    if pool is not None:
+        pool.close()
     if distributed:
         torch.distributed.destroy_process_group()
 
