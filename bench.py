@@ -577,8 +577,12 @@ def main():
         res = step()
         del res
         from das_amd.graphs import enable_trunk_graphs
-        graphs = enable_trunk_graphs(model, opt, data['img'])
-        extra['hip_graphs'] = 'backbone + neck: forward graph, backward graph (das_amd/graphs.py); head and losses eager'
+        try:
+            graphs = enable_trunk_graphs(model, opt, data['img'])
+            extra['hip_graphs'] = 'backbone + neck: forward graph, backward graph (das_amd/graphs.py); head and losses eager'
+        except RuntimeError as e:      # capture refused: the same kernels, queued launch by launch (the line says so)
+            model._graphed_trunk = None
+            extra['hip_graphs'] = f'off (capture failed: {e})'
     else:
         extra['hip_graphs'] = 'off'
     for _ in range(warmup - (1 if graphs is not None else 0)):
