@@ -83,6 +83,8 @@ class DAS(nn.Module):
             main = torch.cuda.current_stream()
             ready = torch.cuda.Event()
             ready.record(main)                  # (the ground truth was put on the device by the main stream)
+        if hasattr(self.bbox_head, 'prefetch_scales'):
+            self.bbox_head.prefetch_scales()    # (a device-to-host copy the head needs: started before the backbone is queued)
         # backbone + neck: two hipGraph replays when the trunk was captured for this batch shape (das_amd/graphs.py)
         trunk = getattr(self, '_graphed_trunk', None)
         if trunk is not None and self.training and torch.is_grad_enabled() and trunk.matches(img):

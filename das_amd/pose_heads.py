@@ -350,12 +350,38 @@ class DASHead(nn.Module):
         r = ops.Ragged(x.reshape(-1, x.shape[-1]), x.shape[0], [x.shape[1:3]])
         return tuple(t.level(0) for t in self.forward_rows(r, [lvl]))
 
+    def prefetch_scales(self):
+        """Start the device-to-host copy of the per-level Scale parameters NOW (the kernels take them by value): called
+        by the detector before the backbone is queued. Read back only when the head needs them, the copy — which depends
+        on nothing but the previous optimizer step — has long finished; read back at that point (as rounds 1-2 did:
+        `.cpu()` inside forward_rows) the host waits for the whole queued backbone and the GPU then waits for the host
+        to queue the rest of the step."""
+        params = [s.scale for lv in self.scales for s in lv]
+        if not params or not params[0].is_cuda:
+            return
+        from .nn import _versions
+        ver = _versions(*params)
+        pend = self.__dict__.get('_scale_prefetch')
+        if pend is not None and pend[0] == ver:
+            return
+        host = torch.empty(len(params), dtype=torch.float32, pin_memory=True)
+        host.copy_(torch.stack([p.detach().float().reshape(()) for p in params]), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self.__dict__['_scale_prefetch'] = (ver, host, done)
+
     def _scale_values(self):
-        """Per-level Scale parameters as python floats (one small D2H copy, cached per version)."""
+        """Per-level Scale parameters as python floats (one small D2H copy per parameter version: see prefetch_scales)."""
         params = [s.scale for lv in self.scales for s in lv]
 
         def make():
-            v = torch.stack([p.detach().float() for p in params]).cpu().tolist()
+            from .nn import _versions
+            pend = self.__dict__.get('_scale_prefetch')
+            if pend is not None and pend[0] == _versions(*params):
+                pend[2].synchronize()
+                v = pend[1].tolist()
+            else:
+                v = torch.stack([p.detach().float() for p in params]).cpu().tolist()
             return [v[i * 4:(i + 1) * 4] for i in range(len(self.scales))]
         return _cache_of(self).get(('scales',), params, make)
 
