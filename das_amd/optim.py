@@ -59,7 +59,7 @@ class FlatSGD:
     ranks whatever the timing."""
 
     def __init__(self, model, lr, momentum=0.9, weight_decay=1e-4, bias_lr_mult=1.0, bias_decay_mult=1.0,
-                 max_grad_norm=0.0, bucket_mb=64, overlap=True):
+                 max_grad_norm=0.0, bucket_mb=64, overlap=True, force_collectives=False):
         self.model, self.base_lr, self.momentum, self.max_grad_norm = model, lr, momentum, max_grad_norm
         module_of = {}
         for mname, mod in model.named_modules():
@@ -117,6 +117,9 @@ class FlatSGD:
         self.steps = 0
         self._sig = self._param_signature()
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # `force_collectives`: run the multi-rank gradient path (bucket launches from the completion hooks, comm stream,
+        # flag exchange) in a process group of ONE rank too — how a one-GPU box exercises it over RCCL
+        self._multi = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
         # param-aligned buckets in buffer order
         n_bucket = max(1, bucket_mb * (1 << 20) // 4)
         self.buckets, bstart = [], 0
@@ -127,7 +130,7 @@ class FlatSGD:
                 self.buckets.append((bstart, total if i == len(self.slots) - 1 else end))
                 bstart = end
         self.overlap = overlap
-        self.comm_stream = torch.cuda.Stream() if self.world > 1 and dev.type == 'cuda' else None
+        self.comm_stream = torch.cuda.Stream() if self._multi and dev.type == 'cuda' else None
         for i, sl in enumerate(self.slots):
             sl.index = i
         self._pexp = None                          # completions per parameter in one backward (learned in iteration 0)
@@ -192,7 +195,7 @@ class FlatSGD:
         parameter edit since the last call invalidates them (they are keyed on PARAM_EPOCH only)."""
         from .autograd import reset_step_state
         reset_step_state()          # (a backward that raised leaves queued weight gradients and sticky flags behind)
-        if self.world > 1 and any(self._pfires):
+        if self._multi and any(self._pfires):
             self._reset_iteration()
         self.flat_g.zero_()
         sig = self._param_signature()
@@ -231,7 +234,7 @@ class FlatSGD:
             self._next -= 1
 
     def _fired(self, sl):
-        if self.world == 1 or not self.overlap:
+        if not self._multi or not self.overlap:
             return
         i = sl.index
         self._pfires[i] += 1
@@ -273,7 +276,7 @@ class FlatSGD:
         buckets that backward did not complete (unused parameters, first iteration), then wait."""
         from .autograd import finish_backward
         finish_backward()           # queued weight gradients launched, side streams joined — whatever backward did
-        if self.world == 1:
+        if not self._multi:
             return
         if self._late:
             raise RuntimeError('a gradient was produced after its bucket had been all-reduced (a parameter '

@@ -171,3 +171,74 @@ def test_two_rank_step_equals_the_single_process_step_on_the_concatenated_batch(
     for n, b in model.named_buffers():
         if 'running' in n:
             torch.testing.assert_close(b.detach().cpu(), b0[n], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RCCL itself (backend 'nccl'): a one-GPU box can only form a group of ONE rank, so the collectives are identities —
+# but they are real RCCL launches: communicator set-up with `device_id`, bucket all-reduces issued from the completion
+# hooks (autograd's thread) on the communication stream while backward is still queueing kernels, the MAX exchange of
+# the end-only flags, the barrier bench.py brackets its timed region with. The step must be the plain single-process
+# step. Yardstick: two plain runs of this tiny net (48 samples per channel in its deepest BatchNorm layers, statistics
+# and weight gradients summed with float atomics) differ by ~6e-4 of the largest gradient in the FIRST step already
+# (tools/dev/rccl_probe.py); a bucket all-reduced before its gradients were complete, or twice, would be off by O(1).
+def _rccl_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    import das_amd
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    from das_amd.optim import FlatSGD, train_iteration
+    from test_model_gpu import tiny_detector_cfg
+
+    def run(force):
+        torch.manual_seed(0)
+        cfg = tiny_detector_cfg()
+        cfg['backbone']['compute_dtype'] = 'f32'
+        model = das_amd.build_model(cfg)
+        model.init_weights()
+        model.to('cuda').train()
+        opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0,
+                      max_grad_norm=35.0, bucket_mb=1, overlap=True, force_collectives=force)
+        ds = SyntheticPoseDataset(num_joints=15, img_shape=(128, 192), length=4, seed=3, max_persons=3)
+        data = collate([ds[i] for i in range(2)], device='cuda')
+        losses, g1 = [], None
+        for it in range(3):
+            losses.append(train_iteration(model, opt, data, 2e-3)['log_vars']['loss'])
+            if it == 0:
+                g1 = opt.flat_g.detach().cpu().clone()      # (the summed gradient of the first step: same parameters in every run)
+        torch.cuda.synchronize()
+        return opt, g1, losses
+
+    _, g_a, l_a = run(False)                     # no process group yet: the plain path, twice
+    _, g_b, _ = run(False)
+    try:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+        dist.barrier()
+    except Exception as e:   # noqa: BLE001
+        ret[rank] = ('skip', repr(e))
+        return
+    opt, g, losses = run(True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    ret[rank] = ('ok', g_a, g_b, g, l_a, losses, opt.overlapped_launches, len(opt.buckets), sum(opt._endonly),
+                 opt.comm_stream is not None)
+    dist.destroy_process_group()
+
+
+def test_rccl_carries_the_overlapped_gradient_buckets():
+    mp.set_start_method('spawn', force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + os.getpid() % 1000
+    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    if ret[0][0] == 'skip':
+        pytest.skip('no RCCL process group on this box: ' + ret[0][1])
+    _, g_a, g_b, g, l_a, losses, overlapped, nb, n_end, has_stream = ret[0]
+    assert has_stream and nb > 4
+    assert overlapped > 0                 # buckets went out over RCCL from the hooks, during backward
+    assert 0 < n_end < nb
+    assert abs(losses[0] - l_a[0]) <= 1e-4 * abs(l_a[0]) and all(torch.isfinite(torch.tensor(losses)))
+    gmax = float(g_a.abs().max())
+    floor = float((g_a - g_b).abs().max())
+    err = float((g - g_a).abs().max())
+    assert err <= max(5 * floor, 2e-3 * gmax), (err, floor, gmax)
+    assert float(g.abs().max()) > 0.5 * gmax

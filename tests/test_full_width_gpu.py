@@ -4,8 +4,9 @@ the CPU oracle (itself pinned bit-exact against the reference, tests/test_oracle
 
   (i)   configs[1]: 1-stage MSPN-50 + FPN + DASHead, eval, B = 1: f32 head maps within 2e-4 of the map range, decode
         kept indices identical (mspn_mmpose.py:657-667, das_head.py:232-267, 653-796);
-  (ii)  configs[2]: 4-stage train step, B = 2: the four losses f32 vs oracle within 1e-3, bf16 vs f32 within a stated
-        band; bf16 vs f32 decode overlap at full size;
+  (ii)  configs[2]: train-mode forward + the four losses, B = 2: 1 stage f32 vs oracle within 1e-4; 4 stages (chaotic
+        at the percent level, in the oracle too) within measured bands; bf16 vs f32 within a stated band; bf16 vs f32
+        decode overlap at full size;
   (iii) configs[4]: exp_mupots topology (3 stages, J = 21, root 14, two recursive-update layers), 768 x 1024, B = 1:
         f32 head maps and decode against the oracle.
 The CPU side costs a few seconds per case (it is the `cpu_baseline` leg of bench.py).
@@ -127,52 +128,66 @@ def test_mupots_three_stage_full_width_eval_f32_maps_and_decode_match_the_oracle
     check_maps_and_decode(refmaps, ref, maps, out, 2e-4)
 
 
-def test_four_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
-    """One train-mode forward + the four losses at B = 2 (batch statistics over two frames): f32 HIP against the
-    oracle, bf16 HIP against f32 HIP. Yardstick for f32 (as in test_train_gpu.py): the oracle evaluated in f64 is
-    the truth, and the oracle's OWN f32 evaluation shows how far f32 rounding moves a loss through ~200 train-mode
-    BatchNorm layers at these widths. With statistics over two frames and random weights the net is chaotic at the
-    percent level: the oracle's f32 run sits 0.1...1.3 % from its f64 run, and two f32 runs of either implementation
-    differ by as much between themselves (summation order of the statistics). The HIP f32 path must sit within
-    max(6 x that deviation, 3 %) of the f64 values; the sharp f32 checks are the eval-mode maps above (2e-4).
-    Band for bf16: activations are rounded to 8 bits of mantissa after every layer; the loss values are sums over
-    ~10^5 locations and move by far less than that."""
+def train_losses_case(stages):
+    """One train-mode forward + the four losses at B = 2 (batch statistics over two frames), full width, 512 x 832:
+    the oracle in f64, the HIP path in f32 and in bf16 on the same weights and frames."""
     import bench
     from das_amd.datasets import SyntheticPoseDataset, collate
     from oracle import backbone as ob, head as oh, loss as ol
-    cfg = bench.model_cfg(4, 'f32')
+    cfg = bench.model_cfg(stages, 'f32')
     hcfg = oracle_hcfg(cfg)
     model = build(cfg, 0)
     ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=2, seed=0)
     ss = [ds[i] for i in range(2)]
     img = torch.stack([s['img'] for s in ss])
     gts = {k: [s[k] for s in ss] for k in ('gt_labels_3d', 'gt_poses_3d', 'centers2d', 'depths')}
-    ref = {}
-    for dt in (torch.float64, torch.float32):
-        bsd, nsd, hsd = [{k: (v.to(dt) if v.is_floating_point() else v) for k, v in d.items()} for d in split_sd(model)]
-        g = {k: [t.to(dt) if t.is_floating_point() else t for t in v] for k, v in gts.items()}
-        with torch.no_grad():
-            feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img.to(dt), 4, (3, 4, 6, 3), train=True), train=True)
-            outs = oh.head_forward(hsd, feats, hcfg, '', True)
-            ref[dt] = {k: float(v) for k, v in ol.head_loss(hsd, '', *outs, g, hcfg).items()}
+    dt = torch.float64
+    bsd, nsd, hsd = [{k: (v.to(dt) if v.is_floating_point() else v) for k, v in d.items()} for d in split_sd(model)]
+    g = {k: [t.to(dt) if t.is_floating_point() else t for t in v] for k, v in gts.items()}
+    with torch.no_grad():
+        feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img.to(dt), stages, (3, 4, 6, 3), train=True), train=True)
+        outs = oh.head_forward(hsd, feats, hcfg, '', True)
+        truth = {k: float(v) for k, v in ol.head_loss(hsd, '', *outs, g, hcfg).items()}
     data = collate(ss, device=DEV)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     model.to(DEV).train()
     with torch.no_grad():
         l32 = {k: float(v) for k, v in model.train_step(data)['log_vars'].items()}
-    report = {k: (l32[k], ref[torch.float32][k], ref[torch.float64][k]) for k in ref[torch.float64]}
-    for k, truth in ref[torch.float64].items():
-        band = max(6 * abs(ref[torch.float32][k] - truth), 3e-2 * abs(truth)) + 1e-5
-        assert abs(l32[k] - truth) <= band, (k, report)
-    cfgb = bench.model_cfg(4, 'bf16')
-    mb = build(cfgb, 0)
+    mb = build(bench.model_cfg(stages, 'bf16'), 0)
     mb.load_state_dict(sd0)
     mb.to(DEV).train()
     with torch.no_grad():
         lbf = {k: float(v) for k, v in mb.train_step(data)['log_vars'].items()}
-    print('full-width 4-stage losses  hip f32 / oracle f32 / oracle f64:', report, ' hip bf16:', lbf)
-    for k in ref[torch.float64]:
-        assert abs(lbf[k] - l32[k]) <= 3e-2 * abs(l32[k]) + 1e-3, (k, lbf[k], l32[k])
+    print(f'full-width {stages}-stage train losses  oracle f64:', truth, ' hip f32:', l32, ' hip bf16:', lbf)
+    return truth, l32, lbf
+
+
+def test_one_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
+    """The SHARP train-mode check at full width: through the ~55 train-mode BatchNorm layers of one stage the four
+    losses of the f32 HIP path sit within 3e-6 of the oracle's f64 values (profiles/r03_loss_spread.txt; VERDICT r2
+    asked for 1e-3) — asserted at 1e-4. bf16 (activations rounded to 8 bits of mantissa after every layer) was
+    measured 0.3-1.5 % from f64 with a run-to-run spread of 0.15-1.2 %; band 4 %."""
+    truth, l32, lbf = train_losses_case(1)
+    for k, t in truth.items():
+        assert abs(l32[k] - t) <= 1e-4 * abs(t), (k, l32[k], t)
+        assert abs(lbf[k] - l32[k]) <= 4e-2 * abs(l32[k]), (k, lbf[k], l32[k])
+
+
+def test_four_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
+    """The benchmarked 4-stage topology. With statistics over two frames and random weights this net is chaotic at the
+    percent level — in the oracle as well: its own f32 evaluation lands 0.15 % (cls, depth) to 1.5 % (pose,
+    centerness) from its f64 evaluation, and differently from run to run (thread-dependent summation order). On the
+    HIP path (BatchNorm statistics summed with float atomics) six f32 runs on identical weights and frames spread by
+    0.6-1.2 % (cls, depth, centerness) and 2.7 % (pose) and lie at most 0.9 % / 2.9 % from the f64 values; six bf16
+    runs spread by 0.8-2.3 % / 5.6 % (tools/dev/loss_spread.py -> profiles/r03_loss_spread.txt). So this test can
+    only bound, not pin: f32 within 4 % (pose: 12 %) of f64, bf16 within 8 % (pose: 20 %) of f32 — about four times
+    the measured extremes. The sharp checks are the 1-stage losses above (1e-4), the eval-mode maps (2e-4) and the
+    per-kernel full-width tests (tests/test_conv_tiles_gpu.py, test_bn_fused_gpu.py)."""
+    truth, l32, lbf = train_losses_case(4)
+    for k, t in truth.items():
+        wide = k in ('loss_pose', 'loss')
+        assert abs(l32[k] - t) <= (12e-2 if wide else 4e-2) * abs(t), (k, l32[k], t)
+        assert abs(lbf[k] - l32[k]) <= (20e-2 if wide else 8e-2) * abs(l32[k]), (k, lbf[k], l32[k])
 
 
 def test_bf16_decode_overlaps_f32_at_full_size():
