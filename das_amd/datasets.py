@@ -41,10 +41,38 @@ class SyntheticPoseDataset:
                     centers2d=torch.from_numpy(c.astype(np.float32)), depths=torch.from_numpy(depth.astype(np.float32)))
 
 
+ANNOTATION_KEYS = ('gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths')
+
+
+def pack_to_device(arrays, device):
+    """numpy arrays -> device tensors of the same shapes / dtypes with ONE host-to-device copy: the arrays are laid out
+    back to back (16-byte aligned) in one byte buffer and the results are views of its device copy."""
+    offs, total = [], 0
+    for a in arrays:
+        total = (total + 15) // 16 * 16
+        offs.append(total)
+        total += a.nbytes
+    host = np.zeros(max(total, 16), dtype=np.uint8)
+    for a, o in zip(arrays, offs):
+        if a.nbytes:
+            host[o:o + a.nbytes] = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+    dev = torch.from_numpy(host).to(device, non_blocking=True)
+    out = []
+    for a, o in zip(arrays, offs):
+        dt = torch.from_numpy(np.empty(0, dtype=a.dtype)).dtype
+        if a.nbytes == 0:
+            out.append(torch.empty(a.shape, dtype=dt, device=device))
+        else:
+            out.append(dev[o:o + a.nbytes].view(dt).view(a.shape))
+    return out
+
+
+
 def collate(samples, device=None):
     """Batch a list of samples the way mmcv's collate + scatter would hand them to `model(**data)`: images of
     different (padded) sizes are zero-padded bottom / right to the largest one (mmcv.parallel.collate on stacked
-    DataContainers), annotations stay per-image lists."""
+    DataContainers), annotations stay per-image lists. With a GPU `device` the ~100 small annotation tensors of a
+    batch go up in ONE host-to-device copy (`pack_to_device`) instead of one each."""
     def dev(t):
         return t.to(device, non_blocking=True) if device is not None else t
     imgs = [s['img'] for s in samples]
@@ -56,8 +84,15 @@ def collate(samples, device=None):
         for b, i in enumerate(imgs):
             img[b, :, :i.shape[-2], :i.shape[-1]] = i
     out = dict(img=dev(img), img_metas=[s['img_metas'] for s in samples])
-    for k in ('gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths'):
-        out[k] = [dev(s[k]) for s in samples]
+    keys = [k for k in ANNOTATION_KEYS if k in samples[0]]
+    if device is not None and torch.device(device).type == 'cuda' and \
+            all(torch.is_tensor(s[k]) and not s[k].is_cuda for s in samples for k in keys):
+        flat = pack_to_device([s[k].numpy() for k in keys for s in samples], device)
+        for j, k in enumerate(keys):
+            out[k] = flat[j * len(samples):(j + 1) * len(samples)]
+    else:
+        for k in keys:
+            out[k] = [dev(s[k]) for s in samples]
     return out
 
 

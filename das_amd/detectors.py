@@ -3,6 +3,7 @@ SingleStageDetector / BaseDetector protocol): backbone -> neck -> bbox_head, `fo
 returning the loss dict, `simple_test` returning per-image pose dicts, `train_step` /
 `forward(return_loss=...)` as the runner calls them (tools/train.py, mmdet3d/apis/test.py:39)."""
 from collections import OrderedDict
+from collections.abc import Mapping
 
 import torch
 import torch.distributed as dist
@@ -23,15 +24,41 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-class LazyLogVars:
-    """The step's log variables still on the device (names + one stacked tensor, already averaged over the ranks);
-    `resolve()` copies them to the host once and returns the OrderedDict of floats `_parse_losses` returns eagerly."""
+class LazyLogVars(Mapping):
+    """The step's log variables (names + one stacked tensor, already averaged over the ranks) as a read-only mapping
+    name -> float that does not stall the step: the device-to-host copy is queued at once into page-locked memory and
+    the host only waits for it when a value is READ (mmdet's `_parse_losses` reads every value back right after the
+    forward pass — a host synchronisation per step; the logger looks at them every `log_config.interval` steps)."""
 
     def __init__(self, names, vals):
-        self.names, self.vals = names, vals
+        self.names = list(names)
+        self._dict = None
+        if vals.is_cuda:
+            self._host = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
+            self._host.copy_(vals, non_blocking=True)
+            self._done = torch.cuda.Event()
+            self._done.record()
+        else:
+            self._host, self._done = vals, None
 
     def resolve(self):
-        return OrderedDict(zip(self.names, self.vals.tolist()))
+        if self._dict is None:
+            if self._done is not None:
+                self._done.synchronize()
+            self._dict = OrderedDict(zip(self.names, self._host.tolist()))
+        return self._dict
+
+    def __getitem__(self, k):
+        return self.resolve()[k]
+
+    def __iter__(self):
+        return iter(self.names)
+
+    def __len__(self):
+        return len(self.names)
+
+    def __repr__(self):
+        return repr(self.resolve())
 
 
 @DETECTORS.register_module()

@@ -421,7 +421,7 @@ def build_optimizer(model, cfg, optimizer_config=None):
 
 def train_iteration(model, optimizer, data, lr):
     """One optimisation step: forward + losses + backward (HIP kernels under autograd), gradient
-    all-reduce over RCCL, fused clip + SGD. Returns the detector's `train_step` dict."""
+    all-reduce over RCCL, fused clip + SGD. Returns the detector's `train_step` dict (queued, not waited for)."""
     optimizer.zero_grad()
     # the log variables stay on the device until the whole step has been queued: read back right after the forward
     # pass (as mmdet's `_parse_losses` does) they drain the launch queue, and backward then starts from an empty one
@@ -430,6 +430,7 @@ def train_iteration(model, optimizer, data, lr):
     out['loss'].backward()
     optimizer.all_reduce_grads()
     optimizer.step(lr)
-    if hasattr(out['log_vars'], 'resolve'):
-        out['log_vars'] = out['log_vars'].resolve()
+    # (`out['log_vars']` is a LazyLogVars: a mapping name -> float whose values reach the host without stalling this
+    # thread; reading one waits for this step's forward pass only. The step is NOT synchronised with the host here:
+    # the next batch can be fetched and the next step queued while this one still runs.)
     return out

@@ -18,6 +18,7 @@ parameters as the reference pipeline would.
 """
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -45,11 +46,59 @@ def _img_ops():
     return image_ops
 
 
+# True in the worker processes of das_amd.loader.ProcessLoader (which never touch the GPU): LoadImageFromFile hands the
+# decoded frame on as an image_ops.FramePlan, every image op of the later stages is recorded on it instead of run, and
+# the trainer replays the record on the GPU. The annotation arithmetic and the random draws are the same code either way.
+DEFER_IMAGE_OPS = False
+
+
 def _is_dev(img):
     return isinstance(img, torch.Tensor) and img.is_cuda
 
 
 # ---------------------------------------------------------------------------------------------- loading
+class _Staging(threading.local):
+    """Per-thread page-locked staging buffers for the frame upload, allocated once per frame size and reused (two per
+    size, alternating: the copy out of one may still be in flight while the next frame is decoded into the other).
+    Why: a host-to-device copy from ordinary (pageable) memory makes the HIP runtime page-lock and unlock the 6 MB
+    source around every copy — driver work that stalls the other streams of the GPU: 16 such uploads per step beside
+    the trainer cost it a quarter of its throughput, although the data path's own GPU time is 0.2 ms per frame
+    (tools/dev/scripts/loader_prof.sh). Allocating page-locked memory per frame is worse still (hipHostMalloc
+    synchronises the device); a persistent buffer costs one host memcpy per frame."""
+    CAP = 256 << 20      # bytes of page-locked memory per thread; frames beyond that go up from pageable memory
+
+    def __init__(self):
+        self.rings, self.bytes = {}, 0
+
+    def upload(self, img, device):
+        n = img.nbytes
+        ring = self.rings.get(n)
+        if ring is None:
+            if self.bytes + 2 * n > self.CAP:
+                return torch.from_numpy(img).to(device)
+            ring = self.rings[n] = [[torch.empty(n, dtype=torch.uint8).pin_memory(), None] for _ in range(2)] + [0]
+            self.bytes += 2 * n
+        slot = ring[ring[2]]
+        ring[2] ^= 1
+        if slot[1] is not None:
+            slot[1].synchronize()        # the copy that last read this buffer is done (two uploads ago: no wait in practice)
+        np.copyto(slot[0].numpy().reshape(img.shape), img)
+        t = slot[0].view(img.shape).to(device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return t
+
+
+_STAGING = _Staging()
+
+
+def _to_device(img, device):
+    """HWC uint8 frame -> device tensor; through this thread's page-locked staging buffers when `device` is a GPU."""
+    if torch.device(device).type != 'cuda' or img.dtype != np.uint8:
+        return torch.from_numpy(img).to(device)
+    return _STAGING.upload(np.ascontiguousarray(img), device)
+
+
 @PIPELINES.register_module()
 class LoadImageFromFile:
     """mmdet LoadImageFromFile(to_float32=True): BGR HWC. The decoded frame goes to the device at once (`device`,
@@ -63,9 +112,18 @@ class LoadImageFromFile:
             filename = os.path.join(results['img_prefix'], results['img_info']['filename'])
         else:
             filename = results['img_info']['filename']
-        if filename.endswith('.npy'):
+        if DEFER_IMAGE_OPS:
+            rgb = not filename.endswith('.npy')
+            if rgb:
+                from PIL import Image
+                pil = Image.open(filename)
+                img = np.array(pil if pil.mode == 'RGB' else pil.convert('RGB'))
+            else:
+                img = np.ascontiguousarray(np.load(filename))
+            t = _img_ops().FramePlan(img, rgb=rgb, to_float=self.to_float32)
+        elif filename.endswith('.npy'):
             img = np.ascontiguousarray(np.load(filename))
-            t = torch.from_numpy(img).to(self.device)
+            t = _to_device(img, self.device)
         else:
             # RGB -> BGR on the device: reversing the channel axis of a 1920 x 1080 frame on the host is a strided
             # byte copy of 11 ms that holds the GIL (the JPEG decode itself, 10 ms, releases it) — with it, eight
@@ -75,12 +133,12 @@ class LoadImageFromFile:
             if pil.mode != 'RGB':           # (convert() copies the frame even when there is nothing to convert: 1.2 ms)
                 pil = pil.convert('RGB')
             img = np.array(pil)
-            t = torch.from_numpy(img).to(self.device).flip(-1)
-        if self.to_float32:
-            t = t.float()
+            t = _to_device(img, self.device).flip(-1)
+        if not DEFER_IMAGE_OPS:
+            t = (t.float() if self.to_float32 else t).contiguous()
         results['filename'] = filename
         results['ori_filename'] = results['img_info']['filename']
-        results['img'] = t.contiguous()
+        results['img'] = t
         results['img_shape'] = tuple(img.shape)
         results['ori_shape'] = tuple(img.shape)
         results['img_fields'] = ['img']
@@ -350,7 +408,7 @@ class PhotoMetricDistortion:
 
     def __call__(self, results):
         p = results['photometric'] = self.draw()
-        _img_ops().photometric_(results['img'], **p)
+        results['img'] = _img_ops().photometric_(results['img'], **p)
         return results
 
 

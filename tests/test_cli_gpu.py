@@ -173,10 +173,18 @@ data = dict(samples_per_gpu=2, train=dict(_delete_=True, type='CMUPanopticDatase
                                           pipeline=train_pipeline, use_bbox_center=False, abs_dz=True, norm_depth=True,
                                           depth_factor=1))
 """)
-    # (workers_per_gpu=4 from the base config: decode + augmentation run in the prefetch threads, das_amd/loader.py)
+    # (workers_per_gpu=4 from the base config; worker_mode=thread: decode + augmentation run in prefetch threads of the
+    # trainer's process, das_amd.loader.PrefetchLoader)
     out = run('tools/train.py', str(cfg), '--work-dir', str(tmp_path / 'w'), '--max-iters', '3', '--no-validate',
-              '--cfg-options', 'model.backbone.num_stages=1', 'runner.max_epochs=1', 'log_config.interval=1')
+              '--cfg-options', 'model.backbone.num_stages=1', 'runner.max_epochs=1', 'log_config.interval=1',
+              'data.worker_mode=thread')
     assert 'loss_pose' in out and 'nan' not in out.lower(), out[-800:]
+    # the same with worker PROCESSES (the default: CPU-only workers decode and move the annotations, the recorded image
+    # ops are replayed here on the GPU, das_amd.loader.ProcessLoader); two epochs through one pool
+    out = run('tools/train.py', str(cfg), '--work-dir', str(tmp_path / 'wp'), '--max-iters', '5', '--no-validate',
+              '--cfg-options', 'model.backbone.num_stages=1', 'runner.max_epochs=2', 'log_config.interval=1',
+              'data.workers_per_gpu=2')
+    assert 'loss_pose' in out and 'nan' not in out.lower() and 'Epoch [2]' in out, out[-800:]
 
 
 def test_process_loader_hands_device_batches_over_in_order():

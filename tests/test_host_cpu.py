@@ -223,6 +223,9 @@ def test_lazy_log_vars_equal_the_eager_ones():
     assert float(loss_e) == 0.5 + (1.5 + 3.0) + 3.0
     got = lv_l.resolve()
     assert list(got) == list(lv_e) == ['loss_cls', 'loss_pose', 'acc', 'loss_depth', 'loss'] and got == lv_e
+    # the lazy form IS a mapping (what train_iteration hands back): reading it resolves it
+    assert list(lv_l) == list(lv_e) and dict(lv_l.items()) == lv_e and lv_l['loss'] == lv_e['loss'] and len(lv_l) == 5
+    assert lv_l == lv_e and 'acc' in lv_l
 
 
 @pytest.mark.parametrize('n,world', [(10, 4), (8, 4), (3, 4), (7, 2), (1, 3), (0, 2)])

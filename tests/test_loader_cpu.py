@@ -61,3 +61,17 @@ def test_look_ahead_is_bounded():
     time.sleep(0.2)
     assert len(ds.calls) <= 1 + 2 + 2 + 1     # consumed + workers + depth (+ the permit the consumer just returned)
     assert [b for b in it] == [[i] for i in range(1, 40)]
+
+
+def test_pack_to_device_keeps_shapes_dtypes_and_values():
+    """One buffer, one copy: the packed views must be the arrays (mixed dtypes, odd sizes, an empty one in the middle)."""
+    import numpy as np
+    from das_amd.datasets import pack_to_device
+    rs = np.random.RandomState(0)
+    arrays = [rs.randn(3, 15, 4).astype(np.float32), np.arange(3, dtype=np.int64), np.zeros((0, 4), np.float32),
+              rs.randn(5).astype(np.float64), rs.randint(0, 9, (2, 7)).astype(np.int32), rs.randn(1, 1).astype(np.float32)]
+    out = pack_to_device(arrays, 'cpu')
+    assert len(out) == len(arrays)
+    for a, t in zip(arrays, out):
+        assert tuple(t.shape) == a.shape and t.numpy().dtype == a.dtype
+        np.testing.assert_array_equal(t.numpy(), a)

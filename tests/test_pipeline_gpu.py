@@ -194,6 +194,65 @@ def test_resize_uint8_bit_exact(hw, size):
     assert got.dtype == np.uint8 and np.array_equal(got, O.resize_bilinear_u8(img, size))
 
 
+def test_recorded_image_ops_replay_bit_identically(tmp_path):
+    """The worker-process path of das_amd.loader.ProcessLoader: with `pipelines.DEFER_IMAGE_OPS` the stages record their
+    image ops on a FramePlan (no GPU call) and draw / move the annotations as ever; the replay on the GPU must give the
+    immediate path's image bit for bit, into a batch slot as well, for both frame kinds (.npy BGR, PIL-decoded RGB) —
+    and the plan must survive pickling (it crosses a process boundary)."""
+    import pickle
+    from PIL import Image
+    from das_amd import pipelines as P
+    from das_amd.image_ops import FramePlan
+    h, w = 270, 480
+    frame = np.random.RandomState(5).randint(0, 256, (h, w, 3)).astype(np.uint8)
+    np.save(tmp_path / 'frame.npy', frame)
+    Image.fromarray(frame).save(tmp_path / 'frame.png')
+    ann = PC.annotations(21, n=5, h=h, w=w)
+    cfg = [
+        dict(type='LoadImageFromFile', to_float32=True),
+        dict(type='LoadAnnotationsPose3D', with_bbox=True, with_label=True),
+        dict(type='ResizePose', scale_depth=True, abs_dz=False, img_scale=[(667, 256), (667, 320)], multiscale_mode='range',
+             keep_ratio=True),
+        dict(type='RandomFlipPose3D', flip_ratio_bev_horizontal=0.5, flip_pairs=PC.FLIP_PAIRS, num_joints=PC.J),
+        dict(type='PhotoMetricDistortion', brightness_delta=32, contrast_range=(0.7, 1.3), saturation_range=(0.7, 1.3),
+             hue_delta=18),
+        dict(type='GlobalRotScaleTransPose', scale_depth=True, abs_dz=False, rot_range=[-0.1, 0.1],
+             scale_ratio_range=[0.9, 1.1], translation_std=[0.02, 0.02], num_joints=PC.J, img_norm_cfg=PC.IMG_NORM,
+             use_bbox_center=False),
+        dict(type='Normalize', **PC.IMG_NORM),
+        dict(type='Pad', size_divisor=32),
+        dict(type='DefaultFormatBundlePose3D', class_names=['person']),
+        dict(type='Collect3D', keys=['img', 'gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths']),
+    ]
+    pipe = P.Compose(cfg)
+    for name in ('frame.npy', 'frame.png'):
+        src = dict(img_info=dict(filename=str(tmp_path / name)), img_prefix=None,
+                   ann_info=dict(bboxes=ann['gt_bboxes'], labels=ann['gt_labels'], centers2d=ann['centers2d'],
+                                 depths=ann['depths'], gt_poses_3d=ann['gt_poses_3d'], gt_labels_3d=ann['gt_labels_3d']))
+        for seed in (1, 2, 3):
+            np.random.seed(seed)
+            now = pipe(copy.deepcopy(src))
+            P.DEFER_IMAGE_OPS = True
+            try:
+                np.random.seed(seed)
+                later = pipe(copy.deepcopy(src))
+            finally:
+                P.DEFER_IMAGE_OPS = False
+            if now is None:
+                assert later is None
+                continue
+            plan = later['img']
+            assert isinstance(plan, FramePlan) and tuple(plan.shape) == tuple(now['img'].shape)
+            plan = pickle.loads(pickle.dumps(plan))
+            assert torch.equal(plan.run('cuda'), now['img'])
+            batch = torch.full((2,) + tuple(plan.shape), 7.0, device='cuda')
+            plan.run('cuda', out=batch[1])
+            assert torch.equal(batch[1], now['img']) and float(batch[0].min()) == 7.0
+            for k in ('gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths'):
+                assert torch.equal(later[k], now[k]), k
+            assert later['img_metas']['flip'] == now['img_metas']['flip']
+
+
 def test_test_pipeline_chain(tmp_path):
     """configs/das/exp_panoptic.py:138-155: MultiScaleFlipAug(img_scale, flip=False)[Resize, RandomFlipPose3D(0),
     Normalize, Pad, DefaultFormatBundlePose3D, Collect3D] on an 8-bit frame."""

@@ -76,10 +76,40 @@ def dataset_cfg(root):
                 depth_factor=1)
 
 
+class Usage:
+    """CPU seconds of this process (+ children) and the cgroup's throttling counters over a phase."""
+
+    def __init__(self):
+        self.t0, self.c0, self.s0 = time.perf_counter(), self._cpu(), self._stat()
+
+    @staticmethod
+    def _cpu():
+        t = os.times()
+        return t.user + t.system + t.children_user + t.children_system
+
+    @staticmethod
+    def _stat():
+        for f in ('/sys/fs/cgroup/cpu.stat', '/sys/fs/cgroup/cpu/cpu.stat'):
+            try:
+                return {k: int(v) for k, v in (ln.split() for ln in open(f))}
+            except OSError:
+                continue
+        return {}
+
+    def __str__(self):
+        dt = time.perf_counter() - self.t0
+        s1 = self._stat()
+        d = {k: s1[k] - self.s0.get(k, 0) for k in s1}
+        thr = d.get('throttled_usec', d.get('throttled_time', 0) / 1e3) / 1e6
+        grp = d.get('usage_usec', 0) / 1e6
+        return (f'[{(self._cpu() - self.c0) / dt:4.1f} cores busy in this process tree, cgroup {grp / dt:4.1f} cores, '
+                f'throttled {d.get("nr_throttled", 0)} periods / {thr:.2f} s of {dt:.1f} s]')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--frames', type=int, default=64)
-    ap.add_argument('--batches', type=int, default=10)
+    ap.add_argument('--batches', type=int, default=40)
     ap.add_argument('--spg', type=int, default=16)
     ap.add_argument('--no-train', action='store_true')
     ap.add_argument('--probe', action='store_true', help='diagnostics: trainer on a resident batch beside the loader variants')
@@ -96,14 +126,14 @@ def main():
     one = next(iter(PrefetchLoader(ds, [[0]], collate, workers=0)))     # (re-draws when the augmentation drops the sample)
     print('sample image', tuple(one['img'].shape), flush=True)
 
-    for workers in (0, 1, 2, 4, 8):
+    for workers in (0, 4):
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t0, use = time.perf_counter(), Usage()
         for data in PrefetchLoader(ds, batches, collate, workers=workers):
             pass
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f'loader alone, workers={workers}: {len(order) / dt:7.1f} img/s', flush=True)
+        print(f'loader alone, workers={workers}: {len(order) / dt:7.1f} img/s  {use}', flush=True)
     if args.no_train:
         return
     model = bench.build_model(torch.device('cuda', 0), num_stages=4, train=True)
@@ -117,11 +147,11 @@ def main():
         print('trunk captured as hipGraphs', flush=True)
         train_iteration(model, opt, first, 2e-3)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    t0, use = time.perf_counter(), Usage()
     for _ in range(len(batches)):
         train_iteration(model, opt, first, 2e-3)
     torch.cuda.synchronize()
-    print(f'train step alone (resident batch {tuple(first["img"].shape)}): {len(order) / (time.perf_counter() - t0):7.1f} img/s',
+    print(f'train step alone (resident batch {tuple(first["img"].shape)}): {len(order) / (time.perf_counter() - t0):7.1f} img/s  {use}',
           flush=True)
     if args.probe:
         # what slows the trainer down beside the loader? (a) the full loader, its batches discarded; (b) decode only
@@ -150,15 +180,17 @@ def main():
                 print(f'trainer on a resident batch beside [{name}], workers={workers}: {len(order) / (time.perf_counter() - t0):7.1f} img/s',
                       flush=True)
         return
-    for workers in (0, 2, 4, 8):
+    for workers in (4,):
+        for data in PrefetchLoader(ds, batches[:3], collate, workers=workers):     # (warm: allocator pools of the streams)
+            train_iteration(model, opt, data, 2e-3)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t0, use = time.perf_counter(), Usage()
         for data in PrefetchLoader(ds, batches, collate, workers=workers):
             train_iteration(model, opt, data, 2e-3)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f'loader threads + 4-stage train step, workers={workers}: {len(order) / dt:7.1f} img/s', flush=True)
-    for workers in (4, 8):
+        print(f'loader threads + 4-stage train step, workers={workers}: {len(order) / dt:7.1f} img/s  {use}', flush=True)
+    for workers in (4,):
         t0 = time.perf_counter()
         pl = ProcessLoader(dataset_cfg(root), workers=workers)
         print(f'{workers} worker processes up in {time.perf_counter() - t0:.1f} s', flush=True)
@@ -170,12 +202,36 @@ def main():
             pass
         torch.cuda.synchronize()
         print(f'loader processes alone, workers={workers}: {len(order) / (time.perf_counter() - t0):7.1f} img/s', flush=True)
-        t0 = time.perf_counter()
-        for data in pl.batches(batches):
+        kept = list(pl.batches(batches))
+        for data in kept[:3]:
             train_iteration(model, opt, data, 2e-3)
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for data in kept:
+            train_iteration(model, opt, data, 2e-3)
+        torch.cuda.synchronize()
+        print(f'train step alone on {len(kept)} DIFFERENT resident batches: {len(order) / (time.perf_counter() - t0):7.1f} img/s', flush=True)
+        del kept, data
+        for data in pl.batches(batches[:3]):
+            train_iteration(model, opt, data, 2e-3)
+        torch.cuda.synchronize()
+        t0, use, h0, w0, l0 = time.perf_counter(), Usage(), pl.host_seconds, pl.wait_seconds, pl.late_batches
+        it, t_next, t_step = iter(pl.batches(batches)), 0.0, 0.0
+        while True:
+            a = time.perf_counter()
+            data = next(it, None)
+            b = time.perf_counter()
+            if data is None:
+                break
+            train_iteration(model, opt, data, 2e-3)
+            t_next, t_step = t_next + b - a, t_step + time.perf_counter() - b
+        torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f'loader processes + 4-stage train step, workers={workers}: {len(order) / dt:7.1f} img/s', flush=True)
+        print(f'   per batch: {t_next / len(batches) * 1e3:.1f} ms in next(loader), {t_step / len(batches) * 1e3:.1f} ms in train_iteration (host), '
+              f'{dt / len(batches) * 1e3:.1f} ms wall; blocked for a batch {(pl.wait_seconds - w0) / len(batches) * 1e3:.1f} ms per batch, '
+              f'{pl.late_batches - l0} of {len(batches)} batches not ready one step ahead', flush=True)
+        print(f'loader processes + 4-stage train step, workers={workers}: {len(order) / dt:7.1f} img/s  {use}  '
+              f'(upload + replay of the image ops: {(pl.host_seconds - h0) / len(batches) * 1e3:.1f} ms of this thread per batch)', flush=True)
         pl.close()
 
 

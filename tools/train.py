@@ -123,10 +123,12 @@ def main():
         val_dataset = build_dataset(val_cfg)
     spg = cfg.data.get('samples_per_gpu', 4)
     workers = cfg.data.get('workers_per_gpu', 0)
-    # data.worker_mode: 'thread' (default: threads of this process, das_amd.loader.PrefetchLoader) or 'process' (the
-    # reference's model: worker processes, each with its own interpreter and HIP context, batches handed over by IPC)
+    # data.worker_mode: 'process' (default, the reference's model: `workers_per_gpu` worker processes — here CPU-only:
+    # decode, random draws and annotation arithmetic; the image ops they record are replayed on this GPU one batch
+    # ahead, das_amd.loader.ProcessLoader) or 'thread' (threads of this process running the whole pipeline,
+    # das_amd.loader.PrefetchLoader: no start-up cost, but they share the interpreter lock with the trainer)
     pool = None
-    if workers > 0 and cfg.data.get('worker_mode', 'thread') == 'process':
+    if workers > 0 and cfg.data.get('worker_mode', 'process') == 'process':
         pool = ProcessLoader(cfg.data.train, device=f'cuda:{local_rank}', workers=workers, seed=args.seed + 1000 * rank)
     lrc = cfg.get('lr_config', {})
     max_epochs = cfg.get('runner', {}).get('max_epochs', 12)
