@@ -1,8 +1,10 @@
 """Batches prepared ahead of the trainer.
 
 The reference trains with `workers_per_gpu=4` (configs/das/exp_panoptic.py:159-160 -> mmdet `build_dataloader`: worker
-processes decode and augment on the CPU). Here augmentation already runs on the GPU (das_amd/pipelines.py), so what is
-left on the host is the JPEG decode and the annotation arithmetic; `PrefetchLoader` moves both off the training thread:
+processes decode and augment on the CPU). Here augmentation runs on the GPU (das_amd/pipelines.py), so what is left on
+the host is the JPEG decode and the annotation arithmetic. Two loaders: `ProcessLoader` (further down; what
+tools/train.py uses by default) keeps the reference's worker processes for the host work and replays the image ops in
+the trainer; `PrefetchLoader` does everything in threads of the trainer's process:
 
   * `workers` background THREADS (PIL's decoder and the host-to-device copy release the GIL) build whole batches, each
     on its own HIP stream: `dataset[i]` for every index of the batch — the pipeline's GPU kernels are queued on that
