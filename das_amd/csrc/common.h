@@ -85,6 +85,24 @@ __device__ __forceinline__ void fold_slots_to_lds(const float* __restrict__ src,
   __syncthreads();
 }
 
+// The same fold as a launch of its own (one thread per value, 256 per workgroup), for the passes over large tensors
+// that run as many small workgroups (bn_apply_stream_kernel, bn_bwd_apply_dz_stream_kernel). Same summation order
+// as fold_slots_to_lds: both give the same bits.
+static __global__ __launch_bounds__(256) void fold_slots_kernel(const float* __restrict__ src, int slots, int n,
+                                                                 float* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int k0 = 0; k0 < slots; k0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (k0 + k < slots) ? src[(size_t)(k0 + k) * n + i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += v[k];
+  }
+  dst[i] = a;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

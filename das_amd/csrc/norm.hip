@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include "tuning.h"
+#include "workspace.h"
 
 namespace {
 constexpr int TPB = 256;
@@ -252,6 +253,76 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
   for (; p < p1; p += PL)
     *reinterpret_cast<uint4*>(y + off + (long long)p * ps) = norm(*reinterpret_cast<const uint4*>(x + off + (long long)p * ps));
 }
+
+// ---- the apply pass of the LARGE layers (tensors of >= ~100 MB: beyond the 256 MiB infinity cache with their residual)
+// A plain 2-read-1-write pass over 218 MB tensors reaches 5.9 TB/s on this GPU when it is launched as ~13 000 small
+// workgroups, four 16-byte vectors per thread, all loads issued before the first use — and 5.1 TB/s as a 2048-workgroup
+// grid-stride loop (tools/dev/probe/triad_probe.hip). bn_apply_kernel above cannot take the many-small-workgroups shape:
+// every workgroup folds the conv epilogue's 16 statistic slots first (32 KB of L2 reads for 256 channels against 49 KB of
+// payload per workgroup at that grid), which is why its grid is capped at 2048. So for these layers the fold is a launch
+// of its own (3 us against a pass of 110-150 us), into a per-stream scratch vector, and the pass is this kernel: the
+// per-channel constants are computed ONCE per workgroup (one channel per thread, into LDS) instead of by every thread
+// for its eight channels, the arithmetic per element is bn_apply_kernel's.
+template <typename T, int VPT>
+__global__ __launch_bounds__(TPB) void bn_apply_stream_kernel(const T* __restrict__ x, T* __restrict__ y, long long count,
+                                                              int C, const float* __restrict__ stats, long long stat_count,
+                                                              float eps, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const T* __restrict__ res,
+                                                              int relu, float* running_mean, float* running_var,
+                                                              float momentum, float* save_mean, float* save_invstd,
+                                                              long long* num_batches_tracked) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;                 // (host: TPB % VC == 0 — a thread keeps its channels for every vector it takes)
+  extern __shared__ float cst[];          // [4][C]: mean, invstd, gamma, beta
+  const float nstat = (float)stat_count;
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    const BnStat s = bn_stat(stats, C, c, nstat, eps);
+    cst[c] = s.mean; cst[C + c] = s.invstd; cst[2 * C + c] = gamma[c]; cst[3 * C + c] = beta[c];
+  }
+  if (blockIdx.x == 0)
+    bn_publish(stats, stat_count, C, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+               num_batches_tracked);
+  __syncthreads();
+  const int c0 = (threadIdx.x % VC) * EPV;
+  float mu[EPV], is[EPV], ga[EPV], be[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    mu[j] = cst[c0 + j]; is[j] = cst[C + c0 + j]; ga[j] = cst[2 * C + c0 + j]; be[j] = cst[3 * C + c0 + j];
+  }
+  const long long total = count * VC;
+  const long long base = (long long)blockIdx.x * (TPB * VPT) + threadIdx.x;
+  uint4 a[VPT], r[VPT];
+#pragma unroll
+  for (int u = 0; u < VPT; ++u) {
+    const long long i = base + u * TPB;
+    a[u] = make_uint4(0, 0, 0, 0);
+    r[u] = a[u];
+    if (i < total) {
+      a[u] = *reinterpret_cast<const uint4*>(x + i * EPV);
+      if (res) r[u] = *reinterpret_cast<const uint4*>(res + i * EPV);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < VPT; ++u) {
+    const long long i = base + u * TPB;
+    if (i >= total) break;
+    float f[EPV];
+    Elem<T>::unpack(a[u], f);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) f[j] = bn_affine(f[j], mu[j], is[j], ga[j], be[j]);
+    if (res) {
+      float rr[EPV];
+      Elem<T>::unpack(r[u], rr);
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) f[j] += rr[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) f[j] = fmaxf(f[j], 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(f);
+  }
+}
 }  // namespace
 
 extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
@@ -271,6 +342,32 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
   const int vpt = std::max(1, (int)dastune::get(dastune::BN_VPT));
   int grid = std::max(1, std::min(grid_for(count * vc), (int)((count * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
   const int nslots = stats_slots < 1 ? 1 : stats_slots;
+  // large layers: fold launch + many-small-workgroups pass (see bn_apply_stream_kernel)
+  const long long stream_from = dastune::get(dastune::BN_STREAM_MINBYTES);
+  const long long xbytes = count * C * (dtype == DAS_BF16 ? 2 : 4);
+  if (stream_from > 0 && xbytes >= stream_from && TPB % vc == 0 && count * vc / (TPB * 4) < 0x7fffffffLL) {
+    const float* folded = stats;
+    if (nslots > 1) {
+      float* ws = dasws::get(dasws::BN_FOLD, s, 2 * (size_t)C * sizeof(float), 64 << 10);
+      if (!ws) return DAS_ERR_LAUNCH;
+      hipLaunchKernelGGL(fold_slots_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, stats, nslots, 2 * C, ws);
+      DAS_CHECK_LAUNCH();
+      folded = ws;
+    }
+    constexpr int VPT = 4;
+    const int sgrid = (int)((count * vc + TPB * VPT - 1) / (TPB * VPT));
+    const size_t ssm = 4 * (size_t)C * sizeof(float);
+#define DAS_BN_STREAM(T)                                                                                              \
+  hipLaunchKernelGGL((bn_apply_stream_kernel<T, VPT>), dim3(sgrid), dim3(TPB), ssm, s, (const T*)x, (T*)y, count, C,   \
+                     folded, nstat, eps, gamma, beta, (const T*)residual, relu, running_mean, running_var, momentum,  \
+                     save_mean, save_invstd, num_batches_tracked)
+    if (dtype == DAS_BF16) DAS_BN_STREAM(bf16_t); else DAS_BN_STREAM(float);
+#undef DAS_BN_STREAM
+    DAS_CHECK_LAUNCH();
+    dastune::note_kernel("bn_apply_stream_kernel");
+    return DAS_OK;
+  }
+  dastune::note_kernel("bn_apply_kernel");
   if (nslots > 1) grid = std::min(grid, 2048);   // (every workgroup folds the slots first)
   const bool fixed = ((long long)grid * TPB) % vc == 0;
   const size_t sm = nslots > 1 ? 2 * (size_t)C * sizeof(float) : 0;

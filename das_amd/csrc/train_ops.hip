@@ -844,6 +844,60 @@ __global__ void bn_bwd_apply_dz_kernel(const T* __restrict__ dz, const T* __rest
   }
 }
 
+// bn_bwd_apply_dz_kernel for LARGE tensors (see bn_apply_stream_kernel, norm.hip): the slots were folded by a launch of
+// their own (`fsumg`: [2C]), one workgroup takes 256 * VPT vectors, all loads are issued before the first use, the
+// per-channel constants are computed once per workgroup into LDS. Arithmetic per element as above.
+template <typename T, int VPT>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_dz_stream_kernel(const T* __restrict__ dz, const T* __restrict__ raw,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ fsumg, long long rows, int C,
+                                                                     T* __restrict__ draw, float* __restrict__ dgamma_acc,
+                                                                     float* __restrict__ dbeta_acc, float inv_n) {
+  constexpr int EPV = Elem<T>::EPV;
+  extern __shared__ float cst[];   // [4][C]: mean, k1, k2, k3
+  if (blockIdx.x == 0 && dgamma_acc) {
+    for (int c = threadIdx.x; c < C; c += TPB) { dbeta_acc[c] += fsumg[c]; dgamma_acc[c] += fsumg[C + c]; }
+  }
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    const float is = invstd[c];
+    cst[c] = mean[c]; cst[C + c] = gamma[c] * is; cst[2 * C + c] = fsumg[c] * inv_n; cst[3 * C + c] = fsumg[C + c] * inv_n * is;
+  }
+  __syncthreads();
+  const int VC = C / EPV;
+  const int c0 = (threadIdx.x % VC) * EPV;
+  float mu[EPV], k1[EPV], k2[EPV], k3[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    mu[j] = cst[c0 + j]; k1[j] = cst[C + c0 + j]; k2[j] = cst[2 * C + c0 + j]; k3[j] = cst[3 * C + c0 + j];
+  }
+  const long long total = rows * VC;
+  const long long base = (long long)blockIdx.x * (TPB * VPT) + threadIdx.x;
+  uint4 gv[VPT], xv[VPT];
+#pragma unroll
+  for (int u = 0; u < VPT; ++u) {
+    const long long i = base + u * TPB;
+    gv[u] = make_uint4(0, 0, 0, 0);
+    xv[u] = gv[u];
+    if (i < total) {
+      gv[u] = *reinterpret_cast<const uint4*>(dz + i * EPV);
+      xv[u] = *reinterpret_cast<const uint4*>(raw + i * EPV);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < VPT; ++u) {
+    const long long i = base + u * TPB;
+    if (i >= total) break;
+    float g[EPV], x[EPV], o[EPV];
+    Elem<T>::unpack(gv[u], g);
+    Elem<T>::unpack(xv[u], x);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) o[j] = k1[j] * (g[j] - k2[j] - (x[j] - mu[j]) * k3[j]);
+    *reinterpret_cast<uint4*>(draw + i * EPV) = Elem<T>::pack(o);
+  }
+}
+
 template <typename T, int MASK>
 void launch_bn_backward(const void* dy, const void* y, const void* raw, long long rows, int C, const float* mean,
                         const float* invstd, const float* gamma, const float* beta, void* draw, void* dres,
@@ -1321,6 +1375,30 @@ extern "C" int das_bn_backward_apply(const void* dz, const void* raw, int dtype,
   const float inv_n = 1.f / (float)stat_rows;
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
   const int vpt = std::max(1, (int)dastune::get(dastune::BN_VPT));
+  const long long stream_from = dastune::get(dastune::BN_STREAM_MINBYTES);
+  if (stream_from > 0 && rows * C * (dtype == DAS_BF16 ? 2 : 4) >= stream_from && TPB % vc == 0 &&
+      rows * vc / (TPB * 4) < 0x7fffffffLL) {
+    const float* folded = sums;
+    if (sums_slots > 1) {
+      float* ws = dasws::get(dasws::BN_FOLD, s, 2 * (size_t)C * sizeof(float), 64 << 10);
+      if (!ws) return DAS_ERR_LAUNCH;
+      hipLaunchKernelGGL(fold_slots_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, sums, sums_slots, 2 * C, ws);
+      DAS_CHECK_LAUNCH();
+      folded = ws;
+    }
+    constexpr int VPT = 4;
+    const int sgrid = (int)((rows * vc + TPB * VPT - 1) / (TPB * VPT));
+    const size_t ssm = 4 * (size_t)C * sizeof(float);
+#define DAS_BN_DZS(T)                                                                                                   \
+  hipLaunchKernelGGL((bn_bwd_apply_dz_stream_kernel<T, VPT>), dim3(sgrid), dim3(TPB), ssm, s, (const T*)dz, (const T*)raw, \
+                     mean, invstd, gamma, folded, rows, C, (T*)draw, dgamma_acc, dbeta_acc, inv_n)
+    if (dtype == DAS_BF16) DAS_BN_DZS(bf16_t); else DAS_BN_DZS(float);
+#undef DAS_BN_DZS
+    DAS_CHECK_LAUNCH();
+    dastune::note_kernel("bn_bwd_apply_dz_stream_kernel");
+    return DAS_OK;
+  }
+  dastune::note_kernel("bn_bwd_apply_dz_kernel");
   // (at most 2048 workgroups: each folds the [slots][2C] sums into LDS before it starts)
   int grid = std::max(1, std::min(std::min(grid_for(rows * vc), 2048),
                                   (int)((rows * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));

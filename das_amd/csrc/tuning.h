@@ -32,6 +32,8 @@ enum Key {
   BN_REDUCE_THREADS,
   BN_VPT,                // 16-byte vectors per thread of the BatchNorm apply passes
   GN_PPB,                // minimum pixels per workgroup of the GroupNorm statistic passes
+  BN_STREAM_MINBYTES,    // BatchNorm apply passes over tensors of at least this many bytes: slot fold as its own launch +
+                         // a one-shot pass of small workgroups (bn_apply_stream_kernel); 0 = never
   N_KEYS
 };
 

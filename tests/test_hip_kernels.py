@@ -219,6 +219,62 @@ def test_bn_statistics_slots_equal_single_array(dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,rows,slots,res,relu', [(256, 3001, 16, True, True), (64, 1500, 16, False, True),
+                                                   (512, 777, 5, True, False), (2048, 130, 1, True, True)])
+def test_bn_apply_stream_path_equals_the_looping_kernel(dtype, C, rows, slots, res, relu):
+    """The large layers' apply pass (slot fold as its own launch + bn_apply_stream_kernel, from `bn.stream_minbytes` on)
+    must give the bits of bn_apply_kernel: output, saved mean / invstd, running statistics, batch counter — with and
+    without residual / ReLU, odd row counts (a ragged last workgroup), 1 / 5 / 16 slots, C up to 2048 (f32: 512)."""
+    o = ops()
+    if dtype == torch.float32 and C > 1024:
+        C = 1024
+    g = torch.Generator(device='cpu').manual_seed(C + rows)
+    raw = (torch.randn(1, rows, 1, C, generator=g) * 2 + 0.3).to(dtype).to(DEV)
+    r = torch.randn(1, rows, 1, C, generator=g).to(dtype).to(DEV) if res else None
+    f = raw.float().reshape(rows, C)
+    tot = torch.stack([f.sum(0), (f * f).sum(0)]).reshape(-1)
+    parts = torch.rand(slots, 2 * C, generator=g).to(DEV)
+    stats = (parts / parts.sum(0, keepdim=True) * tot).contiguous().reshape(-1)     # slots that add up to the totals
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    out = {}
+    for name, minbytes in (('loop', 0), ('stream', 1)):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+        with o.tuning(**{'bn.stream_minbytes': minbytes}):
+            y, m, i = o.bn_train_apply(raw, stats.clone(), gamma, beta, rm, rv, 0.1, 1e-5, residual=r, relu=relu,
+                                       num_batches_tracked=nbt)
+            assert o.last_kernel() == ('bn_apply_stream_kernel' if minbytes else 'bn_apply_kernel')
+        out[name] = (y, m.clone(), i.clone(), rm, rv, nbt)
+    for a, b in zip(out['loop'], out['stream']):
+        assert torch.equal(a, b)
+    assert int(out['stream'][5]) == 1
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,rows,slots', [(256, 3001, 16), (64, 1500, 16), (512, 777, 5), (1024, 130, 1)])
+def test_bn_backward_apply_stream_path_equals_the_looping_kernel(dtype, C, rows, slots):
+    """das_bn_backward_apply on large tensors (slot fold as its own launch + bn_bwd_apply_dz_stream_kernel) against the
+    looping kernel: d raw and the parameter-gradient accumulators, bit for bit."""
+    o = ops()
+    g = torch.Generator(device='cpu').manual_seed(C * 7 + rows)
+    raw = (torch.randn(1, rows, 1, C, generator=g) * 2 + 0.3).to(dtype).to(DEV)
+    dz = torch.randn(1, rows, 1, C, generator=g).to(dtype).to(DEV)
+    mean, invstd = torch.randn(C, generator=g).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    sums = torch.randn(slots * 2 * C, generator=g).to(DEV) * rows / slots
+    out = {}
+    for name, minbytes in (('loop', 0), ('stream', 1)):
+        dg, db = torch.full((C,), 0.25, device=DEV), torch.full((C,), -0.5, device=DEV)
+        with o.tuning(**{'bn.stream_minbytes': minbytes}):
+            draw = o.bn_backward_apply(dz, raw, mean, invstd, gamma, sums.clone(), dg, db)
+            assert o.last_kernel() == ('bn_bwd_apply_dz_stream_kernel' if minbytes else 'bn_bwd_apply_dz_kernel')
+        out[name] = (draw, dg, db)
+    for a, b in zip(out['loop'], out['stream']):
+        assert torch.equal(a, b)
+    assert float((out['stream'][1] - 0.25).abs().max()) > 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('C,G', [(256, 32), (64, 32), (32, 32), (768, 96)])
 def test_groupnorm(dtype, C, G):
     o = ops()

@@ -7,6 +7,10 @@ import torch
 from das_amd import ops
 
 BF = torch.bfloat16
+for a in sys.argv[1:]:                   # key=value -> das_tuning_set (A/B runs, e.g. bn.stream_minbytes=0)
+    from das_amd import _lib
+    k, v = a.split('=')
+    _lib.check(_lib.load().das_tuning_set(k.encode(), int(v)), k)
 # (rows, C): apply no-residual, apply + residual, apply_dz, classic backward (recomputed mask), classic backward (y mask + d residual)
 SHAPES = [
     ((425984, 256), 14, 16, 8, 13, 7), ((425984, 64), 27, 0, 24, 3, 0), ((106496, 512), 10, 16, 12, 10, 4),
