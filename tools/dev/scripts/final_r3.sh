@@ -25,6 +25,6 @@ prof train_eager_serial "--no-graphs --no-wgrad-stream"
 prof infer "--workload infer"
 timeout 300 python3 tools/dev/conv_stamps.py > $O/conv_phase_stamps.txt 2>&1
 timeout 900 python3 tools/dev/loader_bench.py > $O/loader_bench.txt 2>&1
-timeout 300 python3 tools/dev/step_times.py > $O/step_times.txt 2>&1
+timeout 300 python3 tools/dev/step_times.py 30 graphs > $O/step_times.txt 2>&1
 for f in train train_nographs infer decode; do cut -c1-300 $O/${f}_bench_line.json; echo; done
 cut -c1-400 $O/cpu_baseline_full.json

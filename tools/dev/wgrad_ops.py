@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from das_amd import ops
 
+for a in sys.argv[1:]:                   # key=value -> das_tuning_set
+    from das_amd import _lib
+    k_, v_ = a.split('=')
+    _lib.check(_lib.load().das_tuning_set(k_.encode(), int(v_)), k_)
 batches = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wgrad_batches.json')))
 cnt = collections.Counter(json.dumps(o, sort_keys=True) for b in batches for o in b)
 rows = []
