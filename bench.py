@@ -306,6 +306,12 @@ def attach_traffic(roof, workload, batch):
     roof['traffic'] = round(entry['hbm_mb_per_launch'] * 1e6)
     roof['traffic_unit'] = 'bytes per launch (HBM, PMC)'
     roof['traffic_source'] = entry['source']
+    if 'algorithmic_mb_per_launch_same_launches' in entry:
+        # the counters ran over the family's shapes with plain operands (x, w -> y); the step's own launches also read
+        # residuals / BatchNorm-backward operands, so `traffic` is to be compared with THIS figure, not with the line's
+        # algorithmic_mb_per_launch
+        roof['traffic_algorithmic'] = round(entry['algorithmic_mb_per_launch_same_launches'] * 1e6)
+        roof['traffic_over_algorithmic'] = entry['hbm_over_algorithmic']
 
 
 def decode_workload(args, rank, world, dev):

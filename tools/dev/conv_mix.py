@@ -21,6 +21,7 @@ SHAPES = [
 LEVELS = [(64, 104), (32, 52), (16, 26), (8, 13)]
 B = 16
 tot_ms, tot_fl, n, alg = 0.0, 0.0, 0, 0.0
+families = {}      # kernel family (as bench.py tags it) -> [launches, algorithmic bytes] of THIS mix
 for (cnt, H, W, Cin, Cout, k) in SHAPES:
     if H:
         x = torch.randn(B, H, W, Cin, device='cuda', dtype=torch.bfloat16)
@@ -30,6 +31,7 @@ for (cnt, H, W, Cin, Cout, k) in SHAPES:
         rows = x.rows
     w = (torch.randn(Cout, k, k, Cin, device='cuda') / (Cin * k * k) ** 0.5).to(torch.bfloat16)
     y = ops.conv2d(x, w, k, k, 1, k // 2)
+    fam = ops.last_kernel()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(cnt):
@@ -40,5 +42,10 @@ for (cnt, H, W, Cin, Cout, k) in SHAPES:
     tot_fl += cnt * 2.0 * rows * Cout * k * k * Cin
     alg += cnt * (rows * (Cin + Cout) * 2 + w.numel() * 2)
     n += cnt
+    f = families.setdefault(fam, [0, 0.0])
+    f[0] += cnt + 1            # (+ the warm-up launch above: the PMC passes count it too)
+    f[1] += (cnt + 1) * (rows * (Cin + Cout) * 2 + w.numel() * 2)
 print(f'{n} launches, {tot_ms:.3f} ms, {tot_fl / tot_ms / 1e9:.1f} TF, algorithmic bytes per launch {alg / n / 1e6:.2f} MB '
       f'(x read once, y written once, weights once)')
+import json
+print('ALGORITHMIC ' + json.dumps({k: dict(launches=v[0], algorithmic_mb_per_launch=round(v[1] / v[0] / 1e6, 2)) for k, v in families.items()}))

@@ -46,6 +46,21 @@ def main(d, out):
         if e:
             e['source'] = src
             fams.setdefault(tag, {})['train'] = e
+    # algorithmic bytes of exactly the launches the counters saw (tools/dev/conv_mix.py prints them per family)
+    try:
+        alg = json.load(open(f'{out}/r03_conv_mix_algorithmic.json'))['families']
+    except OSError:
+        alg = {}
+    if 'conv_glds3_kernel<pp>' in alg and 'conv_glds3_kernel<splitk>' in alg:   # (one kernel template to the counters)
+        a, b = alg['conv_glds3_kernel<pp>'], alg.pop('conv_glds3_kernel<splitk>')
+        n = a['launches'] + b['launches']
+        alg['conv_glds3_kernel<pp>'] = dict(launches=n, algorithmic_mb_per_launch=(
+            a['launches'] * a['algorithmic_mb_per_launch'] + b['launches'] * b['algorithmic_mb_per_launch']) / n)
+    for tag, a in alg.items():
+        e = fams.get(tag, {}).get('train')
+        if e and e['dispatches'] == a['launches']:
+            e['algorithmic_mb_per_launch_same_launches'] = round(a['algorithmic_mb_per_launch'], 2)
+            e['hbm_over_algorithmic'] = round(e['hbm_mb_per_launch'] / a['algorithmic_mb_per_launch'], 3)
     json.dump(doc, open(path, 'w'), indent=1, sort_keys=True)
     # tracked tables
     for name, dst, cmd in (('cm', 'r03_pmc_mfma_conv_mix', 'tools/dev/conv_mix.py'), ('wm', 'r03_pmc_mfma_wgrad_mix', 'tools/dev/wgrad_mix.py'),
