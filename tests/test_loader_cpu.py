@@ -75,3 +75,58 @@ def test_pack_to_device_keeps_shapes_dtypes_and_values():
     for a, t in zip(arrays, out):
         assert tuple(t.shape) == a.shape and t.numpy().dtype == a.dtype
         np.testing.assert_array_equal(t.numpy(), a)
+
+
+def test_deferred_pipeline_records_the_image_ops_without_a_gpu(tmp_path):
+    """What a ProcessLoader worker does: with `pipelines.DEFER_IMAGE_OPS` the reference's train pipeline runs on a box
+    without a GPU — the image comes out as a FramePlan (decoded frame + the recorded ops, with the shape every stage
+    would have produced), the annotations as ever; the plan survives pickling and a re-run with the same seed records
+    the same plan."""
+    import copy
+    import os
+    import pickle
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import pipeline_cases as PC
+    from das_amd import pipelines as P
+    from das_amd.image_ops import FramePlan
+    h, w = 270, 480
+    np.save(tmp_path / 'frame.npy', np.random.RandomState(5).randint(0, 256, (h, w, 3)).astype(np.uint8))
+    ann = PC.annotations(21, n=5, h=h, w=w)
+    pipe = P.Compose([
+        dict(type='LoadImageFromFile', to_float32=True),
+        dict(type='LoadAnnotationsPose3D', with_bbox=True, with_label=True),
+        dict(type='ResizePose', scale_depth=True, abs_dz=False, img_scale=[(667, 256), (667, 320)], multiscale_mode='range',
+             keep_ratio=True),
+        dict(type='RandomFlipPose3D', flip_ratio_bev_horizontal=1.0, flip_pairs=PC.FLIP_PAIRS, num_joints=PC.J),
+        dict(type='PhotoMetricDistortion'),
+        dict(type='GlobalRotScaleTransPose', scale_depth=True, abs_dz=False, rot_range=[-0.1, 0.1], scale_ratio_range=[0.9, 1.1],
+             translation_std=[0.02, 0.02], num_joints=PC.J, img_norm_cfg=PC.IMG_NORM, use_bbox_center=False),
+        dict(type='Normalize', **PC.IMG_NORM), dict(type='Pad', size_divisor=32),
+        dict(type='DefaultFormatBundlePose3D', class_names=['person']),
+        dict(type='Collect3D', keys=['img', 'gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths']),
+    ])
+    src = dict(img_info=dict(filename=str(tmp_path / 'frame.npy')), img_prefix=None,
+               ann_info=dict(bboxes=ann['gt_bboxes'], labels=ann['gt_labels'], centers2d=ann['centers2d'],
+                             depths=ann['depths'], gt_poses_3d=ann['gt_poses_3d'], gt_labels_3d=ann['gt_labels_3d']))
+    P.DEFER_IMAGE_OPS = True
+    try:
+        outs = []
+        for _ in range(2):
+            np.random.seed(1)
+            outs.append(pipe(copy.deepcopy(src)))
+    finally:
+        P.DEFER_IMAGE_OPS = False
+    a, b = outs
+    plan = a['img']
+    assert isinstance(plan, FramePlan) and not plan.rgb and plan.to_float
+    assert [op for op, _ in plan.ops] == ['resize_bilinear', 'flip_horizontal', 'photometric_', 'warp_affine', 'normalize_pad_chw']
+    new_h, new_w = a['img_metas']['img_shape'][:2]
+    assert plan.ops[0][1] == ((new_w, new_h),) and tuple(plan.shape) == (3,) + tuple(a['img_metas']['pad_shape'][:2])
+    assert plan.shape[1] % 32 == 0 and plan.shape[2] % 32 == 0 and plan.frame.shape == (h, w, 3)
+    again = pickle.loads(pickle.dumps(plan))
+    assert again.ops == plan.ops == b['img'].ops and np.array_equal(again.frame, plan.frame)
+    assert len(pickle.dumps(plan.with_frame(None))) < 2000          # (what travels in the queue message beside the ring slot)
+    for k in ('gt_poses_3d', 'gt_bboxes', 'depths'):
+        assert a[k].shape[0] == b[k].shape[0] > 0 and bool((a[k] == b[k]).all())
