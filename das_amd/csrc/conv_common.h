@@ -149,7 +149,18 @@ constexpr size_t epilogue_smem_bytes() {
 
 // acc[a][b][j]: channel n0 + wave_n0 + a*16 + (lane>>4)*4 + j, pixel m0 + wave_m0 + b*16 + (lane&15).
 // Must be entered after a barrier that ends all LDS reads of the main loop.
-template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, typename Acc>
+// T2D: the tile is a 16 x 16 pixel square of one image (conv3x3_c64_kernel; H and W multiples of 16): `m0` is then the
+// tile index, and tile row ml = (row of the square) * 16 + column. Every row of such a tile exists.
+template <bool T2D>
+__device__ __forceinline__ int tile_row_m(const ConvP& p, int m0, int ml) {
+  if (!T2D) return m0 + ml;
+  const int tw = p.W >> 4, per_img = (p.H >> 4) * tw;
+  const int b = m0 / per_img, t = m0 - b * per_img;
+  const int th = t / tw;
+  return (b * p.H + th * 16 + (ml >> 4)) * p.W + (t - th * tw) * 16 + (ml & 15);
+}
+
+template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, bool T2D = false, typename Acc>
 __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* smem, int m0, int n0) {
   constexpr int TM = TL::TM, TN = TL::TN, NT = TL::NT;
   constexpr int EPVO = 16 / (int)sizeof(OT);
@@ -223,13 +234,13 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
       long long om[CH];
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
-        const int m = m0 + r0 + (it0 + u) * RP;
+        const int m = tile_row_m<T2D>(p, m0, r0 + (it0 + u) * RP);
         om[u] = m < p.M ? orow(m) : 0;
       }
       if (rg) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int m = m0 + r0 + (it0 + u) * RP;
+          const int m = tile_row_m<T2D>(p, m0, r0 + (it0 + u) * RP);
           rv[u] = make_uint4(0, 0, 0, 0);
           if (m < p.M) rv[u] = *reinterpret_cast<const uint4*>(rg + om[u] * p.rps + n);
         }
@@ -237,7 +248,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
       if (bxg) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int m = m0 + r0 + (it0 + u) * RP;
+          const int m = tile_row_m<T2D>(p, m0, r0 + (it0 + u) * RP);
           xv[u] = yv[u] = make_uint4(0, 0, 0, 0);
           if (m < p.M) {
             xv[u] = *reinterpret_cast<const uint4*>(bxg + om[u] * p.bnb_ps + n);
@@ -248,7 +259,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int ml = r0 + (it0 + u) * RP;
-        const int m = m0 + ml;
+        const int m = tile_row_m<T2D>(p, m0, ml);
         if (m >= p.M) break;
         const uint4 raw = *reinterpret_cast<const uint4*>(smem + ml * CS + vec * 16);
         float f[EPVO];

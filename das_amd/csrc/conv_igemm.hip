@@ -315,6 +315,111 @@ __global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
   conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
 }
 
+// =============================================================== 3x3, 64 -> 64 channels, stride 1 (stage-1 bottlenecks)
+// The 3x3 convs of the 128 x 208 stage (64 channels in and out; forward and data gradient: 24 launches per train step)
+// were the slowest layers of the net against their floor: conv_glds_kernel needs 112 us for 31 GFLOP / 109 MB (MFMA
+// time ~30 us, HBM time 18 us). A 128 x 64 tile with K = 576 fills 24 KiB of LDS per K step — the pixel rows again for
+// every one of the nine taps, and the weights again for every tile — for 0.1 us of MFMA work, and the bytes in flight per
+// CU (LDS capacity) over the DMA latency bound the rate at ~6 TB/s of LDS fill. This kernel fills 10x less:
+//   * PERSISTENT, one workgroup per CU: the whole weight matrix (64 x 576 bf16, rows padded to 1168 B: conflict-free
+//     fragment reads) is loaded into LDS once;
+//   * the tile is a 16 x 16 pixel SQUARE and its 18 x 18 x 64-channel input patch (41 KiB, zero-filled outside the image
+//     by the buffer descriptor's range check) is DMA'd ONCE; the nine taps read it at shifted positions (pixel-major,
+//     the 16-byte chunk index XOR-swizzled with the pixel index);
+//   * a fifth wave only issues the DMA of the NEXT tile's patch into the other buffer while the four MFMA waves work
+//     (64 pixels x 64 channels each, 288 MFMAs per tile) and run the shared epilogue (which stages the C tile in the
+//     patch buffer it has just finished reading) — the MFMA waves never wait on vmcnt for a DMA, the loader never stores.
+struct TilingC64 {
+  static constexpr int NT = 256, TM = 4, TN = 4;
+  static __device__ __forceinline__ int wave_m0(int wave) { return wave * 64; }
+  static __device__ __forceinline__ int wave_n0(int) { return 0; }
+};
+constexpr int C64_WROW = 1168, C64_WBYTES = 64 * C64_WROW, C64_PATCH = 41 * 1024;   // (324 pixels x 128 B, in 1 KiB DMA units)
+template <typename OT>
+__global__ __launch_bounds__(320) void conv3x3_c64_kernel(ConvP p, int ntiles) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int c = tid; c < 64 * 72; c += 320) {      // weights: 64 rows of 72 16-byte chunks
+    const int row = c / 72, ch = c - row * 72;
+    *reinterpret_cast<uint4*>(sW + row * C64_WROW + ch * 16) = *reinterpret_cast<const uint4*>(p.w + (size_t)row * 1152 + ch * 16);
+  }
+  __syncthreads();
+  const int tw = p.W >> 4, per_img = (p.H >> 4) * tw;
+  const int nbar = p.stats ? 3 : 1;               // workgroup barriers inside conv_epilogue
+  if (wave == 4) {   // ---- loader wave
+    const v4i_t xrs = make_rsrc(p.x, p.xbytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + C64_WBYTES;
+    const unsigned xps2 = (unsigned)p.xps * 2u;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    auto issue = [&](int tile, int buf) {
+      const int b = tile / per_img, t = tile - b * per_img, th = t / tw;
+      const int h0 = th * 16 - 1, w0 = (t - th * tw) * 16 - 1;
+      int pp = lane >> 3;                          // patch pixel of this lane in instruction 0; + 8 per instruction
+      int pr = 0, pc = pp;
+#pragma unroll 1
+      for (int j = 0; j < 41; ++j) {
+        const int h = h0 + pr, w = w0 + pc;
+        const bool ok = pp < 324 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        const unsigned chunk = (unsigned)((lane & 7) ^ (pp & 7));
+        const unsigned off = (unsigned)((b * p.H + h) * p.W + w) * xps2 + chunk * 16u;
+        dma16_buf(ok ? off : OOB, xrs, lds0 + buf * C64_PATCH + j * 1024);
+        pp += 8; pc += 8;
+        if (pc >= 18) { pc -= 18; ++pr; }
+      }
+    };
+    int i = 0;
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++i) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's patch has landed
+      __builtin_amdgcn_s_barrier();                        // A: ... and the other waves are done with the other buffer
+      if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, (i + 1) & 1);
+      __builtin_amdgcn_s_barrier();                        // B
+      for (int k = 0; k < nbar; ++k) __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+  // ---- MFMA waves: wave w owns rows 4w .. 4w+3 of the square, all 64 output channels
+  const int q = lane & 15, kg = lane >> 4;
+  int i = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++i) {
+    char* buf = smem + C64_WBYTES + (i & 1) * C64_PATCH;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_barrier();                          // A: the patch is in LDS
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          uint4 fa[4], fb[4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int pp = (wave * 4 + b + kh) * 18 + q + kw;
+            fb[b] = *reinterpret_cast<const uint4*>(buf + pp * 128 + (((half * 4 + kg) ^ (pp & 7)) << 4));
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            fa[a] = *reinterpret_cast<const uint4*>(sW + (a * 16 + q) * C64_WROW + ((kh * 3 + kw) * 64 + half * 32 + kg * 8) * 2);
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mma<T>(fa[a], fb[b], acc[a][b]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // B: every wave is done reading the patch
+    conv_epilogue<OT, 64, 256, TilingC64, true>(acc, p, buf, tile, 0);
+  }
+}
+
 // Second half of a split-K convolution: same grid and tile map as the tile-kernel launch it follows; every lane sums
 // its accumulator positions over the slabs (fixed order: deterministic) and the shared epilogue does the rest
 // (scale / shift, C tile through LDS, statistics, residual, ReLU, fused BatchNorm-backward sums, 16-byte stores).
@@ -1325,10 +1430,39 @@ bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   }
 }
 
+// Takes the 3x3, stride-1, "same"-padded bf16 convs with 64 input and 64 output channels on plain NHWC tensors whose
+// height and width are multiples of 16 (the 128 x 208 stage). Returns false when the shape is not its.
+template <typename OT>
+bool try_launch_c64(const ConvP& p, hipStream_t s) {
+  const long long min_tiles = dastune::get(dastune::CONV_C64_MINTILES);   // 0 disables
+  if (min_tiles <= 0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.Cin != 64 || p.Cout != 64 ||
+      p.up_sh != 0 || p.relu_in || p.osub || p.nlev > 1 || p.m_base != 0 || p.xbytes == 0 || p.xps % 8 || p.yps % 8 ||
+      (p.res && p.rps % 8) || (p.bnb_raw && p.bnb_ps % 8) || p.H % 16 || p.W % 16 || p.Ho != p.H || p.Wo != p.W ||
+      p.M % (p.H * p.W) || p.K != 576)
+    return false;
+  const int ntiles = p.M / 256;
+  if (ntiles < min_tiles) return false;
+  const size_t sm = C64_WBYTES + 2 * (size_t)C64_PATCH;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+      return false;
+    attr_set = true;
+  }
+  const int grid = std::min(ntiles, device_cus());
+  dastune::note_kernel("conv3x3_c64_kernel");
+  hipLaunchKernelGGL((conv3x3_c64_kernel<OT>), dim3(grid), dim3(320), sm, s, p, ntiles);
+  return true;
+}
+
 template <typename T, typename OT>
 int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
   if constexpr (sizeof(T) == 2 && sizeof(OT) == 2) {
     if (try_launch_stream1x1(p, s)) {
+      DAS_CHECK_LAUNCH();
+      return DAS_OK;
+    }
+    if (try_launch_c64<OT>(p, s)) {
       DAS_CHECK_LAUNCH();
       return DAS_OK;
     }

@@ -32,6 +32,8 @@ enum Key {
   BN_REDUCE_THREADS,
   BN_VPT,                // 16-byte vectors per thread of the BatchNorm apply passes
   GN_PPB,                // minimum pixels per workgroup of the GroupNorm statistic passes
+  CONV_C64_MINTILES,     // conv3x3_c64_kernel (3x3, 64 -> 64 channels, 16 x 16-pixel tiles with the input patch and the
+                         // whole weight matrix in LDS) from this many tiles up; 0 disables the kernel
   BN_STREAM_MINBYTES,    // BatchNorm apply passes over tensors of at least this many bytes: slot fold as its own launch +
                          // a one-shot pass of small workgroups (bn_apply_stream_kernel); 0 = never
   N_KEYS

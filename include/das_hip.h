@@ -46,7 +46,7 @@ const char* das_target_arch(void);
  * production-size layers dispatch to, A/B benchmarks flip them. No reference counterpart (torch picks its cuDNN /
  * MIOpen algorithm internally: torch.backends.cudnn.benchmark, tools/train.py:115-116). Unknown key: DAS_ERR_ARG.
  * Keys: conv.big_minblocks, conv.big_mink, conv.glds3_pp_mink, conv.glds4_minblocks, conv.glds4_pp (-1 auto / 0 / 1),
- * conv.glds4_mf, conv.stream_minrows, conv.stream_percu, conv.tail_split, conv.splitk_target, conv.splitk_minsteps, conv.splitk_kernels, wgrad.pp_mink, wgrad.bkm, wgrad.blocks, wgrad.pp_blocks,
+ * conv.glds4_mf, conv.stream_minrows, conv.stream_percu, conv.tail_split, conv.splitk_target, conv.splitk_minsteps, conv.splitk_kernels, conv.c64_mintiles, wgrad.pp_mink, wgrad.bkm, wgrad.blocks, wgrad.pp_blocks,
  * bn.reduce_blocks, bn.reduce_threads, bn.vpt, gn.ppb, bn.stream_minbytes. */
 int das_tuning_set(const char* key, long long value);
 int das_tuning_get(const char* key, long long* value);

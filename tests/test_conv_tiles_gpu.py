@@ -162,6 +162,70 @@ def test_tile_dgrad_forced(kernel):
     np.testing.assert_allclose(nchw(dx).numpy(), q(q(x.grad) + q(other)).numpy(), **TOL)
 
 
+# ---------------------------------------------------------------- 3x3, 64 -> 64 channels: patch kernel
+C64 = {'conv.c64_mintiles': 1}
+
+
+@pytest.mark.parametrize('case', [(2, 32, 48), (1, 16, 16), (3, 48, 16), (1, 128, 208)])
+def test_c64_patch_kernel_forward_stats_residual(case):
+    """conv3x3_c64_kernel (16 x 16-pixel tiles, input patch + all weights in LDS, persistent over tiles; production: the
+    128 x 208 stage at B = 16, 1664 tiles on 256 workgroups) against torch: plain output + BatchNorm statistics in
+    slots; scale / shift / residual / ReLU; more tiles than workgroups AND fewer (a single tile); image borders on
+    every side of every image; and the same launch on the 128-row tile kernel gives the same stored values."""
+    o = ops()
+    B, H, W = case
+    x, w = cases.randn(141, B, 64, H, W), cases.randn(142, 64, 64, 3, 3) / 24
+    conv = conv_ref(x, w, 1, 1)
+    xd, wd = nhwc(x), o.pack_weight(w.to(DEV), BF)
+    stats = torch.zeros(4, 128, device=DEV)
+    with o.tuning(**C64):
+        y = o.conv2d(xd, wd, 3, 3, 1, 1, stats=stats.view(-1))
+        assert o.last_kernel() == 'conv3x3_c64_kernel', o.last_kernel()
+    yq = nchw(y)
+    np.testing.assert_allclose(yq.numpy(), q(conv).numpy(), **TOL)
+    n = B * H * W
+    s_ref = torch.cat([yq.sum((0, 2, 3)), (yq ** 2).sum((0, 2, 3))])
+    np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
+    with o.tuning(**{'conv.c64_mintiles': 0}):
+        y_tile = o.conv2d(xd, wd, 3, 3, 1, 1)
+        assert o.last_kernel() != 'conv3x3_c64_kernel'
+    np.testing.assert_allclose(y.float().cpu().numpy(), y_tile.float().cpu().numpy(), rtol=8e-3, atol=8e-3)
+    scale, shift = cases.randn(143, 64).abs() + 0.5, cases.randn(144, 64)
+    res = cases.randn(145, B, 64, H, W)
+    with o.tuning(**C64):
+        y2 = o.conv2d(xd, wd, 3, 3, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), residual=nhwc(res), relu=True)
+        assert o.last_kernel() == 'conv3x3_c64_kernel'
+    aff_q = q(conv * scale[None, :, None, None] + shift[None, :, None, None])
+    np.testing.assert_allclose(nchw(y2).numpy(), F.relu(aff_q + q(res)).numpy(), **TOL)
+
+
+def test_c64_patch_kernel_data_gradient_and_channel_slices():
+    """Data gradient (flipped weights) with a second gradient added in the epilogue; input and output as channel
+    slices of wider tensors (pixel strides 128 / 96)."""
+    o = ops()
+    B, H, W = 2, 32, 32
+    x = cases.randn(151, B, 64, H, W).requires_grad_(True)
+    w = cases.randn(152, 64, 64, 3, 3) / 24
+    dy, other = cases.randn(153, B, 64, H, W), cases.randn(154, B, 64, H, W)
+    F.conv2d(x, q(w), None, 1, 1).backward(q(dy))
+    wide_in = torch.zeros(B, H, W, 128, device=DEV, dtype=BF)
+    wide_in[..., 32:96] = nhwc(dy)
+    with o.tuning(**C64):
+        dx = o.conv2d_dgrad(wide_in[..., 32:96], o.pack_weight_dgrad(w.to(DEV), BF), 3, 3, 1, 1, (H, W), residual=nhwc(other))
+        assert o.last_kernel() == 'conv3x3_c64_kernel', o.last_kernel()
+    np.testing.assert_allclose(nchw(dx).numpy(), q(q(x.grad) + q(other)).numpy(), **TOL)
+
+
+def test_c64_patch_kernel_leaves_other_shapes_alone():
+    o = ops()
+    with o.tuning(**C64):
+        for (H, W, Cin, Cout, k) in [(24, 32, 64, 64, 3), (32, 32, 64, 128, 3), (32, 32, 128, 64, 3), (32, 32, 64, 64, 1)]:
+            x = nhwc(cases.randn(161, 1, Cin, H, W))
+            w = o.pack_weight((cases.randn(162, Cout, Cin, k, k) / 24).to(DEV), BF)
+            o.conv2d(x, w, k, k, 1, k // 2)
+            assert o.last_kernel() != 'conv3x3_c64_kernel', (H, W, Cin, Cout, k)
+
+
 # ---------------------------------------------------------------- split-K (small M, long K)
 SPLITK = {
     # kernel: (tuning that routes the case to it, bit in conv.splitk_kernels, cases B, H, W, Cin, Cout, k, stride, pad)
