@@ -2,6 +2,7 @@
 // the fused epilogue (scale/shift -> LDS-staged C tile -> residual / ReLU / BN statistics ->
 // 16-byte coalesced NHWC stores).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 // Dev builds (make stamps -> libdas_hip_stamps.so, never loaded by the product): thread 0 of every workgroup of the
@@ -160,8 +161,13 @@ __device__ __forceinline__ int tile_row_m(const ConvP& p, int m0, int ml) {
   return (b * p.H + th * 16 + (ml >> 4)) * p.W + (t - th * tw) * 16 + (ml & 15);
 }
 
-template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, bool T2D = false, typename Acc>
-__device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* smem, int m0, int n0) {
+// `carry` (persistent kernels): the thread's per-channel statistic sums [2][16 / sizeof(OT)] live in the CALLER's
+// registers across tiles (a thread keeps its channels: vec = tid % VR) and conv_epilogue_flush_stats reduces and adds
+// them once per workgroup at the end of the launch, instead of an LDS reduction, two barriers and 2 * BN atomics per tile.
+struct NoCarry {};
+template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, bool T2D = false, typename Acc, typename Carry = NoCarry>
+__device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* smem, int m0, int n0, Carry&& carry = Carry{}) {
+  constexpr bool CARRY = !std::is_same<typename std::decay<Carry>::type, NoCarry>::value;   // (a float[2 * EPVO] otherwise)
   constexpr int TM = TL::TM, TN = TL::TN, NT = TL::NT;
   constexpr int EPVO = 16 / (int)sizeof(OT);
   constexpr int CS = BN * (int)sizeof(OT) + 16;  // padded C-tile row stride in bytes
@@ -200,7 +206,9 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   const int n = n0 + vec * EPVO;
   float ssum[EPVO], ssq[EPVO];
 #pragma unroll
-  for (int j = 0; j < EPVO; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  for (int j = 0; j < EPVO; ++j) {
+    if constexpr (CARRY) { ssum[j] = carry[j]; ssq[j] = carry[EPVO + j]; } else { ssum[j] = 0.f; ssq[j] = 0.f; }
+  }
   OT* yg = reinterpret_cast<OT*>(p.y);
   // row of y / residual / bnb tensors that conv output row m goes to
   auto orow = [&](int m) -> long long {
@@ -303,6 +311,11 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
     }
   }
   DAS_STAMP(6);
+  if constexpr (CARRY) {
+#pragma unroll
+    for (int j = 0; j < EPVO; ++j) { carry[j] = ssum[j]; carry[EPVO + j] = ssq[j]; }
+    return;
+  }
   if (p.stats) {
     __syncthreads();
     DAS_STAMP(7);
@@ -314,6 +327,37 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
     }
     __syncthreads();
     for (int i = tid; i < 2 * BN; i += NT) {   // (one pass unless the workgroup has fewer than 2 * BN threads)
+      const int which = i / BN, c = i % BN;
+      if (n0 + c < p.Cout) {
+        float s = 0.f;
+        for (int r = 0; r < RP; ++r) s += red[(which * RP + r) * BN + c];
+        const int slot = p.stat_slots > 1 ? (int)(blockIdx.x % (unsigned)p.stat_slots) : 0;
+        atomicAdd(p.stats + (slot * 2 + which) * p.Cout + n0 + c, s);
+      }
+    }
+  }
+}
+
+// The statistics a persistent kernel carried through its tiles (conv_epilogue's `carry`): the same LDS reduction over the
+// threads that share a channel vector and one round of atomics, once per workgroup. Threads tid >= TL::NT (loader
+// waves) only take part in the two barriers; every wave of the workgroup must call this (after a barrier that ends all
+// reads of `smem`).
+template <typename OT, int BN, typename TL>
+__device__ __forceinline__ void conv_epilogue_flush_stats(const float* carry, const ConvP& p, char* smem, int n0) {
+  constexpr int NT = TL::NT, EPVO = 16 / (int)sizeof(OT), VR = BN * (int)sizeof(OT) / 16, RP = NT / VR;
+  const int tid = threadIdx.x;
+  float* red = reinterpret_cast<float*>(smem);  // [2][RP][BN]
+  if (tid < NT) {
+    const int vec = tid % VR, r0 = tid / VR;
+#pragma unroll
+    for (int j = 0; j < EPVO; ++j) {
+      red[r0 * BN + vec * EPVO + j] = carry[j];
+      red[(RP + r0) * BN + vec * EPVO + j] = carry[EPVO + j];
+    }
+  }
+  __syncthreads();
+  if (tid < NT) {
+    for (int i = tid; i < 2 * BN; i += NT) {
       const int which = i / BN, c = i % BN;
       if (n0 + c < p.Cout) {
         float s = 0.f;

@@ -348,7 +348,6 @@ __global__ __launch_bounds__(320) void conv3x3_c64_kernel(ConvP p, int ntiles) {
   }
   __syncthreads();
   const int tw = p.W >> 4, per_img = (p.H >> 4) * tw;
-  const int nbar = p.stats ? 3 : 1;               // workgroup barriers inside conv_epilogue
   if (wave == 4) {   // ---- loader wave
     const v4i_t xrs = make_rsrc(p.x, p.xbytes);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + C64_WBYTES;
@@ -377,12 +376,19 @@ __global__ __launch_bounds__(320) void conv3x3_c64_kernel(ConvP p, int ntiles) {
       __builtin_amdgcn_s_barrier();                        // A: ... and the other waves are done with the other buffer
       if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, (i + 1) & 1);
       __builtin_amdgcn_s_barrier();                        // B
-      for (int k = 0; k < nbar; ++k) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                        // (the one inside conv_epilogue: C tile staged)
+    }
+    if (p.stats) {
+      __builtin_amdgcn_s_barrier();                        // (the last tile's C rows have been read back)
+      conv_epilogue_flush_stats<OT, 64, TilingC64>(nullptr, p, smem + C64_WBYTES, 0);
     }
     return;
   }
   // ---- MFMA waves: wave w owns rows 4w .. 4w+3 of the square, all 64 output channels
   const int q = lane & 15, kg = lane >> 4;
+  float carry[16];     // this thread's statistic sums, carried through the tiles (see conv_epilogue)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) carry[j] = 0.f;
   int i = 0;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++i) {
     char* buf = smem + C64_WBYTES + (i & 1) * C64_PATCH;
@@ -416,7 +422,15 @@ __global__ __launch_bounds__(320) void conv3x3_c64_kernel(ConvP p, int ntiles) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // B: every wave is done reading the patch
-    conv_epilogue<OT, 64, 256, TilingC64, true>(acc, p, buf, tile, 0);
+    if (p.stats) {   // (wave-uniform)
+      conv_epilogue<OT, 64, 256, TilingC64, true>(acc, p, buf, tile, 0, carry);
+    } else {
+      conv_epilogue<OT, 64, 256, TilingC64, true>(acc, p, buf, tile, 0);
+    }
+  }
+  if (p.stats) {
+    __builtin_amdgcn_s_barrier();
+    conv_epilogue_flush_stats<OT, 64, TilingC64>(carry, p, smem + C64_WBYTES, 0);
   }
 }
 
