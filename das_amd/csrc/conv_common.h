@@ -150,15 +150,17 @@ constexpr size_t epilogue_smem_bytes() {
 
 // acc[a][b][j]: channel n0 + wave_n0 + a*16 + (lane>>4)*4 + j, pixel m0 + wave_m0 + b*16 + (lane&15).
 // Must be entered after a barrier that ends all LDS reads of the main loop.
-// T2D: the tile is a 16 x 16 pixel square of one image (conv3x3_c64_kernel; H and W multiples of 16): `m0` is then the
-// tile index, and tile row ml = (row of the square) * 16 + column. Every row of such a tile exists.
+// T2D: the tile is a 16 x 16 pixel square of one image (conv3x3_c64_kernel): `m0` is then the tile index (images x
+// ceil(H / 16) x ceil(W / 16)), and tile row ml = (row of the square) * 16 + column. Pixels of a border square that lie
+// outside the image come back as p.M ("no such row": skipped by the callers, in any order).
 template <bool T2D>
 __device__ __forceinline__ int tile_row_m(const ConvP& p, int m0, int ml) {
   if (!T2D) return m0 + ml;
-  const int tw = p.W >> 4, per_img = (p.H >> 4) * tw;
+  const int tw = (p.W + 15) >> 4, per_img = ((p.H + 15) >> 4) * tw;
   const int b = m0 / per_img, t = m0 - b * per_img;
   const int th = t / tw;
-  return (b * p.H + th * 16 + (ml >> 4)) * p.W + (t - th * tw) * 16 + (ml & 15);
+  const int h = th * 16 + (ml >> 4), w = (t - th * tw) * 16 + (ml & 15);
+  return (h < p.H && w < p.W) ? (b * p.H + h) * p.W + w : p.M;
 }
 
 // `carry` (persistent kernels): the thread's per-channel statistic sums [2][16 / sizeof(OT)] live in the CALLER's
@@ -268,7 +270,10 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
       for (int u = 0; u < CH; ++u) {
         const int ml = r0 + (it0 + u) * RP;
         const int m = tile_row_m<T2D>(p, m0, ml);
-        if (m >= p.M) break;
+        if (m >= p.M) {
+          if (T2D) continue;   // (a border square: later rows of the chunk may exist)
+          break;
+        }
         const uint4 raw = *reinterpret_cast<const uint4*>(smem + ml * CS + vec * 16);
         float f[EPVO];
         Elem<OT>::unpack(raw, f);

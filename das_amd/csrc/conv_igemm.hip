@@ -347,7 +347,7 @@ __global__ __launch_bounds__(320) void conv3x3_c64_kernel(ConvP p, int ntiles) {
     *reinterpret_cast<uint4*>(sW + row * C64_WROW + ch * 16) = *reinterpret_cast<const uint4*>(p.w + (size_t)row * 1152 + ch * 16);
   }
   __syncthreads();
-  const int tw = p.W >> 4, per_img = (p.H >> 4) * tw;
+  const int tw = (p.W + 15) >> 4, per_img = ((p.H + 15) >> 4) * tw;
   if (wave == 4) {   // ---- loader wave
     const v4i_t xrs = make_rsrc(p.x, p.xbytes);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + C64_WBYTES;
@@ -1444,17 +1444,20 @@ bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
   }
 }
 
-// Takes the 3x3, stride-1, "same"-padded bf16 convs with 64 input and 64 output channels on plain NHWC tensors whose
-// height and width are multiples of 16 (the 128 x 208 stage). Returns false when the shape is not its.
+// Takes the 3x3, stride-1, "same"-padded bf16 convs with 64 input and 64 output channels on plain NHWC tensors (the
+// 128 x 208 stage). Returns false when the shape is not its.
 template <typename OT>
 bool try_launch_c64(const ConvP& p, hipStream_t s) {
   const long long min_tiles = dastune::get(dastune::CONV_C64_MINTILES);   // 0 disables
   if (min_tiles <= 0 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.Cin != 64 || p.Cout != 64 ||
       p.up_sh != 0 || p.relu_in || p.osub || p.nlev > 1 || p.m_base != 0 || p.xbytes == 0 || p.xps % 8 || p.yps % 8 ||
-      (p.res && p.rps % 8) || (p.bnb_raw && p.bnb_ps % 8) || p.H % 16 || p.W % 16 || p.Ho != p.H || p.Wo != p.W ||
-      p.M % (p.H * p.W) || p.K != 576)
+      (p.res && p.rps % 8) || (p.bnb_raw && p.bnb_ps % 8) || p.Ho != p.H || p.Wo != p.W || p.M % (p.H * p.W) || p.K != 576)
     return false;
-  const int ntiles = p.M / 256;
+  // 16 x 16-pixel squares per image; border squares of an image whose height / width is not a multiple of 16 are partly
+  // outside (their MFMA work is wasted: not worth it when that is more than a quarter of the launch)
+  const long long sq = (long long)((p.H + 15) / 16) * ((p.W + 15) / 16);
+  if (sq * 256 * 3 > (long long)p.H * p.W * 4) return false;
+  const int ntiles = (int)(sq * (p.M / (p.H * p.W)));
   if (ntiles < min_tiles) return false;
   const size_t sm = C64_WBYTES + 2 * (size_t)C64_PATCH;
   static bool attr_set = false;

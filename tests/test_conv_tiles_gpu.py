@@ -166,12 +166,13 @@ def test_tile_dgrad_forced(kernel):
 C64 = {'conv.c64_mintiles': 1}
 
 
-@pytest.mark.parametrize('case', [(2, 32, 48), (1, 16, 16), (3, 48, 16), (1, 128, 208)])
+@pytest.mark.parametrize('case', [(2, 32, 48), (1, 16, 16), (3, 48, 16), (1, 128, 208), (2, 40, 60), (1, 128, 232)])
 def test_c64_patch_kernel_forward_stats_residual(case):
     """conv3x3_c64_kernel (16 x 16-pixel tiles, input patch + all weights in LDS, persistent over tiles; production: the
     128 x 208 stage at B = 16, 1664 tiles on 256 workgroups) against torch: plain output + BatchNorm statistics in
     slots; scale / shift / residual / ReLU; more tiles than workgroups AND fewer (a single tile); image borders on
-    every side of every image; and the same launch on the 128-row tile kernel gives the same stored values."""
+    every side of every image; heights / widths that are not multiples of 16 (border squares partly outside: 928-wide
+    frames give W = 232); and the same launch on the 128-row tile kernel gives the same stored values."""
     o = ops()
     B, H, W = case
     x, w = cases.randn(141, B, 64, H, W), cases.randn(142, 64, 64, 3, 3) / 24
@@ -219,7 +220,7 @@ def test_c64_patch_kernel_data_gradient_and_channel_slices():
 def test_c64_patch_kernel_leaves_other_shapes_alone():
     o = ops()
     with o.tuning(**C64):
-        for (H, W, Cin, Cout, k) in [(24, 32, 64, 64, 3), (32, 32, 64, 128, 3), (32, 32, 128, 64, 3), (32, 32, 64, 64, 1)]:
+        for (H, W, Cin, Cout, k) in [(17, 17, 64, 64, 3), (32, 32, 64, 128, 3), (32, 32, 128, 64, 3), (32, 32, 64, 64, 1)]:
             x = nhwc(cases.randn(161, 1, Cin, H, W))
             w = o.pack_weight((cases.randn(162, Cout, Cin, k, k) / 24).to(DEV), BF)
             o.conv2d(x, w, k, k, 1, k // 2)
