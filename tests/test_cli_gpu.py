@@ -187,6 +187,17 @@ data = dict(samples_per_gpu=2, train=dict(_delete_=True, type='CMUPanopticDatase
     assert 'loss_pose' in out and 'nan' not in out.lower() and 'Epoch [2]' in out, out[-800:]
 
 
+def test_train_cli_with_trunk_graphs(tmp_path):
+    """`hip_graphs=True`: tools/train.py captures the backbone + neck after the first step and trains on through the
+    graphs (fixed-size synthetic batches), checkpointing as usual."""
+    out = run('tools/train.py', 'configs/das/exp_panoptic.py', '--work-dir', str(tmp_path / 'g'), '--max-iters', '4',
+              '--no-validate', '--cfg-options', 'model.backbone.num_stages=1', 'runner.max_epochs=1', 'log_config.interval=1',
+              'hip_graphs=True', 'data.samples_per_gpu=2', 'data.train.type=SyntheticPoseDataset', 'data.train.length=8',
+              'data.train.img_shape=(256,384)', 'data.workers_per_gpu=0')
+    assert 'trunk captured as hipGraphs' in out and 'nan' not in out.lower(), out[-800:]
+    assert out.count('loss_pose') >= 4 and os.path.exists(tmp_path / 'g' / 'epoch_1.pth')
+
+
 def test_process_loader_hands_device_batches_over_in_order():
     """das_amd.loader.ProcessLoader: worker processes (own interpreter, own HIP context on the same GPU) build the batches,
     the collated CUDA tensors arrive here by IPC handle, in batch order, and a failing batch raises here."""

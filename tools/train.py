@@ -131,6 +131,7 @@ def main():
     if workers > 0 and cfg.data.get('worker_mode', 'process') == 'process':
         pool = ProcessLoader(cfg.data.train, device=f'cuda:{local_rank}', workers=workers, seed=args.seed + 1000 * rank)
     lrc = cfg.get('lr_config', {})
+    want_graphs = bool(cfg.get('hip_graphs', False))
     max_epochs = cfg.get('runner', {}).get('max_epochs', 12)
     log_every = cfg.get('log_config', {}).get('interval', 50)
     for epoch in range(start_epoch, max_epochs):
@@ -153,6 +154,20 @@ def main():
                          warmup_ratio=lrc.get('warmup_ratio', 1.0))
             out = train_iteration(model, opt, data, lr)
             it += 1
+            if want_graphs and world == 1 and getattr(model, '_graphed_trunk', None) is None:
+                # `hip_graphs=True` (single process; fixed input size): after the first step — every workspace and
+                # schedule exists — the backbone + neck forward / backward of batches shaped like this one are captured
+                # as two hipGraphs (das_amd/graphs.py); other shapes keep the launch-by-launch path
+                from das_amd.graphs import enable_trunk_graphs
+                lv0 = dict(out['log_vars'].items())
+                del out                                       # (no autograd graph may be alive during the capture)
+                try:
+                    enable_trunk_graphs(model, opt, data['img'])
+                    print(f'trunk captured as hipGraphs for batches of shape {tuple(data["img"].shape)}', flush=True)
+                except RuntimeError as e:
+                    want_graphs = False
+                    print(f'hip_graphs: capture refused ({e}); continuing launch by launch', flush=True)
+                out = dict(log_vars=lv0)
             if rank == 0 and it % log_every == 0:
                 lv = ', '.join(f'{k}: {v:.4f}' for k, v in out['log_vars'].items())
                 print(f'Epoch [{epoch + 1}][{b // spg + 1}/{len(order) // spg}] lr: {lr:.3e}, '
