@@ -326,7 +326,7 @@ __global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
 //   * the tile is a 16 x 16 pixel SQUARE and its 18 x 18 x 64-channel input patch (41 KiB, zero-filled outside the image
 //     by the buffer descriptor's range check) is DMA'd ONCE; the nine taps read it at shifted positions (pixel-major,
 //     the 16-byte chunk index XOR-swizzled with the pixel index);
-//   * a fifth wave only issues the DMA of the NEXT tile's patch into the other buffer while the four MFMA waves work
+//   * two more waves only issue the DMA of the NEXT tile's patch into the other buffer while the four MFMA waves work
 //     (64 pixels x 64 channels each, 288 MFMAs per tile) and run the shared epilogue (which stages the C tile in the
 //     patch buffer it has just finished reading) — the MFMA waves never wait on vmcnt for a DMA, the loader never stores.
 struct TilingC64 {
@@ -336,19 +336,19 @@ struct TilingC64 {
 };
 constexpr int C64_WROW = 1168, C64_WBYTES = 64 * C64_WROW, C64_PATCH = 41 * 1024;   // (324 pixels x 128 B, in 1 KiB DMA units)
 template <typename OT>
-__global__ __launch_bounds__(320) void conv3x3_c64_kernel(ConvP p, int ntiles) {
+__global__ __launch_bounds__(384) void conv3x3_c64_kernel(ConvP p, int ntiles) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int c = tid; c < 64 * 72; c += 320) {      // weights: 64 rows of 72 16-byte chunks
+  for (int c = tid; c < 64 * 72; c += 384) {      // weights: 64 rows of 72 16-byte chunks
     const int row = c / 72, ch = c - row * 72;
     *reinterpret_cast<uint4*>(sW + row * C64_WROW + ch * 16) = *reinterpret_cast<const uint4*>(p.w + (size_t)row * 1152 + ch * 16);
   }
   __syncthreads();
   const int tw = (p.W + 15) >> 4, per_img = ((p.H + 15) >> 4) * tw;
-  if (wave == 4) {   // ---- loader wave
+  if (wave >= 4) {   // ---- loader waves (each issues half of a patch's 41 DMA instructions)
     const v4i_t xrs = make_rsrc(p.x, p.xbytes);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + C64_WBYTES;
     const unsigned xps2 = (unsigned)p.xps * 2u;
@@ -356,15 +356,16 @@ __global__ __launch_bounds__(320) void conv3x3_c64_kernel(ConvP p, int ntiles) {
     auto issue = [&](int tile, int buf) {
       const int b = tile / per_img, t = tile - b * per_img, th = t / tw;
       const int h0 = th * 16 - 1, w0 = (t - th * tw) * 16 - 1;
-      int pp = lane >> 3;                          // patch pixel of this lane in instruction 0; + 8 per instruction
-      int pr = 0, pc = pp;
+      const int j0 = (wave - 4) * 21, j1 = wave == 4 ? 21 : 41;
+      int pp = j0 * 8 + (lane >> 3);               // patch pixel of this lane in its first instruction; + 8 per instruction
+      int pr = pp / 18, pc = pp - pr * 18;
 #pragma unroll 1
-      for (int j = 0; j < 41; ++j) {
+      for (int j = j0; j < j1; ++j) {
         const int h = h0 + pr, w = w0 + pc;
         const bool ok = pp < 324 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
         const unsigned chunk = (unsigned)((lane & 7) ^ (pp & 7));
         const unsigned off = (unsigned)((b * p.H + h) * p.W + w) * xps2 + chunk * 16u;
-        dma16_buf(ok ? off : OOB, xrs, lds0 + buf * C64_PATCH + j * 1024);
+        dma16_buf(ok ? off : OOB, xrs, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + buf * C64_PATCH + j * 1024)));
         pp += 8; pc += 8;
         if (pc >= 18) { pc -= 18; ++pr; }
       }
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(320) void conv3x3_c64_kernel(ConvP p, int ntiles) {
     int i = 0;
     if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++i) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's patch has landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's patch has landed (this wave's half)
       __builtin_amdgcn_s_barrier();                        // A: ... and the other waves are done with the other buffer
       if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, (i + 1) & 1);
       __builtin_amdgcn_s_barrier();                        // B
@@ -1468,7 +1469,7 @@ bool try_launch_c64(const ConvP& p, hipStream_t s) {
   }
   const int grid = std::min(ntiles, device_cus());
   dastune::note_kernel("conv3x3_c64_kernel");
-  hipLaunchKernelGGL((conv3x3_c64_kernel<OT>), dim3(grid), dim3(320), sm, s, p, ntiles);
+  hipLaunchKernelGGL((conv3x3_c64_kernel<OT>), dim3(grid), dim3(384), sm, s, p, ntiles);
   return true;
 }
 

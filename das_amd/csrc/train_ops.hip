@@ -456,6 +456,153 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSched sch_) {
   }   // next unit (every wave is past the last step's barrier: the LDS buffers are free)
 }
 
+// Weight gradient of the 3x3, stride-1, 64 -> 64 channel convs (conv2 of the 128 x 208 stage's bottlenecks, 12 per train
+// step): on the 128 x 128 kernel above they were the slowest ops against their floor (105 us for 31 GFLOP / 109 MB: its
+// Cout tile is half empty and every one of the five K tiles reads dY and its own taps' pixel rows again). Same idea as
+// conv3x3_c64_kernel (conv_igemm.hip): PERSISTENT, one workgroup per CU, tiles are 16 x 16-pixel squares; the square's dY
+// (256 pixels x 64 channels) and the 18 x 18 input patch are DMA'd ONCE (two loader waves, one tile ahead, double buffers)
+// and NINE waves — one per tap — multiply dY^T by the patch shifted by their tap (transposing LDS reads, 32 pixels per
+// MFMA step), each keeping its 64 x 64 slice of dW in registers for the whole launch. Partial dW per workgroup go to the
+// workspace [workgroup][tap][o][ci]; wgrad_c64_reduce_kernel sums them in a fixed order (deterministic) into dW.
+constexpr int WC64_DY = 32 * 1024, WC64_PATCH = 41 * 1024;
+__global__ __launch_bounds__(704) void conv_wgrad_c64_kernel(const char* __restrict__ xg, const char* __restrict__ dyg,
+                                                             float* __restrict__ ws, int B, int H, int W, int xps, int rps,
+                                                             unsigned xbytes, unsigned dbytes, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][dY tile | patch]
+  constexpr int STAGE = WC64_DY + WC64_PATCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tw = (W + 15) >> 4, per_img = ((H + 15) >> 4) * tw;
+  if (wave >= 9) {   // ---- loader waves: wave 9 stages dY, wave 10 the input patch
+    const v4i_t xrs = make_rsrc(xg, xbytes), drs = make_rsrc(dyg, dbytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned xps2 = (unsigned)xps * 2u, rps2 = (unsigned)rps * 2u;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    auto issue = [&](int tile, int buf) {
+      const int b = tile / per_img, t = tile - b * per_img, th = t / tw;
+      const int h0 = th * 16, w0 = (t - th * tw) * 16;
+      const unsigned sD = lds0 + buf * STAGE, sX = sD + WC64_DY;
+      if (wave == 9) {
+#pragma unroll 4
+        for (int j = 0; j < 32; ++j) {               // dY: pixel p = r * 16 + c of the square
+          const int pix = j * 8 + (lane >> 3);
+          const int h = h0 + (pix >> 4), w = w0 + (pix & 15);
+          const bool ok = h < H && w < W;
+          const unsigned chunk = (unsigned)((lane & 7) ^ (pix & 7));
+          dma16_buf(ok ? (unsigned)((b * H + h) * W + w) * rps2 + chunk * 16u : OOB, drs, sD + j * 1024);
+        }
+      } else {
+        int pp = lane >> 3, pr = 0, pc = pp;         // patch pixel of this lane in instruction 0; + 8 per instruction
+#pragma unroll 4
+        for (int j = 0; j < 41; ++j) {
+          const int h = h0 - 1 + pr, w = w0 - 1 + pc;
+          const bool ok = pp < 324 && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+          const unsigned chunk = (unsigned)((lane & 7) ^ (pp & 7));
+          dma16_buf(ok ? (unsigned)((b * H + h) * W + w) * xps2 + chunk * 16u : OOB, xrs, sX + j * 1024);
+          pp += 8; pc += 8;
+          if (pc >= 18) { pc -= 18; ++pr; }
+        }
+      }
+    };
+    int i = 0;
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++i) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's operands have landed (this wave's half)
+      __builtin_amdgcn_s_barrier();                        // A: ... and the tap waves are done with the other stage
+      if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, (i + 1) & 1);
+      __builtin_amdgcn_s_barrier();                        // B
+    }
+    return;
+  }
+  // ---- tap waves: wave = kh * 3 + kw
+  const int kh = wave / 3, kw = wave - kh * 3;
+  const int g4 = lane >> 4, q = lane & 15, sub = q & 3, col = g4 * 4 + (q >> 2);
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int i = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++i) {
+    const char* sD = smem + (i & 1) * STAGE;
+    const char* sX = sD + WC64_DY;
+    __builtin_amdgcn_s_barrier();                          // A
+#pragma unroll 2
+    for (int ks = 0; ks < 8; ++ks) {                       // 32 pixels per step: rows 2 ks, 2 ks + 1 of the square
+      uint4 fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v4i16_t lo[2], hi[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pd = (ks * 2 + h) * 16 + col;                       // dY pixel of the square
+          const int px = (ks * 2 + h + kh) * 18 + col + kw;             // input pixel of the patch, shifted by the tap
+          const int slot = t * 2 + (sub >> 1);
+          lo[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4i16_t*)(sD + pd * 128 + ((slot ^ (pd & 7)) << 4) + (sub & 1) * 8));
+          hi[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4i16_t*)(sX + px * 128 + ((slot ^ (px & 7)) << 4) + (sub & 1) * 8));
+        }
+        fa[t] = make_uint4(__builtin_bit_cast(uint2, lo[0]).x, __builtin_bit_cast(uint2, lo[0]).y,
+                           __builtin_bit_cast(uint2, lo[1]).x, __builtin_bit_cast(uint2, lo[1]).y);
+        fb[t] = make_uint4(__builtin_bit_cast(uint2, hi[0]).x, __builtin_bit_cast(uint2, hi[0]).y,
+                           __builtin_bit_cast(uint2, hi[1]).x, __builtin_bit_cast(uint2, hi[1]).y);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[a]),
+                                                              __builtin_bit_cast(bf16x8_t, fb[b]), acc[a][b], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // B: every wave is done reading this stage
+  }
+  // acc[a][b][j]: output channel a * 16 + (lane >> 4) * 4 + j, input channel b * 16 + (lane & 15). Stored straight from
+  // the registers that is 4-byte pieces in 64-byte runs (37 MB of partials per launch: 40 us); through LDS (rows padded to
+  // 68 floats: conflict-free both ways), 32 output channels at a time, every store instruction writes one contiguous KiB.
+  float* dst = ws + ((size_t)blockIdx.x * 9 + wave) * 4096;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stg[(a2 * 16 + g4 * 4 + j) * 68 + b * 16 + q] = acc[half * 2 + a2][b][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's own staging area: no barrier needed)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = r * 4 + g4;
+      const float4 v = *reinterpret_cast<const float4*>(stg + row * 68 + q * 4);
+      *reinterpret_cast<float4*>(dst + (half * 32 + row) * 64 + q * 4) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// dW[o][tap][ci] (+)= sum over the workgroups' partials in a fixed order: 64 outputs per workgroup, four threads per
+// output summing every fourth partial, combined through LDS
+__global__ __launch_bounds__(256) void wgrad_c64_reduce_kernel(const float* __restrict__ ws, int nwg, float* __restrict__ dw,
+                                                               int accumulate) {
+  __shared__ float part[4][64];
+  const int k = threadIdx.x >> 6, oi = threadIdx.x & 63;
+  const int i = blockIdx.x * 64 + oi;             // = (tap * 64 + o) * 64 + ci of the partial layout
+  float s0 = 0.f, s1 = 0.f;
+  int g = k;
+  for (; g + 4 < nwg; g += 8) { s0 += ws[(size_t)g * 36864 + i]; s1 += ws[(size_t)(g + 4) * 36864 + i]; }
+  if (g < nwg) s0 += ws[(size_t)g * 36864 + i];
+  part[k][oi] = s0 + s1;
+  __syncthreads();
+  if (k == 0) {
+    const float v = (part[0][oi] + part[1][oi]) + (part[2][oi] + part[3][oi]);
+    const int tap = i >> 12, o = (i >> 6) & 63, ci = i & 63;
+    float* d = dw + (o * 9 + tap) * 64 + ci;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
 // Ping-pong variant for bf16 with Cout >= 256 and K >= 256: 256 (Cout) x 256 (K columns) tile, 8 waves (2 x 4),
 // 128 x 64 per wave — at 64 x 64 per wave the transposing LDS reads take as long as the MFMAs they feed (8 KiB
 // per 16 MFMAs, 128 B/clk); 128 x 64 reads 12 KiB per 32. 32 pixel rows per step, four LDS stages of four
@@ -989,6 +1136,17 @@ int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d
       h.cls = 0;
     }
   }
+  // conv_wgrad_c64_kernel: 3x3, stride 1, 64 -> 64 channels on a plain NHWC tensor
+  const long long c64_from = dastune::get(dastune::CONV_C64_MINTILES);
+  if (d->dtype == DAS_BF16 && c64_from > 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin == 64 &&
+      d->Cout == 64 && o.nlev <= 1 && d->Ho == d->H && d->Wo == d->W) {
+    const long long sq = (long long)((d->H + 15) / 16) * ((d->W + 15) / 16), npix = (long long)d->B * d->H * d->W;
+    const long long xb = ((npix - 1) * d->x_pix_stride + 64) * 2, db = ((npix - 1) * d->y_pix_stride + 64) * 2;
+    if (sq * d->B >= c64_from && sq * 256 * 3 <= (long long)d->H * d->W * 4 && xb < 0xFFFFFFF0LL && db < 0xFFFFFFF0LL) {
+      o.xbytes = (unsigned)xb;
+      h.cls = 3;
+    }
+  }
   h.tile = h.cls == 0 ? 256 : 128;
   const int ntiles = (o.K + h.tile - 1) / h.tile;
   o.tiles = ((d->Cout + h.tile - 1) / h.tile) * ntiles;
@@ -1295,6 +1453,30 @@ extern "C" int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* 
       if (dws[j] == dws[i]) return DAS_ERR_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n; ++i) {   // class 3 (3x3, 64 -> 64): one persistent launch + its reduction per op
+    if (ops[i].cls != 3) continue;
+    const WgradOpS& o = ops[i].o;
+    const int ntiles = ((o.H + 15) / 16) * ((o.W + 15) / 16) * o.B;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = std::min(ntiles, cus);
+    float* ws = wgrad_workspace(s, (size_t)grid * 36864 * sizeof(float));
+    if (!ws) return DAS_ERR_LAUNCH;
+    const size_t sm = 2 * (size_t)(WC64_DY + WC64_PATCH);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)conv_wgrad_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        return DAS_ERR_LAUNCH;
+      attr_set = true;
+    }
+    const unsigned dbytes = (unsigned)((((long long)o.M - 1) * o.rps + 64) * 2);
+    dastune::note_kernel("conv_wgrad_c64_kernel");
+    hipLaunchKernelGGL(conv_wgrad_c64_kernel, dim3(grid), dim3(704), sm, s, ops[i].x, ops[i].dy, ws, o.B, o.H, o.W, o.xps, o.rps,
+                       o.xbytes, dbytes, ntiles);
+    DAS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_c64_reduce_kernel, dim3(576), dim3(256), 0, s, ws, grid, ops[i].dw, accumulate);
+    DAS_CHECK_LAUNCH();
+  }
   for (int cls = 0; cls < 3; ++cls) {
     HostWgrad* sel[WG_MAXOPS];
     int k = 0;

@@ -453,7 +453,8 @@ def test_tail_split_head_conv_at_inference_batch():
 
 WGRAD_REAL = [
     # B, H, W, Cin, Cout, k, stride, pad, expected kernel
-    (2, 128, 208, 64, 64, 3, 1, 1, 'conv_wgrad_kernel'),        # 5 tiles x 153 splits = 765 workgroups
+    (2, 128, 208, 64, 64, 3, 1, 1, 'conv_wgrad_c64_kernel'),    # 208 squares of 16 x 16 pixels on 208 workgroups
+    (2, 128, 208, 64, 72, 3, 1, 1, 'conv_wgrad_kernel'),        # 5 tiles x 153 splits = 765 workgroups
     (3, 128, 208, 256, 256, 1, 1, 0, 'conv_wgrad_pp_kernel'),   # 1 tile x 256 splits
     (16, 32, 52, 256, 256, 3, 1, 1, 'conv_wgrad_pp_kernel'),    # 9 tiles x 28 splits
     (8, 64, 104, 256, 512, 1, 2, 0, 'conv_wgrad_pp_kernel'),    # stride-2 1x1 (the downsample branch)
@@ -481,6 +482,38 @@ def test_wgrad_real_split(case):
     np.testing.assert_allclose(acc.cpu().numpy(), 2 * dw.cpu().numpy(), rtol=1e-5, atol=1e-5)
     dw2 = o.conv2d_wgrad(nhwc(x), nhwc(dy), k, k, s, p)
     np.testing.assert_allclose(dw2.cpu().numpy(), dw.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', [(1, 16, 16), (3, 48, 32), (2, 40, 60), (2, 128, 232), (5, 64, 64)])
+def test_wgrad_c64_patch_kernel(case):
+    """conv_wgrad_c64_kernel (3x3, 64 -> 64: one wave per tap over 16 x 16-pixel squares, dY and the input patch loaded
+    once per square, per-workgroup partials summed in a fixed order) against torch's weight gradient: a single square,
+    more squares than workgroups (5 x 16 = 80... and 2 x 8 x 15 = 240 on <= 256), border squares partly outside the
+    image, channel-slice operands (pixel strides 96 / 128), written and accumulated, and run-to-run bit-identical."""
+    o = ops()
+    B, H, W = case
+    x = cases.randn(181, B, 64, H, W)
+    dy = cases.randn(182, B, 64, H, W) / (B * H * W) ** 0.5
+    torch.set_num_threads(8)
+    w0 = torch.zeros(64, 64, 3, 3, requires_grad=True)
+    F.conv2d(q(x), w0, None, 1, 1).backward(q(dy))
+    ref = w0.grad.permute(0, 2, 3, 1)
+    wide_x = torch.zeros(B, H, W, 96, device=DEV, dtype=BF)
+    wide_x[..., 16:80] = nhwc(x)
+    wide_dy = torch.zeros(B, H, W, 128, device=DEV, dtype=BF)
+    wide_dy[..., 64:] = nhwc(dy)
+    with o.tuning(**{'conv.c64_mintiles': 1}):
+        dw = o.conv2d_wgrad(wide_x[..., 16:80], wide_dy[..., 64:], 3, 3, 1, 1)
+        assert o.last_kernel() == 'conv_wgrad_c64_kernel', o.last_kernel()
+        np.testing.assert_allclose(dw.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+        acc = dw.clone()
+        o.conv2d_wgrad(nhwc(x), nhwc(dy), 3, 3, 1, 1, out=acc, accumulate=True)
+        np.testing.assert_allclose(acc.cpu().numpy(), 2 * dw.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(o.conv2d_wgrad(nhwc(x), nhwc(dy), 3, 3, 1, 1), dw)      # deterministic
+    with o.tuning(**{'conv.c64_mintiles': 0}):
+        other = o.conv2d_wgrad(nhwc(x), nhwc(dy), 3, 3, 1, 1)
+        assert o.last_kernel() == 'conv_wgrad_kernel'
+    np.testing.assert_allclose(dw.cpu().numpy(), other.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
 
 
 def test_wgrad_ragged_real_split():
