@@ -37,16 +37,24 @@ def main(d, out):
             ('conv_glds3_kernel', cf, cw, src_c, lambda k: k.startswith('conv_glds3_kernel<') and k.endswith('false>')),
             ('conv_glds_kernel', cf, cw, src_c, lambda k: k.startswith('conv_glds_kernel<')),
             ('conv1x1_stream_kernel', cf, cw, src_c, lambda k: k.startswith('conv1x1_stream_kernel<')),
+            ('conv3x3_c64_kernel', cf, cw, src_c, lambda k: k.startswith('conv3x3_c64_kernel<')),
             ('conv_wgrad_pp_kernel', wf, ww, src_w, lambda k: k == 'conv_wgrad_pp_kernel' or 'AccMap256' in k),
-            ('conv_wgrad_kernel<bf16>', wf, ww, src_w, lambda k: k.startswith('conv_wgrad_kernel<') or 'AccMap128' in k),
+            ('conv_wgrad_kernel<bf16>', wf, ww, src_w, lambda k: k.startswith('conv_wgrad_kernel<') or 'AccMap128' in k or
+             k.startswith('conv_wgrad_c64_kernel') or k.startswith('wgrad_c64_reduce_kernel')),
             ('bn_apply_kernel + bn_bwd_apply_dz_kernel + bn_bwd_reduce_kernel + bn_bwd_apply_kernel', bf, bw, src_b,
-             lambda k: k.startswith('bn_')))
+             lambda k: k.startswith('bn_') or k.startswith('fold_slots_kernel')))
     for tag, fe, wr, src, match in tags:
         e = fam(fe, wr, match)
         if e:
             e['source'] = src
             fams.setdefault(tag, {})['train'] = e
     # algorithmic bytes of exactly the launches the counters saw (tools/dev/conv_mix.py prints them per family)
+    for line in open(f'{d}/conv_mix_bare.log'):
+        if line.startswith('ALGORITHMIC '):
+            json.dump(dict(note='algorithmic bytes per launch (x once, y once, weights once) of the launches of tools/dev/conv_mix.py, '
+                                'per kernel family as ops.last_kernel() names it; the PMC passes behind profiles/traffic.json '
+                                'counted the same launches (warm-up launch of every shape included)',
+                           families=json.loads(line[len('ALGORITHMIC '):])), open(f'{out}/r03_conv_mix_algorithmic.json', 'w'))
     try:
         alg = json.load(open(f'{out}/r03_conv_mix_algorithmic.json'))['families']
     except OSError:
