@@ -483,8 +483,12 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=None, help='override the CPU leg\'s thread count')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='run only the CPU leg and print it')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--no-graphs', action='store_true',
-                    help='A/B: queue every launch of the backbone + neck instead of replaying their two hipGraphs (train, 1 GPU)')
+    ap.add_argument('--graph-side-stream', action='store_true', help='A/B: capture the weight gradients on their side streams')
+    ap.add_argument('--graphs', action='store_true',
+                    help='replay the backbone + neck forward / backward as two hipGraphs (train, 1 GPU; das_amd/graphs.py): '
+                         '38 instead of 62 ms of host time per step, but 1 % LESS throughput than queueing every launch '
+                         '(nine A/B pairs on three boxes: 177.2 vs 179.3 img/s) — the GPU, not the host, bounds the step')
+    ap.add_argument('--no-graphs', action='store_true', help='(the default; kept for older command lines)')
     ap.add_argument('--no-wgrad-stream', action='store_true', help='A/B: weight gradients on the main stream')
     ap.add_argument('--wgrad-streams', type=int, default=None, help='A/B: number of weight-gradient side streams')
     ap.add_argument('--wgrad-batch', type=int, default=None, help='A/B: weight gradients per batched launch (1 = off)')
@@ -577,12 +581,15 @@ def main():
             torch.cuda.synchronize()
 
     graphs = None
-    if train and world == 1 and not args.no_graphs:
+    if train and world == 1 and args.graphs and not args.no_graphs:
         # (one eager step first: the optimizer's packed-weight buffers, the weight-gradient schedules and the kernels'
         # attributes exist before anything is captured; it counts as one of the warm-up steps)
         res = step()
         del res
+        from das_amd import graphs as _g
         from das_amd.graphs import enable_trunk_graphs
+        if args.graph_side_stream:
+            _g.CAPTURE_SIDE_STREAM = True
         try:
             graphs = enable_trunk_graphs(model, opt, data['img'])
             extra['hip_graphs'] = 'backbone + neck: forward graph, backward graph (das_amd/graphs.py); head and losses eager'
@@ -590,7 +597,7 @@ def main():
             model._graphed_trunk = None
             extra['hip_graphs'] = f'off (capture failed: {e})'
     else:
-        extra['hip_graphs'] = 'off'
+        extra['hip_graphs'] = 'off (default: every launch queued by hand; --graphs replays the trunk as two hipGraphs)' if train else 'off'
     for _ in range(warmup - (1 if graphs is not None else 0)):
         res = step()
     sync_all()

@@ -27,6 +27,11 @@ from . import autograd as ag
 from . import nn as dnn
 
 
+# Capture the weight gradients on their side streams (forked from / joined to the capture stream by events: the graph
+# then has parallel branches, as the launch-by-launch path has) instead of serially on the capture stream.
+CAPTURE_SIDE_STREAM = False
+
+
 class _Replay(torch.autograd.Function):
     """Forward graph now, backward graph when the feature maps' gradients arrive. `anchor` is a dummy input that
     requires grad: the image does not, and without a differentiable input autograd would not call backward."""
@@ -71,7 +76,9 @@ class GraphedTrunk:
         buffers = [b for m in (model.backbone, model.neck) if m is not None for b in m.buffers()]
         keep_buf = [b.detach().clone() for b in buffers]
         keep_g = optimizer.flat_g.detach().clone()
-        side_was, ag.WGRAD_SIDE_STREAM = ag.WGRAD_SIDE_STREAM, False
+        side_was = ag.WGRAD_SIDE_STREAM
+        if not CAPTURE_SIDE_STREAM:
+            ag.WGRAD_SIDE_STREAM = False
         arena_was = dnn._STATS_ARENA
         self.arena = dnn._ZeroArena()
         self.x = img.detach().clone()
@@ -128,6 +135,7 @@ class GraphedTrunk:
         inside a capture. torch.autograd.grad returns the gradients instead; the few that autograd delivers (most are
         added into the flat gradient by the kernels themselves and come back as None) are added by hand."""
         grads = torch.autograd.grad(outs, params, gouts, allow_unused=True)
+        ag.finish_backward()      # (queued weight gradients launched, their side streams joined: inside the capture)
         with torch.no_grad():
             for p, g in zip(params, grads):
                 if g is not None:
