@@ -1,4 +1,5 @@
-"""Dev tool: how sharp can a train-mode loss comparison at full width be? For the 1-stage and the 4-stage net (B = 2,
+"""Measurement helper of the test suite (it runs the oracle, so it lives under tests/): how sharp can a train-mode loss
+comparison at full width be? For the 1-stage and the 4-stage net (B = 2,
 512 x 832, the weights and frames of tests/test_full_width_gpu.py): the CPU oracle in f64 and f32, then the HIP path n
 times in f32 and n times in bf16 on the same weights and frames (running statistics restored before every run).
 The statistics of a train-mode BatchNorm are summed with float atomics (the order varies run to run) and ~50 / ~200
@@ -9,12 +10,13 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 import bench  # noqa: E402
 from das_amd.datasets import SyntheticPoseDataset, collate  # noqa: E402
-from oracle import backbone as ob, head as oh, loss as ol  # noqa: E402  (dev tool: the oracle as the checker)
+from oracle import backbone as ob, head as oh, loss as ol  # noqa: E402  (the oracle as the checker)
 from test_full_width_gpu import build, oracle_hcfg, split_sd  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6

@@ -179,7 +179,7 @@ def test_four_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
     centerness) from its f64 evaluation, and differently from run to run (thread-dependent summation order). On the
     HIP path (BatchNorm statistics summed with float atomics) six f32 runs on identical weights and frames spread by
     0.6-1.2 % (cls, depth, centerness) and 2.7 % (pose) and lie at most 0.9 % / 2.9 % from the f64 values; six bf16
-    runs spread by 0.8-2.3 % / 5.6 % (tools/dev/loss_spread.py -> profiles/r03_loss_spread.txt). So this test can
+    runs spread by 0.8-2.3 % / 5.6 % (tests/loss_spread.py -> profiles/r03_loss_spread.txt). So this test can
     only bound, not pin: f32 within 4 % (pose: 12 %) of f64, bf16 within 8 % (pose: 20 %) of f32 — about four times
     the measured extremes. The sharp checks are the 1-stage losses above (1e-4), the eval-mode maps (2e-4) and the
     per-kernel full-width tests (tests/test_conv_tiles_gpu.py, test_bn_fused_gpu.py)."""
