@@ -82,17 +82,17 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restric
       for (int j = 0; j < EPV; ++j) { a[j] += g[j]; bb[j] += g[j] * (xx[j] - mu[j]) * rs[j]; }
     };
     int p = p0 + pl;
-    for (; p + PL < p1; p += 2 * PL) {
-      uint4 rg[2], rx[2], ry[2];
+    for (; p + 3 * PL < p1; p += 4 * PL) {   // four pixels' operands in flight (two left this pass at 3.2 TB/s)
+      uint4 rg[4], rx[4], ry[4];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 4; ++u) {
         const long long o = off + (long long)(p + u * PL) * ps;
         rg[u] = *reinterpret_cast<const uint4*>(dy + o);
         rx[u] = *reinterpret_cast<const uint4*>(x + o);
         ry[u] = relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) acc(rg[u], rx[u], ry[u]);
+      for (int u = 0; u < 4; ++u) acc(rg[u], rx[u], ry[u]);
     }
     for (; p < p1; p += PL) {
       const long long o = off + (long long)p * ps;
