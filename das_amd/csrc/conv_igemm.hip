@@ -864,6 +864,8 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   DAS_STAMP(4);
 }
 
+#include "conv_persist.h"
+
 // =============================================================== launch
 inline int device_cus() {
   static int cus = 0;
@@ -873,6 +875,53 @@ inline int device_cus() {
     cus = n > 0 ? n : 256;
   }
   return cus;
+}
+// CUs a persistent one-workgroup-per-CU grid may count on: the device's, minus comm.reserved_cus (left to the RCCL
+// kernels of an overlapped gradient all-reduce; 0 on one GPU).
+inline int usable_cus() {
+  const long long r = dastune::get(dastune::COMM_RESERVED_CUS);
+  const int c = device_cus();
+  return (int)std::max<long long>(8, c - std::max<long long>(0, r));
+}
+// conv_pt3_kernel (conv_persist.h): the 256 x 128 tile kernel as a persistent grid, for launches of more tiles than CUs.
+template <typename OT>
+bool try_launch_pt3(const ConvP& p0, int rows, hipStream_t s) {
+  if constexpr (sizeof(OT) != 2) {
+    return false;
+  } else {
+    const long long mint = dastune::get(dastune::CONV_PT3_MINTILES);   // 0 disables
+    ConvP p = p0;
+    const int nk = p.K / 64;
+    const long long total = (long long)((rows + 255) / 256) * p.ntiles;
+    if (mint <= 0 || total < mint || nk < 2 || p.K % 64 || p.m_base != 0 || p.up_sh != 0 || p.relu_in || p.xbytes == 0 ||
+        p.yps % 8 || (p.res && p.rps % 8) || (p.bnb_raw && p.bnb_ps % 8) || p.ntiles > 64)
+      return false;
+    const bool aff = p.scale || p.shift, bnb = p.bnb_raw != nullptr;
+    if (!bnb && p.stats && (aff || p.res || p.relu)) return false;   // (combinations no caller on the path uses)
+    if (bnb && (p.relu || aff || !p.stats)) return false;
+    long long grid = std::min<long long>(total, usable_cus());
+    grid -= grid % p.ntiles;            // a workgroup keeps its column block (the carried statistics are per channel)
+    if (grid < p.ntiles || grid < 1) return false;
+    const int mode = bnb ? ((p.bnb_relu && !p.bnb_y) ? 4 : 3) : p.res ? (aff ? 5 : 2) : ((aff || p.relu) ? 1 : 0);
+    auto go = [&](auto kern) -> bool {
+      static bool attr = false;   // (one per kernel type)
+      if (!attr) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PT3_SMEM) != hipSuccess) return false;
+        attr = true;
+      }
+      dastune::note_kernel("conv_pt3_kernel");
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), PT3_SMEM, s, p, (int)total);
+      return true;
+    };
+    switch (mode) {
+      case 0: return go(conv_pt3_kernel<0>);
+      case 1: return go(conv_pt3_kernel<1>);
+      case 2: return go(conv_pt3_kernel<2>);
+      case 3: return go(conv_pt3_kernel<3>);
+      case 4: return go(conv_pt3_kernel<4>);
+      default: return go(conv_pt3_kernel<5>);
+    }
+  }
 }
 // Split-K factor for a tile-kernel launch of `nblocks` workgroups with `nk` K steps (steps of 128 bytes: the 64-byte
 // steps of conv_glds4_kernel are counted in pairs): small-M, long-K layers (the 16x26 / 32x52 stages) have too few
@@ -935,6 +984,12 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
   const bool big = (may_split || ks3 > 1) && glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && nb3 * ks3 >= minb &&
                    p.K >= mink &&
                    p.xbytes != 0;  // (0 = more than 4 GiB of input: not addressable by 32-bit buffer offsets)
+  if constexpr (BN == 128 && sizeof(T) == 2) {
+    if (big && ks3 == 1 && may_split && try_launch_pt3<OT>(p, rows, s)) {
+      DAS_CHECK_LAUNCH();
+      return DAS_OK;
+    }
+  }
   const int bm = big ? 256 : BM;
   int mtiles = (rows + bm - 1) / bm;
   if (big && ks3 == 1) {

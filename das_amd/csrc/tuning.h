@@ -36,6 +36,11 @@ enum Key {
                          // whole weight matrix in LDS) from this many tiles up; 0 disables the kernel
   BN_STREAM_MINBYTES,    // BatchNorm apply passes over tensors of at least this many bytes: slot fold as its own launch +
                          // a one-shot pass of small workgroups (bn_apply_stream_kernel); 0 = never
+  CONV_PT3_MINTILES,     // conv_pt3_kernel (persistent 256 x 128 tile grid, conv_persist.h) for launches of at least this many
+                         // tiles; 0 (the default) disables the kernel: measured on the step's multi-round shapes it is within
+                         // +-5 % of the one-tile kernels — parity-tested, kept for the record and for A/B runs
+  COMM_RESERVED_CUS,     // CUs the persistent one-workgroup-per-CU grids leave free (for the RCCL kernels of the overlapped
+                         // gradient all-reduce when several GPUs train together); 0 on one GPU
   N_KEYS
 };
 

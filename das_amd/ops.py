@@ -557,8 +557,11 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         nby += rows * Cout * eo if rd is not None else 0
         if bn_bwd is not None:
             nby += rows * Cout * eo * (2 if bn_bwd.y is not None else 1)
+        mode = ('s' if stats is not None and bn_bwd is None else '') + ('r' if rd is not None else '') + \
+            ('' if bn_bwd is None else ('by' if bn_bwd.y is not None else 'bx')) + ('a' if scale is not None else '') + \
+            ('u' if out_sub is not None else '')
         PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1,
-                        (B, H, W, Cin, Cout, KH, stride, len(x.sizes) if ragged else 1), 1, float(nby)))
+                        (B, H, W, Cin, Cout, KH, stride, len(x.sizes) if ragged else 1, mode), 1, float(nby)))
     return out
 
 

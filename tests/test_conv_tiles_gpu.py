@@ -57,6 +57,9 @@ FORCE = {
                               'conv.glds4_mf': 8, 'conv.stream_minrows': 0},
     'conv_glds4_kernel<pp,288>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.splitk_target': 0,
                                   'conv.glds4_mf': 9, 'conv.stream_minrows': 0},
+    # the persistent 256 x 128 grid, from a single tile up, on few enough workgroups that every one walks several tiles
+    'conv_pt3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.splitk_target': 0,
+                        'conv.stream_minrows': 0, 'conv.pt3_mintiles': 1, 'comm.reserved_cus': 248},
 }
 
 # B, H, W, Cin, Cout, k, stride, pad
@@ -88,6 +91,37 @@ def _run_forced(kernel, case, **kw):
     return x, w, y
 
 
+# the persistent kernel needs K >= 128 (two K steps): the single-step case stays with the one-tile kernels
+SHAPES_PT3 = [c for c in SHAPES3 if c[3] * c[5] * c[5] >= 128] + [
+    (2, 64, 104, 128, 128, 3, 1, 1),   # 52 tiles on 8 workgroups: six or seven tile boundaries per workgroup
+    (3, 40, 52, 256, 384, 1, 1, 0),    # three column blocks (a workgroup keeps its own), 4 K steps
+    (2, 33, 47, 128, 200, 3, 2, 1),    # stride 2, the second column block overhangs Cout
+]
+
+
+@pytest.mark.parametrize('case', SHAPES_PT3)
+def test_pt3_forced(case):
+    x, w, y = _run_forced('conv_pt3_kernel', case)
+    np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
+
+
+def test_pt3_equals_one_tile_kernel_bitwise():
+    """Same K order, same f32 accumulation, same rounding: the persistent grid stores exactly what conv_glds3_kernel<pp>
+    stores (plain epilogue), whatever the number of workgroups that share the tiles."""
+    o = ops()
+    B, H, W, Cin, Cout = 2, 64, 104, 128, 256
+    x, w = cases.randn(171, B, Cin, H, W), cases.randn(172, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
+    xd, wd = nhwc(x), o.pack_weight(w.to(DEV), BF)
+    with o.tuning(**FORCE['conv_glds3_kernel<pp>']):
+        y0 = o.conv2d(xd, wd, 3, 3, 1, 1)
+        assert o.last_kernel() == 'conv_glds3_kernel<pp>'
+    for reserve in (0, 200, 250):
+        with o.tuning(**{**FORCE['conv_pt3_kernel'], 'comm.reserved_cus': reserve}):
+            y1 = o.conv2d(xd, wd, 3, 3, 1, 1)
+            assert o.last_kernel() == 'conv_pt3_kernel'
+        assert torch.equal(y0, y1), reserve
+
+
 @pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>'])
 @pytest.mark.parametrize('case', SHAPES3)
 def test_glds3_forced(kernel, case):
@@ -102,7 +136,7 @@ def test_glds4_forced(kernel, case):
     np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_pt3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_epilogues_forced(kernel):
     """scale / shift / residual / ReLU, then the BatchNorm statistics of the stored values (in slots)."""
     o = ops()
@@ -127,7 +161,7 @@ def test_tile_epilogues_forced(kernel):
     np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_pt3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_ragged_levels_forced(kernel):
     """The head's mode: four FPN levels in one launch, shared 3x3 weights (das_head.py:176-178)."""
     o = ops()
@@ -145,7 +179,7 @@ def test_tile_ragged_levels_forced(kernel):
         np.testing.assert_allclose(nchw(y.level(l)).numpy(), ref.numpy(), **TOL)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_pt3_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_dgrad_forced(kernel):
     """Data gradient of a stride-1 3x3 conv on the tile kernels (flipped weights), with a second gradient of the
     same tensor added in the epilogue."""

@@ -26,6 +26,8 @@ torch.cuda.synchronize()
 agg = {}
 for ent in ops.PROFILE:
     tag, fl, e0, e1, shape = ent[:5]
+    if shape and shape[0] == 'bn':
+        continue
     if shape[0] == 'batch':
         shape = (0, 0, 0, 0, 0, 0, 0, shape[1])
     a = agg.setdefault((tag, shape), [0.0, 0.0, 0])
@@ -38,8 +40,9 @@ for (tag, shape), (fl, sec, n) in agg.items():
     f[0] += fl; f[1] += sec
 for tag, (fl, sec) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print(f'  {sec / R * 1e3:8.3f} ms {fl / sec / 1e12:7.1f} TF  {tag}')
-for (tag, shape), (fl, sec, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
-    Bb, H, W, Cin, Cout, k, s, nl = shape
+for (tag, shape), (fl, sec, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:140]:
+    Bb, H, W, Cin, Cout, k, s, nl = shape[:8]
+    mode = shape[8] if len(shape) > 8 else ''
     # floors per launch: operands once through HBM at 6.3 TB/s; MFMA at 2.5 PF
     per = sec / n
     flop = fl / n
@@ -47,4 +50,4 @@ for (tag, shape), (fl, sec, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[
     hbm = (rows_out * (Cin if k == 1 and s == 1 else min(s * s, k * k) * Cin / (s * s) if False else Cin) + rows_out * Cout) * 2 / 6.3e12 if Cin else 0
     mf = flop / 2.5e15
     print(f'{sec / tot * 100:5.1f}% {sec / R * 1e3:7.3f}ms n={n // R:3d} {per * 1e6:7.1f}us (hbm {hbm * 1e6:6.1f} mfma {mf * 1e6:6.1f}) '
-          f'{fl / sec / 1e12:7.1f}TF {tag[5:30]:22s} HxW={H}x{W} Cin={Cin} Cout={Cout} k={k} s={s} lv={nl}')
+          f'{fl / sec / 1e12:7.1f}TF {tag[5:30]:22s} HxW={H}x{W} Cin={Cin} Cout={Cout} k={k} s={s} lv={nl} mode={mode}')
