@@ -38,13 +38,13 @@ FWD_GFLOP = {1: 227.0, 2: 326.9, 3: 426.8, 4: 526.7}
 TRAIN_GFLOP = {k: 3 * v for k, v in FWD_GFLOP.items()}
 
 
-def model_cfg(num_stages=1, dtype='bf16'):
+def model_cfg(num_stages=1, dtype='bf16', norm='BN'):
     return dict(
         type='DAS', pretrained=None,
         backbone=dict(type='MSPN2', unit_channels=256, num_stages=num_stages, num_units=4, num_blocks=[3, 4, 6, 3],
-                      norm_cfg=dict(type='BN'), compute_dtype=dtype),
+                      norm_cfg=dict(type=norm), compute_dtype=dtype),
         neck=dict(type='FPN', in_channels=[256] * 4, out_channels=256, start_level=1, add_extra_convs='on_output',
-                  num_outs=4, relu_before_extra_convs=True, norm_cfg=dict(type='BN')),
+                  num_outs=4, relu_before_extra_convs=True, norm_cfg=dict(type=norm)),
         bbox_head=dict(type='DASHead', num_classes=1, in_channels=256, feat_channels=256, stacked_convs=2,
                        strides=[8, 16, 32, 64], regress_ranges=((-1, 80), (80, 160), (160, 320), (320, 1e8)),
                        center_sample_radius=1.5, num_joints=J, depth_factor=20, z_norm=50, root_idx=2,
@@ -56,10 +56,10 @@ def model_cfg(num_stages=1, dtype='bf16'):
         test_cfg=dict(nms_across_levels=False, nms_pre=1000, nms_post=100, nms_thr=0.9, score_thr=0.07))
 
 
-def build_model(dev, seed=0, dtype='bf16', num_stages=1, train=False):
+def build_model(dev, seed=0, dtype='bf16', num_stages=1, train=False, norm='BN'):
     import das_amd
     torch.manual_seed(seed)
-    model = das_amd.build_model(model_cfg(num_stages, dtype))
+    model = das_amd.build_model(model_cfg(num_stages, dtype, norm))
     model.init_weights()
     # random-init heads predict ~zero offsets; give the sampling / regression convs some spread so that
     # the deformable and resampling kernels see non-trivial coordinates, as a trained net would
@@ -220,26 +220,127 @@ def cpu_baseline(workload, budget_s=30.0, full=False, threads=None):
                        f'{cores} threads (intra-op), 1 inter-op; host: {desc}; {proto}')
 
 
+def _tbytes(t):
+    """bytes of a tensor / Ragged / list of them (0 for anything else)"""
+    if t is None:
+        return 0
+    if hasattr(t, 'sizes') and hasattr(t, 'data'):
+        t = t.data
+    if isinstance(t, torch.Tensor):
+        return t.numel() * t.element_size()
+    if isinstance(t, (list, tuple)):
+        return sum(_tbytes(u) for u in t)
+    return 0
+
+
+# The families beside the convolutions and the BatchNorm passes (which das_amd.ops times itself): ops.<name> ->
+# (family, algorithmic bytes of a call from its arguments and result — every operand of every pass once).
+def _io(a, k, out):
+    return sum(_tbytes(t) for t in a) + sum(_tbytes(t) for t in k.values()) + _tbytes(out)
+
+
+OTHER_FAMILIES = {
+    # DCNv2 sampling (the GEMM half runs on the conv kernels): x, offsets / masks -> col; backward: dcol, x, offsets twice
+    # (the input-gradient gather and the offset-gradient kernel each read them) -> dx, d offsets
+    'deform_im2col3x3': ('dcnv2 sampling (im2col, col2im gather, offset gradient)', _io),
+    'deform_im2col3x3_backward': ('dcnv2 sampling (im2col, col2im gather, offset gradient)',
+                                  lambda a, k, out: 2 * _io(a, k, None) - _tbytes(a[2]) + _tbytes(out)),
+    # GroupNorm(32) + ReLU: statistics pass + apply pass (2R + 1W); backward reduce + apply (DESIGN section 2: 6R + 1W)
+    'groupnorm': ('groupnorm (stats + apply, backward reduce + apply)', lambda a, k, out: 3 * _tbytes(a[0])),
+    'groupnorm_backward': ('groupnorm (stats + apply, backward reduce + apply)', lambda a, k, out: 7 * _tbytes(a[2])),
+    'maxpool3x3s2': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'maxpool3x3s2_backward': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'upsample_bilinear_ac': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'upsample_bilinear_ac_backward': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'add_upsample_nearest': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'upsample_nearest_backward': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'add3': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'colsum': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'pack_image': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'to_nchw_f32': ('elementwise (pool, upsampling, skip adds, layout, bias sums)', _io),
+    'offset_sample': ('head elementwise (offset_sample, blend, assemble / finalize)', _io),
+    'offset_sample_backward': ('head elementwise (offset_sample, blend, assemble / finalize)', _io),
+    'sigmoid_blend': ('head elementwise (offset_sample, blend, assemble / finalize)', _io),
+    'sigmoid_blend_backward': ('head elementwise (offset_sample, blend, assemble / finalize)', _io),
+    'head_assemble': ('head elementwise (offset_sample, blend, assemble / finalize)', _io),
+    'head_assemble_backward': ('head elementwise (offset_sample, blend, assemble / finalize)', _io),
+    'head_finalize': ('head elementwise (offset_sample, blend, assemble / finalize)', _io),
+    'pack_conv_weights': ('optimizer (weight packing, clip norm, SGD)', lambda a, k, out: _tbytes(a[0]) + _tbytes(a[1]) + _tbytes(a[2])),
+}
+# C entry points without a tensor-level wrapper in ops (das_amd.train_ops calls them): timed at the ctypes boundary.
+# bytes: (index of the element-count argument, bytes per element) or None (latency-bound kernels over ~10^4 rows).
+OTHER_C = {
+    'das_grad_sumsq': ('optimizer (weight packing, clip norm, SGD)', (1, 4)),
+    'das_sgd_momentum_step': ('optimizer (weight packing, clip norm, SGD)', (3, 20)),      # p, g, m read; p, m written
+    'das_assign_targets': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+    'das_sigmoid_focal_loss': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+    'das_smooth_l1_loss': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+    'das_bce_logits_loss': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+    'das_realnvp_log_prob_multi': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+    'das_realnvp_log_prob_multi_backward': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+    'das_rle_prepare': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+    'das_rle_loss': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+    'das_rle_backward': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+}
+
+
+def instrument_other_families(ops):
+    """HIP events (launch stream) around every call of the op wrappers / C entry points above while ops.PROFILE is a list;
+    entries use the layout of das_amd.ops._timed. Idempotent."""
+    if getattr(ops, '_bench_instrumented', False):
+        return
+    ops._bench_instrumented = True
+    from das_amd import _lib
+
+    def timed(fn, family, nbytes):
+        def call(*a, **k):
+            if ops.PROFILE is None:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            ops.PROFILE.append((family, 0.0, e0, e1, ('other',), 1, float(nbytes(a, k, out)), 1))
+            return out
+        return call
+    for name, (family, nb) in OTHER_FAMILIES.items():
+        setattr(ops, name, timed(getattr(ops, name), family, nb))
+    lib = _lib.load()
+    for name, (family, spec) in OTHER_C.items():
+        nb = (lambda a, k, out, spec=spec: (int(getattr(a[spec[0]], 'value', a[spec[0]])) * spec[1]) if spec else 0.0)
+        setattr(lib, name, timed(getattr(lib, name), family, nb))
+
+
 def roofline_from_profile(ops, run_step, dtype, reps=2):
     """HIP events around every launch of the conv families (forward, data gradient, the two weight-gradient kernel
-    classes) and of the BatchNorm passes, on the launch stream. Returns (roofline, roofline_mfma, roofline_hbm,
-    roofline_bn):
-      roofline       the family with the LARGEST TIME in the step (selection rule stated in the object), priced against
-                     the roof its own launch mix sits under: FLOP per algorithmic byte above the ridge
-                     (peak FLOP/s / peak B/s = 312 for bf16) -> dense MFMA peak, below -> HBM peak;
+    classes), of the BatchNorm passes and of every other HIP op of the step (OTHER_FAMILIES / OTHER_C), on the launch
+    stream. Returns (roofline, roofline_mfma, roofline_hbm, roofline_bn, priced):
+      roofline       the family with the LARGEST TIME in the step (selection rule stated in the object; BatchNorm counts
+                     per pass type there, roofline_bn has the passes together), priced against the roof its own launch
+                     mix sits under: FLOP per algorithmic byte above the ridge (peak FLOP/s / peak B/s = 312 for bf16)
+                     -> dense MFMA peak, below -> HBM peak;
       roofline_mfma  the family that carries the most algorithmic FLOPs among those above the ridge;
       roofline_hbm   the conv family with the largest time among those below the ridge;
-      roofline_bn    the BatchNorm passes together (apply, backward apply, backward reduce + apply), HBM-bound."""
+      roofline_bn    the BatchNorm passes together (apply, backward apply, backward reduce + apply), HBM-bound;
+      priced         every millisecond of the measured step: ms per family (conv families, BatchNorm, DCNv2 sampling,
+                     GroupNorm, elementwise, head elementwise, losses, optimizer) + `torch glue + launch gaps` = the
+                     step's wall time in the same pass minus the families' sum."""
     # Kernel quality is measured with the kernels running one at a time: the weight gradients' side stream (which
     # overlaps them with the main stream in the timed region) is switched off for these passes, otherwise a launch's
     # event-to-event time would include whatever ran beside it.
     from das_amd import autograd as ag
+    instrument_other_families(ops)
     side_was, ag.WGRAD_SIDE_STREAM = ag.WGRAD_SIDE_STREAM, False
     run_step()          # (untimed: the first step of this stream layout allocates its workspaces)
     ops.PROFILE = []
+    torch.cuda.synchronize()
+    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w0.record()
     for _ in range(reps):
         run_step()
+    w1.record()
     torch.cuda.synchronize()
+    wall_ms = w0.elapsed_time(w1) / reps
     ag.WGRAD_SIDE_STREAM = side_was
     fam = {}
     for ent in ops.PROFILE:
@@ -252,7 +353,7 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
         f[4] += ent[7] if len(ent) > 7 else 1     # kernel launches
     ops.PROFILE = None
     if not fam:
-        return None, None, None, None
+        return None, None, None, None, None
     peak = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
     ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)    # FLOP per byte above which a launch mix is matrix-core bound
 
@@ -267,10 +368,14 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
                     family_ms_per_step=round(sec / reps * 1e3, 3), algorithmic_mb_per_launch=round(by / max(nl, 1) / 1e6, 2),
                     flop_per_byte=round(fl / max(by, 1.0), 1), ridge_flop_per_byte=round(ridge, 1),
                     tflops=round(fl / sec / 1e12, 2), gbs=round(by / sec / 1e9, 1))
+    other_names = {f for f, _ in OTHER_FAMILIES.values()} | {f for f, _ in OTHER_C.values()}
     conv = {k: v for k, v in fam.items() if v[0] > 0}
-    bn = {k: v for k, v in fam.items() if v[0] == 0}
-    tag, v = max(fam.items(), key=lambda kv: kv[1][1])
-    roof = entry(tag, v, 'largest time per step among the conv families and the BatchNorm passes')
+    bn = {k: v for k, v in fam.items() if v[0] == 0 and k not in other_names}
+    ranked = {k: v for k, v in fam.items() if k not in other_names}
+    tag, v = max(ranked.items(), key=lambda kv: kv[1][1])
+    roof = entry(tag, v, 'largest time per step among the conv families and the BatchNorm passes; BatchNorm is ranked '
+                 'per pass type here (forward apply / backward apply / backward reduce + apply) — together the passes are '
+                 'roofline_bn, which may exceed this family')
     roof['all_families'] = {k: dict(tflops=round(x[0] / x[1] / 1e12, 2), gbs=round(x[3] / x[1] / 1e9, 1),
                                     flop_per_byte=round(x[0] / max(x[3], 1.0), 1), ms_per_step=round(x[1] / reps * 1e3, 3),
                                     launches=x[4] // reps, ops=x[2] // reps) for k, x in fam.items()}
@@ -287,7 +392,20 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
         tot = [sum(x[i] for x in bn.values()) for i in range(5)]
         roof_bn = entry(' + '.join(sorted(bn)), tot, 'all BatchNorm passes of the step (forward apply, backward apply, '
                         'backward reduce + apply); algorithmic bytes = every operand of every pass once')
-    return roof, roof_mfma, roof_hbm, roof_bn
+    # every millisecond of the step: families + the rest (ATen glue launches, launch gaps, event overhead of this pass)
+    fam_ms = {k: x[1] / reps * 1e3 for k, x in fam.items()}
+    at_roof = 0.0
+    for k, x in fam.items():
+        at_roof += max(x[0] / (peak * 1e12), x[3] / (PEAK_HBM_GBS * 1e9)) / reps * 1e3
+    priced = dict(step_ms_this_pass=round(wall_ms, 3),
+                  note='weight gradients on the main stream, HIP events around every launch: this pass runs a few % slower '
+                       'than the timed region; every family at max(FLOPs / MFMA peak, algorithmic bytes / HBM peak) '
+                       'gives families_ms_at_roof',
+                  families_ms={k: round(v, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])},
+                  families_ms_sum=round(sum(fam_ms.values()), 3), families_ms_at_roof=round(at_roof, 3),
+                  fraction_of_roof=round(at_roof / max(sum(fam_ms.values()), 1e-9), 4),
+                  torch_glue_and_gaps_ms=round(wall_ms - sum(fam_ms.values()), 3))
+    return roof, roof_mfma, roof_hbm, roof_bn, priced
 
 
 def attach_traffic(roof, workload, batch):
@@ -314,16 +432,16 @@ def attach_traffic(roof, workload, batch):
         roof['traffic_over_algorithmic'] = entry['hbm_over_algorithmic']
 
 
-def decode_workload(args, rank, world, dev):
+def decode_workload(args, rank, world, dev, quiet=False, batch=None, steps=None, warmup=None, cpu_leg=True):
     """BASELINE configs[4]: exp_mupots geometry (1024x768 input, J=21, strides 8..64 -> 16 320 locations per
     image), decode only: score / threshold / per-level top-k / OKS-NMS of `batch` images per step (one workgroup
     per image). Synthetic eval-mode head outputs, calibrated to ~150 candidates per image above score_thr."""
     import torch.distributed as dist
     from das_amd import ops
     Jm, HW = 21, [(96, 128), (48, 64), (24, 32), (12, 16)]
-    B = args.batch or 512
-    steps = args.steps or 20
-    warmup = args.warmup if args.warmup is not None else 3
+    B = batch or args.batch or 512
+    steps = steps or args.steps or 20
+    warmup = warmup if warmup is not None else (args.warmup if args.warmup is not None else 3)
     g = torch.Generator(device='cpu').manual_seed(100 + rank)
     cls, ctr, pose = [], [], []
     for h, w in HW:
@@ -412,7 +530,7 @@ def decode_workload(args, rank, world, dev):
                      'note': 'one 1024-thread workgroup per image: a sort / NMS latency chain, not a streaming kernel; '
                              'bytes = 2 logits per location + the gathered candidates + the kept poses'},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and cpu_leg:
         from oracle import decode as OD
         n, t0 = 0, time.perf_counter()
         while n < 4 or (time.perf_counter() - t0 < 10.0 and n < 64):
@@ -425,7 +543,53 @@ def decode_workload(args, rank, world, dev):
             n += 1
         line['cpu_baseline'] = dict(value=round(n / (time.perf_counter() - t0), 2), unit='img/s', cores=1, kind='port',
                                     sample=f'{n} images, CPU oracle decode + OKS-NMS (numpy / python), 1 thread')
+    if quiet:
+        return line
     print(json.dumps(line), flush=True)
+    return line
+
+
+def also_workloads(args, dev, model, opt, data):
+    """The two other workloads of BASELINE.json, measured in this process after the train loop (about a second of GPU
+    time each) so that the driver's one JSON line carries them too: `infer` = configs[1] (1-stage, B = 8, forward +
+    decode, 10 timed steps after 3), `decode` = configs[4] geometry (512 images per step, 10 timed steps after 3). Same
+    code paths as `--workload infer` / `--workload decode` (the train model stays resident: 35 of 288 GB)."""
+    import gc
+    out = {}
+    try:
+        gc.collect()
+        from das_amd.datasets import SyntheticPoseDataset, collate
+        m1 = build_model(dev, seed=0, dtype=args.dtype, num_stages=1, train=False)
+        ds = SyntheticPoseDataset(num_joints=J, img_shape=(H, W), length=8, seed=0)
+        d8 = collate([ds[i] for i in range(8)], device=dev)
+        calibrate_scores(m1, d8['img'], d8['img_metas'])
+        for _ in range(3):
+            res = m1(d8['img'], d8['img_metas'], return_loss=False, rescale=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            res = m1(d8['img'], d8['img_metas'], return_loss=False, rescale=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out['infer'] = dict(metric='imgs/sec forward+decode', value=round(8 * n / dt, 1), unit='img/s',
+                            ms_per_step=round(dt / n * 1e3, 3), steps=n, warmup=3, dtype=args.dtype,
+                            model_tflops=round(8 * n * FWD_GFLOP[1] / dt / 1e3, 1),
+                            poses_per_step=sum(len(r['scores']) for r in res),
+                            workload='BASELINE configs[1]: MSPN-50 1-stage + FPN + DASHead J=15, batch 8 x 3x512x832, '
+                                     'forward + decode')
+        del m1, d8, res
+        torch.cuda.empty_cache()
+        line = decode_workload(args, 0, 1, dev, quiet=True, batch=512, steps=10, warmup=3, cpu_leg=False)
+        if line:
+            out['decode'] = dict(metric=line['metric'], value=line['value'], unit=line['unit'], ms_per_step=line['ms_per_step'],
+                                 steps=10, warmup=3, poses_per_sec=line['poses_per_sec'],
+                                 us_per_img=line['roofline']['us_per_img'],
+                                 us_per_img_at_batch_8=line['roofline']['us_per_img_at_batch_8'],
+                                 workload=line['config']['workload'])
+    except Exception as e:   # the train line must not be lost to a failure here
+        out['error'] = f'{type(e).__name__}: {e}'
+    return out
 
 
 def self_launch(n):
@@ -483,6 +647,11 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=None, help='override the CPU leg\'s thread count')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='run only the CPU leg and print it')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--norm', default='BN', choices=['BN', 'SyncBN'],
+                    help='norm_cfg type of backbone and neck: SyncBN is what the reference ships (exp_panoptic.py:20,28); '
+                         'with one rank it is plain BatchNorm arithmetic')
+    ap.add_argument('--no-also', action='store_true',
+                    help='skip the short infer / decode measurements appended to the train line (`also`)')
     ap.add_argument('--graph-side-stream', action='store_true', help='A/B: capture the weight gradients on their side streams')
     ap.add_argument('--graphs', action='store_true',
                     help='replay the backbone + neck forward / backward as two hipGraphs (train, 1 GPU; das_amd/graphs.py): '
@@ -529,6 +698,11 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    comm = None
+    if world > 1:   # ranks the transport really spans: an all-reduce of ones
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        comm = dict(backend=dist.get_backend(), ranks=int(one.item()), world_size=dist.get_world_size())
 
     if args.workload == 'decode':
         decode_workload(args, rank, world, dev)
@@ -553,7 +727,7 @@ def main():
     if args.no_early_targets:
         from das_amd import detectors
         detectors.EARLY_TARGETS = False
-    model = build_model(dev, seed=0, dtype=args.dtype, num_stages=stages, train=train)
+    model = build_model(dev, seed=0, dtype=args.dtype, num_stages=stages, train=train, norm=args.norm)
     ds = SyntheticPoseDataset(num_joints=J, img_shape=(H, W), length=batch * world, seed=0)
     data = collate([ds[rank * batch + i] for i in range(batch)], device=dev)
     metas = data['img_metas']
@@ -618,10 +792,14 @@ def main():
     else:
         extra['poses_per_step_rank0'] = sum(len(r['scores']) for r in res)
 
-    roof, roof_mfma, roof_hbm, roof_bn = roofline_from_profile(ops, step, args.dtype)
+    roof, roof_mfma, roof_hbm, roof_bn, priced = roofline_from_profile(ops, step, args.dtype)
     for r in (roof, roof_mfma, roof_hbm, roof_bn):
         if r is not None:
             attach_traffic(r, 'train' if train else 'infer', batch)
+
+    also = None
+    if train and world == 1 and not args.no_also:
+        also = also_workloads(args, dev, model, opt, data)
 
     if rank == 0:
         total_imgs = batch * world * steps
@@ -640,10 +818,14 @@ def main():
             'model_tflops': round(total_imgs * gflop / dt / 1e3, 2),
             'roofline': roof,
         }
-        for key, r in (('roofline_mfma', roof_mfma), ('roofline_hbm', roof_hbm), ('roofline_bn', roof_bn)):
+        for key, r in (('roofline_mfma', roof_mfma), ('roofline_hbm', roof_hbm), ('roofline_bn', roof_bn), ('priced_step', priced)):
             if r is not None:
                 out[key] = r
         out.update(extra)
+        if comm is not None:
+            out['comm'] = comm      # (backend 'nccl' = RCCL on ROCm; ranks = what an all-reduce of ones returned)
+        if also is not None:
+            out['also'] = also
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload, full=args.cpu_baseline_full, threads=args.cpu_threads)
         print(json.dumps(out), flush=True)

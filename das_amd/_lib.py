@@ -78,6 +78,7 @@ SIGNATURES = {
     'das_tuning_set': (i32, [C.c_char_p, i64]),
     'das_tuning_get': (i32, [C.c_char_p, C.POINTER(i64)]),
     'das_tuning_reset': (i32, []),
+    'das_dev_occupy_cus': (i32, [i32, i32, i32, i32, vp]),
     'das_last_kernel': (C.c_char_p, []),
     'das_img_resize_bilinear': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_img_resize_bilinear_u8': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -47,7 +47,7 @@ def set_wgrad_streams(n):
     from . import _lib
     lib = _lib.load()
     WGRAD_STREAMS = max(1, int(n))
-    _lib.check(lib.das_tuning_set(b'wgrad.pp_blocks', 256 // WGRAD_STREAMS), 'das_tuning_set')
+    _lib.check(lib.das_tuning_set(b'wgrad.pp_blocks', 0 if WGRAD_STREAMS == 1 else 256 // WGRAD_STREAMS), 'das_tuning_set')
     _lib.check(lib.das_tuning_set(b'wgrad.blocks', 0 if WGRAD_STREAMS == 1 else 768 // WGRAD_STREAMS), 'das_tuning_set')
     _side.clear()
 
@@ -157,6 +157,7 @@ def reset_step_state():
     step's gradient, and with the flags set no later backward would flush or join again."""
     _pending.clear()
     _flush_queued[0] = False
+    _rows_checked[0] = False
     for dev_index, ent in _side.items():
         if ent[2]:
             cur = torch.cuda.current_stream(dev_index)
@@ -212,6 +213,27 @@ def _all_reduce(t):
     dist.all_reduce(t)
 
 
+# SyncBN normalises with `rows x world` as the statistics' count, i.e. it assumes every rank holds the same number of
+# pixel rows (torch's SyncBatchNorm all-gathers the counts instead). The DAS pipelines pad every batch to one size, so
+# that holds; it is CHECKED once per optimisation step — at the step's first SyncBN layer, one 2-element all-reduce —
+# rather than assumed: ranks with different padded shapes (mixed-aspect data, a short last batch) raise instead of
+# silently normalising with the wrong count.
+_rows_checked = [False]
+
+
+def _check_equal_rows(rows):
+    if _rows_checked[0]:
+        return
+    _rows_checked[0] = True
+    import torch.distributed as dist
+    t = torch.tensor([float(rows), -float(rows)], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    hi, lo = t.tolist()
+    if hi != -lo:
+        raise RuntimeError(f'SyncBN: ranks hold different numbers of pixel rows (between {int(-lo)} and {int(hi)}; this rank '
+                           f'{rows}): pad the batches of all ranks to one size (Pad(size=...)) or use norm_cfg type BN')
+
+
 def _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual):
     """conv (BatchNorm statistics in its epilogue) -> finalize + apply (+ residual, + ReLU). Returns
     y, raw, mean, invstd, world (number of ranks the statistics span)."""
@@ -224,6 +246,7 @@ def _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual):
     world = _sync_world(bn)
     stat_count = 0
     if world > 1:   # SyncBN: the statistics are those of all ranks' pixels
+        _check_equal_rows(raw.numel() // raw.shape[-1])
         stats = sync_stats(stats, w.shape[0], _all_reduce)
         stat_count = (raw.numel() // raw.shape[-1]) * world
     y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,

@@ -867,22 +867,8 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
 #include "conv_persist.h"
 
 // =============================================================== launch
-inline int device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    cus = n > 0 ? n : 256;
-  }
-  return cus;
-}
-// CUs a persistent one-workgroup-per-CU grid may count on: the device's, minus comm.reserved_cus (left to the RCCL
-// kernels of an overlapped gradient all-reduce; 0 on one GPU).
-inline int usable_cus() {
-  const long long r = dastune::get(dastune::COMM_RESERVED_CUS);
-  const int c = device_cus();
-  return (int)std::max<long long>(8, c - std::max<long long>(0, r));
-}
+using dastune::device_cus;
+using dastune::usable_cus;
 // conv_pt3_kernel (conv_persist.h): the 256 x 128 tile kernel as a persistent grid, for launches of more tiles than CUs.
 template <typename OT>
 bool try_launch_pt3(const ConvP& p0, int rows, hipStream_t s) {
@@ -1404,8 +1390,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
       per_cu = n;
     }
     const int cap = (int)dastune::get(dastune::CONV_STREAM_PERCU);
-    int dev_id = 0, cus = 256;
-    if (hipGetDevice(&dev_id) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
+    const int cus = usable_cus();
     long long grid = (long long)(per_cu > cap && cap > 0 ? cap : per_cu) * cus;
     grid = std::min<long long>(grid, (long long)ntiles * ncol);
     grid = std::max<long long>(ncol, grid / ncol * ncol);
@@ -1522,7 +1507,7 @@ bool try_launch_c64(const ConvP& p, hipStream_t s) {
       return false;
     attr_set = true;
   }
-  const int grid = std::min(ntiles, device_cus());
+  const int grid = std::min(ntiles, usable_cus());
   dastune::note_kernel("conv3x3_c64_kernel");
   hipLaunchKernelGGL((conv3x3_c64_kernel<OT>), dim3(grid), dim3(384), sm, s, p, ntiles);
   return true;

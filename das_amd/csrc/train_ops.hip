@@ -1332,11 +1332,13 @@ int wgrad_launch_class(HostWgrad** ops, int n, int cls, int accumulate, hipStrea
   const int bkm = cls == 1 && dastune::get(dastune::WGRAD_BKM) == 64 ? 64 : 32;
   // grid = ONE resident wave of workgroups (ping-pong: 1 per CU; bf16 128 x 128: 3 per CU; f32: 2 per CU)
   long long grid;
+  const long long ucus = dastune::usable_cus();   // (the device's CUs minus comm.reserved_cus)
   if (cls == 0) {
-    grid = std::max<long long>(1, dastune::get(dastune::WGRAD_PP_BLOCKS));
+    const long long forced = dastune::get(dastune::WGRAD_PP_BLOCKS);
+    grid = forced > 0 ? forced : ucus;
   } else {
     const long long forced = dastune::get(dastune::WGRAD_BLOCKS);
-    grid = forced > 0 ? forced : (cls == 1 && bkm == 32 ? 768 : 512);
+    grid = forced > 0 ? forced : (cls == 1 && bkm == 32 ? 3 : 2) * ucus;
   }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return DAS_ERR_LAUNCH;
@@ -1457,9 +1459,7 @@ extern "C" int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* 
     if (ops[i].cls != 3) continue;
     const WgradOpS& o = ops[i].o;
     const int ntiles = ((o.H + 15) / 16) * ((o.W + 15) / 16) * o.B;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int grid = std::min(ntiles, cus);
+    const int grid = std::min(ntiles, dastune::usable_cus());
     float* ws = wgrad_workspace(s, (size_t)grid * 36864 * sizeof(float));
     if (!ws) return DAS_ERR_LAUNCH;
     const size_t sm = 2 * (size_t)(WC64_DY + WC64_PATCH);

@@ -25,9 +25,9 @@ enum Key {
   CONV_SPLITK_KERNELS,   // bit mask of the kernels that may split: 1 conv_glds_kernel, 2 conv_glds3_kernel, 4 conv_glds4_kernel
   WGRAD_PP_MINK,         // conv_wgrad_pp_kernel for K >= this (and Cout >= 256); 0 disables the kernel
   WGRAD_BKM,             // pixel rows per step of conv_wgrad_kernel<bf16>: 32 or 64
-  WGRAD_BLOCKS,          // target grid of conv_wgrad_kernel; 0 = by shape (768 / 1024: one resident wave of workgroups)
-  WGRAD_PP_BLOCKS,       // target grid of conv_wgrad_pp_kernel (256 = one workgroup per CU); lower it when several
-                         // weight gradients run side by side on different streams
+  WGRAD_BLOCKS,          // target grid of conv_wgrad_kernel; 0 = one resident wave of workgroups (3 or 2 per usable CU)
+  WGRAD_PP_BLOCKS,       // target grid of conv_wgrad_pp_kernel; 0 = one workgroup per usable CU (device CUs minus
+                         // comm.reserved_cus); lower it when several weight gradients run side by side on different streams
   BN_REDUCE_BLOCKS,      // grid / block size of bn_bwd_reduce_kernel
   BN_REDUCE_THREADS,
   BN_VPT,                // 16-byte vectors per thread of the BatchNorm apply passes
@@ -45,6 +45,10 @@ enum Key {
 };
 
 long long get(Key k);
+// CUs of the current device (cached), and the CUs a persistent one-workgroup-per-CU (or n-per-CU) grid may count on:
+// the device's minus comm.reserved_cus (left to the RCCL kernels of an overlapped gradient all-reduce), at least 8.
+int device_cus();
+int usable_cus();
 // `name` must be a string literal (kept by pointer): the kernel the calling thread's last launcher call picked
 void note_kernel(const char* name);
 

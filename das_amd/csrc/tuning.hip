@@ -6,6 +6,8 @@
 
 #include "das_hip.h"
 
+#include <hip/hip_runtime.h>
+
 namespace dastune {
 namespace {
 struct Entry {
@@ -18,7 +20,7 @@ constexpr Entry kTable[N_KEYS] = {
     {"conv.glds4_minblocks", 128}, {"conv.glds4_pp", -1},      {"conv.glds4_mf", 0},
     {"conv.stream_minrows", 16384}, {"conv.stream_percu", 2}, {"conv.tail_split", 1},        {"conv.splitk_target", 256},
     {"conv.splitk_minsteps", 12}, {"conv.splitk_kernels", 3},  {"wgrad.pp_mink", 256},
-    {"wgrad.bkm", 32},            {"wgrad.blocks", 0},        {"wgrad.pp_blocks", 256},      {"bn.reduce_blocks", 256},     {"bn.reduce_threads", 256},
+    {"wgrad.bkm", 32},            {"wgrad.blocks", 0},        {"wgrad.pp_blocks", 0},      {"bn.reduce_blocks", 256},     {"bn.reduce_threads", 256},
     {"bn.vpt", 8},                {"gn.ppb", 256},             {"conv.c64_mintiles", 64},    {"bn.stream_minbytes", 96 << 20},
     {"conv.pt3_mintiles", 0},   {"comm.reserved_cus", 0},
 };
@@ -37,6 +39,23 @@ long long get(Key k) {
   return g_val[k].load(std::memory_order_relaxed);
 }
 void note_kernel(const char* name) { t_last = name; }
+int device_cus() {
+  static std::atomic<int> cus{0};
+  int c = cus.load(std::memory_order_relaxed);
+  if (c == 0) {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    c = n > 0 ? n : 256;
+    cus.store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+int usable_cus() {
+  const long long r = get(COMM_RESERVED_CUS);
+  const int c = device_cus();
+  const long long u = c - (r > 0 ? r : 0);
+  return (int)(u < 8 ? 8 : u);
+}
 }  // namespace dastune
 
 using namespace dastune;

@@ -17,10 +17,16 @@ What makes the capture legal:
     statistics arena is a private one whose memset is the graph's first node, the weight gradients' side stream is
     off (everything on the capture stream);
   * gradients of the trunk's parameters are added into the optimizer's flat gradient buffer by the captured kernels
-    themselves (fixed addresses); the Python completion hooks that drive the overlapped all-reduce do not run at
-    replay, so graphs are a single-process feature (world size 1) — with several ranks the eager path overlaps the
-    gradient all-reduce with backward instead.
-The warm-up's side effects (BatchNorm running statistics, gradients) are undone after the capture."""
+    themselves (fixed addresses). The Python completion hooks that drive the overlapped all-reduce do not run at
+    replay; with several ranks `_Replay.backward` reports the trunk's parameters complete right after it has queued
+    the backward graph (`FlatSGD.mark_complete`), so the head's buckets (complete before the trunk's backward starts)
+    go out while the graph runs and the trunk's buckets right behind it, in the same fixed order on every rank. What
+    the graph gives up is the overlap of the TRUNK's buckets with the trunk's own backward (~0.5 GB of gradients:
+    a few ms on xGMI); a backward captured in bucket-aligned segments would keep it (not built: the four MSPN stages
+    exchange three skip tensors per level). SyncBN layers all-reduce inside the trunk: a trunk that contains one is
+    not captured with several ranks (the collective would have to be part of the graph).
+The warm-up's side effects (BatchNorm running statistics, gradients) are undone after the capture — also when the
+capture is refused (the model is left exactly as it was)."""
 import torch
 
 from . import autograd as ag
@@ -53,6 +59,7 @@ class _Replay(torch.autograd.Function):
             else:
                 dst.copy_(g)
         trunk.bwd.replay()
+        trunk.opt.mark_complete(trunk.slots)     # (several ranks: the trunk's gradient buckets may go out now)
         return None, None, None
 
 
@@ -65,13 +72,15 @@ class GraphedTrunk:
         assert model.training and img.is_cuda
         world = torch.distributed.get_world_size() if torch.distributed.is_available() and \
             torch.distributed.is_initialized() else 1
-        if world != 1:
-            raise RuntimeError('GraphedTrunk: the captured backward cannot drive the overlapped gradient all-reduce; '
-                               'use the eager path with several ranks')
+        if world != 1 and any(getattr(m, '_das_sync', False) for t in (model.backbone, model.neck) if t is not None
+                              for m in t.modules()):
+            raise RuntimeError('GraphedTrunk: the trunk holds SyncBN layers, whose statistics all-reduce cannot be part of '
+                               'the captured graph; use the eager path (or norm_cfg type BN) with several ranks')
         self.model, self.opt = model, optimizer
         self.shape, self.dtype = tuple(img.shape), img.dtype
         dev = img.device
         params = [p for m in (model.backbone, model.neck) if m is not None for p in m.parameters() if p.requires_grad]
+        self.slots = [p._das_slot for p in params if getattr(p, '_das_slot', None) is not None]
         # state the warm-up iterations would leave behind
         buffers = [b for m in (model.backbone, model.neck) if m is not None for b in m.buffers()]
         keep_buf = [b.detach().clone() for b in buffers]
@@ -79,6 +88,8 @@ class GraphedTrunk:
         side_was = ag.WGRAD_SIDE_STREAM
         if not CAPTURE_SIDE_STREAM:
             ag.WGRAD_SIDE_STREAM = False
+        overlap_was, optimizer.overlap = optimizer.overlap, False   # (no collective from the warm-up / capture passes)
+        ok = False
         arena_was = dnn._STATS_ARENA
         self.arena = dnn._ZeroArena()
         self.x = img.detach().clone()
@@ -114,17 +125,26 @@ class GraphedTrunk:
             with torch.cuda.graph(self.bwd, pool=self.fwd.pool(), stream=self.stream):
                 self.arena.reset()
                 self._backward(self.outs, self.gouts, params)
+            ok = True
+            self._epoch_dtypes = [dt for dt, ep in optimizer._packed_epoch.items() if ep == dnn.PARAM_EPOCH[0]]
         finally:
             ag.WGRAD_SIDE_STREAM = side_was
             dnn._STATS_ARENA = arena_was
-        self._epoch_dtypes = [dt for dt, ep in optimizer._packed_epoch.items() if ep == dnn.PARAM_EPOCH[0]]
-        with torch.no_grad():
-            for b, k in zip(buffers, keep_buf):
-                b.copy_(k)
-            optimizer.flat_g.copy_(keep_g)
+            optimizer.overlap = overlap_was
+            if not ok:      # a refused capture may leave the capture stream invalidated: drain the device, drop the stream
+                try:
+                    torch.cuda.synchronize(dev)
+                except RuntimeError:
+                    pass
+                self.stream = None
+            # the warm-up iterations (and a capture that raised half-way) must leave no trace in the model
+            with torch.no_grad():
+                for b, k in zip(buffers, keep_buf):
+                    b.copy_(k)
+                optimizer.flat_g.copy_(keep_g)
+            dnn.bump_param_epoch()               # caches filled so far describe warm-up / graph memory: not for eager use
         for p in params:     # (the capture ran no kernel: nothing was accumulated, but autograd may have created .grad)
             assert p.grad is not None
-        dnn.bump_param_epoch()                   # caches filled during the capture describe graph memory: not for eager use
         torch.cuda.synchronize(dev)
 
     @staticmethod
@@ -156,11 +176,8 @@ class GraphedTrunk:
 
 def enable_trunk_graphs(model, optimizer, example_img):
     """Capture the trunk for batches shaped like `example_img`; the detector's training forward uses it from now on.
-    Returns the GraphedTrunk (None when capture is not applicable: several ranks)."""
-    world = torch.distributed.get_world_size() if torch.distributed.is_available() and \
-        torch.distributed.is_initialized() else 1
-    if world != 1:
-        return None
+    Returns the GraphedTrunk. With several ranks every rank must capture (same model, same shapes); raises when the
+    trunk holds SyncBN layers."""
     trunk = GraphedTrunk(model, optimizer, example_img)
     model._graphed_trunk = trunk
     return trunk

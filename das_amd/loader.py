@@ -175,17 +175,62 @@ class _FrameRing:
         self.registered = False
 
     @classmethod
-    def create(cls, slots, slot_bytes, pin):
+    def create(cls, slots, slot_bytes, pin, min_slots=8):
+        """A ring file of `slots` x `slot_bytes` in /dev/shm (RAM-backed; page-locking it later allocates every page).
+        The capacity is checked first: on a small /dev/shm (64 MiB in a default container) the ring shrinks to what
+        fits — keeping a quarter of the free space for others — down to `min_slots`; below that the file goes to the
+        ordinary temp directory (the page cache: uploads are then staged copies, slower but correct). Never a SIGBUS in a
+        worker on its first frame write."""
         import tempfile
+        import warnings
         where = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None
+        if where is not None:
+            try:
+                st = os.statvfs(where)
+                free = st.f_bavail * st.f_frsize
+            except OSError:
+                free = 0
+            fit = int(free * 3 // 4 // slot_bytes)
+            if fit < slots:
+                if fit >= min_slots:
+                    warnings.warn(f'das_amd.loader: /dev/shm has {free >> 20} MiB free, frame ring shrunk from {slots} to {fit} '
+                                  f'slots of {slot_bytes >> 20} MiB (fewer frames in flight per worker)')
+                    slots = fit
+                else:
+                    warnings.warn(f'das_amd.loader: /dev/shm has {free >> 20} MiB free, too little for a frame ring of even '
+                                  f'{min_slots} x {slot_bytes >> 20} MiB: the ring lives in {tempfile.gettempdir()} instead')
+                    where, slots = None, max(min_slots, min(slots, 16))
         fd, path = tempfile.mkstemp(prefix='das_frames_', dir=where)
-        os.ftruncate(fd, slots * slot_bytes)
+        try:
+            os.posix_fallocate(fd, 0, slots * slot_bytes)    # (fails here, with ENOSPC, instead of a SIGBUS at first touch)
+        except OSError:
+            os.close(fd)
+            os.unlink(path)
+            raise
         os.close(fd)
         ring = cls(path, slots, slot_bytes, True)
         if pin:
-            t = torch.from_numpy(ring.bytes)
-            ring.registered = int(torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel(), 0)) == 0
+            ring.pin()
         return ring
+
+    def pin(self):
+        """Page-lock the ring for asynchronous uploads (needs a GPU context: called when the loader is bound to its device)."""
+        if not self.registered:
+            t = torch.from_numpy(self.bytes)
+            self.registered = int(torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel(), 0)) == 0
+            if not self.registered:
+                import warnings
+                warnings.warn('das_amd.loader: could not page-lock the frame ring; uploads fall back to staged copies')
+        return self.registered
+
+    def unlink(self):
+        """Remove the backing file's name (both sides keep their mappings): it can no longer outlive the processes."""
+        if self.owner and self.path is not None:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+            self.path = None
 
     def slot(self, i, nbytes):
         return self.bytes[i * self.slot_bytes:i * self.slot_bytes + nbytes]
@@ -205,11 +250,7 @@ class _FrameRing:
             pass
         self._mm = None
         os.close(self._fd)
-        if self.owner:
-            try:
-                os.unlink(self.path)
-            except OSError:
-                pass
+        self.unlink()
 
 
 def _process_worker(wid, dataset_cfg, seed, max_redraws, ring_spec, task_q, free_q, result_q):
@@ -281,24 +322,25 @@ class ProcessLoader:
     """`workers` CPU-only processes preparing batches of `build_dataset(dataset_cfg)`; `batches(list of index lists)`
     yields the collated batches on GPU `device`, in order, each prepared one step ahead. The pool lives until `close()`
     (start-up costs a second or two per worker: interpreter, imports), so one loader serves every epoch.
-    `max_frame_bytes` x `ring_slots` of shared, page-locked host memory per worker hold the decoded frames in flight."""
+    `max_frame_bytes` x `ring_slots` of shared, page-locked host memory per worker hold the decoded frames in flight
+    (shrunk when /dev/shm is small: `_FrameRing.create`).
+    `device=None`: start the worker processes NOW and touch no GPU — a trainer creates the loader before its first GPU
+    call (starting processes out of a GPU-initialised parent is the one process-creation pattern to avoid on some
+    hosts) and calls `bind(device)` once the model is on the device; with a device given, both happen here."""
 
     def __init__(self, dataset_cfg, device='cuda', workers=4, depth=2, seed=0, max_redraws=100, start_timeout=300,
                  max_frame_bytes=8 << 20, ring_slots=48):
         import torch.multiprocessing as mp
-        self.device = torch.device(device)
-        if self.device.index is None:
-            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.device, self.side = None, None
         self.workers, self.depth = max(1, int(workers)), max(1, int(depth))
-        with torch.cuda.device(self.device):
-            self.side = torch.cuda.Stream()
-            self.rings = [_FrameRing.create(ring_slots, max_frame_bytes, pin=True) for _ in range(self.workers)]
+        self.rings = [_FrameRing.create(ring_slots, max_frame_bytes, pin=False) for _ in range(self.workers)]
+        ring_slots = min(r.slots for r in self.rings)
         ctx = mp.get_context('spawn')
         self.task_q, self.result_q = ctx.Queue(), ctx.Queue()
         self.free_qs = [ctx.Queue() for _ in range(self.workers)]
         self.procs = [ctx.Process(target=_process_worker, daemon=True, name=f'das-loader-{w}',
                                   args=(w, dataset_cfg, seed, max_redraws,
-                                        (self.rings[w].path, ring_slots, max_frame_bytes), self.task_q, self.free_qs[w],
+                                        (self.rings[w].path, self.rings[w].slots, max_frame_bytes), self.task_q, self.free_qs[w],
                                         self.result_q))
                       for w in range(self.workers)]
         for p in self.procs:
@@ -315,6 +357,21 @@ class ProcessLoader:
                 self.close()
                 raise RuntimeError(f'loader worker {wid} failed to start:\n{info}')
             self.length = info
+        for r in self.rings:     # every worker has mapped its ring: the files' names can go (a crashed trainer leaks nothing)
+            r.unlink()
+        if device is not None:
+            self.bind(device)
+
+    def bind(self, device='cuda'):
+        """Attach the loader to its GPU: side stream for the uploads / recorded image ops, page-locked rings."""
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        with torch.cuda.device(self.device):
+            self.side = torch.cuda.Stream()
+            for r in self.rings:
+                r.pin()
+        return self
 
     def _get(self, timeout, block=True):
         import queue as _q
@@ -401,6 +458,8 @@ class ProcessLoader:
         return out, ev
 
     def batches(self, batches, timeout=600):
+        if self.side is None:
+            self.bind('cuda')
         batches = [list(b) for b in batches]
         n, sent, ready, prepared = len(batches), 0, {}, {}
         window = self.workers + self.depth

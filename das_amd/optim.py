@@ -59,7 +59,7 @@ class FlatSGD:
     ranks whatever the timing."""
 
     def __init__(self, model, lr, momentum=0.9, weight_decay=1e-4, bias_lr_mult=1.0, bias_decay_mult=1.0,
-                 max_grad_norm=0.0, bucket_mb=64, overlap=True, force_collectives=False):
+                 max_grad_norm=0.0, bucket_mb=64, overlap=True, force_collectives=False, comm_reserved_cus=None):
         self.model, self.base_lr, self.momentum, self.max_grad_norm = model, lr, momentum, max_grad_norm
         module_of = {}
         for mname, mod in model.named_modules():
@@ -130,6 +130,13 @@ class FlatSGD:
                 self.buckets.append((bstart, total if i == len(self.slots) - 1 else end))
                 bstart = end
         self.overlap = overlap
+        # CUs the persistent one-workgroup-per-CU kernels (weight gradients, streaming 1x1, 3x3 c64) leave free WHILE
+        # gradient buckets are in flight (das_tuning key comm.reserved_cus, set at the first bucket of a backward and
+        # cleared when the sum is complete): a collective's workgroups that cannot share a CU with a 128-150 KiB-LDS
+        # workgroup otherwise push part of a one-wave grid into a second pass (measured with das_dev_occupy_cus,
+        # 16 occupied CUs cost +10 % of a step without the reserve). Default: 32 with several ranks.
+        self.comm_reserved_cus = int(comm_reserved_cus if comm_reserved_cus is not None else (32 if self.world > 1 else 0))
+        self._reserve_on = False
         self.comm_stream = torch.cuda.Stream() if self._multi and dev.type == 'cuda' else None
         for i, sl in enumerate(self.slots):
             sl.index = i
@@ -211,8 +218,16 @@ class FlatSGD:
                                    '(model.zero_grad(set_to_none=True) or p.grad = ... detached it); use '
                                    'optimizer.zero_grad()')
 
+    def _set_reserve(self, on):
+        if self.comm_reserved_cus <= 0 or on == self._reserve_on or self.flat_g.device.type != 'cuda':
+            return
+        from . import _lib
+        _lib.check(_lib.load().das_tuning_set(b'comm.reserved_cus', self.comm_reserved_cus if on else 0), 'das_tuning_set')
+        self._reserve_on = on
+
     def _launch(self, b):
         s, e = self.buckets[b]
+        self._set_reserve(True)
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             from .autograd import wgrad_streams
@@ -246,6 +261,24 @@ class FlatSGD:
             return
         if self._pfires[i] == self._pexp[i]:
             self._remaining[b] -= 1
+            self._advance()
+
+    def mark_complete(self, slots):
+        """The gradients of `slots`' parameters are complete although their completion hooks did not run: a replayed
+        backward graph (das_amd/graphs.py) adds them into the flat buffer without returning to Python. Same bookkeeping
+        as `_fired` up to the expected count, then the ready buckets go out (descending order, as always)."""
+        if not self._multi or not self.overlap:
+            return
+        for sl in slots:
+            i = sl.index
+            if self._pexp is None:          # first iteration: still learning the expected counts
+                self._pfires[i] = max(self._pfires[i], 1)
+                continue
+            if self._pexp[i] > self._pfires[i]:
+                self._pfires[i] = self._pexp[i]
+                if not self._launched[sl.bucket]:
+                    self._remaining[sl.bucket] -= 1
+        if self._pexp is not None:
             self._advance()
 
     def _learn(self):
@@ -293,6 +326,7 @@ class FlatSGD:
         for w in self._works:
             w.wait()
         self._works = []
+        self._set_reserve(False)
         if self._pexp is None and self.overlap:
             self._learn()
         self._reset_iteration()
@@ -347,16 +381,20 @@ class FlatSGD:
         state[i]['momentum_buffer'] dense OIHW, param_groups[i] = lr / momentum / dampening / weight_decay / nesterov.
         The step count and base lr ride along under `das_*` keys (torch ignores unknown top-level keys)."""
         mom = self._dense_momentum()
-        order = [n for n, p in self.model.named_parameters() if p.requires_grad]
+        # EVERY parameter in named_parameters() order, frozen ones included: mmcv's constructor appends a group for a
+        # parameter with requires_grad=False too (it just never gets a momentum buffer), and torch's load_state_dict
+        # compares group counts
+        order = [n for n, p in self.model.named_parameters()]
         group_of = {}
         for g in self.groups:
             for n, sl in zip(self._names, self.slots):
                 if g['start'] <= sl.off < g['end']:
                     group_of[n] = g
+        main = next(g for g in self.groups if g['key'] == 'main')
         state, pgs = {}, []
         for i, n in enumerate(order):
-            g = group_of[n]
-            if self.steps > 0:
+            g = group_of.get(n, main)      # (frozen: the plain defaults, no state)
+            if self.steps > 0 and n in mom:
                 state[i] = dict(momentum_buffer=mom[n])
             pgs.append(dict(lr=self.base_lr * g['lr_mult'], initial_lr=self.base_lr * g['lr_mult'], momentum=self.momentum,
                             dampening=0, weight_decay=g['wd'], nesterov=False, params=[i]))
@@ -368,10 +406,14 @@ class FlatSGD:
         if 'momentum_buffer' in sd:
             mom, steps = sd['momentum_buffer'], int(sd.get('steps', 1))
         else:
-            order = [n for n, p in self.model.named_parameters() if p.requires_grad]
             flat_ids = [i for g in sd['param_groups'] for i in g['params']]
+            order = [n for n, p in self.model.named_parameters()]          # upstream / this class: frozen ones included
             if len(flat_ids) != len(order):
-                raise ValueError(f'optimizer state holds {len(flat_ids)} parameters, the model has {len(order)}')
+                trainable = [n for n, p in self.model.named_parameters() if p.requires_grad]   # (files of rounds 2-3)
+                if len(flat_ids) != len(trainable):
+                    raise ValueError(f'optimizer state holds {len(flat_ids)} parameters, the model has {len(order)} '
+                                     f'({len(trainable)} trainable)')
+                order = trainable
             mom = {}
             for n, i in zip(order, flat_ids):
                 st = sd['state'].get(i, sd['state'].get(str(i)))
@@ -430,6 +472,16 @@ def train_iteration(model, optimizer, data, lr):
     out['loss'].backward()
     optimizer.all_reduce_grads()
     optimizer.step(lr)
+    # bounded run-ahead: the host may queue at most two steps beyond the one the GPU is running (an event per step, wait for
+    # the one of step n - 2). Unbounded, a kernel fault would surface many steps late and a wall-clock "s/it" would
+    # measure launch-queue time; two steps of slack keep the queue full and never stall a loader.
+    if out['loss'].is_cuda:
+        evs = optimizer.__dict__.setdefault('_step_events', [])
+        ev = torch.cuda.Event()
+        ev.record()
+        evs.append(ev)
+        if len(evs) > 2:
+            evs.pop(0).synchronize()
     # (`out['log_vars']` is a LazyLogVars: a mapping name -> float whose values reach the host without stalling this
     # thread; reading one waits for this step's forward pass only. The step is NOT synchronised with the host here:
     # the next batch can be fetched and the next step queued while this one still runs.)

@@ -47,13 +47,21 @@ const char* das_target_arch(void);
  * MIOpen algorithm internally: torch.backends.cudnn.benchmark, tools/train.py:115-116). Unknown key: DAS_ERR_ARG.
  * Keys: conv.big_minblocks, conv.big_mink, conv.glds3_pp_mink, conv.glds4_minblocks, conv.glds4_pp (-1 auto / 0 / 1),
  * conv.glds4_mf, conv.stream_minrows, conv.stream_percu, conv.tail_split, conv.splitk_target, conv.splitk_minsteps, conv.splitk_kernels, conv.c64_mintiles, wgrad.pp_mink, wgrad.bkm, wgrad.blocks, wgrad.pp_blocks,
- * bn.reduce_blocks, bn.reduce_threads, bn.vpt, gn.ppb, bn.stream_minbytes. */
+ * bn.reduce_blocks, bn.reduce_threads, bn.vpt, gn.ppb, bn.stream_minbytes, conv.pt3_mintiles (persistent 256 x 128 tile
+ * grid: 0 = off), comm.reserved_cus (CUs every persistent grid leaves free: wgrad.blocks / wgrad.pp_blocks 0 = one
+ * resident wave of workgroups on the remaining CUs). */
 int das_tuning_set(const char* key, long long value);
 int das_tuning_get(const char* key, long long* value);
 int das_tuning_reset(void);
 /* Name of the kernel the calling thread's last das_conv2d_nhwc / das_conv2d_wgrad_nhwc call launched
  * ("conv_glds4_kernel<pp>", "conv1x1_stream_kernel", ...): lets a parity test assert WHICH kernel it checked. */
 const char* das_last_kernel(void);
+/* Measurement aid (no reference counterpart): `blocks` workgroups of `threads` threads and `lds_bytes` of LDS each that
+ * do nothing but hold their CU slots for `usec` microseconds on `stream` — stands in for the RCCL kernels of an
+ * overlapped gradient all-reduce when only one GPU is at hand (tools/dev/cu_pressure.py, tests/test_ddp_gpu.py):
+ * with lds_bytes near 160 KiB a workgroup owns its CU, with a few KiB it shares it as a collective's kernel would.
+ * The persistent kernels size their grids for das_tuning key comm.reserved_cus fewer CUs. */
+int das_dev_occupy_cus(int blocks, int threads, int lds_bytes, int usec, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA, fused epilogue.

@@ -203,9 +203,15 @@ def test_process_loader_hands_device_batches_over_in_order():
     the collated CUDA tensors arrive here by IPC handle, in batch order, and a failing batch raises here."""
     from das_amd.loader import ProcessLoader
     cfg = dict(type='SyntheticPoseDataset', num_joints=15, img_shape=(128, 192), length=12, seed=3, max_persons=3)
-    pl = ProcessLoader(cfg, device='cuda:0', workers=2)
+    # started WITHOUT a device (how tools/train.py starts it: before its first GPU call), bound afterwards
+    pl = ProcessLoader(cfg, device=None, workers=2)
     try:
-        assert pl.length == 12
+        assert pl.length == 12 and pl.side is None
+        assert all(r.path is None and not r.registered for r in pl.rings)     # ring files unlinked once the workers mapped them
+        import glob
+        assert not glob.glob('/dev/shm/das_frames_*')
+        pl.bind('cuda:0')
+        assert pl.side is not None and all(r.registered for r in pl.rings)
         batches = [[0, 1], [2, 3], [4, 5], [6, 7], [8, 9]]
         got = list(pl.batches(batches))
         assert len(got) == 5

@@ -41,6 +41,24 @@ def q(t):
     return t.to(BF).float()
 
 
+def assert_bf16_exact(y, ref, frac=0.05):
+    """the bf16-appropriate SHARP check for a kernel that accumulates in f32 and stores bf16. `ref` is the
+    f32 result on the same bf16-rounded operands; only the accumulation order differs (~1e-6 relative), so the stored
+    value is round_bf16(ref) except where ref sits at a rounding midpoint, and then it is the NEIGHBOURING bf16 value:
+    every element within ONE bf16 step of round_bf16(ref) (a single missing product of a K = 2304 reduction is ~0.02 =
+    2.5 steps at |y| < 2), and at most `frac` of the elements off at all. TOL (1.6e-2 relative + absolute) stays as the
+    coarse net below it."""
+    yf, rf = y.float(), ref.float()
+    rq = rf.to(BF).float()
+    step = torch.pow(2.0, torch.floor(torch.log2(rq.abs().clamp_min(1e-30))) - 7)      # bf16 spacing at round(ref)
+    err = (yf - rq).abs()
+    tol = torch.maximum(step * 1.001, torch.full_like(step, 3e-5))     # (one step; floor: f32 accumulation noise near zero)
+    bad = err > tol
+    assert not bool(bad.any()), (int(bad.sum()), float((err / tol).max()), float(err.max()))
+    off = float((err > 3e-5).float().mean())
+    assert off <= frac, off
+
+
 def conv_ref(x, w, s, p):
     """f32 reference on the GPU's own f32 path would be another kernel of ours; use torch on the CPU."""
     return F.conv2d(q(x), q(w), None, s, p)
@@ -103,6 +121,7 @@ SHAPES_PT3 = [c for c in SHAPES3 if c[3] * c[5] * c[5] >= 128] + [
 def test_pt3_forced(case):
     x, w, y = _run_forced('conv_pt3_kernel', case)
     np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
+    assert_bf16_exact(nchw(y), conv_ref(x, w, case[6], case[7]))
 
 
 def test_pt3_equals_one_tile_kernel_bitwise():
@@ -127,6 +146,7 @@ def test_pt3_equals_one_tile_kernel_bitwise():
 def test_glds3_forced(kernel, case):
     x, w, y = _run_forced(kernel, case)
     np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
+    assert_bf16_exact(nchw(y), conv_ref(x, w, case[6], case[7]))
 
 
 @pytest.mark.parametrize('kernel', ['conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
@@ -134,6 +154,7 @@ def test_glds3_forced(kernel, case):
 def test_glds4_forced(kernel, case):
     x, w, y = _run_forced(kernel, case)
     np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
+    assert_bf16_exact(nchw(y), conv_ref(x, w, case[6], case[7]))
 
 
 @pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_pt3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
@@ -432,6 +453,7 @@ def test_tiles_real_sizes(case):
     y = o.conv2d(nhwc(x), o.pack_weight(w.to(DEV), BF), k, k, s, p)
     assert o.last_kernel() == expect, o.last_kernel()
     np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **TOL)
+    assert_bf16_exact(nchw(y), ref)
 
 
 def test_head_ragged_real_size():
@@ -664,3 +686,49 @@ def test_tuning_api_rejects_unknown_key():
     lib = _lib.load()
     assert lib.das_tuning_set(b'no.such.key', 1) == _lib.DAS_ERR_ARG
     assert lib.das_tuning_reset() == 0
+
+
+# ---------------------------------------------------------------- persistent grids under a CU reserve
+def test_persistent_grids_follow_the_cu_reserve():
+    """comm.reserved_cus (the CUs left to a collective's kernels while gradient buckets are in flight): every persistent
+    one-workgroup-per-CU grid shrinks with it — weight-gradient plans of both classes, the streaming 1x1 kernel, the
+    3x3 c64 kernel — and the results do not change (bit-identical for the convolutions: a tile's arithmetic does not
+    depend on which workgroup runs it; the weight gradient regroups f32 partial sums)."""
+    o = ops()
+    import ctypes as C
+    from das_amd import _lib
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B, H, W = 2, 64, 104
+    x1, w1 = nhwc(cases.randn(301, B, 256, H, W)), o.pack_weight((cases.randn(302, 64, 256, 1, 1) / 16).to(DEV), BF)
+    x3, w3 = nhwc(cases.randn(303, B, 64, H, W)), o.pack_weight((cases.randn(304, 64, 64, 3, 3) / 24).to(DEV), BF)
+    xg, dyg = nhwc(cases.randn(305, B, 256, 32, 52)), nhwc(cases.randn(306, B, 256, 32, 52))
+    xs_, dys_ = nhwc(cases.randn(307, B, 64, 32, 52)), nhwc(cases.randn(308, B, 128, 32, 52))
+    out = {}
+    for reserve in (0, 40):
+        with o.tuning(**{'comm.reserved_cus': reserve, 'conv.stream_minrows': 1024, 'conv.c64_mintiles': 1}):
+            y1 = o.conv2d(x1, w1, 1, 1, 1, 0)
+            assert o.last_kernel() == 'conv1x1_stream_kernel'
+            y3 = o.conv2d(x3, w3, 3, 3, 1, 1)
+            assert o.last_kernel() == 'conv3x3_c64_kernel'
+            dw_pp = o.conv2d_wgrad(xg, dyg, 3, 3, 1, 1)
+            plan_pp = o.last_wgrad_plan()
+            dw = o.conv2d_wgrad(xs_, dys_, 1, 1, 1, 0)
+            plan = o.last_wgrad_plan()
+        assert plan_pp['cls'] == 0 and plan_pp['grid'] == cus - reserve, plan_pp
+        assert plan['cls'] == 1 and plan['grid'] == 3 * (cus - reserve), plan
+        out[reserve] = (y1, y3, dw_pp, dw)
+    assert torch.equal(out[0][0], out[40][0]) and torch.equal(out[0][1], out[40][1])
+    for a, b in zip(out[0][2:], out[40][2:]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    # the measurement aid itself: 8 workgroups hold their CUs for 2 ms on a side stream, the main stream keeps working
+    side = torch.cuda.Stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):
+        e0.record()
+        _lib.check(lib.das_dev_occupy_cus(8, 256, 64 * 1024, 2000, C.c_void_p(side.cuda_stream)), 'das_dev_occupy_cus')
+        e1.record()
+    y = o.conv2d(x1, w1, 1, 1, 1, 0)
+    torch.cuda.synchronize()
+    assert 1.8 <= e0.elapsed_time(e1) <= 4.0 and torch.equal(y, out[0][0])
+    assert lib.das_dev_occupy_cus(0, 256, 4096, 10, None) == _lib.DAS_ERR_ARG

@@ -225,3 +225,91 @@ def test_bf16_decode_overlaps_f32_at_full_size():
             d = np.abs(pa[ia.index(idx)][:, :2] - pb[ib.index(idx)][:, :2]).max()
             assert d < 8.0, (idx, d)   # pixels, on 832 x 512 frames
     assert shared >= 0.9 * total, (shared, total)
+
+
+def test_four_stage_full_width_eval_f32_maps_and_decode_match_the_oracle():
+    """the BENCHMARKED topology (4-stage MSPN-50 + FPN + DASHead, J = 15) in eval mode — no batch
+    statistics to amplify rounding, so the check can be sharp through all ~220 conv layers and the three inter-stage
+    seams: every head map within 2e-4 of its range, decode kept indices identical, order included
+    (mspn_mmpose.py:657-667, das_head.py:232-267, 653-796)."""
+    import bench
+    cfg = bench.model_cfg(4, 'f32')
+    refmaps, ref, maps, out = eval_case(cfg, 4, bench.H, bench.W, seed=2)
+    check_maps_and_decode(refmaps, ref, maps, out, 2e-4)
+
+
+GRAD_PARAMS = [
+    'backbone.top.top.0.conv.weight',                                      # the 7x7 stem (the far end of backward)
+    'backbone.top.top.0.bn.weight',
+    'backbone.multi_stage_mspn.0.downsample.layer1.0.conv1.weight',
+    'backbone.multi_stage_mspn.0.downsample.layer3.5.conv2.weight',        # 3x3 256 -> 256 at 32 x 52
+    'backbone.multi_stage_mspn.0.downsample.layer4.2.conv3.weight',        # 512 -> 2048 at 16 x 26
+    'backbone.multi_stage_mspn.0.downsample.layer4.2.bn3.bias',
+    'backbone.multi_stage_mspn.0.upsample.up1.in_skip.conv.weight',        # 2048 -> 256
+    'neck.lateral_convs.0.conv.weight',
+    'bbox_head.pose_convs.1.conv.conv_offset.weight',                      # the DCNv2 offset conv (offset gradient kernel)
+    'bbox_head.pose_convs.1.conv.weight',                                  # the DCNv2 weight (col as GEMM operand)
+    'bbox_head.conv_poses.1.weight',
+    'bbox_head.cls_convs.0.gn.weight',
+]
+
+
+def test_one_stage_full_width_backward_gradients_vs_oracle_f64():
+    """one full-width train step's BACKWARD (1-stage MSPN-50 + FPN + head, B = 2, 512 x 832): the
+    gradients of a dozen parameters spread over the net — stem, bottleneck convs of three stages of resolution, a
+    BatchNorm weight / bias, the 2048 -> 256 lateral, the DCNv2 offset conv and weight, a predictor, a GroupNorm weight —
+    from the HIP f32 path (flat optimizer: the weight-gradient kernels add straight into the flat buffer) against torch
+    autograd through the oracle in f64. Yardstick: the oracle's own f32 evaluation against its f64 one (ReLU masks
+    flip, statistics round): the HIP error must stay within 4x that band (floor 2e-3 of the tensor's largest
+    gradient)."""
+    import bench
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    from das_amd.optim import FlatSGD
+    from oracle import backbone as ob, head as oh, loss as ol
+    cfg = bench.model_cfg(1, 'f32')
+    hcfg = oracle_hcfg(cfg)
+    model = build(cfg, 0)
+    ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=2, seed=0)
+    ss = [ds[i] for i in range(2)]
+    img = torch.stack([s['img'] for s in ss])
+    gts = {k: [s[k] for s in ss] for k in ('gt_labels_3d', 'gt_poses_3d', 'centers2d', 'depths')}
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+
+    def oracle_grads(dt):
+        parts = [{k: (v.to(dt) if v.is_floating_point() else v) for k, v in d.items()} for d in split_sd(model)]
+        leaves = {}
+        for name in GRAD_PARAMS:
+            pre, d = [(p, d) for p, d in zip(('backbone.', 'neck.', 'bbox_head.'), parts) if name.startswith(p)][0]
+            d[name[len(pre):]].requires_grad_(True)
+            leaves[name] = d[name[len(pre):]]
+        bsd, nsd, hsd = parts
+        g = {k: [t.to(dt) if t.is_floating_point() else t for t in v] for k, v in gts.items()}
+        feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img.to(dt), 1, (3, 4, 6, 3), train=True), train=True)
+        outs = oh.head_forward(hsd, feats, hcfg, '', True)
+        sum(ol.head_loss(hsd, '', *outs, g, hcfg).values()).backward()
+        return {n: t.grad.detach().double() for n, t in leaves.items()}
+
+    g64 = oracle_grads(torch.float64)
+    g32 = oracle_grads(torch.float32)
+    data = collate(ss, device=DEV)
+    model.to(DEV).train()
+    opt = FlatSGD(model, lr=1e-3)
+    opt.zero_grad()
+    out = model.train_step(data, None)
+    out['loss'].backward()
+    opt.all_reduce_grads()        # (joins the weight gradients' side stream)
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    report = []
+    for n in GRAD_PARAMS:
+        ref = g64[n]
+        scale = float(ref.abs().max())
+        assert scale > 0, n
+        e_or = float((g32[n] - ref).abs().max()) / scale
+        e_hip = float((params[n].grad.detach().double().cpu() - ref).abs().max()) / scale
+        report.append((n, e_hip, e_or))
+    print('full-width backward: (parameter, HIP f32 vs f64, oracle f32 vs f64) relative to the largest gradient:')
+    for r in report:
+        print('   %-70s %.3e  %.3e' % r)
+    for n, e_hip, e_or in report:
+        assert e_hip <= max(4 * e_or, 2e-3), (n, e_hip, e_or)

@@ -163,3 +163,28 @@ def test_optimizer_state_is_torch_sgd_layout_both_ways():
     opt3 = FlatSGD(make('f32')[0], **kw)
     opt3.load_state_dict(dict(momentum_buffer=opt._dense_momentum(), steps=2, base_lr=2e-3))
     assert torch.equal(opt3.flat_m, opt.flat_m) and opt3.steps == 2
+
+
+def test_optimizer_state_with_a_frozen_parameter_matches_torch_layout():
+    """mmcv's constructor makes a param group for a frozen parameter too (no momentum buffer); FlatSGD's file
+    must have that layout, and a file written by torch over ALL parameters must load."""
+    from das_amd.optim import FlatSGD, train_iteration
+    kw = dict(lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=35.0)
+    model, data = make('f32')
+    frozen = 'backbone.top.top.0.bn.weight'
+    dict(model.named_parameters())[frozen].requires_grad_(False)
+    opt = FlatSGD(model, **kw)
+    for _ in range(2):
+        train_iteration(model, opt, data, 2e-3)
+    torch.cuda.synchronize()
+    sd = opt.state_dict()
+    names = [n for n, _ in model.named_parameters()]
+    assert len(sd['param_groups']) == len(names) and names.index(frozen) not in sd['state']
+    clones = [torch.nn.Parameter(p.detach().clone().contiguous(), requires_grad=p.requires_grad) for _, p in model.named_parameters()]
+    topt = torch.optim.SGD([dict(params=[c]) for c in clones], lr=2e-3, momentum=0.9)
+    topt.load_state_dict(dict(state=sd['state'], param_groups=sd['param_groups']))     # torch accepts the group count
+    model2, _ = make('f32')
+    dict(model2.named_parameters())[frozen].requires_grad_(False)
+    opt2 = FlatSGD(model2, **kw)
+    opt2.load_state_dict(topt.state_dict())
+    assert torch.equal(opt2.flat_m, opt.flat_m)

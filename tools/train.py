@@ -82,6 +82,24 @@ def main():
         os.path.basename(args.config))[0])
     distributed = args.launcher != 'none'
     local_rank = int(os.environ.get('LOCAL_RANK', args.local_rank))
+    # The loader's worker processes start BEFORE this process makes its first GPU call (they are CPU-only and never
+    # create a HIP context; starting processes out of a GPU-initialised parent is what some hosts are fragile about).
+    # data.worker_mode: 'process' (default, the reference's model: `workers_per_gpu` worker processes — decode, random
+    # draws and annotation arithmetic; the image ops they record are replayed on this GPU one batch ahead,
+    # das_amd.loader.ProcessLoader) or 'thread' (threads of this process running the whole pipeline,
+    # das_amd.loader.PrefetchLoader: no start-up cost, but they share the interpreter lock with the trainer)
+    pool = None
+    if cfg.data.get('workers_per_gpu', 0) > 0 and cfg.data.get('worker_mode', 'process') == 'process':
+        pool = ProcessLoader(cfg.data.train, device=None, workers=cfg.data.get('workers_per_gpu', 0),
+                             seed=args.seed + 1000 * int(os.environ.get('RANK', 0)))
+    try:
+        _train(args, cfg, work_dir, distributed, local_rank, pool)
+    finally:        # (an exception, Ctrl-C or a failed capture must not leave worker processes or shared memory behind)
+        if pool is not None:
+            pool.close()
+
+
+def _train(args, cfg, work_dir, distributed, local_rank, pool):
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -123,13 +141,8 @@ def main():
         val_dataset = build_dataset(val_cfg)
     spg = cfg.data.get('samples_per_gpu', 4)
     workers = cfg.data.get('workers_per_gpu', 0)
-    # data.worker_mode: 'process' (default, the reference's model: `workers_per_gpu` worker processes — here CPU-only:
-    # decode, random draws and annotation arithmetic; the image ops they record are replayed on this GPU one batch
-    # ahead, das_amd.loader.ProcessLoader) or 'thread' (threads of this process running the whole pipeline,
-    # das_amd.loader.PrefetchLoader: no start-up cost, but they share the interpreter lock with the trainer)
-    pool = None
-    if workers > 0 and cfg.data.get('worker_mode', 'process') == 'process':
-        pool = ProcessLoader(cfg.data.train, device=f'cuda:{local_rank}', workers=workers, seed=args.seed + 1000 * rank)
+    if pool is not None:
+        pool.bind(f'cuda:{local_rank}')      # (side stream, page-locked frame rings: the workers have been running since start-up)
     lrc = cfg.get('lr_config', {})
     want_graphs = bool(cfg.get('hip_graphs', False))
     max_epochs = cfg.get('runner', {}).get('max_epochs', 12)
@@ -154,8 +167,8 @@ def main():
                          warmup_ratio=lrc.get('warmup_ratio', 1.0))
             out = train_iteration(model, opt, data, lr)
             it += 1
-            if want_graphs and world == 1 and getattr(model, '_graphed_trunk', None) is None:
-                # `hip_graphs=True` (single process; fixed input size): after the first step — every workspace and
+            if want_graphs and getattr(model, '_graphed_trunk', None) is None:
+                # `hip_graphs=True` (fixed input size; with several ranks a trunk without SyncBN layers): after the first step — every workspace and
                 # schedule exists — the backbone + neck forward / backward of batches shaped like this one are captured
                 # as two hipGraphs (das_amd/graphs.py); other shapes keep the launch-by-launch path
                 from das_amd.graphs import enable_trunk_graphs
@@ -188,8 +201,6 @@ def main():
                 print(f'Epoch(val) [{epoch + 1}] {metrics}', flush=True)
         if args.max_iters and it >= args.max_iters:
             break
-    if pool is not None:
-        pool.close()
     if distributed:
         torch.distributed.destroy_process_group()
 
