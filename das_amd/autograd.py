@@ -562,13 +562,21 @@ class ConvFn(Function):
                                      w_classes=packed_weight_dgrad_s2(conv, x.dtype)))
             if dx.shape[-1] != x.shape[-1]:
                 dx = dx[..., :x.shape[-1]]
-        db = ops.colsum(dzr)[:weight.shape[0]] if has_bias else None
+        db = None
+        if has_bias:
+            ba = _param_acc(conv.bias) if getattr(conv, 'bias', None) is not None else None
+            if ba is not None and _d(dzr).shape[-1] == conv.bias.numel():
+                ops.colsum(dzr, acc=ba[1])        # straight into the flat gradient: no temporary, fill or add
+                ba[0].fired()
+            else:
+                db = ops.colsum(dzr)[:weight.shape[0]]
         return dx, dw, db, None, None, None, None, None
 
 
 class GroupNormReLUFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, geom, G, eps, relu):
+    def forward(ctx, x, gamma, beta, geom, G, eps, relu, gn=None):
+        ctx.gn = gn      # (the nn.GroupNorm module: its parameters' flat-gradient slices take the gradients directly)
         xin = _wrap(x, geom)
         out = xin.new(x.shape[-1]) if geom is not None else torch.empty_like(x)
         y, st = ops.groupnorm(xin, gamma, beta, G, eps, relu=relu, out=out, return_stats=True)
@@ -582,9 +590,15 @@ class GroupNormReLUFn(Function):
         x, y, st, gamma = ctx.saved_tensors
         geom, G, eps, relu = ctx.cfg
         dy = dy.contiguous()
+        ga, ba = (_param_acc(ctx.gn.weight), _param_acc(ctx.gn.bias)) if ctx.gn is not None else (None, None)
+        direct = ga is not None and ba is not None
         dx, dgamma, dbeta = ops.groupnorm_backward(_wrap(dy, geom), _wrap(y, geom), _wrap(x, geom), st, gamma, G, eps,
-                                                   relu)
-        return _d(dx), dgamma, dbeta, None, None, None, None
+                                                   relu, dgamma_acc=ga[1] if direct else None,
+                                                   dbeta_acc=ba[1] if direct else None)
+        if direct:
+            ga[0].fired()
+            ba[0].fired()
+        return _d(dx), dgamma, dbeta, None, None, None, None, None
 
 
 class MaxPoolFn(Function):

@@ -99,6 +99,11 @@ class DownsampleModule(nn.Module):
         return tuple(out)
 
 
+def ops_upsample(x, Ho, Wo):
+    from . import ops
+    return ops.upsample_bilinear_ac(x, Ho, Wo)
+
+
 class UpsampleUnit(nn.Module):
     def __init__(self, ind, num_units, in_channels, unit_channels=256, gen_skip=False, gen_cross_conv=False,
                  norm_cfg=dict(type='BN'), out_channels=64):
@@ -114,6 +119,22 @@ class UpsampleUnit(nn.Module):
         self.gen_cross_conv = gen_cross_conv
         if ind == num_units - 1 and gen_cross_conv:
             self.cross_conv = ConvModule(unit_channels, out_channels, 1, norm_cfg=norm_cfg)
+
+    def forward_unused(self, x, up_x):
+        """This unit's output is consumed by nobody (the last stage's finest map when the neck starts at level 1: the
+        reference computes it anyway, mspn_mmpose.py:381-404, and nothing reads it). Eval: nothing to do. Train: the two
+        convs still run — their BatchNorm layers' running statistics are part of the state dict and must advance exactly
+        as the reference's do — but the normalised tensors are never written (`conv_bn_stats_only`), and no autograd
+        node is recorded (the reference's backward does not reach them either)."""
+        assert not self.gen_skip and not (self.ind == self.num_units - 1 and self.gen_cross_conv)
+        if not self.in_skip.bn.training:
+            return None
+        with torch.no_grad():
+            nnops.conv_bn_stats_only(x, self.in_skip.conv, self.in_skip.bn)
+            if self.ind > 0:
+                up = ops_upsample(up_x, x.shape[1], x.shape[2])
+                nnops.conv_bn_stats_only(up, self.up_conv.conv, self.up_conv.bn)
+        return None
 
     def forward(self, x, up_x):
         # x and out each feed several convs: all but the last consumer hand the tensor through their autograd node
@@ -151,10 +172,16 @@ class UpsampleModule(nn.Module):
             self.add_module(f'up{i + 1}', UpsampleUnit(i, num_units, self.in_channels[i], unit_channels, gen_skip,
                                                         gen_cross_conv, norm_cfg=norm_cfg, out_channels=64))
 
-    def forward(self, x):
+    def forward(self, x, skip_finest=False):
         out, skip1, skip2, cross = [], [], [], None
         for i in range(self.num_units):
-            o, s1, s2, c = getattr(self, f'up{i + 1}')(x[i], out[i - 1] if i > 0 else None)
+            unit = getattr(self, f'up{i + 1}')
+            if skip_finest and i == self.num_units - 1:
+                out.append(unit.forward_unused(x[i], out[i - 1] if i > 0 else None))
+                skip1.append(None)
+                skip2.append(None)
+                continue
+            o, s1, s2, c = unit(x[i], out[i - 1] if i > 0 else None)
             out.append(o)
             skip1.append(s1)
             skip2.append(s2)
@@ -172,9 +199,9 @@ class SingleStageNetwork(nn.Module):
         self.downsample = DownsampleModule(list(num_blocks), num_units, has_skip, norm_cfg, in_channels)
         self.upsample = UpsampleModule(unit_channels, num_units, gen_skip, gen_cross_conv, norm_cfg, in_channels)
 
-    def forward(self, x, skip1, skip2):
+    def forward(self, x, skip1, skip2, skip_finest=False):
         mid = self.downsample(x, skip1, skip2)
-        return self.upsample(mid)
+        return self.upsample(mid, skip_finest)
 
 
 class ResNetTop(nn.Module):
@@ -209,15 +236,19 @@ class MSPN2(nn.Module):
                                                             num_blocks, norm_cfg, res_top_channels))
         self.pretrained = pretrained
         self.compute_dtype = torch.bfloat16 if compute_dtype in ('bf16', torch.bfloat16) else torch.float32
+        # True (set by the detector when its neck starts at level >= 1, as every DAS config's does): the last stage's
+        # finest map — outputs[0], stride 4 — has no consumer; forward returns None in its place (UpsampleUnit.forward_unused)
+        self.skip_unused_finest = False
 
     def forward(self, x):
         x = as_nhwc(x, self.compute_dtype)
         x = self.top(x)
         skip1 = skip2 = None
         out = None
+        last = self.multi_stage_mspn[-1]
         for stage in self.multi_stage_mspn:
-            out, skip1, skip2, x = stage(x, skip1, skip2)
-        return [to_nchw_view(o) for o in out[::-1]]
+            out, skip1, skip2, x = stage(x, skip1, skip2, skip_finest=self.skip_unused_finest and stage is last)
+        return [to_nchw_view(o) if o is not None else None for o in out[::-1]]
 
     def init_weights(self, pretrained=None):
         """mspn_mmpose.py:669-721, both branches.

@@ -330,17 +330,20 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
                                   float momentum, float eps, const void* residual, int relu, float* save_mean,
                                   float* save_invstd, long long* num_batches_tracked, long long stat_count,
                                   int stats_slots, void* stream) {
-  if (!x || !y || !stats || !gamma || !beta || !save_mean || !save_invstd || C % 8 || count <= 0) return DAS_ERR_ARG;
+  if (!x || !stats || !gamma || !beta || !save_mean || !save_invstd || C % 8 || count <= 0) return DAS_ERR_ARG;
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
   if (stat_count != 0 && stat_count < count) return DAS_ERR_ARG;
   if (stats_slots < 0 || stats_slots > 64) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const long long nstat = stat_count ? stat_count : count;
+  // y == NULL: finalize only — mean / invstd published, running statistics and the batch counter advanced, nothing
+  // normalised (a layer whose output has no consumer: the statistics are still part of the state dict)
+  if (!y) count = 0;
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
   // at least eight vectors per thread (the per-thread mean / invstd / gamma / beta set-up is ~60 instructions and 32
   // loads): the mid-size layers ran at 1.7...3 TB/s with one vector per thread (1024 channels at 32x52: 37 -> 22 us)
   const int vpt = std::max(1, (int)dastune::get(dastune::BN_VPT));
-  int grid = std::max(1, std::min(grid_for(count * vc), (int)((count * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
+  int grid = count == 0 ? 1 : std::max(1, std::min(grid_for(count * vc), (int)((count * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
   const int nslots = stats_slots < 1 ? 1 : stats_slots;
   // large layers: fold launch + many-small-workgroups pass (see bn_apply_stream_kernel)
   const long long stream_from = dastune::get(dastune::BN_STREAM_MINBYTES);

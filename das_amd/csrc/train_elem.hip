@@ -353,10 +353,10 @@ __global__ void nearest_bwd_kernel(const T* __restrict__ dy, T* __restrict__ db,
   else if ((dtype) == DAS_F32) { using T = float; CALL; } \
   else return DAS_ERR_ARG;
 
-extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void* x, void* dx, int dtype,
-                                      const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
-                                      const float* gamma, float eps, int relu, float* gsums_ws, float* dgamma,
-                                      float* dbeta, void* stream) {
+static int groupnorm_backward_impl(const void* dy, const void* y, const void* x, void* dx, int dtype,
+                                   const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
+                                   const float* gamma, float eps, int relu, float* gsums_ws, float* dgamma,
+                                   float* dbeta, bool accumulate, void* stream) {
   if (!dy || !x || !dx || !fwd_stats || !gamma || !gsums_ws || !dgamma || !dbeta || !lv_valid(lv)) return DAS_ERR_ARG;
   if (C % 8 || C % G || pix_stride % 8 || C > 2048 || (relu && !y)) return DAS_ERR_ARG;
   const int epv = dtype == DAS_BF16 ? 8 : 4;
@@ -364,7 +364,9 @@ extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void*
   hipStream_t s = (hipStream_t)stream;
   const int nseg = lv->num_levels * lv->B;
   // (one fill when the caller laid the three accumulators out back to back: a fill is a ~4 us launch of its own)
-  if (dgamma == gsums_ws + 2 * nseg * G && dbeta == dgamma + C) {
+  if (accumulate) {   // dgamma / dbeta already hold gradients (the optimizer's flat buffer): only the group sums start at zero
+    if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  } else if (dgamma == gsums_ws + 2 * nseg * G && dbeta == dgamma + C) {
     if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * (2 * (size_t)nseg * G + 2 * (size_t)C), s) != hipSuccess) return DAS_ERR_LAUNCH;
   } else {
     if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
@@ -385,6 +387,21 @@ extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void*
   });
   DAS_CHECK_LAUNCH();
   return DAS_OK;
+}
+
+extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void* x, void* dx, int dtype,
+                                      const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
+                                      const float* gamma, float eps, int relu, float* gsums_ws, float* dgamma,
+                                      float* dbeta, void* stream) {
+  return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, eps, relu, gsums_ws, dgamma,
+                                 dbeta, false, stream);
+}
+extern "C" int das_groupnorm_backward_acc(const void* dy, const void* y, const void* x, void* dx, int dtype,
+                                          const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
+                                          const float* gamma, float eps, int relu, float* gsums_ws, float* dgamma,
+                                          float* dbeta, void* stream) {
+  return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, eps, relu, gsums_ws, dgamma,
+                                 dbeta, true, stream);
 }
 
 extern "C" int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W,

@@ -1501,10 +1501,10 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   return das_conv2d_wgrad_batch(1, &x, &dy, &dw, d, accumulate, stream);
 }
 
-extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream) {
+static int colsum_impl(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, bool accumulate, void* stream) {
   if (!x || !out || rows <= 0 || C % 8 || pix_stride % 8 || C > 2048) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int blocks = (int)std::min<long long>(256, std::max<long long>(1, rows / 64));
   if (dtype == DAS_BF16) {
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(TPB), C * sizeof(float), s, (const bf16_t*)x, rows, C,
@@ -1517,6 +1517,12 @@ extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int p
   }
   DAS_CHECK_LAUNCH();
   return DAS_OK;
+}
+extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream) {
+  return colsum_impl(x, dtype, rows, C, pix_stride, out, false, stream);
+}
+extern "C" int das_colsum_acc(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream) {
+  return colsum_impl(x, dtype, rows, C, pix_stride, out, true, stream);
 }
 
 extern "C" int das_bn_train_backward_phase(const void* dy, const void* y, const void* raw, int dtype, long long rows,

@@ -70,6 +70,10 @@ class DAS(nn.Module):
             backbone['pretrained'] = pretrained
         self.backbone = build_backbone(backbone)
         self.neck = build_neck(neck) if neck is not None else None
+        # the neck starts at level >= 1 (every DAS config): the backbone's finest map has no consumer — it is not computed
+        # (eval) / reduced to its BatchNorm statistics (train); das_amd/backbones.py UpsampleUnit.forward_unused
+        if self.neck is not None and getattr(self.neck, 'start_level', 0) >= 1 and hasattr(self.backbone, 'skip_unused_finest'):
+            self.backbone.skip_unused_finest = True
         bbox_head = dict(bbox_head)
         bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
         self.bbox_head = build_head(bbox_head)

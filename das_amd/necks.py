@@ -54,8 +54,9 @@ class FPN(nn.Module):
 
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        dtype = inputs[0].dtype
-        feats = [as_nhwc(t, dtype) for t in inputs]
+        # (levels below start_level are never read: the backbone may hand None for them — MSPN2.skip_unused_finest)
+        dtype = inputs[self.start_level].dtype
+        feats = [as_nhwc(t, dtype) if t is not None else None for t in inputs]
         lats = [l(feats[i + self.start_level]) for i, l in enumerate(self.lateral_convs)]
         n = len(lats)
         for i in range(n - 1, 0, -1):

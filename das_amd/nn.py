@@ -53,13 +53,20 @@ class _Cache:
     def __init__(self):
         self.store = {}
 
-    def get(self, key, sources, make):
+    def get(self, key, sources, make, refresh=None):
+        """refresh(value): rewrite a stale cached value IN PLACE (same shape, same memory) instead of building a new one —
+        the parameters change every optimisation step, so a training step refreshes every entry once; a rebuild costs
+        an allocation + fill + cast + copy (four to six small launches), a refresh one strided copy."""
         ver = _versions(*sources)
         hit = self.store.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         with torch.no_grad():
-            val = make()
+            if hit is not None and refresh is not None:
+                val = hit[1]
+                refresh(val)
+            else:
+                val = make()
         self.store[key] = (ver, val)
         return val
 
@@ -86,14 +93,16 @@ def packed_weight(conv, dtype, cin_pad=None):
     if sl is not None:
         return sl.packed(dtype)  # view of the optimizer's once-per-step packed buffer
     return _cache_of(conv).get(('w', dtype, cin_pad), (conv.weight,),
-                               lambda: ops.pack_weight(conv.weight, dtype, cin_pad=cin_pad))
+                               lambda: ops.pack_weight(conv.weight, dtype, cin_pad=cin_pad),
+                               refresh=lambda buf: ops.pack_weight(conv.weight, dtype, out=buf))
 
 
 def packed_weight_dgrad(conv, dtype):
     sl = _slot_of(conv.weight)
     if sl is not None:
         return sl.packed(dtype, dgrad=True)
-    return _cache_of(conv).get(('wd', dtype), (conv.weight,), lambda: ops.pack_weight_dgrad(conv.weight, dtype))
+    return _cache_of(conv).get(('wd', dtype), (conv.weight,), lambda: ops.pack_weight_dgrad(conv.weight, dtype),
+                               refresh=lambda buf: ops.pack_weight_dgrad(conv.weight, dtype, out=buf))
 
 
 def packed_weight_dgrad_s2(conv, dtype):
@@ -106,13 +115,16 @@ def packed_weight_dgrad_s2(conv, dtype):
                                lambda: ops.dgrad_s2_weights(packed_weight_dgrad(conv, dtype), k, p))
 
 
-def _pad8(v, n, fill=0.0):
+def _pad8(v, n, fill=0.0, out=None):
     """f32 vector of n values padded to a multiple of 8 (the kernels read per-channel constants in vectors of 8). A
     vector that already is f32, contiguous and a multiple of 8 long is used as it is: padding it anyway cost two small
     launches per biased conv and step (the parameters change every step, so nothing here can be cached across steps)."""
     vd = v.detach()
     if n % 8 == 0 and vd.numel() == n and vd.dtype == torch.float32 and vd.is_contiguous():
         return vd
+    if out is not None and out.numel() == (n + 7) // 8 * 8 and out.data_ptr() != vd.data_ptr():
+        out[:n].copy_(vd)      # (refresh of a cached padded copy: the padding keeps its fill value)
+        return out
     out = torch.full(((n + 7) // 8 * 8,), fill, dtype=torch.float32, device=v.device)
     out[:n] = vd.float()
     return out
@@ -133,7 +145,11 @@ def bn_eval_affine(conv, bn):
 def bias_shift(conv):
     if conv.bias is None:
         return None
-    return _cache_of(conv).get(('bias',), (conv.bias,), lambda: _pad8(conv.bias, conv.bias.numel()))
+    n = conv.bias.numel()
+    if n % 8 == 0:
+        return _pad8(conv.bias, n)      # (used as it is: nothing to cache)
+    return _cache_of(conv).get(('bias',), (conv.bias,), lambda: _pad8(conv.bias, n),
+                               refresh=lambda buf: _pad8(conv.bias, n, out=buf))
 
 
 def _channels(x):
@@ -178,6 +194,28 @@ def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False, skip_through=
                                          stat_count=stat_count)
     bn.__dict__.pop('_das_cache', None)  # running stats were updated through raw pointers
     return y
+
+
+def conv_bn_stats_only(x, conv, bn):
+    """Train-mode ConvModule(conv, BN) whose OUTPUT nobody reads: the conv runs (its epilogue reduces the batch
+    statistics), the BatchNorm publishes mean / invstd and advances running_mean / running_var / num_batches_tracked exactly
+    as `conv_bn` would, and the normalised tensor is never written (das_bn_train_apply with y = NULL: finalize only)."""
+    assert bn.training and conv.bias is None
+    from . import autograd as ag
+    w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    cout = w.shape[0]
+    stats = bn_stats_buffer(x, cout)
+    raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
+    rows = raw.numel() // cout
+    world, stat_count = ag._sync_world(bn), rows
+    if world > 1:
+        stats = sync_stats(stats, cout, ag._all_reduce)
+        stat_count = rows * world
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
+                       num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count, finalize_only=True)
+    bn.__dict__.pop('_das_cache', None)
 
 
 class _ZeroArena:
@@ -275,7 +313,7 @@ def group_norm_relu(x, gn, relu=True):
     from . import autograd as ag
     if ag.grad_mode(_tensor(x), gn.weight):
         g = ag._geom(x)
-        return ag._wrap(ag.GroupNormReLUFn.apply(_tensor(x), gn.weight, gn.bias, g, gn.num_groups, gn.eps, relu), g)
+        return ag._wrap(ag.GroupNormReLUFn.apply(_tensor(x), gn.weight, gn.bias, g, gn.num_groups, gn.eps, relu, gn), g)
     return ops.groupnorm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=relu)
 
 

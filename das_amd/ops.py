@@ -169,21 +169,28 @@ def _empty_like_rows(x, C_, dtype):
     return torch.empty(*x.shape[:-1], C_, dtype=dtype, device=x.device)
 
 
-def pack_weight(w, dtype, cin_pad=None, cout_pad=None):
-    """OIHW f32 parameter -> (Cout_pad, KH, KW, Cin_pad) K-contiguous tensor in `dtype`."""
+def pack_weight(w, dtype, cin_pad=None, cout_pad=None, out=None):
+    """OIHW f32 parameter -> (Cout_pad, KH, KW, Cin_pad) K-contiguous tensor in `dtype`.
+    out: a tensor this function returned earlier for a parameter of this shape — rewritten in place by ONE strided,
+    casting copy (the zero padding is already there)."""
     O, I, KH, KW = w.shape
+    if out is not None:
+        out[:O, :, :, :I].copy_(w.detach().permute(0, 2, 3, 1))
+        return out
     cin_pad = cin_pad or (I + 7) // 8 * 8
     cout_pad = cout_pad or (O + 7) // 8 * 8
     p = torch.zeros(cout_pad, KH, KW, cin_pad, dtype=dtype, device=w.device)
-    p[:O, :, :, :I] = w.detach().permute(0, 2, 3, 1).to(dtype)
+    p[:O, :, :, :I].copy_(w.detach().permute(0, 2, 3, 1))
     return p
 
 
-def pack_weight_dgrad(w, dtype):
-    """OIHW f32 parameter -> data-gradient weights (Cin_pad, KH, KW, Cout_pad): taps flipped, I/O swapped."""
+def pack_weight_dgrad(w, dtype, out=None):
+    """OIHW f32 parameter -> data-gradient weights (Cin_pad, KH, KW, Cout_pad): taps flipped, I/O swapped.
+    out: as in pack_weight."""
     O, I, KH, KW = w.shape
-    p = torch.zeros((I + 7) // 8 * 8, KH, KW, (O + 7) // 8 * 8, dtype=dtype, device=w.device)
-    p[:I, :, :, :O] = w.detach().flip(2, 3).permute(1, 2, 3, 0).to(dtype)
+    p = out if out is not None else torch.zeros((I + 7) // 8 * 8, KH, KW, (O + 7) // 8 * 8, dtype=dtype, device=w.device)
+    src = w.detach().permute(1, 2, 3, 0)
+    p[:I, :, :, :O].copy_(src.flip(1, 2) if KH * KW > 1 else src)
     return p
 
 
@@ -410,14 +417,19 @@ def conv2d_wgrad_batch(items, accumulate=True):
         PROFILE.append((tag, flops, e0, e1, ('batch', n), n, nby, 1 + (1 if plan['partial'] > 0 else 0)))
 
 
-def colsum(x):
-    """f32[C] column sums over all rows of an NHWC tensor / Ragged (bias gradient)."""
+def colsum(x, acc=None):
+    """f32[C] column sums over all rows of an NHWC tensor / Ragged (bias gradient).
+    acc: f32[C] the sums are ADDED to instead (the bias's slice of the flat gradient buffer); returns None then."""
     _need_gpu(x)
     xd = _data(x)
     Cc = xd.shape[-1]
     rows = 1
     for s in xd.shape[:-1]:
         rows *= s
+    if acc is not None:
+        assert acc.dtype == torch.float32 and acc.numel() == Cc and acc.is_contiguous()
+        _lib.check(_lib.load().das_colsum_acc(_ptr(xd), _DT[xd.dtype], rows, Cc, _ps(x), _ptr(acc), _stream()), 'das_colsum_acc')
+        return None
     out = torch.empty(Cc, dtype=torch.float32, device=xd.device)
     _lib.check(_lib.load().das_colsum(_ptr(xd), _DT[xd.dtype], rows, Cc, _ps(x), _ptr(out), _stream()), 'das_colsum')
     return out
@@ -628,7 +640,7 @@ def add3(a, b, c=None, relu=False):
 
 
 def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None,
-                   relu=False, num_batches_tracked=None, stat_count=0):
+                   relu=False, num_batches_tracked=None, stat_count=0, finalize_only=False):
     """x (B,H,W,C) raw conv output, stats f32[slots][2C] from the conv epilogue. Returns y, mean, invstd.
     num_batches_tracked: the BatchNorm's int64 counter buffer, incremented on the device by the same launch.
     stat_count: global row count when `stats` was all-reduced over ranks (SyncBN); 0 = this tensor's rows."""
@@ -636,12 +648,12 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     assert x.is_contiguous()
     Cc = x.shape[-1]
     count = x.numel() // Cc
-    y = torch.empty_like(x)
+    y = None if finalize_only else torch.empty_like(x)     # (finalize_only: statistics published / advanced, no output)
     mi = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
     mean, invstd = mi[0], mi[1]
     if num_batches_tracked is not None:
         assert num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda
-    with _timed('bn_apply_kernel', (3 if residual is not None else 2) * x.numel() * x.element_size(),
+    with _timed('bn_apply_kernel', 0 if finalize_only else (3 if residual is not None else 2) * x.numel() * x.element_size(),
                 shape=(count, Cc, int(residual is not None))):
         _lib.check(_lib.load().das_bn_train_apply(_ptr(x), _ptr(y), _DT[x.dtype], count, Cc, _ptr(stats), _ptr(gamma),
                                                   _ptr(beta), _ptr(running_mean), _ptr(running_var), momentum, eps,
@@ -652,8 +664,9 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     return y, mean, invstd
 
 
-def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True):
-    """Returns dx (same container as x), dgamma, dbeta."""
+def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True, dgamma_acc=None, dbeta_acc=None):
+    """Returns dx (same container as x), dgamma, dbeta. dgamma_acc / dbeta_acc (both): f32[C] slices of the flat gradient
+    buffer the parameter gradients are ADDED to instead (dgamma, dbeta come back as None)."""
     _need_gpu(dy, x)
     xd, dyd = _data(x), _data(dy)
     yd = _data(y) if y is not None else None
@@ -663,6 +676,13 @@ def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True):
     assert _ps(dy) == _ps(x) == _ps(dx) and (yd is None or _ps(y) == _ps(x)), 'operands must share the pixel stride'
     # (the three accumulators back to back: the call zeroes them with one fill)
     ngs = lv.num_levels * lv.B * G * 2
+    if dgamma_acc is not None and dbeta_acc is not None:
+        gs = torch.empty(ngs, dtype=torch.float32, device=xd.device)
+        _lib.check(_lib.load().das_groupnorm_backward_acc(_ptr(dyd), _ptr(yd), _ptr(xd), _ptr(_data(dx)), _DT[xd.dtype],
+                                                          C.byref(lv), Cc, _ps(x), G, _ptr(fwd_stats), _ptr(gamma), eps,
+                                                          int(relu), _ptr(gs), _ptr(dgamma_acc), _ptr(dbeta_acc), _stream()),
+                   'das_groupnorm_backward_acc')
+        return dx, None, None
     acc = torch.empty(ngs + 2 * Cc, dtype=torch.float32, device=xd.device)
     gs, dgamma, dbeta = acc[:ngs], acc[ngs:ngs + Cc], acc[ngs + Cc:]
     _lib.check(_lib.load().das_groupnorm_backward(_ptr(dyd), _ptr(yd), _ptr(xd), _ptr(_data(dx)), _DT[xd.dtype],

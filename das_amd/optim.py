@@ -461,6 +461,9 @@ def build_optimizer(model, cfg, optimizer_config=None):
                    bias_decay_mult=pw.get('bias_decay_mult', 1.0), max_grad_norm=clip.get('max_norm', 0.0))
 
 
+MAX_RUN_AHEAD = 3     # steps the host may queue beyond the one the GPU runs (0 = unbounded; see train_iteration)
+
+
 def train_iteration(model, optimizer, data, lr):
     """One optimisation step: forward + losses + backward (HIP kernels under autograd), gradient
     all-reduce over RCCL, fused clip + SGD. Returns the detector's `train_step` dict (queued, not waited for)."""
@@ -472,15 +475,15 @@ def train_iteration(model, optimizer, data, lr):
     out['loss'].backward()
     optimizer.all_reduce_grads()
     optimizer.step(lr)
-    # bounded run-ahead: the host may queue at most two steps beyond the one the GPU is running (an event per step, wait for
-    # the one of step n - 2). Unbounded, a kernel fault would surface many steps late and a wall-clock "s/it" would
+    # bounded run-ahead: the host may queue at most MAX_RUN_AHEAD steps beyond the one the GPU is running (a BLOCKING event
+    # per step, wait for the one of step n - MAX_RUN_AHEAD). Unbounded, a kernel fault would surface many steps late and a wall-clock "s/it" would
     # measure launch-queue time; two steps of slack keep the queue full and never stall a loader.
-    if out['loss'].is_cuda:
+    if MAX_RUN_AHEAD > 0 and out['loss'].is_cuda:
         evs = optimizer.__dict__.setdefault('_step_events', [])
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(blocking=True)     # (a spinning wait on a default event cost 8 ms per step: measured)
         ev.record()
         evs.append(ev)
-        if len(evs) > 2:
+        if len(evs) > MAX_RUN_AHEAD:
             evs.pop(0).synchronize()
     # (`out['log_vars']` is a LazyLogVars: a mapping name -> float whose values reach the host without stalling this
     # thread; reading one waits for this step's forward pass only. The step is NOT synchronised with the host here:

@@ -159,6 +159,8 @@ int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* const* dys,
 int das_wgrad_last_plan(long long* out, int n);
 /* out f32[C] (zeroed by the call) = column sums of x (rows, C) — bias gradients. */
 int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream);
+/* The same sums ADDED to out (the optimizer's flat gradient slice of a bias: no temporary, no fill, no separate add). */
+int das_colsum_acc(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream);
 /* Train-mode BatchNorm (+ReLU, + residual) backward. dZ = dY * (y > 0) when relu; with y == NULL (allowed
  * when no residual was added before the ReLU) the mask is recomputed from raw, gamma and beta, which saves
  * reading y in both passes. sums f32[2C] (zeroed by the call) receive [sum dZ, sum dZ*xhat] = [dbeta,
@@ -208,6 +210,11 @@ int das_pack_conv_weights(const float* flat_src, void* fwd_dst, void* dgrad_dst,
 int das_groupnorm_backward(const void* dy, const void* y, const void* x, void* dx, int dtype, const DasLevels* lv,
                            int C, int pix_stride, int G, const float* fwd_stats, const float* gamma, float eps,
                            int relu, float* gsums_ws, float* dgamma, float* dbeta, void* stream);
+/* The same with dgamma / dbeta ACCUMULATED into (parameter-gradient slices of the optimizer's flat buffer); only
+ * gsums_ws is zeroed by the call. */
+int das_groupnorm_backward_acc(const void* dy, const void* y, const void* x, void* dx, int dtype, const DasLevels* lv,
+                               int C, int pix_stride, int G, const float* fwd_stats, const float* gamma, float eps,
+                               int relu, float* gsums_ws, float* dgamma, float* dbeta, void* stream);
 /* Backward of das_maxpool3x3s2 (gradient goes to the first maximum in scan order, as torch does),
  * das_upsample_bilinear_ac and the upsampled operand of das_add_upsample_nearest. */
 int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W, int C,
@@ -246,7 +253,9 @@ int das_add3(const void* a, const void* b, const void* c, void* y, int dtype, lo
  * stat_count: the population behind `stats` when it is larger than this tensor's `count` rows — SyncBN
  * (`norm_cfg=dict(type='SyncBN')`, configs/_base_/models/das.py): the caller all-reduces `stats` over the ranks
  * first and passes the global row count; 0 = count. stats_slots: `stats` is f32[stats_slots][2*C] partial sums
- * (DasConvDesc.stats_slots; 0 = 1); with more than one slot the call folds them into slot 0 in place first. */
+ * (DasConvDesc.stats_slots; 0 = 1); with more than one slot the call folds them into slot 0 in place first.
+ * y == NULL: finalize only (mean / invstd saved, running statistics and the counter advanced, nothing normalised): a
+ * layer whose output has no consumer — the last MSPN stage's finest map under a neck with start_level = 1. */
 int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
                        const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, const void* residual, int relu, float* save_mean,

@@ -215,3 +215,47 @@ def test_detector_end_to_end_f32_vs_oracle():
         np.testing.assert_allclose(np.array(r['scores']), np.array(o['scores']), rtol=2e-4)
         np.testing.assert_allclose(r['poses'].cpu().numpy(), o['poses'].numpy(), rtol=1e-4, atol=2e-3)
         np.testing.assert_allclose(r['centers'].cpu().numpy(), o['centers'].numpy(), rtol=1e-4, atol=2e-3)
+
+
+def test_unconsumed_finest_map_is_skipped_without_changing_anything_else():
+    """The neck starts at level 1 (every DAS config), so the last MSPN stage's finest map has no consumer; the reference
+    computes it anyway (mspn_mmpose.py:381-404). Here the detector does not (eval) / reduces it to the BatchNorm
+    statistics its two conv layers must keep advancing (train): neck outputs, losses, gradients and EVERY buffer of the
+    state dict must equal the run that computes the map in full."""
+    import das_amd
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    cfg = tiny_detector_cfg()
+    cfg['backbone'].update(compute_dtype='f32', num_stages=2)
+    ds = SyntheticPoseDataset(num_joints=15, img_shape=(128, 192), length=4, seed=3, max_persons=3)
+    data = collate([ds[i] for i in range(2)], device=DEV)
+    res = {}
+    for skip in (True, False):
+        torch.manual_seed(0)
+        model = das_amd.build_model(cfg)
+        model.init_weights()
+        assert model.backbone.skip_unused_finest      # (set by the detector: neck.start_level == 1)
+        model.backbone.skip_unused_finest = skip
+        model.to(DEV).eval()
+        with torch.no_grad():
+            feats_eval = [f.float().clone() for f in model.extract_feat(data['img'])]
+        model.train()
+        out = model.train_step(data, None)
+        out['loss'].backward()
+        torch.cuda.synchronize()
+        res[skip] = (feats_eval, float(out['loss']), {n: b.detach().clone() for n, b in model.named_buffers()},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    (fa, la, ba, ga), (fb, lb, bb, gb) = res[True], res[False]
+    for a, b in zip(fa, fb):
+        assert torch.equal(a, b)
+    assert abs(la - lb) <= 1e-4 * abs(lb)
+    assert set(ba) == set(bb) and set(ga) == set(gb)
+    moved = 0
+    for n in bb:
+        # (two independent runs: float atomics in the statistics reorder sums; the deepest layers of this tiny net see 48 rows)
+        torch.testing.assert_close(ba[n].float(), bb[n].float(), rtol=2e-3, atol=2e-4, msg=n)
+        if 'up4' in n and 'multi_stage_mspn.1' in n and 'running_var' in n:
+            moved += int(not torch.allclose(bb[n], torch.ones_like(bb[n])))
+    assert moved >= 2       # the skipped unit's BatchNorm layers did advance their running statistics
+    # (gradient VALUES of two independent runs of this tiny train-mode net differ by 1e-2 ... 2e-1 of their scale — ReLU masks
+    # flip with the summation order of the statistics, DESIGN section 3 — so only the set of parameters that received a
+    # gradient is compared: the skipped unit's parameters get none in either run, as in the reference)

@@ -39,8 +39,9 @@ for ev in prof.events():
     src = next((f for f in st if 'das_amd/' in f), None)
     if src is None:
         src = st[0]
-    cnt[(ev.name, src.split('das_amd/')[-1][:80])] += 1
-    stacks.setdefault((ev.name, src.split('das_amd/')[-1][:80]), st)
+    key = (ev.name, src.split('das_amd/')[-1][:80] + '  ' + str(ev.input_shapes)[:60])
+    cnt[key] += 1
+    stacks.setdefault(key, st)
 print('events without a stack:', nost)
 for (name, src), n in cnt.most_common(45):
     print(f'{n:4d}  {name:18s} {src}')
