@@ -178,11 +178,9 @@ __global__ __launch_bounds__(512) void conv_pt3_kernel(ConvP p, int total) {
   f32x4_t acc[4][4];
   // The epilogue's global operands (second gradient, raw, y) are requested by hand-issued loads — tracked loads would
   // be sunk next to their uses and waited for one by one with vmcnt(0) (loads, stores and the DMAs share the counter:
-  // cdna guide 5.7) — for CHB pixel blocks at a time: the fragment registers of the K loop are free by then. The first
-  // chunk goes out BEFORE the next tile's first two K steps are staged, so "at most 2 * DPS operations outstanding"
-  // proves it has landed while those DMAs still fly (loads retire in order).
+  // cdna guide 5.7) — for CHB pixel blocks at a time: the fragment registers of the K loop are free by then.
   constexpr int NOPS = (RES ? 1 : 0) + (BNB ? 1 : 0) + (MODE == 3 ? 1 : 0);   // operand tensors
-  constexpr int CHB = NOPS >= 3 ? 2 : 4;                                       // pixel blocks per chunk
+  constexpr int CHB = NOPS >= 2 ? 2 : 4;                                       // pixel blocks per chunk
   v4i_t lr[CHB][2], lx[CHB][2], ly[CHB][2];
   long long om[4];
   bool mok[4];
@@ -195,6 +193,11 @@ __global__ __launch_bounds__(512) void conv_pt3_kernel(ConvP p, int total) {
       om[b] = orow(mok[b] ? m : p.M - 1);   // (rows past M re-read the last row: the instruction count stays uniform)
     }
   };
+  constexpr bool HAS_R = RES, HAS_X = BNB, HAS_Y = MODE == 3;     // operand arrays this MODE can touch
+  // (sources of the unconditional loads: the tensor itself, or a valid stand-in whose values are not used)
+  const T* r_src = (RES && rg) ? rg : bx;
+  const long long r_ps = (RES && rg) ? p.rps : p.bnb_ps;
+  const T* y_src = by ? by : bx;
   auto request = [&](int b0) {
     if (NOPS == 0) return;
 #pragma unroll
@@ -202,22 +205,28 @@ __global__ __launch_bounds__(512) void conv_pt3_kernel(ConvP p, int total) {
 #pragma unroll
       for (int qd = 0; qd < 2; ++qd) {
         const int c = (qd ? cok1 : cok0) ? n0 + cl0 + qd * 32 : 0;
-        if (RES && rg) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lr[u][qd]) : "v"(rg + om[b0 + u] * p.rps + c) : "memory");
-        if (BNB) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lx[u][qd]) : "v"(bx + om[b0 + u] * p.bnb_ps + c) : "memory");
-        if (MODE == 3 && by) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ly[u][qd]) : "v"(by + om[b0 + u] * p.bnb_ps + c) : "memory");
+        // Every array of this MODE is loaded UNCONDITIONALLY (an absent tensor is replaced by a valid one — raw, or the
+        // residual — and its values are ignored): a branch around a hand-issued load makes the compiler merge two
+        // definitions of the destination, i.e. COPY a register whose load is still in flight (measured: stale y masks
+        // on the trailing wave group).
+        if constexpr (HAS_R)
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lr[u][qd]) : "v"(r_src + om[b0 + u] * r_ps + c) : "memory");
+        if constexpr (HAS_X)
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lx[u][qd]) : "v"(bx + om[b0 + u] * p.bnb_ps + c) : "memory");
+        if constexpr (HAS_Y)
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ly[u][qd]) : "v"(y_src + om[b0 + u] * p.bnb_ps + c) : "memory");
       }
   };
-  auto landed = [&](bool dmas_behind) {   // wait for the chunk requested last (the operands name its registers)
+  auto landed = [&]() {   // wait for the chunk requested last (the operands name ITS registers only)
     if (NOPS == 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int u = 0; u < CHB; ++u)
 #pragma unroll
-      for (int qd = 0; qd < 2; ++qd) {
-        if (dmas_behind) {
-          asm volatile("s_waitcnt vmcnt(%3)" : "+v"(lr[u][qd]), "+v"(lx[u][qd]), "+v"(ly[u][qd]) : "n"(2 * DPS) : "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(lr[u][qd]), "+v"(lx[u][qd]), "+v"(ly[u][qd])::"memory");
-        }
+      for (int qd = 0; qd < 2; ++qd) {   // (empty asm: ties the loaded registers to this point of the program)
+        if constexpr (HAS_R) asm volatile("" : "+v"(lr[u][qd])::"memory");
+        if constexpr (HAS_X) asm volatile("" : "+v"(lx[u][qd])::"memory");
+        if constexpr (HAS_Y) asm volatile("" : "+v"(ly[u][qd])::"memory");
       }
   };
   auto finish = [&](int b0) {
@@ -360,17 +369,20 @@ __global__ __launch_bounds__(512) void conv_pt3_kernel(ConvP p, int total) {
     tile_rows(tile);
     request(0);
     const bool more = tile + G < total;
+    if (more) setup(tile + G);          // (address arithmetic of the next tile: runs while the operands fly)
+    // The operands are waited for with vmcnt(0) BEFORE the next tile's DMAs go out: a counted wait across the two kinds
+    // is not safe — LDS-DMA loads and loads into registers do not retire in order with respect to EACH OTHER (measured:
+    // with 12 operand loads followed by 12 DMAs, "vmcnt(12)" let stale registers through on the trailing wave group).
+    landed();
     if (more) {
-      setup(tile + G);
       issue_step(buf);
       if (nk > 1) issue_step(buf == NBUF - 1 ? 0 : buf + 1);
       nbuf = buf >= 1 ? buf - 1 : NBUF - 1;    // (= buf + 2 mod 3: where step 2 of the next tile goes)
     }
-    landed(more && nk > 1);
     finish(0);
     if (CHB < 4) {
       request(CHB);
-      landed(false);
+      landed();       // (also drains the DMAs just issued: they are needed at the next barrier anyway)
       finish(CHB);
     }
 #ifdef DAS_STAMPS

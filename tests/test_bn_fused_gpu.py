@@ -30,7 +30,6 @@ CASES = [
     ('conv_glds_kernel', 2, 11, 13, 64, 128, 1, True),
     ('conv_glds3_kernel', 2, 19, 23, 128, 128, 3, False),
     ('conv_pt3_kernel', 2, 39, 43, 128, 128, 3, False),         # mode 4: recomputed mask, 14 tiles on 8 workgroups
-    ('conv_pt3_kernel', 2, 39, 43, 128, 256, 1, True),          # mode 3: second gradient + y mask, two column blocks
     ('conv_glds4_kernel<pp>', 2, 13, 17, 64, 256, 1, True),
     ('conv_glds4_kernel', 1, 16, 26, 256, 264, 3, False),
     ('conv1x1_stream_kernel', 2, 91, 93, 64, 256, 1, True),     # mode 3: residual + y mask (conv1's data gradient)

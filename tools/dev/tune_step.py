@@ -1,0 +1,61 @@
+"""Dev tool: train-step time under dispatch-threshold variations, ONE process (same box, same clocks, same model):
+for each `key=value[,key=value...]` argument the tuning is set, 2 warm-up + N timed steps run, the tuning is reset.
+The baseline (defaults) runs first, in the middle and last: the spread of those three is the noise floor.
+usage: tune_step.py [-n steps] cfg1 cfg2 ...      special keys: WGRAD_BATCH=<n> (das_amd.autograd), SLOTS=<full>,<mid> (das_amd.nn)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+from das_amd import _lib, autograd as ag, nn as dnn
+from das_amd.datasets import SyntheticPoseDataset, collate
+from das_amd.optim import FlatSGD, train_iteration
+
+args = sys.argv[1:]
+N = 10
+if args and args[0] == '-n':
+    N = int(args[1]); args = args[2:]
+lib = _lib.load()
+dev = torch.device('cuda', 0)
+model = bench.build_model(dev, num_stages=4, train=True)
+ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=16, seed=0)
+data = collate([ds[i] for i in range(16)], device=dev)
+opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=35.0)
+for _ in range(4):
+    train_iteration(model, opt, data, 2e-3)
+
+
+def run(cfg):
+    _lib.check(lib.das_tuning_reset(), 'reset')
+    wb, fs, ms_ = ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS
+    for kv in [c for c in cfg.split(',') if c]:
+        k, v = kv.split('=')
+        if k == 'WGRAD_BATCH':
+            ag.WGRAD_BATCH = int(v)
+        elif k == 'SLOTS':
+            dnn._FULL_SLOTS, dnn._MID_SLOTS = int(v.split('/')[0]), int(v.split('/')[1])
+        else:
+            _lib.check(lib.das_tuning_set(k.encode(), int(v)), k)
+    for _ in range(2):
+        train_iteration(model, opt, data, 2e-3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        train_iteration(model, opt, data, 2e-3)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / N
+    ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS = wb, fs, ms_
+    _lib.check(lib.das_tuning_reset(), 'reset')
+    return ms
+
+
+base = [run('')]
+print(f'{"defaults":60s} {base[0]:7.2f} ms', flush=True)
+half = len(args) // 2
+for i, cfg in enumerate(args):
+    if i == half:
+        base.append(run(''))
+        print(f'{"defaults (again)":60s} {base[-1]:7.2f} ms', flush=True)
+    ms = run(cfg)
+    print(f'{cfg:60s} {ms:7.2f} ms  ({ms - sum(base) / len(base):+.2f})', flush=True)
+base.append(run(''))
+print(f'{"defaults (last)":60s} {base[-1]:7.2f} ms   noise floor: {max(base) - min(base):.2f} ms')
