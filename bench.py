@@ -430,6 +430,9 @@ def attach_traffic(roof, workload, batch):
         # algorithmic_mb_per_launch
         roof['traffic_algorithmic'] = round(entry['algorithmic_mb_per_launch_same_launches'] * 1e6)
         roof['traffic_over_algorithmic'] = entry['hbm_over_algorithmic']
+    elif roof.get('algorithmic_mb_per_launch'):
+        # (round 4: the counters ran over the step's OWN launches, so the line's algorithmic bytes are the comparable figure)
+        roof['traffic_over_algorithmic'] = round(roof['traffic'] / (roof['algorithmic_mb_per_launch'] * 1e6), 3)
 
 
 def decode_workload(args, rank, world, dev, quiet=False, batch=None, steps=None, warmup=None, cpu_leg=True):

@@ -71,7 +71,7 @@ print(f'mode {mode}: occupiers hold {"a whole CU each (160 KiB LDS)" if mode == 
 base, fam0 = run(0, 0)
 print(f'N=0   reserve=0  : step {base:7.2f} ms   ' + '  '.join(f'{k.replace("conv_", "").replace("_kernel", "")} {fam0.get(k, 0):5.2f}' for k in FAMS))
 for n in Ns:
-    for reserve in (0, n):
+    for reserve in ((0, n) if n != 16 else (0, 16, 32)):
         ms, fam = run(n, reserve)
         print(f'N={n:<3d} reserve={reserve:<3d}: step {ms:7.2f} ms   ' +
               '  '.join(f'{k.replace("conv_", "").replace("_kernel", "")} {fam.get(k, 0):5.2f}' for k in FAMS), flush=True)

@@ -48,6 +48,19 @@ def run(cfg):
     return ms
 
 
+R = 1
+if args and args[0] == '-r':
+    R = int(args[1]); args = args[2:]
+if R > 1:       # interleaved repetitions: defaults, cfg1, cfg2, ..., R times; mean and range per configuration
+    res = {c: [] for c in [''] + args}
+    for rep in range(R):
+        for c in [''] + args:
+            res[c].append(run(c))
+    b = sum(res['']) / R
+    for c in [''] + args:
+        v = res[c]
+        print(f'{(c or "defaults"):60s} {sum(v) / R:7.2f} ms  ({sum(v) / R - b:+.2f})  range {min(v):.2f} .. {max(v):.2f}', flush=True)
+    sys.exit(0)
 base = [run('')]
 print(f'{"defaults":60s} {base[0]:7.2f} ms', flush=True)
 half = len(args) // 2
