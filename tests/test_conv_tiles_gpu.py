@@ -374,6 +374,27 @@ def test_stream_affine_residual(cin, cout):
     np.testing.assert_allclose(nchw(y).numpy(), F.relu(aff_q + q(res)).numpy(), **TOL)
 
 
+@pytest.mark.parametrize('cin,cout', [(64, 256), (128, 512), (256, 64), (256, 1024), (64, 64)])
+def test_stream_and_c64_plain_outputs_are_bf16_exact(cin, cout):
+    """The two persistent kernels that carry most of the step's convolution bytes, held to the bf16-exact bar
+    (assert_bf16_exact): conv1x1_stream_kernel on every (K, Cout) class of the step (plain / statistics mode stores the
+    rounded f32 sum), and conv3x3_c64_kernel."""
+    o = ops()
+    B, H, W = 2, 96, 104
+    x = cases.randn(231, B, cin, H, W)
+    w = cases.randn(232, cout, cin, 1, 1) / cin ** 0.5
+    stats = torch.zeros(2 * cout, device=DEV)
+    y = o.conv2d(nhwc(x), o.pack_weight(w.to(DEV), BF), 1, 1, 1, 0, stats=stats)
+    assert o.last_kernel() == 'conv1x1_stream_kernel', o.last_kernel()
+    assert_bf16_exact(nchw(y), conv_ref(x, w, 1, 0))
+    if cin == 64 and cout == 64:
+        w3 = cases.randn(233, 64, 64, 3, 3) / 24
+        with o.tuning(**{'conv.c64_mintiles': 1}):
+            y3 = o.conv2d(nhwc(x), o.pack_weight(w3.to(DEV), BF), 3, 3, 1, 1)
+            assert o.last_kernel() == 'conv3x3_c64_kernel', o.last_kernel()
+        assert_bf16_exact(nchw(y3), conv_ref(x, w3, 1, 1))
+
+
 # ---------------------------------------------------------------- stride-2 data gradient by output parity
 S2 = [
     # B, H, W, Cin, Cout, k, pad
