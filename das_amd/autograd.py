@@ -604,13 +604,15 @@ class GroupNormReLUFn(Function):
 class MaxPoolFn(Function):
     @staticmethod
     def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return ops.maxpool3x3s2(x)
+        y, idx = ops.maxpool3x3s2(x, return_argmax=True)     # (one byte per output: the backward gathers, x is not kept)
+        ctx.save_for_backward(idx)
+        ctx.hw = (x.shape[1], x.shape[2])
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        return ops.maxpool3x3s2_backward(x, dy.contiguous())
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool3x3s2_backward_argmax(dy.contiguous(), idx, *ctx.hw)
 
 
 class BilinearUpFn(Function):

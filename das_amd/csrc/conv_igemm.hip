@@ -1084,7 +1084,12 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
   constexpr int WM = 8 / WN, TM = 64, PB = TM / WM / 16;    // 16-pixel blocks per wave and tile
   constexpr int K = KB * 32, SUBS = (K + 63) / 64;
   constexpr int SUBB = TM * 128, STAGE = SUBS * SUBB;       // bytes
-  constexpr int NS = 4, AHEAD = 3;                          // LDS stages, tiles in flight
+  // LDS stages / tiles in flight. K = 64: a stage is 8 KiB, so three tiles ahead are 24 KiB per workgroup (two per CU);
+  // DAS_STREAM_K64_NS (dev builds, tools/dev/stream_depth_ab.py) deepens that pipeline for an A/B run.
+#ifndef DAS_STREAM_K64_NS
+#define DAS_STREAM_K64_NS 4
+#endif
+  constexpr int NS = KB == 2 ? DAS_STREAM_K64_NS : 4, AHEAD = NS - 1;
   constexpr int IPL = SUBS * 4;                             // DMA instructions per loader wave and tile
   constexpr unsigned OOB = 0xFFFFFFF0u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1114,12 +1119,14 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
     for (int i = 0; i < AHEAD && i < mine; ++i) issue(first + i * tstride, i);
     for (int i = 0; i < mine; ++i) {
       const int later = min(mine - 1 - i, AHEAD - 1);   // tiles issued after tile i that may still be in flight
-      if (later >= 2) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPL) : "memory");
-      } else if (later == 1) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPL) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      switch (later) {                                  // (vmcnt takes an immediate)
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPL) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPL) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPL < 63 ? 3 * IPL : 63) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * IPL < 63 ? 4 * IPL : 63) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * IPL < 63 ? 5 * IPL : 63) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * IPL < 63 ? 6 * IPL : 63) : "memory"); break;
       }
       __builtin_amdgcn_s_barrier();   // tile i is in LDS; the other waves are done with tile i - 1
       if (i + AHEAD < mine) issue(first + (i + AHEAD) * tstride, (i + AHEAD) % NS);
@@ -1383,7 +1390,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
   const int wn = p.Cout >= 256 ? 8 : p.Cout / 32, ncol = p.Cout >= 256 ? p.Cout / 256 : 1;
   const int ntiles = (p.M + 63) / 64;
   const int kb = p.Cin / 32;
-  const size_t sm = 4 * (size_t)((p.Cin + 63) / 64) * 64 * 128 + 8 * 64 * sizeof(float);   // four stages of 64 pixel rows + the waves' reduced sums
+  const size_t sm = (size_t)(p.Cin == 64 ? DAS_STREAM_K64_NS : 4) * ((p.Cin + 63) / 64) * 64 * 128 + 8 * 64 * sizeof(float);   // the stages of 64 pixel rows + the waves' reduced sums
   auto go = [&](auto kern) -> bool {
     static int per_cu = 0;   // (one static per template instance: the lambda is instantiated per kernel type)
     if (per_cu == 0) {

@@ -599,11 +599,17 @@ def to_nchw_f32(x, c0=0, Cn=None):
     return y
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, return_argmax=False):
+    """return_argmax: also the winning tap of every output element (u8, same shape as y) for maxpool3x3s2_backward_argmax."""
     _need_gpu(x)
     B, H, W, Cc = x.shape
     assert x.is_contiguous()
     y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc, dtype=x.dtype, device=x.device)
+    if return_argmax:
+        idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.load().das_maxpool3x3s2_argmax(_ptr(x), _ptr(y), _ptr(idx), _DT[x.dtype], B, H, W, Cc, _stream()),
+                   'das_maxpool3x3s2_argmax')
+        return y, idx
     _lib.check(_lib.load().das_maxpool3x3s2(_ptr(x), _ptr(y), _DT[x.dtype], B, H, W, Cc, _stream()), 'das_maxpool3x3s2')
     return y
 
@@ -699,6 +705,18 @@ def maxpool3x3s2_backward(x, dy):
     dx = torch.empty_like(x)
     _lib.check(_lib.load().das_maxpool3x3s2_backward(_ptr(x), _ptr(dy), _ptr(dx), _DT[x.dtype], B, H, W, Cc, _stream()),
                'das_maxpool3x3s2_backward')
+    return dx
+
+
+def maxpool3x3s2_backward_argmax(dy, idx, H, W):
+    """dx (B, H, W, C) from dy and the forward's winning taps (maxpool3x3s2(x, return_argmax=True))."""
+    _need_gpu(dy, idx)
+    B, Ho, Wo, Cc = dy.shape
+    assert dy.is_contiguous() and idx.is_contiguous() and idx.shape == dy.shape and idx.dtype == torch.uint8
+    assert Ho == (H - 1) // 2 + 1 and Wo == (W - 1) // 2 + 1
+    dx = torch.empty(B, H, W, Cc, dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().das_maxpool3x3s2_backward_argmax(_ptr(dy), _ptr(idx), _ptr(dx), _DT[dy.dtype], B, H, W, Cc, _stream()),
+               'das_maxpool3x3s2_backward_argmax')
     return dx
 
 

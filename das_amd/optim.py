@@ -167,7 +167,7 @@ class FlatSGD:
         for i, sl in enumerate(self._conv_slots):
             O, KH, KW, I = sl.cl_shape
             tab[i] = (sl.off, O, I, KH, KW, tiles)
-            tiles += KH * KW * ((O + 31) // 32) * ((I + 31) // 32)
+            tiles += KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
         self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.flat_p.device)
         self._tiles = tiles
 

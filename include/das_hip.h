@@ -194,7 +194,8 @@ int das_bn_backward_apply(const void* dz, const void* raw, int dtype, long long 
  * entry: fwd_dst[off ...] = the same layout cast to dtype (fwd_dst may be NULL: the f32 path reads the
  * master directly); dgrad_dst[off ...] = (Cin,KH,KW,Cout) with both tap axes flipped — the operand of the
  * data-gradient conv. entries_dev: device copy of the table, tile_start = running sum of
- * KH*KW*ceil(O/32)*ceil(I/32); total_tiles = the final sum. Replaces the per-layer permute / flip / cast
+ * KH*KW*ceil(O/64)*ceil(I/64); total_tiles = the final sum. O and I multiples of 4, off a multiple of 4 elements
+ * (16-byte accesses). Replaces the per-layer permute / flip / cast
  * that torch (cuDNN/MIOpen) does internally for every conv of `loss.backward()`. */
 typedef struct {
   long long off;
@@ -233,6 +234,12 @@ int das_unpack_nhwc_to_nchw(const void* x, float* y, int dtype, int B, int C, in
 
 /* 3x3 stride-2 pad-1 max pooling (mspn_mmpose.py:553 `MaxPool2d`). */
 int das_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream);
+/* The same, also recording the winning tap (0..8 in scan order, the FIRST maximum) of every output element: idx is
+ * u8[B*Ho*Wo*C]. das_maxpool3x3s2_backward_argmax(dy, idx) -> dx then gathers from 80 MB instead of re-deriving the maxima
+ * from x (das_maxpool3x3s2_backward: 338 us per step at B = 16); both backward routes give the same bits. */
+int das_maxpool3x3s2_argmax(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, void* stream);
+int das_maxpool3x3s2_backward_argmax(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C,
+                                     void* stream);
 
 /* Bilinear upsampling, align_corners=True, to (Ho,Wo) (mspn_mmpose.py:385-389). */
 int das_upsample_bilinear_ac(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho, int Wo,

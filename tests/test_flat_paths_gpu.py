@@ -43,7 +43,7 @@ def test_pack_conv_weights_one_launch(dtype):
     for i, w in enumerate(ws):
         O, I, KH, KW = w.shape
         tab[i] = (off, O, I, KH, KW, tiles)
-        tiles += KH * KW * ((O + 31) // 32) * ((I + 31) // 32)
+        tiles += KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
         chunks.append(w.permute(0, 2, 3, 1).reshape(-1))
         off += w.numel()
     flat = torch.cat(chunks).to(DEV)

@@ -67,6 +67,14 @@ def test_pool_and_upsample_backward(dtype):
     y.backward(dy)
     dx = o.maxpool3x3s2_backward(nhwc(a.detach(), dtype), nhwc(dy, dtype))
     close(nchw(dx).numpy(), a.grad.numpy(), dtype)
+    # the route the training path takes since round 4: the forward records the winning tap (one byte per output), the backward
+    # gathers from (dy, idx). Same forward values, same gradient BITS as the route that re-derives the maxima from x, ties included.
+    for (hh, ww) in ((13, 17), (16, 26), (7, 1)):
+        a2 = F.relu(rnd(cases.randn(18, 2, 16, hh, ww), dtype))
+        y2, idx = o.maxpool3x3s2(nhwc(a2, dtype), return_argmax=True)
+        assert torch.equal(y2, o.maxpool3x3s2(nhwc(a2, dtype))) and idx.dtype == torch.uint8 and int(idx.max()) <= 8
+        dy2 = nhwc(rnd(cases.randn(19, *nchw(y2).shape), dtype), dtype)
+        assert torch.equal(o.maxpool3x3s2_backward_argmax(dy2, idx, hh, ww), o.maxpool3x3s2_backward(nhwc(a2, dtype), dy2))
 
     b = rnd(cases.randn(13, 2, 16, 7, 9), dtype).requires_grad_(True)
     up = F.interpolate(b, size=(13, 17), mode='bilinear', align_corners=True)

@@ -38,11 +38,15 @@ def run(cfg):
     for _ in range(2):
         train_iteration(model, opt, data, 2e-3)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(N):
+    # per-step GPU time (events on the stream), MEDIAN over the steps: robust against the occasional slow step of a noisy box
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
+    evs[0].record()
+    for i in range(N):
         train_iteration(model, opt, data, 2e-3)
+        evs[i + 1].record()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3 / N
+    ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(N))
+    ms = ts[N // 2]
     ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS = wb, fs, ms_
     _lib.check(lib.das_tuning_reset(), 'reset')
     return ms
@@ -59,7 +63,8 @@ if R > 1:       # interleaved repetitions: defaults, cfg1, cfg2, ..., R times; m
     b = sum(res['']) / R
     for c in [''] + args:
         v = res[c]
-        print(f'{(c or "defaults"):60s} {sum(v) / R:7.2f} ms  ({sum(v) / R - b:+.2f})  range {min(v):.2f} .. {max(v):.2f}', flush=True)
+        med = sorted(v)[R // 2]
+        print(f'{(c or "defaults"):60s} median {med:7.2f} ms  ({med - sorted(res[""])[R // 2]:+.2f})  range {min(v):.2f} .. {max(v):.2f}', flush=True)
     sys.exit(0)
 base = [run('')]
 print(f'{"defaults":60s} {base[0]:7.2f} ms', flush=True)
