@@ -831,7 +831,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, long long rows, int C,
                                                            float* __restrict__ sums) {
   constexpr int EPV = Elem<T>::EPV;
-  constexpr int U = NT > 256 ? 2 : 4;
+  constexpr int U = NT > 256 ? 2 : 4;   // (8 rows in flight per thread measured no better: 69 / 56 / 45 us against 67 / 49 / 42 in the step, round 4)
   extern __shared__ float sred[];  // [2C]
   const int VC = C / EPV;
   for (int i = threadIdx.x; i < 2 * C; i += NT) sred[i] = 0.f;
