@@ -119,3 +119,51 @@ def test_paramwise_groups_and_lr_schedule():
     assert step_lr(2e-3, 0, 125) == pytest.approx(2e-3 * (1 - 0.5 * (2 / 3)))
     assert step_lr(2e-3, 0, 250) == pytest.approx(2e-3)
     assert step_lr(2e-3, 16, 10 ** 6) == pytest.approx(2e-4) and step_lr(2e-3, 20, 10 ** 6) == pytest.approx(2e-5)
+
+
+def _mark_worker(rank, world, port, ret):
+    """FlatSGD.mark_complete (what a replayed backward graph calls instead of the completion hooks): gradients written
+    into the flat buffer behind autograd's back, reported complete in one call — the buckets must go out early, in the
+    same order on both ranks, and sum correctly; a bucket with a parameter that never fires stays end-only."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from das_amd.optim import FlatSGD
+    torch.manual_seed(0)
+    trunk = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.Conv2d(16, 8, 1))
+    head = torch.nn.Linear(8, 4)
+    unused = torch.nn.Linear(3, 3)
+    holder = torch.nn.ModuleDict(dict(trunk=trunk, head=head, unused=unused))
+    opt = FlatSGD(holder, lr=0.1, bucket_mb=0, overlap=True, comm_reserved_cus=0)
+    trunk_slots = [p._das_slot for p in trunk.parameters()]
+    ok, early = True, []
+    for it in range(3):
+        opt.zero_grad()
+        # the head trains through autograd (its hooks fire) ...
+        head(torch.full((2, 8), float(rank + 1))).sum().backward()
+        # ... the trunk's gradients are written straight into the flat buffer, as a replayed graph does
+        for i, p in enumerate(trunk.parameters()):
+            p.grad.add_(float((rank + 1) * (i + 1)))
+        before = opt.overlapped_launches
+        opt.mark_complete(trunk_slots)
+        early.append(opt.overlapped_launches - before)
+        opt.all_reduce_grads()
+        for i, p in enumerate(trunk.parameters()):
+            ok = ok and torch.allclose(p.grad, torch.full_like(p.grad, 3.0 * (i + 1)))
+        ok = ok and torch.allclose(head.weight.grad, torch.full_like(head.weight.grad, 2.0 * (1 + 2)))
+        ok = ok and float(unused.weight.grad.abs().sum()) == 0.0
+    ret[rank] = (ok, early, sum(opt._endonly), len(opt.buckets))
+    dist.destroy_process_group()
+
+
+def test_mark_complete_drives_the_buckets_world2_gloo():
+    mp.set_start_method('spawn', force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31000 + os.getpid() % 1000
+    mp.spawn(_mark_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        ok, early, n_end, nb = ret[r]
+        assert ok
+        assert early[0] == 0 and early[1] > 0 and early[2] == early[1]      # learnt in iteration 0, early from then on
+        assert 0 < n_end < nb
+    assert ret[0][1] == ret[1][1]

@@ -130,3 +130,39 @@ def test_deferred_pipeline_records_the_image_ops_without_a_gpu(tmp_path):
     assert len(pickle.dumps(plan.with_frame(None))) < 2000          # (what travels in the queue message beside the ring slot)
     for k in ('gt_poses_3d', 'gt_bboxes', 'depths'):
         assert a[k].shape[0] == b[k].shape[0] > 0 and bool((a[k] == b[k]).all())
+
+
+def test_frame_ring_fits_itself_to_the_shared_memory_it_finds(monkeypatch, tmp_path):
+    """48 x 8 MiB per worker does not fit a 64 MiB /dev/shm. The ring shrinks to what fits (keeping a quarter
+    free), or moves to the ordinary temp directory when not even the minimum fits — with a warning, never a SIGBUS — and
+    its file disappears as soon as `unlink()` is called (the mappings stay valid)."""
+    import os
+    import warnings
+    from collections import namedtuple
+    import numpy as np
+    from das_amd import loader
+    Stat = namedtuple('Stat', 'f_bavail f_frsize')
+    real = os.statvfs
+
+    def fake(free):
+        return lambda p: Stat(free // 4096, 4096) if str(p) == '/dev/shm' else real(p)
+    slot = 1 << 20
+    monkeypatch.setattr(os, 'statvfs', fake(24 << 20))          # room for 18 slots of 1 MiB (three quarters of 24)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ring = loader._FrameRing.create(48, slot, pin=False)
+    assert ring.slots == 18 and any('shrunk' in str(x.message) for x in w)
+    assert os.path.exists(ring.path) and ring.path.startswith('/dev/shm')
+    ring.slot(17, 16)[:] = np.arange(16, dtype=np.uint8)
+    path = ring.path
+    ring.unlink()
+    assert ring.path is None and not os.path.exists(path)
+    assert ring.slot(17, 16).tolist() == list(range(16))         # the mapping outlives the name
+    ring.close()
+    monkeypatch.setattr(os, 'statvfs', fake(4 << 20))            # not even 8 slots: the temp directory takes the ring
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ring = loader._FrameRing.create(48, slot, pin=False)
+    assert not ring.path.startswith('/dev/shm') and 8 <= ring.slots <= 16 and any('too little' in str(x.message) for x in w)
+    ring.close()
+    assert ring.path is None
