@@ -1,28 +1,31 @@
-// Persistent 256 x 128 tile convolution (included by conv_igemm.hip inside its anonymous namespace).
+// Persistent 256 x 128 tile convolution (included by conv_igemm.hip inside its anonymous namespace). OFF by default
+// (das_tuning key conv.pt3_mintiles): measured within +-5 % of the one-tile kernels on the step's shapes, DESIGN 2.2f.
 //
 // conv_glds3_kernel<PP> runs its K loop at the rate of the guide's 8-phase template, but a launch of it is a sequence
-// of ROUNDS of one-tile workgroups, and per tile nothing overlaps the first-stage latency (3.8 us), the C tile's trip
-// through LDS + the write burst (4.7 us) or the under-filled last round (416 tiles on 256 CUs): for the layers with
-// K = 512 ... 1152 that is as long as the K loop itself (profiles/r03_conv_phase_stamps.txt). This kernel keeps the same
-// ping-pong K loop (two wave groups half a step apart, three 48-KiB stages, LDS-DMA two steps ahead) and makes the
-// workgroup PERSISTENT:
-//   * one workgroup per CU walks tiles logical + i * gridDim.x (XCD-remapped: the 32 workgroups of an XCD work on 32
-//     neighbouring tiles at any time, so the 3x3 halo rows and the weights they share come from that XCD's L2);
-//   * the DMA stream never drains: the steps are numbered through the tile boundaries, the last two K steps of a tile
-//     already stage the first two of the next one (its address state is rebuilt by the issuing wave meanwhile);
-//   * the epilogue goes straight from the accumulators to global memory — no C tile in LDS, so the stages stay free
-//     for the running prefetch and no barrier is needed: the weight rows are STAGED in a permuted order
-//     (wperm) that makes an accumulator lane own EIGHT consecutive channels of a pixel = one 16-byte store (the
-//     permutation conv1x1_stream_kernel applies to its register-resident weights). The stores are fire-and-forget:
-//     the next tile's K loop starts while they drain;
+// of ROUNDS of one-tile workgroups, and per tile nothing overlaps the first-stage latency (4-5 us), the C tile's trip
+// through LDS + the write burst (3.6 us) or the under-filled last round (416 tiles on 256 CUs). This kernel keeps the
+// same ping-pong K loop (two wave groups half a step apart, three 48-KiB stages, LDS-DMA two steps ahead: the loop body
+// is the one-tile kernel's, step for step) and makes the workgroup PERSISTENT:
+//   * one workgroup per usable CU walks tiles logical + i * gridDim.x (XCD-remapped: the 32 workgroups of an XCD work on
+//     32 neighbouring tiles at any time, so the 3x3 halo rows and the weights they share come from that XCD's L2);
+//   * at a tile boundary — both wave groups aligned, every stage free — the next tile's address state is rebuilt, its
+//     first two K steps are staged, and THEN the finished tile is stored: the DMA latency overlaps the epilogue;
+//   * the epilogue goes straight from the accumulators to global memory — no C tile in LDS, no barrier: the weight rows
+//     are STAGED in a permuted order (wperm) that makes an accumulator lane own EIGHT consecutive channels of a pixel =
+//     one 16-byte store (the permutation conv1x1_stream_kernel applies to its register-resident weights). The stores
+//     are fire-and-forget: the next tile's K loop starts while they drain;
+//   * the epilogue's global operands (second gradient, raw, y) are hand-issued into the dead fragment registers, all
+//     loads of a chunk in flight together, and waited for with vmcnt(0) BEFORE the next tile's DMAs are issued (a
+//     counted wait must not span LDS-DMA loads and register loads: they do not retire in order with respect to each
+//     other); every load is unconditional (a branch around a hand-issued load makes the compiler copy a register that is
+//     still in flight);
 //   * BatchNorm statistics / the fused BatchNorm-backward sums are carried in registers through the tiles (a
 //     workgroup keeps its column block: gridDim.x is a multiple of the column-block count) and leave once per launch.
-// vmcnt counts this wave's DMAs, epilogue loads and stores in one counter; loads retire in order among themselves, so
-// "at most N operations outstanding" still proves that all but the N most recent loads have landed — stores in flight
-// only make the counted waits conservative (cdna guide 5.7; conv1x1_stream_kernel uses the same argument).
+// Inside the K loop the counted vmcnt waits see DMAs only (same kind: in order); stores still draining from the previous
+// epilogue only make them conservative.
 // MODE as conv1x1_stream_kernel: 0 plain / BatchNorm statistics, 1 scale / shift (+ReLU), 2 residual (+ReLU),
-// 3 fused BatchNorm-backward reduction with the mask from the saved output (optional residual, no y = no mask),
-// 4 the same with the mask recomputed from raw, 5 scale / shift + residual (+ReLU).
+// 3 fused BatchNorm-backward reduction with the mask from the saved output (optional residual, no y = no mask; NOT
+// dispatched: see try_launch_pt3), 4 the same with the mask recomputed from raw, 5 scale / shift + residual (+ReLU).
 
 // LDS weight row r holds output channel (column block base) + wperm(r): MFMA row R of A tile a = 2 qd + a1 is channel
 // qd * 32 + (R >> 2) * 8 + a1 * 4 + (R & 3), so accumulator lane (g4 = R >> 2, j = R & 3) owns channels
