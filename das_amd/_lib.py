@@ -106,6 +106,7 @@ SIGNATURES = {
     'das_pack_nchw_to_nhwc': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'das_unpack_nhwc_to_nchw': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_maxpool3x3s2': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'das_upsample_bilinear_ac_stats': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     'das_maxpool3x3s2_argmax': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_maxpool3x3s2_backward_argmax': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_upsample_bilinear_ac': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -303,6 +303,69 @@ class ConvBNTrainFn(Function):
         return dx, dw, dgamma, dbeta, dres, None, None, None
 
 
+class UpConvBNTrainFn(Function):
+    """bilinear upsample (align_corners) -> bias-free 1x1 conv -> train-mode BatchNorm (+ residual) (+ ReLU): the `up_conv`
+    branch of MSPN's upsample units, mspn_mmpose.py:385-389, with the first two steps exchanged. Both are linear maps, one
+    over pixels and one over channels, so conv(upsample(x)) == upsample(conv(x)) exactly in real arithmetic (in floating
+    point up to the order of summation, ~1e-6 relative in f32): the conv, its data gradient and its weight gradient then
+    run on the quarter-size tensor, and the upsampling kernel — which now writes the pre-norm tensor — reduces the
+    BatchNorm statistics the conv epilogue used to reduce (das_upsample_bilinear_ac_stats)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, conv, bn, relu, Ho, Wo):
+        from .nn import bn_stats_buffer_rows, packed_weight, sync_stats
+        w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+        cout = w.shape[0]
+        lo = ops.conv2d(x, w, 1, 1, 1, 0)
+        rows = x.shape[0] * Ho * Wo
+        stats = bn_stats_buffer_rows(rows, cout, x.device)
+        raw = ops.upsample_bilinear_ac(lo, Ho, Wo, stats=stats)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        world, stat_count = _sync_world(bn), 0
+        if world > 1:
+            _check_equal_rows(rows)
+            stats = sync_stats(stats, cout, _all_reduce)
+            stat_count = rows * world
+        y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,
+                                             residual=residual, relu=relu,
+                                             num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count)
+        bn.__dict__.pop('_das_cache', None)
+        ctx.save_for_backward(x, raw, y if residual is not None else None, mean, invstd, gamma, weight, beta)
+        ctx.cfg = (relu, residual is not None, conv, bn)
+        ctx.world = world
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .nn import packed_weight_dgrad
+        x, raw, y, mean, invstd, gamma, weight, beta = ctx.saved_tensors
+        relu, has_res, conv, bn = ctx.cfg
+        dy = dy.contiguous()
+        ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
+        direct = ga is not None and ba is not None
+        if ctx.world > 1:
+            direct = False
+            draw, dres, dgamma, dbeta = ops.bn_train_backward_sync(dy, y if (relu and has_res) else None, raw, mean, invstd,
+                                                                   gamma, relu, has_res, beta, _all_reduce, ctx.world)
+        else:
+            draw, dres, dgamma, dbeta = ops.bn_train_backward(dy, y if (relu and has_res) else None, raw, mean, invstd,
+                                                              gamma, relu, has_res, beta=beta,
+                                                              dgamma_acc=ga[1] if direct else None,
+                                                              dbeta_acc=ba[1] if direct else None)
+        if direct:
+            dgamma = dbeta = None
+            ga[0].fired()
+            ba[0].fired()
+        dlo = ops.upsample_bilinear_ac_backward(draw, x.shape[1], x.shape[2])
+        dw = _wgrad(x, dlo, conv.weight, 1, 1, 0) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad(dlo, packed_weight_dgrad(conv, x.dtype), 1, 1, 1, 0, (x.shape[1], x.shape[2]))
+            if dx.shape[-1] != x.shape[-1]:
+                dx = dx[..., :x.shape[-1]]
+        return dx, dw, dgamma, dbeta, dres, None, None, None, None, None
+
+
 class ConvBNTrainSkipFn(Function):
     """ConvBNTrainFn that also hands its input through as a second output: y, x_skip = f(x).
 

@@ -99,11 +99,6 @@ class DownsampleModule(nn.Module):
         return tuple(out)
 
 
-def ops_upsample(x, Ho, Wo):
-    from . import ops
-    return ops.upsample_bilinear_ac(x, Ho, Wo)
-
-
 class UpsampleUnit(nn.Module):
     def __init__(self, ind, num_units, in_channels, unit_channels=256, gen_skip=False, gen_cross_conv=False,
                  norm_cfg=dict(type='BN'), out_channels=64):
@@ -132,8 +127,7 @@ class UpsampleUnit(nn.Module):
         with torch.no_grad():
             nnops.conv_bn_stats_only(x, self.in_skip.conv, self.in_skip.bn)
             if self.ind > 0:
-                up = ops_upsample(up_x, x.shape[1], x.shape[2])
-                nnops.conv_bn_stats_only(up, self.up_conv.conv, self.up_conv.bn)
+                nnops.upsample_conv_bn_stats_only(up_x, x.shape[1], x.shape[2], self.up_conv.conv, self.up_conv.bn)
         return None
 
     def forward(self, x, up_x):
@@ -144,9 +138,10 @@ class UpsampleUnit(nn.Module):
             lat = conv_bn(x, self.in_skip.conv, self.in_skip.bn, skip_through=thru)
             if thru:
                 lat, x = lat
-            up = nnops.upsample_bilinear(up_x, x.shape[1], x.shape[2])
-            # relu(in_skip(x) + up_conv(up)): add + ReLU fused into up_conv's epilogue
-            out = conv_bn(up, self.up_conv.conv, self.up_conv.bn, relu=True, residual=lat)
+            # relu(in_skip(x) + up_conv(upsample(up_x))): add + ReLU fused into up_conv's BatchNorm pass; in train mode the
+            # 1x1 conv runs before the upsampling, on a quarter of the pixels (nn.upsample_conv_bn)
+            out = nnops.upsample_conv_bn(up_x, x.shape[1], x.shape[2], self.up_conv.conv, self.up_conv.bn, relu=True,
+                                         residual=lat)
         else:
             out = conv_bn(x, self.in_skip.conv, self.in_skip.bn, relu=True, skip_through=thru)
             if thru:

@@ -119,6 +119,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- per-channel partial sums of a workgroup, met in LDS WITHOUT atomics.
+// The reduction passes keep a channel vector per thread and NT / VC "pixel lanes" side by side; every thread ends with EPV
+// (or 2 EPV) partial sums. ds_add_f32 from every lane runs at about half a lane per clock per CU (measured round 4,
+// tools/dev/upstats_bench.py: a kernel of many small workgroups spent more time there than on its traffic; a
+// 256-thread workgroup pays ~4 us, a 1024-thread one ~17 us). Instead: plain 16-byte stores into part[lane][width] (one
+// writer per word), a barrier, and each of the `width` outputs folded by one thread over the lanes.
+template <int EPV>
+__device__ __forceinline__ void lds_put(float* part, int width, int lane, int col, const float (&s)[EPV]) {
+  float* row = part + (size_t)lane * width + col;
+#pragma unroll
+  for (int j = 0; j < EPV; j += 4) *reinterpret_cast<float4*>(row + j) = make_float4(s[j], s[j + 1], s[j + 2], s[j + 3]);
+}
+__device__ __forceinline__ float lds_fold(const float* part, int width, int lanes, int i) {
+  float a = 0.f;
+  for (int r = 0; r < lanes; ++r) a += part[(size_t)r * width + i];
+  return a;
+}
+
 // ---- ragged multi-level rows (DasLevels): row m -> level, image, (h, w), plane origin
 struct LvGeom {
   int l, b, h, w, H, W;

@@ -1,6 +1,7 @@
 // HBM-bound NHWC helper kernels: layout pack/unpack, max-pool, bilinear / nearest upsampling,
 // adds. One 16-byte channel vector per thread (8 bf16 / 4 f32), grid-stride, fully coalesced.
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 
@@ -159,35 +160,81 @@ __global__ void maxpool_bwd_argmax_kernel(const T* __restrict__ dy, const unsign
   }
 }
 
-// torch upsample_bilinear2d, align_corners=True (area_pixel_compute_scale: (in-1)/(out-1) in f32)
-template <typename T>
-__global__ void bilinear_ac_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho,
-                                   int Wo, float sh, float sw) {
+// torch upsample_bilinear2d, align_corners=True (area_pixel_compute_scale: (in-1)/(out-1) in f32).
+// Optionally with the conv epilogue's BatchNorm statistics attached: per-channel sum / sum of squares of the STORED
+// (rounded) outputs into stats[slots][2][C] (workgroup b adds into slot b % slots). Used where a bias-free 1x1 conv follows
+// the upsampling (MSPN's up_conv, mspn_mmpose.py:385-389): the two are linear and commute, so the conv runs on the
+// quarter-size tensor and THIS kernel produces the pre-norm tensor the BatchNorm layer sees.
+// One workgroup = a run of PIX output pixels x all channels; a thread keeps its channel vector.
+// The per-thread partial sums meet in LDS as plain stores ([pixel lane][2C], one writer per word) and are folded by a second
+// sweep (common.h: lds_put / lds_fold). STATS = false is the plain resampling (stats / slots unused, no LDS).
+template <typename T, bool STATS>
+__global__ __launch_bounds__(TPB) void bilinear_ac_stats_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C,
+                                                               int Ho, int Wo, float sh, float sw, int pix_per_block,
+                                                               float* __restrict__ stats, int slots) {
 #pragma clang fp contract(off)
   constexpr int EPV = Elem<T>::EPV;
+  constexpr int NT = TPB;
+  extern __shared__ float part[];   // [PL][2C]
   const int VC = C / EPV;
-  const long long total = (long long)B * Ho * Wo * VC;
-  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-    const int v = (int)(i % VC);
-    long long pix = i / VC;
-    const int wo = (int)(pix % Wo);
-    pix /= Wo;
-    const int ho = (int)(pix % Ho);
-    const long long b = pix / Ho;
-    const float h1r = sh * ho, w1r = sw * wo;
-    const int h1 = (int)h1r, w1 = (int)w1r;
-    const int h1p = (h1 < H - 1) ? 1 : 0, w1p = (w1 < W - 1) ? 1 : 0;
-    const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
-    const T* base = x + ((b * H + h1) * W + w1) * C + v * EPV;
-    float a[EPV], bb[EPV], c[EPV], d[EPV], o[EPV];
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base), a);
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + (long long)w1p * C), bb);
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + (long long)h1p * W * C), c);
-    Elem<T>::unpack(*reinterpret_cast<const uint4*>(base + ((long long)h1p * W + w1p) * C), d);
+  const int VCB = min(VC, NT), PL = NT / VCB, pl = threadIdx.x / VCB;
+  // (pixel indices in 32 bits — the launcher checks — so the row / column split is two 32-bit divisions, not 64-bit ones)
+  const unsigned npix = (unsigned)B * Ho * Wo;
+  const unsigned p0 = blockIdx.x * (unsigned)pix_per_block, p1 = min(npix, p0 + pix_per_block);
+  for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
+    float s[EPV], q[EPV];
 #pragma unroll
-    for (int j = 0; j < EPV; ++j) o[j] = h0l * (w0l * a[j] + w1l * bb[j]) + h1l * (w0l * c[j] + w1l * d[j]);
-    *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(o);
+    for (int j = 0; j < EPV; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    constexpr int U = 4;   // pixels in flight per thread (the loop is bound by load latency, not by arithmetic)
+    for (unsigned pix0 = p0 + pl; pix0 < p1; pix0 += U * PL) {
+      uint4 ra[U], rb[U], rc[U], rd[U];
+      float h1l[U], w1l[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned pix = min(pix0 + (unsigned)u * PL, p1 - 1);   // (a clamped duplicate is loaded and dropped)
+        const unsigned t = pix / (unsigned)Wo, wo = pix - t * Wo;
+        const unsigned b = t / (unsigned)Ho, ho = t - b * Ho;
+        const float h1r = sh * (int)ho, w1r = sw * (int)wo;
+        const int h1 = (int)h1r, w1 = (int)w1r;
+        const int h1p = (h1 < H - 1) ? 1 : 0, w1p = (w1 < W - 1) ? 1 : 0;
+        h1l[u] = h1r - h1;
+        w1l[u] = w1r - w1;
+        const T* base = x + (((long long)b * H + h1) * W + w1) * C + v * EPV;
+        ra[u] = *reinterpret_cast<const uint4*>(base);
+        rb[u] = *reinterpret_cast<const uint4*>(base + (long long)w1p * C);
+        rc[u] = *reinterpret_cast<const uint4*>(base + (long long)h1p * W * C);
+        rd[u] = *reinterpret_cast<const uint4*>(base + ((long long)h1p * W + w1p) * C);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned pix = pix0 + (unsigned)u * PL;
+        if (pix >= p1) break;
+        const float h0l = 1.f - h1l[u], w0l = 1.f - w1l[u];
+        float a[EPV], bb[EPV], c[EPV], d[EPV], o[EPV];
+        Elem<T>::unpack(ra[u], a);
+        Elem<T>::unpack(rb[u], bb);
+        Elem<T>::unpack(rc[u], c);
+        Elem<T>::unpack(rd[u], d);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) o[j] = h0l * (w0l * a[j] + w1l[u] * bb[j]) + h1l[u] * (w0l * c[j] + w1l[u] * d[j]);
+        const uint4 packed = Elem<T>::pack(o);
+        if (y) *reinterpret_cast<uint4*>(y + ((long long)pix * VC + v) * EPV) = packed;
+        if (STATS) {
+          Elem<T>::unpack(packed, o);     // the statistics see the values as stored
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) { s[j] += o[j]; q[j] += o[j] * o[j]; }
+        }
+      }
+    }
+    if (STATS) {
+      lds_put<EPV>(part, 2 * C, pl, v * EPV, s);
+      lds_put<EPV>(part, 2 * C, pl, C + v * EPV, q);
+    }
   }
+  if (!STATS) return;
+  __syncthreads();
+  float* dst = stats + (size_t)(slots > 1 ? blockIdx.x % (unsigned)slots : 0) * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(dst + i, lds_fold(part, 2 * C, PL, i));
 }
 
 // y = a + nearest(b): torch nearest index = min(floor(dst * (in/out)), in-1) with f32 scale
@@ -304,18 +351,46 @@ extern "C" int das_maxpool3x3s2_backward_argmax(const void* dy, const void* idx,
   return DAS_OK;
 }
 
-extern "C" int das_upsample_bilinear_ac(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho,
-                                        int Wo, void* stream) {
-  if (!x || !y || C % 8) return DAS_ERR_ARG;
+// stats == nullptr: the plain resampling
+static int launch_bilinear_ac(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho, int Wo, float* stats,
+                              int stats_slots, void* stream) {
+  if (!x || (!y && !stats) || C % 8 || B < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1) return DAS_ERR_ARG;
+  if (stats && (C > 4096 || stats_slots < 1 || stats_slots > 64)) return DAS_ERR_ARG;
   const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
   const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const long long npix = (long long)B * Ho * Wo;
+  if (npix >= (1ll << 31)) return DAS_ERR_ARG;
+  const int vc = C / (dtype == DAS_F32 ? 4 : 8);
+  const int pl = TPB / (vc < TPB ? vc : TPB);
+  // whole rounds of (pixel lanes x 4 pixels in flight) per workgroup: 128 output pixels (256 channels) for the large maps,
+  // 64 below 256 K pixels (measured: tools/dev/upstats_bench.py; the 2C global atomics per workgroup are not what limits)
+  const int round_px = pl * 4;
+  long long ppb = npix >= (1 << 18) ? 4 * round_px : 2 * round_px;
+  if (dastune::get(dastune::ELEM_UPSTATS_PPB) > 0) ppb = dastune::get(dastune::ELEM_UPSTATS_PPB);
+  const long long grid = (npix + ppb - 1) / ppb;
+  const size_t lds = stats ? (size_t)pl * 2 * C * sizeof(float) : 0;
   DISPATCH_T(dtype, {
-    const long long total = (long long)B * Ho * Wo * (C / Elem<T>::EPV);
-    hipLaunchKernelGGL(bilinear_ac_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const T*)x,
-                       (T*)y, B, H, W, C, Ho, Wo, sh, sw);
+    if (stats)
+      hipLaunchKernelGGL((bilinear_ac_stats_kernel<T, true>), dim3((unsigned)grid), dim3(TPB), lds, (hipStream_t)stream,
+                         (const T*)x, (T*)y, B, H, W, C, Ho, Wo, sh, sw, (int)ppb, stats, stats_slots);
+    else
+      hipLaunchKernelGGL((bilinear_ac_stats_kernel<T, false>), dim3((unsigned)grid), dim3(TPB), 0, (hipStream_t)stream,
+                         (const T*)x, (T*)y, B, H, W, C, Ho, Wo, sh, sw, (int)ppb, nullptr, 1);
   });
   DAS_CHECK_LAUNCH();
   return DAS_OK;
+}
+
+extern "C" int das_upsample_bilinear_ac(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho,
+                                        int Wo, void* stream) {
+  if (!y) return DAS_ERR_ARG;
+  return launch_bilinear_ac(x, y, dtype, B, H, W, C, Ho, Wo, nullptr, 1, stream);
+}
+
+extern "C" int das_upsample_bilinear_ac_stats(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho, int Wo,
+                                              float* stats, int stats_slots, void* stream) {
+  if (!stats) return DAS_ERR_ARG;
+  return launch_bilinear_ac(x, y, dtype, B, H, W, C, Ho, Wo, stats, stats_slots, stream);
 }
 
 extern "C" int das_add_upsample_nearest(const void* a, const void* b, void* y, int dtype, int B, int H, int W, int C,

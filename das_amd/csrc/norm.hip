@@ -150,14 +150,14 @@ template <typename T, int NT>
 __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, DasLevels lv, int C, int ps, int G,
                                                       int pix_per_block, float* __restrict__ stats) {
   constexpr int EPV = Elem<T>::EPV;
-  extern __shared__ float sred[];  // [2*C]
+  extern __shared__ float part[];  // [PL][width] (common.h: lds_put / lds_fold), folded in place into row 0
   const int seg = blockIdx.y;
   const GnSeg sg = gn_segment(lv, seg);
   const int p0 = blockIdx.x * pix_per_block;
   if (p0 >= sg.HW) return;  // block-uniform
   const int VC = C / EPV, cpg = C / G;
-  for (int i = threadIdx.x; i < 2 * C; i += NT) sred[i] = 0.f;
-  __syncthreads();
+  const bool vec_in_group = cpg % EPV == 0;   // a thread's vector lies inside one group: one pair of sums per thread
+  const int width = vec_in_group ? 2 * VC : 2 * C;
   const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = NT / VC;
   float s[EPV], q[EPV];
 #pragma unroll
@@ -184,24 +184,24 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, D
 #pragma unroll
       for (int j = 0; j < EPV; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
     }
-    if (cpg % EPV == 0) {   // the vector lies inside one group: one pair of LDS atomics per thread (slot = first channel)
+    if (vec_in_group) {
       float a = 0.f, c = 0.f;
 #pragma unroll
       for (int j = 0; j < EPV; ++j) { a += s[j]; c += q[j]; }
-      atomicAdd(&sred[v * EPV], a);
-      atomicAdd(&sred[C + v * EPV], c);
+      part[(size_t)pl * width + v] = a;
+      part[(size_t)pl * width + VC + v] = c;
     } else {
-#pragma unroll
-      for (int j = 0; j < EPV; ++j) {
-        atomicAdd(&sred[v * EPV + j], s[j]);
-        atomicAdd(&sred[C + v * EPV + j], q[j]);
-      }
+      lds_put<EPV>(part, width, pl, v * EPV, s);
+      lds_put<EPV>(part, width, pl, C + v * EPV, q);
     }
   }
   __syncthreads();
+  for (int i = threadIdx.x; i < width; i += NT) part[i] = lds_fold(part, width, PL, i);   // (column i: this thread only)
+  __syncthreads();
+  const int per = vec_in_group ? cpg / EPV : cpg, half = width / 2;
   for (int g = threadIdx.x; g < G; g += NT) {
     float a = 0.f, c = 0.f;
-    for (int j = 0; j < cpg; ++j) { a += sred[g * cpg + j]; c += sred[C + g * cpg + j]; }
+    for (int j = 0; j < per; ++j) { a += part[g * per + j]; c += part[half + g * per + j]; }
     atomicAdd(&stats[((long long)seg * G + g) * 2], a);
     atomicAdd(&stats[((long long)seg * G + g) * 2 + 1], c);
   }
@@ -407,13 +407,20 @@ extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLe
   const int ppb_min = (int)dastune::get(dastune::GN_PPB);   // minimum pixels per workgroup
   if (ppb < ppb_min) ppb = ppb_min;
   chunks = (maxhw + ppb - 1) / ppb;
+  // LDS of the statistics pass: [pixel lanes][2 x (vectors | channels)] partial sums
+  const int vc = C / epv;
+  const size_t lds = (size_t)(GN_NT / vc) * 2 * (((C / G) % epv == 0) ? vc : C) * sizeof(float);
+  if (lds > 48 * 1024) {
+    const void* k = dtype == DAS_BF16 ? (const void*)gn_stats_kernel<bf16_t, GN_NT> : (const void*)gn_stats_kernel<float, GN_NT>;
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DAS_ERR_LAUNCH;
+  }
   if (dtype == DAS_BF16) {
-    hipLaunchKernelGGL((gn_stats_kernel<bf16_t, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 2 * C * sizeof(float), s,
+    hipLaunchKernelGGL((gn_stats_kernel<bf16_t, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), lds, s,
                        (const bf16_t*)x, *lv, C, pix_stride, G, ppb, stats_ws);
     hipLaunchKernelGGL((gn_apply_kernel<bf16_t, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 0, s, (const bf16_t*)x, (bf16_t*)y,
                        *lv, C, pix_stride, G, ppb, stats_ws, gamma, beta, eps, relu);
   } else if (dtype == DAS_F32) {
-    hipLaunchKernelGGL((gn_stats_kernel<float, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 2 * C * sizeof(float), s,
+    hipLaunchKernelGGL((gn_stats_kernel<float, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), lds, s,
                        (const float*)x, *lv, C, pix_stride, G, ppb, stats_ws);
     hipLaunchKernelGGL((gn_apply_kernel<float, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 0, s, (const float*)x, (float*)y,
                        *lv, C, pix_stride, G, ppb, stats_ws, gamma, beta, eps, relu);

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restric
                                                               float* __restrict__ gsums, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
   constexpr int EPV = Elem<T>::EPV, NT = GN_NT;
-  extern __shared__ float sred[];  // [2C]
+  extern __shared__ float part[];  // [rows][2C] (common.h: lds_put / lds_fold), folded in place into row 0
   const int seg = blockIdx.y;
   const GnSeg sg = gn_segment(lv, seg);
   const int HW = sg.HW;
@@ -54,8 +54,6 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restric
   if (p0 >= HW) return;
   const int VC = C / EPV, cpg = C / G;
   const float inv_n = 1.f / ((float)HW * (float)cpg);
-  for (int i = threadIdx.x; i < 2 * C; i += NT) sred[i] = 0.f;
-  __syncthreads();
   const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = NT / VC;
   if (pl < PL) {
     float a[EPV], bb[EPV], mu[EPV], rs[EPV];
@@ -99,9 +97,9 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restric
       acc(*reinterpret_cast<const uint4*>(dy + o), *reinterpret_cast<const uint4*>(x + o),
           relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0));
     }
-    if (64 % VC == 0) {
-      // the 64 / VC pixel lanes of a wave that share this channel vector: xor-shuffles, then ONE lane per vector adds
-      // the wave's sums (16 waves per address instead of 16 x 64 / VC threads)
+    if (VC < 64 && 64 % VC == 0) {
+      // the 64 / VC pixel lanes of a wave that share this channel vector: xor-shuffles, then one lane per vector stores the
+      // wave's sums (rows = waves)
       for (int m = VC; m < 64; m <<= 1) {
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
@@ -110,25 +108,23 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restric
         }
       }
       if ((threadIdx.x & 63) < VC) {
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) {
-          atomicAdd(&sred[v * EPV + j], a[j]);
-          atomicAdd(&sred[C + v * EPV + j], bb[j]);
-        }
+        lds_put<EPV>(part, 2 * C, threadIdx.x >> 6, v * EPV, a);
+        lds_put<EPV>(part, 2 * C, threadIdx.x >> 6, C + v * EPV, bb);
       }
     } else {
-#pragma unroll
-      for (int j = 0; j < EPV; ++j) {
-        atomicAdd(&sred[v * EPV + j], a[j]);
-        atomicAdd(&sred[C + v * EPV + j], bb[j]);
-      }
+      lds_put<EPV>(part, 2 * C, pl, v * EPV, a);
+      lds_put<EPV>(part, 2 * C, pl, C + v * EPV, bb);
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += NT) {
-    atomicAdd(dbeta + c, sred[c]);
-    atomicAdd(dgamma + c, sred[C + c]);
+  const int nrows = (VC < 64 && 64 % VC == 0) ? NT / 64 : PL;
+  float* sred = part;   // folded in place: column c is read and written by one thread only
+  for (int c = threadIdx.x; c < 2 * C; c += NT) {
+    const float t = lds_fold(part, 2 * C, nrows, c);
+    sred[c] = t;
+    atomicAdd((c < C ? dbeta : dgamma - C) + c, t);
   }
+  __syncthreads();
   for (int g = threadIdx.x; g < G; g += NT) {
     float s1 = 0.f, s2 = 0.f;
     for (int j = 0; j < cpg; ++j) { s1 += gamma[g * cpg + j] * sred[g * cpg + j]; s2 += gamma[g * cpg + j] * sred[C + g * cpg + j]; }
@@ -379,7 +375,12 @@ static int groupnorm_backward_impl(const void* dy, const void* y, const void* x,
   int ppb = std::max((int)dastune::get(dastune::GN_PPB), (maxhw + chunks - 1) / chunks);   // (see norm.hip)
   chunks = (maxhw + ppb - 1) / ppb;
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3(chunks, nseg), dim3(GN_NT), 2 * C * sizeof(float), s, (const T*)dy,
+    const int vc = C / Elem<T>::EPV;
+    const size_t lds = (size_t)((vc < 64 && 64 % vc == 0) ? GN_NT / 64 : GN_NT / vc) * 2 * C * sizeof(float);
+    if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)gn_bwd_reduce_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds) != hipSuccess)
+      return DAS_ERR_LAUNCH;
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3(chunks, nseg), dim3(GN_NT), lds, s, (const T*)dy,
                        (const T*)y, (const T*)x, *lv, C, pix_stride, G, ppb, fwd_stats, gamma, eps, relu, gsums_ws,
                        dgamma, dbeta);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks, nseg), dim3(GN_NT), 0, s, (const T*)dy, (const T*)y,

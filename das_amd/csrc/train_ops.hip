@@ -781,10 +781,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WgradSched sch_) {
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ x, long long rows, int C, int ps, float* __restrict__ out) {
   constexpr int EPV = Elem<T>::EPV;
-  extern __shared__ float sred[];
+  extern __shared__ float part[];   // [PL][C] (common.h: lds_put / lds_fold)
   const int VC = C / EPV;
-  for (int i = threadIdx.x; i < C; i += TPB) sred[i] = 0.f;
-  __syncthreads();
   const int VCB = min(VC, TPB);  // channel vectors handled side by side (wider rows loop over v)
   const int pl = threadIdx.x / VCB, PL = TPB / VCB;
   for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
@@ -797,11 +795,10 @@ __global__ void colsum_kernel(const T* __restrict__ x, long long rows, int C, in
 #pragma unroll
       for (int j = 0; j < EPV; ++j) s[j] += f[j];
     }
-#pragma unroll
-    for (int j = 0; j < EPV; ++j) atomicAdd(&sred[v * EPV + j], s[j]);
+    lds_put<EPV>(part, C, pl, v * EPV, s);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += TPB) atomicAdd(out + i, sred[i]);
+  for (int i = threadIdx.x; i < C; i += TPB) atomicAdd(out + i, lds_fold(part, C, PL, i));
 }
 
 // ------------------------------------------------------------------ BatchNorm (train) backward
@@ -832,10 +829,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
                                                            float* __restrict__ sums) {
   constexpr int EPV = Elem<T>::EPV;
   constexpr int U = NT > 256 ? 2 : 4;   // (8 rows in flight per thread measured no better: 69 / 56 / 45 us against 67 / 49 / 42 in the step, round 4)
-  extern __shared__ float sred[];  // [2C]
+  extern __shared__ float part[];  // [PL][2C] (common.h: lds_put / lds_fold)
   const int VC = C / EPV;
-  for (int i = threadIdx.x; i < 2 * C; i += NT) sred[i] = 0.f;
-  __syncthreads();
   const int VCB = min(VC, NT);
   const int pl = threadIdx.x / VCB, PL = NT / VCB;
   const long long rstride = (long long)gridDim.x * PL;
@@ -868,14 +863,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
         for (int j = 0; j < EPV; ++j) { s1[j] += g[j]; s2[j] += g[j] * (x[j] - mu[j]) * is[j]; }
       }
     }
-#pragma unroll
-    for (int j = 0; j < EPV; ++j) {
-      atomicAdd(&sred[v * EPV + j], s1[j]);
-      atomicAdd(&sred[C + v * EPV + j], s2[j]);
-    }
+    lds_put<EPV>(part, 2 * C, pl, v * EPV, s1);
+    lds_put<EPV>(part, 2 * C, pl, C + v * EPV, s2);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(sums + i, sred[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(sums + i, lds_fold(part, 2 * C, PL, i));
 }
 
 // pass 2: dRaw = gamma*invstd*(dZ - s1/N - xhat*s2/N); optionally dRes = dZ. Block 0 also adds the two
@@ -1056,10 +1048,10 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
     const int cap = (int)dastune::get(dastune::BN_REDUCE_BLOCKS), nt = (int)dastune::get(dastune::BN_REDUCE_THREADS);
     const int blocks = (int)std::min<long long>(cap, std::max<long long>(1, rows / 64));
     if (nt == 1024) {
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 1024>), dim3(blocks), dim3(1024), 2 * C * sizeof(float), s,
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 1024>), dim3(blocks), dim3(1024), (1024 / std::min(vc, 1024)) * 2 * C * sizeof(float), s,
                          (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
     } else {
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 256>), dim3(blocks), dim3(256), 2 * C * sizeof(float), s,
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 256>), dim3(blocks), dim3(256), (256 / std::min(vc, 256)) * 2 * C * sizeof(float), s,
                          (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
     }
   }
@@ -1507,10 +1499,10 @@ static int colsum_impl(const void* x, int dtype, long long rows, int C, int pix_
   if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int blocks = (int)std::min<long long>(256, std::max<long long>(1, rows / 64));
   if (dtype == DAS_BF16) {
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(TPB), C * sizeof(float), s, (const bf16_t*)x, rows, C,
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(TPB), (TPB / std::min(C / 8, TPB)) * C * sizeof(float), s, (const bf16_t*)x, rows, C,
                        pix_stride, out);
   } else if (dtype == DAS_F32) {
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(TPB), C * sizeof(float), s, (const float*)x, rows, C,
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(TPB), (TPB / std::min(C / 4, TPB)) * C * sizeof(float), s, (const float*)x, rows, C,
                        pix_stride, out);
   } else {
     return DAS_ERR_ARG;

@@ -41,6 +41,7 @@ enum Key {
                          // +-5 % of the one-tile kernels — parity-tested, kept for the record and for A/B runs
   COMM_RESERVED_CUS,     // CUs the persistent one-workgroup-per-CU grids leave free (for the RCCL kernels of the overlapped
                          // gradient all-reduce when several GPUs train together); 0 on one GPU
+  ELEM_UPSTATS_PPB,      // output pixels per workgroup of bilinear_ac_stats_kernel; 0 = by size
   N_KEYS
 };
 

@@ -196,6 +196,45 @@ def conv_bn(x, conv, bn, relu=False, residual=None, relu_in=False, skip_through=
     return y
 
 
+# up_conv(upsample(x)) evaluated as upsample(up_conv(x)) in train mode: see autograd.UpConvBNTrainFn. A switch for A/B runs
+# and for the test that pins the two orders against each other.
+UPCONV_AT_LOW_RES = True
+
+
+def upsample_conv_bn(x_lo, Ho, Wo, conv, bn, relu=False, residual=None):
+    """ConvModule(1x1 conv, BN)(bilinear_upsample(x_lo, (Ho, Wo))) (+ residual) (+ ReLU): MSPN's `up_conv` branch,
+    mspn_mmpose.py:385-389. Train mode with autograd: the conv runs BEFORE the upsampling (one autograd node,
+    UpConvBNTrainFn); otherwise the reference's order."""
+    from . import autograd as ag
+    if (UPCONV_AT_LOW_RES and bn.training and conv.bias is None and conv.kernel_size[0] == 1 and conv.stride[0] == 1
+            and ag.grad_mode(x_lo, conv.weight, bn.weight, residual)):
+        return ag.UpConvBNTrainFn.apply(x_lo, conv.weight, bn.weight, bn.bias, residual, conv, bn, relu, Ho, Wo)
+    return conv_bn(upsample_bilinear(x_lo, Ho, Wo), conv, bn, relu=relu, residual=residual)
+
+
+def upsample_conv_bn_stats_only(x_lo, Ho, Wo, conv, bn):
+    """`conv_bn_stats_only` of upsample_conv_bn: the 1x1 conv at low resolution, then the upsampling kernel reduces the
+    statistics of the tensor it does not write."""
+    from . import autograd as ag
+    if not (UPCONV_AT_LOW_RES and conv.bias is None and conv.kernel_size[0] == 1 and conv.stride[0] == 1):
+        return conv_bn_stats_only(ops.upsample_bilinear_ac(x_lo, Ho, Wo), conv, bn)
+    assert bn.training
+    w = packed_weight(conv, x_lo.dtype, cin_pad=x_lo.shape[-1])
+    cout = w.shape[0]
+    lo = ops.conv2d(x_lo, w, 1, 1, 1, 0)
+    rows = x_lo.shape[0] * Ho * Wo
+    stats = bn_stats_buffer_rows(rows, cout, x_lo.device)
+    ops.upsample_bilinear_ac(lo, Ho, Wo, stats=stats, stats_only=True)
+    world, stat_count = ag._sync_world(bn), rows
+    if world > 1:
+        stats = sync_stats(stats, cout, ag._all_reduce)
+        stat_count = rows * world
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    ops.bn_train_apply(lo, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, mom, bn.eps,
+                       num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count, finalize_only=True)
+    bn.__dict__.pop('_das_cache', None)
+
+
 def conv_bn_stats_only(x, conv, bn):
     """Train-mode ConvModule(conv, BN) whose OUTPUT nobody reads: the conv runs (its epilogue reduces the batch
     statistics), the BatchNorm publishes mean / invstd and advances running_mean / running_var / num_batches_tracked exactly
@@ -262,9 +301,12 @@ def bn_stats_buffer(x, cout):
     adding into one [2*cout] array serialise on the same words, so large-M layers spread them over slots
     (DasConvDesc.stats_slots); das_bn_train_apply sums the slots."""
     xd = x.data if hasattr(x, 'sizes') else x
-    rows = xd.numel() // xd.shape[-1]
+    return bn_stats_buffer_rows(xd.numel() // xd.shape[-1], cout, xd.device)
+
+
+def bn_stats_buffer_rows(rows, cout, device):
     slots = (_FULL_SLOTS if rows >= _FULL_SLOT_ROWS else _MID_SLOTS) if rows >= _SLOT_ROWS else 1
-    return zeroed_stats(slots * 2 * cout, xd.device)
+    return zeroed_stats(slots * 2 * cout, device)
 
 
 def sync_stats(stats, cout, all_reduce):

@@ -614,11 +614,19 @@ def maxpool3x3s2(x, return_argmax=False):
     return y
 
 
-def upsample_bilinear_ac(x, Ho, Wo):
+def upsample_bilinear_ac(x, Ho, Wo, stats=None, stats_only=False):
+    """stats: zeroed f32[slots * 2C] — also reduce the BatchNorm statistics of the OUTPUT (das_upsample_bilinear_ac_stats);
+    stats_only: do not write the output at all (returns None)."""
     _need_gpu(x)
     B, H, W, Cc = x.shape
     assert x.is_contiguous()
-    y = torch.empty(B, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
+    y = None if stats_only else torch.empty(B, Ho, Wo, Cc, dtype=x.dtype, device=x.device)
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.numel() % (2 * Cc) == 0
+        _lib.check(_lib.load().das_upsample_bilinear_ac_stats(_ptr(x), _ptr(y) if y is not None else None, _DT[x.dtype],
+                                                              B, H, W, Cc, Ho, Wo, _ptr(stats),
+                                                              stats.numel() // (2 * Cc), _stream()), 'das_upsample_bilinear_ac_stats')
+        return y
     _lib.check(_lib.load().das_upsample_bilinear_ac(_ptr(x), _ptr(y), _DT[x.dtype], B, H, W, Cc, Ho, Wo, _stream()),
                'das_upsample_bilinear_ac')
     return y

@@ -237,6 +237,13 @@ int das_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int
 /* The same, also recording the winning tap (0..8 in scan order, the FIRST maximum) of every output element: idx is
  * u8[B*Ho*Wo*C]. das_maxpool3x3s2_backward_argmax(dy, idx) -> dx then gathers from 80 MB instead of re-deriving the maxima
  * from x (das_maxpool3x3s2_backward: 338 us per step at B = 16); both backward routes give the same bits. */
+/* das_upsample_bilinear_ac that also reduces the BatchNorm statistics of its OUTPUT: per-channel sum / sum of squares of the
+ * stored values added into stats f32[stats_slots][2*C] (zeroed by the caller; same convention as DasConvDesc.stats). For a
+ * bias-free 1x1 conv behind a bilinear upsampling (MSPN's `up_conv`, mspn_mmpose.py:385-389): both are linear and
+ * commute, so the conv runs on the quarter-size tensor and this call produces the pre-norm tensor with its statistics.
+ * y == NULL: statistics only (of the values as they WOULD be stored in `dtype`), nothing is written. */
+int das_upsample_bilinear_ac_stats(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho, int Wo,
+                                   float* stats, int stats_slots, void* stream);
 int das_maxpool3x3s2_argmax(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, void* stream);
 int das_maxpool3x3s2_backward_argmax(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C,
                                      void* stream);

@@ -1,0 +1,127 @@
+"""MSPN's `up_conv` branch (bilinear upsample -> bias-free 1x1 conv -> train-mode BatchNorm, mspn_mmpose.py:385-389) evaluated
+with the conv BEFORE the upsampling (autograd.UpConvBNTrainFn): the upsampling kernel that reduces the BatchNorm
+statistics, and the exchanged order against the reference's order on one upsample unit."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 8, 13, 256, 16, 26), (1, 5, 7, 64, 9, 13), (2, 32, 52, 256, 64, 104), (1, 3, 4, 2048, 6, 8),
+                                   (3, 1, 1, 128, 4, 4), (2, 64, 104, 256, 128, 208)])
+def test_upsample_with_statistics_kernel(shape, dtype):
+    """das_upsample_bilinear_ac_stats: the tensor is bit-identical to das_upsample_bilinear_ac's; the statistics are the sums of
+    the STORED values (f64 sums of the output as the yardstick); y == NULL leaves the statistics unchanged."""
+    from das_amd import ops
+    from das_amd.nn import bn_stats_buffer_rows
+    B, H, W, C, Ho, Wo = shape
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    x = cases.randn(3, B, H, W, C).to(DEV).to(dt).contiguous()
+    ref = ops.upsample_bilinear_ac(x, Ho, Wo)
+    rows = B * Ho * Wo
+    for stats in (bn_stats_buffer_rows(rows, C, x.device), torch.zeros(3 * 2 * C, device=DEV)):
+        stats.zero_()
+        y = ops.upsample_bilinear_ac(x, Ho, Wo, stats=stats)
+        assert torch.equal(y, ref)
+        got = stats.view(-1, 2, C).double().sum(0)
+        yd = ref.double().view(-1, C)
+        want = torch.stack([yd.sum(0), (yd * yd).sum(0)])
+        scale = torch.stack([yd.abs().sum(0), (yd * yd).sum(0)]) + 1e-30
+        assert float(((got - want).abs() / scale).max()) < 2e-6
+        only = torch.zeros_like(stats)
+        assert ops.upsample_bilinear_ac(x, Ho, Wo, stats=only, stats_only=True) is None
+        got2 = only.view(-1, 2, C).double().sum(0)
+        assert float(((got2 - want).abs() / scale).max()) < 2e-6
+
+
+def _unit(seed, dtype):
+    from das_amd.backbones import UpsampleUnit
+    torch.manual_seed(seed)
+    m = UpsampleUnit(1, 4, 512, 256, gen_skip=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.uniform_(-0.3, 0.3)
+    return m.to(DEV).train()
+
+
+def _run_unit(low_res, dtype, state):
+    from das_amd import nn as nnops
+    from das_amd.autograd import reset_step_state
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    m = _unit(0, dtype)
+    m.load_state_dict(state) if state is not None else None
+    x = cases.randn(11, 2, 16, 26, 512).to(DEV).to(dt).requires_grad_(True)
+    up_x = cases.randn(12, 2, 8, 13, 256).to(DEV).to(dt).requires_grad_(True)
+    g = [cases.randn(13 + i, *s).to(DEV).to(dt) for i, s in enumerate([(2, 16, 26, 256), (2, 16, 26, 512), (2, 16, 26, 512)])]
+    nnops.UPCONV_AT_LOW_RES = low_res
+    try:
+        reset_step_state()
+        out, s1, s2, _ = m(x, up_x)
+        (out.float() * g[0].float()).sum().add((s1.float() * g[1].float()).sum()).add((s2.float() * g[2].float()).sum()).backward()
+        torch.cuda.synchronize()
+    finally:
+        nnops.UPCONV_AT_LOW_RES = True
+    res = {'out': out.detach().float(), 'dx': x.grad.float(), 'dup_x': up_x.grad.float()}
+    res.update({'g.' + n: p.grad.detach().float() for n, p in m.named_parameters()})
+    res.update({'b.' + n: b.detach().float().clone() for n, b in m.named_buffers()})
+    return res, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def test_conv_before_upsampling_equals_the_reference_order_f32():
+    """One upsample unit (in_skip + up_conv + the two skip convs), train mode, f32: output, every gradient and every BatchNorm
+    buffer with the 1x1 conv moved in front of the upsampling against the reference's order. The two differ by the order of
+    f32 summation only: 2e-5 of the tensor's largest magnitude (a flipped ReLU at a value of ~1e-6 moves nothing visible)."""
+    _, state = _run_unit(False, 'f32', None)
+    state = {k: v for k, v in _unit(0, 'f32').state_dict().items()}
+    a, _ = _run_unit(False, 'f32', state)
+    b, _ = _run_unit(True, 'f32', state)
+    assert set(a) == set(b)
+    worst = {}
+    for k in a:
+        scale = float(a[k].abs().max())
+        if scale == 0:
+            assert float(b[k].abs().max()) == 0, k
+            continue
+        worst[k] = float((a[k] - b[k]).abs().max()) / scale
+    print({k: '%.1e' % v for k, v in worst.items()})
+    assert max(worst.values()) < 2e-5, max(worst.items(), key=lambda kv: kv[1])
+    assert worst['out'] > 0, 'the switch did not change the path'
+
+
+def test_conv_before_upsampling_bf16_band():
+    """bf16: the exchanged order rounds at different places (conv output at low resolution, then the interpolated value)
+    — both orders against the f32 run of the reference's order: the new order's error is within 1.5x the old one's."""
+    state = {k: v for k, v in _unit(0, 'f32').state_dict().items()}
+    ref, _ = _run_unit(False, 'f32', state)
+    old, _ = _run_unit(False, 'bf16', state)
+    new, _ = _run_unit(True, 'bf16', state)
+    for k in ('out', 'dx', 'dup_x', 'g.up_conv.conv.weight', 'g.up_conv.bn.weight', 'g.in_skip.conv.weight', 'b.up_conv.bn.running_var'):
+        scale = float(ref[k].abs().max())
+        e_old = float((old[k] - ref[k]).abs().max()) / scale
+        e_new = float((new[k] - ref[k]).abs().max()) / scale
+        print('%-28s old %.2e new %.2e' % (k, e_old, e_new))
+        assert e_new <= max(1.5 * e_old, 4e-3), (k, e_old, e_new)
+
+
+def test_unused_finest_unit_advances_the_same_running_statistics():
+    """UpsampleUnit.forward_unused (the last stage's finest map nobody reads): running statistics through the statistics-only
+    upsampling kernel against the full unit's."""
+    from das_amd.backbones import UpsampleUnit
+    torch.manual_seed(1)
+    full = UpsampleUnit(3, 4, 256, 256).to(DEV).train()
+    lean = UpsampleUnit(3, 4, 256, 256).to(DEV).train()
+    lean.load_state_dict(full.state_dict())
+    x = cases.randn(21, 2, 32, 52, 256).to(DEV)
+    up_x = cases.randn(22, 2, 16, 26, 256).to(DEV)
+    with torch.no_grad():
+        full(x, up_x)
+        assert lean.forward_unused(x, up_x) is None
+    for (n, a), (_, b) in zip(full.named_buffers(), lean.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-7), n
+        assert 'num_batches' not in n or int(a) == 1

@@ -1,7 +1,7 @@
 """Dev tool: train-step time under dispatch-threshold variations, ONE process (same box, same clocks, same model):
 for each `key=value[,key=value...]` argument the tuning is set, 2 warm-up + N timed steps run, the tuning is reset.
 The baseline (defaults) runs first, in the middle and last: the spread of those three is the noise floor.
-usage: tune_step.py [-n steps] cfg1 cfg2 ...      special keys: WGRAD_BATCH=<n> (das_amd.autograd), SLOTS=<full>,<mid> (das_amd.nn)"""
+usage: tune_step.py [-n steps] cfg1 cfg2 ...      special keys: WGRAD_BATCH=<n> (das_amd.autograd), SLOTS=<full>,<mid> and UPCONV=<0|1> (das_amd.nn)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -31,6 +31,8 @@ def run(cfg):
         k, v = kv.split('=')
         if k == 'WGRAD_BATCH':
             ag.WGRAD_BATCH = int(v)
+        elif k == 'UPCONV':
+            dnn.UPCONV_AT_LOW_RES = bool(int(v))
         elif k == 'SLOTS':
             dnn._FULL_SLOTS, dnn._MID_SLOTS = int(v.split('/')[0]), int(v.split('/')[1])
         else:
@@ -48,6 +50,7 @@ def run(cfg):
     ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(N))
     ms = ts[N // 2]
     ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS = wb, fs, ms_
+    dnn.UPCONV_AT_LOW_RES = True
     _lib.check(lib.das_tuning_reset(), 'reset')
     return ms
 
