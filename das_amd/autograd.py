@@ -366,6 +366,83 @@ class UpConvBNTrainFn(Function):
         return dx, dw, dgamma, dbeta, dres, None, None, None, None, None
 
 
+class UpMergeTrainFn(Function):
+    """One MSPN upsample unit's merge in train mode (mspn_mmpose.py:381-404):
+    out = relu(BN1(in_skip(x)) + BN2(up_conv(upsample(up_x)))), as one autograd node over the kernels of
+    das_amd/csrc/upmerge.hip: up_conv runs before the upsampling (UpConvBNTrainFn's exchange), and neither normalised
+    branch nor the upsampled tensor is written — forward or backward. skip_through: x is handed through as a second
+    output (ConvBNTrainSkipFn), its other consumers' gradient arrives as `dskip` and is added in in_skip's data-gradient
+    epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, up_x, w1, g1, b1, w2, g2, b2, in_skip, up_conv, skip_through):
+        from .nn import bn_stats_buffer, bn_stats_buffer_rows, packed_weight
+        c1, bn1, c2, bn2 = in_skip.conv, in_skip.bn, up_conv.conv, up_conv.bn
+        B, Ho, Wo = x.shape[0], x.shape[1], x.shape[2]
+        rows = B * Ho * Wo
+        wp1 = packed_weight(c1, x.dtype, cin_pad=x.shape[-1])
+        cout = wp1.shape[0]
+        stats1 = bn_stats_buffer(x, cout)
+        raw1 = ops.conv2d(x, wp1, 1, 1, 1, 0, stats=stats1)
+        _, mean1, invstd1 = ops.bn_train_apply(raw1, stats1, g1, b1, bn1.running_mean, bn1.running_var,
+                                               bn1.momentum if bn1.momentum is not None else 0.1, bn1.eps,
+                                               num_batches_tracked=bn1.num_batches_tracked, finalize_only=True)
+        z = ops.conv2d(up_x, packed_weight(c2, up_x.dtype, cin_pad=up_x.shape[-1]), 1, 1, 1, 0)
+        stats2 = bn_stats_buffer_rows(z.numel() // cout, cout, x.device)
+        ops.upsample_stats_lowres(z, Ho, Wo, stats2)
+        _, mean2, invstd2 = ops.bn_train_apply(z, stats2, g2, b2, bn2.running_mean, bn2.running_var,
+                                               bn2.momentum if bn2.momentum is not None else 0.1, bn2.eps,
+                                               num_batches_tracked=bn2.num_batches_tracked, stat_count=rows, finalize_only=True)
+        bn1.__dict__.pop('_das_cache', None)
+        bn2.__dict__.pop('_das_cache', None)
+        out = ops.upmerge_forward(raw1, z, (mean1, invstd1, g1, b1), (mean2, invstd2, g2, b2))
+        ctx.save_for_backward(x, up_x, raw1, z, out, mean1, invstd1, mean2, invstd2, g1, g2)
+        ctx.mods = (c1, bn1, c2, bn2)
+        ctx.skip_through = skip_through
+        return (out, x) if skip_through else out
+
+    @staticmethod
+    def backward(ctx, dy, dskip=None):
+        from .nn import packed_weight_dgrad
+        x, up_x, raw1, z, out, mean1, invstd1, mean2, invstd2, g1, g2 = ctx.saved_tensors
+        c1, bn1, c2, bn2 = ctx.mods
+        Cc = raw1.shape[-1]
+        rows = raw1.numel() // Cc
+        dzm, sums = ops.upmerge_backward_reduce(dy.contiguous(), out, raw1, z, mean1, invstd1, mean2, invstd2)
+        acc = [_param_acc(p) for p in (bn1.weight, bn1.bias, bn2.weight, bn2.bias)]
+        direct = all(a is not None for a in acc)
+        # BatchNorm 1: the apply pass every other layer uses (dZ, raw1 -> d raw1); sums[:2C] is its [sum dZ | sum dZ xhat]
+        draw1 = ops.bn_backward_apply(dzm, raw1, mean1, invstd1, g1, sums[:2 * Cc],
+                                      dgamma_acc=acc[0][1] if direct else None, dbeta_acc=acc[1][1] if direct else None)
+        dw1 = _wgrad(x, draw1, c1.weight, 1, 1, 0) if ctx.needs_input_grad[2] else None
+        # BatchNorm 2 + upsampling: d raw2 is never formed; dz = upsample^T(d raw2) from upsample^T(dZ) and low-resolution terms
+        P = ops.upsample_bilinear_ac_backward(dzm, z.shape[1], z.shape[2])
+        dz = ops.upmerge_backward_lowres(P, z, raw1.shape[1], raw1.shape[2], sums, g2, mean2, invstd2, rows,
+                                         dgamma2_acc=acc[2][1] if direct else None, dbeta2_acc=acc[3][1] if direct else None)
+        dw2 = _wgrad(up_x, dz, c2.weight, 1, 1, 0) if ctx.needs_input_grad[5] else None
+        if direct:
+            for a in acc:
+                a[0].fired()
+            dg1 = db1 = dg2 = db2 = None
+        else:
+            db1, dg1, dg2 = sums[:Cc].clone(), sums[Cc:2 * Cc].clone(), sums[2 * Cc:].clone()
+            db2 = db1.clone()
+        dx = dup = None
+        if ctx.needs_input_grad[0]:
+            if dskip is not None:
+                dskip = dskip.contiguous()
+            dx = ops.conv2d_dgrad(draw1, packed_weight_dgrad(c1, x.dtype), 1, 1, 1, 0, (x.shape[1], x.shape[2]), residual=dskip)
+            if dx.shape[-1] != x.shape[-1]:
+                dx = dx[..., :x.shape[-1]]
+        elif dskip is not None:
+            dx = dskip
+        if ctx.needs_input_grad[1]:
+            dup = ops.conv2d_dgrad(dz, packed_weight_dgrad(c2, up_x.dtype), 1, 1, 1, 0, (up_x.shape[1], up_x.shape[2]))
+            if dup.shape[-1] != up_x.shape[-1]:
+                dup = dup[..., :up_x.shape[-1]]
+        return dx, dup, dw1, dg1, db1, dw2, dg2, db2, None, None, None
+
+
 class ConvBNTrainSkipFn(Function):
     """ConvBNTrainFn that also hands its input through as a second output: y, x_skip = f(x).
 

@@ -135,13 +135,12 @@ class UpsampleUnit(nn.Module):
         # (conv_bn(skip_through=True)), so the gradients meet in data-gradient epilogues instead of elementwise adds
         thru = self.gen_skip
         if self.ind > 0:
-            lat = conv_bn(x, self.in_skip.conv, self.in_skip.bn, skip_through=thru)
+            # relu(in_skip(x) + up_conv(upsample(up_x))): in train mode one autograd node (nn.up_merge: up_conv runs before
+            # the upsampling, on a quarter of the pixels, and neither normalised branch is written); otherwise add + ReLU
+            # fused into up_conv's BatchNorm pass
+            out = nnops.up_merge(x, up_x, self.in_skip, self.up_conv, skip_through=thru)
             if thru:
-                lat, x = lat
-            # relu(in_skip(x) + up_conv(upsample(up_x))): add + ReLU fused into up_conv's BatchNorm pass; in train mode the
-            # 1x1 conv runs before the upsampling, on a quarter of the pixels (nn.upsample_conv_bn)
-            out = nnops.upsample_conv_bn(up_x, x.shape[1], x.shape[2], self.up_conv.conv, self.up_conv.bn, relu=True,
-                                         residual=lat)
+                out, x = out
         else:
             out = conv_bn(x, self.in_skip.conv, self.in_skip.bn, relu=True, skip_through=thru)
             if thru:

@@ -42,6 +42,7 @@ enum Key {
   COMM_RESERVED_CUS,     // CUs the persistent one-workgroup-per-CU grids leave free (for the RCCL kernels of the overlapped
                          // gradient all-reduce when several GPUs train together); 0 on one GPU
   ELEM_UPSTATS_PPB,      // output pixels per workgroup of bilinear_ac_stats_kernel; 0 = by size
+  BN_UPMERGE_BLOCKS,     // grid cap of upmerge_bwd_reduce_kernel
   N_KEYS
 };
 

@@ -212,6 +212,29 @@ def upsample_conv_bn(x_lo, Ho, Wo, conv, bn, relu=False, residual=None):
     return conv_bn(upsample_bilinear(x_lo, Ho, Wo), conv, bn, relu=relu, residual=residual)
 
 
+# the whole merge of an MSPN upsample unit as one autograd node (autograd.UpMergeTrainFn); switch for A/B runs and tests
+UPMERGE_FUSED = True
+
+
+def up_merge(x, up_x, in_skip, up_conv, skip_through=False):
+    """relu(in_skip(x) + up_conv(upsample(up_x))) of an MSPN upsample unit (mspn_mmpose.py:381-404); in_skip / up_conv are
+    ConvModules (1x1 conv + BN, no activation). Returns out, or (out, x) with skip_through (see conv_bn)."""
+    from . import autograd as ag
+    c1, bn1, c2, bn2 = in_skip.conv, in_skip.bn, up_conv.conv, up_conv.bn
+    fused = (UPMERGE_FUSED and UPCONV_AT_LOW_RES and bn1.training and bn2.training and c1.bias is None and c2.bias is None
+             and c1.kernel_size[0] == c2.kernel_size[0] == 1 and c1.stride[0] == c2.stride[0] == 1
+             and c1.out_channels == c2.out_channels and ag._sync_world(bn1) == 1 and ag._sync_world(bn2) == 1
+             and ag.grad_mode(x, up_x, c1.weight, bn1.weight, c2.weight, bn2.weight))
+    if fused:
+        return ag.UpMergeTrainFn.apply(x, up_x, c1.weight, bn1.weight, bn1.bias, c2.weight, bn2.weight, bn2.bias, in_skip, up_conv,
+                                       skip_through)
+    lat = conv_bn(x, c1, bn1, skip_through=skip_through)
+    if skip_through:
+        lat, x = lat
+    out = upsample_conv_bn(up_x, x.shape[1], x.shape[2], c2, bn2, relu=True, residual=lat)
+    return (out, x) if skip_through else out
+
+
 def upsample_conv_bn_stats_only(x_lo, Ho, Wo, conv, bn):
     """`conv_bn_stats_only` of upsample_conv_bn: the 1x1 conv at low resolution, then the upsampling kernel reduces the
     statistics of the tensor it does not write."""

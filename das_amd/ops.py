@@ -728,6 +728,88 @@ def maxpool3x3s2_backward_argmax(dy, idx, H, W):
     return dx
 
 
+_UP_TABLES = {}
+
+
+def _upsample_tables(H, Ho, device):
+    """upsample_bilinear (align_corners) along one axis as a matrix U (Ho x H), built with the kernels' f32 arithmetic; returns
+    the three diagonals of U^T U as f32[H][3] (offsets -1, 0, +1) and U^T 1 as f32[H] (das_upmerge_backward_lowres)."""
+    key = (H, Ho, str(device))
+    if key not in _UP_TABLES:
+        import numpy as np
+        s = np.float32(H - 1) / np.float32(Ho - 1) if Ho > 1 else np.float32(0)
+        r = (s * np.arange(Ho, dtype=np.float32)).astype(np.float32)
+        i0 = r.astype(np.int32)
+        l1 = (r - i0.astype(np.float32)).astype(np.float32)
+        l0 = (np.float32(1) - l1).astype(np.float32)
+        ip = (i0 < H - 1).astype(np.int32)
+        U = np.zeros((Ho, H), np.float64)
+        np.add.at(U, (np.arange(Ho), i0), l0)
+        np.add.at(U, (np.arange(Ho), i0 + ip), l1)
+        A = U.T @ U
+        a = np.zeros((H, 3), np.float32)
+        for d in (-1, 0, 1):
+            idx = np.arange(max(0, -d), min(H, H - d))
+            a[idx, d + 1] = A[idx, idx + d]
+        assert abs(A - np.triu(np.tril(A, 1), -1)).max() == 0
+        _UP_TABLES[key] = (torch.from_numpy(a).to(device), torch.from_numpy(U.sum(0).astype(np.float32)).to(device))
+    return _UP_TABLES[key]
+
+
+def upsample_stats_lowres(z, Ho, Wo, stats):
+    """Batch statistics of upsample_bilinear_ac(z, Ho, Wo) (f32, unrounded) added into the zeroed stats f32[slots * 2C], from
+    z alone (das_upsample_stats_lowres)."""
+    _need_gpu(z, stats)
+    B, H, W, Cc = z.shape
+    assert z.is_contiguous() and stats.dtype == torch.float32 and stats.numel() % (2 * Cc) == 0
+    ah, wh = _upsample_tables(H, Ho, z.device)
+    aw, ww = _upsample_tables(W, Wo, z.device)
+    _lib.check(_lib.load().das_upsample_stats_lowres(_ptr(z), _DT[z.dtype], B, H, W, Cc, _ptr(ah), _ptr(aw), _ptr(wh), _ptr(ww),
+                                                     _ptr(stats), stats.numel() // (2 * Cc), _stream()), 'das_upsample_stats_lowres')
+
+
+def upmerge_forward(raw1, z, bn1, bn2):
+    """relu(BN1(raw1) + BN2(upsample(z))); bn = (mean, invstd, gamma, beta) f32[C] each (das_upmerge_forward)."""
+    _need_gpu(raw1, z)
+    B, Ho, Wo, Cc = raw1.shape
+    assert raw1.is_contiguous() and z.is_contiguous() and z.shape[0] == B and z.shape[3] == Cc and z.dtype == raw1.dtype
+    out = torch.empty_like(raw1)
+    _lib.check(_lib.load().das_upmerge_forward(_ptr(raw1), _ptr(z), _ptr(out), _DT[raw1.dtype], B, z.shape[1], z.shape[2], Cc, Ho, Wo,
+                                               *[_ptr(t) for t in bn1], *[_ptr(t) for t in bn2], _stream()), 'das_upmerge_forward')
+    return out
+
+
+def upmerge_backward_reduce(dy, out, raw1, z, mean1, invstd1, mean2, invstd2):
+    """Returns dzm = dy * (out > 0) and sums f32[3C] = [sum dZ | sum dZ xhat1 | sum dZ xhat2] (das_upmerge_backward_reduce)."""
+    _need_gpu(dy, out, raw1, z)
+    B, Ho, Wo, Cc = raw1.shape
+    assert dy.is_contiguous() and dy.shape == raw1.shape == out.shape and dy.dtype == raw1.dtype == out.dtype == z.dtype
+    dzm = torch.empty_like(raw1)
+    sums = torch.empty(3 * Cc, dtype=torch.float32, device=raw1.device)
+    with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', 4 * raw1.numel() * raw1.element_size() + z.numel() * z.element_size(),
+                shape=(raw1.numel() // Cc, Cc, 'upmerge')):
+        _lib.check(_lib.load().das_upmerge_backward_reduce(_ptr(dy), _ptr(out), _ptr(raw1), _ptr(z), _ptr(dzm), _DT[raw1.dtype], B,
+                                                           z.shape[1], z.shape[2], Cc, Ho, Wo, _ptr(mean1), _ptr(invstd1),
+                                                           _ptr(mean2), _ptr(invstd2), _ptr(sums), _stream()),
+                   'das_upmerge_backward_reduce')
+    return dzm, sums
+
+
+def upmerge_backward_lowres(P, z, Ho, Wo, sums, gamma2, mean2, invstd2, stat_rows, dgamma2_acc=None, dbeta2_acc=None):
+    """dz = upsample^T(d raw2) at low resolution (das_upmerge_backward_lowres)."""
+    _need_gpu(P, z, sums)
+    B, H, W, Cc = z.shape
+    assert P.shape == z.shape and P.dtype == z.dtype and P.is_contiguous() and z.is_contiguous()
+    ah, wh = _upsample_tables(H, Ho, z.device)
+    aw, ww = _upsample_tables(W, Wo, z.device)
+    dz = torch.empty_like(z)
+    _lib.check(_lib.load().das_upmerge_backward_lowres(_ptr(P), _ptr(z), _ptr(dz), _DT[z.dtype], B, H, W, Cc, _ptr(ah), _ptr(aw),
+                                                       _ptr(wh), _ptr(ww), _ptr(sums), _ptr(gamma2), _ptr(mean2), _ptr(invstd2),
+                                                       int(stat_rows), _ptr(dgamma2_acc), _ptr(dbeta2_acc), _stream()),
+               'das_upmerge_backward_lowres')
+    return dz
+
+
 def upsample_bilinear_ac_backward(dy, H, W):
     _need_gpu(dy)
     B, Ho, Wo, Cc = dy.shape

@@ -244,6 +244,32 @@ int das_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int
  * y == NULL: statistics only (of the values as they WOULD be stored in `dtype`), nothing is written. */
 int das_upsample_bilinear_ac_stats(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho, int Wo,
                                    float* stats, int stats_slots, void* stream);
+/* The merge step of an MSPN upsample unit in train mode, out = relu(BN1(raw1) + BN2(upsample(z))) (mspn_mmpose.py:381-404; z =
+ * up_conv applied at LOW resolution, see das_upsample_bilinear_ac_stats), without writing either normalised branch or
+ * upsample(z): das_amd/csrc/upmerge.hip has the algebra. raw1 / out (B, Ho, Wo, C), z (B, H, W, C), per-channel f32[C]
+ * mean / invstd (published by das_bn_train_apply) and gamma / beta of the two BatchNorm layers.
+ * das_upsample_stats_lowres: the batch statistics of upsample(z) — per-channel sum / sum of squares added into
+ * stats f32[stats_slots][2C], DasConvDesc.stats' convention — computed from z alone (tables as for
+ * das_upmerge_backward_lowres): sum upsample(z) = sum w z, sum upsample(z)^2 = sum z (upsample^T upsample z). */
+int das_upsample_stats_lowres(const void* z, int dtype, int B, int H, int W, int C, const float* ah, const float* aw,
+                              const float* wh, const float* ww, float* stats, int stats_slots, void* stream);
+int das_upmerge_forward(const void* raw1, const void* z, void* out, int dtype, int B, int H, int W, int C, int Ho, int Wo,
+                        const float* mean1, const float* invstd1, const float* gamma1, const float* beta1,
+                        const float* mean2, const float* invstd2, const float* gamma2, const float* beta2, void* stream);
+/* Backward pass A: dzm = dy * (out > 0) written once (the gradient of both pre-activation branches), and
+ * sums f32[3C] = [sum dZ | sum dZ xhat1 | sum dZ xhat2] (zeroed here), xhat2 from upsample(z) recomputed on the fly. The first
+ * 2C are BatchNorm 1's sums in das_bn_backward_apply's layout (one slot). */
+int das_upmerge_backward_reduce(const void* dy, const void* out, const void* raw1, const void* z, void* dzm, int dtype,
+                                int B, int H, int W, int C, int Ho, int Wo, const float* mean1, const float* invstd1,
+                                const float* mean2, const float* invstd2, float* sums, void* stream);
+/* Backward pass D, at low resolution: dz = upsample^T(d raw2) from P = upsample^T(dzm) (das_upsample_bilinear_ac_backward), z, the
+ * sums of pass A and the tables of upsample^T upsample (ah f32[H][3], aw f32[W][3]: its tridiagonal factors; wh f32[H], ww
+ * f32[W]: upsample^T 1). stat_rows = B * Ho * Wo (times the ranks under SyncBN). dgamma2_acc / dbeta2_acc (both or
+ * neither): BatchNorm 2's parameter gradients are ADDED there. */
+int das_upmerge_backward_lowres(const void* P, const void* z, void* dz, int dtype, int B, int H, int W, int C,
+                                const float* ah, const float* aw, const float* wh, const float* ww, const float* sums,
+                                const float* gamma2, const float* mean2, const float* invstd2, long long stat_rows,
+                                float* dgamma2_acc, float* dbeta2_acc, void* stream);
 int das_maxpool3x3s2_argmax(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, void* stream);
 int das_maxpool3x3s2_backward_argmax(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C,
                                      void* stream);

@@ -1,6 +1,7 @@
 """MSPN's `up_conv` branch (bilinear upsample -> bias-free 1x1 conv -> train-mode BatchNorm, mspn_mmpose.py:385-389) evaluated
-with the conv BEFORE the upsampling (autograd.UpConvBNTrainFn): the upsampling kernel that reduces the BatchNorm
-statistics, and the exchanged order against the reference's order on one upsample unit."""
+with the conv BEFORE the upsampling (autograd.UpConvBNTrainFn), and the unit's whole merge relu(BN(in_skip(x)) + BN(...)) as
+one autograd node that writes neither normalised branch (autograd.UpMergeTrainFn, csrc/upmerge.hip): the upsampling kernel
+that reduces the BatchNorm statistics, and both against the reference's order on one upsample unit."""
 import numpy as np
 import pytest
 import torch
@@ -39,6 +40,27 @@ def test_upsample_with_statistics_kernel(shape, dtype):
         assert float(((got2 - want).abs() / scale).max()) < 2e-6
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 8, 13, 256, 16, 26), (1, 5, 7, 64, 9, 13), (2, 32, 52, 256, 64, 104), (3, 1, 1, 128, 4, 4),
+                                   (1, 6, 5, 32, 6, 5), (2, 4, 4, 16, 13, 9)])
+def test_statistics_of_the_upsampled_tensor_from_the_low_resolution(shape, dtype):
+    """das_upsample_stats_lowres: sum and sum of squares of upsample(z) from z alone (w = upsample^T 1 and the 3 x 3 stencil of
+    upsample^T upsample) against f64 sums over torch's interpolation of the same z."""
+    import torch.nn.functional as F
+    from das_amd import ops
+    B, H, W, C, Ho, Wo = shape
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    z = (cases.randn(5, B, H, W, C) + 0.3).to(DEV).to(dt).contiguous()
+    up = F.interpolate(z.double().permute(0, 3, 1, 2), size=(Ho, Wo), mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
+    want = torch.stack([up.reshape(-1, C).sum(0), (up * up).reshape(-1, C).sum(0)])
+    scale = torch.stack([up.abs().reshape(-1, C).sum(0), (up * up).reshape(-1, C).sum(0)]) + 1e-30
+    for slots in (1, 4):
+        stats = torch.zeros(slots * 2 * C, device=DEV)
+        ops.upsample_stats_lowres(z, Ho, Wo, stats)
+        got = stats.view(slots, 2, C).double().sum(0)
+        assert float(((got - want).abs() / scale).max()) < 5e-6, (slots, float(((got - want).abs() / scale).max()))
+
+
 def _unit(seed, dtype):
     from das_amd.backbones import UpsampleUnit
     torch.manual_seed(seed)
@@ -50,8 +72,11 @@ def _unit(seed, dtype):
     return m.to(DEV).train()
 
 
-def _run_unit(low_res, dtype, state):
+def _run_unit(mode, dtype, state):
+    """mode: False / 'ref' = the reference's order, kernel by kernel; 'lowres' = up_conv before the upsampling, the BatchNorm
+    passes as everywhere else; True / 'merge' = the whole merge as one node (the default path)."""
     from das_amd import nn as nnops
+    low_res = mode not in (False, 'ref')
     from das_amd.autograd import reset_step_state
     dt = torch.float32 if dtype == 'f32' else torch.bfloat16
     m = _unit(0, dtype)
@@ -60,13 +85,14 @@ def _run_unit(low_res, dtype, state):
     up_x = cases.randn(12, 2, 8, 13, 256).to(DEV).to(dt).requires_grad_(True)
     g = [cases.randn(13 + i, *s).to(DEV).to(dt) for i, s in enumerate([(2, 16, 26, 256), (2, 16, 26, 512), (2, 16, 26, 512)])]
     nnops.UPCONV_AT_LOW_RES = low_res
+    nnops.UPMERGE_FUSED = mode in (True, 'merge')
     try:
         reset_step_state()
         out, s1, s2, _ = m(x, up_x)
         (out.float() * g[0].float()).sum().add((s1.float() * g[1].float()).sum()).add((s2.float() * g[2].float()).sum()).backward()
         torch.cuda.synchronize()
     finally:
-        nnops.UPCONV_AT_LOW_RES = True
+        nnops.UPCONV_AT_LOW_RES = nnops.UPMERGE_FUSED = True
     res = {'out': out.detach().float(), 'dx': x.grad.float(), 'dup_x': up_x.grad.float()}
     res.update({'g.' + n: p.grad.detach().float() for n, p in m.named_parameters()})
     res.update({'b.' + n: b.detach().float().clone() for n, b in m.named_buffers()})
@@ -79,19 +105,20 @@ def test_conv_before_upsampling_equals_the_reference_order_f32():
     f32 summation only: 2e-5 of the tensor's largest magnitude (a flipped ReLU at a value of ~1e-6 moves nothing visible)."""
     _, state = _run_unit(False, 'f32', None)
     state = {k: v for k, v in _unit(0, 'f32').state_dict().items()}
-    a, _ = _run_unit(False, 'f32', state)
-    b, _ = _run_unit(True, 'f32', state)
-    assert set(a) == set(b)
-    worst = {}
-    for k in a:
-        scale = float(a[k].abs().max())
-        if scale == 0:
-            assert float(b[k].abs().max()) == 0, k
-            continue
-        worst[k] = float((a[k] - b[k]).abs().max()) / scale
-    print({k: '%.1e' % v for k, v in worst.items()})
-    assert max(worst.values()) < 2e-5, max(worst.items(), key=lambda kv: kv[1])
-    assert worst['out'] > 0, 'the switch did not change the path'
+    a, _ = _run_unit('ref', 'f32', state)
+    for mode in ('lowres', 'merge'):
+        b, _ = _run_unit(mode, 'f32', state)
+        assert set(a) == set(b)
+        worst = {}
+        for k in a:
+            scale = float(a[k].abs().max())
+            if scale == 0:
+                assert float(b[k].abs().max()) == 0, k
+                continue
+            worst[k] = float((a[k] - b[k]).abs().max()) / scale
+        print(mode, {k: '%.1e' % v for k, v in worst.items()})
+        assert max(worst.values()) < 2e-5, (mode, max(worst.items(), key=lambda kv: kv[1]))
+        assert worst['out'] > 0, 'the switch did not change the path'
 
 
 def test_conv_before_upsampling_bf16_band():
@@ -100,13 +127,17 @@ def test_conv_before_upsampling_bf16_band():
     state = {k: v for k, v in _unit(0, 'f32').state_dict().items()}
     ref, _ = _run_unit(False, 'f32', state)
     old, _ = _run_unit(False, 'bf16', state)
-    new, _ = _run_unit(True, 'bf16', state)
+    for mode in ('lowres', 'merge'):
+        _bf16_band(ref, old, _run_unit(mode, 'bf16', state)[0], mode)
+
+
+def _bf16_band(ref, old, new, mode):
     for k in ('out', 'dx', 'dup_x', 'g.up_conv.conv.weight', 'g.up_conv.bn.weight', 'g.in_skip.conv.weight', 'b.up_conv.bn.running_var'):
         scale = float(ref[k].abs().max())
         e_old = float((old[k] - ref[k]).abs().max()) / scale
         e_new = float((new[k] - ref[k]).abs().max()) / scale
-        print('%-28s old %.2e new %.2e' % (k, e_old, e_new))
-        assert e_new <= max(1.5 * e_old, 4e-3), (k, e_old, e_new)
+        print('%-7s %-28s old %.2e new %.2e' % (mode, k, e_old, e_new))
+        assert e_new <= max(1.5 * e_old, 4e-3), (mode, k, e_old, e_new)
 
 
 def test_unused_finest_unit_advances_the_same_running_statistics():

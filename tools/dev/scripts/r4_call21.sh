@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r4
+timeout 900 python3 -m pytest tests/test_upconv_gpu.py -q -m gpu -s -x 2>&1 | tail -40 > gpurun_out/r4/pytest_upmerge.txt
+cat gpurun_out/r4/pytest_upmerge.txt | cut -c1-1500
+timeout 900 python3 -m pytest tests/test_train_gpu.py tests/test_model_gpu.py tests/test_bn_fused_gpu.py tests/test_topologies_gpu.py -q -m gpu -x 2>&1 | tail -8
+timeout 600 python3 tools/dev/tune_step.py -r 3 UPMERGE=0 UPCONV=0 > gpurun_out/r4/tune_upmerge.txt 2>&1
+cat gpurun_out/r4/tune_upmerge.txt
