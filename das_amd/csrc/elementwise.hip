@@ -180,7 +180,7 @@ __global__ __launch_bounds__(TPB) void bilinear_ac_stats_kernel(const T* __restr
   const int VCB = min(VC, NT), PL = NT / VCB, pl = threadIdx.x / VCB;
   // (pixel indices in 32 bits — the launcher checks — so the row / column split is two 32-bit divisions, not 64-bit ones)
   const unsigned npix = (unsigned)B * Ho * Wo;
-  const unsigned p0 = blockIdx.x * (unsigned)pix_per_block, p1 = min(npix, p0 + pix_per_block);
+  const unsigned p0 = (unsigned)xcd_remap(blockIdx.x, gridDim.x) * (unsigned)pix_per_block, p1 = min(npix, p0 + pix_per_block);   // (neighbouring runs share source rows: same XCD, same L2)
   for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
     float s[EPV], q[EPV];
 #pragma unroll

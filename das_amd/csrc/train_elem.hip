@@ -310,6 +310,78 @@ __global__ void bilinear_ac_bwd_kernel(const T* __restrict__ dy, T* __restrict__
   }
 }
 
+// The same sum for magnifications up to 2.5 x (scale > 0.4: at most five source rows / columns carry weight), a channel
+// vector per thread: the weights of the 7 candidate rows and 7 candidate columns are evaluated once (14 bil_w instead of
+// 49 + 49 inside the loops), the first live candidate found, and the 5 x 5 taps loaded unconditionally from clamped
+// addresses — a tap outside the support has weight 0 and adds +-0. Rows ascending, columns ascending, (wh * ww) * g: the
+// order and the products of the kernel above.
+struct BilTaps {
+  int start;
+  float w[5];
+};
+__device__ __forceinline__ BilTaps bil_taps(int src, int n_src, int n_dst, float scale) {
+  const int lo = scale > 0.f ? max(0, (int)floorf((src - 1) / scale) - 1) : 0;
+  float w7[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) w7[i] = (lo + i < n_dst) ? bil_w(lo + i, src, n_src, scale) : 0.f;
+  const int f = w7[0] != 0.f ? 0 : (w7[1] != 0.f ? 1 : 2);
+  BilTaps t;
+  t.start = lo + f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) t.w[k] = f == 0 ? w7[k] : (f == 1 ? w7[k + 1] : w7[k + 2]);
+  return t;
+}
+constexpr int BWD5_MAXP = 1024;   // pixels per workgroup (at most 4 per pixel lane, at most 256 lanes)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bilinear_ac_bwd5_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W,
+                                                               int C, int Ho, int Wo, float sh, float sw, int pix_per_block) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  const int VCB = min(VC, TPB), PL = TPB / VCB, pl = threadIdx.x / VCB;
+  const unsigned npix = (unsigned)B * H * W;
+  const unsigned q0 = (unsigned)xcd_remap(blockIdx.x, gridDim.x) * (unsigned)pix_per_block, q1 = min(npix, q0 + pix_per_block);
+  // the taps of this run's pixels, once per workgroup (a third of the kernel's instructions when every thread derived them)
+  __shared__ BilTaps s_th[BWD5_MAXP], s_tw[BWD5_MAXP];
+  for (unsigned i = threadIdx.x; i < 2 * (q1 - q0); i += TPB) {
+    const unsigned k = i >> 1, pix = q0 + k;
+    const unsigned t = pix / (unsigned)W, w = pix - t * W;
+    const unsigned h = t % (unsigned)H;
+    if (i & 1) s_tw[k] = bil_taps((int)w, W, Wo, sw);
+    else s_th[k] = bil_taps((int)h, H, Ho, sh);
+  }
+  __syncthreads();
+  for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
+    for (unsigned pix = q0 + pl; pix < q1; pix += PL) {
+      const unsigned b = pix / ((unsigned)H * W);
+      const BilTaps th = s_th[pix - q0], tw = s_tw[pix - q0];
+      float acc[EPV];
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) acc[j] = 0.f;
+      const T* plane = dy + (long long)b * Ho * Wo * C + v * EPV;
+      // all 25 vectors requested before the first is used: five dependent round trips per pixel left the kernel latency bound
+      uint4 q[25];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const T* row = plane + (long long)min(th.start + r, Ho - 1) * Wo * C;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) q[r * 5 + c] = *reinterpret_cast<const uint4*>(row + (long long)min(tw.start + c, Wo - 1) * C);
+      }
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          float g[EPV];
+          Elem<T>::unpack(q[r * 5 + c], g);
+          const float ww = th.w[r] * tw.w[c];
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) acc[j] += ww * g[j];
+        }
+      }
+      *reinterpret_cast<uint4*>(dx + ((long long)pix * VC + v) * EPV) = Elem<T>::pack(acc);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ nearest upsample backward
 // db[hs,ws] = sum of dy[h,w] over the fine pixels whose nearest source is (hs,ws)
 template <typename T>
@@ -423,6 +495,18 @@ extern "C" int das_upsample_bilinear_ac_backward(const void* dy, void* dx, int d
   if (!dy || !dx || C % 8) return DAS_ERR_ARG;
   const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
   const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const long long npix = (long long)B * H * W;
+  if (sh > 0.4f && sw > 0.4f && npix < (1ll << 31)) {   // at most five live taps per axis
+    const int vc = C / (dtype == DAS_F32 ? 4 : 8);
+    const int pl = TPB / (vc < TPB ? vc : TPB);
+    const long long ppb = (long long)pl * (npix >= (1 << 16) ? 4 : 2);   // (<= BWD5_MAXP; measured: tools/dev/upT_bench.py)
+    DISPATCH_T(dtype, {
+      hipLaunchKernelGGL(bilinear_ac_bwd5_kernel<T>, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(TPB), 0, (hipStream_t)stream,
+                         (const T*)dy, (T*)dx, B, H, W, C, Ho, Wo, sh, sw, (int)ppb);
+    });
+    DAS_CHECK_LAUNCH();
+    return DAS_OK;
+  }
   DISPATCH_T(dtype, {
     const long long total = (long long)B * H * W * (C / Elem<T>::EPV);
     hipLaunchKernelGGL(bilinear_ac_bwd_kernel<T>, dim3(grid_for(total, 65536)), dim3(TPB), 0, (hipStream_t)stream,

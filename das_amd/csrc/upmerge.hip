@@ -83,7 +83,7 @@ __global__ __launch_bounds__(TPB) void upmerge_fwd_kernel(const T* __restrict__ 
   const int VC = C / EPV;
   const int VCB = min(VC, TPB), PL = TPB / VCB, pl = threadIdx.x / VCB;
   const unsigned npix = (unsigned)B * Ho * Wo;
-  const unsigned q0 = blockIdx.x * (unsigned)pix_per_block, q1 = min(npix, q0 + pix_per_block);
+  const unsigned q0 = (unsigned)xcd_remap(blockIdx.x, gridDim.x) * (unsigned)pix_per_block, q1 = min(npix, q0 + pix_per_block);
   for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
     const int c0 = v * EPV;
     float m1[EPV], i1[EPV], g1[EPV], b1[EPV], m2[EPV], i2[EPV], g2[EPV], b2[EPV];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TPB) void upmerge_fwd_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------- backward, pass A
-// One workgroup per CU (grid-stride over pixels), as bn_bwd_reduce_kernel: every workgroup ends with 3C global atomics.
+// A few workgroups per CU, each over its own run of pixels; every workgroup ends with 3C global atomics.
 template <typename T>
 __global__ __launch_bounds__(TPB) void upmerge_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ out,
                                                                  const T* __restrict__ raw1, const T* __restrict__ z,
@@ -134,7 +134,11 @@ __global__ __launch_bounds__(TPB) void upmerge_bwd_reduce_kernel(const T* __rest
   const int VC = C / EPV;
   const int VCB = min(VC, TPB), PL = TPB / VCB, pl = threadIdx.x / VCB;
   const unsigned npix = (unsigned)B * Ho * Wo;
-  const unsigned stride = gridDim.x * (unsigned)PL;
+  // a contiguous run of pixels per workgroup, neighbouring runs on one XCD: the rows of z two runs share stay in one L2
+  const unsigned run = (npix + gridDim.x - 1) / gridDim.x;
+  const unsigned long long r0 = (unsigned long long)xcd_remap(blockIdx.x, gridDim.x) * run;
+  const unsigned long long r1 = r0 + run < npix ? r0 + run : npix;
+  const unsigned stride = (unsigned)PL;
   for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
     const int c0 = v * EPV;
     float m1[EPV], i1[EPV], m2[EPV], i2[EPV], sa[EPV], sb1[EPV], sb2[EPV];
@@ -145,14 +149,14 @@ __global__ __launch_bounds__(TPB) void upmerge_bwd_reduce_kernel(const T* __rest
     }
     constexpr int U = 2;
     // (64-bit loop counter: pix + U * stride may pass 2^32 on the last trip)
-    for (unsigned long long pix0 = blockIdx.x * (unsigned)PL + pl; pix0 < npix; pix0 += (unsigned long long)U * stride) {
+    for (unsigned long long pix0 = r0 + pl; pix0 < r1; pix0 += (unsigned long long)U * stride) {
       PixGeom g[U];
       uint4 rz[U][4], rg[U], ro[U], rx[U];
       bool live[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const unsigned long long pu = pix0 + (unsigned long long)u * stride;
-        live[u] = pu < npix;
+        live[u] = pu < r1;
         const unsigned pix = live[u] ? (unsigned)pu : (unsigned)pix0;
         g[u] = pix_geom(pix, H, W, C, Ho, Wo, sh, sw);
         load_corners(z, g[u], W, C, c0, rz[u]);
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(TPB) void upstats_lowres_kernel(const T* __restrict
   const int VC = C / EPV;
   const int VCB = min(VC, TPB), PL = TPB / VCB, pl = threadIdx.x / VCB;
   const unsigned npix = (unsigned)B * H * W;
-  const unsigned q0 = blockIdx.x * (unsigned)pix_per_block, q1 = min(npix, q0 + pix_per_block);
+  const unsigned q0 = (unsigned)xcd_remap(blockIdx.x, gridDim.x) * (unsigned)pix_per_block, q1 = min(npix, q0 + pix_per_block);
   for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
     const int c0 = v * EPV;
     float s[EPV], q[EPV];
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(TPB) void upmerge_bwd_lowres_kernel(const T* __rest
   }
   const int VCB = min(VC, TPB), PL = TPB / VCB, pl = threadIdx.x / VCB;
   const unsigned npix = (unsigned)B * H * W;
-  const unsigned q0 = blockIdx.x * (unsigned)pix_per_block, q1 = min(npix, q0 + pix_per_block);
+  const unsigned q0 = (unsigned)xcd_remap(blockIdx.x, gridDim.x) * (unsigned)pix_per_block, q1 = min(npix, q0 + pix_per_block);
   for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
     const int c0 = v * EPV;
     float k1[EPV], k2[EPV], k3[EPV], mu[EPV];

@@ -83,7 +83,10 @@ def test_pool_and_upsample_backward(dtype):
     db = o.upsample_bilinear_ac_backward(nhwc(dup, dtype), 7, 9)
     close(nchw(db).numpy(), b.grad.numpy(), dtype)
     # exact 2x (the MSPN case) and a 1-row source
-    for (h, w, Ho, Wo) in [(16, 26, 32, 52), (1, 4, 3, 9)]:
+    # (... and the shapes around the five-tap kernel's limit of 2.5 x: 2 x with odd sizes, 2.4 x, 2.6 x (generic kernel), identity,
+    # reductions, one column)
+    for (h, w, Ho, Wo) in [(16, 26, 32, 52), (1, 4, 3, 9), (5, 7, 9, 13), (64, 104, 128, 208), (6, 6, 14, 14), (6, 6, 15, 16),
+                           (7, 9, 7, 9), (13, 17, 7, 9), (9, 1, 18, 1), (3, 2, 6, 5)]:
         b = rnd(cases.randn(15, 1, 8, h, w), dtype).requires_grad_(True)
         up = F.interpolate(b, size=(Ho, Wo), mode='bilinear', align_corners=True)
         dup = rnd(cases.randn(16, *up.shape), dtype)
