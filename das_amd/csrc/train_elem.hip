@@ -331,7 +331,7 @@ __device__ __forceinline__ BilTaps bil_taps(int src, int n_src, int n_dst, float
   for (int k = 0; k < 5; ++k) t.w[k] = f == 0 ? w7[k] : (f == 1 ? w7[k + 1] : w7[k + 2]);
   return t;
 }
-constexpr int BWD5_MAXP = 1024;   // pixels per workgroup (at most 4 per pixel lane, at most 256 lanes)
+constexpr int BWD5_MAXP = 512;   // pixels per workgroup
 template <typename T>
 __global__ __launch_bounds__(TPB) void bilinear_ac_bwd5_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W,
                                                                int C, int Ho, int Wo, float sh, float sw, int pix_per_block) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(TPB) void bilinear_ac_bwd5_kernel(const T* __restri
   const unsigned npix = (unsigned)B * H * W;
   const unsigned q0 = (unsigned)xcd_remap(blockIdx.x, gridDim.x) * (unsigned)pix_per_block, q1 = min(npix, q0 + pix_per_block);
   // the taps of this run's pixels, once per workgroup (a third of the kernel's instructions when every thread derived them)
-  __shared__ BilTaps s_th[BWD5_MAXP], s_tw[BWD5_MAXP];
+  __shared__ BilTaps s_th[BWD5_MAXP], s_tw[BWD5_MAXP];   // (static: the dynamic-LDS form of this kernel ran 25 % slower)
   for (unsigned i = threadIdx.x; i < 2 * (q1 - q0); i += TPB) {
     const unsigned k = i >> 1, pix = q0 + k;
     const unsigned t = pix / (unsigned)W, w = pix - t * W;
@@ -499,7 +499,8 @@ extern "C" int das_upsample_bilinear_ac_backward(const void* dy, void* dx, int d
   if (sh > 0.4f && sw > 0.4f && npix < (1ll << 31)) {   // at most five live taps per axis
     const int vc = C / (dtype == DAS_F32 ? 4 : 8);
     const int pl = TPB / (vc < TPB ? vc : TPB);
-    const long long ppb = (long long)pl * (npix >= (1 << 16) ? 4 : 2);   // (<= BWD5_MAXP; measured: tools/dev/upT_bench.py)
+    long long ppb = std::min<long long>(BWD5_MAXP, (long long)pl * (npix >= (1 << 16) ? 4 : 2));   // (measured: tools/dev/upT_bench.py)
+    if (dastune::get(dastune::ELEM_UPSTATS_PPB) > 0) ppb = std::min<long long>(BWD5_MAXP, dastune::get(dastune::ELEM_UPSTATS_PPB));
     DISPATCH_T(dtype, {
       hipLaunchKernelGGL(bilinear_ac_bwd5_kernel<T>, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(TPB), 0, (hipStream_t)stream,
                          (const T*)dy, (T*)dx, B, H, W, C, Ho, Wo, sh, sw, (int)ppb);

@@ -19,8 +19,8 @@ def t(fn, n=12, cold=True):
 for (B, H, W, C) in [(16, 64, 104, 256), (16, 32, 52, 256)]:
     dy = torch.randn(B, 2 * H, 2 * W, C, device=dev).bfloat16()
     line = ['%dx%d:' % (2 * H, 2 * W)]
-    for ppb in (8, 16, 32, 64):
+    for ppb in (0, 16, 32, 64, 0):
         _lib.check(lib.das_tuning_set(b'elem.upstats_ppb', ppb), 'set')
-        line.append('%d: %.1f (warm %.1f)' % (ppb, t(lambda: ops.upsample_bilinear_ac_backward(dy, H, W)), t(lambda: ops.upsample_bilinear_ac_backward(dy, H, W), cold=False)))
+        line.append('%d/%dKB: %.1f (warm %.1f)' % (ppb & 0xffff, ppb >> 16, t(lambda: ops.upsample_bilinear_ac_backward(dy, H, W)), t(lambda: ops.upsample_bilinear_ac_backward(dy, H, W), cold=False)))
     _lib.check(lib.das_tuning_set(b'elem.upstats_ppb', 0), 'set')
     print(' '.join(line), flush=True)
