@@ -366,6 +366,77 @@ class UpConvBNTrainFn(Function):
         return dx, dw, dgamma, dbeta, dres, None, None, None, None, None
 
 
+class ConvStatsFn(Function):
+    """conv (no bias) with the train-mode BatchNorm's statistics finalised (running buffers advanced), the normalisation
+    itself left to the consumer (BnReluAdd3Fn): returns raw, mean, invstd (+ x handed through, see ConvBNTrainSkipFn).
+    The gradient that arrives for `raw` is the BatchNorm's complete backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv, bn, skip_through):
+        from .nn import bn_stats_buffer, packed_weight
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+        stats = bn_stats_buffer(x, w.shape[0])
+        raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
+        _, mean, invstd = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                             bn.momentum if bn.momentum is not None else 0.1, bn.eps,
+                                             num_batches_tracked=bn.num_batches_tracked, finalize_only=True)
+        bn.__dict__.pop('_das_cache', None)
+        ctx.save_for_backward(x)
+        ctx.cfg = (k, s, p, conv)
+        ctx.mark_non_differentiable(mean, invstd)
+        return (raw, mean, invstd, x) if skip_through else (raw, mean, invstd)
+
+    @staticmethod
+    def backward(ctx, draw, _dmean, _dinvstd, dskip=None):
+        from .nn import packed_weight_dgrad, packed_weight_dgrad_s2
+        (x,) = ctx.saved_tensors
+        k, s, p, conv = ctx.cfg
+        draw = draw.contiguous()
+        dw = _wgrad(x, draw, conv.weight, k, s, p) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if dskip is not None:
+                dskip = dskip.contiguous()
+            dx = ops.conv2d_dgrad(draw, packed_weight_dgrad(conv, x.dtype), k, k, s, p, (x.shape[1], x.shape[2]),
+                                  residual=dskip, w_classes=packed_weight_dgrad_s2(conv, x.dtype))
+            if dx.shape[-1] != x.shape[-1]:
+                dx = dx[..., :x.shape[-1]]
+        elif dskip is not None:
+            dx = dskip
+        return dx, dw, None, None, None
+
+
+class BnReluAdd3Fn(Function):
+    """x + relu(BN1(raw1)) + relu(BN2(raw2)) over ConvStatsFn's outputs: MSPN's cross-stage merge (mspn_mmpose.py:254-275)
+    as one pass forward and two backward (csrc/skipadd.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, raw1, mean1, invstd1, g1, b1, raw2, mean2, invstd2, g2, b2, bn1, bn2):
+        out = ops.bn_relu_add3_forward(x, raw1, (mean1, invstd1, g1, b1), raw2, (mean2, invstd2, g2, b2))
+        ctx.save_for_backward(raw1, mean1, invstd1, g1, b1, raw2, mean2, invstd2, g2, b2)
+        ctx.mods = (bn1, bn2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raw1, mean1, invstd1, g1, b1, raw2, mean2, invstd2, g2, b2 = ctx.saved_tensors
+        bn1, bn2 = ctx.mods
+        g = g.contiguous()
+        acc = [_param_acc(p) for p in (bn1.weight, bn1.bias, bn2.weight, bn2.bias)]
+        direct = all(a is not None for a in acc)
+        d1, d2, sums = ops.bn_relu_add3_backward(g, raw1, (mean1, invstd1, g1, b1), raw2, (mean2, invstd2, g2, b2),
+                                                 acc=tuple(a[1] for a in acc) if direct else None)
+        if direct:
+            for a in acc:
+                a[0].fired()
+            db1 = dg1 = db2 = dg2 = None
+        else:
+            Cc = raw1.shape[-1]
+            db1, dg1, db2, dg2 = (sums[i * Cc:(i + 1) * Cc].clone() for i in range(4))
+        return g, d1, None, None, dg1, db1, d2, None, None, dg2, db2, None, None
+
+
 class UpMergeTrainFn(Function):
     """One MSPN upsample unit's merge in train mode (mspn_mmpose.py:381-404):
     out = relu(BN1(in_skip(x)) + BN2(up_conv(upsample(up_x)))), as one autograd node over the kernels of

@@ -93,7 +93,7 @@ class DownsampleModule(nn.Module):
             else:
                 x = y
             if self.has_skip:
-                x = nnops.add3(x, skip1[i], skip2[i])
+                x = nnops.skip_add(x, skip1[i], skip2[i])
             out.append(x)
         out.reverse()
         return tuple(out)
@@ -147,9 +147,9 @@ class UpsampleUnit(nn.Module):
                 out, x = out
         skip1 = skip2 = cross = None
         if self.gen_skip:
-            skip1 = self.out_skip1(x)
-            m = self.out_skip2
-            skip2, out = conv_bn(out, m.conv, m.norm, relu=m.with_activation, skip_through=True)
+            # (train mode: normalised by their consumer, the next stage's add — nn.conv_bn_deferred / skip_add)
+            skip1 = nnops.conv_bn_deferred(x, self.out_skip1)
+            skip2, out = nnops.conv_bn_deferred(out, self.out_skip2, skip_through=True)
         if self.ind == self.num_units - 1 and self.gen_cross_conv:
             m = self.cross_conv
             cross, out = conv_bn(out, m.conv, m.norm, relu=m.with_activation, skip_through=True)

@@ -212,6 +212,43 @@ def upsample_conv_bn(x_lo, Ho, Wo, conv, bn, relu=False, residual=None):
     return conv_bn(upsample_bilinear(x_lo, Ho, Wo), conv, bn, relu=relu, residual=residual)
 
 
+# MSPN's cross-stage skips (out_skip1 / out_skip2 -> the next stage's add) with the BatchNorm apply deferred to the add
+# (autograd.ConvStatsFn + BnReluAdd3Fn); switch for A/B runs and tests
+DEFERRED_SKIPS = True
+
+
+class DeferredBN:
+    """A ConvModule(conv, BN, ReLU) evaluated up to the BatchNorm's statistics: the consumer (skip_add) normalises."""
+    __slots__ = ('raw', 'mean', 'invstd', 'bn')
+
+    def __init__(self, raw, mean, invstd, bn):
+        self.raw, self.mean, self.invstd, self.bn = raw, mean, invstd, bn
+
+
+def conv_bn_deferred(x, module, skip_through=False):
+    """module(x) for a ConvModule with BN + ReLU whose only consumer is skip_add: in train mode with autograd a DeferredBN
+    (the normalised tensor is never written), otherwise the tensor. skip_through as conv_bn."""
+    from . import autograd as ag
+    conv, bn = module.conv, module.norm
+    if (DEFERRED_SKIPS and module.with_activation and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
+            and conv.bias is None and ag._sync_world(bn) == 1
+            and ag.grad_mode(x, conv.weight, bn.weight)):
+        res = ag.ConvStatsFn.apply(x, conv.weight, conv, bn, skip_through)
+        d = DeferredBN(res[0], res[1], res[2], bn)
+        return (d, res[3]) if skip_through else d
+    return conv_bn(x, conv, bn, relu=module.with_activation, skip_through=skip_through)
+
+
+def skip_add(x, s1, s2):
+    """x + s1 + s2 where s1, s2 are tensors or DeferredBN (both of one kind)."""
+    if isinstance(s1, DeferredBN) or isinstance(s2, DeferredBN):
+        from . import autograd as ag
+        assert isinstance(s1, DeferredBN) and isinstance(s2, DeferredBN)
+        return ag.BnReluAdd3Fn.apply(x, s1.raw, s1.mean, s1.invstd, s1.bn.weight, s1.bn.bias,
+                                     s2.raw, s2.mean, s2.invstd, s2.bn.weight, s2.bn.bias, s1.bn, s2.bn)
+    return add3(x, s1, s2)
+
+
 # the whole merge of an MSPN upsample unit as one autograd node (autograd.UpMergeTrainFn); switch for A/B runs and tests
 UPMERGE_FUSED = True
 

@@ -756,6 +756,43 @@ def _upsample_tables(H, Ho, device):
     return _UP_TABLES[key]
 
 
+def _bn_ptrs(bn1, bn2):
+    arr = (C.c_void_p * 8)(*[_ptr(t) for t in (*bn1, *bn2)])
+    return arr
+
+
+def bn_relu_add3_forward(x, raw1, bn1, raw2, bn2):
+    """x + relu(BN1(raw1)) + relu(BN2(raw2)); bn = (mean, invstd, gamma, beta) f32[C] (das_bn_relu_add3_forward)."""
+    _need_gpu(x, raw1, raw2)
+    assert x.is_contiguous() and raw1.is_contiguous() and raw2.is_contiguous() and x.shape == raw1.shape == raw2.shape
+    assert x.dtype == raw1.dtype == raw2.dtype
+    Cc = x.shape[-1]
+    out = torch.empty_like(x)
+    arr = _bn_ptrs(bn1, bn2)
+    with _timed('bn_apply_kernel', 4 * x.numel() * x.element_size(), shape=(x.numel() // Cc, Cc, 'skipadd')):
+        _lib.check(_lib.load().das_bn_relu_add3_forward(_ptr(x), _ptr(raw1), _ptr(raw2), _ptr(out), _DT[x.dtype], x.numel() // Cc, Cc,
+                                                        arr, _stream()), 'das_bn_relu_add3_forward')
+    return out
+
+
+def bn_relu_add3_backward(g, raw1, bn1, raw2, bn2, acc=None):
+    """Returns d raw1, d raw2, sums f32[4C] = [dbeta1 | dgamma1 | dbeta2 | dgamma2]; acc = (dgamma1, dbeta1, dgamma2, dbeta2)
+    accumulators the parameter gradients are also added to (das_bn_relu_add3_backward)."""
+    _need_gpu(g, raw1, raw2)
+    assert g.is_contiguous() and g.shape == raw1.shape == raw2.shape and g.dtype == raw1.dtype == raw2.dtype
+    Cc = g.shape[-1]
+    rows = g.numel() // Cc
+    d1, d2 = torch.empty_like(raw1), torch.empty_like(raw2)
+    sums = torch.empty(4 * Cc, dtype=torch.float32, device=g.device)
+    arr = _bn_ptrs(bn1, bn2)
+    a = acc if acc is not None else (None, None, None, None)
+    with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', 8 * g.numel() * g.element_size(), launches=2, shape=(rows, Cc, 'skipadd')):
+        _lib.check(_lib.load().das_bn_relu_add3_backward(_ptr(g), _ptr(raw1), _ptr(raw2), _ptr(d1), _ptr(d2), _DT[g.dtype], rows, Cc,
+                                                         arr, _ptr(sums), rows, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]),
+                                                         _stream()), 'das_bn_relu_add3_backward')
+    return d1, d2, sums
+
+
 def upsample_stats_lowres(z, Ho, Wo, stats):
     """Batch statistics of upsample_bilinear_ac(z, Ho, Wo) (f32, unrounded) added into the zeroed stats f32[slots * 2C], from
     z alone (das_upsample_stats_lowres)."""

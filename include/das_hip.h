@@ -270,6 +270,18 @@ int das_upmerge_backward_lowres(const void* P, const void* z, void* dz, int dtyp
                                 const float* ah, const float* aw, const float* wh, const float* ww, const float* sums,
                                 const float* gamma2, const float* mean2, const float* invstd2, long long stat_rows,
                                 float* dgamma2_acc, float* dbeta2_acc, void* stream);
+/* MSPN's cross-stage merge in train mode, out = x + relu(BN1(raw1)) + relu(BN2(raw2)) (mspn_mmpose.py:254-275: the next stage's
+ * level feature plus the previous stage's two skip branches, out_skip1 / out_skip2 of mspn_mmpose.py:381-404), without
+ * writing the two normalised tensors (das_amd/csrc/skipadd.hip). All tensors (rows, C); bn = 8 pointers to f32[C]:
+ * mean1, invstd1, gamma1, beta1, mean2, invstd2, gamma2, beta2.
+ * Backward: g = d out (also d x); writes d raw1, d raw2 (the full train-mode BatchNorm backward of each branch, ReLU mask
+ * recomputed from raw_i) and sums f32[4C] = [sum g1 | sum g1 xhat1 | sum g2 | sum g2 xhat2] (dbeta_i | dgamma_i); stat_rows =
+ * rows. The four accumulators (all or none): the parameter gradients are ADDED there as well. */
+int das_bn_relu_add3_forward(const void* x, const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C,
+                             const float* const* bn, void* stream);
+int das_bn_relu_add3_backward(const void* g, const void* raw1, const void* raw2, void* draw1, void* draw2, int dtype,
+                              long long rows, int C, const float* const* bn, float* sums, long long stat_rows,
+                              float* dgamma1_acc, float* dbeta1_acc, float* dgamma2_acc, float* dbeta2_acc, void* stream);
 int das_maxpool3x3s2_argmax(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, void* stream);
 int das_maxpool3x3s2_backward_argmax(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C,
                                      void* stream);

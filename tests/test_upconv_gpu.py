@@ -74,7 +74,8 @@ def _unit(seed, dtype):
 
 def _run_unit(mode, dtype, state):
     """mode: False / 'ref' = the reference's order, kernel by kernel; 'lowres' = up_conv before the upsampling, the BatchNorm
-    passes as everywhere else; True / 'merge' = the whole merge as one node (the default path)."""
+    passes as everywhere else; 'merge' = the whole merge as one node; True / 'deferred' = that, and the two skip branches
+    normalised by their consumer (the default path). The unit's skips meet a third tensor as in the next stage's add."""
     from das_amd import nn as nnops
     low_res = mode not in (False, 'ref')
     from das_amd.autograd import reset_step_state
@@ -83,17 +84,22 @@ def _run_unit(mode, dtype, state):
     m.load_state_dict(state) if state is not None else None
     x = cases.randn(11, 2, 16, 26, 512).to(DEV).to(dt).requires_grad_(True)
     up_x = cases.randn(12, 2, 8, 13, 256).to(DEV).to(dt).requires_grad_(True)
-    g = [cases.randn(13 + i, *s).to(DEV).to(dt) for i, s in enumerate([(2, 16, 26, 256), (2, 16, 26, 512), (2, 16, 26, 512)])]
+    g = [cases.randn(13 + i, *s).to(DEV).to(dt) for i, s in enumerate([(2, 16, 26, 256), (2, 16, 26, 512)])]
+    xn = cases.randn(15, 2, 16, 26, 512).to(DEV).to(dt).requires_grad_(True)
     nnops.UPCONV_AT_LOW_RES = low_res
-    nnops.UPMERGE_FUSED = mode in (True, 'merge')
+    nnops.UPMERGE_FUSED = mode in (True, 'merge', 'deferred')
+    nnops.DEFERRED_SKIPS = mode in (True, 'deferred')
     try:
         reset_step_state()
         out, s1, s2, _ = m(x, up_x)
-        (out.float() * g[0].float()).sum().add((s1.float() * g[1].float()).sum()).add((s2.float() * g[2].float()).sum()).backward()
+        assert isinstance(s1, nnops.DeferredBN) == isinstance(s2, nnops.DeferredBN) == nnops.DEFERRED_SKIPS
+        nxt = nnops.skip_add(xn, s1, s2)
+        (out.float() * g[0].float()).sum().add((nxt.float() * g[1].float()).sum()).backward()
         torch.cuda.synchronize()
     finally:
-        nnops.UPCONV_AT_LOW_RES = nnops.UPMERGE_FUSED = True
-    res = {'out': out.detach().float(), 'dx': x.grad.float(), 'dup_x': up_x.grad.float()}
+        nnops.UPCONV_AT_LOW_RES = nnops.UPMERGE_FUSED = nnops.DEFERRED_SKIPS = True
+    res = {'out': out.detach().float(), 'next': nxt.detach().float(), 'dx': x.grad.float(), 'dup_x': up_x.grad.float(),
+           'dxn': xn.grad.float()}
     res.update({'g.' + n: p.grad.detach().float() for n, p in m.named_parameters()})
     res.update({'b.' + n: b.detach().float().clone() for n, b in m.named_buffers()})
     return res, {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -106,7 +112,7 @@ def test_conv_before_upsampling_equals_the_reference_order_f32():
     _, state = _run_unit(False, 'f32', None)
     state = {k: v for k, v in _unit(0, 'f32').state_dict().items()}
     a, _ = _run_unit('ref', 'f32', state)
-    for mode in ('lowres', 'merge'):
+    for mode in ('lowres', 'merge', 'deferred'):
         b, _ = _run_unit(mode, 'f32', state)
         assert set(a) == set(b)
         worst = {}
@@ -127,12 +133,12 @@ def test_conv_before_upsampling_bf16_band():
     state = {k: v for k, v in _unit(0, 'f32').state_dict().items()}
     ref, _ = _run_unit(False, 'f32', state)
     old, _ = _run_unit(False, 'bf16', state)
-    for mode in ('lowres', 'merge'):
+    for mode in ('lowres', 'merge', 'deferred'):
         _bf16_band(ref, old, _run_unit(mode, 'bf16', state)[0], mode)
 
 
 def _bf16_band(ref, old, new, mode):
-    for k in ('out', 'dx', 'dup_x', 'g.up_conv.conv.weight', 'g.up_conv.bn.weight', 'g.in_skip.conv.weight', 'b.up_conv.bn.running_var'):
+    for k in ('out', 'next', 'dx', 'dup_x', 'g.out_skip1.conv.weight', 'g.out_skip2.bn.weight', 'g.up_conv.conv.weight', 'g.up_conv.bn.weight', 'g.in_skip.conv.weight', 'b.up_conv.bn.running_var'):
         scale = float(ref[k].abs().max())
         e_old = float((old[k] - ref[k]).abs().max()) / scale
         e_new = float((new[k] - ref[k]).abs().max()) / scale
@@ -156,3 +162,45 @@ def test_unused_finest_unit_advances_the_same_running_statistics():
     for (n, a), (_, b) in zip(full.named_buffers(), lean.named_buffers()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-7), n
         assert 'num_batches' not in n or int(a) == 1
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('rows,C', [(2 * 16 * 26, 512), (333, 64), (1000, 2048), (7, 8), (4 * 32 * 52, 256)])
+def test_bn_relu_add3_kernels_vs_torch_f64(rows, C, dtype):
+    """das_bn_relu_add3_forward / _backward against torch autograd in f64 through x + relu(batch_norm(raw1)) +
+    relu(batch_norm(raw2)) (training mode: the gradient passes through the batch statistics)."""
+    import torch.nn.functional as F
+    from das_amd import ops
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    mk = lambda seed: cases.randn(seed, rows, C).to(dt)
+    x, r1, r2, g = mk(1), mk(2) * 1.5 + 0.2, mk(3) * 0.7 - 0.1, mk(4)
+    ga = [torch.rand(C, generator=torch.Generator().manual_seed(5 + i)) + 0.5 for i in range(2)]
+    be = [torch.rand(C, generator=torch.Generator().manual_seed(7 + i)) - 0.5 for i in range(2)]
+    leaves = [t.double().requires_grad_(True) for t in (x, r1, r2, ga[0], be[0], ga[1], be[1])]
+    X, R1, R2, G1, B1, G2, B2 = leaves
+    ref = X + F.relu(F.batch_norm(R1, None, None, G1, B1, True, 0.1, 1e-5)) + F.relu(F.batch_norm(R2, None, None, G2, B2, True, 0.1, 1e-5))
+    ref.backward(g.double())
+    par = []
+    for r, gam, bet in ((r1, ga[0], be[0]), (r2, ga[1], be[1])):
+        rd = r.double()
+        mean, var = rd.mean(0), rd.var(0, unbiased=False)
+        par.append(tuple(t.float().to(DEV).contiguous() for t in (mean, (var + 1e-5).rsqrt(), gam, bet)))
+    xd, r1d, r2d, gd = (t.to(DEV).contiguous() for t in (x, r1, r2, g))
+    out = ops.bn_relu_add3_forward(xd, r1d, par[0], r2d, par[1])
+    acc = tuple(torch.full((C,), 0.25, device=DEV) for _ in range(4))
+    d1, d2, sums = ops.bn_relu_add3_backward(gd, r1d, par[0], r2d, par[1], acc=acc)
+    tol = 2e-5 if dtype == 'f32' else 1.2e-2
+
+    def close(a, b, what, t=tol):
+        scale = float(b.abs().max()) + 1e-30
+        err = float((a.double().cpu() - b).abs().max()) / scale
+        assert err < t, (what, err)
+
+    close(out, ref.detach(), 'out')
+    close(d1, R1.grad, 'd raw1')
+    close(d2, R2.grad, 'd raw2')
+    want = [B1.grad, G1.grad, B2.grad, G2.grad]
+    for i, w in enumerate(want):
+        close(sums[i * C:(i + 1) * C], w, 'sums %d' % i, 5e-5 if dtype == 'f32' else tol)
+    for a, w, n in zip(acc, (G1.grad, B1.grad, G2.grad, B2.grad), ('dgamma1', 'dbeta1', 'dgamma2', 'dbeta2')):
+        close(a - 0.25, w, n, 1e-4 if dtype == 'f32' else tol)
