@@ -256,6 +256,25 @@ def _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual):
     return y, raw, mean, invstd, world
 
 
+def _conv_stats_forward(x, conv, bn, gamma, beta):
+    """conv (BatchNorm statistics in its epilogue) -> finalize only (mean / invstd published, running buffers advanced): the
+    normalisation is left to a consumer. One rank's statistics only. Returns raw, mean, invstd."""
+    from .nn import bn_stats_buffer, packed_weight
+    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+    stats = bn_stats_buffer(x, w.shape[0])
+    raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
+    _, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var,
+                                         bn.momentum if bn.momentum is not None else 0.1, bn.eps,
+                                         num_batches_tracked=bn.num_batches_tracked, finalize_only=True)
+    bn.__dict__.pop('_das_cache', None)
+    return raw, mean, invstd
+
+
+# a bottleneck's projection shortcut normalised inside bn3's apply pass (ops.bn_dual_apply); switch for A/B runs and tests
+DUAL_APPLY = True
+
+
 class ConvBNTrainFn(Function):
     """conv (no bias) -> train-mode BatchNorm (+ residual) (+ ReLU). mspn_mmpose.py:126-157,381-404."""
 
@@ -555,10 +574,16 @@ class BottleneckChainFn(Function):
             if blk.downsample is not None:
                 wd, gd, bd = (next(it) for _ in range(3))
                 ds = blk.downsample
-                idn, rawd, md, idd, _ = _convbn_train_forward(xin, ds.conv, ds.bn, gd, bd, False, None)
+                if DUAL_APPLY and _sync_world(ds.bn) == 1 and _sync_world(blk.bn3) == 1:
+                    # the shortcut's normalised tensor is read by bn3's apply pass only: never written
+                    rawd, md, idd = _conv_stats_forward(xin, ds.conv, ds.bn, gd, bd)
+                    raw3, m3, i3 = _conv_stats_forward(y2, blk.conv3, blk.bn3, g3, b3)
+                    y3 = ops.bn_dual_apply(raw3, (m3, i3, g3, b3), rawd, (md, idd, gd, bd), relu=True)
+                else:
+                    idn, rawd, md, idd, _ = _convbn_train_forward(xin, ds.conv, ds.bn, gd, bd, False, None)
+                    y3, raw3, m3, i3, _ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, idn)
             else:
-                idn = xin
-            y3, raw3, m3, i3, _ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, idn)
+                y3, raw3, m3, i3, _ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, xin)
             ent['u'] = len(saved)
             saved += [raw1, m1, i1, y1, raw2, m2, i2, y2, raw3, m3, i3, y3]
             if blk.downsample is not None:

@@ -65,6 +65,51 @@ __global__ __launch_bounds__(TPB) void bn_relu_add3_fwd_kernel(const T* __restri
   }
 }
 
+// out = relu(BN1(raw1) + BN2(raw2)): a bottleneck's last BatchNorm with the block's projection shortcut (mspn_mmpose.py:126-157:
+// `out = bn3(conv3(..)) + downsample(x)`, then ReLU) — the normalised shortcut is never written.
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_dual_apply_kernel(const T* __restrict__ raw1, const T* __restrict__ raw2,
+                                                            T* __restrict__ out, long long rows, int C, int rows_per_block,
+                                                            BnPar p1, BnPar p2, int relu) {
+  constexpr int EPV = Elem<T>::EPV;
+  const int VC = C / EPV;
+  const int VCB = min(VC, TPB), PL = TPB / VCB, pl = threadIdx.x / VCB;
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int v = threadIdx.x % VCB; v < VC && pl < PL; v += VCB) {
+    const int c0 = v * EPV;
+    float m1[EPV], i1[EPV], g1[EPV], b1[EPV], m2[EPV], i2[EPV], g2[EPV], b2[EPV];
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      m1[j] = p1.mean[c0 + j]; i1[j] = p1.invstd[c0 + j]; g1[j] = p1.gamma[c0 + j]; b1[j] = p1.beta[c0 + j];
+      m2[j] = p2.mean[c0 + j]; i2[j] = p2.invstd[c0 + j]; g2[j] = p2.gamma[c0 + j]; b2[j] = p2.beta[c0 + j];
+    }
+    constexpr int U = 4;
+    for (long long r = r0 + pl; r < r1; r += (long long)U * PL) {
+      uint4 ra[U], rb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long o = min(r + (long long)u * PL, r1 - 1) * C + c0;
+        ra[u] = *reinterpret_cast<const uint4*>(raw1 + o);
+        rb[u] = *reinterpret_cast<const uint4*>(raw2 + o);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long ru = r + (long long)u * PL;
+        if (ru >= r1) break;
+        float fa[EPV], fb[EPV], o[EPV];
+        Elem<T>::unpack(ra[u], fa);
+        Elem<T>::unpack(rb[u], fb);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) {
+          const float t = bn_affine(fa[j], m1[j], i1[j], g1[j], b1[j]) + bn_affine(fb[j], m2[j], i2[j], g2[j], b2[j]);
+          o[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+        *reinterpret_cast<uint4*>(out + ru * C + c0) = Elem<T>::pack(o);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(TPB) void bn_relu_add3_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ raw1,
                                                                       const T* __restrict__ raw2, long long rows, int C,
@@ -204,6 +249,23 @@ extern "C" int das_bn_relu_add3_forward(const void* x, const void* raw1, const v
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(bn_relu_add3_fwd_kernel<T>, dim3((unsigned)grid), dim3(TPB), 0, (hipStream_t)stream, (const T*)x,
                        (const T*)raw1, (const T*)raw2, (T*)out, rows, C, (int)rpb, p1, p2);
+  });
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C,
+                                 const float* const* bn, int relu, void* stream) {
+  if (!raw1 || !raw2 || !out || !bn || !par_ok(bn) || rows < 1 || C % 8 || C < 8 || C > 4096) return DAS_ERR_ARG;
+  const int vc = C / (dtype == DAS_F32 ? 4 : 8);
+  const int pl = TPB / (vc < TPB ? vc : TPB);
+  const long long rpb = (long long)pl * 4 * (rows * C >= (1ll << 24) ? 2 : 1);
+  const long long grid = (rows + rpb - 1) / rpb;
+  if (grid >= (1ll << 31)) return DAS_ERR_ARG;
+  const BnPar p1{bn[0], bn[1], bn[2], bn[3]}, p2{bn[4], bn[5], bn[6], bn[7]};
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(bn_dual_apply_kernel<T>, dim3((unsigned)grid), dim3(TPB), 0, (hipStream_t)stream, (const T*)raw1,
+                       (const T*)raw2, (T*)out, rows, C, (int)rpb, p1, p2, relu);
   });
   DAS_CHECK_LAUNCH();
   return DAS_OK;

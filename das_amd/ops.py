@@ -761,6 +761,19 @@ def _bn_ptrs(bn1, bn2):
     return arr
 
 
+def bn_dual_apply(raw1, bn1, raw2, bn2, relu=True):
+    """relu(BN1(raw1) + BN2(raw2)); bn = (mean, invstd, gamma, beta) f32[C] (das_bn_dual_apply)."""
+    _need_gpu(raw1, raw2)
+    assert raw1.is_contiguous() and raw2.is_contiguous() and raw1.shape == raw2.shape and raw1.dtype == raw2.dtype
+    Cc = raw1.shape[-1]
+    out = torch.empty_like(raw1)
+    arr = _bn_ptrs(bn1, bn2)
+    with _timed('bn_apply_kernel', 3 * raw1.numel() * raw1.element_size(), shape=(raw1.numel() // Cc, Cc, 'dual')):
+        _lib.check(_lib.load().das_bn_dual_apply(_ptr(raw1), _ptr(raw2), _ptr(out), _DT[raw1.dtype], raw1.numel() // Cc, Cc, arr,
+                                                 int(relu), _stream()), 'das_bn_dual_apply')
+    return out
+
+
 def bn_relu_add3_forward(x, raw1, bn1, raw2, bn2):
     """x + relu(BN1(raw1)) + relu(BN2(raw2)); bn = (mean, invstd, gamma, beta) f32[C] (das_bn_relu_add3_forward)."""
     _need_gpu(x, raw1, raw2)

@@ -277,6 +277,10 @@ int das_upmerge_backward_lowres(const void* P, const void* z, void* dz, int dtyp
  * Backward: g = d out (also d x); writes d raw1, d raw2 (the full train-mode BatchNorm backward of each branch, ReLU mask
  * recomputed from raw_i) and sums f32[4C] = [sum g1 | sum g1 xhat1 | sum g2 | sum g2 xhat2] (dbeta_i | dgamma_i); stat_rows =
  * rows. The four accumulators (all or none): the parameter gradients are ADDED there as well. */
+/* out = relu?(BN1(raw1) + BN2(raw2)): a bottleneck's bn3 with the block's projection shortcut `downsample(x)`
+ * (mspn_mmpose.py:126-157) normalised on the fly — the shortcut's normalised tensor is never written. bn as below. */
+int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C, const float* const* bn,
+                      int relu, void* stream);
 int das_bn_relu_add3_forward(const void* x, const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C,
                              const float* const* bn, void* stream);
 int das_bn_relu_add3_backward(const void* g, const void* raw1, const void* raw2, void* draw1, void* draw2, int dtype,

@@ -204,3 +204,27 @@ def test_bn_relu_add3_kernels_vs_torch_f64(rows, C, dtype):
         close(sums[i * C:(i + 1) * C], w, 'sums %d' % i, 5e-5 if dtype == 'f32' else tol)
     for a, w, n in zip(acc, (G1.grad, B1.grad, G2.grad, B2.grad), ('dgamma1', 'dbeta1', 'dgamma2', 'dbeta2')):
         close(a - 0.25, w, n, 1e-4 if dtype == 'f32' else tol)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('rows,C', [(2 * 16 * 26, 512), (333, 64), (50, 2048), (7, 8)])
+def test_bn_dual_apply_vs_the_two_pass_form(rows, C, dtype):
+    """das_bn_dual_apply = relu(BN3(raw3) + BNd(rawd)) (a bottleneck's last BatchNorm with the projection shortcut normalised on
+    the fly) against f64, and against the two-pass form (shortcut normalised and stored, then added in bn3's pass) in the
+    storage type's rounding."""
+    from das_amd import ops
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    r3, rd = (cases.randn(31, rows, C) * 1.3 + 0.1).to(dt).to(DEV), (cases.randn(32, rows, C) * 0.8 - 0.2).to(dt).to(DEV)
+    par = []
+    for i, r in enumerate((r3, rd)):
+        x = r.double()
+        gam = (torch.rand(C, generator=torch.Generator().manual_seed(40 + i)) + 0.5).to(DEV)
+        bet = (torch.rand(C, generator=torch.Generator().manual_seed(50 + i)) - 0.5).to(DEV)
+        par.append((x.mean(0).float(), (x.var(0, unbiased=False) + 1e-5).rsqrt().float(), gam, bet))
+    aff = lambda r, p: (r.double() - p[0].double()) * p[1].double() * p[2].double() + p[3].double()
+    want = torch.relu(aff(r3, par[0]) + aff(rd, par[1]))
+    got = ops.bn_dual_apply(r3.view(1, 1, rows, C), par[0], rd.view(1, 1, rows, C), par[1], relu=True).view(rows, C)
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) / scale < (1e-6 if dtype == 'f32' else 4e-3)
+    lin = ops.bn_dual_apply(r3.view(1, 1, rows, C), par[0], rd.view(1, 1, rows, C), par[1], relu=False).view(rows, C)
+    assert float((lin.double() - (aff(r3, par[0]) + aff(rd, par[1]))).abs().max()) / scale < (1e-6 if dtype == 'f32' else 4e-3)
