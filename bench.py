@@ -391,7 +391,9 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
     if bn:
         tot = [sum(x[i] for x in bn.values()) for i in range(5)]
         roof_bn = entry(' + '.join(sorted(bn)), tot, 'all BatchNorm passes of the step (forward apply, backward apply, '
-                        'backward reduce + apply); algorithmic bytes = every operand of every pass once')
+                        'backward reduce + apply; the fused forms count under the pass they replace: upsample-unit merge, '
+                        'cross-stage skip add, projection-shortcut dual apply); algorithmic bytes = every operand of every '
+                        'pass once')
     # every millisecond of the step: families + the rest (ATen glue launches, launch gaps, event overhead of this pass)
     fam_ms = {k: x[1] / reps * 1e3 for k, x in fam.items()}
     at_roof = 0.0

@@ -814,6 +814,11 @@ def upsample_stats_lowres(z, Ho, Wo, stats):
     assert z.is_contiguous() and stats.dtype == torch.float32 and stats.numel() % (2 * Cc) == 0
     ah, wh = _upsample_tables(H, Ho, z.device)
     aw, ww = _upsample_tables(W, Wo, z.device)
+    with _timed('bn_apply_kernel', z.numel() * z.element_size(), shape=(z.numel() // Cc, Cc, 'upstats')):
+        _upsample_stats_lowres(z, B, H, W, Cc, ah, aw, wh, ww, stats)
+
+
+def _upsample_stats_lowres(z, B, H, W, Cc, ah, aw, wh, ww, stats):
     _lib.check(_lib.load().das_upsample_stats_lowres(_ptr(z), _DT[z.dtype], B, H, W, Cc, _ptr(ah), _ptr(aw), _ptr(wh), _ptr(ww),
                                                      _ptr(stats), stats.numel() // (2 * Cc), _stream()), 'das_upsample_stats_lowres')
 
@@ -824,8 +829,11 @@ def upmerge_forward(raw1, z, bn1, bn2):
     B, Ho, Wo, Cc = raw1.shape
     assert raw1.is_contiguous() and z.is_contiguous() and z.shape[0] == B and z.shape[3] == Cc and z.dtype == raw1.dtype
     out = torch.empty_like(raw1)
-    _lib.check(_lib.load().das_upmerge_forward(_ptr(raw1), _ptr(z), _ptr(out), _DT[raw1.dtype], B, z.shape[1], z.shape[2], Cc, Ho, Wo,
-                                               *[_ptr(t) for t in bn1], *[_ptr(t) for t in bn2], _stream()), 'das_upmerge_forward')
+    with _timed('bn_apply_kernel', 2 * raw1.numel() * raw1.element_size() + z.numel() * z.element_size(),
+                shape=(raw1.numel() // Cc, Cc, 'upmerge')):
+        _lib.check(_lib.load().das_upmerge_forward(_ptr(raw1), _ptr(z), _ptr(out), _DT[raw1.dtype], B, z.shape[1], z.shape[2], Cc, Ho,
+                                                   Wo, *[_ptr(t) for t in bn1], *[_ptr(t) for t in bn2], _stream()),
+                   'das_upmerge_forward')
     return out
 
 
@@ -853,10 +861,11 @@ def upmerge_backward_lowres(P, z, Ho, Wo, sums, gamma2, mean2, invstd2, stat_row
     ah, wh = _upsample_tables(H, Ho, z.device)
     aw, ww = _upsample_tables(W, Wo, z.device)
     dz = torch.empty_like(z)
-    _lib.check(_lib.load().das_upmerge_backward_lowres(_ptr(P), _ptr(z), _ptr(dz), _DT[z.dtype], B, H, W, Cc, _ptr(ah), _ptr(aw),
-                                                       _ptr(wh), _ptr(ww), _ptr(sums), _ptr(gamma2), _ptr(mean2), _ptr(invstd2),
-                                                       int(stat_rows), _ptr(dgamma2_acc), _ptr(dbeta2_acc), _stream()),
-               'das_upmerge_backward_lowres')
+    with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', 3 * z.numel() * z.element_size(), shape=(z.numel() // Cc, Cc, 'uplow')):
+        _lib.check(_lib.load().das_upmerge_backward_lowres(_ptr(P), _ptr(z), _ptr(dz), _DT[z.dtype], B, H, W, Cc, _ptr(ah), _ptr(aw),
+                                                           _ptr(wh), _ptr(ww), _ptr(sums), _ptr(gamma2), _ptr(mean2), _ptr(invstd2),
+                                                           int(stat_rows), _ptr(dgamma2_acc), _ptr(dbeta2_acc), _stream()),
+                   'das_upmerge_backward_lowres')
     return dz
 
 
