@@ -404,6 +404,7 @@ class ConvStatsFn(Function):
         ctx.save_for_backward(x)
         ctx.cfg = (k, s, p, conv)
         ctx.mark_non_differentiable(mean, invstd)
+        ctx.set_materialize_grads(False)   # (no zero tensors for the gradients of mean / invstd: 4 launches per call)
         return (raw, mean, invstd, x) if skip_through else (raw, mean, invstd)
 
     @staticmethod
@@ -907,6 +908,19 @@ class DeformIm2colFn(Function):
         return _d(dx).to(x.dtype), _d(dom), None
 
 
+def _dcn_gemm_weight(dcn, weight, col):
+    """(O_pad, 1, 1, 9 C_pad) GEMM weight of a DCNv2 layer in col's dtype: the optimizer's once-per-step packed copy when the
+    layer's flat storage is usable as it is (channels-last (O, 3, 3, C) == (O, 1, 1, 9C)), else a cached pack refreshed in place."""
+    from .nn import _cache_of, _slot_of
+    cpad = col.shape[-1] // 9
+    sl = _slot_of(weight, cpad)
+    if sl is not None and sl.cl_shape[0] % 8 == 0:
+        return sl.packed(col.dtype).reshape(sl.cl_shape[0], 1, 1, 9 * cpad)
+    return _cache_of(dcn).get(('w', col.dtype), (weight,),
+                              lambda: ops.pack_weight(weight, col.dtype).reshape(-1, 1, 1, 9 * cpad),
+                              refresh=lambda buf: ops.pack_weight(weight, col.dtype, out=buf.view(-1, 3, 3, cpad)))
+
+
 class DcnGemmFn(Function):
     """The GEMM half of DCNv2: y = col (rows, 9C) x W^T + bias, W = dcn.weight (O, C, 3, 3)."""
 
@@ -914,8 +928,7 @@ class DcnGemmFn(Function):
     def forward(ctx, col, weight, bias, dcn, geom):
         from .nn import _cache_of, _pad8
         O, Cc = weight.shape[0], weight.shape[1]
-        w = _cache_of(dcn).get(('w', col.dtype), (weight,),
-                               lambda: ops.pack_weight(weight, col.dtype).reshape(-1, 1, 1, 9 * col.shape[-1] // 9))
+        w = _dcn_gemm_weight(dcn, weight, col)
         shift = None
         if bias is not None:
             shift = _cache_of(dcn).get(('b',), (bias,), lambda: _pad8(bias, bias.numel()))
@@ -934,9 +947,13 @@ class DcnGemmFn(Function):
         dyr = _wrap(dy, geom)
 
         def make_wt():  # (9C_pad.., 1, 1, O_pad) = transpose of the packed GEMM weight
-            wp = ops.pack_weight(weight, col.dtype).reshape(-1, 9 * col.shape[-1] // 9)
+            wp = _dcn_gemm_weight(dcn, weight, col).reshape(-1, col.shape[-1])
             return wp.t().contiguous().reshape(wp.shape[1], 1, 1, wp.shape[0])
-        wt = _cache_of(dcn).get(('wt', col.dtype), (weight,), make_wt)
+
+        def refresh_wt(buf):   # one strided copy into the cached tensor (the weights change every step)
+            wp = _dcn_gemm_weight(dcn, weight, col).reshape(-1, col.shape[-1])
+            buf.view(wp.shape[1], wp.shape[0]).copy_(wp.t())
+        wt = _cache_of(dcn).get(('wt', col.dtype), (weight,), make_wt, refresh=refresh_wt)
         dcol = _d(ops.conv2d(dyr, wt, 1, 1))
         sl = getattr(dcn.weight, '_das_slot', None)
         cpad = col.shape[-1] // 9

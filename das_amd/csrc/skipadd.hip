@@ -272,7 +272,8 @@ extern "C" int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, 
 }
 
 extern "C" int das_bn_relu_add3_backward(const void* g, const void* raw1, const void* raw2, void* draw1, void* draw2, int dtype,
-                                         long long rows, int C, const float* const* bn, float* sums, long long stat_rows,
+                                         long long rows, int C, const float* const* bn, float* sums, int sums_zeroed,
+                                         long long stat_rows,
                                          float* dgamma1_acc, float* dbeta1_acc, float* dgamma2_acc, float* dbeta2_acc,
                                          void* stream) {
   if (!g || !raw1 || !raw2 || !draw1 || !draw2 || !bn || !par_ok(bn) || !sums || rows < 1 || stat_rows < 1 || C % 8 || C < 8 ||
@@ -281,7 +282,7 @@ extern "C" int das_bn_relu_add3_backward(const void* g, const void* raw1, const 
   const int nacc = (dgamma1_acc != nullptr) + (dbeta1_acc != nullptr) + (dgamma2_acc != nullptr) + (dbeta2_acc != nullptr);
   if (nacc != 0 && nacc != 4) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(float) * 4 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (!sums_zeroed && hipMemsetAsync(sums, 0, sizeof(float) * 4 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int vc = C / (dtype == DAS_F32 ? 4 : 8);
   const int pl = TPB / (vc < TPB ? vc : TPB);
   const long long cap = dastune::get(dastune::BN_UPMERGE_BLOCKS);

@@ -350,11 +350,11 @@ extern "C" int das_upmerge_forward(const void* raw1, const void* z, void* out, i
 extern "C" int das_upmerge_backward_reduce(const void* dy, const void* out, const void* raw1, const void* z, void* dzm, int dtype,
                                            int B, int H, int W, int C, int Ho, int Wo, const float* mean1,
                                            const float* invstd1, const float* mean2, const float* invstd2, float* sums,
-                                           void* stream) {
+                                           int sums_zeroed, void* stream) {
   if (!dy || !out || !raw1 || !z || !dzm || !mean1 || !invstd1 || !mean2 || !invstd2 || !sums || !geom_ok(B, H, W, C, Ho, Wo))
     return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(float) * 3 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (!sums_zeroed && hipMemsetAsync(sums, 0, sizeof(float) * 3 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
   const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
   const long long npix = (long long)B * Ho * Wo;

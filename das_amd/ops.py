@@ -796,12 +796,13 @@ def bn_relu_add3_backward(g, raw1, bn1, raw2, bn2, acc=None):
     Cc = g.shape[-1]
     rows = g.numel() // Cc
     d1, d2 = torch.empty_like(raw1), torch.empty_like(raw2)
-    sums = torch.empty(4 * Cc, dtype=torch.float32, device=g.device)
+    from .nn import zeroed_stats
+    sums = zeroed_stats(4 * Cc, g.device)
     arr = _bn_ptrs(bn1, bn2)
     a = acc if acc is not None else (None, None, None, None)
     with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', 8 * g.numel() * g.element_size(), launches=2, shape=(rows, Cc, 'skipadd')):
         _lib.check(_lib.load().das_bn_relu_add3_backward(_ptr(g), _ptr(raw1), _ptr(raw2), _ptr(d1), _ptr(d2), _DT[g.dtype], rows, Cc,
-                                                         arr, _ptr(sums), rows, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]),
+                                                         arr, _ptr(sums), 1, rows, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]),
                                                          _stream()), 'das_bn_relu_add3_backward')
     return d1, d2, sums
 
@@ -843,12 +844,13 @@ def upmerge_backward_reduce(dy, out, raw1, z, mean1, invstd1, mean2, invstd2):
     B, Ho, Wo, Cc = raw1.shape
     assert dy.is_contiguous() and dy.shape == raw1.shape == out.shape and dy.dtype == raw1.dtype == out.dtype == z.dtype
     dzm = torch.empty_like(raw1)
-    sums = torch.empty(3 * Cc, dtype=torch.float32, device=raw1.device)
+    from .nn import zeroed_stats
+    sums = zeroed_stats(3 * Cc, raw1.device)
     with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', 4 * raw1.numel() * raw1.element_size() + z.numel() * z.element_size(),
                 shape=(raw1.numel() // Cc, Cc, 'upmerge')):
         _lib.check(_lib.load().das_upmerge_backward_reduce(_ptr(dy), _ptr(out), _ptr(raw1), _ptr(z), _ptr(dzm), _DT[raw1.dtype], B,
                                                            z.shape[1], z.shape[2], Cc, Ho, Wo, _ptr(mean1), _ptr(invstd1),
-                                                           _ptr(mean2), _ptr(invstd2), _ptr(sums), _stream()),
+                                                           _ptr(mean2), _ptr(invstd2), _ptr(sums), 1, _stream()),
                    'das_upmerge_backward_reduce')
     return dzm, sums
 

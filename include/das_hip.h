@@ -49,7 +49,8 @@ const char* das_target_arch(void);
  * conv.glds4_mf, conv.stream_minrows, conv.stream_percu, conv.tail_split, conv.splitk_target, conv.splitk_minsteps, conv.splitk_kernels, conv.c64_mintiles, wgrad.pp_mink, wgrad.bkm, wgrad.blocks, wgrad.pp_blocks,
  * bn.reduce_blocks, bn.reduce_threads, bn.vpt, gn.ppb, bn.stream_minbytes, conv.pt3_mintiles (persistent 256 x 128 tile
  * grid: 0 = off), comm.reserved_cus (CUs every persistent grid leaves free: wgrad.blocks / wgrad.pp_blocks 0 = one
- * resident wave of workgroups on the remaining CUs). */
+ * resident wave of workgroups on the remaining CUs), elem.upstats_ppb (output pixels per workgroup of the resampling
+ * kernels, 0 = by size), bn.upmerge_blocks (grid cap of the fused reduce passes of upmerge.hip / skipadd.hip). */
 int das_tuning_set(const char* key, long long value);
 int das_tuning_get(const char* key, long long* value);
 int das_tuning_reset(void);
@@ -257,11 +258,11 @@ int das_upmerge_forward(const void* raw1, const void* z, void* out, int dtype, i
                         const float* mean1, const float* invstd1, const float* gamma1, const float* beta1,
                         const float* mean2, const float* invstd2, const float* gamma2, const float* beta2, void* stream);
 /* Backward pass A: dzm = dy * (out > 0) written once (the gradient of both pre-activation branches), and
- * sums f32[3C] = [sum dZ | sum dZ xhat1 | sum dZ xhat2] (zeroed here), xhat2 from upsample(z) recomputed on the fly. The first
- * 2C are BatchNorm 1's sums in das_bn_backward_apply's layout (one slot). */
+ * sums f32[3C] = [sum dZ | sum dZ xhat1 | sum dZ xhat2] (zeroed here unless sums_zeroed says the caller did), xhat2 from
+ * upsample(z) recomputed on the fly. The first 2C are BatchNorm 1's sums in das_bn_backward_apply's layout (one slot). */
 int das_upmerge_backward_reduce(const void* dy, const void* out, const void* raw1, const void* z, void* dzm, int dtype,
                                 int B, int H, int W, int C, int Ho, int Wo, const float* mean1, const float* invstd1,
-                                const float* mean2, const float* invstd2, float* sums, void* stream);
+                                const float* mean2, const float* invstd2, float* sums, int sums_zeroed, void* stream);
 /* Backward pass D, at low resolution: dz = upsample^T(d raw2) from P = upsample^T(dzm) (das_upsample_bilinear_ac_backward), z, the
  * sums of pass A and the tables of upsample^T upsample (ah f32[H][3], aw f32[W][3]: its tridiagonal factors; wh f32[H], ww
  * f32[W]: upsample^T 1). stat_rows = B * Ho * Wo (times the ranks under SyncBN). dgamma2_acc / dbeta2_acc (both or
@@ -275,8 +276,8 @@ int das_upmerge_backward_lowres(const void* P, const void* z, void* dz, int dtyp
  * writing the two normalised tensors (das_amd/csrc/skipadd.hip). All tensors (rows, C); bn = 8 pointers to f32[C]:
  * mean1, invstd1, gamma1, beta1, mean2, invstd2, gamma2, beta2.
  * Backward: g = d out (also d x); writes d raw1, d raw2 (the full train-mode BatchNorm backward of each branch, ReLU mask
- * recomputed from raw_i) and sums f32[4C] = [sum g1 | sum g1 xhat1 | sum g2 | sum g2 xhat2] (dbeta_i | dgamma_i); stat_rows =
- * rows. The four accumulators (all or none): the parameter gradients are ADDED there as well. */
+ * recomputed from raw_i) and sums f32[4C] = [sum g1 | sum g1 xhat1 | sum g2 | sum g2 xhat2] (dbeta_i | dgamma_i; zeroed here
+ * unless sums_zeroed); stat_rows = rows. The four accumulators (all or none): the parameter gradients are ADDED there as well. */
 /* out = relu?(BN1(raw1) + BN2(raw2)): a bottleneck's bn3 with the block's projection shortcut `downsample(x)`
  * (mspn_mmpose.py:126-157) normalised on the fly — the shortcut's normalised tensor is never written. bn as below. */
 int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C, const float* const* bn,
@@ -284,8 +285,8 @@ int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, int dtype, 
 int das_bn_relu_add3_forward(const void* x, const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C,
                              const float* const* bn, void* stream);
 int das_bn_relu_add3_backward(const void* g, const void* raw1, const void* raw2, void* draw1, void* draw2, int dtype,
-                              long long rows, int C, const float* const* bn, float* sums, long long stat_rows,
-                              float* dgamma1_acc, float* dbeta1_acc, float* dgamma2_acc, float* dbeta2_acc, void* stream);
+                              long long rows, int C, const float* const* bn, float* sums, int sums_zeroed,
+                              long long stat_rows, float* dgamma1_acc, float* dbeta1_acc, float* dgamma2_acc, float* dbeta2_acc, void* stream);
 int das_maxpool3x3s2_argmax(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, void* stream);
 int das_maxpool3x3s2_backward_argmax(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C,
                                      void* stream);
