@@ -46,6 +46,48 @@ __device__ __forceinline__ void bn_publish(const float* __restrict__ stats, long
   if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
 }
 
+// Finalize only (das_bn_train_apply with y == NULL): one thread per channel over as many 64-thread workgroups as that
+// takes — the same fold order and the same arithmetic as the apply kernels. As workgroup 0 of an apply kernel with an
+// empty body this took 6-15 us (one workgroup walking 2C sums and C channels); the fused train-mode passes call it
+// ~60 times a step.
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ gstats, int slots, long long count, int C,
+                                                         float* running_mean, float* running_var, float momentum, float eps,
+                                                         float* save_mean, float* save_invstd, long long* num_batches_tracked) {
+#pragma clang fp contract(off)
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (c >= C) return;
+  float sum[2];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    float a = 0.f;
+    if (slots > 1) {
+      for (int k0 = 0; k0 < slots; k0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (k0 + k < slots) ? gstats[(size_t)(k0 + k) * 2 * C + w * C + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += v[k];
+      }
+    } else {
+      a = gstats[w * C + c];
+    }
+    sum[w] = a;
+  }
+  const float n = (float)count;
+  BnStat st;
+  st.mean = sum[0] / n;
+  st.var = fmaxf(sum[1] / n - st.mean * st.mean, 0.f);
+  st.invstd = 1.0f / sqrtf(st.var + eps);
+  save_mean[c] = st.mean;
+  save_invstd[c] = st.invstd;
+  if (running_mean) {
+    const float unbiased = count > 1 ? st.var * (n / (n - 1.f)) : st.var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * st.mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
 // One 16-byte channel vector per thread and iteration. The grid stride is a multiple of the channel-vector
 // count whenever that count is a power of two (every BN on the path), so a thread keeps its channels for the
 // whole loop and the per-channel constants live in registers (FIXED); two iterations are kept in flight.
@@ -64,6 +106,20 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
   // fold launch — the host caps the grid so that this stays a small fraction of the loads).
   extern __shared__ float fstat[];   // [2C]
   const float* stats = gstats;
+  // The first pair of vectors is requested BEFORE the statistics are folded and the constants derived: the two memory
+  // round trips (slots -> LDS -> constants, and x) then overlap instead of following each other — the mid-size
+  // layers' launches are a few microseconds of exactly that chain.
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  const bool first = FIXED && i + stride < total;
+  uint4 pa0 = make_uint4(0, 0, 0, 0), pa1 = pa0, pr0 = pa0, pr1 = pa0;
+  if (first) {
+    pa0 = *reinterpret_cast<const uint4*>(x + i * EPV);
+    pa1 = *reinterpret_cast<const uint4*>(x + (i + stride) * EPV);
+    if (res) {
+      pr0 = *reinterpret_cast<const uint4*>(res + i * EPV);
+      pr1 = *reinterpret_cast<const uint4*>(res + (i + stride) * EPV);
+    }
+  }
   if (slots > 1) {
     fold_slots_to_lds(gstats, slots, 2 * C, fstat);
     stats = fstat;
@@ -99,9 +155,13 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
     }
     *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(f);
   };
-  long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (FIXED) {
     if (i < total) load_consts((int)(i % VC) * EPV);
+    if (first) {
+      finish(i, pa0, pr0);
+      finish(i + stride, pa1, pr1);
+      i += 2 * stride;
+    }
     for (; i + stride < total; i += 2 * stride) {
       const uint4 a0 = *reinterpret_cast<const uint4*>(x + i * EPV);
       const uint4 a1 = *reinterpret_cast<const uint4*>(x + (i + stride) * EPV);
@@ -338,7 +398,13 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
   const long long nstat = stat_count ? stat_count : count;
   // y == NULL: finalize only — mean / invstd published, running statistics and the batch counter advanced, nothing
   // normalised (a layer whose output has no consumer: the statistics are still part of the state dict)
-  if (!y) count = 0;
+  if (!y) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, stats, stats_slots < 1 ? 1 : stats_slots, nstat, C,
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, num_batches_tracked);
+    DAS_CHECK_LAUNCH();
+    dastune::note_kernel("bn_finalize_kernel");
+    return DAS_OK;
+  }
   const int vc = C / (dtype == DAS_BF16 ? 8 : 4);
   // at least eight vectors per thread (the per-thread mean / invstd / gamma / beta set-up is ~60 instructions and 32
   // loads): the mid-size layers ran at 1.7...3 TB/s with one vector per thread (1024 channels at 32x52: 37 -> 22 us)
