@@ -26,7 +26,8 @@ class DasConvDesc(C.Structure):
                 ('num_levels', i32), ('lvl_H', i32 * 5), ('lvl_W', i32 * 5), ('in_up', i32), ('stats_slots', i32),
                 ('bnb_raw', vp), ('bnb_y', vp), ('bnb_mean', vp), ('bnb_invstd', vp), ('bnb_gamma', vp), ('bnb_beta', vp),
                 ('bnb_relu', i32), ('bnb_pix_stride', i32),
-                ('out_sub', i32), ('out_ph', i32), ('out_pw', i32), ('out_H', i32), ('out_W', i32)]
+                ('out_sub', i32), ('out_ph', i32), ('out_pw', i32), ('out_H', i32), ('out_W', i32),
+                ('bnb_mask_bits', vp)]
 
 
 class DasPackEntry(C.Structure):
@@ -93,6 +94,7 @@ SIGNATURES = {
     'das_pack_conv_weights': (i32, [vp, vp, vp, i32, vp, i32, i32, vp]),
     'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
     'das_colsum_acc': (i32, [vp, i32, i64, i32, i32, vp, vp]),
+    'das_bn_train_backward_bits': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
     'das_bn_train_backward_phase': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i64, vp]),
     'das_bn_backward_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]),
@@ -108,10 +110,10 @@ SIGNATURES = {
     'das_maxpool3x3s2': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_upsample_bilinear_ac_stats': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     'das_upsample_stats_lowres': (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
-    'das_upmerge_forward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [vp] * 8 + [vp]),
-    'das_upmerge_backward_reduce': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
+    'das_upmerge_forward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32] + [vp] * 8 + [vp, vp]),
+    'das_upmerge_backward_reduce': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     'das_upmerge_backward_lowres': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]),
-    'das_bn_dual_apply': (i32, [vp, vp, vp, i32, i64, i32, vp, i32, vp]),
+    'das_bn_dual_apply': (i32, [vp, vp, vp, i32, i64, i32, vp, i32, vp, vp]),
     'das_bn_relu_add3_forward': (i32, [vp, vp, vp, vp, i32, i64, i32, vp, vp]),
     'das_bn_relu_add3_backward': (i32, [vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp]),
     'das_maxpool3x3s2_argmax': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -120,7 +122,7 @@ SIGNATURES = {
     'das_add_upsample_nearest': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_add3': (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
     'das_bn_train_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp, i64, i32,
-                                 vp]),
+                                 vp, vp]),
     'das_groupnorm_nhwc': (i32, [vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp, vp]),
     'das_deform_im2col3x3': (i32, [vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp]),
     'das_offset_sample': (i32, [vp, vp, vp, vp, C.POINTER(DasLevels), i32, i32, i32, i32, i32, i32, vp]),

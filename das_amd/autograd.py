@@ -234,9 +234,15 @@ def _check_equal_rows(rows):
                            f'{rows}): pad the batches of all ranks to one size (Pad(size=...)) or use norm_cfg type BN')
 
 
-def _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual):
+# The ReLU mask of a BatchNorm + residual + ReLU layer recorded as bits by the forward apply pass (1/16 of the output) and
+# read by the backward instead of the output itself (ops.relu_bits_buffer); switch for A/B runs and tests
+MASK_BITS = True
+
+
+def _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual, bits=None):
     """conv (BatchNorm statistics in its epilogue) -> finalize + apply (+ residual, + ReLU). Returns
-    y, raw, mean, invstd, world (number of ranks the statistics span)."""
+    y, raw, mean, invstd, world (number of ranks the statistics span). bits: a list that receives the ReLU mask of y as
+    bits (or None) when the layer has a residual and a ReLU."""
     from .nn import bn_stats_buffer, packed_weight, sync_stats
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
@@ -249,9 +255,12 @@ def _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual):
         _check_equal_rows(raw.numel() // raw.shape[-1])
         stats = sync_stats(stats, w.shape[0], _all_reduce)
         stat_count = (raw.numel() // raw.shape[-1]) * world
+    mask = ops.relu_bits_buffer(raw) if (bits is not None and MASK_BITS and relu and residual is not None) else None
     y, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps,
                                          residual=residual, relu=relu,
-                                         num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count)
+                                         num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count, bits_out=mask)
+    if bits is not None:
+        bits.append(mask)
     bn.__dict__.pop('_das_cache', None)  # running stats changed under the cache's feet (raw-pointer update)
     return y, raw, mean, invstd, world
 
@@ -281,8 +290,10 @@ class ConvBNTrainFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv, bn, relu):
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        y, raw, mean, invstd, world = _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual)
-        ctx.save_for_backward(x, raw, y if residual is not None else None, mean, invstd, gamma, weight, beta)
+        bits = []
+        y, raw, mean, invstd, world = _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual, bits=bits)
+        ctx.bits = bits[0] if world == 1 else None   # (the mask of y as bits: the backward then never reads y)
+        ctx.save_for_backward(x, raw, y if (residual is not None and ctx.bits is None) else None, mean, invstd, gamma, weight, beta)
         ctx.cfg = (k, s, p, relu, residual is not None, conv, bn)
         ctx.world = world
         return y
@@ -301,10 +312,11 @@ class ConvBNTrainFn(Function):
             draw, dres, dgamma, dbeta = ops.bn_train_backward_sync(dy, y if (relu and has_res) else None, raw, mean, invstd,
                                                                    gamma, relu, has_res, beta, _all_reduce, ctx.world)
         else:
-            draw, dres, dgamma, dbeta = ops.bn_train_backward(dy, y if (relu and has_res) else None, raw, mean, invstd,
-                                                              gamma, relu, has_res, beta=beta,
+            draw, dres, dgamma, dbeta = ops.bn_train_backward(dy, y if (relu and has_res and ctx.bits is None) else None, raw,
+                                                              mean, invstd, gamma, relu, has_res, beta=beta,
                                                               dgamma_acc=ga[1] if direct else None,
-                                                              dbeta_acc=ba[1] if direct else None)
+                                                              dbeta_acc=ba[1] if direct else None,
+                                                              bits=ctx.bits if (relu and has_res) else None)
         if direct:
             dgamma = dbeta = None
             ga[0].fired()
@@ -486,8 +498,9 @@ class UpMergeTrainFn(Function):
                                                num_batches_tracked=bn2.num_batches_tracked, stat_count=rows, finalize_only=True)
         bn1.__dict__.pop('_das_cache', None)
         bn2.__dict__.pop('_das_cache', None)
-        out = ops.upmerge_forward(raw1, z, (mean1, invstd1, g1, b1), (mean2, invstd2, g2, b2))
-        ctx.save_for_backward(x, up_x, raw1, z, out, mean1, invstd1, mean2, invstd2, g1, g2)
+        mask = ops.relu_bits_buffer(raw1) if MASK_BITS else None
+        out = ops.upmerge_forward(raw1, z, (mean1, invstd1, g1, b1), (mean2, invstd2, g2, b2), bits_out=mask)
+        ctx.save_for_backward(x, up_x, raw1, z, out if mask is None else None, mean1, invstd1, mean2, invstd2, g1, g2, mask)
         ctx.mods = (c1, bn1, c2, bn2)
         ctx.skip_through = skip_through
         return (out, x) if skip_through else out
@@ -495,11 +508,11 @@ class UpMergeTrainFn(Function):
     @staticmethod
     def backward(ctx, dy, dskip=None):
         from .nn import packed_weight_dgrad
-        x, up_x, raw1, z, out, mean1, invstd1, mean2, invstd2, g1, g2 = ctx.saved_tensors
+        x, up_x, raw1, z, out, mean1, invstd1, mean2, invstd2, g1, g2, mask = ctx.saved_tensors
         c1, bn1, c2, bn2 = ctx.mods
         Cc = raw1.shape[-1]
         rows = raw1.numel() // Cc
-        dzm, sums = ops.upmerge_backward_reduce(dy.contiguous(), out, raw1, z, mean1, invstd1, mean2, invstd2)
+        dzm, sums = ops.upmerge_backward_reduce(dy.contiguous(), out, raw1, z, mean1, invstd1, mean2, invstd2, bits=mask)
         acc = [_param_acc(p) for p in (bn1.weight, bn1.bias, bn2.weight, bn2.bias)]
         direct = all(a is not None for a in acc)
         # BatchNorm 1: the apply pass every other layer uses (dZ, raw1 -> d raw1); sums[:2C] is its [sum dZ | sum dZ xhat]
@@ -572,6 +585,7 @@ class BottleneckChainFn(Function):
             w1, g1, b1, w2, g2, b2, w3, g3, b3 = (next(it) for _ in range(9))
             y1, raw1, m1, i1, _ = _convbn_train_forward(xin, blk.conv1, blk.bn1, g1, b1, True, None)
             y2, raw2, m2, i2, _ = _convbn_train_forward(y1, blk.conv2, blk.bn2, g2, b2, True, None)
+            mb = []   # the ReLU mask of y3 as bits (None under SyncBN: its two-phase backward reads y3)
             if blk.downsample is not None:
                 wd, gd, bd = (next(it) for _ in range(3))
                 ds = blk.downsample
@@ -579,14 +593,17 @@ class BottleneckChainFn(Function):
                     # the shortcut's normalised tensor is read by bn3's apply pass only: never written
                     rawd, md, idd = _conv_stats_forward(xin, ds.conv, ds.bn, gd, bd)
                     raw3, m3, i3 = _conv_stats_forward(y2, blk.conv3, blk.bn3, g3, b3)
-                    y3 = ops.bn_dual_apply(raw3, (m3, i3, g3, b3), rawd, (md, idd, gd, bd), relu=True)
+                    mb.append(ops.relu_bits_buffer(raw3) if MASK_BITS else None)
+                    y3 = ops.bn_dual_apply(raw3, (m3, i3, g3, b3), rawd, (md, idd, gd, bd), relu=True, bits_out=mb[0])
                 else:
                     idn, rawd, md, idd, _ = _convbn_train_forward(xin, ds.conv, ds.bn, gd, bd, False, None)
-                    y3, raw3, m3, i3, _ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, idn)
+                    y3, raw3, m3, i3, w3_ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, idn, bits=mb)
+                    mb[0] = mb[0] if w3_ == 1 else None
             else:
-                y3, raw3, m3, i3, _ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, xin)
+                y3, raw3, m3, i3, w3_ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, xin, bits=mb)
+                mb[0] = mb[0] if w3_ == 1 else None
             ent['u'] = len(saved)
-            saved += [raw1, m1, i1, y1, raw2, m2, i2, y2, raw3, m3, i3, y3]
+            saved += [raw1, m1, i1, y1, raw2, m2, i2, y2, raw3, m3, i3, y3, mb[0]]
             if blk.downsample is not None:
                 ent['d'] = len(saved)
                 saved += [rawd, md, idd]
@@ -651,7 +668,7 @@ class BottleneckChainFn(Function):
                 grads[pi], grads[pi + 1] = f[C_:], f[:C_]
             return draw
 
-        def classic_bn(bn, gamma, beta, pi, dyv, y, raw, mean, invstd, relu, want_dres):
+        def classic_bn(bn, gamma, beta, pi, dyv, y, raw, mean, invstd, relu, want_dres, bits=None):
             world = _sync_world(bn)
             if world > 1:
                 draw, dres, dgamma, dbeta = ops.bn_train_backward_sync(dyv, y, raw, mean, invstd, gamma, relu, want_dres,
@@ -660,9 +677,9 @@ class BottleneckChainFn(Function):
                 return draw, dres
             ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
             direct = ga is not None and ba is not None
-            draw, dres, dgamma, dbeta = ops.bn_train_backward(dyv, y, raw, mean, invstd, gamma, relu, want_dres, beta=beta,
-                                                              dgamma_acc=ga[1] if direct else None,
-                                                              dbeta_acc=ba[1] if direct else None)
+            draw, dres, dgamma, dbeta = ops.bn_train_backward(dyv, None if bits is not None else y, raw, mean, invstd, gamma, relu,
+                                                              want_dres, beta=beta, dgamma_acc=ga[1] if direct else None,
+                                                              dbeta_acc=ba[1] if direct else None, bits=bits)
             if direct:
                 ga[0].fired()
                 ba[0].fired()
@@ -675,9 +692,9 @@ class BottleneckChainFn(Function):
             grads[pi] = _wgrad(xin, draw, conv.weight, k, s, p)
 
         def dgrad(conv, draw, xin, residual=None, fuse=None, accumulate=None):
-            """data gradient of `conv` wrt xin; fuse = (raw, y, mean, invstd, gamma, beta) of the BatchNorm+ReLU layer
-            that produced xin -> returns (dZ, sums) of that layer instead of the plain gradient; accumulate = a tensor
-            already holding another gradient of xin, added to in place"""
+            """data gradient of `conv` wrt xin; fuse = (raw, y, mean, invstd, gamma, beta[, mask bits instead of y]) of the
+            BatchNorm+ReLU layer that produced xin -> returns (dZ, sums) of that layer instead of the plain gradient;
+            accumulate = a tensor already holding another gradient of xin, added to in place"""
             k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
             w = packed_weight_dgrad(conv, xin.dtype)
             wc = packed_weight_dgrad_s2(conv, xin.dtype)
@@ -686,19 +703,20 @@ class BottleneckChainFn(Function):
                                         accumulate=accumulate)
             sums = bn_stats_buffer(xin, xin.shape[-1])
             dz = ops.conv2d_dgrad(draw, w, k, k, s, p, (xin.shape[1], xin.shape[2]), residual=residual,
-                                  bn_bwd=ops.BnBwd(*fuse, True), stats=sums, w_classes=wc)
+                                  bn_bwd=ops.BnBwd(*fuse[:6], True, bits=fuse[6] if len(fuse) > 6 else None), stats=sums,
+                                  w_classes=wc)
             return dz, sums
 
         x0 = saved[0]
         carry_dy, carry_dz = dy.contiguous(), None     # gradient wrt the current block's output: raw, or (dZ, sums)
         for bi in range(len(blocks) - 1, -1, -1):
             blk, ent, po = blocks[bi], plan[bi], offs[bi]
-            raw1, m1, i1, y1, raw2, m2, i2, y2, raw3, m3, i3, y3 = saved[ent['u']:ent['u'] + 12]
+            raw1, m1, i1, y1, raw2, m2, i2, y2, raw3, m3, i3, y3, bits3 = saved[ent['u']:ent['u'] + 13]
             xin = x0 if bi == 0 else saved[plan[bi - 1]['u'] + 11]
             w1, g1, b1, w2, g2, b2, w3, g3, b3 = params[po:po + 9]
             # ---- bn3 (+ identity, ReLU)
             if carry_dz is None:
-                draw3, dz3 = classic_bn(blk.bn3, g3, b3, po + 7, carry_dy, y3, raw3, m3, i3, True, True)
+                draw3, dz3 = classic_bn(blk.bn3, g3, b3, po + 7, carry_dy, y3, raw3, m3, i3, True, True, bits=bits3)
             else:
                 dz3, sums3 = carry_dz
                 draw3 = finish_bn(blk.bn3, g3, b3, po + 7, dz3, raw3, m3, i3, sums3)
@@ -722,8 +740,11 @@ class BottleneckChainFn(Function):
             elif bi > 0:   # xin is the previous block's output: mask by it, reduce for its bn3
                 pent, ppo = plan[bi - 1], offs[bi - 1]
                 praw3, pm3, pi3 = saved[pent['u'] + 8:pent['u'] + 11]
+                pbits3 = saved[pent['u'] + 12]
                 pg3, pb3 = params[ppo + 7], params[ppo + 8]
-                carry_dy, carry_dz = None, dgrad(blk.conv1, draw1, xin, residual=dz3, fuse=(praw3, xin, pm3, pi3, pg3, pb3))
+                # (the previous block's ReLU mask: its recorded bits, or its output xin itself)
+                fuse = (praw3, None, pm3, pi3, pg3, pb3, pbits3) if pbits3 is not None else (praw3, xin, pm3, pi3, pg3, pb3)
+                carry_dy, carry_dz = None, dgrad(blk.conv1, draw1, xin, residual=dz3, fuse=fuse)
             else:
                 carry_dy, carry_dz = dgrad(blk.conv1, draw1, xin, residual=dz3), None
         assert carry_dz is None

@@ -67,6 +67,34 @@ __device__ __forceinline__ float bn_affine(float x, float mean, float invstd, fl
   return __fmaf_rn((x - mean) * invstd, gamma, beta);
 }
 
+// ---- ReLU masks as bits. A BatchNorm layer whose ReLU follows a residual add needs (y > 0) in its backward; reading y for
+// that costs a full tensor pass per consumer. The forward apply pass can record the mask instead: ONE BYTE PER 16-BYTE
+// VECTOR of y (bit j = element j of the vector is > 0; 8 bits for bf16, the low 4 for f32), i.e. 1/16 of y's bytes,
+// indexed by the vector's index (rows * C / EPV + vector in row). relu_bits: the byte of a packed (stored) vector;
+// mask_vec: a vector whose elements are 1.0 / 0.0 by the byte — what the consumers' `y > 0` tests then see.
+template <typename T>
+__device__ __forceinline__ unsigned relu_bits(const uint4& packed) {
+  constexpr int EPV = Elem<T>::EPV;
+  float o[EPV];
+  Elem<T>::unpack(packed, o);
+  unsigned b = 0;
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) b |= (o[j] > 0.f ? 1u : 0u) << j;
+  return b;
+}
+template <typename T>
+__device__ __forceinline__ uint4 mask_vec(unsigned b);
+template <>
+__device__ __forceinline__ uint4 mask_vec<float>(unsigned b) {
+  return make_uint4((b & 1) ? 0x3F800000u : 0u, (b & 2) ? 0x3F800000u : 0u, (b & 4) ? 0x3F800000u : 0u, (b & 8) ? 0x3F800000u : 0u);
+}
+template <>
+__device__ __forceinline__ uint4 mask_vec<bf16_t>(unsigned b) {
+  return make_uint4(((b & 1) ? 0x3F80u : 0u) | ((b & 2) ? 0x3F800000u : 0u), ((b & 4) ? 0x3F80u : 0u) | ((b & 8) ? 0x3F800000u : 0u),
+                    ((b & 16) ? 0x3F80u : 0u) | ((b & 32) ? 0x3F800000u : 0u),
+                    ((b & 64) ? 0x3F80u : 0u) | ((b & 128) ? 0x3F800000u : 0u));
+}
+
 // Sum the [slots][n] per-workgroup slot partials into dst[n] (LDS), fixed order. All 16 loads of a value are in flight
 // together: a serial `a += src[k * n + i]` chain costs one L2 round trip per slot at the head of every workgroup
 // (16 us per launch measured on the BatchNorm apply passes). slots <= 64; ends with a workgroup barrier.

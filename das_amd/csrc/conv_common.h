@@ -49,6 +49,7 @@ struct ConvP {
   const char* bnb_raw;   // (M, Cout) pre-norm tensor, pixel stride bnb_ps; nullptr = feature off
   const char* bnb_y;     // (M, Cout) post-ReLU output: mask = y > 0 (needed when a residual entered before the ReLU);
                          // nullptr with bnb_relu: mask recomputed as bn_affine(raw) > 0
+  const unsigned char* bnb_bits;   // instead of bnb_y: its ReLU mask as one byte per 16-byte vector (common.h: relu_bits)
   const float* bnb_mean;
   const float* bnb_invstd;
   const float* bnb_gamma;
@@ -222,6 +223,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   const OT* rg = reinterpret_cast<const OT*>(p.res);
   const OT* bxg = reinterpret_cast<const OT*>(p.bnb_raw);   // fused BatchNorm-backward reduction (see ConvP)
   const OT* byg = reinterpret_cast<const OT*>(p.bnb_y);
+  const unsigned char* bbits = p.bnb_bits;
   if (n < p.Cout) {
     constexpr int ITERS = BMT / RP;  // rows per thread, processed CH at a time
     constexpr int CH = ITERS % 4 == 0 ? 4 : ITERS % 3 == 0 ? 3 : ITERS % 2 == 0 ? 2 : 1;
@@ -232,8 +234,8 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
 #pragma unroll
       for (int j = 0; j < EPVO; ++j) {
         bmu[j] = p.bnb_mean[n + j]; bis[j] = p.bnb_invstd[n + j];
-        bga[j] = (p.bnb_relu && !byg) ? p.bnb_gamma[n + j] : 0.f;
-        bbe[j] = (p.bnb_relu && !byg) ? p.bnb_beta[n + j] : 0.f;
+        bga[j] = (p.bnb_relu && !byg && !bbits) ? p.bnb_gamma[n + j] : 0.f;
+        bbe[j] = (p.bnb_relu && !byg && !bbits) ? p.bnb_beta[n + j] : 0.f;
       }
     }
 #pragma unroll 1
@@ -263,6 +265,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
           if (m < p.M) {
             xv[u] = *reinterpret_cast<const uint4*>(bxg + om[u] * p.bnb_ps + n);
             if (byg) yv[u] = *reinterpret_cast<const uint4*>(byg + om[u] * p.bnb_ps + n);
+            else if (bbits) yv[u].x = bbits[(om[u] * p.bnb_ps + n) / EPVO];   // (expanded at use: the load stays in flight)
           }
         }
       }
@@ -296,9 +299,9 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
           float x[EPVO];
           Elem<OT>::unpack(xv[u], x);
           if (p.bnb_relu) {
-            if (byg) {
+            if (byg || bbits) {
               float o[EPVO];
-              Elem<OT>::unpack(yv[u], o);
+              Elem<OT>::unpack(byg ? yv[u] : mask_vec<OT>(yv[u].x), o);
 #pragma unroll
               for (int j = 0; j < EPVO; ++j) f[j] = o[j] > 0.f ? f[j] : 0.f;
             } else {

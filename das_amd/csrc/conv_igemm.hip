@@ -888,7 +888,7 @@ bool try_launch_pt3(const ConvP& p0, int rows, hipStream_t s) {
     long long grid = std::min<long long>(total, usable_cus());
     grid -= grid % p.ntiles;            // a workgroup keeps its column block (the carried statistics are per channel)
     if (grid < p.ntiles || grid < 1) return false;
-    const int mode = bnb ? ((p.bnb_relu && !p.bnb_y) ? 4 : 3) : p.res ? (aff ? 5 : 2) : ((aff || p.relu) ? 1 : 0);
+    const int mode = bnb ? ((p.bnb_relu && !p.bnb_y && !p.bnb_bits) ? 4 : 3) : p.res ? (aff ? 5 : 2) : ((aff || p.relu) ? 1 : 0);
     // (mode 3 — three operand tensors per pixel block — is left to the one-tile kernels: on hardware its first y-mask
     // vector of the trailing wave group came back stale although every load had been waited for with vmcnt(0) and the
     // ISA shows no write to those registers in between; not understood, tools/dev/pt3_debug.py reproduces it)
@@ -1176,6 +1176,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
     const T* rgb = reinterpret_cast<const T*>(p.res);
     const T* bx = reinterpret_cast<const T*>(p.bnb_raw);
     const T* by = MODE == 3 ? reinterpret_cast<const T*>(p.bnb_y) : nullptr;
+    const unsigned char* bb = MODE == 3 ? p.bnb_bits : nullptr;   // (the mask as a byte per vector instead of y)
     float mu[8], is[8], ga[8], be[8];
     if constexpr (MODE == 4) {
 #pragma unroll
@@ -1193,6 +1194,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
 #pragma unroll
       for (int h0 = 0; h0 < PB; h0 += HB) {
         v4i_t lr[HB], lx[HB], ly[HB];
+        int lb[HB];
 #pragma unroll
         for (int h = 0; h < HB; ++h) {
           long long m = (long long)t * TM + wm * (TM / WM) + (h0 + h) * 16 + q;
@@ -1200,6 +1202,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
           const long long eo = m * p.bnb_ps + (cok ? c8 : 0);
           asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lx[h]) : "v"(bx + eo) : "memory");
           if (by) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ly[h]) : "v"(by + eo) : "memory");
+          if (bb) asm volatile("global_load_ubyte %0, %1, off" : "=v"(lb[h]) : "v"(bb + eo / 8) : "memory");
           if (rgb) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lr[h]) : "v"(rgb + m * p.rps + (cok ? c8 : 0)) : "memory");
         }
         f32x4_t acc0[HB], acc1[HB];
@@ -1220,7 +1223,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
         }
 #pragma unroll
         for (int h = 0; h < HB; ++h)   // (the operands name the destination registers: they stay allocated until here)
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[h]), "+v"(ly[h]), "+v"(lr[h])::"memory");
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[h]), "+v"(ly[h]), "+v"(lr[h]), "+v"(lb[h])::"memory");
 #pragma unroll
         for (int h = 0; h < HB; ++h) {
           const long long m = (long long)t * TM + wm * (TM / WM) + (h0 + h) * 16 + q;
@@ -1240,9 +1243,9 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
             if (MODE == 4) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] = bn_affine(x[j], mu[j], is[j], ga[j], be[j]) > 0.f ? v[j] : 0.f;
-            } else if (by) {
+            } else if (by || bb) {
               float yo[8];
-              Elem<T>::unpack(__builtin_bit_cast(uint4, ly[h]), yo);
+              Elem<T>::unpack(by ? __builtin_bit_cast(uint4, ly[h]) : mask_vec<T>((unsigned)lb[h]), yo);
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] = yo[j] > 0.f ? v[j] : 0.f;
             }
@@ -1413,7 +1416,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
   const bool bnb = p.bnb_raw != nullptr;
   if (!bnb && p.stats && (aff || p.res)) return false;   // (combinations no caller on the path uses)
   if (bnb && (p.relu || aff)) return false;
-  const int mode = bnb ? ((p.bnb_relu && !p.bnb_y) ? 4 : 3) : p.res ? (aff ? 5 : 2) : (aff ? 1 : 0);
+  const int mode = bnb ? ((p.bnb_relu && !p.bnb_y && !p.bnb_bits) ? 4 : 3) : p.res ? (aff ? 5 : 2) : (aff ? 1 : 0);
   if (mode == 4 && p.res) return false;   // (the recomputed mask is only valid when no residual entered before the ReLU)
 #define DAS_STREAM_CASE(KBV, WNV)                                         \
   if (kb == KBV && wn == WNV) {                                           \
@@ -1590,13 +1593,14 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
       return DAS_ERR_ARG;
   }
   p.bnb_raw = (const char*)d->bnb_raw; p.bnb_y = (const char*)d->bnb_y;
+  p.bnb_bits = p.bnb_y ? nullptr : (const unsigned char*)d->bnb_mask_bits;
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta;
   p.bnb_relu = d->bnb_relu; p.bnb_ps = d->bnb_pix_stride;
   if (p.bnb_raw) {   // fused BatchNorm-backward reduction: see DasConvDesc
     if (!d->stats || d->out_dtype != d->dtype || d->relu || d->scale || d->shift || !p.bnb_mean || !p.bnb_invstd ||
         p.bnb_ps < d->Cout || p.bnb_ps % 8)
       return DAS_ERR_ARG;
-    if (p.bnb_relu && !p.bnb_y && (!p.bnb_gamma || !p.bnb_beta)) return DAS_ERR_ARG;
+    if (p.bnb_relu && !p.bnb_y && !p.bnb_bits && (!p.bnb_gamma || !p.bnb_beta)) return DAS_ERR_ARG;
   }
   {
     const long long npix = p.nlev > 1 ? M : (long long)d->B * d->H * d->W;

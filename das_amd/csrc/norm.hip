@@ -97,7 +97,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const T* __restrict__ res, int relu, float* running_mean, float* running_var,
                                 float momentum, float* save_mean, float* save_invstd,
-                                long long* num_batches_tracked) {
+                                long long* num_batches_tracked, unsigned char* __restrict__ bits) {
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV;
   const long long total = count * VC;
@@ -153,7 +153,9 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, long
 #pragma unroll
       for (int j = 0; j < EPV; ++j) f[j] = fmaxf(f[j], 0.f);
     }
-    *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(f);
+    const uint4 packed = Elem<T>::pack(f);
+    *reinterpret_cast<uint4*>(y + i * EPV) = packed;
+    if (bits) bits[i] = (unsigned char)relu_bits<T>(packed);   // (common.h: the ReLU mask for the backward, 1/16 of y)
   };
   if (FIXED) {
     if (i < total) load_consts((int)(i % VC) * EPV);
@@ -330,7 +332,8 @@ __global__ __launch_bounds__(TPB) void bn_apply_stream_kernel(const T* __restric
                                                               const float* __restrict__ beta, const T* __restrict__ res,
                                                               int relu, float* running_mean, float* running_var,
                                                               float momentum, float* save_mean, float* save_invstd,
-                                                              long long* num_batches_tracked) {
+                                                              long long* num_batches_tracked,
+                                                              unsigned char* __restrict__ bits) {
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV;                 // (host: TPB % VC == 0 — a thread keeps its channels for every vector it takes)
   extern __shared__ float cst[];          // [4][C]: mean, invstd, gamma, beta
@@ -380,7 +383,9 @@ __global__ __launch_bounds__(TPB) void bn_apply_stream_kernel(const T* __restric
 #pragma unroll
       for (int j = 0; j < EPV; ++j) f[j] = fmaxf(f[j], 0.f);
     }
-    *reinterpret_cast<uint4*>(y + i * EPV) = Elem<T>::pack(f);
+    const uint4 packed = Elem<T>::pack(f);
+    *reinterpret_cast<uint4*>(y + i * EPV) = packed;
+    if (bits) bits[i] = (unsigned char)relu_bits<T>(packed);
   }
 }
 }  // namespace
@@ -389,7 +394,8 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
                                   float momentum, float eps, const void* residual, int relu, float* save_mean,
                                   float* save_invstd, long long* num_batches_tracked, long long stat_count,
-                                  int stats_slots, void* stream) {
+                                  int stats_slots, void* relu_bits_out, void* stream) {
+  unsigned char* bits = (unsigned char*)relu_bits_out;
   if (!x || !stats || !gamma || !beta || !save_mean || !save_invstd || C % 8 || count <= 0) return DAS_ERR_ARG;
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
   if (stat_count != 0 && stat_count < count) return DAS_ERR_ARG;
@@ -429,7 +435,7 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
 #define DAS_BN_STREAM(T)                                                                                              \
   hipLaunchKernelGGL((bn_apply_stream_kernel<T, VPT>), dim3(sgrid), dim3(TPB), ssm, s, (const T*)x, (T*)y, count, C,   \
                      folded, nstat, eps, gamma, beta, (const T*)residual, relu, running_mean, running_var, momentum,  \
-                     save_mean, save_invstd, num_batches_tracked)
+                     save_mean, save_invstd, num_batches_tracked, bits)
     if (dtype == DAS_BF16) DAS_BN_STREAM(bf16_t); else DAS_BN_STREAM(float);
 #undef DAS_BN_STREAM
     DAS_CHECK_LAUNCH();
@@ -443,7 +449,7 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
 #define DAS_BN_APPLY(T, F)                                                                                          \
   hipLaunchKernelGGL((bn_apply_kernel<T, F>), dim3(grid), dim3(TPB), sm, s, (const T*)x, (T*)y, count, C, stats, nslots, nstat, \
                      eps, gamma, beta, (const T*)residual, relu, running_mean, running_var, momentum, save_mean,      \
-                     save_invstd, num_batches_tracked)
+                     save_invstd, num_batches_tracked, bits)
   if (dtype == DAS_BF16) {
     if (fixed) DAS_BN_APPLY(bf16_t, true); else DAS_BN_APPLY(bf16_t, false);
   } else {

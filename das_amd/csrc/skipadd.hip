@@ -70,7 +70,7 @@ __global__ __launch_bounds__(TPB) void bn_relu_add3_fwd_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(TPB) void bn_dual_apply_kernel(const T* __restrict__ raw1, const T* __restrict__ raw2,
                                                             T* __restrict__ out, long long rows, int C, int rows_per_block,
-                                                            BnPar p1, BnPar p2, int relu) {
+                                                            BnPar p1, BnPar p2, int relu, unsigned char* __restrict__ bits) {
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV;
   const int VCB = min(VC, TPB), PL = TPB / VCB, pl = threadIdx.x / VCB;
@@ -104,7 +104,9 @@ __global__ __launch_bounds__(TPB) void bn_dual_apply_kernel(const T* __restrict_
           const float t = bn_affine(fa[j], m1[j], i1[j], g1[j], b1[j]) + bn_affine(fb[j], m2[j], i2[j], g2[j], b2[j]);
           o[j] = relu ? fmaxf(t, 0.f) : t;
         }
-        *reinterpret_cast<uint4*>(out + ru * C + c0) = Elem<T>::pack(o);
+        const uint4 packed = Elem<T>::pack(o);
+        *reinterpret_cast<uint4*>(out + ru * C + c0) = packed;
+        if (bits) bits[ru * VC + v] = (unsigned char)relu_bits<T>(packed);
       }
     }
   }
@@ -255,7 +257,7 @@ extern "C" int das_bn_relu_add3_forward(const void* x, const void* raw1, const v
 }
 
 extern "C" int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C,
-                                 const float* const* bn, int relu, void* stream) {
+                                 const float* const* bn, int relu, void* relu_bits_out, void* stream) {
   if (!raw1 || !raw2 || !out || !bn || !par_ok(bn) || rows < 1 || C % 8 || C < 8 || C > 4096) return DAS_ERR_ARG;
   const int vc = C / (dtype == DAS_F32 ? 4 : 8);
   const int pl = TPB / (vc < TPB ? vc : TPB);
@@ -265,7 +267,7 @@ extern "C" int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, 
   const BnPar p1{bn[0], bn[1], bn[2], bn[3]}, p2{bn[4], bn[5], bn[6], bn[7]};
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(bn_dual_apply_kernel<T>, dim3((unsigned)grid), dim3(TPB), 0, (hipStream_t)stream, (const T*)raw1,
-                       (const T*)raw2, (T*)out, rows, C, (int)rpb, p1, p2, relu);
+                       (const T*)raw2, (T*)out, rows, C, (int)rpb, p1, p2, relu, (unsigned char*)relu_bits_out);
   });
   DAS_CHECK_LAUNCH();
   return DAS_OK;

@@ -208,7 +208,7 @@ __device__ __forceinline__ void wgrad_load_unit(const WgradSched& g, const Wgrad
   p.M = o.M; p.K = o.K; p.HoWo = o.HoWo; p.ntiles = p.nblocks = 0; p.m_base = 0; p.xbytes = o.xbytes; p.nlev = o.nlev; p.B = o.B;
 #pragma unroll
   for (int l = 0; l < MAXLV; ++l) { p.lvH[l] = o.lvH[l]; p.lvW[l] = o.lvW[l]; p.lvStart[l] = o.lvStart[l]; }
-  p.bnb_raw = p.bnb_y = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;
+  p.bnb_raw = p.bnb_y = nullptr; p.bnb_bits = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;
 }
 // accumulators of a whole reduction -> dW (row-major Cout x K), same element map as wgrad_reduce_kernel. A wave tile
 // inside the result (the common case, wave-uniform test) runs without per-element tests: the old values of an
@@ -822,6 +822,7 @@ __device__ __forceinline__ void bn_masked_grad(float* g, const float* x, const u
 // pass 1: s1[c] = sum dZ, s2[c] = sum dZ * xhat with dZ = dY * mask. Four rows in flight per thread.
 template <typename T, int MASK, int NT>
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                           const unsigned char* __restrict__ bits,   // (MASK 1: instead of y, common.h relu_bits)
                                                            const T* __restrict__ raw, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
@@ -850,7 +851,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
         if (ru < rows) {
           gv[u] = *reinterpret_cast<const uint4*>(dy + ru * C + v * EPV);
           xv[u] = *reinterpret_cast<const uint4*>(raw + ru * C + v * EPV);
-          if (MASK == 1) yv[u] = *reinterpret_cast<const uint4*>(y + ru * C + v * EPV);
+          if (MASK == 1) {   // (the mask byte is only REQUESTED here: expanding it at once would make every load wait for it)
+            if (bits) yv[u].x = bits[ru * VC + v];
+            else yv[u] = *reinterpret_cast<const uint4*>(y + ru * C + v * EPV);
+          }
         }
       }
 #pragma unroll
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
         float g[EPV], x[EPV];
         Elem<T>::unpack(gv[u], g);
         Elem<T>::unpack(xv[u], x);
-        bn_masked_grad<T, MASK>(g, x, yv[u], mu, is, ga, be);
+        bn_masked_grad<T, MASK>(g, x, (MASK == 1 && bits) ? mask_vec<T>(yv[u].x) : yv[u], mu, is, ga, be);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) { s1[j] += g[j]; s2[j] += g[j] * (x[j] - mu[j]) * is[j]; }
       }
@@ -873,7 +877,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
 // pass 2: dRaw = gamma*invstd*(dZ - s1/N - xhat*s2/N); optionally dRes = dZ. Block 0 also adds the two
 // sums into the parameter-gradient accumulators (dbeta += s1, dgamma += s2) when they are given.
 template <typename T, int MASK, bool FIXED>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ raw,
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                    const unsigned char* __restrict__ bits, const T* __restrict__ raw,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ sums, long long rows, int C, T* __restrict__ draw,
@@ -899,7 +904,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     float g[EPV], x[EPV], o[EPV];
     Elem<T>::unpack(gv, g);
     Elem<T>::unpack(xv, x);
-    bn_masked_grad<T, MASK>(g, x, yv, mu, is, ga, be);
+    bn_masked_grad<T, MASK>(g, x, (MASK == 1 && bits) ? mask_vec<T>(yv.x) : yv, mu, is, ga, be);
     if (dres) *reinterpret_cast<uint4*>(dres + i * EPV) = Elem<T>::pack(g);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) o[j] = k1[j] * (g[j] - k2[j] - (x[j] - mu[j]) * k3[j]);
@@ -914,7 +919,10 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
       const uint4 g0 = *reinterpret_cast<const uint4*>(dy + i * EPV), g1 = *reinterpret_cast<const uint4*>(dy + i1 * EPV);
       const uint4 x0 = *reinterpret_cast<const uint4*>(raw + i * EPV), x1 = *reinterpret_cast<const uint4*>(raw + i1 * EPV);
       uint4 y0 = z4, y1 = z4;
-      if (MASK == 1) { y0 = *reinterpret_cast<const uint4*>(y + i * EPV); y1 = *reinterpret_cast<const uint4*>(y + i1 * EPV); }
+      if (MASK == 1) {   // (with bits: the byte travels in .x and is expanded inside finish)
+        if (bits) { y0.x = bits[i]; y1.x = bits[i1]; }
+        else { y0 = *reinterpret_cast<const uint4*>(y + i * EPV); y1 = *reinterpret_cast<const uint4*>(y + i1 * EPV); }
+      }
       finish(i, g0, x0, y0);
       finish(i1, g1, x1, y1);
     }
@@ -924,7 +932,10 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     const uint4 g0 = *reinterpret_cast<const uint4*>(dy + i * EPV);
     const uint4 x0 = *reinterpret_cast<const uint4*>(raw + i * EPV);
     uint4 y0 = z4;
-    if (MASK == 1) y0 = *reinterpret_cast<const uint4*>(y + i * EPV);
+    if (MASK == 1) {
+      if (bits) y0.x = bits[i];
+      else y0 = *reinterpret_cast<const uint4*>(y + i * EPV);
+    }
     finish(i, g0, x0, y0);
   }
 }
@@ -1038,7 +1049,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_dz_stream_kernel(const T* __
 }
 
 template <typename T, int MASK>
-void launch_bn_backward(const void* dy, const void* y, const void* raw, long long rows, int C, const float* mean,
+void launch_bn_backward(const void* dy, const void* y, const unsigned char* bits, const void* raw, long long rows, int C, const float* mean,
                         const float* invstd, const float* gamma, const float* beta, void* draw, void* dres,
                         float* sums, float* dgamma_acc, float* dbeta_acc, int phase, long long stat_rows,
                         hipStream_t s) {
@@ -1049,10 +1060,10 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
     const int blocks = (int)std::min<long long>(cap, std::max<long long>(1, rows / 64));
     if (nt == 1024) {
       hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 1024>), dim3(blocks), dim3(1024), (1024 / std::min(vc, 1024)) * 2 * C * sizeof(float), s,
-                         (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
+                         (const T*)dy, (const T*)y, bits, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
     } else {
       hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, 256>), dim3(blocks), dim3(256), (256 / std::min(vc, 256)) * 2 * C * sizeof(float), s,
-                         (const T*)dy, (const T*)y, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
+                         (const T*)dy, (const T*)y, bits, (const T*)raw, mean, invstd, gamma, beta, rows, C, sums);
     }
   }
   if (phase == 1) return;
@@ -1060,11 +1071,11 @@ void launch_bn_backward(const void* dy, const void* y, const void* raw, long lon
   const int vpt = std::max(1, (int)dastune::get(dastune::BN_VPT));   // vectors per thread (see das_bn_train_apply)
   const int grid = std::max(1, std::min(grid_for(rows * vc), (int)((rows * vc + (long long)TPB * vpt - 1) / ((long long)TPB * vpt))));
   if (((long long)grid * TPB) % vc == 0) {
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, true>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, true>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y, bits,
                        (const T*)raw, mean, invstd, gamma, beta, sums, rows, C, (T*)draw, (T*)dres, dgamma_acc,
                        dbeta_acc, inv_n);
   } else {
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, false>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK, false>), dim3(grid), dim3(TPB), 0, s, (const T*)dy, (const T*)y, bits,
                        (const T*)raw, mean, invstd, gamma, beta, sums, rows, C, (T*)draw, (T*)dres, dgamma_acc,
                        dbeta_acc, inv_n);
   }
@@ -1517,22 +1528,21 @@ extern "C" int das_colsum_acc(const void* x, int dtype, long long rows, int C, i
   return colsum_impl(x, dtype, rows, C, pix_stride, out, true, stream);
 }
 
-extern "C" int das_bn_train_backward_phase(const void* dy, const void* y, const void* raw, int dtype, long long rows,
-                                           int C, const float* mean, const float* invstd, const float* gamma,
-                                           const float* beta, int relu, void* draw, void* dres, float* sums,
-                                           int sums_prezeroed, float* dgamma_acc, float* dbeta_acc, int phase,
-                                           long long stat_rows, void* stream) {
+static int bn_train_backward_impl(const void* dy, const void* y, const unsigned char* bits, const void* raw, int dtype,
+                                  long long rows, int C, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, int relu, void* draw, void* dres, float* sums, int sums_prezeroed,
+                                  float* dgamma_acc, float* dbeta_acc, int phase, long long stat_rows, void* stream) {
   if (!dy || !raw || !mean || !invstd || !gamma || !sums || rows <= 0 || C % 8 || C > 2048) return DAS_ERR_ARG;
   if (phase < 0 || phase > 2 || (phase != 1 && !draw) || stat_rows < rows) return DAS_ERR_ARG;
-  if (relu && !y && !beta) return DAS_ERR_ARG;
+  if (relu && !y && !bits && !beta) return DAS_ERR_ARG;
   if ((dgamma_acc == nullptr) != (dbeta_acc == nullptr)) return DAS_ERR_ARG;
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (phase != 2 && !sums_prezeroed && hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, s) != hipSuccess)
     return DAS_ERR_LAUNCH;
-  const int mask = !relu ? 0 : (y ? 1 : 2);
+  const int mask = !relu ? 0 : ((y || bits) ? 1 : 2);
 #define DAS_BN_BWD(T, MASK)                                                                                         \
-  launch_bn_backward<T, MASK>(dy, y, raw, rows, C, mean, invstd, gamma, beta, draw, dres, sums, dgamma_acc, dbeta_acc, \
+  launch_bn_backward<T, MASK>(dy, y, bits, raw, rows, C, mean, invstd, gamma, beta, draw, dres, sums, dgamma_acc, dbeta_acc, \
                               phase, stat_rows, s)
   if (dtype == DAS_BF16) {
     if (mask == 0) DAS_BN_BWD(bf16_t, 0); else if (mask == 1) DAS_BN_BWD(bf16_t, 1); else DAS_BN_BWD(bf16_t, 2);
@@ -1542,6 +1552,24 @@ extern "C" int das_bn_train_backward_phase(const void* dy, const void* y, const 
 #undef DAS_BN_BWD
   DAS_CHECK_LAUNCH();
   return DAS_OK;
+}
+
+extern "C" int das_bn_train_backward_phase(const void* dy, const void* y, const void* raw, int dtype, long long rows,
+                                           int C, const float* mean, const float* invstd, const float* gamma,
+                                           const float* beta, int relu, void* draw, void* dres, float* sums,
+                                           int sums_prezeroed, float* dgamma_acc, float* dbeta_acc, int phase,
+                                           long long stat_rows, void* stream) {
+  return bn_train_backward_impl(dy, y, nullptr, raw, dtype, rows, C, mean, invstd, gamma, beta, relu, draw, dres, sums,
+                                sums_prezeroed, dgamma_acc, dbeta_acc, phase, stat_rows, stream);
+}
+
+extern "C" int das_bn_train_backward_bits(const void* dy, const void* y_relu_bits, const void* raw, int dtype, long long rows,
+                                          int C, const float* mean, const float* invstd, const float* gamma, void* draw,
+                                          void* dres, float* sums, int sums_prezeroed, float* dgamma_acc, float* dbeta_acc,
+                                          void* stream) {
+  if (!y_relu_bits) return DAS_ERR_ARG;
+  return bn_train_backward_impl(dy, nullptr, (const unsigned char*)y_relu_bits, raw, dtype, rows, C, mean, invstd, gamma,
+                                nullptr, 1, draw, dres, sums, sums_prezeroed, dgamma_acc, dbeta_acc, 0, rows, stream);
 }
 
 extern "C" int das_bn_backward_apply(const void* dz, const void* raw, int dtype, long long rows, int C, const float* mean,

@@ -78,7 +78,7 @@ struct BnPar {
 template <typename T>
 __global__ __launch_bounds__(TPB) void upmerge_fwd_kernel(const T* __restrict__ raw1, const T* __restrict__ z, T* __restrict__ out,
                                                           int B, int H, int W, int C, int Ho, int Wo, float sh, float sw,
-                                                          int pix_per_block, BnPar p1, BnPar p2) {
+                                                          int pix_per_block, BnPar p1, BnPar p2, unsigned char* __restrict__ bits) {
   constexpr int EPV = Elem<T>::EPV;
   const int VC = C / EPV;
   const int VCB = min(VC, TPB), PL = TPB / VCB, pl = threadIdx.x / VCB;
@@ -113,7 +113,9 @@ __global__ __launch_bounds__(TPB) void upmerge_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < EPV; ++j)
           o[j] = fmaxf(bn_affine(up[j], m2[j], i2[j], g2[j], b2[j]) + bn_affine(x1[j], m1[j], i1[j], g1[j], b1[j]), 0.f);
-        *reinterpret_cast<uint4*>(out + (long long)pix * C + c0) = Elem<T>::pack(o);
+        const uint4 packed = Elem<T>::pack(o);
+        *reinterpret_cast<uint4*>(out + (long long)pix * C + c0) = packed;
+        if (bits) bits[(long long)pix * VC + v] = (unsigned char)relu_bits<T>(packed);
       }
     }
   }
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(TPB) void upmerge_fwd_kernel(const T* __restrict__ 
 // A few workgroups per CU, each over its own run of pixels; every workgroup ends with 3C global atomics.
 template <typename T>
 __global__ __launch_bounds__(TPB) void upmerge_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ out,
+                                                                 const unsigned char* __restrict__ bits,   // (instead of out)
                                                                  const T* __restrict__ raw1, const T* __restrict__ z,
                                                                  T* __restrict__ dzm, int B, int H, int W, int C, int Ho, int Wo,
                                                                  float sh, float sw, const float* __restrict__ mean1,
@@ -162,7 +165,8 @@ __global__ __launch_bounds__(TPB) void upmerge_bwd_reduce_kernel(const T* __rest
         load_corners(z, g[u], W, C, c0, rz[u]);
         const long long o = (long long)pix * C + c0;
         rg[u] = *reinterpret_cast<const uint4*>(dy + o);
-        ro[u] = *reinterpret_cast<const uint4*>(out + o);
+        if (bits) ro[u].x = bits[(long long)pix * VC + v];   // (expanded at use)
+        else ro[u] = *reinterpret_cast<const uint4*>(out + o);
         rx[u] = *reinterpret_cast<const uint4*>(raw1 + o);
       }
 #pragma unroll
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(TPB) void upmerge_bwd_reduce_kernel(const T* __rest
         interp<T>(rz[u], g[u], up);
         Elem<T>::unpack(rx[u], x1);
         Elem<T>::unpack(rg[u], gg);
-        Elem<T>::unpack(ro[u], oo);
+        Elem<T>::unpack(bits ? mask_vec<T>(ro[u].x) : ro[u], oo);
 #pragma unroll
         for (int j = 0; j < EPV; ++j) gg[j] = oo[j] > 0.f ? gg[j] : 0.f;
         const uint4 packed = Elem<T>::pack(gg);
@@ -327,7 +331,7 @@ static bool geom_ok(int B, int H, int W, int C, int Ho, int Wo) {
 extern "C" int das_upmerge_forward(const void* raw1, const void* z, void* out, int dtype, int B, int H, int W, int C, int Ho, int Wo,
                                    const float* mean1, const float* invstd1, const float* gamma1, const float* beta1,
                                    const float* mean2, const float* invstd2, const float* gamma2, const float* beta2,
-                                   void* stream) {
+                                   void* relu_bits_out, void* stream) {
   if (!raw1 || !z || !out || !mean1 || !invstd1 || !gamma1 || !beta1 || !mean2 || !invstd2 || !gamma2 || !beta2 ||
       !geom_ok(B, H, W, C, Ho, Wo))
     return DAS_ERR_ARG;
@@ -341,17 +345,18 @@ extern "C" int das_upmerge_forward(const void* raw1, const void* z, void* out, i
   const BnPar p1{mean1, invstd1, gamma1, beta1}, p2{mean2, invstd2, gamma2, beta2};
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(upmerge_fwd_kernel<T>, dim3((unsigned)grid), dim3(TPB), 0, (hipStream_t)stream, (const T*)raw1,
-                       (const T*)z, (T*)out, B, H, W, C, Ho, Wo, sh, sw, (int)ppb, p1, p2);
+                       (const T*)z, (T*)out, B, H, W, C, Ho, Wo, sh, sw, (int)ppb, p1, p2, (unsigned char*)relu_bits_out);
   });
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }
 
-extern "C" int das_upmerge_backward_reduce(const void* dy, const void* out, const void* raw1, const void* z, void* dzm, int dtype,
+extern "C" int das_upmerge_backward_reduce(const void* dy, const void* out, const void* out_relu_bits, const void* raw1,
+                                           const void* z, void* dzm, int dtype,
                                            int B, int H, int W, int C, int Ho, int Wo, const float* mean1,
                                            const float* invstd1, const float* mean2, const float* invstd2, float* sums,
                                            int sums_zeroed, void* stream) {
-  if (!dy || !out || !raw1 || !z || !dzm || !mean1 || !invstd1 || !mean2 || !invstd2 || !sums || !geom_ok(B, H, W, C, Ho, Wo))
+  if (!dy || (!out && !out_relu_bits) || !raw1 || !z || !dzm || !mean1 || !invstd1 || !mean2 || !invstd2 || !sums || !geom_ok(B, H, W, C, Ho, Wo))
     return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (!sums_zeroed && hipMemsetAsync(sums, 0, sizeof(float) * 3 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
@@ -369,7 +374,7 @@ extern "C" int das_upmerge_backward_reduce(const void* dy, const void* out, cons
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return DAS_ERR_LAUNCH;
     hipLaunchKernelGGL(upmerge_bwd_reduce_kernel<T>, dim3(blocks), dim3(TPB), lds, s, (const T*)dy, (const T*)out,
-                       (const T*)raw1, (const T*)z, (T*)dzm, B, H, W, C, Ho, Wo, sh, sw, mean1, invstd1, mean2, invstd2, sums);
+                       out ? nullptr : (const unsigned char*)out_relu_bits, (const T*)raw1, (const T*)z, (T*)dzm, B, H, W, C, Ho, Wo, sh, sw, mean1, invstd1, mean2, invstd2, sums);
   });
   DAS_CHECK_LAUNCH();
   return DAS_OK;

@@ -283,10 +283,12 @@ class BnBwd:
     tensor into its epilogue (DasConvDesc.bnb_*): raw = that layer's pre-norm tensor, y = its post-ReLU output (only
     when a residual entered before the ReLU; None = recompute the mask from raw), per-channel mean / invstd / gamma /
     beta, relu flag."""
-    __slots__ = ('raw', 'y', 'mean', 'invstd', 'gamma', 'beta', 'relu')
+    __slots__ = ('raw', 'y', 'mean', 'invstd', 'gamma', 'beta', 'relu', 'bits')
 
-    def __init__(self, raw, y, mean, invstd, gamma, beta, relu):
+    def __init__(self, raw, y, mean, invstd, gamma, beta, relu, bits=None):
+        """bits: instead of y, its ReLU mask as recorded by the forward apply pass (relu_bits_buffer): 1/16 of y's bytes."""
         self.raw, self.y, self.mean, self.invstd, self.gamma, self.beta, self.relu = raw, y, mean, invstd, gamma, beta, relu
+        self.bits = bits if y is None else None
 
 
 def bn_backward_apply(dz, raw, mean, invstd, gamma, sums, dgamma_acc=None, dbeta_acc=None, stat_rows=0):
@@ -435,11 +437,20 @@ def colsum(x, acc=None):
     return out
 
 
-def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta=None, dgamma_acc=None, dbeta_acc=None):
+def relu_bits_buffer(x):
+    """u8 buffer for the ReLU mask of a tensor shaped like x: one byte per 16-byte vector (das_bn_train_apply relu_bits_out)."""
+    assert (x.numel() * x.element_size()) % 16 == 0
+    return torch.empty(x.numel() * x.element_size() // 16, dtype=torch.uint8, device=x.device)
+
+
+def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta=None, dgamma_acc=None, dbeta_acc=None, bits=None):
     """Returns d_raw, d_residual (or None), dgamma, dbeta. y=None with relu: the ReLU mask is recomputed
     from raw (needs beta; only valid when no residual entered before the ReLU). dgamma_acc/dbeta_acc:
-    f32[C] buffers the parameter gradients are also added to."""
-    _need_gpu(dy, raw)
+    f32[C] buffers the parameter gradients are also added to. bits (with y=None, relu): the mask as recorded by the forward
+    (relu_bits_buffer) — valid with a residual, and neither pass reads y."""
+    _need_gpu(dy, raw, bits)
+    if bits is not None:
+        assert y is None and relu and bits.dtype == torch.uint8 and bits.numel() * 16 == raw.numel() * raw.element_size()
     assert dy.is_contiguous() and raw.is_contiguous() and (y is None or y.is_contiguous())
     Cc = raw.shape[-1]
     rows = raw.numel() // Cc
@@ -451,12 +462,19 @@ def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta=Non
         sums, prezeroed = zeroed_stats(2 * Cc, raw.device), 1
     else:
         sums, prezeroed = torch.empty(2 * Cc, dtype=torch.float32, device=raw.device), 0
-    assert not (relu and y is None and want_dres), 'the recomputed mask ignores a residual'
+    assert not (relu and y is None and bits is None and want_dres), 'the recomputed mask ignores a residual'
     # two passes (the sums must be complete before anything can be applied): reduce reads dY, raw (, y); apply reads them
     # again and writes d raw (, d residual)
     nin = 3 if y is not None else 2
     with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', (2 * nin + 1 + (1 if want_dres else 0)) * raw.numel() *
-                raw.element_size(), launches=2, shape=(rows, Cc, nin, int(bool(want_dres)))):
+                raw.element_size() + (bits.numel() * 2 if bits is not None else 0), launches=2,
+                shape=(rows, Cc, nin if bits is None else 'bits', int(bool(want_dres)))):
+        if bits is not None:
+            _lib.check(_lib.load().das_bn_train_backward_bits(_ptr(dy), _ptr(bits), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean),
+                                                              _ptr(invstd), _ptr(gamma), _ptr(draw), _ptr(dres), _ptr(sums),
+                                                              prezeroed, _ptr(dgamma_acc), _ptr(dbeta_acc), _stream()),
+                       'das_bn_train_backward_bits')
+            return draw, dres, sums[Cc:], sums[:Cc]
         _lib.check(_lib.load().das_bn_train_backward(_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean),
                                                      _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _ptr(draw),
                                                      _ptr(dres), _ptr(sums), prezeroed, _ptr(dgamma_acc),
@@ -550,7 +568,10 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         d.bnb_mean, d.bnb_invstd = b.mean.data_ptr(), b.invstd.data_ptr()
         d.bnb_gamma, d.bnb_beta = b.gamma.data_ptr(), b.beta.data_ptr()
         d.bnb_relu, d.bnb_pix_stride = int(b.relu), Cout
-        _need_gpu(b.raw, b.y, b.mean, b.invstd, b.gamma, b.beta)
+        if b.bits is not None:
+            assert b.bits.dtype == torch.uint8 and b.bits.numel() * 16 == b.raw.numel() * b.raw.element_size()
+            d.bnb_mask_bits = b.bits.data_ptr()
+        _need_gpu(b.raw, b.y, b.mean, b.invstd, b.gamma, b.beta, b.bits)
     if ragged:
         for l, (h, w_) in enumerate(x.sizes):
             d.lvl_H[l], d.lvl_W[l] = h, w_
@@ -568,9 +589,10 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         nby = xd.numel() * xd.element_size() + Cout * KH * KW * Cin * xd.element_size() + rows * Cout * eo
         nby += rows * Cout * eo if rd is not None else 0
         if bn_bwd is not None:
-            nby += rows * Cout * eo * (2 if bn_bwd.y is not None else 1)
+            nby += rows * Cout * eo * (2 if bn_bwd.y is not None else 1) + (rows * Cout * eo // 16 if bn_bwd.bits is not None else 0)
         mode = ('s' if stats is not None and bn_bwd is None else '') + ('r' if rd is not None else '') + \
-            ('' if bn_bwd is None else ('by' if bn_bwd.y is not None else 'bx')) + ('a' if scale is not None else '') + \
+            ('' if bn_bwd is None else ('by' if bn_bwd.y is not None else 'bm' if bn_bwd.bits is not None else 'bx')) + \
+            ('a' if scale is not None else '') + \
             ('u' if out_sub is not None else '')
         PROFILE.append((tag, 2.0 * rows * Cout * KH * KW * Cin, e0, e1,
                         (B, H, W, Cin, Cout, KH, stride, len(x.sizes) if ragged else 1, mode), 1, float(nby)))
@@ -654,7 +676,7 @@ def add3(a, b, c=None, relu=False):
 
 
 def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, residual=None,
-                   relu=False, num_batches_tracked=None, stat_count=0, finalize_only=False):
+                   relu=False, num_batches_tracked=None, stat_count=0, finalize_only=False, bits_out=None):
     """x (B,H,W,C) raw conv output, stats f32[slots][2C] from the conv epilogue. Returns y, mean, invstd.
     num_batches_tracked: the BatchNorm's int64 counter buffer, incremented on the device by the same launch.
     stat_count: global row count when `stats` was all-reduced over ranks (SyncBN); 0 = this tensor's rows."""
@@ -673,7 +695,7 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
                                                   _ptr(beta), _ptr(running_mean), _ptr(running_var), momentum, eps,
                                                   _ptr(residual), int(relu), _ptr(mean), _ptr(invstd),
                                                   _ptr(num_batches_tracked), int(stat_count),
-                                                  stats.numel() // (2 * Cc), _stream()),
+                                                  stats.numel() // (2 * Cc), _ptr(bits_out), _stream()),
                    'das_bn_train_apply')
     return y, mean, invstd
 
@@ -761,7 +783,7 @@ def _bn_ptrs(bn1, bn2):
     return arr
 
 
-def bn_dual_apply(raw1, bn1, raw2, bn2, relu=True):
+def bn_dual_apply(raw1, bn1, raw2, bn2, relu=True, bits_out=None):
     """relu(BN1(raw1) + BN2(raw2)); bn = (mean, invstd, gamma, beta) f32[C] (das_bn_dual_apply)."""
     _need_gpu(raw1, raw2)
     assert raw1.is_contiguous() and raw2.is_contiguous() and raw1.shape == raw2.shape and raw1.dtype == raw2.dtype
@@ -770,7 +792,7 @@ def bn_dual_apply(raw1, bn1, raw2, bn2, relu=True):
     arr = _bn_ptrs(bn1, bn2)
     with _timed('bn_apply_kernel', 3 * raw1.numel() * raw1.element_size(), shape=(raw1.numel() // Cc, Cc, 'dual')):
         _lib.check(_lib.load().das_bn_dual_apply(_ptr(raw1), _ptr(raw2), _ptr(out), _DT[raw1.dtype], raw1.numel() // Cc, Cc, arr,
-                                                 int(relu), _stream()), 'das_bn_dual_apply')
+                                                 int(relu), _ptr(bits_out), _stream()), 'das_bn_dual_apply')
     return out
 
 
@@ -824,7 +846,7 @@ def _upsample_stats_lowres(z, B, H, W, Cc, ah, aw, wh, ww, stats):
                                                      _ptr(stats), stats.numel() // (2 * Cc), _stream()), 'das_upsample_stats_lowres')
 
 
-def upmerge_forward(raw1, z, bn1, bn2):
+def upmerge_forward(raw1, z, bn1, bn2, bits_out=None):
     """relu(BN1(raw1) + BN2(upsample(z))); bn = (mean, invstd, gamma, beta) f32[C] each (das_upmerge_forward)."""
     _need_gpu(raw1, z)
     B, Ho, Wo, Cc = raw1.shape
@@ -833,22 +855,23 @@ def upmerge_forward(raw1, z, bn1, bn2):
     with _timed('bn_apply_kernel', 2 * raw1.numel() * raw1.element_size() + z.numel() * z.element_size(),
                 shape=(raw1.numel() // Cc, Cc, 'upmerge')):
         _lib.check(_lib.load().das_upmerge_forward(_ptr(raw1), _ptr(z), _ptr(out), _DT[raw1.dtype], B, z.shape[1], z.shape[2], Cc, Ho,
-                                                   Wo, *[_ptr(t) for t in bn1], *[_ptr(t) for t in bn2], _stream()),
+                                                   Wo, *[_ptr(t) for t in bn1], *[_ptr(t) for t in bn2], _ptr(bits_out), _stream()),
                    'das_upmerge_forward')
     return out
 
 
-def upmerge_backward_reduce(dy, out, raw1, z, mean1, invstd1, mean2, invstd2):
+def upmerge_backward_reduce(dy, out, raw1, z, mean1, invstd1, mean2, invstd2, bits=None):
     """Returns dzm = dy * (out > 0) and sums f32[3C] = [sum dZ | sum dZ xhat1 | sum dZ xhat2] (das_upmerge_backward_reduce)."""
-    _need_gpu(dy, out, raw1, z)
+    _need_gpu(dy, raw1, z)
     B, Ho, Wo, Cc = raw1.shape
-    assert dy.is_contiguous() and dy.shape == raw1.shape == out.shape and dy.dtype == raw1.dtype == out.dtype == z.dtype
+    assert dy.is_contiguous() and dy.shape == raw1.shape and dy.dtype == raw1.dtype == z.dtype
+    assert (out is None) != (bits is None) and (out is None or (out.shape == raw1.shape and out.dtype == raw1.dtype))
     dzm = torch.empty_like(raw1)
     from .nn import zeroed_stats
     sums = zeroed_stats(3 * Cc, raw1.device)
-    with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', 4 * raw1.numel() * raw1.element_size() + z.numel() * z.element_size(),
-                shape=(raw1.numel() // Cc, Cc, 'upmerge')):
-        _lib.check(_lib.load().das_upmerge_backward_reduce(_ptr(dy), _ptr(out), _ptr(raw1), _ptr(z), _ptr(dzm), _DT[raw1.dtype], B,
+    with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', (4 if bits is None else 3) * raw1.numel() * raw1.element_size() +
+                z.numel() * z.element_size() + (bits.numel() if bits is not None else 0), shape=(raw1.numel() // Cc, Cc, 'upmerge')):
+        _lib.check(_lib.load().das_upmerge_backward_reduce(_ptr(dy), _ptr(out), _ptr(bits), _ptr(raw1), _ptr(z), _ptr(dzm), _DT[raw1.dtype], B,
                                                            z.shape[1], z.shape[2], Cc, Ho, Wo, _ptr(mean1), _ptr(invstd1),
                                                            _ptr(mean2), _ptr(invstd2), _ptr(sums), 1, _stream()),
                    'das_upmerge_backward_reduce')

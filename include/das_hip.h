@@ -125,6 +125,10 @@ typedef struct {
    * (ph, pw), each over only the taps that land on dY samples — das_conv2d_nhwc with in_up = 2 multiplies three zeros
    * for every sample (torch: conv_transpose / cuDNN dgrad behind mspn_mmpose.py's stride-2 Bottlenecks). */
   int out_sub, out_ph, out_pw, out_H, out_W;
+  /* Instead of bnb_y (used when bnb_y == NULL): the ReLU mask of that layer as bits, one byte per 16-byte vector of y
+   * (bit j = element j > 0; index = element offset / elements per vector, y contiguous with pixel stride
+   * bnb_pix_stride) as das_bn_train_apply / das_bn_dual_apply / das_upmerge_forward record it: 1/16 of y's bytes. */
+  const void* bnb_mask_bits;
 } DasConvDesc;
 int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream);
 
@@ -178,6 +182,11 @@ int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dt
  * all-reduces `sums`; phase 2 = only the apply pass with 1/N taken from stat_rows (all ranks' rows) — what
  * torch's SyncBatchNorm backward does with its all_reduce of (sum_dy, sum_dy_xmu). phase 0 = both at once.
  * The parameter-gradient accumulators are fed from `sums` in phase 2: hand them only when `sums` is local. */
+/* das_bn_train_backward for a ReLU layer whose mask was recorded as bits by the forward (das_bn_train_apply's
+ * relu_bits_out): neither pass reads y. */
+int das_bn_train_backward_bits(const void* dy, const void* y_relu_bits, const void* raw, int dtype, long long rows, int C,
+                               const float* mean, const float* invstd, const float* gamma, void* draw, void* dres,
+                               float* sums, int sums_prezeroed, float* dgamma_acc, float* dbeta_acc, void* stream);
 int das_bn_train_backward_phase(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 int relu, void* draw, void* dres, float* sums, int sums_prezeroed, float* dgamma_acc,
@@ -256,11 +265,13 @@ int das_upsample_stats_lowres(const void* z, int dtype, int B, int H, int W, int
                               const float* wh, const float* ww, float* stats, int stats_slots, void* stream);
 int das_upmerge_forward(const void* raw1, const void* z, void* out, int dtype, int B, int H, int W, int C, int Ho, int Wo,
                         const float* mean1, const float* invstd1, const float* gamma1, const float* beta1,
-                        const float* mean2, const float* invstd2, const float* gamma2, const float* beta2, void* stream);
+                        const float* mean2, const float* invstd2, const float* gamma2, const float* beta2,
+                        void* relu_bits_out, void* stream);
 /* Backward pass A: dzm = dy * (out > 0) written once (the gradient of both pre-activation branches), and
  * sums f32[3C] = [sum dZ | sum dZ xhat1 | sum dZ xhat2] (zeroed here unless sums_zeroed says the caller did), xhat2 from
  * upsample(z) recomputed on the fly. The first 2C are BatchNorm 1's sums in das_bn_backward_apply's layout (one slot). */
-int das_upmerge_backward_reduce(const void* dy, const void* out, const void* raw1, const void* z, void* dzm, int dtype,
+int das_upmerge_backward_reduce(const void* dy, const void* out, const void* out_relu_bits, const void* raw1, const void* z,
+                                void* dzm, int dtype,
                                 int B, int H, int W, int C, int Ho, int Wo, const float* mean1, const float* invstd1,
                                 const float* mean2, const float* invstd2, float* sums, int sums_zeroed, void* stream);
 /* Backward pass D, at low resolution: dz = upsample^T(d raw2) from P = upsample^T(dzm) (das_upsample_bilinear_ac_backward), z, the
@@ -281,7 +292,7 @@ int das_upmerge_backward_lowres(const void* P, const void* z, void* dz, int dtyp
 /* out = relu?(BN1(raw1) + BN2(raw2)): a bottleneck's bn3 with the block's projection shortcut `downsample(x)`
  * (mspn_mmpose.py:126-157) normalised on the fly — the shortcut's normalised tensor is never written. bn as below. */
 int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C, const float* const* bn,
-                      int relu, void* stream);
+                      int relu, void* relu_bits_out, void* stream);
 int das_bn_relu_add3_forward(const void* x, const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C,
                              const float* const* bn, void* stream);
 int das_bn_relu_add3_backward(const void* g, const void* raw1, const void* raw2, void* draw1, void* draw2, int dtype,
@@ -312,12 +323,15 @@ int das_add3(const void* a, const void* b, const void* c, void* y, int dtype, lo
  * first and passes the global row count; 0 = count. stats_slots: `stats` is f32[stats_slots][2*C] partial sums
  * (DasConvDesc.stats_slots; 0 = 1); with more than one slot the call folds them into slot 0 in place first.
  * y == NULL: finalize only (mean / invstd saved, running statistics and the counter advanced, nothing normalised): a
- * layer whose output has no consumer — the last MSPN stage's finest map under a neck with start_level = 1. */
+ * layer whose output has no consumer — the last MSPN stage's finest map under a neck with start_level = 1.
+ * relu_bits_out (optional): u8[count * C / (16 / element size)] — the mask y > 0 as one byte per 16-byte vector of y
+ * (bit j = element j of the vector), 1/16 of y's bytes: what the backward of a BatchNorm + residual + ReLU layer needs
+ * of y (das_bn_train_backward_bits, DasConvDesc.bnb_mask_bits), so that no backward pass reads y for its mask. */
 int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C, const float* stats,
                        const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, const void* residual, int relu, float* save_mean,
                        float* save_invstd, long long* num_batches_tracked, long long stat_count, int stats_slots,
-                       void* stream);
+                       void* relu_bits_out, void* stream);
 
 /* Ragged multi-level pixel rows. The DASHead shares its weights across FPN levels
  * (das_head.py:176-178 `multi_apply(self.forward_single, feats, ...)`), so the head ops below take

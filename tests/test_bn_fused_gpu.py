@@ -98,6 +98,22 @@ def test_dgrad_epilogue_reduces_bn_backward(case, dtype):
     np.testing.assert_allclose(folded.numpy() / rows, s_self.numpy() / rows, rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(folded.numpy() / rows, s_ref.numpy() / rows, rtol=2e-2, atol=5e-3)   # (knife-edge masks)
 
+    if bnb.y is not None:
+        # the same launch with the ReLU mask handed over as BITS (one byte per 16-byte vector of y, what the forward apply
+        # pass records) instead of y: dZ bit-identical, sums equal up to the order of the float atomics
+        yd = bnb.y
+        per = 16 // yd.element_size()
+        wts = (2 ** torch.arange(per, device=DEV)).to(torch.int32)
+        bits = ((yd.reshape(-1, per) > 0).to(torch.int32) * wts).sum(1).to(torch.uint8)
+        sums_b = torch.zeros_like(sums)
+        bnb_b = o.BnBwd(bnb.raw, None, bnb.mean, bnb.invstd, bnb.gamma, bnb.beta, True, bits=bits)
+        with o.tuning(**FORCE[kernel]):
+            dz_b = o.conv2d(nhwc(dy, dtype), o.pack_weight(wf.to(DEV), dtype), k, k, 1, k // 2,
+                            residual=nhwc(res, dtype) if with_res else None, bn_bwd=bnb_b, stats=sums_b)
+            assert o.last_kernel() == kernel, o.last_kernel()
+        assert torch.equal(dz_b, dz)
+        np.testing.assert_allclose(sums_b.view(slots, -1).sum(0).cpu().numpy() / rows, folded.numpy() / rows, rtol=1e-5, atol=1e-6)
+
     # the apply pass on (dZ, sums) equals torch autograd through BatchNorm(train)+ReLU given the same dZ
     draw = o.bn_backward_apply(dz, bnb.raw, bnb.mean, bnb.invstd, bnb.gamma, sums)
     s1, s2 = s_self[:Cout], s_self[Cout:]
@@ -206,3 +222,36 @@ def test_chain_backward_with_flat_optimizer_direct_accumulation():
     big = [n for n in g0 if g0[n].numel() >= 256 and float(g0[n].abs().max()) > 0]
     cos = np.array([_cos(g0[n], g1[n]) for n in big])
     assert np.median(cos) > 0.999 and cos.min() > 0.98, (np.median(cos), cos.min())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('rows,C', [(2 * 16 * 26, 512), (333, 64), (70000, 256), (9, 8)])
+def test_relu_mask_bits_producer_and_consumers(rows, C, dtype):
+    """The forward apply pass records (y > 0) as one byte per 16-byte vector (das_bn_train_apply relu_bits_out, also the dual
+    apply); das_bn_train_backward_bits with those bits gives the BITS of das_bn_train_backward with y."""
+    from das_amd import ops as o
+    raw = (cases.randn(301, rows, C) * 1.3).to(dtype).to(DEV)
+    res = cases.randn(302, rows, C).to(dtype).to(DEV)
+    dy = cases.randn(303, rows, C).to(dtype).to(DEV)
+    gamma, beta = (cases.randn(304, C).abs() + 0.5).to(DEV), (cases.randn(305, C) * 0.5).to(DEV)
+    stats = torch.stack([raw.float().sum(0), (raw.float() ** 2).sum(0)]).reshape(-1).contiguous()
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    per = 16 // raw.element_size()
+    wts = (2 ** torch.arange(per, device=DEV)).to(torch.int32)
+    pack = lambda y: ((y.reshape(-1, per) > 0).to(torch.int32) * wts).sum(1).to(torch.uint8)
+    x4 = raw.view(1, 1, rows, C)
+    bits = o.relu_bits_buffer(x4)
+    y, mean, invstd = o.bn_train_apply(x4, stats, gamma, beta, rm, rv, residual=res.view(1, 1, rows, C), relu=True, bits_out=bits)
+    assert torch.equal(bits, pack(y)) and 0 < int((y > 0).sum()) < y.numel()
+    bits2 = o.relu_bits_buffer(x4)
+    y2 = o.bn_dual_apply(x4, (mean, invstd, gamma, beta), res.view(1, 1, rows, C), (mean * 0, invstd * 0 + 1, gamma * 0 + 1, beta * 0),
+                         relu=True, bits_out=bits2)
+    assert torch.equal(bits2, pack(y2))
+    a = o.bn_train_backward(dy.view(1, 1, rows, C), y, x4, mean, invstd, gamma, True, True, beta=beta)
+    b = o.bn_train_backward(dy.view(1, 1, rows, C), None, x4, mean, invstd, gamma, True, True, beta=beta, bits=bits)
+    assert torch.equal(a[1], b[1])          # dZ = dY * mask: the same bits
+    # (d raw goes through the per-channel sums, reduced with float atomics: equal up to their order, as two runs of one path)
+    scale = float(a[0].float().abs().max())
+    assert float((a[0].float() - b[0].float()).abs().max()) <= (2e-2 if dtype == torch.bfloat16 else 2e-5) * scale
+    for u, v in zip(a[2:], b[2:]):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-3)
