@@ -98,9 +98,9 @@ SIGNATURES = {
     'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
     'das_bn_train_backward_phase': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i64, vp]),
     'das_bn_backward_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]),
-    'das_groupnorm_backward': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp,
+    'das_groupnorm_backward': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, vp, f32, i32, vp,
                                      vp, vp, vp]),
-    'das_groupnorm_backward_acc': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp,
+    'das_groupnorm_backward_acc': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, vp, f32, i32, vp,
                                      vp, vp, vp]),
     'das_maxpool3x3s2_backward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_upsample_bilinear_ac_backward': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

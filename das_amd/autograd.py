@@ -831,6 +831,10 @@ class ConvFn(Function):
         return dx, dw, db, None, None, None, None, None
 
 
+# GroupNorm + ReLU backward with the mask recomputed from the input instead of read from the output; switch for A/B runs / tests
+GN_REMASK = True
+
+
 class GroupNormReLUFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, geom, G, eps, relu, gn=None):
@@ -839,20 +843,21 @@ class GroupNormReLUFn(Function):
         out = xin.new(x.shape[-1]) if geom is not None else torch.empty_like(x)
         y, st = ops.groupnorm(xin, gamma, beta, G, eps, relu=relu, out=out, return_stats=True)
         yd = _d(y)
-        ctx.save_for_backward(x, yd, st, gamma)
+        # (the ReLU mask is recomputed from x in the backward — no residual enters these layers — so y is not kept)
+        ctx.save_for_backward(x, None if GN_REMASK else yd, st, gamma, beta)
         ctx.cfg = (geom, G, eps, relu)
         return yd
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, st, gamma = ctx.saved_tensors
+        x, y, st, gamma, beta = ctx.saved_tensors
         geom, G, eps, relu = ctx.cfg
         dy = dy.contiguous()
         ga, ba = (_param_acc(ctx.gn.weight), _param_acc(ctx.gn.bias)) if ctx.gn is not None else (None, None)
         direct = ga is not None and ba is not None
-        dx, dgamma, dbeta = ops.groupnorm_backward(_wrap(dy, geom), _wrap(y, geom), _wrap(x, geom), st, gamma, G, eps,
-                                                   relu, dgamma_acc=ga[1] if direct else None,
-                                                   dbeta_acc=ba[1] if direct else None)
+        dx, dgamma, dbeta = ops.groupnorm_backward(_wrap(dy, geom), _wrap(y, geom) if y is not None else None, _wrap(x, geom), st,
+                                                   gamma, G, eps, relu, dgamma_acc=ga[1] if direct else None,
+                                                   dbeta_acc=ba[1] if direct else None, beta=beta)
         if direct:
             ga[0].fired()
             ba[0].fired()

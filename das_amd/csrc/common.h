@@ -95,6 +95,11 @@ __device__ __forceinline__ uint4 mask_vec<bf16_t>(unsigned b) {
                     ((b & 64) ? 0x3F80u : 0u) | ((b & 128) ? 0x3F800000u : 0u));
 }
 
+// GroupNorm's affine, written once so that the forward and the backward's recomputed ReLU mask round identically.
+__device__ __forceinline__ float gn_affine(float x, float mean, float rstd, float gamma, float beta) {
+  return __fmaf_rn((x - mean) * rstd, gamma, beta);
+}
+
 // Sum the [slots][n] per-workgroup slot partials into dst[n] (LDS), fixed order. All 16 loads of a value are in flight
 // together: a serial `a += src[k * n + i]` chain costs one L2 round trip per slot at the head of every workgroup
 // (16 us per launch measured on the BatchNorm apply passes). slots <= 64; ends with a workgroup barrier.

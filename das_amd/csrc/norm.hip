@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     Elem<T>::unpack(r, f);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-      const float o = (f[j] - mean[j]) * rstd[j] * ga[j] + be[j];
+      const float o = gn_affine(f[j], mean[j], rstd[j], ga[j], be[j]);
       f[j] = relu ? fmaxf(o, 0.f) : o;
     }
     return Elem<T>::pack(f);

@@ -42,7 +42,8 @@ template <typename T>
 __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                               const T* __restrict__ x, DasLevels lv, int C, int ps, int G,
                                                               int pix_per_block, const float* __restrict__ fstats,
-                                                              const float* __restrict__ gamma, float eps, int relu,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, int relu,
                                                               float* __restrict__ gsums, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta) {
   constexpr int EPV = Elem<T>::EPV, NT = GN_NT;
@@ -56,13 +57,16 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restric
   const float inv_n = 1.f / ((float)HW * (float)cpg);
   const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = NT / VC;
   if (pl < PL) {
-    float a[EPV], bb[EPV], mu[EPV], rs[EPV];
+    // relu without y: the mask is recomputed from x (y > 0 <=> gn_affine(x) > 0, the forward's own arithmetic) — y is not read
+    const bool remask = relu && !y;
+    float a[EPV], bb[EPV], mu[EPV], rs[EPV], ga[EPV], be[EPV];
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       const int g = (v * EPV + j) / cpg;
       const float m = fstats[((long long)seg * G + g) * 2] * inv_n;
       const float var = fmaxf(fstats[((long long)seg * G + g) * 2 + 1] * inv_n - m * m, 0.f);
       mu[j] = m; rs[j] = rsqrtf(var + eps); a[j] = 0.f; bb[j] = 0.f;
+      ga[j] = remask ? gamma[v * EPV + j] : 0.f; be[j] = remask ? beta[v * EPV + j] : 0.f;
     }
     const int p1 = min(p0 + pix_per_block, HW);
     const long long off = sg.row0 * ps + v * EPV;
@@ -70,7 +74,10 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restric
       float g[EPV], xx[EPV];
       Elem<T>::unpack(rg, g);
       Elem<T>::unpack(rx, xx);
-      if (relu) {
+      if (remask) {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) g[j] = gn_affine(xx[j], mu[j], rs[j], ga[j], be[j]) > 0.f ? g[j] : 0.f;
+      } else if (relu) {
         float o[EPV];
         Elem<T>::unpack(ry, o);
 #pragma unroll
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restric
         const long long o = off + (long long)(p + u * PL) * ps;
         rg[u] = *reinterpret_cast<const uint4*>(dy + o);
         rx[u] = *reinterpret_cast<const uint4*>(x + o);
-        ry[u] = relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0);
+        ry[u] = (relu && y) ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc(rg[u], rx[u], ry[u]);
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_reduce_kernel(const T* __restric
     for (; p < p1; p += PL) {
       const long long o = off + (long long)p * ps;
       acc(*reinterpret_cast<const uint4*>(dy + o), *reinterpret_cast<const uint4*>(x + o),
-          relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0));
+          (relu && y) ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0));
     }
     if (VC < 64 && 64 % VC == 0) {
       // the 64 / VC pixel lanes of a wave that share this channel vector: xor-shuffles, then one lane per vector stores the
@@ -139,7 +146,8 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_apply_kernel(const T* __restrict
                                                              int C, int ps, int G, int pix_per_block,
                                                              const float* __restrict__ fstats,
                                                              const float* __restrict__ gsums,
-                                                             const float* __restrict__ gamma, float eps, int relu) {
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int relu) {
   constexpr int EPV = Elem<T>::EPV, NT = GN_NT;
   const int seg = blockIdx.y;
   const GnSeg sg = gn_segment(lv, seg);
@@ -149,13 +157,14 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_apply_kernel(const T* __restrict
   const int v = threadIdx.x % VC, pl = threadIdx.x / VC, PL = NT / VC;
   if (pl >= PL) return;
   const float inv_n = 1.f / ((float)sg.HW * (float)cpg);
-  float mu[EPV], rs[EPV], ga[EPV], k1[EPV], k2[EPV];
+  const bool remask = relu && !y;
+  float mu[EPV], rs[EPV], ga[EPV], be[EPV], k1[EPV], k2[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) {
     const int c = v * EPV + j, gi = c / cpg;
     const float m = fstats[((long long)seg * G + gi) * 2] * inv_n;
     const float var = fmaxf(fstats[((long long)seg * G + gi) * 2 + 1] * inv_n - m * m, 0.f);
-    mu[j] = m; rs[j] = rsqrtf(var + eps); ga[j] = gamma[c];
+    mu[j] = m; rs[j] = rsqrtf(var + eps); ga[j] = gamma[c]; be[j] = remask ? beta[c] : 0.f;
     k1[j] = gsums[((long long)seg * G + gi) * 2] * inv_n;
     k2[j] = gsums[((long long)seg * G + gi) * 2 + 1] * inv_n;
   }
@@ -165,7 +174,10 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_apply_kernel(const T* __restrict
     float g[EPV], xx[EPV], o[EPV];
     Elem<T>::unpack(rg, g);
     Elem<T>::unpack(rx, xx);
-    if (relu) {
+    if (remask) {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) g[j] = gn_affine(xx[j], mu[j], rs[j], ga[j], be[j]) > 0.f ? g[j] : 0.f;
+    } else if (relu) {
       float yy[EPV];
       Elem<T>::unpack(ry, yy);
 #pragma unroll
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_apply_kernel(const T* __restrict
       const long long o = off + (long long)(p + u * PL) * ps;
       rg[u] = *reinterpret_cast<const uint4*>(dy + o);
       rx[u] = *reinterpret_cast<const uint4*>(x + o);
-      ry[u] = relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0);
+      ry[u] = (relu && y) ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) *reinterpret_cast<uint4*>(dx + off + (long long)(p + u * PL) * ps) = one(rg[u], rx[u], ry[u]);
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(GN_NT) void gn_bwd_apply_kernel(const T* __restrict
   for (; p < p1; p += PL) {
     const long long o = off + (long long)p * ps;
     *reinterpret_cast<uint4*>(dx + o) = one(*reinterpret_cast<const uint4*>(dy + o), *reinterpret_cast<const uint4*>(x + o),
-                                            relu ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0));
+                                            (relu && y) ? *reinterpret_cast<const uint4*>(y + o) : make_uint4(0, 0, 0, 0));
   }
 }
 
@@ -423,10 +435,10 @@ __global__ void nearest_bwd_kernel(const T* __restrict__ dy, T* __restrict__ db,
 
 static int groupnorm_backward_impl(const void* dy, const void* y, const void* x, void* dx, int dtype,
                                    const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
-                                   const float* gamma, float eps, int relu, float* gsums_ws, float* dgamma,
-                                   float* dbeta, bool accumulate, void* stream) {
+                                   const float* gamma, const float* beta, float eps, int relu, float* gsums_ws,
+                                   float* dgamma, float* dbeta, bool accumulate, void* stream) {
   if (!dy || !x || !dx || !fwd_stats || !gamma || !gsums_ws || !dgamma || !dbeta || !lv_valid(lv)) return DAS_ERR_ARG;
-  if (C % 8 || C % G || pix_stride % 8 || C > 2048 || (relu && !y)) return DAS_ERR_ARG;
+  if (C % 8 || C % G || pix_stride % 8 || C > 2048 || (relu && !y && !beta)) return DAS_ERR_ARG;
   const int epv = dtype == DAS_BF16 ? 8 : 4;
   if ((C / epv) > GN_NT) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -453,10 +465,10 @@ static int groupnorm_backward_impl(const void* dy, const void* y, const void* x,
                                                (int)lds) != hipSuccess)
       return DAS_ERR_LAUNCH;
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3(chunks, nseg), dim3(GN_NT), lds, s, (const T*)dy,
-                       (const T*)y, (const T*)x, *lv, C, pix_stride, G, ppb, fwd_stats, gamma, eps, relu, gsums_ws,
+                       (const T*)y, (const T*)x, *lv, C, pix_stride, G, ppb, fwd_stats, gamma, beta, eps, relu, gsums_ws,
                        dgamma, dbeta);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks, nseg), dim3(GN_NT), 0, s, (const T*)dy, (const T*)y,
-                       (const T*)x, (T*)dx, *lv, C, pix_stride, G, ppb, fwd_stats, gsums_ws, gamma, eps, relu);
+                       (const T*)x, (T*)dx, *lv, C, pix_stride, G, ppb, fwd_stats, gsums_ws, gamma, beta, eps, relu);
   });
   DAS_CHECK_LAUNCH();
   return DAS_OK;
@@ -464,17 +476,17 @@ static int groupnorm_backward_impl(const void* dy, const void* y, const void* x,
 
 extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void* x, void* dx, int dtype,
                                       const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
-                                      const float* gamma, float eps, int relu, float* gsums_ws, float* dgamma,
-                                      float* dbeta, void* stream) {
-  return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, eps, relu, gsums_ws, dgamma,
-                                 dbeta, false, stream);
+                                      const float* gamma, const float* beta, float eps, int relu, float* gsums_ws,
+                                      float* dgamma, float* dbeta, void* stream) {
+  return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, beta, eps, relu, gsums_ws,
+                                 dgamma, dbeta, false, stream);
 }
 extern "C" int das_groupnorm_backward_acc(const void* dy, const void* y, const void* x, void* dx, int dtype,
                                           const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
-                                          const float* gamma, float eps, int relu, float* gsums_ws, float* dgamma,
-                                          float* dbeta, void* stream) {
-  return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, eps, relu, gsums_ws, dgamma,
-                                 dbeta, true, stream);
+                                          const float* gamma, const float* beta, float eps, int relu, float* gsums_ws,
+                                          float* dgamma, float* dbeta, void* stream) {
+  return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, beta, eps, relu, gsums_ws,
+                                 dgamma, dbeta, true, stream);
 }
 
 extern "C" int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W,

@@ -700,9 +700,11 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     return y, mean, invstd
 
 
-def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True, dgamma_acc=None, dbeta_acc=None):
+def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True, dgamma_acc=None, dbeta_acc=None, beta=None):
     """Returns dx (same container as x), dgamma, dbeta. dgamma_acc / dbeta_acc (both): f32[C] slices of the flat gradient
-    buffer the parameter gradients are ADDED to instead (dgamma, dbeta come back as None)."""
+    buffer the parameter gradients are ADDED to instead (dgamma, dbeta come back as None). y=None with relu (needs beta):
+    the ReLU mask is recomputed from x, y is not read."""
+    assert not (relu and y is None and beta is None)
     _need_gpu(dy, x)
     xd, dyd = _data(x), _data(dy)
     yd = _data(y) if y is not None else None
@@ -715,14 +717,14 @@ def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True, dgamm
     if dgamma_acc is not None and dbeta_acc is not None:
         gs = torch.empty(ngs, dtype=torch.float32, device=xd.device)
         _lib.check(_lib.load().das_groupnorm_backward_acc(_ptr(dyd), _ptr(yd), _ptr(xd), _ptr(_data(dx)), _DT[xd.dtype],
-                                                          C.byref(lv), Cc, _ps(x), G, _ptr(fwd_stats), _ptr(gamma), eps,
+                                                          C.byref(lv), Cc, _ps(x), G, _ptr(fwd_stats), _ptr(gamma), _ptr(beta), eps,
                                                           int(relu), _ptr(gs), _ptr(dgamma_acc), _ptr(dbeta_acc), _stream()),
                    'das_groupnorm_backward_acc')
         return dx, None, None
     acc = torch.empty(ngs + 2 * Cc, dtype=torch.float32, device=xd.device)
     gs, dgamma, dbeta = acc[:ngs], acc[ngs:ngs + Cc], acc[ngs + Cc:]
     _lib.check(_lib.load().das_groupnorm_backward(_ptr(dyd), _ptr(yd), _ptr(xd), _ptr(_data(dx)), _DT[xd.dtype],
-                                                  C.byref(lv), Cc, _ps(x), G, _ptr(fwd_stats), _ptr(gamma), eps,
+                                                  C.byref(lv), Cc, _ps(x), G, _ptr(fwd_stats), _ptr(gamma), _ptr(beta), eps,
                                                   int(relu), _ptr(gs), _ptr(dgamma), _ptr(dbeta), _stream()),
                'das_groupnorm_backward')
     return dx, dgamma, dbeta

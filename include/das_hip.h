@@ -217,15 +217,17 @@ int das_pack_conv_weights(const float* flat_src, void* fwd_dst, void* dgrad_dst,
 
 /* GroupNorm(+ReLU) backward over ragged rows. x = pre-norm input saved by forward, y = forward output
  * (ReLU mask), fwd_stats = the forward's stats workspace (sum, sumsq per level/image/group).
- * gsums_ws f32[num_levels*B*G*2], dgamma/dbeta f32[C]: all zeroed by the call. */
+ * gsums_ws f32[num_levels*B*G*2], dgamma/dbeta f32[C]: all zeroed by the call.
+ * y == NULL with relu: the mask is recomputed from x with the forward's own arithmetic (needs beta) and neither pass
+ * reads y — no residual enters a GroupNorm layer of the head, so y > 0 <=> its affine > 0. */
 int das_groupnorm_backward(const void* dy, const void* y, const void* x, void* dx, int dtype, const DasLevels* lv,
-                           int C, int pix_stride, int G, const float* fwd_stats, const float* gamma, float eps,
-                           int relu, float* gsums_ws, float* dgamma, float* dbeta, void* stream);
+                           int C, int pix_stride, int G, const float* fwd_stats, const float* gamma, const float* beta,
+                           float eps, int relu, float* gsums_ws, float* dgamma, float* dbeta, void* stream);
 /* The same with dgamma / dbeta ACCUMULATED into (parameter-gradient slices of the optimizer's flat buffer); only
  * gsums_ws is zeroed by the call. */
 int das_groupnorm_backward_acc(const void* dy, const void* y, const void* x, void* dx, int dtype, const DasLevels* lv,
-                               int C, int pix_stride, int G, const float* fwd_stats, const float* gamma, float eps,
-                               int relu, float* gsums_ws, float* dgamma, float* dbeta, void* stream);
+                               int C, int pix_stride, int G, const float* fwd_stats, const float* gamma, const float* beta,
+                               float eps, int relu, float* gsums_ws, float* dgamma, float* dbeta, void* stream);
 /* Backward of das_maxpool3x3s2 (gradient goes to the first maximum in scan order, as torch does),
  * das_upsample_bilinear_ac and the upsampled operand of das_add_upsample_nearest. */
 int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W, int C,
