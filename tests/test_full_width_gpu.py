@@ -252,8 +252,19 @@ def test_four_stage_full_width_eval_f32_maps_and_decode_match_the_oracle():
                         metas, J, cfg['bbox_head']['strides'], cfg['test_cfg'], return_index=True)
     oi = out[0]['index'].cpu().numpy()
     assert len(oi) > 20
-    np.testing.assert_array_equal(oi, same[0]['index'].numpy())
-    np.testing.assert_allclose(out[0]['poses'].cpu().numpy(), same[0]['poses'].numpy(), rtol=2e-3, atol=2e-2)
+    si, sc = same[0]['index'].numpy(), np.asarray(same[0]['scores'], np.float64)
+    hp, sp = out[0]['poses'].cpu().numpy(), same[0]['poses'].numpy()
+    if not np.array_equal(oi, si):
+        # The two decoders round sigmoid differently in the last bit; on this smooth score map a pair of candidates can sit
+        # closer than that. Such a pair may swap places — nothing else may differ: the same kept set, and every displaced
+        # candidate's oracle score within 1e-6 (relative) of the score of the candidate that took its place.
+        assert sorted(oi.tolist()) == sorted(si.tolist()), (oi, si)
+        pos = {int(v): k for k, v in enumerate(si)}
+        for k in np.nonzero(oi != si)[0]:
+            other = pos[int(oi[k])]
+            assert abs(sc[k] - sc[other]) <= 1e-6 * abs(sc[k]), (k, other, sc[k], sc[other])
+        hp = hp[[int(np.nonzero(oi == v)[0][0]) for v in si]]
+    np.testing.assert_allclose(hp, sp, rtol=2e-3, atol=2e-2)
     ri = ref[0]['index'].numpy()
     assert len(set(oi.tolist()) & set(ri.tolist())) >= 0.9 * len(ri), (len(set(oi.tolist()) & set(ri.tolist())), len(ri))
 
