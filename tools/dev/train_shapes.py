@@ -10,7 +10,9 @@ from das_amd.optim import FlatSGD, train_iteration
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 from das_amd import autograd as _ag
-_ag.WGRAD_SIDE_STREAM = False   # kernels one at a time: per-shape times are not stretched by overlapped weight gradients
+_ag.WGRAD_SIDE_STREAM = False
+if os.environ.get('WGB'):
+    _ag.WGRAD_BATCH = int(os.environ['WGB'])   # (dev: unbatched weight gradients -> per-layer times)   # kernels one at a time: per-shape times are not stretched by overlapped weight gradients
 dev = torch.device('cuda', 0)
 model = bench.build_model(dev, num_stages=4, train=True)
 ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=B, seed=0)
