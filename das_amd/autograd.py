@@ -234,6 +234,10 @@ def _check_equal_rows(rows):
                            f'{rows}): pad the batches of all ranks to one size (Pad(size=...)) or use norm_cfg type BN')
 
 
+# A gradient that only has to be masked by recorded bits before it is added as a residual is masked inside the adding
+# data-gradient epilogue instead of being written masked first; switch for A/B runs and tests
+RES_BITS = True
+
 # The ReLU mask of a BatchNorm + residual + ReLU layer recorded as bits by the forward apply pass (1/16 of the output) and
 # read by the backward instead of the output itself (ops.relu_bits_buffer); switch for A/B runs and tests
 MASK_BITS = True
@@ -716,7 +720,13 @@ class BottleneckChainFn(Function):
             w1, g1, b1, w2, g2, b2, w3, g3, b3 = params[po:po + 9]
             # ---- bn3 (+ identity, ReLU)
             if carry_dz is None:
-                draw3, dz3 = classic_bn(blk.bn3, g3, b3, po + 7, carry_dy, y3, raw3, m3, i3, True, True, bits=bits3)
+                # with the mask as bits the identity branch's gradient dY * mask need not be written: the conv1 data gradient
+                # below takes (dY, bits) as its residual and masks on the fly (DasConvDesc.residual_mask_bits)
+                lazy = (RES_BITS and bits3 is not None and bi > 0 and blk.downsample is None and _sync_world(blk.bn3) == 1
+                        and blk.conv1.stride[0] == 1)
+                draw3, dz3 = classic_bn(blk.bn3, g3, b3, po + 7, carry_dy, y3, raw3, m3, i3, True, not lazy, bits=bits3)
+                if lazy:
+                    dz3 = (carry_dy, bits3)
             else:
                 dz3, sums3 = carry_dz
                 draw3 = finish_bn(blk.bn3, g3, b3, po + 7, dz3, raw3, m3, i3, sums3)

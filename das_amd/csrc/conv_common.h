@@ -50,6 +50,8 @@ struct ConvP {
   const char* bnb_y;     // (M, Cout) post-ReLU output: mask = y > 0 (needed when a residual entered before the ReLU);
                          // nullptr with bnb_relu: mask recomputed as bn_affine(raw) > 0
   const unsigned char* bnb_bits;   // instead of bnb_y: its ReLU mask as one byte per 16-byte vector (common.h: relu_bits)
+  const unsigned char* res_bits;   // (with bnb_raw) the residual enters masked by these bits: res * mask — a gradient whose
+                                   // ReLU mask was recorded as bits, so that the masked copy never has to be written
   const float* bnb_mean;
   const float* bnb_invstd;
   const float* bnb_gamma;
@@ -224,6 +226,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   const OT* bxg = reinterpret_cast<const OT*>(p.bnb_raw);   // fused BatchNorm-backward reduction (see ConvP)
   const OT* byg = reinterpret_cast<const OT*>(p.bnb_y);
   const unsigned char* bbits = p.bnb_bits;
+  const unsigned char* rbits = bxg ? p.res_bits : nullptr;
   if (n < p.Cout) {
     constexpr int ITERS = BMT / RP;  // rows per thread, processed CH at a time
     constexpr int CH = ITERS % 4 == 0 ? 4 : ITERS % 3 == 0 ? 3 : ITERS % 2 == 0 ? 2 : 1;
@@ -243,6 +246,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
       // the residual rows of a chunk are requested together, ahead of the LDS reads, so that their
       // memory latency overlaps instead of adding up row by row
       uint4 rv[CH], xv[CH], yv[CH];
+      unsigned rmb[CH];
       long long om[CH];
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
@@ -254,7 +258,11 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
         for (int u = 0; u < CH; ++u) {
           const int m = tile_row_m<T2D>(p, m0, r0 + (it0 + u) * RP);
           rv[u] = make_uint4(0, 0, 0, 0);
-          if (m < p.M) rv[u] = *reinterpret_cast<const uint4*>(rg + om[u] * p.rps + n);
+          rmb[u] = 0xff;
+          if (m < p.M) {
+            rv[u] = *reinterpret_cast<const uint4*>(rg + om[u] * p.rps + n);
+            if (rbits) rmb[u] = rbits[(om[u] * p.rps + n) / EPVO];
+          }
         }
       }
       if (bxg) {
@@ -287,6 +295,10 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
         if (rg) {
           float r[EPVO];
           Elem<OT>::unpack(rv[u], r);
+          if (rbits) {
+#pragma unroll
+            for (int j = 0; j < EPVO; ++j) r[j] = (rmb[u] >> j & 1u) ? r[j] : 0.f;
+          }
 #pragma unroll
           for (int j = 0; j < EPVO; ++j) f[j] += r[j];
         }

@@ -892,7 +892,7 @@ bool try_launch_pt3(const ConvP& p0, int rows, hipStream_t s) {
     // (mode 3 — three operand tensors per pixel block — is left to the one-tile kernels: on hardware its first y-mask
     // vector of the trailing wave group came back stale although every load had been waited for with vmcnt(0) and the
     // ISA shows no write to those registers in between; not understood, tools/dev/pt3_debug.py reproduces it)
-    if (mode == 3) return false;
+    if (mode == 3 || p.res_bits) return false;
     auto go = [&](auto kern) -> bool {
       static bool attr = false;   // (one per kernel type)
       if (!attr) {
@@ -1177,6 +1177,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
     const T* bx = reinterpret_cast<const T*>(p.bnb_raw);
     const T* by = MODE == 3 ? reinterpret_cast<const T*>(p.bnb_y) : nullptr;
     const unsigned char* bb = MODE == 3 ? p.bnb_bits : nullptr;   // (the mask as a byte per vector instead of y)
+    const unsigned char* rb = rgb ? p.res_bits : nullptr;        // (the residual's own mask: res * mask)
     float mu[8], is[8], ga[8], be[8];
     if constexpr (MODE == 4) {
 #pragma unroll
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
 #pragma unroll
       for (int h0 = 0; h0 < PB; h0 += HB) {
         v4i_t lr[HB], lx[HB], ly[HB];
-        int lb[HB];
+        int lb[HB], lrb[HB];
 #pragma unroll
         for (int h = 0; h < HB; ++h) {
           long long m = (long long)t * TM + wm * (TM / WM) + (h0 + h) * 16 + q;
@@ -1204,6 +1205,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
           if (by) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ly[h]) : "v"(by + eo) : "memory");
           if (bb) asm volatile("global_load_ubyte %0, %1, off" : "=v"(lb[h]) : "v"(bb + eo / 8) : "memory");
           if (rgb) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lr[h]) : "v"(rgb + m * p.rps + (cok ? c8 : 0)) : "memory");
+          if (rb) asm volatile("global_load_ubyte %0, %1, off" : "=v"(lrb[h]) : "v"(rb + (m * p.rps + (cok ? c8 : 0)) / 8) : "memory");
         }
         f32x4_t acc0[HB], acc1[HB];
 #pragma unroll
@@ -1223,7 +1225,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
         }
 #pragma unroll
         for (int h = 0; h < HB; ++h)   // (the operands name the destination registers: they stay allocated until here)
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[h]), "+v"(ly[h]), "+v"(lr[h]), "+v"(lb[h])::"memory");
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[h]), "+v"(ly[h]), "+v"(lr[h]), "+v"(lb[h]), "+v"(lrb[h])::"memory");
 #pragma unroll
         for (int h = 0; h < HB; ++h) {
           const long long m = (long long)t * TM + wm * (TM / WM) + (h0 + h) * 16 + q;
@@ -1236,6 +1238,10 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
             if (rgb) {
               float r[8];
               Elem<T>::unpack(__builtin_bit_cast(uint4, lr[h]), r);
+              if (rb) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = ((unsigned)lrb[h] >> j & 1u) ? r[j] : 0.f;
+              }
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] += r[j];
             }
@@ -1594,6 +1600,8 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   }
   p.bnb_raw = (const char*)d->bnb_raw; p.bnb_y = (const char*)d->bnb_y;
   p.bnb_bits = p.bnb_y ? nullptr : (const unsigned char*)d->bnb_mask_bits;
+  p.res_bits = (p.bnb_raw && d->residual) ? (const unsigned char*)d->residual_mask_bits : nullptr;
+  if (d->residual_mask_bits && !p.res_bits) return DAS_ERR_ARG;   // (only the fused BatchNorm-backward launches mask their residual)
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_gamma = d->bnb_gamma; p.bnb_beta = d->bnb_beta;
   p.bnb_relu = d->bnb_relu; p.bnb_ps = d->bnb_pix_stride;
   if (p.bnb_raw) {   // fused BatchNorm-backward reduction: see DasConvDesc

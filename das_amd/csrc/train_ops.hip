@@ -208,7 +208,7 @@ __device__ __forceinline__ void wgrad_load_unit(const WgradSched& g, const Wgrad
   p.M = o.M; p.K = o.K; p.HoWo = o.HoWo; p.ntiles = p.nblocks = 0; p.m_base = 0; p.xbytes = o.xbytes; p.nlev = o.nlev; p.B = o.B;
 #pragma unroll
   for (int l = 0; l < MAXLV; ++l) { p.lvH[l] = o.lvH[l]; p.lvW[l] = o.lvW[l]; p.lvStart[l] = o.lvStart[l]; }
-  p.bnb_raw = p.bnb_y = nullptr; p.bnb_bits = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;
+  p.bnb_raw = p.bnb_y = nullptr; p.bnb_bits = nullptr; p.res_bits = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;
 }
 // accumulators of a whole reduction -> dW (row-major Cout x K), same element map as wgrad_reduce_kernel. A wave tile
 // inside the result (the common case, wave-uniform test) runs without per-element tests: the old values of an

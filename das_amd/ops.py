@@ -246,6 +246,7 @@ def conv2d_dgrad(dy, w_dgrad, KH, KW, stride, pad, in_hw, residual=None, bn_bwd=
         assert accumulate is None
         return conv2d(dy, w_dgrad, KH, KW, 1, KH - 1 - pad, residual=residual, bn_bwd=bn_bwd, stats=stats)
     if stride == 2 and KH == KW and s2_decomposable(KH, pad):
+        assert not isinstance(residual, tuple), 'masked residuals: stride-1 data gradients only'
         cls = _s2_classes(KH, pad)
         every = all(n for _, n, _ in cls)
         if every or (bn_bwd is None and stats is None):
@@ -515,6 +516,12 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
     _need_gpu(x, w)
     lib = _lib.load()
     ragged = isinstance(x, Ragged)
+    res_bits = None
+    if isinstance(residual, tuple):    # (tensor, bits): the residual enters masked by recorded ReLU bits (bn_bwd launches only)
+        residual, res_bits = residual
+        assert bn_bwd is not None and res_bits.dtype == torch.uint8 and \
+            res_bits.numel() * 16 == residual.numel() * residual.element_size() and residual.is_contiguous()
+        _need_gpu(res_bits)
     xd = _data(x)
     Cin = xd.shape[-1]
     Cout = w.shape[0]
@@ -571,6 +578,8 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
         if b.bits is not None:
             assert b.bits.dtype == torch.uint8 and b.bits.numel() * 16 == b.raw.numel() * b.raw.element_size()
             d.bnb_mask_bits = b.bits.data_ptr()
+        if res_bits is not None:
+            d.residual_mask_bits = res_bits.data_ptr()
         _need_gpu(b.raw, b.y, b.mean, b.invstd, b.gamma, b.beta, b.bits)
     if ragged:
         for l, (h, w_) in enumerate(x.sizes):

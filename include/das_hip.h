@@ -129,6 +129,11 @@ typedef struct {
    * (bit j = element j > 0; index = element offset / elements per vector, y contiguous with pixel stride
    * bnb_pix_stride) as das_bn_train_apply / das_bn_dual_apply / das_upmerge_forward record it: 1/16 of y's bytes. */
   const void* bnb_mask_bits;
+  /* With bnb_raw and residual: the residual enters as residual * mask, the mask given as bits in the same layout (one byte
+   * per 16-byte vector of the residual tensor). For a residual that is the gradient of a BatchNorm + identity + ReLU layer's
+   * output: the identity branch receives dY * (y > 0), and with the bits recorded by the forward that masked tensor never
+   * has to be written by the layer's backward (das_bn_train_backward with dres == NULL). */
+  const void* residual_mask_bits;
 } DasConvDesc;
 int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream);
 

@@ -114,6 +114,22 @@ def test_dgrad_epilogue_reduces_bn_backward(case, dtype):
         assert torch.equal(dz_b, dz)
         np.testing.assert_allclose(sums_b.view(slots, -1).sum(0).cpu().numpy() / rows, folded.numpy() / rows, rtol=1e-5, atol=1e-6)
 
+    if with_res:
+        # a residual that enters masked by recorded bits (DasConvDesc.residual_mask_bits) == the same residual masked beforehand
+        rd = nhwc(res, dtype)
+        per = 16 // rd.element_size()
+        wts = (2 ** torch.arange(per, device=DEV)).to(torch.int32)
+        keep = torch.rand(rd.numel(), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).reshape(rd.shape) > 0.4
+        rbits = (keep.reshape(-1, per).to(torch.int32) * wts).sum(1).to(torch.uint8)
+        outs = []
+        for resarg in ((rd * keep).contiguous(), (rd, rbits)):
+            sm = torch.zeros_like(sums)
+            with o.tuning(**FORCE[kernel]):
+                outs.append(o.conv2d(nhwc(dy, dtype), o.pack_weight(wf.to(DEV), dtype), k, k, 1, k // 2, residual=resarg,
+                                     bn_bwd=bnb, stats=sm))
+                assert o.last_kernel() == kernel, o.last_kernel()
+        assert torch.equal(outs[0], outs[1])
+
     # the apply pass on (dZ, sums) equals torch autograd through BatchNorm(train)+ReLU given the same dZ
     draw = o.bn_backward_apply(dz, bnb.raw, bnb.mean, bnb.invstd, bnb.gamma, sums)
     s1, s2 = s_self[:Cout], s_self[Cout:]
