@@ -239,3 +239,31 @@ def test_multi_rank_result_collection_keeps_the_tail(n, world):
     # a sampler padded the reference's way (indices repeated up to a multiple of world) is trimmed to the dataset size
     padded = [[dict(idx=i % max(n, 1)) for i in range(r, -(-n // world) * world, world)] for r in range(world)] if n else parts
     assert [r['idx'] for r in collect_results(padded, n)] == list(range(n))
+
+
+@pytest.mark.parametrize('H,Ho', [(8, 16), (13, 26), (5, 9), (1, 4), (7, 7), (6, 15), (26, 52)])
+def test_upsample_adjoint_tables_match_torch_interpolate(H, Ho):
+    """ops._upsample_tables (host side of das_upsample_stats_lowres / das_upmerge_backward_lowres): the three diagonals of
+    U^T U and U^T 1 for U = bilinear upsampling with align_corners along one axis, against the matrix torch's interpolation
+    defines (F.interpolate of the identity, f64): U^T U is tridiagonal, and with both axes the tables reproduce
+    sum upsample(z) and sum upsample(z)^2 from z alone."""
+    import torch.nn.functional as F
+    from das_amd import ops
+    a, w = ops._upsample_tables(H, Ho, 'cpu')
+    U = F.interpolate(torch.eye(H, dtype=torch.float64)[None], size=Ho, mode='linear', align_corners=True)[0].T   # (Ho, H)
+    A = U.T @ U
+    assert float((A - torch.triu(torch.tril(A, 1), -1)).abs().max()) < 1e-12
+    for d in (-1, 0, 1):
+        idx = torch.arange(max(0, -d), min(H, H - d))
+        assert torch.allclose(a[idx, d + 1].double(), A[idx, idx + d], atol=2e-6), d
+    assert torch.allclose(w.double(), U.sum(0), atol=2e-6)
+    # two axes: statistics of the upsampled tensor from the low resolution
+    W, Wo = 5, 11
+    aw, ww = ops._upsample_tables(W, Wo, 'cpu')
+    z = cases.randn(9, H, W).double()
+    up = F.interpolate(z[None, None], size=(Ho, Wo), mode='bilinear', align_corners=True)[0, 0]
+    zp = F.pad(z, (1, 1, 1, 1))
+    G = sum(a[:, dh + 1].double()[:, None] * aw[:, dw + 1].double()[None, :] * zp[1 + dh:1 + dh + H, 1 + dw:1 + dw + W]
+            for dh in (-1, 0, 1) for dw in (-1, 0, 1))
+    assert abs(float((w.double()[:, None] * ww.double()[None, :] * z).sum() - up.sum())) < 1e-5 * max(1.0, float(up.abs().sum()))
+    assert abs(float((z * G).sum() - (up * up).sum())) < 1e-5 * float((up * up).sum())
