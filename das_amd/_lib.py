@@ -115,7 +115,7 @@ SIGNATURES = {
     'das_upmerge_backward_lowres': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]),
     'das_bn_dual_apply': (i32, [vp, vp, vp, i32, i64, i32, vp, i32, vp, vp]),
     'das_bn_relu_add3_forward': (i32, [vp, vp, vp, vp, i32, i64, i32, vp, vp]),
-    'das_bn_relu_add3_backward': (i32, [vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp]),
+    'das_bn_relu_add3_backward': (i32, [vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, i32, i64, vp, vp, vp, vp, i32, vp]),
     'das_maxpool3x3s2_argmax': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_maxpool3x3s2_backward_argmax': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_upsample_bilinear_ac': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

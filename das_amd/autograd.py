@@ -271,15 +271,21 @@ def _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual, bits=None):
 
 def _conv_stats_forward(x, conv, bn, gamma, beta):
     """conv (BatchNorm statistics in its epilogue) -> finalize only (mean / invstd published, running buffers advanced): the
-    normalisation is left to a consumer. One rank's statistics only. Returns raw, mean, invstd."""
-    from .nn import bn_stats_buffer, packed_weight
+    normalisation is left to a consumer. SyncBN: the statistics are summed over the ranks first. Returns raw, mean, invstd."""
+    from .nn import bn_stats_buffer, packed_weight, sync_stats
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
     stats = bn_stats_buffer(x, w.shape[0])
     raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
+    world, stat_count = _sync_world(bn), 0
+    if world > 1:
+        rows = raw.numel() // raw.shape[-1]
+        _check_equal_rows(rows)
+        stats = sync_stats(stats, w.shape[0], _all_reduce)
+        stat_count = rows * world
     _, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var,
                                          bn.momentum if bn.momentum is not None else 0.1, bn.eps,
-                                         num_batches_tracked=bn.num_batches_tracked, finalize_only=True)
+                                         num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count, finalize_only=True)
     bn.__dict__.pop('_das_cache', None)
     return raw, mean, invstd
 
@@ -408,15 +414,8 @@ class ConvStatsFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, conv, bn, skip_through):
-        from .nn import bn_stats_buffer, packed_weight
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
-        stats = bn_stats_buffer(x, w.shape[0])
-        raw = ops.conv2d(x, w, k, k, s, p, stats=stats)
-        _, mean, invstd = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                             bn.momentum if bn.momentum is not None else 0.1, bn.eps,
-                                             num_batches_tracked=bn.num_batches_tracked, finalize_only=True)
-        bn.__dict__.pop('_das_cache', None)
+        raw, mean, invstd = _conv_stats_forward(x, conv, bn, bn.weight, bn.bias)   # (SyncBN: statistics of all ranks)
         ctx.save_for_backward(x)
         ctx.cfg = (k, s, p, conv)
         ctx.mark_non_differentiable(mean, invstd)
@@ -461,14 +460,24 @@ class BnReluAdd3Fn(Function):
         g = g.contiguous()
         acc = [_param_acc(p) for p in (bn1.weight, bn1.bias, bn2.weight, bn2.bias)]
         direct = all(a is not None for a in acc)
-        d1, d2, sums = ops.bn_relu_add3_backward(g, raw1, (mean1, invstd1, g1, b1), raw2, (mean2, invstd2, g2, b2),
-                                                 acc=tuple(a[1] for a in acc) if direct else None)
+        world = max(_sync_world(bn1), _sync_world(bn2))
+        Cc = raw1.shape[-1]
+        if world > 1:
+            # SyncBN: reduce, sum over the ranks, apply; the parameter gradients are this rank's sums (the gradient
+            # all-reduce adds the ranks' contributions)
+            d1, d2, sums = ops.bn_relu_add3_backward(g, raw1, (mean1, invstd1, g1, b1), raw2, (mean2, invstd2, g2, b2),
+                                                     all_reduce=_all_reduce, world=world)
+            if direct:
+                for a, i in zip(acc, (1, 0, 3, 2)):      # acc order: dgamma1, dbeta1, dgamma2, dbeta2
+                    a[1].add_(sums[i * Cc:(i + 1) * Cc])
+        else:
+            d1, d2, sums = ops.bn_relu_add3_backward(g, raw1, (mean1, invstd1, g1, b1), raw2, (mean2, invstd2, g2, b2),
+                                                     acc=tuple(a[1] for a in acc) if direct else None)
         if direct:
             for a in acc:
                 a[0].fired()
             db1 = dg1 = db2 = dg2 = None
         else:
-            Cc = raw1.shape[-1]
             db1, dg1, db2, dg2 = (sums[i * Cc:(i + 1) * Cc].clone() for i in range(4))
         return g, d1, None, None, dg1, db1, d2, None, None, dg2, db2, None, None
 
@@ -491,22 +500,30 @@ class UpMergeTrainFn(Function):
         cout = wp1.shape[0]
         stats1 = bn_stats_buffer(x, cout)
         raw1 = ops.conv2d(x, wp1, 1, 1, 1, 0, stats=stats1)
-        _, mean1, invstd1 = ops.bn_train_apply(raw1, stats1, g1, b1, bn1.running_mean, bn1.running_var,
-                                               bn1.momentum if bn1.momentum is not None else 0.1, bn1.eps,
-                                               num_batches_tracked=bn1.num_batches_tracked, finalize_only=True)
         z = ops.conv2d(up_x, packed_weight(c2, up_x.dtype, cin_pad=up_x.shape[-1]), 1, 1, 1, 0)
         stats2 = bn_stats_buffer_rows(z.numel() // cout, cout, x.device)
         ops.upsample_stats_lowres(z, Ho, Wo, stats2)
+        world = max(_sync_world(bn1), _sync_world(bn2))
+        if world > 1:   # SyncBN: both layers' statistics over all ranks' pixels, ONE collective for the two
+            _check_equal_rows(rows)
+            both = torch.cat([stats1.view(-1, 2 * cout).sum(0), stats2.view(-1, 2 * cout).sum(0)])
+            _all_reduce(both)
+            stats1, stats2 = both[:2 * cout], both[2 * cout:]
+        _, mean1, invstd1 = ops.bn_train_apply(raw1, stats1, g1, b1, bn1.running_mean, bn1.running_var,
+                                               bn1.momentum if bn1.momentum is not None else 0.1, bn1.eps,
+                                               num_batches_tracked=bn1.num_batches_tracked, stat_count=rows * world,
+                                               finalize_only=True)
         _, mean2, invstd2 = ops.bn_train_apply(z, stats2, g2, b2, bn2.running_mean, bn2.running_var,
                                                bn2.momentum if bn2.momentum is not None else 0.1, bn2.eps,
-                                               num_batches_tracked=bn2.num_batches_tracked, stat_count=rows, finalize_only=True)
+                                               num_batches_tracked=bn2.num_batches_tracked, stat_count=rows * world,
+                                               finalize_only=True)
         bn1.__dict__.pop('_das_cache', None)
         bn2.__dict__.pop('_das_cache', None)
         mask = ops.relu_bits_buffer(raw1) if MASK_BITS else None
         out = ops.upmerge_forward(raw1, z, (mean1, invstd1, g1, b1), (mean2, invstd2, g2, b2), bits_out=mask)
         ctx.save_for_backward(x, up_x, raw1, z, out if mask is None else None, mean1, invstd1, mean2, invstd2, g1, g2, mask)
         ctx.mods = (c1, bn1, c2, bn2)
-        ctx.skip_through = skip_through
+        ctx.skip_through, ctx.world = skip_through, world
         return (out, x) if skip_through else out
 
     @staticmethod
@@ -519,21 +536,32 @@ class UpMergeTrainFn(Function):
         dzm, sums = ops.upmerge_backward_reduce(dy.contiguous(), out, raw1, z, mean1, invstd1, mean2, invstd2, bits=mask)
         acc = [_param_acc(p) for p in (bn1.weight, bn1.bias, bn2.weight, bn2.bias)]
         direct = all(a is not None for a in acc)
+        world, local = ctx.world, sums
+        if world > 1:
+            # SyncBN: the apply passes need the sums over all ranks' rows; the parameter gradients stay this rank's sums
+            sums = local.clone()
+            _all_reduce(sums)
+            if direct:
+                acc[0][1].add_(local[Cc:2 * Cc]); acc[1][1].add_(local[:Cc])
+                acc[2][1].add_(local[2 * Cc:]); acc[3][1].add_(local[:Cc])
+        kernel_acc = direct and world == 1
         # BatchNorm 1: the apply pass every other layer uses (dZ, raw1 -> d raw1); sums[:2C] is its [sum dZ | sum dZ xhat]
         draw1 = ops.bn_backward_apply(dzm, raw1, mean1, invstd1, g1, sums[:2 * Cc],
-                                      dgamma_acc=acc[0][1] if direct else None, dbeta_acc=acc[1][1] if direct else None)
+                                      dgamma_acc=acc[0][1] if kernel_acc else None, dbeta_acc=acc[1][1] if kernel_acc else None,
+                                      stat_rows=rows * world)
         dw1 = _wgrad(x, draw1, c1.weight, 1, 1, 0) if ctx.needs_input_grad[2] else None
         # BatchNorm 2 + upsampling: d raw2 is never formed; dz = upsample^T(d raw2) from upsample^T(dZ) and low-resolution terms
         P = ops.upsample_bilinear_ac_backward(dzm, z.shape[1], z.shape[2])
-        dz = ops.upmerge_backward_lowres(P, z, raw1.shape[1], raw1.shape[2], sums, g2, mean2, invstd2, rows,
-                                         dgamma2_acc=acc[2][1] if direct else None, dbeta2_acc=acc[3][1] if direct else None)
+        dz = ops.upmerge_backward_lowres(P, z, raw1.shape[1], raw1.shape[2], sums, g2, mean2, invstd2, rows * world,
+                                         dgamma2_acc=acc[2][1] if kernel_acc else None,
+                                         dbeta2_acc=acc[3][1] if kernel_acc else None)
         dw2 = _wgrad(up_x, dz, c2.weight, 1, 1, 0) if ctx.needs_input_grad[5] else None
         if direct:
             for a in acc:
                 a[0].fired()
             dg1 = db1 = dg2 = db2 = None
         else:
-            db1, dg1, dg2 = sums[:Cc].clone(), sums[Cc:2 * Cc].clone(), sums[2 * Cc:].clone()
+            db1, dg1, dg2 = local[:Cc].clone(), local[Cc:2 * Cc].clone(), local[2 * Cc:].clone()
             db2 = db1.clone()
         dx = dup = None
         if ctx.needs_input_grad[0]:
@@ -593,11 +621,11 @@ class BottleneckChainFn(Function):
             if blk.downsample is not None:
                 wd, gd, bd = (next(it) for _ in range(3))
                 ds = blk.downsample
-                if DUAL_APPLY and _sync_world(ds.bn) == 1 and _sync_world(blk.bn3) == 1:
+                if DUAL_APPLY:
                     # the shortcut's normalised tensor is read by bn3's apply pass only: never written
                     rawd, md, idd = _conv_stats_forward(xin, ds.conv, ds.bn, gd, bd)
                     raw3, m3, i3 = _conv_stats_forward(y2, blk.conv3, blk.bn3, g3, b3)
-                    mb.append(ops.relu_bits_buffer(raw3) if MASK_BITS else None)
+                    mb.append(ops.relu_bits_buffer(raw3) if (MASK_BITS and _sync_world(blk.bn3) == 1) else None)
                     y3 = ops.bn_dual_apply(raw3, (m3, i3, g3, b3), rawd, (md, idd, gd, bd), relu=True, bits_out=mb[0])
                 else:
                     idn, rawd, md, idd, _ = _convbn_train_forward(xin, ds.conv, ds.bn, gd, bd, False, None)

@@ -277,14 +277,15 @@ extern "C" int das_bn_relu_add3_backward(const void* g, const void* raw1, const 
                                          long long rows, int C, const float* const* bn, float* sums, int sums_zeroed,
                                          long long stat_rows,
                                          float* dgamma1_acc, float* dbeta1_acc, float* dgamma2_acc, float* dbeta2_acc,
-                                         void* stream) {
-  if (!g || !raw1 || !raw2 || !draw1 || !draw2 || !bn || !par_ok(bn) || !sums || rows < 1 || stat_rows < 1 || C % 8 || C < 8 ||
+                                         int phase, void* stream) {
+  if (phase < 0 || phase > 2) return DAS_ERR_ARG;
+  if (!g || !raw1 || !raw2 || ((!draw1 || !draw2) && phase != 1) || !bn || !par_ok(bn) || !sums || rows < 1 || stat_rows < 1 || C % 8 || C < 8 ||
       C > 4096)
     return DAS_ERR_ARG;
   const int nacc = (dgamma1_acc != nullptr) + (dbeta1_acc != nullptr) + (dgamma2_acc != nullptr) + (dbeta2_acc != nullptr);
   if (nacc != 0 && nacc != 4) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (!sums_zeroed && hipMemsetAsync(sums, 0, sizeof(float) * 4 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (phase != 2 && !sums_zeroed && hipMemsetAsync(sums, 0, sizeof(float) * 4 * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int vc = C / (dtype == DAS_F32 ? 4 : 8);
   const int pl = TPB / (vc < TPB ? vc : TPB);
   const long long cap = dastune::get(dastune::BN_UPMERGE_BLOCKS);
@@ -298,9 +299,11 @@ extern "C" int das_bn_relu_add3_backward(const void* g, const void* raw1, const 
     if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)bn_relu_add3_bwd_reduce_kernel<T>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return DAS_ERR_LAUNCH;
-    hipLaunchKernelGGL(bn_relu_add3_bwd_reduce_kernel<T>, dim3(blocks), dim3(TPB), lds, s, (const T*)g, (const T*)raw1,
-                       (const T*)raw2, rows, C, p1, p2, sums);
-    hipLaunchKernelGGL(bn_relu_add3_bwd_apply_kernel<T>, dim3((unsigned)grid), dim3(TPB), 0, s, (const T*)g, (const T*)raw1,
+    if (phase != 2)
+      hipLaunchKernelGGL(bn_relu_add3_bwd_reduce_kernel<T>, dim3(blocks), dim3(TPB), lds, s, (const T*)g, (const T*)raw1,
+                         (const T*)raw2, rows, C, p1, p2, sums);
+    if (phase != 1)
+      hipLaunchKernelGGL(bn_relu_add3_bwd_apply_kernel<T>, dim3((unsigned)grid), dim3(TPB), 0, s, (const T*)g, (const T*)raw1,
                        (const T*)raw2, (T*)draw1, (T*)draw2, rows, C, (int)rpb, p1, p2, sums, 1.f / (float)stat_rows,
                        dgamma1_acc, dbeta1_acc, dgamma2_acc, dbeta2_acc);
   });

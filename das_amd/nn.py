@@ -231,7 +231,7 @@ def conv_bn_deferred(x, module, skip_through=False):
     from . import autograd as ag
     conv, bn = module.conv, module.norm
     if (DEFERRED_SKIPS and module.with_activation and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
-            and conv.bias is None and ag._sync_world(bn) == 1
+            and conv.bias is None
             and ag.grad_mode(x, conv.weight, bn.weight)):
         res = ag.ConvStatsFn.apply(x, conv.weight, conv, bn, skip_through)
         d = DeferredBN(res[0], res[1], res[2], bn)
@@ -260,7 +260,7 @@ def up_merge(x, up_x, in_skip, up_conv, skip_through=False):
     c1, bn1, c2, bn2 = in_skip.conv, in_skip.bn, up_conv.conv, up_conv.bn
     fused = (UPMERGE_FUSED and UPCONV_AT_LOW_RES and bn1.training and bn2.training and c1.bias is None and c2.bias is None
              and c1.kernel_size[0] == c2.kernel_size[0] == 1 and c1.stride[0] == c2.stride[0] == 1
-             and c1.out_channels == c2.out_channels and ag._sync_world(bn1) == 1 and ag._sync_world(bn2) == 1
+             and c1.out_channels == c2.out_channels and ag._sync_world(bn1) == ag._sync_world(bn2)
              and ag.grad_mode(x, up_x, c1.weight, bn1.weight, c2.weight, bn2.weight))
     if fused:
         return ag.UpMergeTrainFn.apply(x, up_x, c1.weight, bn1.weight, bn1.bias, c2.weight, bn2.weight, bn2.bias, in_skip, up_conv,

@@ -821,9 +821,10 @@ def bn_relu_add3_forward(x, raw1, bn1, raw2, bn2):
     return out
 
 
-def bn_relu_add3_backward(g, raw1, bn1, raw2, bn2, acc=None):
-    """Returns d raw1, d raw2, sums f32[4C] = [dbeta1 | dgamma1 | dbeta2 | dgamma2]; acc = (dgamma1, dbeta1, dgamma2, dbeta2)
-    accumulators the parameter gradients are also added to (das_bn_relu_add3_backward)."""
+def bn_relu_add3_backward(g, raw1, bn1, raw2, bn2, acc=None, all_reduce=None, world=1):
+    """Returns d raw1, d raw2, sums f32[4C] = [dbeta1 | dgamma1 | dbeta2 | dgamma2] (this rank's); acc = (dgamma1, dbeta1,
+    dgamma2, dbeta2) accumulators the parameter gradients are also added to (das_bn_relu_add3_backward).
+    SyncBN (world > 1): the two passes run around all_reduce(sums) — the apply pass sees the sums over all ranks' rows."""
     _need_gpu(g, raw1, raw2)
     assert g.is_contiguous() and g.shape == raw1.shape == raw2.shape and g.dtype == raw1.dtype == raw2.dtype
     Cc = g.shape[-1]
@@ -833,10 +834,21 @@ def bn_relu_add3_backward(g, raw1, bn1, raw2, bn2, acc=None):
     sums = zeroed_stats(4 * Cc, g.device)
     arr = _bn_ptrs(bn1, bn2)
     a = acc if acc is not None else (None, None, None, None)
+    lib = _lib.load()
+    if world > 1:
+        assert acc is None, 'the accumulators take LOCAL sums: add them from the returned sums'
+        _lib.check(lib.das_bn_relu_add3_backward(_ptr(g), _ptr(raw1), _ptr(raw2), None, None, _DT[g.dtype], rows, Cc, arr, _ptr(sums),
+                                                 1, rows, None, None, None, None, 1, _stream()), 'das_bn_relu_add3_backward')
+        glob = sums.clone()
+        all_reduce(glob)
+        _lib.check(lib.das_bn_relu_add3_backward(_ptr(g), _ptr(raw1), _ptr(raw2), _ptr(d1), _ptr(d2), _DT[g.dtype], rows, Cc, arr,
+                                                 _ptr(glob), 1, rows * world, None, None, None, None, 2, _stream()),
+                   'das_bn_relu_add3_backward')
+        return d1, d2, sums
     with _timed('bn_bwd_reduce_kernel + bn_bwd_apply_kernel', 8 * g.numel() * g.element_size(), launches=2, shape=(rows, Cc, 'skipadd')):
-        _lib.check(_lib.load().das_bn_relu_add3_backward(_ptr(g), _ptr(raw1), _ptr(raw2), _ptr(d1), _ptr(d2), _DT[g.dtype], rows, Cc,
-                                                         arr, _ptr(sums), 1, rows, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]),
-                                                         _stream()), 'das_bn_relu_add3_backward')
+        _lib.check(lib.das_bn_relu_add3_backward(_ptr(g), _ptr(raw1), _ptr(raw2), _ptr(d1), _ptr(d2), _DT[g.dtype], rows, Cc,
+                                                 arr, _ptr(sums), 1, rows, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), 0,
+                                                 _stream()), 'das_bn_relu_add3_backward')
     return d1, d2, sums
 
 

@@ -295,7 +295,9 @@ int das_upmerge_backward_lowres(const void* P, const void* z, void* dz, int dtyp
  * mean1, invstd1, gamma1, beta1, mean2, invstd2, gamma2, beta2.
  * Backward: g = d out (also d x); writes d raw1, d raw2 (the full train-mode BatchNorm backward of each branch, ReLU mask
  * recomputed from raw_i) and sums f32[4C] = [sum g1 | sum g1 xhat1 | sum g2 | sum g2 xhat2] (dbeta_i | dgamma_i; zeroed here
- * unless sums_zeroed); stat_rows = rows. The four accumulators (all or none): the parameter gradients are ADDED there as well. */
+ * unless sums_zeroed); stat_rows = rows. The four accumulators (all or none): the parameter gradients are ADDED there as well.
+ * phase: 0 = both passes; SyncBN: 1 = only the sums of this rank's rows (the caller sums them over the ranks), 2 = only the
+ * apply pass with `sums` as given and 1/N from stat_rows (all ranks' rows) — hand the accumulators only with LOCAL sums. */
 /* out = relu?(BN1(raw1) + BN2(raw2)): a bottleneck's bn3 with the block's projection shortcut `downsample(x)`
  * (mspn_mmpose.py:126-157) normalised on the fly — the shortcut's normalised tensor is never written. bn as below. */
 int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C, const float* const* bn,
@@ -304,7 +306,8 @@ int das_bn_relu_add3_forward(const void* x, const void* raw1, const void* raw2, 
                              const float* const* bn, void* stream);
 int das_bn_relu_add3_backward(const void* g, const void* raw1, const void* raw2, void* draw1, void* draw2, int dtype,
                               long long rows, int C, const float* const* bn, float* sums, int sums_zeroed,
-                              long long stat_rows, float* dgamma1_acc, float* dbeta1_acc, float* dgamma2_acc, float* dbeta2_acc, void* stream);
+                              long long stat_rows, float* dgamma1_acc, float* dbeta1_acc, float* dgamma2_acc, float* dbeta2_acc,
+                              int phase, void* stream);
 int das_maxpool3x3s2_argmax(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, void* stream);
 int das_maxpool3x3s2_backward_argmax(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C,
                                      void* stream);

@@ -79,6 +79,10 @@ def _equiv_cfg():
     cfg['backbone']['compute_dtype'] = 'f32'
     cfg['backbone']['norm_cfg'] = dict(type='SyncBN')
     cfg['neck']['norm_cfg'] = dict(type='SyncBN')
+    # two stages: the cross-stage skips (deferred BatchNorm apply), the upsample units' merge and the projection shortcut's
+    # dual apply all run their SyncBN forms (statistics / backward sums summed over the ranks). One block per layer: the
+    # reference builds a layer's further blocks with plain BatchNorm, which two ranks cannot reproduce on half batches.
+    cfg['backbone']['num_stages'] = 2
     return cfg
 
 
