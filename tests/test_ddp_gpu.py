@@ -171,7 +171,9 @@ def test_two_rank_step_equals_the_single_process_step_on_the_concatenated_batch(
     # (relative to how far the step moved the tensor — floor: 1 % of the largest move of any tensor; f32 summation
     # order of statistics and gradients differs between the two runs)
     bad = sorted(((e / max(m, 1e-2 * step), e, m, n) for e, m, n in rows), reverse=True)[:6]
-    assert bad[0][0] < 2e-2, bad
+    # (two stages deep the run-to-run spread of the float atomics alone reaches 2-4e-2 of a tensor's move on the head's first
+    # convs — seen between two runs of this very test; a missing factor `world` or an unsynchronised sum would be O(1))
+    assert bad[0][0] < 8e-2, bad
     for n, b in model.named_buffers():
         if 'running' in n:
             torch.testing.assert_close(b.detach().cpu(), b0[n], rtol=1e-4, atol=1e-6)
