@@ -94,6 +94,7 @@ SIGNATURES = {
     'das_pack_conv_weights': (i32, [vp, vp, vp, i32, vp, i32, i32, vp]),
     'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
     'das_colsum_acc': (i32, [vp, i32, i64, i32, i32, vp, vp]),
+    'das_bn_train_backward_bits_phase': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i64, vp]),
     'das_bn_train_backward_bits': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     'das_bn_train_backward': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
     'das_bn_train_backward_phase': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i64, vp]),

@@ -302,7 +302,7 @@ class ConvBNTrainFn(Function):
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         bits = []
         y, raw, mean, invstd, world = _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual, bits=bits)
-        ctx.bits = bits[0] if world == 1 else None   # (the mask of y as bits: the backward then never reads y)
+        ctx.bits = bits[0]   # (the mask of y as bits: the backward then never reads y)
         ctx.save_for_backward(x, raw, y if (residual is not None and ctx.bits is None) else None, mean, invstd, gamma, weight, beta)
         ctx.cfg = (k, s, p, relu, residual is not None, conv, bn)
         ctx.world = world
@@ -319,8 +319,9 @@ class ConvBNTrainFn(Function):
         # without a residual the ReLU mask is recomputed from raw: y is not read at all
         if ctx.world > 1:   # SyncBN: reduce, sum over ranks, apply; parameter gradients stay local
             direct = False
-            draw, dres, dgamma, dbeta = ops.bn_train_backward_sync(dy, y if (relu and has_res) else None, raw, mean, invstd,
-                                                                   gamma, relu, has_res, beta, _all_reduce, ctx.world)
+            draw, dres, dgamma, dbeta = ops.bn_train_backward_sync(dy, y if (relu and has_res and ctx.bits is None) else None, raw,
+                                                                   mean, invstd, gamma, relu, has_res, beta, _all_reduce, ctx.world,
+                                                                   bits=ctx.bits if (relu and has_res) else None)
         else:
             draw, dres, dgamma, dbeta = ops.bn_train_backward(dy, y if (relu and has_res and ctx.bits is None) else None, raw,
                                                               mean, invstd, gamma, relu, has_res, beta=beta,
@@ -617,7 +618,7 @@ class BottleneckChainFn(Function):
             w1, g1, b1, w2, g2, b2, w3, g3, b3 = (next(it) for _ in range(9))
             y1, raw1, m1, i1, _ = _convbn_train_forward(xin, blk.conv1, blk.bn1, g1, b1, True, None)
             y2, raw2, m2, i2, _ = _convbn_train_forward(y1, blk.conv2, blk.bn2, g2, b2, True, None)
-            mb = []   # the ReLU mask of y3 as bits (None under SyncBN: its two-phase backward reads y3)
+            mb = []   # the ReLU mask of y3 as bits
             if blk.downsample is not None:
                 wd, gd, bd = (next(it) for _ in range(3))
                 ds = blk.downsample
@@ -625,15 +626,13 @@ class BottleneckChainFn(Function):
                     # the shortcut's normalised tensor is read by bn3's apply pass only: never written
                     rawd, md, idd = _conv_stats_forward(xin, ds.conv, ds.bn, gd, bd)
                     raw3, m3, i3 = _conv_stats_forward(y2, blk.conv3, blk.bn3, g3, b3)
-                    mb.append(ops.relu_bits_buffer(raw3) if (MASK_BITS and _sync_world(blk.bn3) == 1) else None)
+                    mb.append(ops.relu_bits_buffer(raw3) if MASK_BITS else None)
                     y3 = ops.bn_dual_apply(raw3, (m3, i3, g3, b3), rawd, (md, idd, gd, bd), relu=True, bits_out=mb[0])
                 else:
                     idn, rawd, md, idd, _ = _convbn_train_forward(xin, ds.conv, ds.bn, gd, bd, False, None)
-                    y3, raw3, m3, i3, w3_ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, idn, bits=mb)
-                    mb[0] = mb[0] if w3_ == 1 else None
+                    y3, raw3, m3, i3, _ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, idn, bits=mb)
             else:
-                y3, raw3, m3, i3, w3_ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, xin, bits=mb)
-                mb[0] = mb[0] if w3_ == 1 else None
+                y3, raw3, m3, i3, _ = _convbn_train_forward(y2, blk.conv3, blk.bn3, g3, b3, True, xin, bits=mb)
             ent['u'] = len(saved)
             saved += [raw1, m1, i1, y1, raw2, m2, i2, y2, raw3, m3, i3, y3, mb[0]]
             if blk.downsample is not None:
@@ -703,8 +702,8 @@ class BottleneckChainFn(Function):
         def classic_bn(bn, gamma, beta, pi, dyv, y, raw, mean, invstd, relu, want_dres, bits=None):
             world = _sync_world(bn)
             if world > 1:
-                draw, dres, dgamma, dbeta = ops.bn_train_backward_sync(dyv, y, raw, mean, invstd, gamma, relu, want_dres,
-                                                                       beta, _all_reduce, world)
+                draw, dres, dgamma, dbeta = ops.bn_train_backward_sync(dyv, None if bits is not None else y, raw, mean, invstd,
+                                                                       gamma, relu, want_dres, beta, _all_reduce, world, bits=bits)
                 deliver(bn, pi, dgamma, dbeta)
                 return draw, dres
             ga, ba = _param_acc(bn.weight), _param_acc(bn.bias)
@@ -750,8 +749,7 @@ class BottleneckChainFn(Function):
             if carry_dz is None:
                 # with the mask as bits the identity branch's gradient dY * mask need not be written: the conv1 data gradient
                 # below takes (dY, bits) as its residual and masks on the fly (DasConvDesc.residual_mask_bits)
-                lazy = (RES_BITS and bits3 is not None and bi > 0 and blk.downsample is None and _sync_world(blk.bn3) == 1
-                        and blk.conv1.stride[0] == 1)
+                lazy = RES_BITS and bits3 is not None and bi > 0 and blk.downsample is None and blk.conv1.stride[0] == 1
                 draw3, dz3 = classic_bn(blk.bn3, g3, b3, po + 7, carry_dy, y3, raw3, m3, i3, True, not lazy, bits=bits3)
                 if lazy:
                     dz3 = (carry_dy, bits3)

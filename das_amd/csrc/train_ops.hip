@@ -1572,6 +1572,16 @@ extern "C" int das_bn_train_backward_bits(const void* dy, const void* y_relu_bit
                                 nullptr, 1, draw, dres, sums, sums_prezeroed, dgamma_acc, dbeta_acc, 0, rows, stream);
 }
 
+extern "C" int das_bn_train_backward_bits_phase(const void* dy, const void* y_relu_bits, const void* raw, int dtype,
+                                                long long rows, int C, const float* mean, const float* invstd,
+                                                const float* gamma, void* draw, void* dres, float* sums, int sums_prezeroed,
+                                                float* dgamma_acc, float* dbeta_acc, int phase, long long stat_rows,
+                                                void* stream) {
+  if (!y_relu_bits) return DAS_ERR_ARG;
+  return bn_train_backward_impl(dy, nullptr, (const unsigned char*)y_relu_bits, raw, dtype, rows, C, mean, invstd, gamma,
+                                nullptr, 1, draw, dres, sums, sums_prezeroed, dgamma_acc, dbeta_acc, phase, stat_rows, stream);
+}
+
 extern "C" int das_bn_backward_apply(const void* dz, const void* raw, int dtype, long long rows, int C, const float* mean,
                                      const float* invstd, const float* gamma, const float* sums, int sums_slots,
                                      void* draw, float* dgamma_acc, float* dbeta_acc, long long stat_rows, void* stream) {

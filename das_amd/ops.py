@@ -483,12 +483,13 @@ def bn_train_backward(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta=Non
     return draw, dres, sums[Cc:], sums[:Cc]
 
 
-def bn_train_backward_sync(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta, all_reduce, world):
+def bn_train_backward_sync(dy, y, raw, mean, invstd, gamma, relu, want_dres, beta, all_reduce, world, bits=None):
     """SyncBN backward in two phases around a cross-rank sum of the per-channel sums (what torch's
     SyncBatchNorm does with its all_reduce of sum_dy / sum_dy_xmu). `all_reduce(t)` sums t over the ranks in
     place. Returns d_raw, d_residual, dgamma, dbeta (the LOCAL parameter gradients: the data-parallel
-    gradient all-reduce adds the ranks' contributions, exactly as for every other parameter)."""
-    _need_gpu(dy, raw)
+    gradient all-reduce adds the ranks' contributions, exactly as for every other parameter). bits (with y=None, relu): the
+    ReLU mask as recorded by the forward (relu_bits_buffer) instead of y."""
+    _need_gpu(dy, raw, bits)
     assert dy.is_contiguous() and raw.is_contiguous() and (y is None or y.is_contiguous())
     Cc = raw.shape[-1]
     rows = raw.numel() // Cc
@@ -496,12 +497,19 @@ def bn_train_backward_sync(dy, y, raw, mean, invstd, gamma, relu, want_dres, bet
     dres = torch.empty_like(raw) if want_dres else None
     sums = torch.empty(2 * Cc, dtype=torch.float32, device=raw.device)
     lib = _lib.load()
-    args = (_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-            int(relu), _ptr(draw), _ptr(dres), _ptr(sums), 0, None, None)
-    _lib.check(lib.das_bn_train_backward_phase(*args, 1, rows, _stream()), 'das_bn_train_backward_phase')
+    if bits is not None:
+        assert y is None and relu and bits.dtype == torch.uint8 and bits.numel() * 16 == raw.numel() * raw.element_size()
+        args = (_ptr(dy), _ptr(bits), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(draw),
+                _ptr(dres), _ptr(sums), 0, None, None)
+        fn, name = lib.das_bn_train_backward_bits_phase, 'das_bn_train_backward_bits_phase'
+    else:
+        args = (_ptr(dy), _ptr(y), _ptr(raw), _DT[raw.dtype], rows, Cc, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                int(relu), _ptr(draw), _ptr(dres), _ptr(sums), 0, None, None)
+        fn, name = lib.das_bn_train_backward_phase, 'das_bn_train_backward_phase'
+    _lib.check(fn(*args, 1, rows, _stream()), name)
     local = sums.clone()
     all_reduce(sums)
-    _lib.check(lib.das_bn_train_backward_phase(*args, 2, rows * world, _stream()), 'das_bn_train_backward_phase')
+    _lib.check(fn(*args, 2, rows * world, _stream()), name)
     return draw, dres, local[Cc:], local[:Cc]
 
 

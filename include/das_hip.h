@@ -192,6 +192,11 @@ int das_bn_train_backward(const void* dy, const void* y, const void* raw, int dt
 int das_bn_train_backward_bits(const void* dy, const void* y_relu_bits, const void* raw, int dtype, long long rows, int C,
                                const float* mean, const float* invstd, const float* gamma, void* draw, void* dres,
                                float* sums, int sums_prezeroed, float* dgamma_acc, float* dbeta_acc, void* stream);
+/* ... and in the two phases of das_bn_train_backward_phase (SyncBN). */
+int das_bn_train_backward_bits_phase(const void* dy, const void* y_relu_bits, const void* raw, int dtype, long long rows, int C,
+                                     const float* mean, const float* invstd, const float* gamma, void* draw, void* dres,
+                                     float* sums, int sums_prezeroed, float* dgamma_acc, float* dbeta_acc, int phase,
+                                     long long stat_rows, void* stream);
 int das_bn_train_backward_phase(const void* dy, const void* y, const void* raw, int dtype, long long rows, int C,
                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 int relu, void* draw, void* dres, float* sums, int sums_prezeroed, float* dgamma_acc,

@@ -64,6 +64,17 @@ def test_two_emulated_ranks_equal_full_batch(relu, res):
                                                    raw[h].contiguous(), mean, invstd, gamma, relu, res, beta,
                                                    all_reduce, 2)
         outs.append((d, dres, dg, db))
+        if relu and res:
+            # the same two-phase backward with the ReLU mask handed over as bits (one byte per 16-byte vector of y) instead of y
+            per = 16 // yh.element_size()
+            wts = (2 ** torch.arange(per, device=yh.device)).to(torch.int32)
+            bits = ((yh.reshape(-1, per) > 0).to(torch.int32) * wts).sum(1).to(torch.uint8)
+            d2, dres2, dg2, db2 = o.bn_train_backward_sync(dy[h].contiguous(), None, raw[h].contiguous(), mean, invstd, gamma,
+                                                           relu, res, beta, all_reduce, 2, bits=bits)
+            assert torch.equal(dres2, dres)
+            torch.testing.assert_close(d2, d, rtol=1e-5, atol=2e-6)
+            torch.testing.assert_close(dg2, dg, rtol=1e-5, atol=1e-4)
+            torch.testing.assert_close(db2, db, rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(torch.cat([a[0] for a in outs]), d_full, rtol=1e-5, atol=2e-6)
     if res:
         torch.testing.assert_close(torch.cat([a[1] for a in outs]), dres_full, rtol=0, atol=0)
