@@ -183,62 +183,75 @@ def mpii_compute_3d_pck(seq_err, pck_thresh=150):
     return curves, pcks, aucs
 
 
+def _bone_table(o1, trav):
+    """(child, parent) index arrays of the walk. The reference pairs the i-th joint of the traversal with the i-th
+    entry of the parent list (not the child's own parent, mupots_3dhp.py:483-486), so the table is built the same way
+    and the walk below keeps its sequential meaning: a child is placed relative to wherever its listed parent
+    currently is."""
+    child = np.asarray(trav, dtype=np.int64)
+    return child, np.asarray(o1, dtype=np.int64)[:len(child)]
+
+
+def rescale_bones(pose, gt, o1, trav):
+    """Give every bone of `pose` the length it has in `gt`, keeping its direction (mupots_3dhp.py:480-489).
+    pose (..., 3, J) and gt (..., 3, J) broadcast against each other, so all (GT person, prediction) pairs of a
+    frame go through one call. Directions and lengths of all bones come from two vectorised differences; only the
+    placement walks the table (sixteen adds on the whole batch)."""
+    child, parent = _bone_table(o1, trav)
+    pose, gt = np.broadcast_arrays(pose, gt)
+    bone = pose[..., child] - pose[..., parent]                              # (..., 3, nb)
+    want = np.sqrt(np.square(gt[..., child] - gt[..., parent]).sum(axis=-2))  # (..., nb)
+    have = np.sqrt(np.square(bone).sum(axis=-2))
+    step = bone * (want / have)[..., None, :]
+    out = np.array(pose)
+    for b in range(len(child)):
+        out[..., child[b]] = out[..., parent[b]] + step[..., b]
+    return out
+
+
 def norm_by_bone_length(pred, gt, o1, trav):
-    """Re-scale every bone of pred (3, J) to the GT's length, walking the skeleton from the root (:482-491)."""
-    mapped = pred.copy()
-    for i in range(len(trav)):
-        idx = trav[i]
-        gt_len = np.linalg.norm(gt[:, idx] - gt[:, o1[i]])
-        vec = pred[:, idx] - pred[:, o1[i]]
-        mapped[:, idx] = mapped[:, o1[i]] + vec * gt_len / np.linalg.norm(vec)
-    return mapped
+    """Single-pair form under the reference's name."""
+    return rescale_bones(pred, gt, o1, trav)
 
 
-def procrustes(predicted, target):
-    """Similarity alignment of predicted (3, J) onto target (3, J) (:494-530)."""
-    predicted, target = predicted.T[None, ...], target.T[None, ...]
-    muX, muY = np.mean(target, axis=1, keepdims=True), np.mean(predicted, axis=1, keepdims=True)
-    X0, Y0 = target - muX, predicted - muY
-    normX = np.sqrt(np.sum(X0 ** 2, axis=(1, 2), keepdims=True))
-    normY = np.sqrt(np.sum(Y0 ** 2, axis=(1, 2), keepdims=True))
-    X0 = X0 / normX
-    Y0 = Y0 / normY
-    H = np.matmul(X0.transpose(0, 2, 1), Y0)
-    U, s, Vt = np.linalg.svd(H)
-    V = Vt.transpose(0, 2, 1)
-    R = np.matmul(V, U.transpose(0, 2, 1))
-    sign = np.sign(np.expand_dims(np.linalg.det(R), axis=1))     # no reflections
-    V[:, :, -1] *= sign
-    s[:, -1] *= sign.flatten()
-    R = np.matmul(V, U.transpose(0, 2, 1))
-    tr = np.expand_dims(np.sum(s, axis=1, keepdims=True), axis=2)
-    a = tr * normX / normY
-    t = muX - a * np.matmul(muY, R)
-    return (a * np.matmul(predicted, R) + t)[0].T
+def procrustes(pose, target):
+    """Least-squares similarity transform (scale, proper rotation, translation) of pose (..., 3, J) onto
+    target (..., 3, J), batched over the leading axes (the reference's `procrustes`, mupots_3dhp.py:492-528, one pair
+    at a time; computed here in column form from the un-normalised cross-covariance: Kabsch / Umeyama)."""
+    pose, target = np.broadcast_arrays(np.asarray(pose, dtype=np.float64), np.asarray(target, dtype=np.float64))
+    c_pose = pose.mean(axis=-1, keepdims=True)
+    c_tgt = target.mean(axis=-1, keepdims=True)
+    a, b = pose - c_pose, target - c_tgt
+    left, sing, right = np.linalg.svd(b @ np.swapaxes(a, -1, -2))            # b a^T = left diag(sing) right
+    flip = np.sign(np.linalg.det(left @ right))                             # -1 where the best fit is a reflection
+    left = left.copy()
+    left[..., :, -1] *= flip[..., None]
+    rot = left @ right
+    gain = (sing[..., :-1].sum(axis=-1) + flip * sing[..., -1]) / np.square(a).sum(axis=(-1, -2))
+    return gain[..., None, None] * (rot @ a) + c_tgt
 
 
 def match_people(gt_poses, pred_poses, o1, trav, threshold=250):
-    """GT person -> index of the closest prediction after depth-ratio scaling and bone normalisation, relative and
-    absolute, -1 beyond `threshold` mm (`match`, :533-566). gt (3, 17) list, pred (P, 3, 17)."""
-    matches, matches_abs = [], []
-    p2 = np.float32(pred_poses)
-    p2_root = p2[:, :, MUPOTS_ROOT:MUPOTS_ROOT + 1]
-    p2 = p2 - p2_root
-    for g in gt_poses:
-        p1 = np.float32(g)
-        p1_root = p1[:, MUPOTS_ROOT:MUPOTS_ROOT + 1]
-        p1 = p1 - p1_root
-        diffs, diffs_abs = [], []
-        for j in range(len(p2)):
-            p = p2[j].copy()
-            p[:2] *= p1_root[[2]] / p2_root[j, [2]]
-            p = norm_by_bone_length(p, p1, o1, trav)
-            diffs.append(np.sqrt(np.power(p - p1, 2).sum(axis=0)).mean())
-            diffs_abs.append(np.sqrt(np.power(p + p2_root[j] - p1 - p1_root, 2).sum(axis=0)).mean())
-        diffs, diffs_abs = np.float32(diffs), np.float32(diffs_abs)
-        matches.append(-1 if diffs.min() > threshold else int(np.argmin(diffs)))
-        matches_abs.append(-1 if diffs_abs.min() > threshold else int(np.argmin(diffs_abs)))
-    return matches, matches_abs
+    """For every GT person the index of the closest prediction, root-relative and absolute, -1 when even the closest is
+    further than `threshold` mm on average (`match`, mupots_3dhp.py:531-566). Distances are taken after the prediction's
+    x / y have been scaled by the ratio of the root depths and its bones set to the GT's lengths. All G x P pairs at
+    once, in float32 as the reference computes them. gt: G arrays (3, 17); pred (P, 3, 17)."""
+    gt = np.stack([np.asarray(g) for g in gt_poses]).astype(np.float32)      # (G, 3, J)
+    pr = np.asarray(pred_poses).astype(np.float32)                           # (P, 3, J)
+    gt_root = gt[:, :, MUPOTS_ROOT:MUPOTS_ROOT + 1]
+    pr_root = pr[:, :, MUPOTS_ROOT:MUPOTS_ROOT + 1]
+    gt_rel = (gt - gt_root)[:, None]                                         # (G, 1, 3, J)
+    cand = np.repeat((pr - pr_root)[None], len(gt), axis=0)                  # (G, P, 3, J)
+    cand[:, :, :2] *= (gt_root[:, None, 2:3] / pr_root[None, :, 2:3])
+    cand = rescale_bones(cand, gt_rel, o1, trav)
+    rel = np.sqrt(np.square(cand - gt_rel).sum(axis=2)).mean(axis=-1)        # (G, P)
+    absolute = np.sqrt(np.square(cand + pr_root[None] - gt_rel - gt_root[:, None]).sum(axis=2)).mean(axis=-1)
+
+    def pick(dist):
+        best = dist.argmin(axis=1)
+        ok = dist[np.arange(len(dist)), best] <= threshold
+        return [int(i) if k else -1 for i, k in zip(best, ok)]
+    return pick(rel), pick(absolute)
 
 
 def eval_mupots_sequence(annots, name2pred, ts, eval_mode='all'):

@@ -75,3 +75,33 @@ def test_mupots_helpers_vs_reference(golden_dir):
     X = rs.normal(0, 50, (3, 9))
     back = E.pixel2world(E.world2pixel(X.copy(), K, R, t), K, R, t)[-1]
     np.testing.assert_allclose(back, X, atol=2e-2)       # (world2pixel divides by z + 1e-5)
+
+
+def test_mupots_helpers_live_against_the_reference_over_random_frames():
+    """Authoring container only: the batched helpers against the reference's one-pair-at-a-time functions imported
+    from /root/reference (mupots_3dhp.py:480-566) on 40 random frames, incl. frames whose closest prediction is too far."""
+    import refstub
+    if not os.path.isdir(refstub.REF):
+        pytest.skip('reference tree absent (GPU box)')
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    from make_golden_eval import load_ref_datasets
+    _, mup = load_ref_datasets()
+    o1 = mup.mpii_get_joints('relavant')[1]
+    trav = E.SAFE_TRAVERSAL[1:]
+    assert o1 == E.MPII_O1
+    rs = np.random.RandomState(3)
+    for it in range(40):
+        G, P = rs.randint(1, 5), rs.randint(1, 7)
+        gt = [rs.normal(0, 300, (3, 17)) + np.array([[0.0], [0.0], [3000.0]]) for _ in range(G)]
+        pred = np.stack([gt[rs.randint(G)] + rs.normal(0, 40 if rs.rand() < 0.7 else 600, (3, 17)) for _ in range(P)])
+        ref = mup.match(gt, pred.copy(), o1, trav)
+        got = E.match_people(gt, pred.copy(), o1, trav)
+        assert [int(i) for i in ref[0]] == got[0] and [int(i) for i in ref[1]] == got[1], it
+        a, b = pred[0], gt[0]
+        np.testing.assert_allclose(E.procrustes(a.copy(), b.copy()), mup.procrustes(a.copy(), b.copy()), rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(E.norm_by_bone_length(a.copy(), b.copy(), o1, trav),
+                                   mup.norm_by_bone_length(a.copy(), b.copy(), o1, trav), rtol=1e-12)
+    # batched alignment == pair by pair
+    A, B = rs.normal(0, 100, (5, 3, 17)), rs.normal(0, 100, (5, 3, 17))
+    np.testing.assert_allclose(E.procrustes(A, B), np.stack([E.procrustes(x, y) for x, y in zip(A, B)]), rtol=1e-12)
