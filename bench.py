@@ -197,11 +197,18 @@ def cpu_baseline(workload, budget_s=30.0, full=False, threads=None):
             feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img, 1, (3, 4, 6, 3)))
             c, p, k = oh.head_forward(hsd, feats, hcfg, '', False)
             return od.get_poses(c, p, k, metas, J, hcfg['strides'], tcfg)
-    warmups = 5 if full else 1
+    # Protocol: BASELINE.md section 4 (5 warm-ups, mean of 20 iterations) whenever it fits `full_fit_s` seconds on this
+    # host — judged from the first (cold) iteration —, else a bounded sample that says so in `protocol`.
+    full_fit_s = 120.0
     t0 = time.perf_counter()
-    for _ in range(warmups):
+    step()
+    first = time.perf_counter() - t0
+    if not full and 25 * first <= full_fit_s:
+        full = True
+    warmups = 5 if full else 1
+    for _ in range(warmups - 1):
         step()
-    warm = (time.perf_counter() - t0) / warmups
+    warm = first
     t0, n = time.perf_counter(), 0
     while True:
         step()
@@ -213,9 +220,11 @@ def cpu_baseline(workload, budget_s=30.0, full=False, threads=None):
     what = ('4-stage forward + 4 losses + backward + clip_grad_norm_(35) + SGD(momentum 0.9, wd 1e-4) step'
             if workload == 'train' else '1-stage forward + decode')
     proto = ('BASELINE.md section 4 protocol: 5 warm-ups, mean of 20 iterations' if full else
-             f'bounded sample: {warmups} warm-up, mean of {n} iterations (time cap {budget_s:.0f} s; the full '
-             f'5 + 20 protocol is `bench.py --cpu-baseline-full`)')
-    return dict(value=round(B * n / dt, 4), unit='img/s', cores=cores, kind='port',
+             f'bounded sample: {warmups} warm-up, mean of {n} iterations (time cap {budget_s:.0f} s; the full 5 + 20 '
+             f'protocol did not fit {full_fit_s:.0f} s on this host — first iteration {first:.1f} s —, `bench.py '
+             f'--cpu-baseline-full` forces it)')
+    return dict(value=round(B * n / dt, 4), unit='img/s', cores=cores, kind='port', protocol='full' if full else 'bounded',
+                warmups=warmups, iterations=n,
                 sample=f'{n} x (batch {B} x 3 x {H} x {W}) {what}; CPU oracle fp32, torch {torch.__version__}, '
                        f'{cores} threads (intra-op), 1 inter-op; host: {desc}; {proto}')
 
@@ -285,7 +294,8 @@ OTHER_C = {
 
 
 def instrument_other_families(ops):
-    """HIP events (launch stream) around every call of the op wrappers / C entry points above while ops.PROFILE is a list;
+    """Every call of the op wrappers / C entry points above becomes a PROFILE entry while ops.PROFILE is a list: the span of
+    the library's own event pairs (das_prof_*, recorded inside the entry point around its launches) the call produced;
     entries use the layout of das_amd.ops._timed. Idempotent."""
     if getattr(ops, '_bench_instrumented', False):
         return
@@ -296,11 +306,10 @@ def instrument_other_families(ops):
         def call(*a, **k):
             if ops.PROFILE is None:
                 return fn(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            i0 = ops._prof_mark()
             out = fn(*a, **k)
-            e1.record()
-            ops.PROFILE.append((family, 0.0, e0, e1, ('other',), 1, float(nbytes(a, k, out)), 1))
+            sp = ops._Span(i0, ops._prof_mark())
+            ops.PROFILE.append((family, 0.0, sp, sp, ('other',), 1, float(nbytes(a, k, out)), 1))
             return out
         return call
     for name, (family, nb) in OTHER_FAMILIES.items():
@@ -311,10 +320,72 @@ def instrument_other_families(ops):
         setattr(lib, name, timed(getattr(lib, name), family, nb))
 
 
-def roofline_from_profile(ops, run_step, dtype, reps=2):
-    """HIP events around every launch of the conv families (forward, data gradient, the two weight-gradient kernel
-    classes), of the BatchNorm passes and of every other HIP op of the step (OTHER_FAMILIES / OTHER_C), on the launch
-    stream. Returns (roofline, roofline_mfma, roofline_hbm, roofline_bn, priced):
+PRICED_REPS = 5            # repetitions of the per-launch pass; per launch index the MINIMUM is priced
+PRICED_FIT = 1.02          # families_ms_sum must fit into the pass's own step time within this factor
+PRICED_PASS_OVER_STEP = 1.15   # ... and the pass's step time must stay within this factor of the timed region's
+PRICED_RETRIES = 3
+
+
+def _priced_pass(ops, run_step, reps):
+    """`reps` single steps, each between das_prof_begin / das_prof_end. Returns (wall ms per step, per step the list of
+    (tag, flops, ms, ops, algorithmic bytes, launches))."""
+    walls, passes = [], []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ops.profile_begin()
+        w0.record()
+        run_step()
+        w1.record()
+        torch.cuda.synchronize()
+        ents = ops.profile_end()
+        walls.append(w0.elapsed_time(w1))
+        passes.append([(e[0], e[1], e[2].elapsed_time(), e[5] if len(e) > 5 else 1, e[6] if len(e) > 6 else 0.0,
+                        e[7] if len(e) > 7 else 1) for e in ents])
+    return walls, passes
+
+
+def _fold_passes(passes):
+    """Per family [flops, seconds (minimum per launch index over the passes), ops, bytes, launches, seconds (median)] of ONE
+    step. The launch sequence of a step is deterministic; should two passes disagree on it, the families' sums are
+    compared instead (aligned = False)."""
+    import statistics
+    aligned = all(len(p) == len(passes[0]) and all(x[0] == y[0] for x, y in zip(p, passes[0])) for p in passes[1:])
+    fam = {}
+    if aligned:
+        for i, ent in enumerate(passes[0]):
+            ts = [p[i][2] for p in passes]
+            f = fam.setdefault(ent[0], [0.0, 0.0, 0, 0.0, 0, 0.0])
+            f[0] += ent[1]
+            f[1] += min(ts) * 1e-3
+            f[2] += ent[3]
+            f[3] += ent[4]
+            f[4] += ent[5]
+            f[5] += statistics.median(ts) * 1e-3
+    else:
+        per = []
+        for p in passes:
+            d = {}
+            for ent in p:
+                f = d.setdefault(ent[0], [0.0, 0.0, 0, 0.0, 0, 0.0])
+                f[0] += ent[1]; f[1] += ent[2] * 1e-3; f[2] += ent[3]; f[3] += ent[4]; f[4] += ent[5]
+            per.append(d)
+        for k in per[0]:
+            have = [d[k] for d in per if k in d]
+            best = min(have, key=lambda f: f[1])
+            fam[k] = best[:5] + [statistics.median(f[1] for f in have)]
+    return fam, aligned
+
+
+def roofline_from_profile(ops, run_step, dtype, ms_per_step=None, reps=PRICED_REPS):
+    """Event pairs recorded INSIDE the library around every launch of the conv families (forward, data gradient, the two
+    weight-gradient kernel classes), of the BatchNorm passes and of every other HIP op of the step (OTHER_FAMILIES /
+    OTHER_C) — das_prof_*, on the stream each launch goes to, nothing of the interpreter between an event and its launch.
+    `reps` single-step passes; a launch is priced at its MINIMUM over the passes (median reported beside it). The pass
+    checks itself: the families must fit into the pass's own step time (x PRICED_FIT) and that step time must stay within
+    PRICED_PASS_OVER_STEP of the timed region's; otherwise the pass is repeated (PRICED_RETRIES times) and, failing
+    that, `priced_step.unreliable` is set and the headline comes from roofline_hbm / roofline_mfma.
+    Returns (roofline, roofline_mfma, roofline_hbm, roofline_bn, priced):
       roofline       the family with the LARGEST TIME in the step (selection rule stated in the object; BatchNorm counts
                      per pass type there, roofline_bn has the passes together), priced against the roof its own launch
                      mix sits under: FLOP per algorithmic byte above the ridge (peak FLOP/s / peak B/s = 312 for bf16)
@@ -328,57 +399,53 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
     # Kernel quality is measured with the kernels running one at a time: the weight gradients' side stream (which
     # overlaps them with the main stream in the timed region) is switched off for these passes, otherwise a launch's
     # event-to-event time would include whatever ran beside it.
+    import statistics
     from das_amd import autograd as ag
     instrument_other_families(ops)
     side_was, ag.WGRAD_SIDE_STREAM = ag.WGRAD_SIDE_STREAM, False
     run_step()          # (untimed: the first step of this stream layout allocates its workspaces)
-    ops.PROFILE = []
-    torch.cuda.synchronize()
-    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    w0.record()
-    for _ in range(reps):
-        run_step()
-    w1.record()
-    torch.cuda.synchronize()
-    wall_ms = w0.elapsed_time(w1) / reps
-    ag.WGRAD_SIDE_STREAM = side_was
-    fam = {}
-    for ent in ops.PROFILE:
-        tag, flops, e0, e1 = ent[:4]
-        f = fam.setdefault(tag, [0.0, 0.0, 0, 0.0, 0])
-        f[0] += flops
-        f[1] += e0.elapsed_time(e1) * 1e-3
-        f[2] += ent[5] if len(ent) > 5 else 1     # ops (a batched weight-gradient launch covers several)
-        f[3] += ent[6] if len(ent) > 6 else 0.0   # algorithmic bytes: every operand once
-        f[4] += ent[7] if len(ent) > 7 else 1     # kernel launches
-    ops.PROFILE = None
-    if not fam:
-        return None, None, None, None, None
+    attempts, problems = 0, []
+    try:
+        while True:
+            attempts += 1
+            walls, passes = _priced_pass(ops, run_step, reps)
+            if not passes or not passes[0]:
+                return None, None, None, None, None
+            fam, aligned = _fold_passes(passes)
+            wall_ms, wall_med = min(walls), statistics.median(walls)
+            fam_sum = sum(f[1] for f in fam.values()) * 1e3
+            bad = []
+            if fam_sum > PRICED_FIT * wall_ms:
+                bad.append(f'families {fam_sum:.2f} ms > {PRICED_FIT} x pass step {wall_ms:.2f} ms')
+            if ms_per_step is not None and wall_ms > PRICED_PASS_OVER_STEP * ms_per_step:
+                bad.append(f'pass step {wall_ms:.2f} ms > {PRICED_PASS_OVER_STEP} x timed step {ms_per_step:.2f} ms')
+            if not bad or attempts > PRICED_RETRIES:
+                break
+            problems.append('; '.join(bad))
+    finally:
+        ag.WGRAD_SIDE_STREAM = side_was
+    unreliable = bool(bad)
+    if bad:
+        problems.append('; '.join(bad))
     peak = PEAK_BF16_TFLOPS if dtype == 'bf16' else PEAK_F32_TFLOPS
     ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)    # FLOP per byte above which a launch mix is matrix-core bound
 
     def entry(tag, v, rule):
-        fl, sec, nops, by, nl = v
+        fl, sec, nops, by, nl = v[:5]
         mfma = by > 0 and fl / by >= ridge
         ach = fl / sec / 1e12 if mfma else by / sec / 1e9
         pk = peak if mfma else PEAK_HBM_GBS
         return dict(bound='mfma' if mfma else 'hbm', kernel=tag, achieved=round(ach, 2 if mfma else 1), peak=pk,
                     unit='TFLOP/s' if mfma else 'GB/s', frac=round(ach / pk, 4), traffic=None, selection=rule,
-                    launches_per_step=nl // reps, ops_per_step=nops // reps, avg_launch_us=round(sec / max(nl, 1) * 1e6, 2),
-                    family_ms_per_step=round(sec / reps * 1e3, 3), algorithmic_mb_per_launch=round(by / max(nl, 1) / 1e6, 2),
+                    launches_per_step=nl, ops_per_step=nops, avg_launch_us=round(sec / max(nl, 1) * 1e6, 2),
+                    family_ms_per_step=round(sec * 1e3, 3), family_ms_per_step_median=round(v[5] * 1e3, 3),
+                    algorithmic_mb_per_launch=round(by / max(nl, 1) / 1e6, 2),
                     flop_per_byte=round(fl / max(by, 1.0), 1), ridge_flop_per_byte=round(ridge, 1),
                     tflops=round(fl / sec / 1e12, 2), gbs=round(by / sec / 1e9, 1))
     other_names = {f for f, _ in OTHER_FAMILIES.values()} | {f for f, _ in OTHER_C.values()}
     conv = {k: v for k, v in fam.items() if v[0] > 0}
     bn = {k: v for k, v in fam.items() if v[0] == 0 and k not in other_names}
     ranked = {k: v for k, v in fam.items() if k not in other_names}
-    tag, v = max(ranked.items(), key=lambda kv: kv[1][1])
-    roof = entry(tag, v, 'largest time per step among the conv families and the BatchNorm passes; BatchNorm is ranked '
-                 'per pass type here (forward apply / backward apply / backward reduce + apply) — together the passes are '
-                 'roofline_bn, which may exceed this family')
-    roof['all_families'] = {k: dict(tflops=round(x[0] / x[1] / 1e12, 2), gbs=round(x[3] / x[1] / 1e9, 1),
-                                    flop_per_byte=round(x[0] / max(x[3], 1.0), 1), ms_per_step=round(x[1] / reps * 1e3, 3),
-                                    launches=x[4] // reps, ops=x[2] // reps) for k, x in fam.items()}
     above = {k: x for k, x in conv.items() if x[3] > 0 and x[0] / x[3] >= ridge}
     below = {k: x for k, x in conv.items() if x[3] > 0 and x[0] / x[3] < ridge}
     roof_mfma = roof_hbm = roof_bn = None
@@ -389,21 +456,43 @@ def roofline_from_profile(ops, run_step, dtype, reps=2):
         t, x = max(below.items(), key=lambda kv: kv[1][1])
         roof_hbm = entry(t, x, 'largest time among the conv families below the ridge')
     if bn:
-        tot = [sum(x[i] for x in bn.values()) for i in range(5)]
+        tot = [sum(x[i] for x in bn.values()) for i in range(6)]
         roof_bn = entry(' + '.join(sorted(bn)), tot, 'all BatchNorm passes of the step (forward apply, backward apply, '
                         'backward reduce + apply; the fused forms count under the pass they replace: upsample-unit merge, '
                         'cross-stage skip add, projection-shortcut dual apply); algorithmic bytes = every operand of every '
                         'pass once')
+    if unreliable and (roof_hbm or roof_mfma):
+        # a pass that does not fit its own step must not pick the headline: fall back to the two per-roof entries
+        cands = [r for r in (roof_hbm, roof_mfma) if r is not None]
+        roof = dict(max(cands, key=lambda r: r['family_ms_per_step']))
+        roof['selection'] = ('priced_step.unreliable: the per-launch pass failed its self-check, so the headline is the '
+                             'larger of roofline_hbm / roofline_mfma instead of the family with the largest time')
+    else:
+        tag, v = max(ranked.items(), key=lambda kv: kv[1][1])
+        roof = entry(tag, v, 'largest time per step among the conv families and the BatchNorm passes; BatchNorm is ranked '
+                     'per pass type here (forward apply / backward apply / backward reduce + apply) — together the passes '
+                     'are roofline_bn, which may exceed this family')
+    roof['all_families'] = {k: dict(tflops=round(x[0] / x[1] / 1e12, 2), gbs=round(x[3] / x[1] / 1e9, 1),
+                                    flop_per_byte=round(x[0] / max(x[3], 1.0), 1), ms_per_step=round(x[1] * 1e3, 3),
+                                    ms_per_step_median=round(x[5] * 1e3, 3), launches=x[4], ops=x[2])
+                            for k, x in fam.items()}
     # every millisecond of the step: families + the rest (ATen glue launches, launch gaps, event overhead of this pass)
-    fam_ms = {k: x[1] / reps * 1e3 for k, x in fam.items()}
+    fam_ms = {k: x[1] * 1e3 for k, x in fam.items()}
     at_roof = 0.0
     for k, x in fam.items():
-        at_roof += max(x[0] / (peak * 1e12), x[3] / (PEAK_HBM_GBS * 1e9)) / reps * 1e3
-    priced = dict(step_ms_this_pass=round(wall_ms, 3),
-                  note='weight gradients on the main stream, HIP events around every launch: this pass runs a few % slower '
-                       'than the timed region; every family at max(FLOPs / MFMA peak, algorithmic bytes / HBM peak) '
-                       'gives families_ms_at_roof',
+        at_roof += max(x[0] / (peak * 1e12), x[3] / (PEAK_HBM_GBS * 1e9)) * 1e3
+    priced = dict(step_ms_this_pass=round(wall_ms, 3), step_ms_this_pass_median=round(wall_med, 3),
+                  reps=reps, attempts=attempts, launch_sequences_aligned=aligned, unreliable=unreliable,
+                  checks=dict(families_fit_step=f'families_ms_sum <= {PRICED_FIT} x step_ms_this_pass',
+                              pass_vs_timed_step=f'step_ms_this_pass <= {PRICED_PASS_OVER_STEP} x ms_per_step',
+                              timed_ms_per_step=None if ms_per_step is None else round(ms_per_step, 3),
+                              failures=problems),
+                  note='weight gradients on the main stream; one HIP event pair per C entry point, recorded inside the '
+                       'library right around its launches (das_prof_*); each launch priced at its minimum over the '
+                       'repetitions (families_ms_median: the median instead); every family at max(FLOPs / MFMA peak, '
+                       'algorithmic bytes / HBM peak) gives families_ms_at_roof',
                   families_ms={k: round(v, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])},
+                  families_ms_median={k: round(x[5] * 1e3, 3) for k, x in sorted(fam.items(), key=lambda kv: -kv[1][1])},
                   families_ms_sum=round(sum(fam_ms.values()), 3), families_ms_at_roof=round(at_roof, 3),
                   fraction_of_roof=round(at_roof / max(sum(fam_ms.values()), 1e-9), 4),
                   torch_glue_and_gaps_ms=round(wall_ms - sum(fam_ms.values()), 3))
@@ -797,7 +886,7 @@ def main():
     else:
         extra['poses_per_step_rank0'] = sum(len(r['scores']) for r in res)
 
-    roof, roof_mfma, roof_hbm, roof_bn, priced = roofline_from_profile(ops, step, args.dtype)
+    roof, roof_mfma, roof_hbm, roof_bn, priced = roofline_from_profile(ops, step, args.dtype, ms_per_step=dt / steps * 1e3)
     for r in (roof, roof_mfma, roof_hbm, roof_bn):
         if r is not None:
             attach_traffic(r, 'train' if train else 'infer', batch)

@@ -81,6 +81,10 @@ SIGNATURES = {
     'das_tuning_reset': (i32, []),
     'das_dev_occupy_cus': (i32, [i32, i32, i32, i32, vp]),
     'das_last_kernel': (C.c_char_p, []),
+    'das_prof_begin': (i32, []),
+    'das_prof_end': (i32, []),
+    'das_prof_count': (i64, []),
+    'das_prof_read': (i32, [vp, vp, i32, i64]),
     'das_img_resize_bilinear': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_img_resize_bilinear_u8': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_img_flip_horizontal': (i32, [vp, vp, i32, i32, i32, vp]),

@@ -209,16 +209,42 @@ def _sync_world(bn):
 
 
 def _all_reduce(t):
+    """Sum a SyncBN statistics vector over the ranks — on the statistics' OWN process group (nn.stats_group): one process
+    group is one RCCL communicator, and a communicator runs its collectives in issue order whatever stream they were
+    called from, so on the default group a layer's two-vector message would queue behind whichever 64 MiB gradient
+    bucket is in flight (optim.FlatSGD._launch) and the main stream would wait for it."""
     import torch.distributed as dist
-    dist.all_reduce(t)
+    from .nn import stats_group
+    dist.all_reduce(t, group=stats_group())
 
 
 # SyncBN normalises with `rows x world` as the statistics' count, i.e. it assumes every rank holds the same number of
 # pixel rows (torch's SyncBatchNorm all-gathers the counts instead). The DAS pipelines pad every batch to one size, so
-# that holds; it is CHECKED once per optimisation step — at the step's first SyncBN layer, one 2-element all-reduce —
-# rather than assumed: ranks with different padded shapes (mixed-aspect data, a short last batch) raise instead of
-# silently normalising with the wrong count.
+# that holds; it is CHECKED once per optimisation step — at the step's first SyncBN layer, one 2-element MAX all-reduce
+# on the statistics' group — rather than assumed: ranks with different padded shapes (mixed-aspect data, a short last
+# batch) raise instead of silently normalising with the wrong count. The host never waits for the answer inside the
+# forward pass: the two numbers travel to page-locked memory asynchronously and are looked at when they have arrived
+# (at a later step's first SyncBN layer, at most ROWS_CHECK_LAG steps late, or in verify_rows()).
 _rows_checked = [False]
+_rows_pending = []          # [(host tensor [max rows, max -rows], event or None, this rank's rows)]
+ROWS_CHECK_LAG = 3          # = optim.MAX_RUN_AHEAD: never the reason the launch thread stops running ahead
+
+
+def verify_rows(wait=False):
+    """Look at the row-count checks whose answers have arrived (all of them with wait=True); raises on a mismatch."""
+    while _rows_pending:
+        host, ev, rows = _rows_pending[0]
+        if ev is not None and not (wait or len(_rows_pending) > ROWS_CHECK_LAG) and not ev.query():
+            return
+        if ev is not None:
+            ev.synchronize()
+        _rows_pending.pop(0)
+        hi, lo = host.tolist()
+        if hi != -lo:
+            _rows_pending.clear()
+            raise RuntimeError(f'SyncBN: ranks hold different numbers of pixel rows (between {int(-lo)} and {int(hi)}; this '
+                               f'rank {rows}): pad the batches of all ranks to one size (Pad(size=...)) or use norm_cfg '
+                               f'type BN')
 
 
 def _check_equal_rows(rows):
@@ -226,12 +252,21 @@ def _check_equal_rows(rows):
         return
     _rows_checked[0] = True
     import torch.distributed as dist
-    t = torch.tensor([float(rows), -float(rows)], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    hi, lo = t.tolist()
-    if hi != -lo:
-        raise RuntimeError(f'SyncBN: ranks hold different numbers of pixel rows (between {int(-lo)} and {int(hi)}; this rank '
-                           f'{rows}): pad the batches of all ranks to one size (Pad(size=...)) or use norm_cfg type BN')
+    from .nn import stats_group
+    verify_rows()
+    t = torch.tensor([float(rows), -float(rows)], dtype=torch.float64)
+    if dist.get_backend() == 'nccl':
+        t = t.cuda(non_blocking=True)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=stats_group())
+    if t.is_cuda:
+        host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event(blocking=True)
+        ev.record()
+        _rows_pending.append((host, ev, rows))
+    else:            # gloo: the answer is on the host already
+        _rows_pending.append((t, None, rows))
+        verify_rows()
 
 
 # A gradient that only has to be masked by recorded bits before it is added as a residual is masked inside the adding
@@ -288,6 +323,36 @@ def _conv_stats_forward(x, conv, bn, gamma, beta):
                                          num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count, finalize_only=True)
     bn.__dict__.pop('_das_cache', None)
     return raw, mean, invstd
+
+
+def _conv_stats_forward_pair(a, b):
+    """_conv_stats_forward of two (x, conv, bn, gamma, beta) layers whose outputs are consumed together (a first
+    bottleneck's projection shortcut and its conv3, both read by ONE dual apply pass). When both are SyncBN over the same
+    ranks their statistics travel in ONE message (nn.sync_stats_many) instead of two."""
+    from .nn import bn_stats_buffer, packed_weight, sync_stats_many
+    wa, wb = _sync_world(a[2]), _sync_world(b[2])
+    if wa <= 1 or wa != wb:
+        return _conv_stats_forward(*a), _conv_stats_forward(*b)
+    raws, stats, couts = [], [], []
+    for x, conv, bn, gamma, beta in (a, b):
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
+        st = bn_stats_buffer(x, w.shape[0])
+        raws.append(ops.conv2d(x, w, k, k, s, p, stats=st))
+        stats.append(st)
+        couts.append(w.shape[0])
+    _check_equal_rows(raws[0].numel() // raws[0].shape[-1])
+    stats = sync_stats_many(stats, couts, _all_reduce)
+    out = []
+    for (x, conv, bn, gamma, beta), raw, st in zip((a, b), raws, stats):
+        rows = raw.numel() // raw.shape[-1]
+        _, mean, invstd = ops.bn_train_apply(raw, st, gamma, beta, bn.running_mean, bn.running_var,
+                                             bn.momentum if bn.momentum is not None else 0.1, bn.eps,
+                                             num_batches_tracked=bn.num_batches_tracked, stat_count=rows * wa,
+                                             finalize_only=True)
+        bn.__dict__.pop('_das_cache', None)
+        out.append((raw, mean, invstd))
+    return out[0], out[1]
 
 
 # a bottleneck's projection shortcut normalised inside bn3's apply pass (ops.bn_dual_apply); switch for A/B runs and tests
@@ -428,6 +493,8 @@ class ConvStatsFn(Function):
         from .nn import packed_weight_dgrad, packed_weight_dgrad_s2
         (x,) = ctx.saved_tensors
         k, s, p, conv = ctx.cfg
+        if draw is None:        # only the handed-through x took part in this backward (autograd.grad over selected outputs)
+            return dskip, None, None, None, None
         draw = draw.contiguous()
         dw = _wgrad(x, draw, conv.weight, k, s, p) if ctx.needs_input_grad[1] else None
         dx = None
@@ -624,8 +691,8 @@ class BottleneckChainFn(Function):
                 ds = blk.downsample
                 if DUAL_APPLY:
                     # the shortcut's normalised tensor is read by bn3's apply pass only: never written
-                    rawd, md, idd = _conv_stats_forward(xin, ds.conv, ds.bn, gd, bd)
-                    raw3, m3, i3 = _conv_stats_forward(y2, blk.conv3, blk.bn3, g3, b3)
+                    (rawd, md, idd), (raw3, m3, i3) = _conv_stats_forward_pair((xin, ds.conv, ds.bn, gd, bd),
+                                                                               (y2, blk.conv3, blk.bn3, g3, b3))
                     mb.append(ops.relu_bits_buffer(raw3) if MASK_BITS else None)
                     y3 = ops.bn_dual_apply(raw3, (m3, i3, g3, b3), rawd, (md, idd, gd, bd), relu=True, bits_out=mb[0])
                 else:

@@ -148,8 +148,10 @@ class UpsampleUnit(nn.Module):
         skip1 = skip2 = cross = None
         if self.gen_skip:
             # (train mode: normalised by their consumer, the next stage's add — nn.conv_bn_deferred / skip_add)
-            skip1 = nnops.conv_bn_deferred(x, self.out_skip1)
-            skip2, out = nnops.conv_bn_deferred(out, self.out_skip2, skip_through=True)
+            # (the fused add handles ONE statistics span for both layers: a pair that mixes SyncBN and plain BN takes
+            # the per-layer path — `partner`)
+            skip1 = nnops.conv_bn_deferred(x, self.out_skip1, partner=self.out_skip2)
+            skip2, out = nnops.conv_bn_deferred(out, self.out_skip2, skip_through=True, partner=self.out_skip1)
         if self.ind == self.num_units - 1 and self.gen_cross_conv:
             m = self.cross_conv
             cross, out = conv_bn(out, m.conv, m.norm, relu=m.with_activation, skip_through=True)

@@ -12,6 +12,7 @@
 //   normalize_pad  mmcv.imnormalize (BGR->RGB swap, (x - mean) / std) + Pad(size_divisor) + HWC->CHW (formating.py:383-442)
 // All HBM-bound elementwise / gather passes: one thread per output pixel (three channels).
 #include "common.h"
+#include "prof.h"
 
 namespace {
 constexpr int TPB = 256;
@@ -177,6 +178,7 @@ __global__ void img_normalize_pad_kernel(const float* __restrict__ src, float* _
 }  // namespace
 
 extern "C" int das_img_resize_bilinear(const float* src, float* dst, int Hs, int Ws, int Hd, int Wd, int C, void* stream) {
+  DAS_PROF(stream);
   if (!src || !dst || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1 || C < 1) return DAS_ERR_ARG;
   const double sx = 1.0 / ((double)Wd / Ws), sy = 1.0 / ((double)Hd / Hs);   // (as cv2.resize forms them)
   hipLaunchKernelGGL(img_resize_kernel, dim3(blocks_for((long long)Hd * Wd)), dim3(TPB), 0, (hipStream_t)stream, src, dst,
@@ -187,6 +189,7 @@ extern "C" int das_img_resize_bilinear(const float* src, float* dst, int Hs, int
 
 extern "C" int das_img_resize_bilinear_u8(const unsigned char* src, unsigned char* dst, int Hs, int Ws, int Hd, int Wd, int C,
                                           void* stream) {
+  DAS_PROF(stream);
   if (!src || !dst || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1 || C < 1) return DAS_ERR_ARG;
   const double sx = 1.0 / ((double)Wd / Ws), sy = 1.0 / ((double)Hd / Hs);
   hipLaunchKernelGGL(img_resize_u8_kernel, dim3(blocks_for((long long)Hd * Wd)), dim3(TPB), 0, (hipStream_t)stream, src,
@@ -196,6 +199,7 @@ extern "C" int das_img_resize_bilinear_u8(const unsigned char* src, unsigned cha
 }
 
 extern "C" int das_img_flip_horizontal(const float* src, float* dst, int H, int W, int C, void* stream) {
+  DAS_PROF(stream);
   if (!src || !dst || src == dst || H < 1 || W < 1 || C < 1) return DAS_ERR_ARG;
   hipLaunchKernelGGL(img_flip_kernel, dim3(blocks_for((long long)H * W)), dim3(TPB), 0, (hipStream_t)stream, src, dst, H, W, C);
   DAS_CHECK_LAUNCH();
@@ -203,6 +207,7 @@ extern "C" int das_img_flip_horizontal(const float* src, float* dst, int H, int 
 }
 
 extern "C" int das_img_photometric(float* img, int H, int W, const DasPhotometric* p, void* stream) {
+  DAS_PROF(stream);
   if (!img || !p || H < 1 || W < 1) return DAS_ERR_ARG;
   int seen = 0;
   for (int c = 0; c < 3; ++c) {
@@ -218,6 +223,7 @@ extern "C" int das_img_photometric(float* img, int H, int W, const DasPhotometri
 
 extern "C" int das_img_warp_affine(const float* src, float* dst, int Hs, int Ws, int Hd, int Wd, const double* M,
                                    const float* border, void* stream) {
+  DAS_PROF(stream);
   if (!src || !dst || src == dst || !M || !border || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1) return DAS_ERR_ARG;
   DasAffine a;
   // invert the 2x3 map exactly as cv::warpAffine does (double arithmetic, this order of operations)
@@ -240,6 +246,7 @@ extern "C" int das_img_warp_affine(const float* src, float* dst, int Hs, int Ws,
 
 extern "C" int das_img_normalize_pad_chw(const float* src, float* dst, int H, int W, int Hp, int Wp, const double* mean,
                                          const double* std, int to_rgb, void* stream) {
+  DAS_PROF(stream);
   if (!src || !dst || !mean || !std || H < 1 || W < 1 || Hp < H || Wp < W) return DAS_ERR_ARG;
   DasNormalize n;
   n.mean_f64 = n.std_f64 = 0;

@@ -18,6 +18,7 @@
 // A "ragged multi-level" mode (nlev > 1) lets one launch cover all FPN levels of the shared-weight
 // head convs: rows of level l start at lvStart[l] and carry their own (H, W).
 #include <algorithm>
+#include "prof.h"
 #include <cstdlib>
 
 #include "conv_common.h"
@@ -864,55 +865,9 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   DAS_STAMP(4);
 }
 
-#include "conv_persist.h"
-
 // =============================================================== launch
 using dastune::device_cus;
 using dastune::usable_cus;
-// conv_pt3_kernel (conv_persist.h): the 256 x 128 tile kernel as a persistent grid, for launches of more tiles than CUs.
-template <typename OT>
-bool try_launch_pt3(const ConvP& p0, int rows, hipStream_t s) {
-  if constexpr (sizeof(OT) != 2) {
-    return false;
-  } else {
-    const long long mint = dastune::get(dastune::CONV_PT3_MINTILES);   // 0 disables
-    ConvP p = p0;
-    const int nk = p.K / 64;
-    const long long total = (long long)((rows + 255) / 256) * p.ntiles;
-    if (mint <= 0 || total < mint || nk < 2 || p.K % 64 || p.m_base != 0 || p.up_sh != 0 || p.relu_in || p.xbytes == 0 ||
-        p.yps % 8 || (p.res && p.rps % 8) || (p.bnb_raw && p.bnb_ps % 8) || p.ntiles > 64)
-      return false;
-    const bool aff = p.scale || p.shift, bnb = p.bnb_raw != nullptr;
-    if (!bnb && p.stats && (aff || p.res || p.relu)) return false;   // (combinations no caller on the path uses)
-    if (bnb && (p.relu || aff || !p.stats)) return false;
-    long long grid = std::min<long long>(total, usable_cus());
-    grid -= grid % p.ntiles;            // a workgroup keeps its column block (the carried statistics are per channel)
-    if (grid < p.ntiles || grid < 1) return false;
-    const int mode = bnb ? ((p.bnb_relu && !p.bnb_y && !p.bnb_bits) ? 4 : 3) : p.res ? (aff ? 5 : 2) : ((aff || p.relu) ? 1 : 0);
-    // (mode 3 — three operand tensors per pixel block — is left to the one-tile kernels: on hardware its first y-mask
-    // vector of the trailing wave group came back stale although every load had been waited for with vmcnt(0) and the
-    // ISA shows no write to those registers in between; not understood, tools/dev/pt3_debug.py reproduces it)
-    if (mode == 3 || p.res_bits) return false;
-    auto go = [&](auto kern) -> bool {
-      static bool attr = false;   // (one per kernel type)
-      if (!attr) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PT3_SMEM) != hipSuccess) return false;
-        attr = true;
-      }
-      dastune::note_kernel("conv_pt3_kernel");
-      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), PT3_SMEM, s, p, (int)total);
-      return true;
-    };
-    switch (mode) {
-      case 0: return go(conv_pt3_kernel<0>);
-      case 1: return go(conv_pt3_kernel<1>);
-      case 2: return go(conv_pt3_kernel<2>);
-      case 3: return go(conv_pt3_kernel<3>);
-      case 4: return go(conv_pt3_kernel<4>);
-      default: return go(conv_pt3_kernel<5>);
-    }
-  }
-}
 // Split-K factor for a tile-kernel launch of `nblocks` workgroups with `nk` K steps (steps of 128 bytes: the 64-byte
 // steps of conv_glds4_kernel are counted in pairs): small-M, long-K layers (the 16x26 / 32x52 stages) have too few
 // tiles to fill the chip, and every K step of a lone workgroup exposes its DMA latency. The K steps are spread over
@@ -974,12 +929,6 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
   const bool big = (may_split || ks3 > 1) && glds && BN == 128 && sizeof(OT) == 2 && p.up_sh == 0 && nb3 * ks3 >= minb &&
                    p.K >= mink &&
                    p.xbytes != 0;  // (0 = more than 4 GiB of input: not addressable by 32-bit buffer offsets)
-  if constexpr (BN == 128 && sizeof(T) == 2) {
-    if (big && ks3 == 1 && may_split && try_launch_pt3<OT>(p, rows, s)) {
-      DAS_CHECK_LAUNCH();
-      return DAS_OK;
-    }
-  }
   const int bm = big ? 256 : BM;
   int mtiles = (rows + bm - 1) / bm;
   if (big && ks3 == 1) {
@@ -1557,6 +1506,7 @@ int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
 }  // namespace
 
 extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream) {
+  DAS_PROF(stream);
   if (!x || !w || !y || !d) return DAS_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->x_pix_stride % 8 || d->y_pix_stride % 8) return DAS_ERR_ARG;
   if (d->x_pix_stride < d->Cin || d->y_pix_stride < d->Cout) return DAS_ERR_ARG;

@@ -6,6 +6,7 @@
 // Thresholding before the per-level top-k is equivalent to the reference's order (top-k first,
 // threshold after concat) because the threshold is applied to the same score.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 constexpr int TPB = 1024;
@@ -437,6 +438,7 @@ extern "C" int das_decode_cap(const DasDecodeDesc* d) {
 
 extern "C" int das_decode(const DasDecodeDesc* d, float* out_scores, float* out_poses, float* out_centers,
                           int* out_index, int* out_count, void* ws, void* stream) {
+  DAS_PROF(stream);
   if (!d || !out_scores || !out_poses || !out_centers || !out_index || !out_count || !ws) return DAS_ERR_ARG;
   if (d->B < 1 || d->J < 1 || d->num_levels < 1 || d->num_levels > DAS_MAX_LEVELS || d->nms_post < 1) return DAS_ERR_ARG;
   for (int l = 0; l < d->num_levels; ++l)

@@ -1,6 +1,7 @@
 // HBM-bound NHWC helper kernels: layout pack/unpack, max-pool, bilinear / nearest upsampling,
 // adds. One 16-byte channel vector per thread (8 bf16 / 4 f32), grid-stride, fully coalesced.
 #include "common.h"
+#include "prof.h"
 #include "tuning.h"
 
 namespace {
@@ -296,6 +297,7 @@ __global__ void add3_kernel(const T* __restrict__ a, const T* __restrict__ b, co
 
 extern "C" int das_pack_nchw_to_nhwc(const float* x, void* y, int dtype, int B, int C, int H, int W, int Cpad,
                                      void* stream) {
+  DAS_PROF(stream);
   if (!x || !y || Cpad < C) return DAS_ERR_ARG;
   const long long total = (long long)B * H * W * Cpad;
   DISPATCH_T(dtype, hipLaunchKernelGGL(pack_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, x,
@@ -306,6 +308,7 @@ extern "C" int das_pack_nchw_to_nhwc(const float* x, void* y, int dtype, int B, 
 
 extern "C" int das_unpack_nhwc_to_nchw(const void* x, float* y, int dtype, int B, int C, int H, int W, int pix_stride,
                                        int c0, void* stream) {
+  DAS_PROF(stream);
   if (!x || !y || c0 + C > pix_stride) return DAS_ERR_ARG;
   const long long total = (long long)B * H * W * C;
   DISPATCH_T(dtype, hipLaunchKernelGGL(unpack_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
@@ -315,6 +318,7 @@ extern "C" int das_unpack_nhwc_to_nchw(const void* x, float* y, int dtype, int B
 }
 
 extern "C" int das_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H, int W, int C, void* stream) {
+  DAS_PROF(stream);
   if (!x || !y || C % 8) return DAS_ERR_ARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   DISPATCH_T(dtype, {
@@ -327,6 +331,7 @@ extern "C" int das_maxpool3x3s2(const void* x, void* y, int dtype, int B, int H,
 }
 
 extern "C" int das_maxpool3x3s2_argmax(const void* x, void* y, void* idx, int dtype, int B, int H, int W, int C, void* stream) {
+  DAS_PROF(stream);
   if (!x || !y || !idx || C % 8) return DAS_ERR_ARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   DISPATCH_T(dtype, {
@@ -340,6 +345,7 @@ extern "C" int das_maxpool3x3s2_argmax(const void* x, void* y, void* idx, int dt
 
 extern "C" int das_maxpool3x3s2_backward_argmax(const void* dy, const void* idx, void* dx, int dtype, int B, int H, int W, int C,
                                                 void* stream) {
+  DAS_PROF(stream);
   if (!dy || !idx || !dx || C % 8) return DAS_ERR_ARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   DISPATCH_T(dtype, {
@@ -383,18 +389,21 @@ static int launch_bilinear_ac(const void* x, void* y, int dtype, int B, int H, i
 
 extern "C" int das_upsample_bilinear_ac(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho,
                                         int Wo, void* stream) {
+  DAS_PROF(stream);
   if (!y) return DAS_ERR_ARG;
   return launch_bilinear_ac(x, y, dtype, B, H, W, C, Ho, Wo, nullptr, 1, stream);
 }
 
 extern "C" int das_upsample_bilinear_ac_stats(const void* x, void* y, int dtype, int B, int H, int W, int C, int Ho, int Wo,
                                               float* stats, int stats_slots, void* stream) {
+  DAS_PROF(stream);
   if (!stats) return DAS_ERR_ARG;
   return launch_bilinear_ac(x, y, dtype, B, H, W, C, Ho, Wo, stats, stats_slots, stream);
 }
 
 extern "C" int das_add_upsample_nearest(const void* a, const void* b, void* y, int dtype, int B, int H, int W, int C,
                                         int Hb, int Wb, void* stream) {
+  DAS_PROF(stream);
   if (!a || !b || !y || C % 8) return DAS_ERR_ARG;
   const float sh = (float)Hb / (float)H, sw = (float)Wb / (float)W;
   DISPATCH_T(dtype, {
@@ -408,6 +417,7 @@ extern "C" int das_add_upsample_nearest(const void* a, const void* b, void* y, i
 
 extern "C" int das_add3(const void* a, const void* b, const void* c, void* y, int dtype, long long n, int relu,
                         void* stream) {
+  DAS_PROF(stream);
   if (!a || !b || !y || n % 8) return DAS_ERR_ARG;
   DISPATCH_T(dtype, {
     const long long nvec = n / Elem<T>::EPV;

@@ -3,6 +3,7 @@
 // All HBM / latency bound gather work in f32 arithmetic. Every kernel works on "ragged" rows
 // (DasLevels): one launch covers all FPN levels.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 constexpr int TPB = 256;
@@ -321,6 +322,7 @@ __global__ void head_finalize_kernel(float* __restrict__ pose, float* __restrict
 
 extern "C" int das_deform_im2col3x3(const void* x, const float* om, void* col, int dtype, const DasLevels* lv, int C,
                                     int x_pix_stride, int om_pix_stride, void* stream) {
+  DAS_PROF(stream);
   if (!x || !om || !col || !lv_valid(lv) || C % 8 || x_pix_stride % 8 || om_pix_stride < 27) return DAS_ERR_ARG;
   const long long npix = lv_total_rows(*lv);
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
@@ -354,6 +356,7 @@ extern "C" int das_deform_im2col3x3(const void* x, const float* om, void* col, i
 extern "C" int das_offset_sample(const float* uvd, const float* samp_off, const float* conf, float* out,
                                  const DasLevels* lv, int J, int heads, int uvd_ps, int so_ps, int conf_ps, int out_ps,
                                  void* stream) {
+  DAS_PROF(stream);
   if (!uvd || !samp_off || !conf || !out || !lv_valid(lv) || heads != 4 || J < 1) return DAS_ERR_ARG;
   if (uvd_ps < 3 * J || conf_ps < 3 * J || out_ps < 3 * J || so_ps < 8 * J) return DAS_ERR_ARG;
   const long long total = lv_total_rows(*lv) * J;
@@ -365,6 +368,7 @@ extern "C" int das_offset_sample(const float* uvd, const float* samp_off, const 
 
 extern "C" int das_sigmoid_blend(const float* off, const float* w, const float* nxt, float* out, long long npix, int C,
                                  int off_ps, int w_ps, int nxt_ps, int out_ps, void* stream) {
+  DAS_PROF(stream);
   if (!off || !w || !nxt || !out || npix <= 0 || C < 1) return DAS_ERR_ARG;
   hipLaunchKernelGGL(sigmoid_blend_kernel, dim3(grid_for(npix * C)), dim3(TPB), 0, (hipStream_t)stream, off, w, nxt,
                      out, npix, C, off_ps, w_ps, nxt_ps, out_ps);
@@ -376,6 +380,7 @@ static bool head_desc_ok(const DasHeadDesc* d) { return d && d->J >= 1 && d->roo
 
 extern "C" int das_head_assemble(const float* raw, float* pose_pred, float* uvd_out, const DasLevels* lv,
                                  const DasHeadDesc* d, void* stream) {
+  DAS_PROF(stream);
   if (!raw || !pose_pred || !uvd_out || !lv_valid(lv) || !head_desc_ok(d)) return DAS_ERR_ARG;
   const long long npix = lv_total_rows(*lv);
   hipLaunchKernelGGL(head_assemble_kernel, dim3(grid_for(npix * (3 + 6 * d->J))), dim3(TPB), 0, (hipStream_t)stream,
@@ -386,6 +391,7 @@ extern "C" int das_head_assemble(const float* raw, float* pose_pred, float* uvd_
 
 extern "C" int das_head_finalize(float* pose_pred, float* ref_uvd, const DasLevels* lv, const DasHeadDesc* d,
                                  int ref_ps, int eval_mode, void* stream) {
+  DAS_PROF(stream);
   if (!pose_pred || !ref_uvd || !lv_valid(lv) || !head_desc_ok(d) || ref_ps < 3 * d->J) return DAS_ERR_ARG;
   const long long npix = lv_total_rows(*lv);
   hipLaunchKernelGGL(head_finalize_kernel, dim3(grid_for(npix * (3 * d->J + 1))), dim3(TPB), 0, (hipStream_t)stream,

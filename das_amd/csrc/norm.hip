@@ -1,6 +1,7 @@
 // Normalisation kernels over NHWC: train-mode BatchNorm finalize/apply and GroupNorm(+ReLU).
 // All HBM-bound; statistics in f32.
 #include <algorithm>
+#include "prof.h"
 
 #include "common.h"
 #include "tuning.h"
@@ -395,6 +396,7 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
                                   float momentum, float eps, const void* residual, int relu, float* save_mean,
                                   float* save_invstd, long long* num_batches_tracked, long long stat_count,
                                   int stats_slots, void* relu_bits_out, void* stream) {
+  DAS_PROF(stream);
   unsigned char* bits = (unsigned char*)relu_bits_out;
   if (!x || !stats || !gamma || !beta || !save_mean || !save_invstd || C % 8 || count <= 0) return DAS_ERR_ARG;
   if (dtype != DAS_BF16 && dtype != DAS_F32) return DAS_ERR_ARG;
@@ -463,6 +465,7 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
 extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLevels* lv, int C, int pix_stride,
                                   int G, const float* gamma, const float* beta, float eps, int relu, float* stats_ws,
                                   void* stream) {
+  DAS_PROF(stream);
   if (!x || !y || !gamma || !beta || !stats_ws || !lv_valid(lv) || C % 8 || C % G || pix_stride % 8 || C > 2048)
     return DAS_ERR_ARG;
   const int epv = dtype == DAS_BF16 ? 8 : 4;

@@ -10,6 +10,7 @@
 //   apply    one sweep over g, raw1, raw2 -> d raw_i = gamma_i invstd_i (g_i - sum g_i / N - xhat_i sum g_i xhat_i / N)
 // against two reduce passes (two reads each) and two apply passes (two reads, one write each).
 #include "common.h"
+#include "prof.h"
 #include "tuning.h"
 
 #include <algorithm>
@@ -241,6 +242,7 @@ static bool par_ok(const float* const* p) {
 
 extern "C" int das_bn_relu_add3_forward(const void* x, const void* raw1, const void* raw2, void* out, int dtype, long long rows,
                                         int C, const float* const* bn, void* stream) {
+  DAS_PROF(stream);
   if (!x || !raw1 || !raw2 || !out || !bn || !par_ok(bn) || rows < 1 || C % 8 || C < 8 || C > 4096) return DAS_ERR_ARG;
   const int vc = C / (dtype == DAS_F32 ? 4 : 8);
   const int pl = TPB / (vc < TPB ? vc : TPB);
@@ -258,6 +260,7 @@ extern "C" int das_bn_relu_add3_forward(const void* x, const void* raw1, const v
 
 extern "C" int das_bn_dual_apply(const void* raw1, const void* raw2, void* out, int dtype, long long rows, int C,
                                  const float* const* bn, int relu, void* relu_bits_out, void* stream) {
+  DAS_PROF(stream);
   if (!raw1 || !raw2 || !out || !bn || !par_ok(bn) || rows < 1 || C % 8 || C < 8 || C > 4096) return DAS_ERR_ARG;
   const int vc = C / (dtype == DAS_F32 ? 4 : 8);
   const int pl = TPB / (vc < TPB ? vc : TPB);
@@ -278,6 +281,7 @@ extern "C" int das_bn_relu_add3_backward(const void* g, const void* raw1, const 
                                          long long stat_rows,
                                          float* dgamma1_acc, float* dbeta1_acc, float* dgamma2_acc, float* dbeta2_acc,
                                          int phase, void* stream) {
+  DAS_PROF(stream);
   if (phase < 0 || phase > 2) return DAS_ERR_ARG;
   if (!g || !raw1 || !raw2 || ((!draw1 || !draw2) && phase != 1) || !bn || !par_ok(bn) || !sums || rows < 1 || stat_rows < 1 || C % 8 || C < 8 ||
       C > 4096)

@@ -3,6 +3,7 @@
 // 16-byte channel vector of the gradient it produces), so results are deterministic and need no atomics
 // except the per-channel / per-group statistic reductions.
 #include <algorithm>
+#include "prof.h"
 
 #include "common.h"
 #include "tuning.h"
@@ -478,6 +479,7 @@ extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void*
                                       const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
                                       const float* gamma, const float* beta, float eps, int relu, float* gsums_ws,
                                       float* dgamma, float* dbeta, void* stream) {
+  DAS_PROF(stream);
   return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, beta, eps, relu, gsums_ws,
                                  dgamma, dbeta, false, stream);
 }
@@ -485,12 +487,14 @@ extern "C" int das_groupnorm_backward_acc(const void* dy, const void* y, const v
                                           const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
                                           const float* gamma, const float* beta, float eps, int relu, float* gsums_ws,
                                           float* dgamma, float* dbeta, void* stream) {
+  DAS_PROF(stream);
   return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, beta, eps, relu, gsums_ws,
                                  dgamma, dbeta, true, stream);
 }
 
 extern "C" int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W,
                                          int C, void* stream) {
+  DAS_PROF(stream);
   if (!x || !dy || !dx || C % 8) return DAS_ERR_ARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   DISPATCH_T(dtype, {
@@ -504,6 +508,7 @@ extern "C" int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx
 
 extern "C" int das_upsample_bilinear_ac_backward(const void* dy, void* dx, int dtype, int B, int H, int W, int C,
                                                  int Ho, int Wo, void* stream) {
+  DAS_PROF(stream);
   if (!dy || !dx || C % 8) return DAS_ERR_ARG;
   const float sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
   const float sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -531,6 +536,7 @@ extern "C" int das_upsample_bilinear_ac_backward(const void* dy, void* dx, int d
 
 extern "C" int das_upsample_nearest_backward(const void* dy, void* db, int dtype, int B, int H, int W, int C, int Hb,
                                              int Wb, void* stream) {
+  DAS_PROF(stream);
   if (!dy || !db || C % 8) return DAS_ERR_ARG;
   const float sh = (float)Hb / (float)H, sw = (float)Wb / (float)W;
   DISPATCH_T(dtype, {

@@ -20,6 +20,7 @@
 //             rows of (delta, activation) pairs, parked in LDS, are reduced per weight: one atomic per weight per block.
 // params per flow (f32): layer i = [t-net | s-net], net = W1[64][D] b1[64] W2[64][64] b2[64] W3[D][64] b3[D].
 #include "common.h"
+#include "prof.h"
 
 namespace {
 constexpr int FH = 64;          // hidden width
@@ -361,6 +362,7 @@ static bool jobs_ok(const DasFlowJob* jobs, int njobs, int rows_total, bool back
 
 extern "C" int das_realnvp_log_prob_multi(const float* x, int rows_total, int D, const DasFlowJob* jobs, int njobs,
                                           int layers, unsigned mask_bits, float* logp, float* z_out, void* stream) {
+  DAS_PROF(stream);
   if (!x || !logp || !z_out || rows_total < 1 || layers < 1 || layers * D > 32 || (D != 2 && D != 3)) return DAS_ERR_ARG;
   if (!jobs_ok(jobs, njobs, rows_total, false)) return DAS_ERR_ARG;
   FlowJobs fj;
@@ -381,6 +383,7 @@ extern "C" int das_realnvp_log_prob_multi(const float* x, int rows_total, int D,
 extern "C" int das_realnvp_log_prob_multi_backward(const float* z_final, const float* grad_logp, int rows_total, int D,
                                                    const DasFlowJob* jobs, int njobs, int layers, unsigned mask_bits,
                                                    float* dx, void* stream) {
+  DAS_PROF(stream);
   if (!z_final || !grad_logp || !dx || rows_total < 1 || layers < 1 || layers * D > 32 || (D != 2 && D != 3))
     return DAS_ERR_ARG;
   if (!jobs_ok(jobs, njobs, rows_total, true)) return DAS_ERR_ARG;
@@ -413,6 +416,7 @@ extern "C" int das_realnvp_log_prob_multi_backward(const float* z_final, const f
 
 extern "C" int das_realnvp_log_prob(const float* x, int N, int D, const float* params, int layers, unsigned mask_bits,
                                     float* logp, float* z_out, void* stream) {
+  DAS_PROF(stream);
   DasFlowJob j;
   j.params = params; j.dparams = nullptr; j.dst_table = nullptr; j.row_start = 0; j.row_end = N;
   return das_realnvp_log_prob_multi(x, N, D, &j, 1, layers, mask_bits, logp, z_out, stream);
@@ -421,6 +425,7 @@ extern "C" int das_realnvp_log_prob(const float* x, int N, int D, const float* p
 extern "C" int das_realnvp_log_prob_backward(const float* z_final, const float* grad_logp, int N, int D,
                                              const float* params, int layers, unsigned mask_bits, float* dx,
                                              float* dparams, float* const* dst_table, void* stream) {
+  DAS_PROF(stream);
   DasFlowJob j;
   j.params = params; j.dparams = dparams; j.dst_table = dst_table; j.row_start = 0; j.row_end = N;
   return das_realnvp_log_prob_multi_backward(z_final, grad_logp, N, D, &j, 1, layers, mask_bits, dx, stream);

@@ -3,6 +3,7 @@
 // Scatter-type gradients accumulate in f32 with atomics (as mmcv's col2im does); the caller
 // hands zeroed f32 buffers.
 #include "common.h"
+#include "prof.h"
 
 #ifndef DAS_DCN_TG
 #define DAS_DCN_TG 3   // taps per load group of deform_col2im_kernel (1, 3 or 9)
@@ -479,6 +480,7 @@ __global__ void head_assemble_bwd_kernel(const float* __restrict__ raw, const fl
 extern "C" int das_deform_im2col3x3_backward(const void* x, const float* om, const void* dcol, float* dx, float* dom,
                                              int dtype, const DasLevels* lv, int C, int x_pix_stride,
                                              int om_pix_stride, int dom_pix_stride, void* stream) {
+  DAS_PROF(stream);
   if (!x || !om || !dcol || !dx || !dom || !lv_valid(lv) || C % 8 || x_pix_stride % 8 || om_pix_stride < 27 ||
       dom_pix_stride < 27)
     return DAS_ERR_ARG;
@@ -515,6 +517,7 @@ extern "C" int das_offset_sample_backward(const float* uvd, const float* samp_of
                                           const float* grad_out, float* d_uvd, float* d_samp_off, float* d_conf,
                                           const DasLevels* lv, int J, int heads, int uvd_ps, int so_ps, int conf_ps,
                                           int gout_ps, void* stream) {
+  DAS_PROF(stream);
   if (!uvd || !samp_off || !conf || !grad_out || !d_uvd || !d_samp_off || !d_conf || !lv_valid(lv) || heads != 4 ||
       J < 1)
     return DAS_ERR_ARG;
@@ -528,6 +531,7 @@ extern "C" int das_offset_sample_backward(const float* uvd, const float* samp_of
 extern "C" int das_sigmoid_blend_backward(const float* off, const float* w, const float* nxt, const float* grad_out,
                                           float* d_off, float* d_w, float* d_nxt, long long npix, int C, int off_ps,
                                           int w_ps, int nxt_ps, void* stream) {
+  DAS_PROF(stream);
   if (!off || !w || !nxt || !grad_out || !d_off || !d_w || !d_nxt || npix <= 0 || C < 1) return DAS_ERR_ARG;
   hipLaunchKernelGGL(sigmoid_blend_bwd_kernel, dim3(grid_for(npix * C)), dim3(TPB), 0, (hipStream_t)stream, off, w, nxt,
                      grad_out, d_off, d_w, d_nxt, npix, C, off_ps, w_ps, nxt_ps);
@@ -537,6 +541,7 @@ extern "C" int das_sigmoid_blend_backward(const float* off, const float* w, cons
 
 extern "C" int das_head_assemble_backward(const float* raw, const float* d_pose, const float* d_uvd, float* d_raw,
                                           float* d_scale, const DasLevels* lv, const DasHeadDesc* d, void* stream) {
+  DAS_PROF(stream);
   if (!raw || !d_pose || !d_uvd || !d_raw || !d_scale || !lv_valid(lv) || !d || d->J < 1) return DAS_ERR_ARG;
   const long long npix = lv_total_rows(*lv);
   hipStream_t s = (hipStream_t)stream;

@@ -1,6 +1,7 @@
 // Dense-head training kernels: point-to-person target assignment, sigmoid focal loss, SmoothL1 / BCE on
 // the positives, and the optimizer side (global grad norm, fused SGD-momentum with clipping).
 #include <algorithm>
+#include "prof.h"
 
 #include "common.h"
 
@@ -189,6 +190,7 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 
 extern "C" int das_assign_targets(const DasLevels* lv, const DasTargetDesc* d, const float* gt, const float* centers,
                                   const int* gt_start, int* labels, float* targets, float* centerness, void* stream) {
+  DAS_PROF(stream);
   if (!lv_valid(lv) || !d || !gt_start || !labels || !targets || !centerness || d->J < 1) return DAS_ERR_ARG;
   const long long rows = lv_total_rows(*lv);
   hipLaunchKernelGGL(assign_targets_kernel, dim3(grid_for(rows)), dim3(TPB), 0, (hipStream_t)stream, *lv, *d, gt,
@@ -200,6 +202,7 @@ extern "C" int das_assign_targets(const DasLevels* lv, const DasTargetDesc* d, c
 extern "C" int das_sigmoid_focal_loss(const float* logits, int pix_stride, const int* labels, const float* weight,
                                       long long rows, float gamma, float alpha, float* grad, float* loss_sum,
                                       void* stream) {
+  DAS_PROF(stream);
   if (!logits || !labels || !grad || !loss_sum || rows <= 0) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return DAS_ERR_LAUNCH;
@@ -211,6 +214,7 @@ extern "C" int das_sigmoid_focal_loss(const float* logits, int pix_stride, const
 
 extern "C" int das_smooth_l1_loss(const float* pred, const float* target, const float* weight, long long n, float beta,
                                   float* grad, float* loss_sum, void* stream) {
+  DAS_PROF(stream);
   if (!pred || !target || !grad || !loss_sum || n <= 0 || beta <= 0.f) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return DAS_ERR_LAUNCH;
@@ -222,6 +226,7 @@ extern "C" int das_smooth_l1_loss(const float* pred, const float* target, const 
 
 extern "C" int das_bce_logits_loss(const float* logits, const float* target, const float* weight, long long n,
                                    float* grad, float* loss_sum, void* stream) {
+  DAS_PROF(stream);
   if (!logits || !target || !grad || !loss_sum || n <= 0) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return DAS_ERR_LAUNCH;
@@ -232,6 +237,7 @@ extern "C" int das_bce_logits_loss(const float* logits, const float* target, con
 }
 
 extern "C" int das_grad_sumsq(const float* g, long long n, float* out, int zero_first, void* stream) {
+  DAS_PROF(stream);
   if (!g || !out || n <= 0) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* partials = nullptr;
@@ -246,6 +252,7 @@ extern "C" int das_grad_sumsq(const float* g, long long n, float* out, int zero_
 extern "C" int das_sgd_momentum_step(float* p, const float* g, float* buf, long long n, float lr, float momentum,
                                      float weight_decay, float grad_scale, float max_norm, const float* grad_sumsq,
                                      int first_step, void* stream) {
+  DAS_PROF(stream);
   if (!p || !g || !buf || n <= 0) return DAS_ERR_ARG;
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 8192)), dim3(TPB), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum,
                      weight_decay, grad_scale, max_norm, grad_sumsq, first_step);

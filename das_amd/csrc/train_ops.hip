@@ -7,6 +7,7 @@
 //                         fragments are single dwords, so no transpose is needed.
 //   BatchNorm (train) backward, GroupNorm backward, column sums (bias gradients).
 #include <algorithm>
+#include "prof.h"
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,23 @@ struct WG<float> {
   static constexpr int ROWB = 512;
   static __device__ __forceinline__ int swz(int slot, int row) { return slot; }
 };
+// 16-byte slot of a staged row -> slot it is stored in, for rows of ROWB bytes (bf16 tiles of 64 / 128 / 256 channels; f32
+// tiles are not swizzled). A transposing fragment read (ds_read_b64_tr_b16) touches 16 rows x 32 bytes; eight consecutive
+// rows must land on eight different 32-byte columns of the 256 bytes the banks span: rows of 256 or 512 bytes all start on
+// bank 0, so the row's low three bits rotate the 32-byte column; with 128-byte rows two rows share the banks already and
+// the remaining two bits do.
+template <typename T, int ROWB>
+__device__ __forceinline__ int swz_rb(int slot, int row) {
+  if constexpr (sizeof(T) != 2) return slot;
+  else if constexpr (ROWB == 128) return slot ^ (((row >> 1) & 3) << 1);
+  else return slot ^ ((row & 7) << 1);
+}
+// conv_wgrad_kernel's (Cout x K) tile is four waves of 64 x 64 in one of three arrangements, picked per op on the host
+// (wgrad_prepare): 128 x 128 (waves 2 x 2), 64 x 256 (1 x 4: layers with <= 64 output channels — the 128-wide Cout tile
+// was half empty) and 256 x 64 (4 x 1: K = 64, the 1x1 convs with 64 input channels). Same 16 384 accumulators per
+// workgroup in every arrangement, so partial tiles of all three share one workspace layout and one reduce kernel.
+__host__ __device__ inline int shape_to(int shape) { return shape == 1 ? 64 : shape == 2 ? 256 : 128; }
+__host__ __device__ inline int shape_tn(int shape) { return shape == 1 ? 256 : shape == 2 ? 64 : 128; }
 
 // The pixel-row reduction advances every staged row by a constant each step, and the rows ONE wave stages per
 // step are ROWS consecutive pixel rows. So a single wave-uniform walker (scalar registers, SALU) follows the
@@ -133,26 +151,24 @@ template <int WAVES_, int TA_>
 struct AccMap {   // register order of a workgroup tile: slot = ((wave * TA + a) * 4 + b) * 64 + lane, float4 = j
   static constexpr int WAVES = WAVES_, TA = TA_, SLOTS = WAVES_ * TA_ * 4 * 64;
 };
-struct AccMap128 : AccMap<4, 4> {   // conv_wgrad_kernel: 128 x 128, waves 2 x 2 of 64 x 64
-  static constexpr int TILE = 128;
-  static __device__ __forceinline__ int wave_o(int wave) { return (wave >> 1) * 64; }
-  static __device__ __forceinline__ int wave_n(int wave) { return (wave & 1) * 64; }
+struct AccMap128 : AccMap<4, 4> {   // conv_wgrad_kernel: four waves of 64 x 64 as 128 x 128 / 64 x 256 / 256 x 64 (shape 0 / 1 / 2)
+  static __device__ __forceinline__ int wave_o(int wave, int shape) { return shape == 0 ? (wave >> 1) * 64 : shape == 1 ? 0 : wave * 64; }
+  static __device__ __forceinline__ int wave_n(int wave, int shape) { return shape == 0 ? (wave & 1) * 64 : shape == 1 ? wave * 64 : 0; }
 };
 struct AccMap256 : AccMap<8, 8> {   // conv_wgrad_pp_kernel: 256 x 256, waves 2 x 4 of 128 x 64
-  static constexpr int TILE = 256;
-  static __device__ __forceinline__ int wave_o(int wave) { return (wave & 1) * 128; }
-  static __device__ __forceinline__ int wave_n(int wave) { return (wave >> 2) * 128 + ((wave >> 1) & 1) * 64; }
+  static __device__ __forceinline__ int wave_o(int wave, int) { return (wave & 1) * 128; }
+  static __device__ __forceinline__ int wave_n(int wave, int) { return (wave >> 2) * 128 + ((wave >> 1) & 1) * 64; }
 };
 template <typename MAP, int TA>
 __device__ __forceinline__ void store_partial_tile(float* ws, int split, int tiles, int tile, int wave, int lane,
-                                                   int o_left, int n_left, const f32x4_t (&acc)[TA][4]) {
+                                                   int o_left, int n_left, const f32x4_t (&acc)[TA][4], int shape = 0) {
   f32x4_t* dst = reinterpret_cast<f32x4_t*>(ws) + ((size_t)split * tiles + tile) * MAP::SLOTS + wave * (TA * 4 * 64) + lane;
 #pragma unroll
   for (int a = 0; a < TA; ++a) {
-    if (MAP::wave_o(wave) + a * 16 >= o_left) break;   // rows past Cout / columns past K: never read back
+    if (MAP::wave_o(wave, shape) + a * 16 >= o_left) break;   // rows past Cout / columns past K: never read back
 #pragma unroll
     for (int b = 0; b < 4; ++b)
-      if (MAP::wave_n(wave) + b * 16 < n_left) dst[(a * 4 + b) * 64] = acc[a][b];
+      if (MAP::wave_n(wave, shape) + b * 16 < n_left) dst[(a * 4 + b) * 64] = acc[a][b];
   }
 }
 // ---- many weight gradients in ONE persistent launch, scheduled on the host ----
@@ -178,6 +194,7 @@ struct WgradOpS {        // geometry of one op (device table)
   int nlev, B;
   int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];
   int tiles;
+  int shape;            // conv_wgrad_kernel: wave arrangement of this op's tiles (shape_to / shape_tn)
 };
 struct WgradUnit {
   int op, tile;
@@ -216,9 +233,9 @@ __device__ __forceinline__ void wgrad_load_unit(const WgradSched& g, const Wgrad
 // 128 load -> wait -> add -> store round trips per lane); wave tiles that overhang Cout / K take the per-element path.
 template <typename MAP, int TA>
 __device__ __forceinline__ void store_direct_tile(float* dw, int K, int Cout, int o0, int n0, int wave, int lane,
-                                                  int accumulate, const f32x4_t (&acc)[TA][4]) {
+                                                  int accumulate, const f32x4_t (&acc)[TA][4], int shape = 0) {
   const int q = lane & 15, g4 = lane >> 4;
-  const int wo = o0 + MAP::wave_o(wave), wn = n0 + MAP::wave_n(wave);
+  const int wo = o0 + MAP::wave_o(wave, shape), wn = n0 + MAP::wave_n(wave, shape);
   if (wo + TA * 16 <= Cout && wn + 64 <= K) {
     float* base = dw + (size_t)(wo + g4 * 4) * K + wn + q;
 #pragma unroll
@@ -260,7 +277,8 @@ struct WgradRedJob {
   int op, o0, n0;       // tile origin
   int base, splits;     // partial tiles base .. base + splits of the workspace
   int groups;           // reduce groups (> 1: atomics into a zeroed / accumulating dW)
-  int pad_[2];
+  int shape;            // wave arrangement of the tile (conv_wgrad_kernel: 0 / 1 / 2; 0 for the ping-pong kernel)
+  int pad_[1];
 };
 struct WgradRedArgs {
   const WgradRedJob* jobs;
@@ -284,9 +302,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradRedArgs g) {
   const int Cout = g.ops[jb.op].Cout, K = g.ops[jb.op].K;
   const int slot = bx * 256 + threadIdx.x;
   const int lane = slot & 63, b = (slot >> 6) & 3, a = (slot >> 8) % MAP::TA, wave = slot / (MAP::TA * 256);
-  const int o0 = jb.o0 + MAP::wave_o(wave) + a * 16 + (lane >> 4) * 4;
-  const int n = jb.n0 + MAP::wave_n(wave) + b * 16 + (lane & 15);
-  if (jb.o0 + MAP::wave_o(wave) + a * 16 >= Cout || n >= K) return;
+  const int o0 = jb.o0 + MAP::wave_o(wave, jb.shape) + a * 16 + (lane >> 4) * 4;
+  const int n = jb.n0 + MAP::wave_n(wave, jb.shape) + b * 16 + (lane & 15);
+  if (jb.o0 + MAP::wave_o(wave, jb.shape) + a * 16 >= Cout || n >= K) return;
   const int per = (jb.splits + jb.groups - 1) / jb.groups;
   const int s0 = grp * per, s1 = min(jb.splits, s0 + per);
   const f32x4_t* src = reinterpret_cast<const f32x4_t*>(g.ws) + (size_t)jb.base * MAP::SLOTS + slot;
@@ -308,28 +326,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradRedArgs g) {
   }
 }
 
-// p.x = forward input X, p.res = dY (pixel stride p.rps), p.y = the workspace the partial tiles are stored to.
-template <typename T, int BKM>   // BKM = pixel rows per step
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSched sch_) {
-  const int u_end = sch_.first[blockIdx.x + 1];
-  for (int ui = sch_.first[blockIdx.x]; ui < u_end; ++ui) {   // (body indented as the single-unit kernel it grew from)
-  const WgradUnit& un = sch_.units[ui];
-  ConvP p;
-  float* dw;
-  wgrad_load_unit(sch_, un, p, dw);
+// One unit (tile x run of pixel steps) of conv_wgrad_kernel. p.x = forward input X, p.res = dY (pixel stride p.rps).
+// SHAPE: the tile's wave arrangement (shape_to x shape_tn; f32 runs 128 x 128 only). The dY tile (BKM rows x TO channels)
+// and the im2col'd X tile (BKM rows x TN columns) are DMA'd row-major, 1 KiB per wave instruction — rows of 128 / 256 /
+// 512 bytes, i.e. 8 / 4 / 2 rows per instruction —; wave w stages rows [w BKM/4, (w + 1) BKM/4) of BOTH tiles, so one
+// wave-uniform row walker serves both.
+template <typename T, int BKM, int SHAPE>   // BKM = pixel rows per step
+__device__ __forceinline__ void wgrad_unit(const WgradSched& sch_, const WgradUnit& un, const ConvP& p, float* dw, char* smem) {
   constexpr int EPV = Elem<T>::EPV;
-  constexpr int ROWB = WG<T>::ROWB, SLOTS = ROWB / 16;
-  constexpr int TILE = BKM * ROWB;             // bytes per operand tile
-  constexpr int RPI = 1024 / ROWB;             // rows per wave-instruction
-  constexpr int IPW = BKM / RPI / 4;           // DMA instructions per wave per tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TO = SHAPE == 1 ? 64 : SHAPE == 2 ? 256 : 128, TN = SHAPE == 1 ? 256 : SHAPE == 2 ? 64 : 128;
+  constexpr int ROWB_D = TO * (int)sizeof(T), ROWB_X = TN * (int)sizeof(T);
+  constexpr int SLOTS_D = ROWB_D / 16, SLOTS_X = ROWB_X / 16;
+  constexpr int TILE_D = BKM * ROWB_D, TILE_X = BKM * ROWB_X;   // bytes per operand tile
+  constexpr int RPI_D = 1024 / ROWB_D, RPI_X = 1024 / ROWB_X;   // rows per wave-instruction
+  constexpr int ROWS = BKM / 4;                                 // rows a wave stages per step
+  constexpr int IPW_D = ROWS / RPI_D, IPW_X = ROWS / RPI_X;     // DMA instructions per wave per tile
+  static_assert(IPW_D >= 1 && IPW_X >= 1, "tile rows");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = (p.K + 127) / 128;
+  const int ntiles = (p.K + TN - 1) / TN;
   const int tile = un.tile;
-  const int o0 = (tile / ntiles) * 128, n0 = (tile % ntiles) * 128;
-  const int wave_o0 = (wave >> 1) * 64, wave_n0 = (wave & 1) * 64;
+  const int o0 = (tile / ntiles) * TO, n0 = (tile % ntiles) * TN;
+  const int wave_o0 = AccMap128::wave_o(wave, SHAPE), wave_n0 = AccMap128::wave_n(wave, SHAPE);
   const long long m_begin = (long long)un.step0 * BKM;
 
   const T* xg = reinterpret_cast<const T*>(p.x);
@@ -338,17 +357,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSched sch_) {
 
   // per (lane, instruction) constants: dY pointer of the current row, X column -> (tap, ci); plus the row walker
   // (wave-uniform: the first of the ROWS consecutive rows this wave stages)
-  constexpr int ROWS = IPW * RPI;
-  int xkh[IPW], xkw[IPW], xci[IPW];
-  bool ook[IPW], nok[IPW];
-  const T* dcur[IPW];
-  const int d0 = lane / SLOTS;
+  bool ook[IPW_D];
+  const T* dcur[IPW_D];
+  const int d0d = lane / SLOTS_D, d0x = lane / SLOTS_X;
 #pragma unroll
-  for (int j = 0; j < IPW; ++j) {
-    const int row = (wave * IPW + j) * RPI + d0;
-    const int logical = WG<T>::swz(lane % SLOTS, row);
+  for (int j = 0; j < IPW_D; ++j) {
+    const int row = wave * ROWS + j * RPI_D + d0d;
+    const int logical = swz_rb<T, ROWB_D>(lane % SLOTS_D, row);
     ook[j] = o0 + logical * EPV < p.Cout;
     dcur[j] = dyg + (m_begin + row) * p.rps + o0 + logical * EPV;
+  }
+  int xkh[IPW_X], xkw[IPW_X], xci[IPW_X];
+  bool nok[IPW_X];
+#pragma unroll
+  for (int j = 0; j < IPW_X; ++j) {
+    const int row = wave * ROWS + j * RPI_X + d0x;
+    const int logical = swz_rb<T, ROWB_X>(lane % SLOTS_X, row);
     const int n = n0 + logical * EPV;
     nok[j] = n < p.K;
     const int tap = n / p.Cin;
@@ -362,18 +386,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSched sch_) {
   const long long dstep = (long long)BKM * p.rps;
 
   auto issue = [&](int buf) {  // DMA the tiles of the walker's current rows, then advance it one step
-    char* sD = smem + buf * 2 * TILE;
-    char* sX = sD + TILE;
+    char* sD = smem + buf * (TILE_D + TILE_X);
+    char* sX = sD + TILE_D;
     auto stage = [&](auto in_plane) {
+      constexpr bool IN = decltype(in_plane)::value;
 #pragma unroll
-      for (int j = 0; j < IPW; ++j) {
-        const LaneRow lr = lane_row<decltype(in_plane)::value>(p, rw, j * RPI + d0);
-        dma16((lr.ok && ook[j]) ? dcur[j] : zero, sD + (wave * IPW + j) * 1024);
+      for (int j = 0; j < IPW_D; ++j) {
+        const bool ok = IN ? true : rw.m + j * RPI_D + d0d < p.M;
+        dma16((ok && ook[j]) ? dcur[j] : zero, sD + (wave * IPW_D + j) * 1024);
         dcur[j] += dstep;
+      }
+#pragma unroll
+      for (int j = 0; j < IPW_X; ++j) {
+        const LaneRow lr = lane_row<IN>(p, rw, j * RPI_X + d0x);
         const int hi = lr.hi0 + xkh[j], wi = lr.wi0 + xkw[j];
         const bool ok = lr.ok && nok[j] && (unsigned)hi < (unsigned)lr.H && (unsigned)wi < (unsigned)lr.W;
         const T* sx = ok ? xg + (lr.pix0 + hi * lr.W + wi) * p.xps + xci[j] : zero;
-        dma16(sx, sX + (wave * IPW + j) * 1024);
+        dma16(sx, sX + (wave * IPW_X + j) * 1024);
       }
     };
     if (__builtin_expect(rows_in_plane<ROWS>(p, rw), 1)) {
@@ -397,8 +426,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSched sch_) {
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
     if (s + 1 < nsteps) issue(buf ^ 1);
-    const char* sD = smem + buf * 2 * TILE;
-    const char* sX = sD + TILE;
+    const char* sD = smem + buf * (TILE_D + TILE_X);
+    const char* sX = sD + TILE_D;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int half = 0; half < BKM / 32; ++half) {
@@ -411,11 +440,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSched sch_) {
             const int row = half * 32 + h * 16 + g4 * 4 + (q >> 2);
             const int sub = q & 3;
             const int ca = wave_o0 + t * 16, cb = wave_n0 + t * 16;
-            const int sa = WG<T>::swz((ca >> 3) + (sub >> 1), row), sb = WG<T>::swz((cb >> 3) + (sub >> 1), row);
+            const int sa = swz_rb<T, ROWB_D>((ca >> 3) + (sub >> 1), row), sb = swz_rb<T, ROWB_X>((cb >> 3) + (sub >> 1), row);
             lo[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) v4i16_t*)(sD + row * ROWB + sa * 16 + (sub & 1) * 8));
+                (__attribute__((address_space(3))) v4i16_t*)(sD + row * ROWB_D + sa * 16 + (sub & 1) * 8));
             hi[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) v4i16_t*)(sX + row * ROWB + sb * 16 + (sub & 1) * 8));
+                (__attribute__((address_space(3))) v4i16_t*)(sX + row * ROWB_X + sb * 16 + (sub & 1) * 8));
           }
           fa[t] = make_uint4(__builtin_bit_cast(uint2, lo[0]).x, __builtin_bit_cast(uint2, lo[0]).y,
                              __builtin_bit_cast(uint2, lo[1]).x, __builtin_bit_cast(uint2, lo[1]).y);
@@ -436,8 +465,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSched sch_) {
         const int row = kk * 4 + g4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          fa[t] = *reinterpret_cast<const float*>(sD + row * ROWB + (wave_o0 + t * 16 + q) * 4);
-          fb[t] = *reinterpret_cast<const float*>(sX + row * ROWB + (wave_n0 + t * 16 + q) * 4);
+          fa[t] = *reinterpret_cast<const float*>(sD + row * ROWB_D + (wave_o0 + t * 16 + q) * 4);
+          fb[t] = *reinterpret_cast<const float*>(sX + row * ROWB_X + (wave_n0 + t * 16 + q) * 4);
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -449,11 +478,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradSched sch_) {
   }
 
   if (un.dest >= 0) {
-    store_partial_tile<AccMap128>(sch_.ws, un.dest, 1, 0, wave, lane, p.Cout - o0, p.K - n0, acc);
+    store_partial_tile<AccMap128>(sch_.ws, un.dest, 1, 0, wave, lane, p.Cout - o0, p.K - n0, acc, SHAPE);
   } else {
-    store_direct_tile<AccMap128>(dw, p.K, p.Cout, o0, n0, wave, lane, sch_.accumulate, acc);
+    store_direct_tile<AccMap128>(dw, p.K, p.Cout, o0, n0, wave, lane, sch_.accumulate, acc, SHAPE);
   }
-  }   // next unit (every wave is past the last step's barrier: the LDS buffers are free)
+}
+
+// (second bound: three waves per SIMD = three workgroups per CU, the occupancy the 32-row steps were chosen for: at most 168 registers)
+template <typename T, int BKM>
+__global__ __launch_bounds__(256, BKM == 32 ? 3 : 2) void conv_wgrad_kernel(WgradSched sch_) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int u_end = sch_.first[blockIdx.x + 1];
+  for (int ui = sch_.first[blockIdx.x]; ui < u_end; ++ui) {
+    const WgradUnit& un = sch_.units[ui];
+    ConvP p;
+    float* dw;
+    wgrad_load_unit(sch_, un, p, dw);
+    if constexpr (sizeof(T) == 2) {
+      const int shape = __builtin_amdgcn_readfirstlane(sch_.ops[un.op].shape);
+      if (shape == 1) wgrad_unit<T, BKM, 1>(sch_, un, p, dw, smem);
+      else if (shape == 2) wgrad_unit<T, BKM, 2>(sch_, un, p, dw, smem);
+      else wgrad_unit<T, BKM, 0>(sch_, un, p, dw, smem);
+    } else {
+      wgrad_unit<T, BKM, 0>(sch_, un, p, dw, smem);
+    }
+    // next unit (every wave is past the last step's barrier: the LDS buffers are free)
+  }
 }
 
 // Weight gradient of the 3x3, stride-1, 64 -> 64 channel convs (conv2 of the 128 x 208 stage's bottlenecks, 12 per train
@@ -1095,8 +1145,8 @@ struct HostWgrad {   // one validated op
   const char* x;
   const char* dy;
   float* dw;
-  int dtype, cls;   // cls: 0 = bf16 ping-pong 256 x 256, 1 = bf16 128 x 128, 2 = f32 128 x 128
-  int tile;         // tile edge
+  int dtype, cls;   // cls: 0 = bf16 ping-pong 256 x 256, 1 = bf16 four waves of 64 x 64 (o.shape), 2 = f32 128 x 128
+  int tile_o, tile_n;   // tile edges along Cout / K
 };
 
 int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d, HostWgrad& h) {
@@ -1150,9 +1200,21 @@ int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d
       h.cls = 3;
     }
   }
-  h.tile = h.cls == 0 ? 256 : 128;
-  const int ntiles = (o.K + h.tile - 1) / h.tile;
-  o.tiles = ((d->Cout + h.tile - 1) / h.tile) * ntiles;
+  // conv_wgrad_kernel<bf16>: the wave arrangement that pads the (Cout x K) result least — 64 x 256 for layers with <= 64
+  // output channels, 256 x 64 for K = 64, 128 x 128 otherwise and on ties (wgrad.shapes = 0: always 128 x 128)
+  o.shape = 0;
+  if (h.cls == 1 && dastune::get(dastune::WGRAD_SHAPES) != 0) {
+    long long best = 0;
+    for (int sh = 0; sh < 3; ++sh) {
+      const long long to = shape_to(sh), tn = shape_tn(sh);
+      const long long area = ((d->Cout + to - 1) / to * to) * ((o.K + tn - 1) / tn * tn);
+      if (sh == 0 || area < best) { best = area; o.shape = sh; }
+    }
+  }
+  h.tile_o = h.cls == 0 ? 256 : shape_to(o.shape);
+  h.tile_n = h.cls == 0 ? 256 : shape_tn(o.shape);
+  const int ntiles = (o.K + h.tile_n - 1) / h.tile_n;
+  o.tiles = ((d->Cout + h.tile_o - 1) / h.tile_o) * ntiles;
   return DAS_OK;
 }
 
@@ -1279,14 +1341,14 @@ void wgrad_schedule(const HostWgrad* const* ops, int n, int grid, int bkm, Wgrad
   for (int i = 0; i < n; ++i) {
     if (best_splits[i] <= 1) continue;
     base[i] = plan.partials;
-    const int tile_edge = ops[i]->tile, ntiles = (ops[i]->o.K + tile_edge - 1) / tile_edge;
+    const int tile_o = ops[i]->tile_o, tile_n = ops[i]->tile_n, ntiles = (ops[i]->o.K + tile_n - 1) / tile_n;
     // one small result with hundreds of splits: several reduce groups, each adding atomically
     const int groups = std::max(1, std::min(best_splits[i] / 8, 256 / std::max(1, ops[i]->o.tiles * 16)));
     if (groups > 1) plan.zero_ops.push_back(i);
     plan.max_groups = std::max(plan.max_groups, groups);
     for (int t = 0; t < ops[i]->o.tiles; ++t) {
       WgradRedJob jb{};
-      jb.op = i; jb.o0 = (t / ntiles) * tile_edge; jb.n0 = (t % ntiles) * tile_edge;
+      jb.op = i; jb.o0 = (t / ntiles) * tile_o; jb.n0 = (t % ntiles) * tile_n; jb.shape = ops[i]->o.shape;
       jb.base = plan.partials + t * best_splits[i]; jb.splits = best_splits[i]; jb.groups = groups;
       plan.jobs.push_back(jb);
     }
@@ -1314,6 +1376,7 @@ void wgrad_schedule(const HostWgrad* const* ops, int n, int grid, int bkm, Wgrad
 }
 
 thread_local long long g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local long long g_last_shape = 0;   // wave arrangement of the last launch's first op (conv_wgrad_kernel<bf16>)
 std::atomic<long long> g_plan_misses{0};   // schedules built so far (process-wide): a steady training loop stops adding to it
 
 // schedules by op-list signature (shapes, class, grid): a training step repeats the same few lists
@@ -1390,6 +1453,7 @@ int wgrad_launch_class(HostWgrad** ops, int n, int cls, int accumulate, hipStrea
     const long long st[8] = {cls, plan->grid, (long long)plan->units.size(), direct, plan->partials, (long long)plan->jobs.size(),
                              longest, plan->max_groups};
     std::memcpy(g_last_plan, st, sizeof(st));
+    g_last_shape = ops[0]->o.shape;
   }
   float* ws = nullptr;
   if (plan->partials > 0) {
@@ -1420,7 +1484,7 @@ int wgrad_launch_class(HostWgrad** ops, int n, int cls, int accumulate, hipStrea
     hipLaunchKernelGGL(conv_wgrad_pp_kernel, dim3((unsigned)grid), dim3(512), sm, s, g);
   } else if (cls == 1) {
     dastune::note_kernel("conv_wgrad_kernel");
-    const size_t sm = 2 * 2 * (size_t)bkm * 256;
+    const size_t sm = 2 * (size_t)bkm * 640;   // two buffers of (dY tile + X tile): 512 B of rows per step at 128 x 128, 640 B at 64 x 256 / 256 x 64
     if (bkm == 32) {
       hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 32>), dim3((unsigned)grid), dim3(256), sm, s, g);
     } else {
@@ -1449,6 +1513,7 @@ int wgrad_launch_class(HostWgrad** ops, int n, int cls, int accumulate, hipStrea
 
 extern "C" int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* const* dys, float* const* dws,
                                       const DasConvDesc* descs, int accumulate, void* stream) {
+  DAS_PROF(stream);
   if (n < 1 || n > WG_MAXOPS || !xs || !dys || !dws || !descs) return DAS_ERR_ARG;
   HostWgrad ops[WG_MAXOPS];
   for (int i = 0; i < n; ++i) {
@@ -1495,12 +1560,14 @@ extern "C" int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* 
 
 extern "C" int das_wgrad_last_plan(long long* out, int n) {
   if (!out || n < 1) return DAS_ERR_ARG;
-  for (int i = 0; i < n; ++i) out[i] = i < 8 ? g_last_plan[i] : (i == 8 ? g_plan_misses.load(std::memory_order_relaxed) : 0);
+  for (int i = 0; i < n; ++i)
+    out[i] = i < 8 ? g_last_plan[i] : (i == 8 ? g_plan_misses.load(std::memory_order_relaxed) : (i == 9 ? g_last_shape : 0));
   return DAS_OK;
 }
 
 extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate,
                                      void* stream) {
+  DAS_PROF(stream);
   return das_conv2d_wgrad_batch(1, &x, &dy, &dw, d, accumulate, stream);
 }
 
@@ -1522,9 +1589,11 @@ static int colsum_impl(const void* x, int dtype, long long rows, int C, int pix_
   return DAS_OK;
 }
 extern "C" int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream) {
+  DAS_PROF(stream);
   return colsum_impl(x, dtype, rows, C, pix_stride, out, false, stream);
 }
 extern "C" int das_colsum_acc(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream) {
+  DAS_PROF(stream);
   return colsum_impl(x, dtype, rows, C, pix_stride, out, true, stream);
 }
 
@@ -1559,6 +1628,7 @@ extern "C" int das_bn_train_backward_phase(const void* dy, const void* y, const 
                                            const float* beta, int relu, void* draw, void* dres, float* sums,
                                            int sums_prezeroed, float* dgamma_acc, float* dbeta_acc, int phase,
                                            long long stat_rows, void* stream) {
+  DAS_PROF(stream);
   return bn_train_backward_impl(dy, y, nullptr, raw, dtype, rows, C, mean, invstd, gamma, beta, relu, draw, dres, sums,
                                 sums_prezeroed, dgamma_acc, dbeta_acc, phase, stat_rows, stream);
 }
@@ -1567,6 +1637,7 @@ extern "C" int das_bn_train_backward_bits(const void* dy, const void* y_relu_bit
                                           int C, const float* mean, const float* invstd, const float* gamma, void* draw,
                                           void* dres, float* sums, int sums_prezeroed, float* dgamma_acc, float* dbeta_acc,
                                           void* stream) {
+  DAS_PROF(stream);
   if (!y_relu_bits) return DAS_ERR_ARG;
   return bn_train_backward_impl(dy, nullptr, (const unsigned char*)y_relu_bits, raw, dtype, rows, C, mean, invstd, gamma,
                                 nullptr, 1, draw, dres, sums, sums_prezeroed, dgamma_acc, dbeta_acc, 0, rows, stream);
@@ -1577,6 +1648,7 @@ extern "C" int das_bn_train_backward_bits_phase(const void* dy, const void* y_re
                                                 const float* gamma, void* draw, void* dres, float* sums, int sums_prezeroed,
                                                 float* dgamma_acc, float* dbeta_acc, int phase, long long stat_rows,
                                                 void* stream) {
+  DAS_PROF(stream);
   if (!y_relu_bits) return DAS_ERR_ARG;
   return bn_train_backward_impl(dy, nullptr, (const unsigned char*)y_relu_bits, raw, dtype, rows, C, mean, invstd, gamma,
                                 nullptr, 1, draw, dres, sums, sums_prezeroed, dgamma_acc, dbeta_acc, phase, stat_rows, stream);
@@ -1585,6 +1657,7 @@ extern "C" int das_bn_train_backward_bits_phase(const void* dy, const void* y_re
 extern "C" int das_bn_backward_apply(const void* dz, const void* raw, int dtype, long long rows, int C, const float* mean,
                                      const float* invstd, const float* gamma, const float* sums, int sums_slots,
                                      void* draw, float* dgamma_acc, float* dbeta_acc, long long stat_rows, void* stream) {
+  DAS_PROF(stream);
   if (!dz || !raw || !mean || !invstd || !gamma || !sums || !draw || rows <= 0 || C % 8 || C > 2048) return DAS_ERR_ARG;
   if (sums_slots < 1 || sums_slots > 64 || stat_rows < rows) return DAS_ERR_ARG;
   if ((dgamma_acc == nullptr) != (dbeta_acc == nullptr)) return DAS_ERR_ARG;
@@ -1639,6 +1712,7 @@ extern "C" int das_bn_train_backward(const void* dy, const void* y, const void* 
                                      const float* mean, const float* invstd, const float* gamma, const float* beta,
                                      int relu, void* draw, void* dres, float* sums, int sums_prezeroed,
                                      float* dgamma_acc, float* dbeta_acc, void* stream) {
+  DAS_PROF(stream);
   return das_bn_train_backward_phase(dy, y, raw, dtype, rows, C, mean, invstd, gamma, beta, relu, draw, dres, sums,
                                      sums_prezeroed, dgamma_acc, dbeta_acc, 0, rows, stream);
 }

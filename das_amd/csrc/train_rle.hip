@@ -12,6 +12,7 @@
 //                        positive row is written by exactly one thread per column (no atomics, deterministic).
 // One thread per (positive, joint). Everything is f32, as in the reference.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -177,6 +178,7 @@ extern "C" int das_rle_blocks(const DasRleDesc* d) { return desc_ok(d) ? blocks_
 extern "C" int das_rle_prepare(const float* pose, const float* aux, const long long* pos, const float* real,
                                const float* vis, const int* is2d, const int* slot, const DasRleDesc* d, float* x2,
                                float* w2, float* x3, float* w3, void* stream) {
+  DAS_PROF(stream);
   if (!pose || !aux || !pos || !real || !vis || !is2d || !slot || !desc_ok(d)) return DAS_ERR_ARG;
   if ((d->stride2 > 0 && (!x2 || !w2)) || (d->stride3 > 0 && (!x3 || !w3))) return DAS_ERR_ARG;
   hipLaunchKernelGGL(rle_prepare_kernel, dim3(blocks_of(d)), dim3(TPB), 0, (hipStream_t)stream, pose, aux, pos, real, vis,
@@ -188,6 +190,7 @@ extern "C" int das_rle_prepare(const float* pose, const float* aux, const long l
 extern "C" int das_rle_loss(const float* pose, const float* aux, const long long* pos, const float* real,
                             const float* vis, const int* is2d, const int* slot, const float* depth_t,
                             const float* logp2, const float* logp3, const DasRleDesc* d, float* partials, void* stream) {
+  DAS_PROF(stream);
   if (!pose || !aux || !pos || !real || !vis || !is2d || !slot || !depth_t || !partials || !desc_ok(d)) return DAS_ERR_ARG;
   if ((d->stride2 > 0 && !logp2) || (d->stride3 > 0 && !logp3)) return DAS_ERR_ARG;
   hipLaunchKernelGGL(rle_loss_kernel, dim3(blocks_of(d)), dim3(TPB), 0, (hipStream_t)stream, pose, aux, pos, real, vis,
@@ -200,6 +203,7 @@ extern "C" int das_rle_backward(const float* pose, const float* aux, const long 
                                 const float* vis, const int* is2d, const int* slot, const float* depth_t,
                                 const float* dx2, const float* dx3, const float* g_sums, const DasRleDesc* d,
                                 float* dpose, float* daux, void* stream) {
+  DAS_PROF(stream);
   if (!pose || !aux || !pos || !real || !vis || !is2d || !slot || !depth_t || !g_sums || !dpose || !daux || !desc_ok(d))
     return DAS_ERR_ARG;
   if ((d->stride2 > 0 && !dx2) || (d->stride3 > 0 && !dx3)) return DAS_ERR_ARG;

@@ -24,6 +24,7 @@ enum Key {
   CONV_SPLITK_MINSTEPS,  // ... keeping at least this many K steps (of 128 bytes) per split
   CONV_SPLITK_KERNELS,   // bit mask of the kernels that may split: 1 conv_glds_kernel, 2 conv_glds3_kernel, 4 conv_glds4_kernel
   WGRAD_PP_MINK,         // conv_wgrad_pp_kernel for K >= this (and Cout >= 256); 0 disables the kernel
+  WGRAD_SHAPES,          // conv_wgrad_kernel<bf16>: 1 = wave arrangement per op (128 x 128 / 64 x 256 / 256 x 64), 0 = always 128 x 128
   WGRAD_BKM,             // pixel rows per step of conv_wgrad_kernel<bf16>: 32 or 64
   WGRAD_BLOCKS,          // target grid of conv_wgrad_kernel; 0 = one resident wave of workgroups (3 or 2 per usable CU)
   WGRAD_PP_BLOCKS,       // target grid of conv_wgrad_pp_kernel; 0 = one workgroup per usable CU (device CUs minus
@@ -36,9 +37,6 @@ enum Key {
                          // whole weight matrix in LDS) from this many tiles up; 0 disables the kernel
   BN_STREAM_MINBYTES,    // BatchNorm apply passes over tensors of at least this many bytes: slot fold as its own launch +
                          // a one-shot pass of small workgroups (bn_apply_stream_kernel); 0 = never
-  CONV_PT3_MINTILES,     // conv_pt3_kernel (persistent 256 x 128 tile grid, conv_persist.h) for launches of at least this many
-                         // tiles; 0 (the default) disables the kernel: measured on the step's multi-round shapes it is within
-                         // +-5 % of the one-tile kernels — parity-tested, kept for the record and for A/B runs
   COMM_RESERVED_CUS,     // CUs the persistent one-workgroup-per-CU grids leave free (for the RCCL kernels of the overlapped
                          // gradient all-reduce when several GPUs train together); 0 on one GPU
   ELEM_UPSTATS_PPB,      // output pixels per workgroup of bilinear_ac_stats_kernel; 0 = by size
@@ -53,5 +51,7 @@ int device_cus();
 int usable_cus();
 // `name` must be a string literal (kept by pointer): the kernel the calling thread's last launcher call picked
 void note_kernel(const char* name);
+// note_kernel calls of the calling thread so far (prof.hip: did the entry point inside this scope pick a kernel?)
+unsigned long long note_count();
 
 }  // namespace dastune

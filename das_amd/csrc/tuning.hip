@@ -19,10 +19,10 @@ constexpr Entry kTable[N_KEYS] = {
     {"conv.big_minblocks", 100},  {"conv.big_mink", 0},       {"conv.glds3_pp_mink", 1024},
     {"conv.glds4_minblocks", 128}, {"conv.glds4_pp", -1},      {"conv.glds4_mf", 0},
     {"conv.stream_minrows", 16384}, {"conv.stream_percu", 2}, {"conv.tail_split", 1},        {"conv.splitk_target", 256},
-    {"conv.splitk_minsteps", 12}, {"conv.splitk_kernels", 3},  {"wgrad.pp_mink", 256},
+    {"conv.splitk_minsteps", 12}, {"conv.splitk_kernels", 3},  {"wgrad.pp_mink", 256},  {"wgrad.shapes", 1},
     {"wgrad.bkm", 32},            {"wgrad.blocks", 0},        {"wgrad.pp_blocks", 0},      {"bn.reduce_blocks", 256},     {"bn.reduce_threads", 256},
     {"bn.vpt", 8},                {"gn.ppb", 256},             {"conv.c64_mintiles", 64},    {"bn.stream_minbytes", 96 << 20},
-    {"conv.pt3_mintiles", 0},   {"comm.reserved_cus", 0},  {"elem.upstats_ppb", 0},   {"bn.upmerge_blocks", 512},
+    {"comm.reserved_cus", 0},  {"elem.upstats_ppb", 0},   {"bn.upmerge_blocks", 512},
 };
 std::atomic<long long> g_val[N_KEYS];
 std::atomic<bool> g_init{false};
@@ -32,13 +32,18 @@ void init_once() {
   g_init.store(true, std::memory_order_release);
 }
 thread_local const char* t_last = "";
+thread_local unsigned long long t_notes = 0;   // note_kernel calls of this thread
 }  // namespace
 
 long long get(Key k) {
   init_once();
   return g_val[k].load(std::memory_order_relaxed);
 }
-void note_kernel(const char* name) { t_last = name; }
+void note_kernel(const char* name) {
+  t_last = name;
+  ++t_notes;
+}
+unsigned long long note_count() { return t_notes; }
 int device_cus() {
   static std::atomic<int> cus{0};
   int c = cus.load(std::memory_order_relaxed);

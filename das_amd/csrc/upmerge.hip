@@ -22,6 +22,7 @@
 //                    3 x 3 stencil with position-dependent coefficients (two small tables from the host), and w = wh (x) ww.
 // d raw2 = a2 (dZ - s2a/N - xhat2 s2b/N) at high resolution is never formed: dz = upsample^T(d raw2) by linearity.
 #include "common.h"
+#include "prof.h"
 #include "tuning.h"
 
 namespace {
@@ -332,6 +333,7 @@ extern "C" int das_upmerge_forward(const void* raw1, const void* z, void* out, i
                                    const float* mean1, const float* invstd1, const float* gamma1, const float* beta1,
                                    const float* mean2, const float* invstd2, const float* gamma2, const float* beta2,
                                    void* relu_bits_out, void* stream) {
+  DAS_PROF(stream);
   if (!raw1 || !z || !out || !mean1 || !invstd1 || !gamma1 || !beta1 || !mean2 || !invstd2 || !gamma2 || !beta2 ||
       !geom_ok(B, H, W, C, Ho, Wo))
     return DAS_ERR_ARG;
@@ -356,6 +358,7 @@ extern "C" int das_upmerge_backward_reduce(const void* dy, const void* out, cons
                                            int B, int H, int W, int C, int Ho, int Wo, const float* mean1,
                                            const float* invstd1, const float* mean2, const float* invstd2, float* sums,
                                            int sums_zeroed, void* stream) {
+  DAS_PROF(stream);
   if (!dy || (!out && !out_relu_bits) || !raw1 || !z || !dzm || !mean1 || !invstd1 || !mean2 || !invstd2 || !sums || !geom_ok(B, H, W, C, Ho, Wo))
     return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -384,6 +387,7 @@ extern "C" int das_upmerge_backward_lowres(const void* P, const void* z, void* d
                                            const float* ah, const float* aw, const float* wh, const float* ww,
                                            const float* sums, const float* gamma2, const float* mean2, const float* invstd2,
                                            long long stat_rows, float* dgamma2_acc, float* dbeta2_acc, void* stream) {
+  DAS_PROF(stream);
   if (!P || !z || !dz || !ah || !aw || !wh || !ww || !sums || !gamma2 || !mean2 || !invstd2 || stat_rows < 1 || B < 1 || H < 1 ||
       W < 1 || C % 8 || C < 8 || (dgamma2_acc == nullptr) != (dbeta2_acc == nullptr))
     return DAS_ERR_ARG;
@@ -405,6 +409,7 @@ extern "C" int das_upmerge_backward_lowres(const void* P, const void* z, void* d
 
 extern "C" int das_upsample_stats_lowres(const void* z, int dtype, int B, int H, int W, int C, const float* ah, const float* aw,
                                          const float* wh, const float* ww, float* stats, int stats_slots, void* stream) {
+  DAS_PROF(stream);
   if (!z || !ah || !aw || !wh || !ww || !stats || B < 1 || H < 1 || W < 1 || C % 8 || C < 8 || C > 4096 || stats_slots < 1 ||
       stats_slots > 64)
     return DAS_ERR_ARG;

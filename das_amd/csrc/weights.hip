@@ -8,6 +8,7 @@
 // both at the tensor's own element offset inside flat destination buffers, so a layer's packed weights are
 // plain views. One workgroup transposes a 64x64 (Cout x Cin) tile of one tap through LDS.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
 
 extern "C" int das_pack_conv_weights(const float* flat_src, void* fwd_dst, void* dgrad_dst, int dtype,
                                      const DasPackEntry* entries_dev, int n_entries, int total_tiles, void* stream) {
+  DAS_PROF(stream);
   if (!flat_src || !dgrad_dst || !entries_dev || n_entries < 1 || total_tiles < 1) return DAS_ERR_ARG;
   if (((uintptr_t)flat_src | (uintptr_t)fwd_dst | (uintptr_t)dgrad_dst) & 15) return DAS_ERR_ARG;   // (16-byte accesses)
   hipStream_t s = (hipStream_t)stream;

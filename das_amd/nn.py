@@ -56,7 +56,14 @@ class _Cache:
     def get(self, key, sources, make, refresh=None):
         """refresh(value): rewrite a stale cached value IN PLACE (same shape, same memory) instead of building a new one —
         the parameters change every optimisation step, so a training step refreshes every entry once; a rebuild costs
-        an allocation + fill + cast + copy (four to six small launches), a refresh one strided copy."""
+        an allocation + fill + cast + copy (four to six small launches), a refresh one strided copy.
+        CONSTRAINT (the same one the optimizer's once-per-step packed buffers impose, optim.FlatSGD / _Slot.packed): packed
+        operands are views of memory that is rewritten when the parameters change, and the backward functions fetch the
+        data-gradient weights at backward time — so a backward pass must run BEFORE the parameters it differentiates are
+        updated (forward, backward, step: what train_iteration and tools/train.py do). Two forward passes with an
+        optimizer step between them followed by the first one's backward, or parameter edits (EMA, manual surgery)
+        between a forward and its backward, would differentiate the NEW weights. Not reachable from train_iteration;
+        stated here because a rebuilt tensor (the behaviour without `refresh`) would have kept the old values alive."""
         ver = _versions(*sources)
         hit = self.store.get(key)
         if hit is not None and hit[0] == ver:
@@ -225,13 +232,16 @@ class DeferredBN:
         self.raw, self.mean, self.invstd, self.bn = raw, mean, invstd, bn
 
 
-def conv_bn_deferred(x, module, skip_through=False):
+def conv_bn_deferred(x, module, skip_through=False, partner=None):
     """module(x) for a ConvModule with BN + ReLU whose only consumer is skip_add: in train mode with autograd a DeferredBN
-    (the normalised tensor is never written), otherwise the tensor. skip_through as conv_bn."""
+    (the normalised tensor is never written), otherwise the tensor. skip_through as conv_bn. partner: the ConvModule whose
+    output meets this one in skip_add — the fused add's backward sums BOTH layers' reductions over one set of ranks, so a
+    pair of which only one layer is SyncBN (several ranks) is evaluated layer by layer instead."""
     from . import autograd as ag
     conv, bn = module.conv, module.norm
-    if (DEFERRED_SKIPS and module.with_activation and isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training
-            and conv.bias is None
+    same_span = partner is None or ag._sync_world(partner.norm) == ag._sync_world(bn)
+    if (DEFERRED_SKIPS and same_span and module.with_activation and isinstance(bn, nn.modules.batchnorm._BatchNorm)
+            and bn.training and conv.bias is None
             and ag.grad_mode(x, conv.weight, bn.weight)):
         res = ag.ConvStatsFn.apply(x, conv.weight, conv, bn, skip_through)
         d = DeferredBN(res[0], res[1], res[2], bn)
@@ -244,6 +254,8 @@ def skip_add(x, s1, s2):
     if isinstance(s1, DeferredBN) or isinstance(s2, DeferredBN):
         from . import autograd as ag
         assert isinstance(s1, DeferredBN) and isinstance(s2, DeferredBN)
+        assert ag._sync_world(s1.bn) == ag._sync_world(s2.bn), \
+            'skip_add: one SyncBN and one plain BatchNorm layer (build both with conv_bn_deferred(..., partner=the other))'
         return ag.BnReluAdd3Fn.apply(x, s1.raw, s1.mean, s1.invstd, s1.bn.weight, s1.bn.bias,
                                      s2.raw, s2.mean, s2.invstd, s2.bn.weight, s2.bn.bias, s1.bn, s2.bn)
     return add3(x, s1, s2)
@@ -367,6 +379,34 @@ def bn_stats_buffer(x, cout):
 def bn_stats_buffer_rows(rows, cout, device):
     slots = (_FULL_SLOTS if rows >= _FULL_SLOT_ROWS else _MID_SLOTS) if rows >= _SLOT_ROWS else 1
     return zeroed_stats(slots * 2 * cout, device)
+
+
+_STATS_GROUP = [None, None]     # (the statistics' process group, the default group it was created beside)
+
+
+def stats_group():
+    """The SyncBN statistics' own process group over all ranks (the reference ships SyncBN: configs/das/exp_panoptic.py:20,28;
+    its launcher is tools/dist_train.sh:8-9). Created ONCE per default group, by the first call — every rank reaches its
+    first SyncBN layer (or FlatSGD's constructor, which calls this when the model holds SyncBN layers) at the same point
+    of the program, and dist.new_group is itself a collective. A group of its own = an RCCL communicator of its own with
+    its own internal stream: a layer's two-vector message is not ordered behind the gradient buckets the default group is
+    carrying (optim.FlatSGD._launch) — on ONE communicator collectives execute in issue order whatever streams they
+    were called from, which would serialise the overlap away exactly in the configuration the reference ships."""
+    import torch.distributed as dist
+    default = dist.distributed_c10d._get_default_group()
+    if _STATS_GROUP[1] is not default:
+        _STATS_GROUP[0] = dist.new_group()
+        _STATS_GROUP[1] = default
+    return _STATS_GROUP[0]
+
+
+def sync_stats_many(stats_list, couts, all_reduce):
+    """SyncBN statistics of several layers whose conv outputs are available together (a first bottleneck's projection
+    shortcut and its conv3; the upsample unit's two branches): slots folded, the [2 C] vectors concatenated, ONE message."""
+    folded = [st if st.numel() == 2 * c else st.view(-1, 2 * c).sum(0) for st, c in zip(stats_list, couts)]
+    both = torch.cat(folded)
+    all_reduce(both)
+    return list(both.split([2 * c for c in couts]))
 
 
 def sync_stats(stats, cout, all_reduce):

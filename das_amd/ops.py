@@ -13,28 +13,78 @@ from . import _lib
 
 _DT = {torch.float32: _lib.DAS_F32, torch.bfloat16: _lib.DAS_BF16}
 
-# bench.py sets this to a list to time every conv launch with HIP events recorded on the launch
-# stream: entries are (kernel family tag, algorithmic FLOPs, start event, end event, shape).
+# Per-launch timing for bench.py and the tools under tools/dev: profile_begin() makes this a list and switches on the
+# library's own event pairs (das_prof_*, recorded INSIDE each C entry point right around its launches, on the stream
+# they go to); every wrapper below then appends (kernel family tag, algorithmic FLOPs, span, span, shape, ops,
+# algorithmic bytes, launches), where `span` says which of the library's records the call produced.
 PROFILE = None
+_PROF_MS = None        # per-record milliseconds of the last finished pass (numpy f32), filled by profile_end()
+_PROF_NAMES = None
+
+
+class _Span:
+    """Records [i0, i1) of the library's event pairs. elapsed_time() has torch.cuda.Event's shape (ms), so a PROFILE
+    entry reads the same whether a tool expects events or spans."""
+    __slots__ = ('i0', 'i1')
+
+    def __init__(self, i0, i1):
+        self.i0, self.i1 = i0, i1
+
+    def elapsed_time(self, other=None):
+        assert _PROF_MS is not None, 'profile_end() first'
+        return float(_PROF_MS[self.i0:self.i1].sum())
+
+
+def _prof_mark():
+    return _lib.load().das_prof_count()
+
+
+def profile_begin():
+    global PROFILE, _PROF_MS, _PROF_NAMES
+    _lib.check(_lib.load().das_prof_begin(), 'das_prof_begin')
+    PROFILE, _PROF_MS, _PROF_NAMES = [], None, None
+
+
+def profile_end():
+    """Stops recording, waits for the recorded events and returns the pass's entries (their spans now resolve)."""
+    global PROFILE, _PROF_MS, _PROF_NAMES
+    import numpy as np
+    lib = _lib.load()
+    lib.das_prof_end()
+    n = lib.das_prof_count()
+    ms = np.zeros(max(n, 1), dtype=np.float32)
+    names = np.zeros((max(n, 1), 64), dtype=np.uint8)
+    _lib.check(lib.das_prof_read(ms.ctypes.data, names.ctypes.data, 64, n), 'das_prof_read')
+    if n and float(ms[:n].min()) < 0:
+        raise _lib.DasHipError('das_prof_read: a record without a valid event pair')
+    _PROF_MS = ms[:n]
+    _PROF_NAMES = [bytes(r).split(b'\0', 1)[0].decode() for r in names[:n]]
+    ent, PROFILE = PROFILE, None
+    return ent
+
+
+def profile_records():
+    """(name, ms) of every record of the last pass, in launch order: name = the kernel a conv / weight-gradient
+    launcher picked, or the entry point."""
+    return list(zip(_PROF_NAMES, (float(v) for v in _PROF_MS)))
 
 
 class _timed:
-    """bench.py's per-launch record for the non-conv families (BatchNorm passes): HIP events on the launch stream
-    around the call, when PROFILE is a list. nbytes = algorithmic bytes of the op (every operand of every pass once)."""
+    """Per-call record for the non-conv families (BatchNorm passes) while PROFILE is a list.
+    nbytes = algorithmic bytes of the op (every operand of every pass once)."""
 
     def __init__(self, tag, nbytes, launches=1, shape=()):
         self.tag, self.nbytes, self.launches, self.shape = tag, float(nbytes), launches, ('bn',) + tuple(shape)
 
     def __enter__(self):
         if PROFILE is not None:
-            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.e0.record()
+            self.i0 = _prof_mark()
         return self
 
     def __exit__(self, *exc):
         if PROFILE is not None and exc[0] is None:
-            self.e1.record()
-            PROFILE.append((self.tag, 0.0, self.e0, self.e1, self.shape, 1, self.nbytes, self.launches))
+            sp = _Span(self.i0, _prof_mark())
+            PROFILE.append((self.tag, 0.0, sp, sp, self.shape, 1, self.nbytes, self.launches))
         return False
 
 
@@ -67,10 +117,12 @@ def last_kernel():
 
 def last_wgrad_plan():
     """Schedule of this thread's last weight-gradient launch (das_wgrad_last_plan): dict of kernel class, grid, units,
-    direct (units stored straight into dW), partial (tiles through the workspace), reduced, longest list, groups."""
-    out = (C.c_longlong * 9)()
-    _lib.check(_lib.load().das_wgrad_last_plan(out, 9), 'das_wgrad_last_plan')
-    return dict(zip(('cls', 'grid', 'units', 'direct', 'partial', 'reduced', 'longest', 'groups', 'schedules_built'), list(out)))
+    direct (units stored straight into dW), partial (tiles through the workspace), reduced, longest list, groups, schedules
+    built so far, shape (wave arrangement of the launch's first op: 0 = 128 x 128, 1 = 64 x 256, 2 = 256 x 64)."""
+    out = (C.c_longlong * 10)()
+    _lib.check(_lib.load().das_wgrad_last_plan(out, 10), 'das_wgrad_last_plan')
+    return dict(zip(('cls', 'grid', 'units', 'direct', 'partial', 'reduced', 'longest', 'groups', 'schedules_built', 'shape'),
+                    list(out)))
 
 
 def _stream():
@@ -335,12 +387,11 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad, out=None, accumulate=False):
             d.lvl_H[l], d.lvl_W[l] = h, w_
     assert dyd.dtype == xd.dtype
     if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        i0 = _prof_mark()
     _lib.check(_lib.load().das_conv2d_wgrad_nhwc(_ptr(xd), _ptr(dyd), _ptr(dw), C.byref(d), int(accumulate), _stream()),
                'das_conv2d_wgrad_nhwc')
     if PROFILE is not None:
-        e1.record()
+        e0 = e1 = _Span(i0, _prof_mark())
         rows = x.rows if ragged else B * Ho * Wo
         tag = f'conv_wgrad_kernel<{"bf16" if xd.dtype == torch.bfloat16 else "float"}>'
         nby = (xd.numel() + dyd.numel()) * xd.element_size() + dw.numel() * 4
@@ -406,12 +457,11 @@ def conv2d_wgrad_batch(items, accumulate=True):
         flops += fl
         nby += (_data(x).numel() + _data(dy).numel()) * _data(x).element_size() + out.numel() * 4
     if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        i0 = _prof_mark()
     _lib.check(_lib.load().das_conv2d_wgrad_batch(n, xs, dys, dws, descs, 1 if accumulate else 0, _stream()),
                'das_conv2d_wgrad_batch')
     if PROFILE is not None:
-        e1.record()
+        e0 = e1 = _Span(i0, _prof_mark())
         x0, dy0, KH0, KW0 = items[0][:4]
         dt = 'bf16' if _data(x0).dtype == torch.bfloat16 else 'float'
         tag = 'conv_wgrad_pp_kernel' if _is_pp_wgrad(x0, dy0, KH0, KW0) else f'conv_wgrad_kernel<{dt}>'
@@ -595,11 +645,10 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
     if rd is not None:
         assert rd.shape == od.shape and rd.dtype == od.dtype
     if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        i0 = _prof_mark()
     _lib.check(lib.das_conv2d_nhwc(_ptr(xd), _ptr(w), _ptr(od), C.byref(d), _stream()), 'das_conv2d_nhwc')
     if PROFILE is not None:
-        e1.record()
+        e0 = e1 = _Span(i0, _prof_mark())
         tag = last_kernel()   # the kernel the launcher picked (das_last_kernel): equals the rocprof kernel family
         # algorithmic bytes: every operand once (x, weights, y, + residual, + the BatchNorm-backward operands)
         eo = od.element_size()

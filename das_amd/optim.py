@@ -138,6 +138,11 @@ class FlatSGD:
         self.comm_reserved_cus = int(comm_reserved_cus if comm_reserved_cus is not None else (32 if self.world > 1 else 0))
         self._reserve_on = False
         self.comm_stream = torch.cuda.Stream() if self._multi and dev.type == 'cuda' else None
+        if self.world > 1 and any(getattr(m, '_das_sync', False) for m in model.modules()):
+            # the SyncBN statistics' own communicator exists before the first step (dist.new_group is a collective:
+            # every rank constructs its optimizer at the same point of the program)
+            from .nn import stats_group
+            stats_group()
         for i, sl in enumerate(self.slots):
             sl.index = i
         self._pexp = None                          # completions per parameter in one backward (learned in iteration 0)

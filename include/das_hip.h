@@ -46,9 +46,8 @@ const char* das_target_arch(void);
  * production-size layers dispatch to, A/B benchmarks flip them. No reference counterpart (torch picks its cuDNN /
  * MIOpen algorithm internally: torch.backends.cudnn.benchmark, tools/train.py:115-116). Unknown key: DAS_ERR_ARG.
  * Keys: conv.big_minblocks, conv.big_mink, conv.glds3_pp_mink, conv.glds4_minblocks, conv.glds4_pp (-1 auto / 0 / 1),
- * conv.glds4_mf, conv.stream_minrows, conv.stream_percu, conv.tail_split, conv.splitk_target, conv.splitk_minsteps, conv.splitk_kernels, conv.c64_mintiles, wgrad.pp_mink, wgrad.bkm, wgrad.blocks, wgrad.pp_blocks,
- * bn.reduce_blocks, bn.reduce_threads, bn.vpt, gn.ppb, bn.stream_minbytes, conv.pt3_mintiles (persistent 256 x 128 tile
- * grid: 0 = off), comm.reserved_cus (CUs every persistent grid leaves free: wgrad.blocks / wgrad.pp_blocks 0 = one
+ * conv.glds4_mf, conv.stream_minrows, conv.stream_percu, conv.tail_split, conv.splitk_target, conv.splitk_minsteps, conv.splitk_kernels, conv.c64_mintiles, wgrad.pp_mink, wgrad.shapes (1: conv_wgrad_kernel picks 128 x 128 / 64 x 256 / 256 x 64 wave arrangements per op), wgrad.bkm, wgrad.blocks, wgrad.pp_blocks,
+ * bn.reduce_blocks, bn.reduce_threads, bn.vpt, gn.ppb, bn.stream_minbytes, comm.reserved_cus (CUs every persistent grid leaves free: wgrad.blocks / wgrad.pp_blocks 0 = one
  * resident wave of workgroups on the remaining CUs), elem.upstats_ppb (output pixels per workgroup of the resampling
  * kernels, 0 = by size), bn.upmerge_blocks (grid cap of the fused reduce passes of upmerge.hip / skipadd.hip). */
 int das_tuning_set(const char* key, long long value);
@@ -63,6 +62,19 @@ const char* das_last_kernel(void);
  * with lds_bytes near 160 KiB a workgroup owns its CU, with a few KiB it shares it as a collective's kernel would.
  * The persistent kernels size their grids for das_tuning key comm.reserved_cus fewer CUs. */
 int das_dev_occupy_cus(int blocks, int threads, int lds_bytes, int usec, void* stream);
+/* Launch timing inside the library (measurement; the reference's counterpart is the wall clock of
+ * tools/analysis_tools/benchmark.py:63-90, which cannot attribute time to kernels). Between das_prof_begin and
+ * das_prof_end every entry point that launches kernels records one HIP event on ITS stream right before its first
+ * launch and one right after its last: no interpreter / FFI time sits between an event and the launch it brackets. An
+ * entry point called by another one does not record again. das_prof_count: records so far (a caller brackets its own
+ * call with two counts to learn which records it produced). das_prof_read: waits for the first n records' events and
+ * returns their elapsed milliseconds (-1 for a record whose events failed) and, when `names` is given, per record the
+ * kernel name its launcher picked (das_last_kernel) or else the entry point's name, name_stride (>= 16) bytes apiece.
+ * Event pairs are reused by the next das_prof_begin. Off, a scope costs one load. */
+int das_prof_begin(void);
+int das_prof_end(void);
+long long das_prof_count(void);
+int das_prof_read(float* ms, char* names, int name_stride, long long n);
 
 /* ------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA, fused epilogue.

@@ -29,7 +29,6 @@ CASES = [
     ('conv_glds_kernel', 2, 11, 13, 64, 72, 3, False),
     ('conv_glds_kernel', 2, 11, 13, 64, 128, 1, True),
     ('conv_glds3_kernel', 2, 19, 23, 128, 128, 3, False),
-    ('conv_pt3_kernel', 2, 39, 43, 128, 128, 3, False),         # mode 4: recomputed mask, 14 tiles on 8 workgroups
     ('conv_glds4_kernel<pp>', 2, 13, 17, 64, 256, 1, True),
     ('conv_glds4_kernel', 1, 16, 26, 256, 264, 3, False),
     ('conv1x1_stream_kernel', 2, 91, 93, 64, 256, 1, True),     # mode 3: residual + y mask (conv1's data gradient)
@@ -45,8 +44,6 @@ FORCE = {
     'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
     'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
     'conv1x1_stream_kernel': {},
-    'conv_pt3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0,
-                        'conv.pt3_mintiles': 1, 'comm.reserved_cus': 248},
     'conv3x3_c64_kernel': {'conv.c64_mintiles': 1},
 }
 

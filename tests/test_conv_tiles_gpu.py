@@ -75,9 +75,6 @@ FORCE = {
                               'conv.glds4_mf': 8, 'conv.stream_minrows': 0},
     'conv_glds4_kernel<pp,288>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.splitk_target': 0,
                                   'conv.glds4_mf': 9, 'conv.stream_minrows': 0},
-    # the persistent 256 x 128 grid, from a single tile up, on few enough workgroups that every one walks several tiles
-    'conv_pt3_kernel': {'conv.big_minblocks': 1, 'conv.glds4_minblocks': 0, 'conv.splitk_target': 0,
-                        'conv.stream_minrows': 0, 'conv.pt3_mintiles': 1, 'comm.reserved_cus': 248},
 }
 
 # B, H, W, Cin, Cout, k, stride, pad
@@ -109,38 +106,6 @@ def _run_forced(kernel, case, **kw):
     return x, w, y
 
 
-# the persistent kernel needs K >= 128 (two K steps): the single-step case stays with the one-tile kernels
-SHAPES_PT3 = [c for c in SHAPES3 if c[3] * c[5] * c[5] >= 128] + [
-    (2, 64, 104, 128, 128, 3, 1, 1),   # 52 tiles on 8 workgroups: six or seven tile boundaries per workgroup
-    (3, 40, 52, 256, 384, 1, 1, 0),    # three column blocks (a workgroup keeps its own), 4 K steps
-    (2, 33, 47, 128, 200, 3, 2, 1),    # stride 2, the second column block overhangs Cout
-]
-
-
-@pytest.mark.parametrize('case', SHAPES_PT3)
-def test_pt3_forced(case):
-    x, w, y = _run_forced('conv_pt3_kernel', case)
-    np.testing.assert_allclose(nchw(y).numpy(), conv_ref(x, w, case[6], case[7]).numpy(), **TOL)
-    assert_bf16_exact(nchw(y), conv_ref(x, w, case[6], case[7]))
-
-
-def test_pt3_equals_one_tile_kernel_bitwise():
-    """Same K order, same f32 accumulation, same rounding: the persistent grid stores exactly what conv_glds3_kernel<pp>
-    stores (plain epilogue), whatever the number of workgroups that share the tiles."""
-    o = ops()
-    B, H, W, Cin, Cout = 2, 64, 104, 128, 256
-    x, w = cases.randn(171, B, Cin, H, W), cases.randn(172, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
-    xd, wd = nhwc(x), o.pack_weight(w.to(DEV), BF)
-    with o.tuning(**FORCE['conv_glds3_kernel<pp>']):
-        y0 = o.conv2d(xd, wd, 3, 3, 1, 1)
-        assert o.last_kernel() == 'conv_glds3_kernel<pp>'
-    for reserve in (0, 200, 250):
-        with o.tuning(**{**FORCE['conv_pt3_kernel'], 'comm.reserved_cus': reserve}):
-            y1 = o.conv2d(xd, wd, 3, 3, 1, 1)
-            assert o.last_kernel() == 'conv_pt3_kernel'
-        assert torch.equal(y0, y1), reserve
-
-
 @pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>'])
 @pytest.mark.parametrize('case', SHAPES3)
 def test_glds3_forced(kernel, case):
@@ -157,7 +122,7 @@ def test_glds4_forced(kernel, case):
     assert_bf16_exact(nchw(y), conv_ref(x, w, case[6], case[7]))
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_pt3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_epilogues_forced(kernel):
     """scale / shift / residual / ReLU, then the BatchNorm statistics of the stored values (in slots)."""
     o = ops()
@@ -182,7 +147,7 @@ def test_tile_epilogues_forced(kernel):
     np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_pt3_kernel', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_ragged_levels_forced(kernel):
     """The head's mode: four FPN levels in one launch, shared 3x3 weights (das_head.py:176-178)."""
     o = ops()
@@ -200,7 +165,7 @@ def test_tile_ragged_levels_forced(kernel):
         np.testing.assert_allclose(nchw(y.level(l)).numpy(), ref.numpy(), **TOL)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_pt3_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
 def test_tile_dgrad_forced(kernel):
     """Data gradient of a stride-1 3x3 conv on the tile kernels (flipped weights), with a second gradient of the
     same tensor added in the epilogue."""
@@ -559,6 +524,77 @@ def test_wgrad_real_split(case):
     np.testing.assert_allclose(acc.cpu().numpy(), 2 * dw.cpu().numpy(), rtol=1e-5, atol=1e-5)
     dw2 = o.conv2d_wgrad(nhwc(x), nhwc(dy), k, k, s, p)
     np.testing.assert_allclose(dw2.cpu().numpy(), dw.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+WGRAD_SHAPES = [
+    # B, H, W, Cin, Cout, k, stride, pad, expected wave arrangement (1 = 64 x 256, 2 = 256 x 64)
+    (2, 128, 208, 64, 256, 1, 1, 0, 2),     # K = 64: conv3 of the 128 x 208 stage's bottlenecks
+    (2, 128, 208, 256, 64, 1, 1, 0, 1),     # Cout = 64: conv1 of the same
+    (2, 64, 104, 256, 32, 3, 1, 1, 1),      # Cout = 32 (half of the 64-row tile empty), nine K tiles
+    (1, 64, 96, 8, 64, 7, 2, 3, 1),         # the stem: K = 392 = one full K tile + 136 columns, 8-channel taps
+    (2, 40, 60, 64, 200, 1, 1, 0, 2),       # Cout = 200 overhangs the 256-row tile
+    (2, 40, 60, 72, 48, 3, 1, 1, 1),        # K = 648: the taps' 72 channels straddle the 16-byte slots' swizzle
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_SHAPES)
+def test_wgrad_wave_arrangements(case):
+    """conv_wgrad_kernel<bf16> as 64 x 256 / 256 x 64 tiles (four waves of 64 x 64 in a row / a column) for the layers whose
+    128 x 128 tile was half empty: against torch's weight gradient, against the 128 x 128 arrangement of the same op
+    (wgrad.shapes = 0: f32 summation order only), accumulating, deterministic; das_wgrad_last_plan says which ran."""
+    o = ops()
+    B, H, W, Cin, Cout, k, s, p, shape = case
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = cases.randn(261, B, Cin, H, W)
+    dy = cases.randn(262, B, Cout, Ho, Wo) / (B * Ho * Wo) ** 0.5
+    torch.set_num_threads(8)
+    w0 = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    F.conv2d(q(x), w0, None, s, p).backward(q(dy))
+    ref = w0.grad.permute(0, 2, 3, 1).numpy()
+    xd, dyd = nhwc(x), nhwc(dy)
+    dw = o.conv2d_wgrad(xd, dyd, k, k, s, p)
+    assert o.last_kernel() == 'conv_wgrad_kernel' and o.last_wgrad_plan()['shape'] == shape, o.last_wgrad_plan()
+    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()))
+    with o.tuning(**{'wgrad.shapes': 0}):
+        sq = o.conv2d_wgrad(xd, dyd, k, k, s, p)
+        assert o.last_wgrad_plan()['shape'] == 0
+    np.testing.assert_allclose(dw.cpu().numpy(), sq.cpu().numpy(), rtol=1e-4, atol=2e-5 * float(np.abs(ref).max()))
+    acc = dw.clone()
+    o.conv2d_wgrad(xd, dyd, k, k, s, p, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), 2 * dw.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    again = o.conv2d_wgrad(xd, dyd, k, k, s, p)
+    if o.last_wgrad_plan()['groups'] == 1:      # one reduce group per tile: fixed summation order
+        assert torch.equal(again, dw)
+    else:                                       # a lone small result cut into hundreds of runs: atomic reduce groups
+        np.testing.assert_allclose(again.cpu().numpy(), dw.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(np.abs(ref).max()) + 1e-7)
+    # one launch with all three arrangements side by side == the single launches
+    x2 = cases.randn(263, B, 128, H, W)
+    dy2 = cases.randn(264, B, 128, H, W) / (B * H * W) ** 0.5
+    outs = [torch.zeros(Cout, k, k, Cin, device=DEV), torch.zeros(128, 1, 1, 128, device=DEV)]
+    o.conv2d_wgrad_batch([(xd, dyd, k, k, s, p, outs[0]), (nhwc(x2), nhwc(dy2), 1, 1, 1, 0, outs[1])])
+    np.testing.assert_allclose(outs[0].cpu().numpy(), dw.cpu().numpy(), rtol=1e-4, atol=2e-5 * float(np.abs(ref).max()))
+    single = o.conv2d_wgrad(nhwc(x2), nhwc(dy2), 1, 1, 1, 0)
+    np.testing.assert_allclose(outs[1].cpu().numpy(), single.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_wgrad_wave_arrangement_ragged_predictor():
+    """The head's 256 -> 48 predictor over the four ragged levels (Cout = 48: the 64 x 256 arrangement) against torch."""
+    o = ops()
+    B, Cc, Co = 2, 256, 48
+    sizes = [(64, 104), (32, 52), (16, 26), (8, 13)]
+    xs = [cases.randn(271 + i, B, Cc, h, ww) for i, (h, ww) in enumerate(sizes)]
+    rows = sum(B * h * ww for h, ww in sizes)
+    dys = [cases.randn(281 + i, B, Co, h, ww) / rows ** 0.5 for i, (h, ww) in enumerate(sizes)]
+    torch.set_num_threads(8)
+    w0 = torch.zeros(Co, Cc, 1, 1, requires_grad=True)
+    for xl, dl in zip(xs, dys):
+        F.conv2d(q(xl), w0, None, 1, 0).backward(q(dl))
+    xr = o.Ragged.from_levels([nhwc(t) for t in xs])
+    dyr = o.Ragged.from_levels([nhwc(t) for t in dys])
+    dw = o.conv2d_wgrad(xr, dyr, 1, 1, 1, 0)
+    assert o.last_kernel() == 'conv_wgrad_kernel' and o.last_wgrad_plan()['shape'] == 1
+    got = dw.cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), w0.grad.numpy(), rtol=2e-3, atol=2e-3 * float(w0.grad.abs().max()))
 
 
 @pytest.mark.parametrize('case', [(1, 16, 16), (3, 48, 32), (2, 40, 60), (2, 128, 232), (5, 64, 64)])

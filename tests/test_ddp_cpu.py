@@ -167,3 +167,106 @@ def test_mark_complete_drives_the_buckets_world2_gloo():
         assert early[0] == 0 and early[1] > 0 and early[2] == early[1]      # learnt in iteration 0, early from then on
         assert 0 < n_end < nb
     assert ret[0][1] == ret[1][1]
+
+
+def _stats_group_worker(rank, world, port, ret):
+    """Gradient buckets (default group, launched from completion hooks) interleaved with SyncBN-style statistics
+    all-reduces (their own group, das_amd.nn.stats_group) in forward and backward, under per-rank random delays."""
+    import random
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from das_amd import autograd as ag, nn as dnn
+    from das_amd.optim import FlatSGD
+    rnd = random.Random(1234 + 77 * rank)          # different delays on every rank
+    log = []
+    real_all_reduce = dist.all_reduce
+
+    def logged(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        which = 'stats' if (group is not None and group is dnn._STATS_GROUP[0]) else 'default'
+        log.append((which, t.numel(), str(op)))
+        time.sleep(rnd.random() * 0.004)
+        return real_all_reduce(t, op=op, group=group, async_op=async_op)
+    dist.all_reduce = logged
+
+    class SyncScale(torch.autograd.Function):
+        """y = x * mean_over_ranks(sum(x)) / sum(x)-style layer: one statistics message forward, one backward."""
+
+        @staticmethod
+        def forward(ctx, x):
+            s = x.detach().sum().reshape(1).clone()
+            ag._check_equal_rows(x.shape[0])
+            ag._all_reduce(s)
+            ctx.save_for_backward(x)
+            ctx.s = float(s) / world
+            return x * ctx.s
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            time.sleep(rnd.random() * 0.004)
+            t = (g * x).sum().reshape(1).clone()
+            ag._all_reduce(t)                       # (the cross-rank term of d s / d x)
+            return g * ctx.s + float(t) / world
+
+    torch.manual_seed(0)
+    layers = torch.nn.ModuleList([torch.nn.Linear(6, 6) for _ in range(5)])
+    opt = FlatSGD(layers, lr=0.1, bucket_mb=0, overlap=True)
+    group = dnn.stats_group()
+    ok = group is not dist.distributed_c10d._get_default_group() and dnn.stats_group() is group
+    for it in range(3):
+        ag.reset_step_state()
+        opt.zero_grad()
+        x = torch.randn(4, 6, generator=torch.Generator().manual_seed(100 * it + rank))
+        for lin in layers:
+            x = SyncScale.apply(torch.tanh(lin(x)))
+        x.square().sum().backward()
+        opt.all_reduce_grads()
+    # single-process reference of the last iteration's gradient of the last layer: both ranks' samples, exact sums
+    ret[rank] = (ok, [e for e in log], [float(p.grad.abs().sum()) for p in layers.parameters()], opt.overlapped_launches)
+    dist.all_reduce = real_all_reduce
+    dist.destroy_process_group()
+
+
+def test_syncbn_statistics_travel_on_their_own_group_in_a_rank_invariant_order_world2_gloo():
+    mp.set_start_method('spawn', force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 32500 + os.getpid() % 1000
+    mp.spawn(_stats_group_worker, args=(2, port, ret), nprocs=2, join=True)
+    (ok0, log0, g0, ov0), (ok1, log1, g1, ov1) = ret[0], ret[1]
+    assert ok0 and ok1
+    # every rank issued the same sequence of collectives PER GROUP (sizes and ops), whatever its delays were
+    for which in ('stats', 'default'):
+        a, b = [e for e in log0 if e[0] == which], [e for e in log1 if e[0] == which]
+        assert a == b and len(a) > 0, which
+    stats = [e for e in log0 if e[0] == 'stats']
+    # per step: 5 forward + 5 backward statistics messages + ONE row-count check (MAX), never on the default group
+    assert len(stats) == 3 * (5 + 5 + 1) and sum('MAX' in e[2] for e in stats) == 3
+    assert ov0 == ov1 and ov0 > 0                     # buckets did go out during backward, between the statistics messages
+    assert g0 == g1                                   # summed gradients identical on both ranks
+
+
+def _rows_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from das_amd import autograd as ag
+    ag.reset_step_state()
+    ag._check_equal_rows(128)             # equal everywhere: passes
+    ag.reset_step_state()
+    try:
+        ag._check_equal_rows(128 + 16 * rank)
+        ret[rank] = 'no error'
+    except RuntimeError as e:
+        ret[rank] = str(e)
+    dist.destroy_process_group()
+
+
+def test_syncbn_row_count_check_raises_on_every_rank_world2_gloo():
+    mp.set_start_method('spawn', force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + os.getpid() % 1000
+    mp.spawn(_rows_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert 'different numbers of pixel rows (between 128 and 144' in ret[r], ret[r]

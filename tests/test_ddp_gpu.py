@@ -180,6 +180,107 @@ def test_two_rank_step_equals_the_single_process_step_on_the_concatenated_batch(
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The tight form of the equivalence: per FUSED NODE, where no deep net amplifies the float-atomic spread. A first
+# bottleneck with its projection shortcut (dual apply; both layers' statistics in ONE message), one MSPN upsample unit's merge
+# and the next stage's add with the two deferred skip layers: two ranks with SyncBN against one process with plain
+# BatchNorm on the concatenated batch, in f32 — outputs, input gradients, summed parameter gradients, running statistics.
+def _node_modules(norm):
+    from das_amd.backbones import Bottleneck, UpsampleUnit
+    from das_amd.nn import ConvModule
+    torch.manual_seed(5)
+    ds = ConvModule(32, 64, 1, stride=2, padding=0, norm_cfg=dict(type=norm), act_cfg=None)
+    blk = torch.nn.Sequential(Bottleneck(32, 16, stride=2, downsample=ds, norm_cfg=dict(type=norm)))
+    unit = UpsampleUnit(1, 4, 64, unit_channels=32, gen_skip=True, norm_cfg=dict(type=norm))
+    mods = torch.nn.ModuleDict(dict(blk=blk, unit=unit)).to('cuda').train()
+    with torch.no_grad():
+        for n, p in mods.named_parameters():      # BatchNorm affine away from (1, 0): the sums matter
+            if p.dim() == 1:
+                p.copy_(torch.linspace(0.5, 1.5, p.numel()) if n.endswith('weight') else torch.linspace(-0.3, 0.3, p.numel()))
+    return mods
+
+
+def _node_inputs():
+    g = torch.Generator().manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=g)   # noqa: E731
+    return dict(x=mk(4, 16, 24, 32), up=mk(4, 4, 6, 32), y2=mk(4, 8, 12, 64), G1=mk(4, 8, 12, 32), G2=mk(4, 8, 12, 64))
+
+
+def _node_run(mods, t):
+    from das_amd import autograd as ag, nn as nnops
+    ag.reset_step_state()
+    t = {k: v.to('cuda').contiguous() for k, v in t.items()}
+    for k in ('x', 'up', 'y2'):
+        t[k].requires_grad_(True)
+    y = ag.bottleneck_chain(t['x'], mods['blk'])
+    assert y is not None
+    out, s1, s2, _ = mods['unit'](y, t['up'])
+    assert isinstance(s1, nnops.DeferredBN) and isinstance(s2, nnops.DeferredBN)
+    z = nnops.skip_add(t['y2'], s1, s2)
+    ((out * t['G1']).sum() + (z * t['G2']).sum()).backward()
+    torch.cuda.synchronize()
+    res = dict(out=out.detach().cpu(), z=z.detach().cpu(), dx=t['x'].grad.cpu(), dup=t['up'].grad.cpu(), dy2=t['y2'].grad.cpu())
+    res.update({'g.' + n: p.grad.detach().float().cpu() for n, p in mods.named_parameters()})
+    res.update({'b.' + n: b.detach().cpu().clone() for n, b in mods.named_buffers() if 'running' in n})
+    return res
+
+
+def _node_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        probe = torch.ones(4, device='cuda')
+        dist.all_reduce(probe)
+    except Exception as e:   # noqa: BLE001
+        ret[rank] = ('skip', repr(e))
+        dist.destroy_process_group()
+        return
+    from das_amd import nn as nnops
+    n_msgs = [0]
+    real = dist.all_reduce
+
+    def counted(t, *a, **k):
+        n_msgs[0] += 1
+        assert k.get('group') is nnops._STATS_GROUP[0] and nnops._STATS_GROUP[0] is not None   # never the gradients' group
+        return real(t, *a, **k)
+    dist.all_reduce = counted
+    mods = _node_modules('SyncBN')
+    half = slice(2 * rank, 2 * rank + 2)
+    res = _node_run(mods, {k: v[half] for k, v in _node_inputs().items()})
+    dist.all_reduce = real
+    ret[rank] = ('ok', res, n_msgs[0])
+    dist.destroy_process_group()
+
+
+def test_fused_syncbn_nodes_on_two_ranks_equal_plain_batchnorm_on_the_whole_batch_f32():
+    mp.set_start_method('spawn', force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 34500 + os.getpid() % 1000
+    mp.spawn(_node_worker, args=(2, port, ret), nprocs=2, join=True)
+    if ret[0][0] == 'skip':
+        pytest.skip('gloo cannot all-reduce device tensors in this build: ' + ret[0][1])
+    ref = _node_run(_node_modules('BN'), _node_inputs())
+    (_, r0, m0), (_, r1, m1) = ret[0], ret[1]
+    # messages per rank: row check 1; bottleneck forward bn1, bn2, (shortcut + bn3 TOGETHER) = 3; unit merge 1, two deferred skip
+    # convs 2; backward: skip add 1, merge 1, bottleneck bn3 + shortcut (classic, 2) + bn2, bn1 (2)
+    assert m0 == m1 and m0 <= 14, (m0, m1)
+    worst = []
+    for k, want in ref.items():
+        if k.startswith('g.'):
+            got = r0[k] + r1[k]                       # parameter gradients are LOCAL sums: the gradient all-reduce adds them
+        elif k.startswith('b.'):
+            assert torch.equal(r0[k], r1[k]), k
+            got = r0[k]
+        else:
+            got = torch.cat([r0[k], r1[k]])
+        err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-6)
+        worst.append((err, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 3e-5, worst[:6]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # RCCL itself (backend 'nccl'): a one-GPU box can only form a group of ONE rank, so the collectives are identities —
 # but they are real RCCL launches: communicator set-up with `device_id`, bucket all-reduces issued from the completion
 # hooks (autograd's thread) on the communication stream while backward is still queueing kernels, the MAX exchange of

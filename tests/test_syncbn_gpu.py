@@ -81,3 +81,40 @@ def test_two_emulated_ranks_equal_full_batch(relu, res):
     # the ranks' local parameter gradients add up to the full-batch ones (the gradient all-reduce does that)
     torch.testing.assert_close(outs[0][2] + outs[1][2], dg_full, rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(outs[0][3] + outs[1][3], db_full, rtol=1e-5, atol=1e-4)
+
+
+def test_row_count_check_is_looked_at_lazily_and_raises_when_its_answer_says_so():
+    """autograd.verify_rows: the answer of the per-step row-count all-reduce reaches the host through page-locked memory
+    and an event; it is looked at once it HAS arrived (never waited for inside the forward pass) and at the latest
+    ROWS_CHECK_LAG steps late."""
+    from das_amd import autograd as ag
+    ag._rows_pending.clear()
+
+    def push(hi, lo):
+        dev = torch.tensor([hi, lo], dtype=torch.float64, device='cuda')
+        host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+        host.copy_(dev, non_blocking=True)
+        ev = torch.cuda.Event(blocking=True)
+        ev.record()
+        ag._rows_pending.append((host, ev, int(hi)))
+    push(128.0, -128.0)
+    torch.cuda.synchronize()
+    ag.verify_rows()
+    assert not ag._rows_pending
+    push(144.0, -128.0)
+    with pytest.raises(RuntimeError, match='between 128 and 144'):
+        ag.verify_rows(wait=True)
+    assert not ag._rows_pending
+    # an answer that has not arrived is left alone ... (a long kernel in front of the copy)
+    from das_amd import _lib
+    _lib.check(_lib.load().das_dev_occupy_cus(1, 64, 1024, 200000, None), 'occupy')
+    push(64.0, -64.0)
+    ag.verify_rows()
+    assert len(ag._rows_pending) == 1
+    # ... unless more than ROWS_CHECK_LAG are queued
+    for _ in range(ag.ROWS_CHECK_LAG):
+        push(64.0, -64.0)
+    ag.verify_rows()
+    assert len(ag._rows_pending) <= ag.ROWS_CHECK_LAG
+    ag.verify_rows(wait=True)
+    assert not ag._rows_pending

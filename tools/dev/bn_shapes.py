@@ -16,13 +16,14 @@ data = collate([ds[i] for i in range(16)], device=dev)
 opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=35.0)
 for _ in range(2):
     train_iteration(model, opt, data, 2e-3)
-ops.PROFILE = []
+ops.profile_begin()
 R = 3
 for _ in range(R):
     train_iteration(model, opt, data, 2e-3)
 torch.cuda.synchronize()
+PROFILE = ops.profile_end()
 agg = {}
-for ent in ops.PROFILE:
+for ent in PROFILE:
     tag, fl, e0, e1, shape = ent[:5]
     if not (shape and shape[0] == 'bn'):
         continue

@@ -11,13 +11,14 @@ img = torch.randn(8, 3, bench.H, bench.W, device=dev)
 metas = [dict(scale_factor=np.ones(4, dtype=np.float32), filename='')] * 8
 for _ in range(3):
     model(img, metas, return_loss=False)
-ops.PROFILE = []
+ops.profile_begin()
 R = 5
 for _ in range(R):
     model(img, metas, return_loss=False)
 torch.cuda.synchronize()
+PROFILE = ops.profile_end()
 agg = {}
-for tag, fl, e0, e1, shape in [e[:5] for e in ops.PROFILE]:
+for tag, fl, e0, e1, shape in [e[:5] for e in PROFILE]:
     a = agg.setdefault((tag, shape), [0.0, 0.0, 0])
     a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
 tot = sum(a[1] for a in agg.values())

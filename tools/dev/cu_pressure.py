@@ -55,14 +55,13 @@ def run(n, reserve, steps=6):
     side_was, ag.WGRAD_SIDE_STREAM = ag.WGRAD_SIDE_STREAM, False
     train_iteration(model, opt, data, 2e-3)
     torch.cuda.synchronize()
-    ops.PROFILE = []
+    ops.profile_begin()
     occupy(n, 160000)
     train_iteration(model, opt, data, 2e-3)
     torch.cuda.synchronize()
     fam = {}
-    for ent in ops.PROFILE:
+    for ent in ops.profile_end():
         fam[ent[0]] = fam.get(ent[0], 0.0) + ent[2].elapsed_time(ent[3])
-    ops.PROFILE = None
     ag.WGRAD_SIDE_STREAM = side_was
     return ms, fam
 

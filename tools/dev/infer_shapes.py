@@ -17,13 +17,14 @@ bench.calibrate_scores(model, data['img'], metas)
 for _ in range(3):
     model(data['img'], metas, return_loss=False, rescale=True)
 torch.cuda.synchronize()
-ops.PROFILE = []
+ops.profile_begin()
 R = 3
 for _ in range(R):
     model(data['img'], metas, return_loss=False, rescale=True)
 torch.cuda.synchronize()
+PROFILE = ops.profile_end()
 agg = {}
-for ent in ops.PROFILE:
+for ent in PROFILE:
     tag, fl, e0, e1, shape = ent[:5]
     a = agg.setdefault((tag, shape), [0.0, 0.0, 0])
     a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
