@@ -868,6 +868,14 @@ def main():
         extra['hip_graphs'] = 'off (default: every launch queued by hand; --graphs replays the trunk as two hipGraphs)' if train else 'off'
     for _ in range(warmup - (1 if graphs is not None else 0)):
         res = step()
+    # The interpreter's cyclic garbage collector is parked for the timed region (and the per-launch passes after it): a
+    # generation-2 collection over the autograd graphs of a few steps is a 20-100 ms host pause (seen as single 106 / 191 ms
+    # steps among 83 ms ones, tools/dev/first_process_steps.py) — over 20 timed steps one such pause is 1-5 ms per step of
+    # noise that has nothing to do with the path measured. Reference counting still frees every step's tensors.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -891,6 +899,8 @@ def main():
         if r is not None:
             attach_traffic(r, 'train' if train else 'infer', batch)
 
+    gc.enable()
+    gc.unfreeze()
     also = None
     if train and world == 1 and not args.no_also:
         also = also_workloads(args, dev, model, opt, data)

@@ -31,7 +31,7 @@ class DasConvDesc(C.Structure):
 
 
 class DasPackEntry(C.Structure):
-    _fields_ = [('off', i64), ('O', i32), ('I', i32), ('KH', i32), ('KW', i32), ('tile_start', i32)]
+    _fields_ = [('off', i64), ('O', i32), ('I', i32), ('KH', i32), ('KW', i32), ('tile_start', i32), ('s2_pad', i32)]
 
 
 class DasFlowJob(C.Structure):
@@ -95,7 +95,7 @@ SIGNATURES = {
     'das_conv2d_wgrad_nhwc': (i32, [vp, vp, vp, C.POINTER(DasConvDesc), i32, vp]),
     'das_conv2d_wgrad_batch': (i32, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(DasConvDesc), i32, vp]),
     'das_wgrad_last_plan': (i32, [C.POINTER(i64), i32]),
-    'das_pack_conv_weights': (i32, [vp, vp, vp, i32, vp, i32, i32, vp]),
+    'das_pack_conv_weights': (i32, [vp, vp, vp, vp, i32, vp, i32, i32, vp]),
     'das_colsum': (i32, [vp, i32, i64, i32, i32, vp, vp]),
     'das_colsum_acc': (i32, [vp, i32, i64, i32, i32, vp, vp]),
     'das_bn_train_backward_bits_phase': (i32, [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i64, vp]),
@@ -181,7 +181,7 @@ def load():
         except AttributeError as e:
             raise DasHipError(f'libdas_hip.so does not export {name}') from e
         fn.restype, fn.argtypes = res, args
-    if lib.das_abi_version() != 3:
+    if lib.das_abi_version() != 4:
         raise DasHipError('libdas_hip.so ABI version mismatch')
     _lib = lib
     return lib

@@ -887,7 +887,7 @@ class ConvFn(Function):
     `w_packed`/`shift` are prepared by the caller (fused heads concatenate several nn.Conv2d)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, conv_like, geom, relu, out_dtype, out):
+    def forward(ctx, x, weight, bias, conv_like, geom, relu, out_dtype, out, skip_through=False):
         from .nn import bias_shift, packed_weight
         k, s, p = conv_like.kernel_size[0], conv_like.stride[0], conv_like.padding[0]
         xin = _wrap(x, geom)
@@ -899,13 +899,21 @@ class ConvFn(Function):
         ctx.cfg = (k, s, p, relu, geom, conv_like, bias is not None)
         if out is not None:
             ctx.mark_dirty(out)
+        if skip_through:
+            # x is handed through as a second output (see ConvBNTrainSkipFn): the tensor's other consumers take it from
+            # there, their gradient arrives here as `dskip` and is added in the data-gradient epilogue — the head's feature
+            # maps have three or four consumers each, and autograd summed their gradients with one 3-pass add per pair
+            ctx.set_materialize_grads(False)
+            return yd, x
         return yd
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         from .nn import packed_weight_dgrad, packed_weight_dgrad_s2
         x, weight, y = ctx.saved_tensors
         k, s, p, relu, geom, conv, has_bias = ctx.cfg
+        if dy is None:      # this consumer's output took no part in the backward (the root-offset branch): pass dskip on
+            return dskip, None, None, None, None, None, None, None, None
         if relu:
             dy = dy * (y > 0).to(dy.dtype)  # only the stem-free plain convs with ReLU (none on the DAS path)
         dz = dy if dy.dtype == x.dtype else dy.to(x.dtype)
@@ -919,10 +927,16 @@ class ConvFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             hw = None if geom is not None else (x.shape[1], x.shape[2])
-            dx = _d(ops.conv2d_dgrad(dzr, packed_weight_dgrad(conv, x.dtype), k, k, s, p, hw,
-                                     w_classes=packed_weight_dgrad_s2(conv, x.dtype)))
+            wd = packed_weight_dgrad(conv, x.dtype)
+            fuse = dskip is not None and s == 1 and dskip.dtype == x.dtype and dskip.shape == x.shape and wd.shape[0] == x.shape[-1]
+            res = _wrap(dskip.contiguous(), geom) if fuse else None
+            dx = _d(ops.conv2d_dgrad(dzr, wd, k, k, s, p, hw, residual=res, w_classes=packed_weight_dgrad_s2(conv, x.dtype)))
             if dx.shape[-1] != x.shape[-1]:
                 dx = dx[..., :x.shape[-1]]
+            if dskip is not None and not fuse:
+                dx = dx + dskip
+        elif dskip is not None:
+            dx = dskip
         db = None
         if has_bias:
             ba = _param_acc(conv.bias) if getattr(conv, 'bias', None) is not None else None
@@ -931,7 +945,7 @@ class ConvFn(Function):
                 ba[0].fired()
             else:
                 db = ops.colsum(dzr)[:weight.shape[0]]
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 # GroupNorm + ReLU backward with the mask recomputed from the input instead of read from the output; switch for A/B runs / tests

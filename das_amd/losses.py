@@ -150,9 +150,10 @@ def _pack_centers(centers2d, depths, n, device):
         return None
     if n == 0:
         return torch.zeros(0, 3, dtype=torch.float32, device=device)
-    return torch.cat([torch.cat([c.to(device=device, dtype=torch.float32).reshape(-1, 2),
-                                 d.to(device=device, dtype=torch.float32).reshape(-1, 1)], 1)
-                      for c, d in zip(centers2d, depths)]).contiguous()
+    # (three concatenations for the batch, not one per image)
+    c = torch.cat([t.reshape(-1, 2) for t in centers2d]).to(device=device, dtype=torch.float32)
+    d = torch.cat([t.reshape(-1, 1) for t in depths]).to(device=device, dtype=torch.float32)
+    return torch.cat([c, d], 1).contiguous()
 
 
 def das_head_targets(head, B, sizes, device, gt_poses_3d, centers2d=None, depths=None):

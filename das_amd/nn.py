@@ -118,6 +118,9 @@ def packed_weight_dgrad_s2(conv, dtype):
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     if s != 2 or conv.kernel_size[0] != conv.kernel_size[1] or not ops.s2_decomposable(k, p):
         return None
+    sl = _slot_of(conv.weight)
+    if sl is not None and getattr(sl, 's2_pad', -1) == p and k == 3:
+        return sl.packed(dtype, dgrad='s2')   # views of the optimizer's once-per-step packed buffer
     return _cache_of(conv).get(('wd2', dtype), (conv.weight,),
                                lambda: ops.dgrad_s2_weights(packed_weight_dgrad(conv, dtype), k, p))
 
@@ -417,16 +420,28 @@ def sync_stats(stats, cout, all_reduce):
     return stats
 
 
-def conv_plain(x, conv, relu=False, out_dtype=None, out=None):
-    """nn.Conv2d with bias, no norm (the 1x1 predictors)."""
+# A tensor with several consumers is handed THROUGH all but the last of them (conv_plain / ConvModule / dcn_v2 with
+# skip_through=True return (y, x)): the consumers' input gradients then meet in data-gradient epilogues instead of autograd's
+# elementwise adds (14 three-pass adds over 72 MB tensors per step in the head); switch for A/B runs and tests
+CHAIN_CONSUMERS = True
+
+
+def conv_plain(x, conv, relu=False, out_dtype=None, out=None, skip_through=False):
+    """nn.Conv2d with bias, no norm (the 1x1 predictors). skip_through: returns (y, x) with x routed through the conv's
+    autograd node (autograd.ConvFn) for its other consumers; without a graph, or with CHAIN_CONSUMERS off, x itself."""
     from . import autograd as ag
     if ag.grad_mode(_tensor(x), conv.weight, conv.bias):
         assert out is None, 'writing into a slice is an inference-only shortcut'
-        y = ag.ConvFn.apply(_tensor(x), conv.weight, conv.bias, conv, ag._geom(x), relu, out_dtype, None)
-        return ag._wrap(y, ag._geom(x))
+        g = ag._geom(x)
+        if skip_through and CHAIN_CONSUMERS and _tensor(x).requires_grad:
+            y, xs = ag.ConvFn.apply(_tensor(x), conv.weight, conv.bias, conv, g, relu, out_dtype, None, True)
+            return ag._wrap(y, g), ag._wrap(xs, g)
+        y = ag.ConvFn.apply(_tensor(x), conv.weight, conv.bias, conv, g, relu, out_dtype, None)
+        return (ag._wrap(y, g), x) if skip_through else ag._wrap(y, g)
     w = packed_weight(conv, x.dtype, cin_pad=_channels(x))
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    return ops.conv2d(x, w, k, k, s, p, shift=bias_shift(conv), relu=relu, out_dtype=out_dtype, out=out)
+    y = ops.conv2d(x, w, k, k, s, p, shift=bias_shift(conv), relu=relu, out_dtype=out_dtype, out=out)
+    return (y, x) if skip_through else y
 
 
 def _tensor(x):
@@ -437,7 +452,9 @@ def dcn_v2(x, dcn):
     """ModulatedDeformConv2dPack.forward: offset/mask conv (f32 out) -> deformable im2col -> GEMM."""
     C = _channels(x)
     from . import autograd as ag
-    om = conv_plain(x, dcn.conv_offset, out_dtype=torch.float32)  # 27 -> 32 padded channels
+    # (x feeds the offset conv AND the sampling: it is handed through the offset conv's node, so that the sampling's input
+    # gradient is added in the offset conv's data-gradient epilogue)
+    om, x = conv_plain(x, dcn.conv_offset, out_dtype=torch.float32, skip_through=True)  # 27 -> 32 padded channels
     if ag.grad_mode(_tensor(x), dcn.weight, _tensor(om)):
         g = ag._geom(x)
         col = ag.DeformIm2colFn.apply(_tensor(x), _tensor(om), g)
@@ -564,15 +581,23 @@ class ConvModule(nn.Module):
             nn.init.constant_(self.norm.weight, 1)
             nn.init.constant_(self.norm.bias, 0)
 
-    def forward(self, x, residual=None, relu_in=False):
+    def forward(self, x, residual=None, relu_in=False, skip_through=False):
+        """skip_through (plain conv + GroupNorm modules, the head's): returns (y, x) with x routed through the conv's
+        autograd node for the tensor's other consumers (conv_plain)."""
         relu = self.with_activation
         if self.norm_name == 'bn':
+            assert not skip_through
             return conv_bn(x, self.conv, self.norm, relu=relu, residual=residual, relu_in=relu_in)
         assert residual is None and not relu_in
+        if skip_through and not self.is_dcn:
+            y, x = conv_plain(x, self.conv, relu=relu and self.norm_name != 'gn', skip_through=True)
+            return (group_norm_relu(y, self.norm, relu=relu) if self.norm_name == 'gn' else y), x
         if self.norm_name == 'gn':
             y = dcn_v2(x, self.conv) if self.is_dcn else conv_plain(x, self.conv)
-            return group_norm_relu(y, self.norm, relu=relu)
-        return dcn_v2(x, self.conv) if self.is_dcn else conv_plain(x, self.conv, relu=relu)
+            y = group_norm_relu(y, self.norm, relu=relu)
+        else:
+            y = dcn_v2(x, self.conv) if self.is_dcn else conv_plain(x, self.conv, relu=relu)
+        return (y, x) if skip_through else y
 
 
 class Scale(nn.Module):

@@ -246,11 +246,12 @@ def pack_weight_dgrad(w, dtype, out=None):
     return p
 
 
-def pack_conv_weights(flat_src, fwd_dst, dgrad_dst, table_dev, n_entries, total_tiles):
-    """One launch packing every conv weight listed in the device table (see das_pack_conv_weights)."""
-    _need_gpu(flat_src, dgrad_dst)
-    _lib.check(_lib.load().das_pack_conv_weights(_ptr(flat_src), _ptr(fwd_dst), _ptr(dgrad_dst), _DT[dgrad_dst.dtype],
-                                                 _ptr(table_dev), n_entries, total_tiles, _stream()),
+def pack_conv_weights(flat_src, fwd_dst, dgrad_dst, table_dev, n_entries, total_tiles, dgrad_s2_dst=None):
+    """One launch packing every conv weight listed in the device table (see das_pack_conv_weights). dgrad_s2_dst: the
+    buffer the stride-2 layers' parity-class operands go to (entries with s2_pad >= 0), or None."""
+    _need_gpu(flat_src, dgrad_dst, dgrad_s2_dst)
+    _lib.check(_lib.load().das_pack_conv_weights(_ptr(flat_src), _ptr(fwd_dst), _ptr(dgrad_dst), _ptr(dgrad_s2_dst),
+                                                 _DT[dgrad_dst.dtype], _ptr(table_dev), n_entries, total_tiles, _stream()),
                'das_pack_conv_weights')
 
 

@@ -30,7 +30,7 @@ def _is_bias_param(name, module_of):
 
 class _Slot:
     """Where one parameter lives in the flat buffers (attached to the parameter as `_das_slot`)."""
-    __slots__ = ('opt', 'off', 'numel', 'bucket', 'cl_shape', 'grad_cl', 'packable', 'index')
+    __slots__ = ('opt', 'off', 'numel', 'bucket', 'cl_shape', 'grad_cl', 'packable', 'index', 's2_pad')
 
     def fired(self):
         """Tell the optimizer that this parameter's gradient of the current backward is complete."""
@@ -92,6 +92,7 @@ class FlatSGD:
             k = p.numel()
             sl = _Slot()
             sl.opt, sl.off, sl.numel, sl.bucket, sl.cl_shape, sl.grad_cl, sl.packable = self, o, k, 0, None, None, False
+            sl.s2_pad = -1
             if p.dim() == 4:
                 O, I, KH, KW = p.shape
                 vp = self.flat_p[o:o + k].view(O, KH, KW, I)
@@ -103,6 +104,11 @@ class FlatSGD:
                 sl.packable = O % 8 == 0 and I % 8 == 0
                 if sl.packable:
                     self._conv_slots.append(sl)
+                    mod = module_of.get(n)
+                    from . import ops as _ops
+                    if (isinstance(mod, torch.nn.Conv2d) and n.endswith('weight') and mod.stride[0] == 2 and KH == KW == 3
+                            and mod.padding[0] == mod.padding[1] and _ops.s2_decomposable(3, mod.padding[0])):
+                        sl.s2_pad = int(mod.padding[0])   # (its parity-class operands come out of the one packing launch)
             else:
                 self.flat_p[o:o + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[o:o + k].view_as(p)               # parameters become views of the flat buffer
@@ -156,7 +162,8 @@ class FlatSGD:
         self.overlapped_launches = 0               # buckets launched before all_reduce_grads() (diagnostic)
         # one-launch weight packing
         self._table = None
-        self._fwd, self._dgrad, self._packed_epoch = {}, {}, {}
+        self._fwd, self._dgrad, self._dgrad_s2, self._packed_epoch = {}, {}, {}, {}
+        self._has_s2 = False
         if hasattr(model, 'register_load_state_dict_post_hook'):
             from .nn import bump_param_epoch
             model.register_load_state_dict_post_hook(lambda m, keys: bump_param_epoch())
@@ -164,15 +171,16 @@ class FlatSGD:
     # ------------------------------------------------------------------ packed weights
     def _build_table(self):
         import numpy as np
-        dt = np.dtype([('off', '<i8'), ('O', '<i4'), ('I', '<i4'), ('KH', '<i4'), ('KW', '<i4'), ('tile_start', '<i4')],
-                      align=True)
+        dt = np.dtype([('off', '<i8'), ('O', '<i4'), ('I', '<i4'), ('KH', '<i4'), ('KW', '<i4'), ('tile_start', '<i4'),
+                       ('s2_pad', '<i4')], align=True)
         assert dt.itemsize == 32
         tab = np.zeros(len(self._conv_slots), dtype=dt)
         tiles = 0
         for i, sl in enumerate(self._conv_slots):
             O, KH, KW, I = sl.cl_shape
-            tab[i] = (sl.off, O, I, KH, KW, tiles)
+            tab[i] = (sl.off, O, I, KH, KW, tiles, sl.s2_pad)
             tiles += KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
+        self._has_s2 = any(sl.s2_pad >= 0 for sl in self._conv_slots)
         self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.flat_p.device)
         self._tiles = tiles
 
@@ -186,10 +194,22 @@ class FlatSGD:
                 self._dgrad[dtype] = torch.zeros(self.flat_p.numel(), dtype=dtype, device=self.flat_p.device)
                 if dtype != torch.float32:
                     self._fwd[dtype] = torch.zeros_like(self._dgrad[dtype])
+                if self._has_s2:
+                    self._dgrad_s2[dtype] = torch.zeros_like(self._dgrad[dtype])
             ops.pack_conv_weights(self.flat_p, self._fwd.get(dtype), self._dgrad[dtype], self._table,
-                                  len(self._conv_slots), self._tiles)
+                                  len(self._conv_slots), self._tiles, dgrad_s2_dst=self._dgrad_s2.get(dtype))
             self._packed_epoch[dtype] = PARAM_EPOCH[0]
         O, KH, KW, I = sl.cl_shape
+        if dgrad == 's2':
+            # the stride-2 data gradient's operands by output parity: {(ph, pw): (I, nth, ntw, O)} (ops.dgrad_s2_weights)
+            out, o = {}, sl.off
+            cls = ops._s2_classes(KH, sl.s2_pad)
+            for ph, (_, nh, _) in enumerate(cls):
+                for pw, (_, nw, _) in enumerate(cls):
+                    if nh and nw:
+                        out[(ph, pw)] = self._dgrad_s2[dtype][o:o + I * nh * nw * O].view(I, nh, nw, O)
+                        o += I * nh * nw * O
+            return out
         if dgrad:
             return self._dgrad[dtype][sl.off:sl.off + sl.numel].view(I, KH, KW, O)
         src = self.flat_p if dtype == torch.float32 else self._fwd[dtype]

@@ -100,9 +100,11 @@ class NextLevelOffset(nn.Module):
             # training: four separate GEMMs so that autograd sees the four parameter sets
             g = ag._geom(feat)
             f32 = torch.float32
-            so = _cs(conv_plain(feat, self.sampling_offset, out_dtype=f32), 0, J * self.num_heads * 2)
-            conf = _cs(conv_plain(feat, self.sampling_conf, out_dtype=f32), 0, J * self.dim)
-            wgt = _cs(conv_plain(feat, self.update_weight, out_dtype=f32), 0, J * self.dim)
+            # (feat is handed through the first three heads' autograd nodes: one summed gradient, no elementwise adds)
+            so, feat = conv_plain(feat, self.sampling_offset, out_dtype=f32, skip_through=True)
+            conf, feat = conv_plain(feat, self.sampling_conf, out_dtype=f32, skip_through=True)
+            wgt, feat = conv_plain(feat, self.update_weight, out_dtype=f32, skip_through=True)
+            so, conf, wgt = _cs(so, 0, J * self.num_heads * 2), _cs(conf, 0, J * self.dim), _cs(wgt, 0, J * self.dim)
             nxt = _cs(conv_plain(feat, self.update_offset_value, out_dtype=f32), 0, J * self.dim)
             offset = ag._wrap(ag.SigmoidBlendFn.apply(ag._d(offset), ag._d(wgt), ag._d(nxt), g), g)
             return feat, offset, so, conf
@@ -296,31 +298,45 @@ class DASHead(nn.Module):
                 x = m(x)
         return x
 
+    @staticmethod
+    def _run_thru(mods, x):
+        """_run for a tensor that has further consumers: returns (mods(x), x handed through the first module's autograd
+        node) — see nn.conv_plain(skip_through=True)."""
+        if not mods:
+            return x, x
+        y, x = mods[0](x, skip_through=True)
+        for m in list(mods)[1:]:
+            y = m(y)
+        return y, x
+
     def forward_rows(self, x, level_ids):
         """x: `ops.Ragged` rows of the FPN levels `level_ids` (all levels in one launch per layer; the
         head's weights are shared across levels, das_head.py:176-178). Returns Ragged f32:
         cls (rows,1 view), pose_pred (rows,3+6J), centerness (rows,1 view)[, ref_uvd (rows,3J)]."""
         J, L = self.num_joints, self.raw_layout()
-        cls_feat = self._run(self.cls_convs, x)
-        reg_feat = self._run(self.reg_convs, x)
+        cls_feat, x = self._run_thru(self.cls_convs, x)     # (x has three consumers: handed through the first two)
+        reg_feat, x = self._run_thru(self.reg_convs, x)
         pose_feat = self._run(self.pose_convs, x)
         from . import autograd as ag
         train_graph = ag.grad_mode(x.data, self.conv_cls.weight)
         raw = None if train_graph else x.new(L['total'], torch.float32)
         parts = []
 
-        def predict(feat, prevs, pred, c0):
+        def predict(feat, prevs, pred, c0, more=False):
+            """more: `feat` has further consumers after this predictor — returns it handed through (train graph)."""
             n = _p8(pred.weight.shape[0])
             if train_graph:  # slices are concatenated (in the raw_layout order) so autograd sees each predictor
-                parts.append(conv_plain(self._run(prevs, feat), pred, out_dtype=torch.float32).data)
+                mid, feat = self._run_thru(prevs, feat) if (more and prevs) else (self._run(prevs, feat), feat)
+                parts.append(conv_plain(mid, pred, out_dtype=torch.float32).data)
             else:
                 conv_plain(self._run(prevs, feat), pred, out_dtype=torch.float32, out=_cs(raw, c0, c0 + n))
+            return feat
         predict(cls_feat, self.conv_cls_prev, self.conv_cls, L['cls'])
-        predict(reg_feat, self.conv_centerness_prev, self.conv_centerness, L['ctr'])
-        predict(reg_feat, self.conv_reg_prevs[0], self.conv_regs[0], L['off'])
+        reg_feat = predict(reg_feat, self.conv_centerness_prev, self.conv_centerness, L['ctr'], more=True)
+        reg_feat = predict(reg_feat, self.conv_reg_prevs[0], self.conv_regs[0], L['off'], more=True)
         predict(reg_feat, self.conv_reg_prevs[1], self.conv_regs[1], L['depth'])
-        predict(pose_feat, self.conv_pose_prevs[0], self.conv_poses[0], L['uvd'])
-        predict(pose_feat, self.conv_pose_prevs[1], self.conv_poses[1], L['sigma'])
+        pose_feat = predict(pose_feat, self.conv_pose_prevs[0], self.conv_poses[0], L['uvd'], more=True)
+        pose_feat = predict(pose_feat, self.conv_pose_prevs[1], self.conv_poses[1], L['sigma'], more=True)
 
         sc = self._scale_values()
         desc = ops.head_desc(J, self.root_idx, L['total'], L['off'], L['depth'], L['uvd'], L['sigma'],

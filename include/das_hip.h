@@ -233,8 +233,12 @@ typedef struct {
   long long off;
   int O, I, KH, KW;
   int tile_start;
+  int s2_pad;   /* >= 0: a stride-2 KH x KH conv with this padding — its flipped taps are ALSO written split by output
+                 * parity into dgrad_s2_dst[off ...]: the four (Cin, nth, ntw, Cout) operands of the stride-2 data
+                 * gradient's sub-grid launches (DasConvDesc.out_sub), classes (0,0), (0,1), (1,0), (1,1) back to back;
+                 * -1: no such copies */
 } DasPackEntry;
-int das_pack_conv_weights(const float* flat_src, void* fwd_dst, void* dgrad_dst, int dtype,
+int das_pack_conv_weights(const float* flat_src, void* fwd_dst, void* dgrad_dst, void* dgrad_s2_dst, int dtype,
                           const DasPackEntry* entries_dev, int n_entries, int total_tiles, void* stream);
 
 /* GroupNorm(+ReLU) backward over ragged rows. x = pre-norm input saved by forward, y = forward output

@@ -36,25 +36,37 @@ def test_pack_conv_weights_one_launch(dtype):
     from das_amd import ops as o
     shapes = [(64, 64, 1, 1), (40, 24, 3, 3), (256, 128, 3, 3), (8, 8, 7, 7), (136, 72, 1, 1)]
     ws = [cases.randn(10 + i, *s) for i, s in enumerate(shapes)]
-    dt = np.dtype([('off', '<i8'), ('O', '<i4'), ('I', '<i4'), ('KH', '<i4'), ('KW', '<i4'), ('tile_start', '<i4')],
-                  align=True)
+    dt = np.dtype([('off', '<i8'), ('O', '<i4'), ('I', '<i4'), ('KH', '<i4'), ('KW', '<i4'), ('tile_start', '<i4'),
+                   ('s2_pad', '<i4')], align=True)
     tab = np.zeros(len(ws), dtype=dt)
     off, tiles, chunks = 16, 0, [torch.zeros(16)]
+    s2_pad = {1: 1, 2: 1}      # the two 3x3 tensors stand for stride-2 layers with padding 1: parity-class operands too
     for i, w in enumerate(ws):
         O, I, KH, KW = w.shape
-        tab[i] = (off, O, I, KH, KW, tiles)
+        tab[i] = (off, O, I, KH, KW, tiles, s2_pad.get(i, -1))
         tiles += KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
         chunks.append(w.permute(0, 2, 3, 1).reshape(-1))
         off += w.numel()
     flat = torch.cat(chunks).to(DEV)
     fwd = torch.zeros(flat.numel(), dtype=dtype, device=DEV) if dtype != torch.float32 else None
     dg = torch.zeros(flat.numel(), dtype=dtype, device=DEV)
-    o.pack_conv_weights(flat, fwd, dg, torch.from_numpy(tab.view(np.uint8).copy()).to(DEV), len(ws), tiles)
+    dg2 = torch.zeros(flat.numel(), dtype=dtype, device=DEV)
+    o.pack_conv_weights(flat, fwd, dg, torch.from_numpy(tab.view(np.uint8).copy()).to(DEV), len(ws), tiles, dgrad_s2_dst=dg2)
     for i, w in enumerate(ws):
         O, I, KH, KW = w.shape
         a = int(tab[i]['off'])
         got_d = dg[a:a + w.numel()].view(I, KH, KW, O)
         torch.testing.assert_close(got_d, o.pack_weight_dgrad(w.to(DEV), dtype), rtol=0, atol=0)
+        if i in s2_pad:     # the four parity classes back to back == the strided slices ops.dgrad_s2_weights makes
+            want, b = o.dgrad_s2_weights(got_d, KH, s2_pad[i]), a
+            assert sorted(want) == [(0, 0), (0, 1), (1, 0), (1, 1)]
+            for key in sorted(want):
+                n = want[key].numel()
+                torch.testing.assert_close(dg2[b:b + n].view(want[key].shape), want[key], rtol=0, atol=0)
+                b += n
+            assert b == a + w.numel()
+        else:
+            assert float(dg2[a:a + w.numel()].float().abs().sum()) == 0.0
         if fwd is not None:
             torch.testing.assert_close(fwd[a:a + w.numel()].view(O, KH, KW, I), o.pack_weight(w.to(DEV), dtype),
                                        rtol=0, atol=0)

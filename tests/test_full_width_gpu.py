@@ -290,10 +290,11 @@ def four_stage_eval():
 
 
 # measured on MI355X (printed by the test): bf16 head maps of the 4-stage net against the f32 oracle, relative to each map's
-# range, and the joints of the detections both paths keep; the bounds are 2x the measured values (VERDICT r4 #8 ii)
-BF16_EVAL_MAP_BOUND = {'cls': 0.2, 'pose': 0.2, 'ctr': 0.2}
-BF16_EVAL_JOINT_PX_BOUND = 16.0
-BF16_EVAL_SHARED_MIN = 0.8
+# range — cls 3.8e-3, pose 3.1e-2, centerness 8.9e-2 —, 99 of the oracle's 100 detections kept, the shared detections'
+# joints within 0.11 px; the bounds are 2x the measured values (VERDICT r4 #8 ii)
+BF16_EVAL_MAP_BOUND = {'cls': 7.6e-3, 'pose': 6.3e-2, 'ctr': 1.8e-1}
+BF16_EVAL_JOINT_PX_BOUND = 0.25
+BF16_EVAL_SHARED_MIN = 0.95
 
 
 def test_four_stage_full_width_eval_bf16_maps_and_decode_against_the_oracle():
@@ -330,7 +331,9 @@ def test_four_stage_full_width_eval_bf16_maps_and_decode_against_the_oracle():
 # kernels the benchmarked B = 16 step must have dispatched (das_prof record names)
 B16_KERNELS = ('conv_glds4_kernel<pp,288>', 'conv_glds4_kernel<pp>', 'conv_glds3_kernel<pp>', 'conv1x1_stream_kernel',
                'conv3x3_c64_kernel', 'conv_wgrad_pp_kernel', 'conv_wgrad_kernel')
-B16_BAND = dict(loss_cls=0.08, loss_depth=0.08, loss_centerness=0.08, loss_pose=0.2, loss=0.2)
+# (measured: bf16 0.16 % / 0.08 % / 0.09 % (cls, depth, centerness) and 0.45 % (pose) from f32 — statistics over 16 frames are far
+# less chaotic than over 2; bands ~10x the measured values, a draw of the float atomics included)
+B16_BAND = dict(loss_cls=0.02, loss_depth=0.02, loss_centerness=0.02, loss_pose=0.04, loss=0.04)
 
 
 def test_benchmarked_b16_step_bf16_losses_follow_f32_and_dispatch_the_benchmarked_kernels():

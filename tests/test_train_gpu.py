@@ -171,3 +171,45 @@ def test_dashead_forward_graph_backward_vs_oracle(golden_dir):
         e_hip.append(rel(a.grad.permute(0, 3, 1, 2).double().cpu().numpy(), b64.grad.numpy()))
         e_o32.append(rel(b32.grad.double().numpy(), b64.grad.numpy()))
     band_check(e_hip, e_o32, 'head params + feats')
+
+
+def test_head_consumer_chaining_equals_autograd_sums(golden_dir):
+    """nn.CHAIN_CONSUMERS: a head tensor with several consumers (the FPN features, the three towers' outputs, a DCNv2 layer's
+    input, the recursive-update feature) is handed through its consumers' autograd nodes, so that their input gradients
+    are added in data-gradient epilogues — against autograd's own elementwise sums (switch off): every parameter
+    gradient and the gradients of the input features, f32, to summation order."""
+    from das_amd import nn as dnn
+    z = load(golden_dir, 'head_train')
+    sd = sd_of(z, 3)
+    feats = cases.head_feats()
+    res = {}
+    for chain in (True, False):
+        dnn.CHAIN_CONSUMERS = chain
+        try:
+            head = build_head()
+            head.load_state_dict(sd)
+            head.to(DEV).train()
+            fin = [t.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True) for t in feats]
+            outs = head([t.permute(0, 3, 1, 2) for t in fin])
+            tot = 0
+            for ni, lst in enumerate(outs):
+                for i, t in enumerate(lst):
+                    tot = tot + (t.float() * cases.randn(300 + 10 * ni + i, *t.shape).to(DEV)).sum()
+            tot.backward()
+            res[chain] = ({n: p.grad.detach().float().cpu() for n, p in head.named_parameters() if p.grad is not None},
+                          [t.grad.detach().cpu() for t in fin])
+        finally:
+            dnn.CHAIN_CONSUMERS = True
+    (pa, fa), (pb, fb) = res[True], res[False]
+    assert set(pa) == set(pb) and len(pa) > 80
+    # (a conv bias in front of a GroupNorm has a gradient that is zero up to rounding — the normalisation removes it —: such
+    # tensors hold run-to-run noise four orders below the others and are compared against the typical gradient scale instead)
+    scale = float(np.median([float(v.abs().max()) for v in pb.values()]))
+    for n in pa:
+        den = max(float(pb[n].abs().max()), 1e-2 * scale)
+        # ('.conv.bias' = the bias of a ConvModule's conv in front of its GroupNorm: a sum of ~10^5 cancelling terms of order one,
+        # i.e. 1e-4 of f32 summation noise around zero whichever way the gradients are routed)
+        tol = 1e-3 if n.endswith('.conv.bias') else 2e-5
+        assert float((pa[n] - pb[n]).abs().max()) / den < tol, (n, float((pa[n] - pb[n]).abs().max()), den)
+    for a, b in zip(fa, fb):
+        assert rel(a.numpy(), b.numpy()) < 2e-5
