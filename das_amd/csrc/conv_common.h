@@ -170,7 +170,10 @@ __device__ __forceinline__ int tile_row_m(const ConvP& p, int m0, int ml) {
 // registers across tiles (a thread keeps its channels: vec = tid % VR) and conv_epilogue_flush_stats reduces and adds
 // them once per workgroup at the end of the launch, instead of an LDS reduction, two barriers and 2 * BN atomics per tile.
 struct NoCarry {};
-template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, bool T2D = false, typename Acc, typename Carry = NoCarry>
+// BITS = false: the ReLU-mask-as-bits operands (ConvP::bnb_bits / res_bits) are compiled out — conv3x3_c64_kernel's epilogue is
+// not overlapped with anything (one workgroup owns the CU), and the step's launches of that kernel never carry bits.
+template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, bool T2D = false, bool BITS = true, typename Acc,
+          typename Carry = NoCarry>
 __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* smem, int m0, int n0, Carry&& carry = Carry{}) {
   constexpr bool CARRY = !std::is_same<typename std::decay<Carry>::type, NoCarry>::value;   // (a float[2 * EPVO] otherwise)
   constexpr int TM = TL::TM, TN = TL::TN, NT = TL::NT;
@@ -225,8 +228,8 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   const OT* rg = reinterpret_cast<const OT*>(p.res);
   const OT* bxg = reinterpret_cast<const OT*>(p.bnb_raw);   // fused BatchNorm-backward reduction (see ConvP)
   const OT* byg = reinterpret_cast<const OT*>(p.bnb_y);
-  const unsigned char* bbits = p.bnb_bits;
-  const unsigned char* rbits = bxg ? p.res_bits : nullptr;
+  const unsigned char* bbits = BITS ? p.bnb_bits : nullptr;
+  const unsigned char* rbits = (BITS && bxg) ? p.res_bits : nullptr;
   if (n < p.Cout) {
     constexpr int ITERS = BMT / RP;  // rows per thread, processed CH at a time
     constexpr int CH = ITERS % 4 == 0 ? 4 : ITERS % 3 == 0 ? 3 : ITERS % 2 == 0 ? 2 : 1;

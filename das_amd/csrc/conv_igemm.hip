@@ -336,7 +336,7 @@ struct TilingC64 {
   static __device__ __forceinline__ int wave_n0(int) { return 0; }
 };
 constexpr int C64_WROW = 1168, C64_WBYTES = 64 * C64_WROW, C64_PATCH = 41 * 1024;   // (324 pixels x 128 B, in 1 KiB DMA units)
-template <typename OT>
+template <typename OT, bool BITS>
 __global__ __launch_bounds__(384) void conv3x3_c64_kernel(ConvP p, int ntiles) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -425,9 +425,9 @@ __global__ __launch_bounds__(384) void conv3x3_c64_kernel(ConvP p, int ntiles) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // B: every wave is done reading the patch
     if (p.stats) {   // (wave-uniform)
-      conv_epilogue<OT, 64, 256, TilingC64, true>(acc, p, buf, tile, 0, carry);
+      conv_epilogue<OT, 64, 256, TilingC64, true, BITS>(acc, p, buf, tile, 0, carry);
     } else {
-      conv_epilogue<OT, 64, 256, TilingC64, true>(acc, p, buf, tile, 0);
+      conv_epilogue<OT, 64, 256, TilingC64, true, BITS>(acc, p, buf, tile, 0);
     }
   }
   if (p.stats) {
@@ -1472,13 +1472,18 @@ bool try_launch_c64(const ConvP& p, hipStream_t s) {
   const size_t sm = C64_WBYTES + 2 * (size_t)C64_PATCH;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<OT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<OT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_c64_kernel<OT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
       return false;
     attr_set = true;
   }
   const int grid = std::min(ntiles, usable_cus());
   dastune::note_kernel("conv3x3_c64_kernel");
-  hipLaunchKernelGGL((conv3x3_c64_kernel<OT>), dim3(grid), dim3(384), sm, s, p, ntiles);
+  if (p.bnb_bits || p.res_bits) {
+    hipLaunchKernelGGL((conv3x3_c64_kernel<OT, true>), dim3(grid), dim3(384), sm, s, p, ntiles);
+  } else {   // (the step's launches: conv2 of a bottleneck never sees a mask as bits)
+    hipLaunchKernelGGL((conv3x3_c64_kernel<OT, false>), dim3(grid), dim3(384), sm, s, p, ntiles);
+  }
   return true;
 }
 

@@ -1,8 +1,8 @@
 """Round 4: HBM traffic and matrix-core counters of the REAL train step's launches (no proxy mix).
 Inputs: the rocpd databases of three `rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 2 --warmup 1
 --no-cpu-baseline --no-also` passes (FETCH_SIZE; WRITE_SIZE; the MFMA set) — tools/dev/scripts/pmc_r4.sh.
-Outputs under <out>: r04_pmc_step_traffic.md (every kernel variant: dispatches, mean us, fetch / write MB per dispatch, TB/s),
-r04_stream_modes.md (conv1x1_stream_kernel<KB, WN, MODE> only), r04_pmc_mfma_step.md, and the `train` entries of traffic.json
+Outputs under <out>: r05_pmc_step_traffic.md (every kernel variant: dispatches, mean us, fetch / write MB per dispatch, TB/s),
+r05_stream_modes.md (conv1x1_stream_kernel<KB, WN, MODE> only), r05_pmc_mfma_step.md, and the `train` entries of traffic.json
 (bytes per launch of every bench.py family, from the step's own launches).
 usage: pmc_step_tables.py fetch.db write.db mfma.db <out dir>"""
 import json
@@ -55,7 +55,7 @@ def main(fdb, wdb, mdb, out):
         us = dur.get(k, (0, 0.0))[1]
         rows.append((k, n, us, fmb, wmb))
     rows.sort(key=lambda r: -r[1] * r[2])
-    with open(f'{out}/r04_pmc_step_traffic.md', 'w') as f:
+    with open(f'{out}/r05_pmc_step_traffic.md', 'w') as f:
         f.write('# HBM traffic of every kernel of the REAL train step (round 4)\n\n')
         f.write(f'commands: `{CMD.format("FETCH_SIZE")}` and the same with `WRITE_SIZE` (separate passes, kernel trace only: '
                 'tools/dev/scripts/pmc_r4.sh). The launches are the step\'s own (B = 16, 4-stage MSPN-50 + FPN + head; warm-up, timed and '
@@ -65,11 +65,11 @@ def main(fdb, wdb, mdb, out):
         f.write('| kernel | dispatches | mean us | fetch MB | write MB | (fetch + write) / time, TB/s |\n|---|---|---|---|---|---|\n')
         for k, n, us, fmb, wmb in rows[:70]:
             f.write(f'| `{k[:100]}` | {n} | {us:.1f} | {fmb:.1f} | {wmb:.1f} | {(fmb + wmb) / max(us, 1e-9):.2f} |\n')
-    with open(f'{out}/r04_stream_modes.md', 'w') as f:
+    with open(f'{out}/r05_stream_modes.md', 'w') as f:
         f.write('# conv1x1_stream_kernel<KB, WN, MODE> on the step\'s real operands (round 4; VERDICT r3 #2(i))\n\n')
         f.write('K = 32 KB input channels, WN waves across 32-channel groups; MODE 0 forward + BatchNorm statistics, 2 data gradient + '
                 'second gradient, 3 data gradient + fused BatchNorm-backward sums with the mask from y (+ second gradient), 4 the same with '
-                'the mask recomputed from raw. Same passes as r04_pmc_step_traffic.md.\n\n')
+                'the mask recomputed from raw. Same passes as r05_pmc_step_traffic.md.\n\n')
         f.write('| variant | dispatches | mean us | fetch MB | write MB | TB/s |\n|---|---|---|---|---|---|\n')
         tot = [0, 0.0, 0.0]
         for k, n, us, fmb, wmb in sorted((r for r in rows if r[0].startswith('conv1x1_stream_kernel<')), key=lambda r: r[0]):
@@ -78,7 +78,7 @@ def main(fdb, wdb, mdb, out):
         f.write(f'\nfamily: {tot[0]} dispatches, {tot[2] / max(tot[1], 1e-9):.2f} TB/s of measured HBM traffic\n')
     # matrix-core counters
     mf, mdur = per_kernel(mdb, 'mfma')
-    with open(f'{out}/r04_pmc_mfma_step.md', 'w') as f:
+    with open(f'{out}/r05_pmc_mfma_step.md', 'w') as f:
         f.write('# Matrix-core counters of the REAL train step\'s tile / weight-gradient kernels (round 4)\n\n')
         f.write(f'command: `{CMD.format("SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE")}`. '
                 'mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128): GUI_ACTIVE is summed over the 8 XCDs (32 CUs x 4 SIMDs each); '
