@@ -228,8 +228,13 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   const OT* rg = reinterpret_cast<const OT*>(p.res);
   const OT* bxg = reinterpret_cast<const OT*>(p.bnb_raw);   // fused BatchNorm-backward reduction (see ConvP)
   const OT* byg = reinterpret_cast<const OT*>(p.bnb_y);
-  const unsigned char* bbits = BITS ? p.bnb_bits : nullptr;
-  const unsigned char* rbits = (BITS && bxg) ? p.res_bits : nullptr;
+#ifdef DAS_EPI_NOBITS   // dev build (make nobits): what do the dynamic bits branches cost the launches that carry no bits?
+  constexpr bool BITS_ = false;
+#else
+  constexpr bool BITS_ = BITS;
+#endif
+  const unsigned char* bbits = BITS_ ? p.bnb_bits : nullptr;
+  const unsigned char* rbits = (BITS_ && bxg) ? p.res_bits : nullptr;
   if (n < p.Cout) {
     constexpr int ITERS = BMT / RP;  // rows per thread, processed CH at a time
     constexpr int CH = ITERS % 4 == 0 ? 4 : ITERS % 3 == 0 ? 3 : ITERS % 2 == 0 ? 2 : 1;

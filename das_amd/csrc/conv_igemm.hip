@@ -475,7 +475,10 @@ __global__ __launch_bounds__((BN == 256 ? 512 : 2 * BMT)) void splitk_finish_ker
 // K-steps ahead of the MFMAs: per step  s_waitcnt vmcnt(one tile's DMAs still in flight) -> s_barrier ->
 // issue tile k+2 into the buffer freed by step k-1 -> MFMAs on tile k. Counted vmcnt + raw s_barrier
 // (a __syncthreads() would drain the DMA queue, cdna guide section 5).
-template <typename T, typename OT, bool PP = false>
+// BITS = false: the epilogue without the mask-bits operands (conv_common.h), for the launches that carry none — the epilogue
+// of a one-workgroup-per-CU tile kernel overlaps with nothing, and its dynamic bits branches cost the 256 x 128 kernel 4-8 %
+// of a launch (make nobits / tools/dev/train_shapes.py: conv_glds3<pp> 6.2 -> 5.96 ms, conv_glds3 2.8 -> 2.6 ms per step)
+template <typename T, typename OT, bool PP = false, bool BITS = true>
 __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   constexpr int BN = 128, BMT = 256, NBUF = 3;
   constexpr int EPV = Elem<T>::EPV;
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   DAS_STAMP(3);
   if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); DAS_STAMP(4); return; }
   __syncthreads();  // all LDS reads done before the C tile reuses the buffers
-  conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
+  conv_epilogue<OT, BN, BMT, Tiling<BN, BMT>, false, BITS>(acc, p, smem, m0, n0);
   DAS_STAMP(4);
 }
 
@@ -953,8 +956,10 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
     (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
     (void)hipFuncSetAttribute((const void*)conv_glds_kernel<T, OT, BN, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_glds);
     if (BN == 128) {
-      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
-      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
     }
     attr_set = true;
   }
@@ -970,10 +975,13 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
       }
     }
     dastune::note_kernel(pp3 ? "conv_glds3_kernel<pp>" : "conv_glds3_kernel");
+    const bool bits = p.bnb_bits || p.res_bits;
     if (pp3) {
-      hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      if (bits) hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true, true>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      else hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
     } else {
-      hipLaunchKernelGGL((conv_glds3_kernel<T, OT, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      if (bits) hipLaunchKernelGGL((conv_glds3_kernel<T, OT, false, true>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      else hipLaunchKernelGGL((conv_glds3_kernel<T, OT, false, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
     }
   } else if (glds) {
     const int ks = BN >= 64 ? pick_ksplit(p.nblocks, nk128, 2, 1, (long long)rows * p.Cout, tail) : 1;

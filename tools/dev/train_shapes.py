@@ -9,6 +9,9 @@ from das_amd.datasets import SyntheticPoseDataset, collate
 from das_amd.optim import FlatSGD, train_iteration
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+if os.environ.get('DASLIB'):   # dev: a variant build of the library (make nobits / deep / stamps)
+    from das_amd import _lib as _l
+    _l.LIB_PATH = os.path.join(os.path.dirname(_l.LIB_PATH), os.environ['DASLIB'])
 from das_amd import autograd as _ag
 _ag.WGRAD_SIDE_STREAM = False
 if os.environ.get('WGB'):
