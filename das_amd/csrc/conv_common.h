@@ -169,6 +169,9 @@ __device__ __forceinline__ int tile_row_m(const ConvP& p, int m0, int ml) {
 // `carry` (persistent kernels): the thread's per-channel statistic sums [2][16 / sizeof(OT)] live in the CALLER's
 // registers across tiles (a thread keeps its channels: vec = tid % VR) and conv_epilogue_flush_stats reduces and adds
 // them once per workgroup at the end of the launch, instead of an LDS reduction, two barriers and 2 * BN atomics per tile.
+#ifndef DAS_EPI_CH
+#define DAS_EPI_CH 4
+#endif
 struct NoCarry {};
 // BITS = false: the ReLU-mask-as-bits operands (ConvP::bnb_bits / res_bits) are compiled out — conv3x3_c64_kernel's epilogue is
 // not overlapped with anything (one workgroup owns the CU), and the step's launches of that kernel never carry bits.
@@ -237,7 +240,11 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   const unsigned char* rbits = (BITS_ && bxg) ? p.res_bits : nullptr;
   if (n < p.Cout) {
     constexpr int ITERS = BMT / RP;  // rows per thread, processed CH at a time
-    constexpr int CH = ITERS % 4 == 0 ? 4 : ITERS % 3 == 0 ? 3 : ITERS % 2 == 0 ? 2 : 1;
+    // rows in flight per chunk: four, but two on the 256-channel tiles — with 32 vectors of per-channel constants and three operand
+    // vectors per row live, four rows made conv_glds4_kernel spill 70 registers around every row (no spills with two: -0.15 ms
+    // per step; the 128-channel tiles lose 2-4 % with two, make variant VAR=ch2)
+    constexpr int CHMAX = DAS_EPI_CH < 4 ? DAS_EPI_CH : (BN >= 256 ? 2 : 4);
+    constexpr int CH = (ITERS % 4 == 0 && CHMAX >= 4) ? 4 : (ITERS % 3 == 0 && CHMAX >= 3) ? 3 : ITERS % 2 == 0 ? 2 : 1;
     static_assert(BMT % RP == 0, "tile rows must be a multiple of the rows per pass");
     static_assert(ITERS % CH == 0, "tile rows per thread must be a multiple of the chunk");
     float bmu[EPVO], bis[EPVO], bga[EPVO], bbe[EPVO];
