@@ -172,6 +172,9 @@ __device__ __forceinline__ int tile_row_m(const ConvP& p, int m0, int ml) {
 #ifndef DAS_EPI_CH
 #define DAS_EPI_CH 4
 #endif
+#ifndef DAS_EPI_DEEP
+#define DAS_EPI_DEEP 1
+#endif
 struct NoCarry {};
 // BITS = false: the ReLU-mask-as-bits operands (ConvP::bnb_bits / res_bits) are compiled out — conv3x3_c64_kernel's epilogue is
 // not overlapped with anything (one workgroup owns the CU), and the step's launches of that kernel never carry bits.
@@ -244,9 +247,9 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
     // vectors per row live, four rows made conv_glds4_kernel spill 70 registers around every row (no spills with two: -0.15 ms
     // per step; the 128-channel tiles lose 2-4 % with two, make variant VAR=ch2)
     constexpr int CHMAX = DAS_EPI_CH < 4 ? DAS_EPI_CH : (BN >= 256 ? 2 : 4);
-    constexpr int CH = (ITERS % 4 == 0 && CHMAX >= 4) ? 4 : (ITERS % 3 == 0 && CHMAX >= 3) ? 3 : ITERS % 2 == 0 ? 2 : 1;
+    constexpr int CH0 = (ITERS % 4 == 0 && CHMAX >= 4) ? 4 : (ITERS % 3 == 0 && CHMAX >= 3) ? 3 : ITERS % 2 == 0 ? 2 : 1;
     static_assert(BMT % RP == 0, "tile rows must be a multiple of the rows per pass");
-    static_assert(ITERS % CH == 0, "tile rows per thread must be a multiple of the chunk");
+    static_assert(ITERS % CH0 == 0, "tile rows per thread must be a multiple of the chunk");
     float bmu[EPVO], bis[EPVO], bga[EPVO], bbe[EPVO];
     if (bxg) {
 #pragma unroll
@@ -256,6 +259,12 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
         bbe[j] = (p.bnb_relu && !byg && !bbits) ? p.bnb_beta[n + j] : 0.f;
       }
     }
+    // The rows of a chunk are requested together (their memory latency overlaps instead of adding up row by row). A launch
+    // whose only epilogue operand is the pre-norm tensor of the fused BatchNorm backward (mask recomputed: no residual, no y,
+    // no bits — most data gradients inside a bottleneck chain) takes ALL its rows in one chunk on the 128-channel tiles: one
+    // exposed round trip per tile instead of two.
+    auto rows_loop = [&](auto chc) {
+      constexpr int CH = decltype(chc)::value;
 #pragma unroll 1
     for (int it0 = 0; it0 < ITERS; it0 += CH) {
       // the residual rows of a chunk are requested together, ahead of the LDS reads, so that their
@@ -343,6 +352,13 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
         }
         *reinterpret_cast<uint4*>(yg + om[u] * p.yps + n) = outv;
       }
+    }
+    };
+    constexpr int CHDEEP = (BN == 128 && BMT >= 256 && !T2D && ITERS % 8 == 0 && DAS_EPI_DEEP) ? 8 : CH0;   // (conv_glds3_kernel: the others have no registers to spare)
+    if (CHDEEP != CH0 && bxg && !rg && !byg && !bbits) {
+      rows_loop(std::integral_constant<int, CHDEEP>{});
+    } else {
+      rows_loop(std::integral_constant<int, CH0>{});
     }
   }
   DAS_STAMP(6);

@@ -198,7 +198,7 @@ __device__ __forceinline__ void splitk_store(const Acc& acc, const ConvP& p, int
 }
 
 template <typename T, typename OT, int BN, int BMT>
-__global__ __launch_bounds__(2 * BMT) void conv_glds_kernel(ConvP p) {
+__global__ __launch_bounds__(2 * BMT, 2) void conv_glds_kernel(ConvP p) {   // (two workgroups per CU: at most 256 registers)
   constexpr int EPV = Elem<T>::EPV;
   constexpr int BK = 8 * EPV;  // 128 bytes of K per row
   constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN;
