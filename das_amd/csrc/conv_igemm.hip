@@ -1019,7 +1019,8 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
 // MODE (keeps each variant under the 168 registers that ten waves per workgroup allow): 0 = plain, optional BatchNorm
 // statistics (training forward); 1 = scale / shift, optional ReLU (eval); 2 = residual add, optional ReLU (data gradient);
 // 3 / 4 = data gradient with the fused BatchNorm-backward reduction (ConvP::bnb_*): optional residual, mask from the
-// saved output y (3; no y = no mask) or recomputed from raw with the layer's affine (4), per-channel sums in registers;
+// saved output y (3; no y = no mask), from its recorded bits (6) or recomputed from raw with the layer's affine (4),
+// per-channel sums in registers;
 // 5 = scale / shift, then residual add, optional ReLU (the closing 1x1 conv of an eval-mode bottleneck).
 // The per-channel sums of a wave end up in lane 15 of each DPP row: sixteen values (8 channels x {sum, sum of squares})
 // for each of the four channel groups. Sixteen atomic instructions with four live lanes each cost the launch 4-5 us of
@@ -1037,7 +1038,7 @@ __device__ __forceinline__ void stream_stat_flush(float* sred, int lane, int n0,
 template <int KB, int WN, int MODE>   // K = 32 * KB input channels; WN waves across the 32-channel groups, 8 / WN across pixels
 __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, int ntiles) {
   using T = bf16_t;
-  constexpr bool STATS = MODE == 0, AFF = MODE == 1 || MODE == 5, RES = MODE == 2 || MODE == 5, BNB = MODE == 3 || MODE == 4;
+  constexpr bool STATS = MODE == 0, AFF = MODE == 1 || MODE == 5, RES = MODE == 2 || MODE == 5, BNB = MODE == 3 || MODE == 4 || MODE == 6;
   constexpr int WM = 8 / WN, TM = 64, PB = TM / WM / 16;    // 16-pixel blocks per wave and tile
   constexpr int K = KB * 32, SUBS = (K + 63) / 64;
   constexpr int SUBB = TM * 128, STAGE = SUBS * SUBB;       // bytes
@@ -1129,11 +1130,17 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
     // opens, HB pixel blocks at a time, by hand-issued loads that land while those blocks' MFMAs run; the wait that
     // follows also drains the previous blocks' stores (one counter for both kinds) — the price of not keeping a second
     // register set per operand, which this variant has no room for.
-    constexpr int HB = PB > 2 ? 2 : PB;
+    // (MODE 6 — the mask as bits, no y vectors — has the registers for all of a tile's pixel blocks at once — one exposed round trip per tile instead of two: the
+    // small-M launches walk three or four tiles per workgroup with nothing else to hide the latency behind)
+#ifndef DAS_STREAM_HB6
+#define DAS_STREAM_HB6 PB
+#endif
+    // (K = 256 with eight column waves keeps 64 weight registers: two blocks at a time there, as in MODE 3)
+    constexpr int HB = (MODE == 6 && !(KB == 8 && WN == 8)) ? (DAS_STREAM_HB6 < PB ? DAS_STREAM_HB6 : PB) : (PB > 2 ? 2 : PB);
     const T* rgb = reinterpret_cast<const T*>(p.res);
     const T* bx = reinterpret_cast<const T*>(p.bnb_raw);
     const T* by = MODE == 3 ? reinterpret_cast<const T*>(p.bnb_y) : nullptr;
-    const unsigned char* bb = MODE == 3 ? p.bnb_bits : nullptr;   // (the mask as a byte per vector instead of y)
+    const unsigned char* bb = MODE == 6 ? p.bnb_bits : nullptr;   // (the mask as a byte per vector instead of y)
     const unsigned char* rb = rgb ? p.res_bits : nullptr;        // (the residual's own mask: res * mask)
     float mu[8], is[8], ga[8], be[8];
     if constexpr (MODE == 4) {
@@ -1181,8 +1188,13 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
           }
         }
 #pragma unroll
-        for (int h = 0; h < HB; ++h)   // (the operands name the destination registers: they stay allocated until here)
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[h]), "+v"(ly[h]), "+v"(lr[h]), "+v"(lb[h]), "+v"(lrb[h])::"memory");
+        for (int h = 0; h < HB; ++h) {   // (the operands name the destination registers: they stay allocated until here)
+          if constexpr (MODE == 6) {    // (no y vectors in this variant: their registers are what lets HB cover the whole tile)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[h]), "+v"(lr[h]), "+v"(lb[h]), "+v"(lrb[h])::"memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[h]), "+v"(ly[h]), "+v"(lr[h]), "+v"(lb[h]), "+v"(lrb[h])::"memory");
+          }
+        }
 #pragma unroll
         for (int h = 0; h < HB; ++h) {
           const long long m = (long long)t * TM + wm * (TM / WM) + (h0 + h) * 16 + q;
@@ -1379,7 +1391,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
   const bool bnb = p.bnb_raw != nullptr;
   if (!bnb && p.stats && (aff || p.res)) return false;   // (combinations no caller on the path uses)
   if (bnb && (p.relu || aff)) return false;
-  const int mode = bnb ? ((p.bnb_relu && !p.bnb_y && !p.bnb_bits) ? 4 : 3) : p.res ? (aff ? 5 : 2) : (aff ? 1 : 0);
+  const int mode = bnb ? ((p.bnb_relu && !p.bnb_y && !p.bnb_bits) ? 4 : (p.bnb_bits ? 6 : 3)) : p.res ? (aff ? 5 : 2) : (aff ? 1 : 0);
   if (mode == 4 && p.res) return false;   // (the recomputed mask is only valid when no residual entered before the ReLU)
 #define DAS_STREAM_CASE(KBV, WNV)                                         \
   if (kb == KBV && wn == WNV) {                                           \
@@ -1388,6 +1400,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
     if (mode == 2) return go(conv1x1_stream_kernel<KBV, WNV, 2>);         \
     if (mode == 3) return go(conv1x1_stream_kernel<KBV, WNV, 3>);         \
     if (mode == 5) return go(conv1x1_stream_kernel<KBV, WNV, 5>);         \
+    if (mode == 6) return go(conv1x1_stream_kernel<KBV, WNV, 6>);         \
     if constexpr (WNV == 2) return go(conv1x1_stream_kernel<KBV, WNV, 4>); \
     return false;   /* (mode 4 with wide outputs would spill: the tile kernels take those) */ \
   }
