@@ -202,11 +202,17 @@ def cpu_baseline(workload, budget_s=30.0, full=False, threads=None):
     full_fit_s = 120.0
     t0 = time.perf_counter()
     step()
-    first = time.perf_counter() - t0
-    if not full and 25 * first <= full_fit_s:
-        full = True
-    warmups = 5 if full else 1
-    for _ in range(warmups - 1):
+    first = time.perf_counter() - t0          # (cold: allocator, thread pool, page faults — typically twice a steady one)
+    done = 1
+    if not full:
+        t0 = time.perf_counter()
+        step()
+        second = time.perf_counter() - t0
+        done = 2
+        if first + second + 23 * second <= full_fit_s:
+            full = True
+    warmups = 5 if full else done
+    for _ in range(warmups - done):
         step()
     warm = first
     t0, n = time.perf_counter(), 0
@@ -221,7 +227,7 @@ def cpu_baseline(workload, budget_s=30.0, full=False, threads=None):
             if workload == 'train' else '1-stage forward + decode')
     proto = ('BASELINE.md section 4 protocol: 5 warm-ups, mean of 20 iterations' if full else
              f'bounded sample: {warmups} warm-up, mean of {n} iterations (time cap {budget_s:.0f} s; the full 5 + 20 '
-             f'protocol did not fit {full_fit_s:.0f} s on this host — first iteration {first:.1f} s —, `bench.py '
+             f'protocol did not fit {full_fit_s:.0f} s on this host — first iteration {first:.1f} s, second {second:.1f} s —, `bench.py '
              f'--cpu-baseline-full` forces it)')
     return dict(value=round(B * n / dt, 4), unit='img/s', cores=cores, kind='port', protocol='full' if full else 'bounded',
                 warmups=warmups, iterations=n,

@@ -15,7 +15,7 @@ FAMS = {   # priced family tag -> kernels (regex on the trace's kernel name)
     'bn_bwd_apply_dz_kernel': r'bn_bwd_apply_dz_kernel|bn_bwd_apply_dz_stream_kernel',
     'conv1x1_stream_kernel': r'conv1x1_stream_kernel',
     'conv_wgrad_pp_kernel': r'conv_wgrad_pp_kernel|wgrad_reduce_kernel<.*AccMap256',
-    'conv_wgrad_kernel<bf16>': r'conv_wgrad_kernel<|wgrad_reduce_kernel<.*AccMap128',
+    'conv_wgrad_kernel<bf16>': r'conv_wgrad_kernel<|wgrad_reduce_kernel<.*AccMap128|conv_wgrad_c64_kernel|wgrad_c64_reduce_kernel',
 }
 
 
