@@ -130,6 +130,7 @@ SIGNATURES = {
                                  vp, vp]),
     'das_groupnorm_nhwc': (i32, [vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp, vp]),
     'das_deform_im2col3x3': (i32, [vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp]),
+    'das_dcn3x3_fused': (i32, [vp, vp, vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, i32, i32, vp]),
     'das_offset_sample': (i32, [vp, vp, vp, vp, C.POINTER(DasLevels), i32, i32, i32, i32, i32, i32, vp]),
     'das_sigmoid_blend': (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     'das_head_assemble': (i32, [vp, vp, vp, C.POINTER(DasLevels), C.POINTER(DasHeadDesc), vp]),

@@ -1051,6 +1051,17 @@ class DeformIm2colFn(Function):
         return _d(dx).to(x.dtype), _d(dom), None
 
 
+def _dcn_gemm_weight_c(dcn, weight, dtype, cpad):
+    """_dcn_gemm_weight for callers that have no col tensor (the fused forward): same cache entries."""
+    from .nn import _cache_of, _slot_of
+    sl = _slot_of(weight, cpad)
+    if sl is not None and sl.cl_shape[0] % 8 == 0:
+        return sl.packed(dtype).reshape(sl.cl_shape[0], 1, 1, 9 * cpad)
+    return _cache_of(dcn).get(('w', dtype), (weight,),
+                              lambda: ops.pack_weight(weight, dtype).reshape(-1, 1, 1, 9 * cpad),
+                              refresh=lambda buf: ops.pack_weight(weight, dtype, out=buf.view(-1, 3, 3, cpad)))
+
+
 def _dcn_gemm_weight(dcn, weight, col):
     """(O_pad, 1, 1, 9 C_pad) GEMM weight of a DCNv2 layer in col's dtype: the optimizer's once-per-step packed copy when the
     layer's flat storage is usable as it is (channels-last (O, 3, 3, C) == (O, 1, 1, 9C)), else a cached pack refreshed in place."""
@@ -1082,36 +1093,73 @@ class DcnGemmFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from .nn import _cache_of
         col, weight = ctx.saved_tensors
         dcn, geom, has_bias = ctx.cfg
-        O, Cc = weight.shape[0], weight.shape[1]
-        dy = dy.contiguous()
-        dyr = _wrap(dy, geom)
-
-        def make_wt():  # (9C_pad.., 1, 1, O_pad) = transpose of the packed GEMM weight
-            wp = _dcn_gemm_weight(dcn, weight, col).reshape(-1, col.shape[-1])
-            return wp.t().contiguous().reshape(wp.shape[1], 1, 1, wp.shape[0])
-
-        def refresh_wt(buf):   # one strided copy into the cached tensor (the weights change every step)
-            wp = _dcn_gemm_weight(dcn, weight, col).reshape(-1, col.shape[-1])
-            buf.view(wp.shape[1], wp.shape[0]).copy_(wp.t())
-        wt = _cache_of(dcn).get(('wt', col.dtype), (weight,), make_wt, refresh=refresh_wt)
-        dcol = _d(ops.conv2d(dyr, wt, 1, 1))
-        sl = getattr(dcn.weight, '_das_slot', None)
-        cpad = col.shape[-1] // 9
-        if sl is not None and sl.direct(cpad, dy.shape[-1]):
-            # (O,3,3,C) channels-last storage == the (O,1,1,9C) GEMM weight: add straight into the flat gradient
-            flush_wgrads()
-            with _on_side(col, dy):
-                ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0, out=sl.grad_cl, accumulate=True)
-            sl.fired()
-            dw = None
-        else:
-            dwp = ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0)          # (O_pad, 1, 1, 9*Cin_pad)
-            dw = dwp.reshape(dwp.shape[0], 3, 3, cpad)[:O, :, :, :Cc].permute(0, 3, 1, 2)
-        db = ops.colsum(dyr)[:O] if has_bias else None
+        dcol, dw, db = _dcn_gemm_backward(col, weight, dcn, geom, has_bias, dy)
         return dcol, dw, db, None, None
+
+
+def _dcn_gemm_backward(col, weight, dcn, geom, has_bias, dy):
+    """Backward of y = col x W^T + bias: d col (GEMM with the transposed weight), dW (weight gradient over col, straight
+    into the flat gradient when the optimizer's storage allows), d bias. Shared by DcnGemmFn and DcnFusedFn."""
+    from .nn import _cache_of
+    O, Cc = weight.shape[0], weight.shape[1]
+    dy = dy.contiguous()
+    dyr = _wrap(dy, geom)
+
+    def make_wt():  # (9C_pad.., 1, 1, O_pad) = transpose of the packed GEMM weight
+        wp = _dcn_gemm_weight(dcn, weight, col).reshape(-1, col.shape[-1])
+        return wp.t().contiguous().reshape(wp.shape[1], 1, 1, wp.shape[0])
+
+    def refresh_wt(buf):   # one strided copy into the cached tensor (the weights change every step)
+        wp = _dcn_gemm_weight(dcn, weight, col).reshape(-1, col.shape[-1])
+        buf.view(wp.shape[1], wp.shape[0]).copy_(wp.t())
+    wt = _cache_of(dcn).get(('wt', col.dtype), (weight,), make_wt, refresh=refresh_wt)
+    dcol = _d(ops.conv2d(dyr, wt, 1, 1))
+    sl = getattr(dcn.weight, '_das_slot', None)
+    cpad = col.shape[-1] // 9
+    if sl is not None and sl.direct(cpad, dy.shape[-1]):
+        # (O,3,3,C) channels-last storage == the (O,1,1,9C) GEMM weight: add straight into the flat gradient
+        flush_wgrads()
+        with _on_side(col, dy):
+            ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0, out=sl.grad_cl, accumulate=True)
+        sl.fired()
+        dw = None
+    else:
+        dwp = ops.conv2d_wgrad(_wrap(col, geom), dyr, 1, 1, 1, 0)          # (O_pad, 1, 1, 9*Cin_pad)
+        dw = dwp.reshape(dwp.shape[0], 3, 3, cpad)[:O, :, :, :Cc].permute(0, 3, 1, 2)
+    db = ops.colsum(dyr)[:O] if has_bias else None
+    return dcol, dw, db
+
+
+# DCNv2 forward as one kernel in TRAINING (ops.dcn3x3_fused with `col` as a side output for the weight gradient). Off by default:
+# measured 487 us against 495 us for im2col + GEMM on a head layer at B = 16 — the kernel is bound by its ~650 vector instructions
+# per wave and K step (DESIGN 2.2g); the eval forward (no col: 420 us) uses it from das_tuning key dcn.fused_minrows rows up.
+DCN_FUSED = False
+
+
+class DcnFusedFn(Function):
+    """ModulatedDeformConv2d forward in ONE kernel; backward = DcnGemmFn's + DeformIm2colFn's on the saved col."""
+
+    @staticmethod
+    def forward(ctx, x, om, weight, bias, dcn, geom):
+        from .nn import _cache_of, _pad8
+        w = _dcn_gemm_weight_c(dcn, weight, x.dtype, x.shape[-1])
+        shift = None
+        if bias is not None:
+            shift = _cache_of(dcn).get(('b',), (bias,), lambda: _pad8(bias, bias.numel()))
+        y, col = ops.dcn3x3_fused(_wrap(x, geom), _wrap(om, geom), w, shift, want_col=True)
+        ctx.save_for_backward(x, om, _d(col), weight)
+        ctx.cfg = (dcn, geom, bias is not None)
+        return _d(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, om, col, weight = ctx.saved_tensors
+        dcn, geom, has_bias = ctx.cfg
+        dcol, dw, db = _dcn_gemm_backward(col, weight, dcn, geom, has_bias, dy)
+        dx, dom = ops.deform_im2col3x3_backward(_wrap(x, geom), _wrap(om, geom), _wrap(dcol.contiguous(), geom))
+        return _d(dx).to(x.dtype), _d(dom), dw, db, None, None
 
 
 class OffsetSampleFn(Function):

@@ -41,6 +41,8 @@ enum Key {
                          // gradient all-reduce when several GPUs train together); 0 on one GPU
   ELEM_UPSTATS_PPB,      // output pixels per workgroup of bilinear_ac_stats_kernel; 0 = by size
   BN_UPMERGE_BLOCKS,     // grid cap of upmerge_bwd_reduce_kernel
+  DCN_FUSED_MINROWS,     // das_dcn3x3_fused instead of im2col + GEMM in the eval forward from this many pixel rows up (0 = never):
+                         // 15 % ahead at 141 k rows, behind at 71 k (its 128-pixel tiles fill three rounds for 2.2 rounds of work)
   N_KEYS
 };
 

@@ -455,16 +455,29 @@ def dcn_v2(x, dcn):
     # (x feeds the offset conv AND the sampling: it is handed through the offset conv's node, so that the sampling's input
     # gradient is added in the offset conv's data-gradient epilogue)
     om, x = conv_plain(x, dcn.conv_offset, out_dtype=torch.float32, skip_through=True)  # 27 -> 32 padded channels
+    # one kernel (sampling into the GEMM's LDS stage, das_dcn3x3_fused) for the shapes it takes: bf16, C % 64 == 0, Cout <= 256
+    fusable = (_tensor(x).dtype == torch.bfloat16 and C % 64 == 0 and dcn.weight.shape[0] % 8 == 0
+               and dcn.weight.shape[0] <= 256 and dcn.weight.shape[1] == C)
     if ag.grad_mode(_tensor(x), dcn.weight, _tensor(om)):
         g = ag._geom(x)
+        if fusable and ag.DCN_FUSED:
+            return ag._wrap(ag.DcnFusedFn.apply(_tensor(x), _tensor(om), dcn.weight, dcn.bias, dcn, g), g)
         col = ag.DeformIm2colFn.apply(_tensor(x), _tensor(om), g)
         return ag._wrap(ag.DcnGemmFn.apply(col, dcn.weight, dcn.bias, dcn, g), g)
-    col = ops.deform_im2col3x3(x, om)
     w = _cache_of(dcn).get(('w', x.dtype), (dcn.weight,),
                            lambda: ops.pack_weight(dcn.weight, x.dtype).reshape(dcn.weight.shape[0], 1, 1, 9 * C))
     shift = None
     if dcn.bias is not None:
         shift = _cache_of(dcn).get(('b',), (dcn.bias,), lambda: _pad8(dcn.bias, dcn.bias.numel()))
+    if fusable:
+        import ctypes
+        from . import _lib
+        minrows = ctypes.c_longlong()
+        _lib.load().das_tuning_get(b'dcn.fused_minrows', ctypes.byref(minrows))
+        rows = _tensor(x).numel() // C
+        if ag.DCN_FUSED or (minrows.value > 0 and rows >= minrows.value):
+            return ops.dcn3x3_fused(x, om, w, shift)
+    col = ops.deform_im2col3x3(x, om)
     return ops.conv2d(col, w, 1, 1, shift=shift)
 
 

@@ -1022,6 +1022,24 @@ def deform_im2col3x3(x, om):
     return col
 
 
+def dcn3x3_fused(x, om, w, bias=None, want_col=False):
+    """DCNv2 forward in one kernel (das_dcn3x3_fused): x NHWC / Ragged bf16 (C % 64 == 0), om f32 offsets + mask logits,
+    w (Cout, 1, 1, 9 C) bf16 GEMM weight (Cout <= 256), bias f32 padded to 8 or None. Returns y, or (y, col) with
+    want_col (the sampled operand as das_deform_im2col3x3 would have written it: kept for the weight gradient)."""
+    _need_gpu(x, om, w)
+    xd, omd = _data(x), _data(om)
+    Cc, Cout = xd.shape[-1], w.shape[0]
+    assert xd.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and omd.dtype == torch.float32
+    assert w.numel() == Cout * 9 * Cc and w.is_contiguous()
+    lv = _levels(x)
+    y = _empty_like_rows(x, Cout, xd.dtype)
+    col = _empty_like_rows(x, 9 * Cc, xd.dtype) if want_col else None
+    _lib.check(_lib.load().das_dcn3x3_fused(_ptr(xd), _ptr(omd), _ptr(w), _ptr(bias), _ptr(_data(y)),
+                                            _ptr(_data(col)) if col is not None else None, _DT[xd.dtype], C.byref(lv), Cc,
+                                            Cout, _ps(x), _ps(om), _ps(y), _stream()), 'das_dcn3x3_fused')
+    return (y, col) if want_col else y
+
+
 def offset_sample(uvd, samp_off, conf, J, heads=4):
     _need_gpu(uvd, samp_off, conf)
     out = _empty_like_rows(uvd, 3 * J, torch.float32)

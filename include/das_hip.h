@@ -49,7 +49,8 @@ const char* das_target_arch(void);
  * conv.glds4_mf, conv.stream_minrows, conv.stream_percu, conv.tail_split, conv.splitk_target, conv.splitk_minsteps, conv.splitk_kernels, conv.c64_mintiles, wgrad.pp_mink, wgrad.shapes (1: conv_wgrad_kernel picks 128 x 128 / 64 x 256 / 256 x 64 wave arrangements per op), wgrad.bkm, wgrad.blocks, wgrad.pp_blocks,
  * bn.reduce_blocks, bn.reduce_threads, bn.vpt, gn.ppb, bn.stream_minbytes, comm.reserved_cus (CUs every persistent grid leaves free: wgrad.blocks / wgrad.pp_blocks 0 = one
  * resident wave of workgroups on the remaining CUs), elem.upstats_ppb (output pixels per workgroup of the resampling
- * kernels, 0 = by size), bn.upmerge_blocks (grid cap of the fused reduce passes of upmerge.hip / skipadd.hip). */
+ * kernels, 0 = by size), bn.upmerge_blocks (grid cap of the fused reduce passes of upmerge.hip / skipadd.hip),
+ * dcn.fused_minrows (das_amd.nn.dcn_v2: das_dcn3x3_fused in the eval forward from this many pixel rows up; 0 = never). */
 int das_tuning_set(const char* key, long long value);
 int das_tuning_get(const char* key, long long* value);
 int das_tuning_reset(void);
@@ -369,6 +370,16 @@ int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C
  * the rows of ALL levels back to back: level l contributes B*H[l]*W[l] rows in (b,h,w) order. A plain
  * (B,H,W,C) tensor is the special case num_levels = 1. */
 /* (typedef DasLevels: see the top of this header) */
+
+/* DCNv2 forward as ONE kernel (round 5): y = ModulatedDeformConv2d(x; offsets / mask logits om; w, bias) without a `col`
+ * tensor between the sampling and the GEMM — the sampled pixel operand of a 128-pixel x 256-channel tile goes straight into
+ * LDS (csrc/dcn_fused.hip). Same call sites as das_deform_im2col3x3 + das_conv2d_nhwc on col (das_head.py:107-108,
+ * anchor_free_mono3d_pose_head.py:111-112,131-132, recursive_update.py:177-178). x: rows x C bf16 (C % 64 == 0); om as for
+ * das_deform_im2col3x3; w: (Cout, 9 C) bf16, K = tap * C + channel (= the (Cout, 3, 3, C) channels-last weight); bias f32[Cout
+ * padded to 8] or NULL; y: rows x Cout bf16, Cout % 8 == 0, Cout <= 256. col: NULL, or (rows, 9 C) bf16 that ALSO receives
+ * the sampled values (bit-identical to das_deform_im2col3x3's; the training forward keeps it for the weight gradient). */
+int das_dcn3x3_fused(const void* x, const float* om, const void* w, const float* bias, void* y, void* col, int dtype,
+                     const DasLevels* lv, int C, int Cout, int x_pix_stride, int om_pix_stride, int y_pix_stride, void* stream);
 
 /* GroupNorm (+ReLU) over NHWC rows (torch GroupNorm, das_head.py:54, recursive_update.py:178,244);
  * statistics per (level, image, group). stats workspace: f32[num_levels*B*G*2], zeroed by the call. */

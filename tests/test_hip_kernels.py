@@ -305,6 +305,89 @@ def test_dcnv2_im2col_plus_gemm(dtype):
                                                                   else dict(rtol=3e-2, atol=3e-2)))
 
 
+@pytest.mark.parametrize('case', [(2, 64, 40, 11, 14, False), (1, 128, 256, 37, 23, False), (2, 256, 256, 0, 0, True),
+                                  (1, 64, 8, 9, 130, False)])
+def test_dcnv2_fused_forward(case):
+    """das_dcn3x3_fused (sampling straight into the GEMM's LDS stage) against the oracle's modulated_deform_conv2d and
+    against the two-kernel path on the same operands: `col` side output BIT-identical to das_deform_im2col3x3's, y equal to the
+    GEMM over that col up to f32 accumulation order (bf16-exact bar); plain NHWC (tile overhang, Cout < 256) and the head's
+    four ragged levels (offsets that leave the plane, level boundaries inside a 128-pixel tile)."""
+    from oracle.nn_ops import modulated_deform_conv2d
+    o = ops()
+    B, C, O, H, W, ragged = case
+    bf = torch.bfloat16
+    w, bias = cases.randn(225, O, C, 3, 3) / (3 * C ** 0.5), cases.randn(226, O)
+    sizes = [(16, 26), (8, 13), (4, 7), (2, 4)] if ragged else [(H, W)]
+    xs = [cases.randn(224 + i, B, C, h, ww) for i, (h, ww) in enumerate(sizes)]
+    oms = [cases.randn(227 + i, B, 27, h, ww) for i, (h, ww) in enumerate(sizes)]
+    for t in oms:
+        t[:, :18] *= 2.5
+    omd = []
+    for t in oms:
+        z = torch.zeros(t.shape[0], t.shape[2], t.shape[3], 32, device=DEV)
+        z[..., :27] = t.permute(0, 2, 3, 1).to(DEV)
+        omd.append(z)
+    if ragged:
+        xr = o.Ragged.from_levels([nhwc(t, bf) for t in xs])
+        omr = o.Ragged.from_levels(omd)
+    else:
+        xr, omr = nhwc(xs[0], bf), omd[0]
+    wp = o.pack_weight(w.to(DEV), bf).reshape(O, 1, 1, 9 * C)
+    shift = bias.to(DEV)
+    y, col = o.dcn3x3_fused(xr, omr, wp, shift, want_col=True)
+    y_only = o.dcn3x3_fused(xr, omr, wp, shift)
+    col2 = o.deform_im2col3x3(xr, omr)
+    y2 = o.conv2d(col2, wp, 1, 1, shift=shift)
+    dd = (lambda t: t.data) if ragged else (lambda t: t)
+    assert torch.equal(dd(col), dd(col2))
+    assert torch.equal(dd(y), dd(y_only))
+    ya, yb = dd(y).float().cpu().numpy(), dd(y2).float().cpu().numpy()
+    scale = float(np.abs(yb).max())
+    assert float(np.abs(ya - yb).max()) <= 2 ** -7 * scale, float(np.abs(ya - yb).max()) / scale   # one bf16 step of the largest value
+    assert float((ya != yb).mean()) < 0.08     # (f32 accumulation order differs between the two GEMMs: rounding midpoints only)
+    for i, (xl, ol) in enumerate(zip(xs, oms)):
+        ref = modulated_deform_conv2d(rnd(xl, bf), ol[:, :18], torch.sigmoid(ol[:, 18:]), rnd(w, bf), bias)
+        got = nchw(y.level(i) if ragged else y)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=3e-2, atol=3e-2)
+
+
+def test_dcnv2_fused_through_the_module_train_and_eval():
+    """nn.dcn_v2 with the one-kernel forward switched on (autograd.DCN_FUSED for the training graph, das_tuning key
+    dcn.fused_minrows for eval) against the two-kernel path on the same module and input, bf16: the output within one bf16 step,
+    the gradients of the input, the DCN weight / bias and the offset conv equal up to the GEMMs' accumulation order."""
+    from das_amd import autograd as ag, nn as dnn
+    o = ops()
+    torch.manual_seed(3)
+    mod = dnn.ConvModule(64, 64, 3, padding=1, conv_cfg=dict(type='DCNv2'), norm_cfg=None, act_cfg=None).to(DEV)
+    with torch.no_grad():
+        mod.conv.conv_offset.weight.normal_(0, 0.05)
+        mod.conv.conv_offset.bias.normal_(0, 0.5)
+    x0 = (cases.randn(301, 2, 64, 19, 23)).permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+    gy = cases.randn(302, 2, 19, 23, 64).to(DEV).to(torch.bfloat16)
+    res = {}
+    for fused in (False, True):
+        ag.DCN_FUSED = fused
+        try:
+            for p_ in mod.parameters():
+                p_.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = mod(x)
+            assert o.last_kernel() == ('dcn3x3_fused_kernel' if fused else o.last_kernel())
+            (y.float() * gy.float()).sum().backward()
+            with torch.no_grad(), o.tuning(**{'dcn.fused_minrows': 1 if fused else 0}):
+                ye = mod(x0)
+            res[fused] = (y.detach().float(), ye.float(), x.grad.float(), {n: p_.grad.float().clone() for n, p_ in mod.named_parameters()})
+        finally:
+            ag.DCN_FUSED = False
+    (ya, yea, dxa, ga), (yb, yeb, dxb, gb) = res[False], res[True]
+    step = 2 ** -7 * float(ya.abs().max())
+    assert float((ya - yb).abs().max()) <= step and float((yea - yeb).abs().max()) <= step
+    assert torch.equal(yb, yeb)                               # train-graph forward == eval forward of the fused kernel
+    assert float((dxa - dxb).abs().max()) <= 4e-2 * float(dxa.abs().max())
+    for n in ga:
+        assert float((ga[n] - gb[n]).abs().max()) <= 4e-2 * float(ga[n].abs().max()) + 1e-6, n
+
+
 def test_offset_sample_matches_oracle(golden_dir):
     import os
     from oracle.head import offset_sample

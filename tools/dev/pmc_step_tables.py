@@ -1,4 +1,4 @@
-"""Round 4: HBM traffic and matrix-core counters of the REAL train step's launches (no proxy mix).
+"""Rounds 4-5: HBM traffic and matrix-core counters of the REAL train step's launches (no proxy mix).
 Inputs: the rocpd databases of three `rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 2 --warmup 1
 --no-cpu-baseline --no-also` passes (FETCH_SIZE; WRITE_SIZE; the MFMA set) — tools/dev/scripts/pmc_r4.sh.
 Outputs under <out>: r05_pmc_step_traffic.md (every kernel variant: dispatches, mean us, fetch / write MB per dispatch, TB/s),
@@ -66,7 +66,7 @@ def main(fdb, wdb, mdb, out):
         for k, n, us, fmb, wmb in rows[:70]:
             f.write(f'| `{k[:100]}` | {n} | {us:.1f} | {fmb:.1f} | {wmb:.1f} | {(fmb + wmb) / max(us, 1e-9):.2f} |\n')
     with open(f'{out}/r05_stream_modes.md', 'w') as f:
-        f.write('# conv1x1_stream_kernel<KB, WN, MODE> on the step\'s real operands (round 4; VERDICT r3 #2(i))\n\n')
+        f.write('# conv1x1_stream_kernel<KB, WN, MODE> on the step\'s real operands (round 5)\n\n')
         f.write('K = 32 KB input channels, WN waves across 32-channel groups; MODE 0 forward + BatchNorm statistics, 2 data gradient + '
                 'second gradient, 3 data gradient + fused BatchNorm-backward sums with the mask from y (+ second gradient), 4 the same with '
                 'the mask recomputed from raw. Same passes as r05_pmc_step_traffic.md.\n\n')
