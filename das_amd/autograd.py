@@ -1132,10 +1132,10 @@ def _dcn_gemm_backward(col, weight, dcn, geom, has_bias, dy):
     return dcol, dw, db
 
 
-# DCNv2 forward as one kernel in TRAINING (ops.dcn3x3_fused with `col` as a side output for the weight gradient). Off by default:
-# measured 487 us against 495 us for im2col + GEMM on a head layer at B = 16 — the kernel is bound by its ~650 vector instructions
-# per wave and K step; the eval forward (no col: 420 us) uses it from das_tuning key dcn.fused_minrows rows up.
-DCN_FUSED = False
+# DCNv2 forward as one kernel in the training graph (ops.dcn3x3_fused with `col` as a side output for the weight gradient): 441 us
+# against 499 us for im2col + GEMM on a head layer at B = 16, -0.35 ms per step. The eval forward (no col: 398 us)
+# uses it from das_tuning key dcn.fused_minrows rows up. Switch for A/B runs and tests.
+DCN_FUSED = True
 
 
 class DcnFusedFn(Function):

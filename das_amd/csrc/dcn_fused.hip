@@ -15,6 +15,7 @@
 // anchor_free_mono3d_pose_head.py:111-112,131-132, recursive_update.py:177-178.
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "conv_common.h"
 #include "prof.h"
@@ -169,13 +170,16 @@ __global__ __launch_bounds__(DNT) void dcn3x3_fused_kernel(ConvP p, DcnP d) {
       for (int c = 0; c < 4; ++c) {
         // (branch-free: a corner outside the plane enters with weight 0 — its stand-in row is finite, and adding +-0 to the
         // running sum leaves it bit for bit what skipping the corner leaves)
-        float f[8];
-        Elem<T>::unpack(__builtin_bit_cast(uint4, cr[it][c]), f);
         const float wc = (e.ok >> c & 1) ? wts[c] : 0.f;
         const das_f32x2_t w2 = {wc, wc};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const das_f32x2_t f2 = {f[2 * j], f[2 * j + 1]};
+          // (a dword's two bf16 values become a register PAIR directly: built element by element the compiler spent a third
+          // of the step's instructions on moves that put the halves side by side)
+          const unsigned xw = (unsigned)cr[it][c][j];
+          typedef unsigned das_u32x2_t __attribute__((ext_vector_type(2)));
+          const das_u32x2_t u2 = {xw << 16, xw & 0xffff0000u};
+          const das_f32x2_t f2 = __builtin_bit_cast(das_f32x2_t, u2);
           const das_f32x2_t pr = w2 * f2;
           o2[j] = o2[j] + pr;
         }
@@ -220,42 +224,50 @@ __global__ __launch_bounds__(DNT) void dcn3x3_fused_kernel(ConvP p, DcnP d) {
   __builtin_amdgcn_s_barrier();
   const int frow = lane & 15, fkg = lane >> 4;
   // one K step; `ld` = the register set the loads of step s + 2 go to (it held step s), `use` = the set holding step s + 1
+  // (ONE variant of the step, the same instruction counts in every step: with a run-time choice between two waits the compiler
+  // copied the whole register set behind each of them, with several instantiations it spilled 120 registers. The last steps
+  // therefore re-request step nk - 1's operands — valid addresses, results unused — instead of requesting nothing.)
   auto step = [&](int s, v4i_t (&ld)[2][4], v4i_t (&use)[2][4]) {
     const int buf = s & 1;
-    const bool ahead2 = s + 2 < nk;
-    if (s + 1 < nk) issue_w(s + 1, buf ^ 1);     // 4 DMA instructions per wave
-    if (ahead2) gather_load(s + 2, ld);          // 8 loads
+    issue_w(min(s + 1, nk - 1), buf ^ 1);     // 4 DMA instructions per wave
+    gather_load(min(s + 2, nk - 1), ld);      // 8 loads
     const char* sA = smem + buf * DBUF;
     const char* sW = sA + DA_BYTES;
+    auto multiply = [&]() {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      uint4 fb[TM], fa[TN];
+      for (int t = 0; t < 2; ++t) {
+        uint4 fb[TM], fa[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fb[i] = *reinterpret_cast<const uint4*>(sA + slot128(wave_m0 + i * 16 + frow, t * 4 + fkg));
+        for (int i = 0; i < TM; ++i) fb[i] = *reinterpret_cast<const uint4*>(sA + slot128(wave_m0 + i * 16 + frow, t * 4 + fkg));
 #pragma unroll
-      for (int i = 0; i < TN; ++i) fa[i] = *reinterpret_cast<const uint4*>(sW + slot128(wave_n0 + i * 16 + frow, t * 4 + fkg));
+        for (int i = 0; i < TN; ++i) fa[i] = *reinterpret_cast<const uint4*>(sW + slot128(wave_n0 + i * 16 + frow, t * 4 + fkg));
 #pragma unroll
-      for (int a = 0; a < TN; ++a)
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) mma<T>(fa[a], fb[b], acc[a][b]);
-    }
-    if (s + 1 < nk) {
-      // the 8 loads of step s + 1 (issued one step ago) are older than the 4 DMAs + 8 loads issued at the top of this step; the
-      // two col stores of the previous step may or may not be done. In flight at most 8 + 2 + 12: once <= 12 remain, at least
-      // 10 have completed, of which at most 2 are stores — so the 8 oldest loads have.
-      if (ahead2) DCN_WAIT(12, use); else DCN_WAIT(0, use);
-      gather_write(s + 1, buf ^ 1, use);
-    }
-    // next step's weight tile: the 4 DMAs are older than this step's 8 loads; up to 4 col stores may be outstanding. Once <= 8
-    // remain (of 4 + 8 + 4) at least 8 have completed, at most 4 of them stores: the 4 DMAs have landed.
-    if (ahead2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          for (int b = 0; b < TM; ++b) mma<T>(fa[a], fb[b], acc[a][b]);
+      }
+    };
+    multiply();
+    // the 8 loads of step s + 1 (issued one step ago) are older than the 4 DMAs + 8 loads issued at the top of this step; col
+    // stores may or may not be done. If one of those 8 loads were still outstanding, so would be the 12 younger loads / DMAs
+    // (loads return in order): more than 12 outstanding. Hence "<= 12" proves they have landed, whatever the stores do.
+    DCN_WAIT(12, use);
+    if (s + 1 < nk) gather_write(s + 1, buf ^ 1, use);
+    // (Tried and measured no better: the same work as ONE interleaved instruction stream — wait first, then the MFMAs and the
+    // sampling arithmetic in one basic block under __builtin_amdgcn_sched_group_barrier(MFMA 1 / VALU 8): 417 us against 399;
+    // two code ORDERS for the two waves of a SIMD, so that one multiplies while the other samples: the compiler spilled 100
+    // registers, and scratch traffic breaks the hand-counted waits.)
+    // next step's weight tile: the 4 DMAs are older than this step's 8 loads — "<= 8 outstanding" proves they have landed
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's operand vectors are in LDS
     __builtin_amdgcn_s_barrier();                        // ... and every wave is done reading stage `buf`
   };
-  for (int s = 0; s < nk; s += 2) {
+  for (int s = 0; s < nk; s += 2) {     // (s even: set A held step s)
     step(s, crA, crB);
     if (s + 1 < nk) step(s + 1, crB, crA);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing stand-in loads / DMAs: the epilogue reuses the stages
+  __builtin_amdgcn_s_barrier();
 #undef DCN_WAIT
   conv_epilogue<T, DBN, DBM>(acc, p, smem, (int)m0, 0);
 }

@@ -378,7 +378,7 @@ def test_dcnv2_fused_through_the_module_train_and_eval():
                 ye = mod(x0)
             res[fused] = (y.detach().float(), ye.float(), x.grad.float(), {n: p_.grad.float().clone() for n, p_ in mod.named_parameters()})
         finally:
-            ag.DCN_FUSED = False
+            ag.DCN_FUSED = True
     (ya, yea, dxa, ga), (yb, yeb, dxb, gb) = res[False], res[True]
     step = 2 ** -7 * float(ya.abs().max())
     assert float((ya - yb).abs().max()) <= step and float((yea - yeb).abs().max()) <= step

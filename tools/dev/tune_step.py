@@ -39,6 +39,8 @@ def run(cfg):
             ag.GN_REMASK = bool(int(v))
         elif k == 'BITS':
             ag.MASK_BITS = bool(int(v))
+        elif k == 'DCNF':
+            ag.DCN_FUSED = bool(int(v))
         elif k == 'CHAIN':
             dnn.CHAIN_CONSUMERS = bool(int(v))
         elif k == 'DUAL':
@@ -64,6 +66,7 @@ def run(cfg):
     ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(N))
     ms = ts[N // 2]
     ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS = wb, fs, ms_
+    ag.DCN_FUSED = True
     dnn.CHAIN_CONSUMERS = dnn.UPCONV_AT_LOW_RES = dnn.UPMERGE_FUSED = dnn.DEFERRED_SKIPS = ag.DUAL_APPLY = ag.MASK_BITS = ag.GN_REMASK = ag.RES_BITS = True
     _lib.check(lib.das_tuning_reset(), 'reset')
     return ms
