@@ -107,7 +107,8 @@ def test_row_count_check_is_looked_at_lazily_and_raises_when_its_answer_says_so(
     assert not ag._rows_pending
     # an answer that has not arrived is left alone ... (a long kernel in front of the copy)
     from das_amd import _lib
-    _lib.check(_lib.load().das_dev_occupy_cus(1, 64, 1024, 200000, None), 'occupy')
+    import ctypes
+    _lib.check(_lib.load().das_dev_occupy_cus(1, 64, 1024, 200000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'occupy')
     push(64.0, -64.0)
     ag.verify_rows()
     assert len(ag._rows_pending) == 1
