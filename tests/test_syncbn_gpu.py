@@ -90,8 +90,9 @@ def test_row_count_check_is_looked_at_lazily_and_raises_when_its_answer_says_so(
     from das_amd import autograd as ag
     ag._rows_pending.clear()
 
-    def push(hi, lo):
-        dev = torch.tensor([hi, lo], dtype=torch.float64, device='cuda')
+    def push(hi, lo, dev=None):
+        if dev is None:
+            dev = torch.tensor([hi, lo], dtype=torch.float64, device='cuda')
         host = torch.empty(2, dtype=torch.float64, pin_memory=True)
         host.copy_(dev, non_blocking=True)
         ev = torch.cuda.Event(blocking=True)
@@ -108,13 +109,16 @@ def test_row_count_check_is_looked_at_lazily_and_raises_when_its_answer_says_so(
     # an answer that has not arrived is left alone ... (a long kernel in front of the copy)
     from das_amd import _lib
     import ctypes
-    _lib.check(_lib.load().das_dev_occupy_cus(1, 64, 1024, 200000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'occupy')
-    push(64.0, -64.0)
+    # (the device-side values exist before the long kernel: creating them behind it would block the host until it has finished)
+    devs = [torch.tensor([64.0, -64.0], dtype=torch.float64, device='cuda') for _ in range(ag.ROWS_CHECK_LAG + 1)]
+    torch.cuda.synchronize()
+    _lib.check(_lib.load().das_dev_occupy_cus(1, 64, 1024, 300000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'occupy')
+    push(64.0, -64.0, devs[0])
     ag.verify_rows()
     assert len(ag._rows_pending) == 1
     # ... unless more than ROWS_CHECK_LAG are queued
-    for _ in range(ag.ROWS_CHECK_LAG):
-        push(64.0, -64.0)
+    for i in range(ag.ROWS_CHECK_LAG):
+        push(64.0, -64.0, devs[1 + i])
     ag.verify_rows()
     assert len(ag._rows_pending) <= ag.ROWS_CHECK_LAG
     ag.verify_rows(wait=True)
