@@ -1034,9 +1034,18 @@ def dcn3x3_fused(x, om, w, bias=None, want_col=False):
     lv = _levels(x)
     y = _empty_like_rows(x, Cout, xd.dtype)
     col = _empty_like_rows(x, 9 * Cc, xd.dtype) if want_col else None
+    i0 = _prof_mark() if PROFILE is not None else 0
     _lib.check(_lib.load().das_dcn3x3_fused(_ptr(xd), _ptr(omd), _ptr(w), _ptr(bias), _ptr(_data(y)),
                                             _ptr(_data(col)) if col is not None else None, _DT[xd.dtype], C.byref(lv), Cc,
                                             Cout, _ps(x), _ps(om), _ps(y), _stream()), 'das_dcn3x3_fused')
+    if PROFILE is not None:   # a conv family of its own: the GEMM's FLOPs, every operand once (x, offsets, weights -> y, col)
+        e0 = e1 = _Span(i0, _prof_mark())
+        rows = xd.numel() // Cc
+        nby = (xd.numel() + w.numel() + _data(y).numel() + (_data(col).numel() if want_col else 0)) * 2 + omd.numel() * 4
+        ragged = isinstance(x, Ragged)
+        PROFILE.append(('dcn3x3_fused_kernel', 2.0 * rows * Cout * 9 * Cc, e0, e1,
+                        (x.B if ragged else xd.shape[0], 0, 0, Cc, Cout, 3, 1, len(x.sizes) if ragged else 1,
+                         'dcn+col' if want_col else 'dcn'), 1, float(nby)))
     return (y, col) if want_col else y
 
 
