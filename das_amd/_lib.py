@@ -81,6 +81,7 @@ SIGNATURES = {
     'das_tuning_reset': (i32, []),
     'das_dev_occupy_cus': (i32, [i32, i32, i32, i32, vp]),
     'das_last_kernel': (C.c_char_p, []),
+    'das_conv_last_tile_rows': (i32, []),
     'das_prof_begin': (i32, []),
     'das_prof_end': (i32, []),
     'das_prof_count': (i64, []),

@@ -41,6 +41,8 @@ struct ConvP {
               // reads x[t >> up_sh] when t is a multiple of 1 << up_sh, else contributes zero
   int M, K, HoWo, ntiles, nblocks;
   int m_base;       // first output row of this launch's tile 0 (a conv may be covered by two launches: see launch_bn)
+  int mstep;        // 0, or the rows a 256-row tile kernel's tile covers (< 256, a multiple of 16): tile t starts at row
+                    // m_base + t * mstep and its rows from mstep on are treated as rows past M (balanced_mstep, conv_igemm.hip)
   unsigned xbytes;  // addressable bytes of x from its base (0 if >= 4 GiB): range of the buffer descriptor
   // Fused BatchNorm-backward reduction (data-gradient launches, DasConvDesc.bnb_*): the value about to be stored,
   // g = conv + residual, is the gradient wrt the OUTPUT of a train-mode BatchNorm (+ReLU) layer whose pre-norm

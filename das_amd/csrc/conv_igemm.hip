@@ -494,7 +494,8 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
   const int n0 = (logical % p.ntiles) * BN;
-  const int m0 = p.m_base + (logical / p.ntiles) * BMT;
+  const int m0 = p.m_base + (logical / p.ntiles) * (p.mstep ? p.mstep : BMT);
+  if (p.mstep) p.M = min(p.M, m0 + p.mstep);   // balanced tiles: this tile's rows from mstep on do not exist
   const int wave_m0 = (wave & 3) * 64, wave_n0 = (wave >> 2) * 64;
 
   // Operands are fetched with `buffer_load_dwordx4 ... offen lds`: 32-bit byte offsets against a buffer
@@ -698,7 +699,8 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
   const int n0 = (logical % p.ntiles) * BN;
-  const int m0 = p.m_base + (logical / p.ntiles) * BMT;
+  const int m0 = p.m_base + (logical / p.ntiles) * (p.mstep ? p.mstep : BMT);
+  if (p.mstep) p.M = min(p.M, m0 + p.mstep);   // balanced tiles (see conv_glds3_kernel)
   const int wave_m0 = Tiling<BN, BMT>::wave_m0(wave), wave_n0 = Tiling<BN, BMT>::wave_n0(wave);
 
   const int lrow = lane >> 2, pslot = lane & 3;
@@ -916,6 +918,25 @@ inline long long tail_split_mtiles(long long mtiles, int ntiles, bool allowed) {
   return keep >= 1 && keep < mtiles ? keep : mtiles;
 }
 
+// Balanced pixel tiles. The same launches, when their last round is more than half full (no tail split): 416 tiles on
+// 256 CUs are two rounds for 1.6 rounds of work. The rows are spread over ALL the tiles of the full rounds instead — 512
+// tiles of 208 rows: every tile still runs the 256-row K loop (rows from mstep on are rows past M to the loaders and the
+// epilogue: zero fill without memory traffic, nothing stored), but moves 19 % fewer bytes, and these launches are bound
+// by bytes and latency per CU, not by the matrix pipe. Returns the tile step (a multiple of 16) or 0 (no change) and
+// the new number of M tiles.
+thread_local int t_last_tile_rows = 0;
+inline int balanced_mstep(int rows, int bmt, int ntiles, bool one_by_one, int* mtiles) {
+  const long long mode = dastune::get(dastune::CONV_BALANCE_ROWS);
+  if (mode <= 0 || (mode == 1 && !one_by_one)) return 0;
+  const long long cus = device_cus(), nb = (long long)*mtiles * ntiles;
+  const long long rounds = (nb + cus - 1) / cus, cap = rounds * cus / ntiles;   // M tiles the full rounds hold
+  if (nb % cus == 0 || cap <= *mtiles || rounds > 8) return 0;
+  const int step = (int)(((rows + cap - 1) / cap + 15) / 16 * 16);
+  if (step >= bmt || step * 20 > bmt * 19 || step < bmt / 2) return 0;   // (under 5 % to gain; under half a tile: the 128-row kernel's case)
+  *mtiles = (rows + step - 1) / step;
+  return step;
+}
+
 template <typename T, typename OT, int BN>
 int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_split = true) {
   ConvP p = p0;
@@ -943,6 +964,8 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
       if (rc != DAS_OK) return rc;
       p.M = tail.m_base;
       mtiles = (int)keep;
+    } else if (may_split) {
+      p.mstep = balanced_mstep(rows, 256, p.ntiles, p.KH == 1 && p.KW == 1, &mtiles);
     }
   }
   p.nblocks = p.ntiles * mtiles;
@@ -975,6 +998,7 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
       }
     }
     dastune::note_kernel(pp3 ? "conv_glds3_kernel<pp>" : "conv_glds3_kernel");
+    t_last_tile_rows = p.mstep ? p.mstep : 256;
     const bool bits = p.bnb_bits || p.res_bits;
     if (pp3) {
       if (bits) hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true, true>), dim3(p.nblocks), dim3(512), sm_big, s, p);
@@ -1452,17 +1476,22 @@ bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
     const long long mf = dastune::get(dastune::CONV_GLDS4_MF);   // 0 = by cost, 8 / 9 force the tile height
     if (pp && (mf == 9 || (mf == 0 && cost288 < cost256))) {
       p.nblocks = (int)nb288;
+      t_last_tile_rows = 288;
       dastune::note_kernel("conv_glds4_kernel<pp,288>");
       hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 288>), dim3(p.nblocks), dim3(512), sm4x, s, p);
       return true;
     }
+    int mt = (int)keep;
     if (keep < mtiles) {   // rows of the under-filled last round: second launch (128-row tiles, split-K)
       ConvP tail = p0;
       tail.m_base = (int)keep * 256;
       if (launch<T, OT, 128>(tail, glds, aligned, s, false) != DAS_OK) return false;
       p.M = tail.m_base;
+    } else {
+      p.mstep = balanced_mstep(p.M, 256, p.ntiles, p.KH == 1 && p.KW == 1, &mt);
     }
-    p.nblocks = (int)(keep * p.ntiles);
+    p.nblocks = mt * p.ntiles;
+    t_last_tile_rows = p.mstep ? p.mstep : 256;
     dastune::note_kernel(pp ? "conv_glds4_kernel<pp>" : "conv_glds4_kernel");
     if (pp) {
       hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 256>), dim3(p.nblocks), dim3(512), sm4, s, p);
@@ -1531,8 +1560,11 @@ int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int das_conv_last_tile_rows(void) { return t_last_tile_rows; }
+
 extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream) {
   DAS_PROF(stream);
+  t_last_tile_rows = 0;
   if (!x || !w || !y || !d) return DAS_ERR_ARG;
   if (d->Cin % 8 || d->Cout % 8 || d->x_pix_stride % 8 || d->y_pix_stride % 8) return DAS_ERR_ARG;
   if (d->x_pix_stride < d->Cin || d->y_pix_stride < d->Cout) return DAS_ERR_ARG;
@@ -1566,7 +1598,7 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   if (d->in_up == 2 && (d->stride != 1 || p.nlev > 1)) return DAS_ERR_ARG;
   p.up_sh = d->in_up == 2 ? 1 : 0;
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
-  p.ntiles = p.nblocks = 0; p.m_base = 0;
+  p.ntiles = p.nblocks = 0; p.m_base = 0; p.mstep = 0;
   p.ws = nullptr; p.ksplit = 1;
   p.osub = d->out_sub ? 1 : 0; p.oph = d->out_ph; p.opw = d->out_pw; p.oH = d->out_H; p.oW = d->out_W;
   if (p.osub) {   // sub-grid output: see DasConvDesc

@@ -222,7 +222,7 @@ __device__ __forceinline__ void wgrad_load_unit(const WgradSched& g, const Wgrad
   p.scale = p.shift = nullptr; p.stats = nullptr; p.stat_slots = 1;
   p.H = o.H; p.W = o.W; p.Cin = o.Cin; p.xps = o.xps; p.Ho = o.Ho; p.Wo = o.Wo; p.Cout = o.Cout; p.yps = 0;
   p.KH = o.KH; p.KW = o.KW; p.stride = o.stride; p.pad = o.pad; p.relu_in = p.relu = 0; p.rps = o.rps; p.up_sh = 0;
-  p.M = o.M; p.K = o.K; p.HoWo = o.HoWo; p.ntiles = p.nblocks = 0; p.m_base = 0; p.xbytes = o.xbytes; p.nlev = o.nlev; p.B = o.B;
+  p.M = o.M; p.K = o.K; p.HoWo = o.HoWo; p.ntiles = p.nblocks = 0; p.m_base = 0; p.mstep = 0; p.xbytes = o.xbytes; p.nlev = o.nlev; p.B = o.B;
 #pragma unroll
   for (int l = 0; l < MAXLV; ++l) { p.lvH[l] = o.lvH[l]; p.lvW[l] = o.lvW[l]; p.lvStart[l] = o.lvStart[l]; }
   p.bnb_raw = p.bnb_y = nullptr; p.bnb_bits = nullptr; p.res_bits = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_gamma = p.bnb_beta = nullptr; p.bnb_relu = p.bnb_ps = 0;

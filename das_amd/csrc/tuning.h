@@ -43,6 +43,8 @@ enum Key {
   BN_UPMERGE_BLOCKS,     // grid cap of upmerge_bwd_reduce_kernel
   DCN_FUSED_MINROWS,     // das_dcn3x3_fused instead of im2col + GEMM in the eval forward from this many pixel rows up (0 = never):
                          // 15 % ahead at 141 k rows, behind at 71 k (its 128-pixel tiles fill three rounds for 2.2 rounds of work)
+  CONV_BALANCE_ROWS,     // one-workgroup-per-CU tile launches whose last round would be partly empty spread their pixel rows evenly
+                         // over the tiles of full rounds (tiles of ConvP::mstep < 256 rows): 0 off, 1 the 1x1 convs, 2 every conv
   N_KEYS
 };
 

@@ -115,6 +115,11 @@ def last_kernel():
     return _lib.load().das_last_kernel().decode()
 
 
+def last_tile_rows():
+    """Rows per pixel tile of this thread's last conv2d launch on a 256-row tile kernel (das_conv_last_tile_rows)."""
+    return int(_lib.load().das_conv_last_tile_rows())
+
+
 def last_wgrad_plan():
     """Schedule of this thread's last weight-gradient launch (das_wgrad_last_plan): dict of kernel class, grid, units,
     direct (units stored straight into dW), partial (tiles through the workspace), reduced, longest list, groups, schedules

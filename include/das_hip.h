@@ -50,13 +50,18 @@ const char* das_target_arch(void);
  * bn.reduce_blocks, bn.reduce_threads, bn.vpt, gn.ppb, bn.stream_minbytes, comm.reserved_cus (CUs every persistent grid leaves free: wgrad.blocks / wgrad.pp_blocks 0 = one
  * resident wave of workgroups on the remaining CUs), elem.upstats_ppb (output pixels per workgroup of the resampling
  * kernels, 0 = by size), bn.upmerge_blocks (grid cap of the fused reduce passes of upmerge.hip / skipadd.hip),
- * dcn.fused_minrows (das_amd.nn.dcn_v2: das_dcn3x3_fused in the eval forward from this many pixel rows up; 0 = never). */
+ * dcn.fused_minrows (das_amd.nn.dcn_v2: das_dcn3x3_fused in the eval forward from this many pixel rows up; 0 = never),
+ * conv.balance_rows (0 off / 1 the 1x1 convs / 2 every conv: see das_conv_last_tile_rows). */
 int das_tuning_set(const char* key, long long value);
 int das_tuning_get(const char* key, long long* value);
 int das_tuning_reset(void);
 /* Name of the kernel the calling thread's last das_conv2d_nhwc / das_conv2d_wgrad_nhwc call launched
  * ("conv_glds4_kernel<pp>", "conv1x1_stream_kernel", ...): lets a parity test assert WHICH kernel it checked. */
 const char* das_last_kernel(void);
+/* Rows per pixel tile of the calling thread's last das_conv2d_nhwc launch on a 256-row tile kernel: 256 (288), or the
+ * smaller balanced step (tuning key conv.balance_rows: a launch whose last round of one-workgroup-per-CU tiles would be
+ * partly empty spreads its rows evenly over the tiles of full rounds); 0 if the last launch used another kernel. */
+int das_conv_last_tile_rows(void);
 /* Measurement aid (no reference counterpart): `blocks` workgroups of `threads` threads and `lds_bytes` of LDS each that
  * do nothing but hold their CU slots for `usec` microseconds on `stream` — stands in for the RCCL kernels of an
  * overlapped gradient all-reduce when only one GPU is at hand (tools/dev/cu_pressure.py, tests/test_ddp_gpu.py):

@@ -182,6 +182,52 @@ def test_tile_dgrad_forced(kernel):
     np.testing.assert_allclose(nchw(dx).numpy(), q(q(x.grad) + q(other)).numpy(), **TOL)
 
 
+# ---------------------------------------------------------------- balanced pixel tiles (conv.balance_rows)
+BALANCED = [
+    # B, H, W, Cin, Cout, k, kernel, conv.balance_rows, expected rows per tile
+    (16, 64, 104, 512, 128, 1, 'conv_glds3_kernel', 1, 208),        # 416 tiles of 256 rows on 256 CUs -> 512 of 208
+    (16, 64, 104, 512, 256, 1, 'conv_glds4_kernel<pp>', 1, 208),    # the 256 x 256 tile kernel, same rows
+    (16, 32, 52, 1024, 256, 1, 'conv_glds3_kernel<pp>', 1, 208),    # 104 x 2 tiles (one round, 81 % full) -> 128 x 2
+    (16, 32, 52, 256, 256, 3, 'conv_glds3_kernel<pp>', 2, 208),     # 3x3 (borders inside the shorter tiles): only with 2
+    (16, 32, 52, 256, 256, 3, 'conv_glds3_kernel<pp>', 1, 256),     # ... and left alone with 1
+]
+
+
+@pytest.mark.parametrize('case', BALANCED)
+def test_balanced_pixel_tiles_store_what_the_full_tiles_store(case):
+    """A 256-row tile launch whose last round of one-workgroup-per-CU tiles would be partly empty spreads its rows over the
+    tiles of full rounds (ConvP::mstep, das_conv_last_tile_rows): every output element is still the same K loop in the same
+    order, so the stored tensor is BIT-identical to the plain tiling's; the BatchNorm statistics (float atomics over other
+    workgroups) agree to rounding; epilogue operands (residual, fused BatchNorm-backward with mask bits) follow the rows."""
+    o = ops()
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip('the cases are sized for 256 CUs')
+    B, H, W, Cin, Cout, k, kernel, mode, rows = case
+    x = nhwc(cases.randn(171, B, Cin, H, W))
+    w = o.pack_weight((cases.randn(172, Cout, Cin, k, k) / (Cin * k * k) ** 0.5).to(DEV), BF)
+    res = nhwc(cases.randn(173, B, Cout, H, W))
+    raw = nhwc(cases.randn(174, B, Cout, H, W))
+    bits = (torch.rand(B * H * W * Cout // 8, device=DEV) * 256).to(torch.uint8)
+    mean, invstd = cases.randn(175, Cout).to(DEV) * 0.1, (cases.randn(176, Cout).abs() + 0.5).to(DEV)
+    gamma, beta = (cases.randn(177, Cout).abs() + 0.5).to(DEV), (cases.randn(178, Cout) * 0.2).to(DEV)
+    fuse = o.BnBwd(raw, None, mean, invstd, gamma, beta, True, bits=bits)
+    out = {}
+    for m in (0, mode):
+        with o.tuning(**{'conv.balance_rows': m, 'conv.stream_minrows': 0}):
+            s1, s2 = torch.zeros(2 * Cout, device=DEV), torch.zeros(2 * Cout, device=DEV)
+            y1 = o.conv2d(x, w, k, k, 1, k // 2, stats=s1)
+            assert o.last_kernel() == kernel, o.last_kernel()
+            assert o.last_tile_rows() == (rows if m else 256), (m, o.last_tile_rows())
+            y2 = o.conv2d(x, w, k, k, 1, k // 2, residual=res, bn_bwd=fuse, stats=s2)
+            assert o.last_tile_rows() == (rows if m else 256), (m, o.last_tile_rows())
+            out[m] = (y1, s1, y2, s2)
+    assert torch.equal(out[0][0], out[mode][0]) and torch.equal(out[0][2], out[mode][2])
+    n = B * H * W
+    for i in (1, 3):
+        np.testing.assert_allclose(out[mode][i].cpu().numpy() / n, out[0][i].cpu().numpy() / n, rtol=1e-4, atol=1e-5)
+    assert float((out[mode][2] == 0).float().mean()) > 0.2      # the mask bits are in effect
+
+
 # ---------------------------------------------------------------- 3x3, 64 -> 64 channels: patch kernel
 C64 = {'conv.c64_mintiles': 1}
 

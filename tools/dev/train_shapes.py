@@ -16,6 +16,11 @@ from das_amd import autograd as _ag
 _ag.WGRAD_SIDE_STREAM = False
 if os.environ.get('WGB'):
     _ag.WGRAD_BATCH = int(os.environ['WGB'])   # (dev: unbatched weight gradients -> per-layer times)   # kernels one at a time: per-shape times are not stretched by overlapped weight gradients
+if os.environ.get('TUNE'):     # dev: dispatch keys for the whole run, TUNE=conv.balance_rows=0,conv.tail_split=0
+    from das_amd import _lib as _l2
+    for kv in os.environ['TUNE'].split(','):
+        k, v = kv.split('=')
+        _l2.check(_l2.load().das_tuning_set(k.encode(), int(v)), k)
 dev = torch.device('cuda', 0)
 model = bench.build_model(dev, num_stages=4, train=True)
 ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=B, seed=0)
