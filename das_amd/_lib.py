@@ -34,6 +34,11 @@ class DasPackEntry(C.Structure):
     _fields_ = [('off', i64), ('O', i32), ('I', i32), ('KH', i32), ('KW', i32), ('tile_start', i32), ('s2_pad', i32)]
 
 
+class DasBnFinalize(C.Structure):
+    _fields_ = [('stats', vp), ('stats_slots', i32), ('C', i32), ('count', i64), ('running_mean', vp), ('running_var', vp),
+                ('momentum', f32), ('eps', f32), ('save_mean', vp), ('save_invstd', vp), ('num_batches_tracked', vp)]
+
+
 class DasFlowJob(C.Structure):
     _fields_ = [('params', vp), ('dparams', vp), ('dst_table', vp), ('row_start', i32), ('row_end', i32)]
 
@@ -107,7 +112,7 @@ SIGNATURES = {
     'das_groupnorm_backward': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, vp, f32, i32, vp,
                                      vp, vp, vp]),
     'das_groupnorm_backward_acc': (i32, [vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, vp, f32, i32, vp,
-                                     vp, vp, vp]),
+                                         vp, vp, i32, vp]),
     'das_maxpool3x3s2_backward': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'das_upsample_bilinear_ac_backward': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_upsample_nearest_backward': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -127,9 +132,10 @@ SIGNATURES = {
     'das_upsample_bilinear_ac': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_add_upsample_nearest': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'das_add3': (i32, [vp, vp, vp, vp, i32, i64, i32, vp]),
+    'das_bn_finalize_many': (i32, [C.POINTER(DasBnFinalize), i32, vp]),
     'das_bn_train_apply': (i32, [vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp, i64, i32,
                                  vp, vp]),
-    'das_groupnorm_nhwc': (i32, [vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp, vp]),
+    'das_groupnorm_nhwc': (i32, [vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp, vp, f32, i32, vp, i32, vp]),
     'das_deform_im2col3x3': (i32, [vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, vp]),
     'das_dcn3x3_fused': (i32, [vp, vp, vp, vp, vp, vp, i32, C.POINTER(DasLevels), i32, i32, i32, i32, i32, vp]),
     'das_offset_sample': (i32, [vp, vp, vp, vp, C.POINTER(DasLevels), i32, i32, i32, i32, i32, i32, vp]),

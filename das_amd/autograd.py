@@ -331,7 +331,7 @@ def _conv_stats_forward_pair(a, b):
     ranks their statistics travel in ONE message (nn.sync_stats_many) instead of two."""
     from .nn import bn_stats_buffer, packed_weight, sync_stats_many
     wa, wb = _sync_world(a[2]), _sync_world(b[2])
-    if wa <= 1 or wa != wb:
+    if wa != wb:
         return _conv_stats_forward(*a), _conv_stats_forward(*b)
     raws, stats, couts = [], [], []
     for x, conv, bn, gamma, beta in (a, b):
@@ -341,18 +341,35 @@ def _conv_stats_forward_pair(a, b):
         raws.append(ops.conv2d(x, w, k, k, s, p, stats=st))
         stats.append(st)
         couts.append(w.shape[0])
-    _check_equal_rows(raws[0].numel() // raws[0].shape[-1])
-    stats = sync_stats_many(stats, couts, _all_reduce)
-    out = []
-    for (x, conv, bn, gamma, beta), raw, st in zip((a, b), raws, stats):
-        rows = raw.numel() // raw.shape[-1]
-        _, mean, invstd = ops.bn_train_apply(raw, st, gamma, beta, bn.running_mean, bn.running_var,
-                                             bn.momentum if bn.momentum is not None else 0.1, bn.eps,
-                                             num_batches_tracked=bn.num_batches_tracked, stat_count=rows * wa,
-                                             finalize_only=True)
-        bn.__dict__.pop('_das_cache', None)
-        out.append((raw, mean, invstd))
-    return out[0], out[1]
+    if wa > 1:
+        _check_equal_rows(raws[0].numel() // raws[0].shape[-1])
+        stats = sync_stats_many(stats, couts, _all_reduce)
+    fin = _finalize_many([(bn, st, raw.numel() // raw.shape[-1] * wa, raw.shape[-1])
+                          for (x, conv, bn, gamma, beta), raw, st in zip((a, b), raws, stats)])
+    return (raws[0],) + fin[0], (raws[1],) + fin[1]
+
+
+FINALIZE_MANY = True    # one finalize launch for the layers of a fused consumer (False: one per layer); A/B switch
+
+
+def _finalize_many(items):
+    """mean / invstd published and running statistics advanced for [(bn, stats, count, C)] in ONE launch (layers whose
+    statistics are complete together and whose normalisation one fused consumer does). Returns [(mean, invstd)]."""
+    if not FINALIZE_MANY:
+        fin = []
+        for it in items:
+            fin += _finalize_many_impl([it])
+        return fin
+    return _finalize_many_impl(items)
+
+
+def _finalize_many_impl(items):
+    fin = ops.bn_finalize_many([(st, Cc, count, bn.running_mean, bn.running_var,
+                                 bn.momentum if bn.momentum is not None else 0.1, bn.eps, bn.num_batches_tracked)
+                                for bn, st, count, Cc in items])
+    for bn, _, _, _ in items:
+        bn.__dict__.pop('_das_cache', None)   # running stats changed under the cache's feet (raw-pointer update)
+    return fin
 
 
 # a bottleneck's projection shortcut normalised inside bn3's apply pass (ops.bn_dual_apply); switch for A/B runs and tests
@@ -577,16 +594,7 @@ class UpMergeTrainFn(Function):
             both = torch.cat([stats1.view(-1, 2 * cout).sum(0), stats2.view(-1, 2 * cout).sum(0)])
             _all_reduce(both)
             stats1, stats2 = both[:2 * cout], both[2 * cout:]
-        _, mean1, invstd1 = ops.bn_train_apply(raw1, stats1, g1, b1, bn1.running_mean, bn1.running_var,
-                                               bn1.momentum if bn1.momentum is not None else 0.1, bn1.eps,
-                                               num_batches_tracked=bn1.num_batches_tracked, stat_count=rows * world,
-                                               finalize_only=True)
-        _, mean2, invstd2 = ops.bn_train_apply(z, stats2, g2, b2, bn2.running_mean, bn2.running_var,
-                                               bn2.momentum if bn2.momentum is not None else 0.1, bn2.eps,
-                                               num_batches_tracked=bn2.num_batches_tracked, stat_count=rows * world,
-                                               finalize_only=True)
-        bn1.__dict__.pop('_das_cache', None)
-        bn2.__dict__.pop('_das_cache', None)
+        (mean1, invstd1), (mean2, invstd2) = _finalize_many([(bn1, stats1, rows * world, cout), (bn2, stats2, rows * world, cout)])
         mask = ops.relu_bits_buffer(raw1) if MASK_BITS else None
         out = ops.upmerge_forward(raw1, z, (mean1, invstd1, g1, b1), (mean2, invstd2, g2, b2), bits_out=mask)
         ctx.save_for_backward(x, up_x, raw1, z, out if mask is None else None, mean1, invstd1, mean2, invstd2, g1, g2, mask)
@@ -940,8 +948,10 @@ class ConvFn(Function):
         db = None
         if has_bias:
             ba = _param_acc(conv.bias) if getattr(conv, 'bias', None) is not None else None
-            if ba is not None and _d(dzr).shape[-1] == conv.bias.numel():
-                ops.colsum(dzr, acc=ba[1])        # straight into the flat gradient: no temporary, fill or add
+            if ba is not None and 0 <= _d(dzr).shape[-1] - conv.bias.numel() < 8:
+                # straight into the flat gradient: no temporary, fill or add (a gradient as wide as the layer's channel count
+                # padded to a multiple of 8: only the columns that exist are summed)
+                ops.colsum(dzr, acc=ba[1].reshape(-1))
                 ba[0].fired()
             else:
                 db = ops.colsum(dzr)[:weight.shape[0]]
@@ -958,7 +968,9 @@ class GroupNormReLUFn(Function):
         ctx.gn = gn      # (the nn.GroupNorm module: its parameters' flat-gradient slices take the gradients directly)
         xin = _wrap(x, geom)
         out = xin.new(x.shape[-1]) if geom is not None else torch.empty_like(x)
-        y, st = ops.groupnorm(xin, gamma, beta, G, eps, relu=relu, out=out, return_stats=True)
+        from .nn import kept_zeros
+        y, st = ops.groupnorm(xin, gamma, beta, G, eps, relu=relu, out=out, return_stats=True,
+                              ws=kept_zeros(ops.groupnorm_stats_size(xin, G), x.device))
         yd = _d(y)
         # (the ReLU mask is recomputed from x in the backward — no residual enters these layers — so y is not kept)
         ctx.save_for_backward(x, None if GN_REMASK else yd, st, gamma, beta)
@@ -972,9 +984,14 @@ class GroupNormReLUFn(Function):
         dy = dy.contiguous()
         ga, ba = (_param_acc(ctx.gn.weight), _param_acc(ctx.gn.bias)) if ctx.gn is not None else (None, None)
         direct = ga is not None and ba is not None
-        dx, dgamma, dbeta = ops.groupnorm_backward(_wrap(dy, geom), _wrap(y, geom) if y is not None else None, _wrap(x, geom), st,
+        from .nn import zeroed_stats
+        from . import nn as _nn
+        xr = _wrap(x, geom)
+        dx, dgamma, dbeta = ops.groupnorm_backward(_wrap(dy, geom), _wrap(y, geom) if y is not None else None, xr, st,
                                                    gamma, G, eps, relu, dgamma_acc=ga[1] if direct else None,
-                                                   dbeta_acc=ba[1] if direct else None, beta=beta)
+                                                   dbeta_acc=ba[1] if direct else None, beta=beta,
+                                                   ws=zeroed_stats(ops.groupnorm_stats_size(xr, G), x.device)
+                                                   if (direct and _nn.ZEROED_GN_WS) else None)
         if direct:
             ga[0].fired()
             ba[0].fired()
@@ -1055,8 +1072,8 @@ def _dcn_gemm_weight_c(dcn, weight, dtype, cpad):
     """_dcn_gemm_weight for callers that have no col tensor (the fused forward): same cache entries."""
     from .nn import _cache_of, _slot_of
     sl = _slot_of(weight, cpad)
-    if sl is not None and sl.cl_shape[0] % 8 == 0:
-        return sl.packed(dtype).reshape(sl.cl_shape[0], 1, 1, 9 * cpad)
+    if sl is not None:
+        return sl.packed(dtype).reshape(sl.o_pad, 1, 1, 9 * cpad)
     return _cache_of(dcn).get(('w', dtype), (weight,),
                               lambda: ops.pack_weight(weight, dtype).reshape(-1, 1, 1, 9 * cpad),
                               refresh=lambda buf: ops.pack_weight(weight, dtype, out=buf.view(-1, 3, 3, cpad)))
@@ -1068,8 +1085,8 @@ def _dcn_gemm_weight(dcn, weight, col):
     from .nn import _cache_of, _slot_of
     cpad = col.shape[-1] // 9
     sl = _slot_of(weight, cpad)
-    if sl is not None and sl.cl_shape[0] % 8 == 0:
-        return sl.packed(col.dtype).reshape(sl.cl_shape[0], 1, 1, 9 * cpad)
+    if sl is not None:
+        return sl.packed(col.dtype).reshape(sl.o_pad, 1, 1, 9 * cpad)
     return _cache_of(dcn).get(('w', col.dtype), (weight,),
                               lambda: ops.pack_weight(weight, col.dtype).reshape(-1, 1, 1, 9 * cpad),
                               refresh=lambda buf: ops.pack_weight(weight, col.dtype, out=buf.view(-1, 3, 3, cpad)))

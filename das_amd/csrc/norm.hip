@@ -51,11 +51,10 @@ __device__ __forceinline__ void bn_publish(const float* __restrict__ stats, long
 // takes — the same fold order and the same arithmetic as the apply kernels. As workgroup 0 of an apply kernel with an
 // empty body this took 6-15 us (one workgroup walking 2C sums and C channels); the fused train-mode passes call it
 // ~60 times a step.
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ gstats, int slots, long long count, int C,
-                                                         float* running_mean, float* running_var, float momentum, float eps,
-                                                         float* save_mean, float* save_invstd, long long* num_batches_tracked) {
+__device__ __forceinline__ void bn_finalize_channel(int c, const float* __restrict__ gstats, int slots, long long count, int C,
+                                                    float* running_mean, float* running_var, float momentum, float eps,
+                                                    float* save_mean, float* save_invstd, long long* num_batches_tracked) {
 #pragma clang fp contract(off)
-  const int c = blockIdx.x * 64 + threadIdx.x;
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
   if (c >= C) return;
   float sum[2];
@@ -87,6 +86,21 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * st.mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
   }
+}
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ gstats, int slots, long long count, int C,
+                                                         float* running_mean, float* running_var, float momentum, float eps,
+                                                         float* save_mean, float* save_invstd, long long* num_batches_tracked) {
+  bn_finalize_channel(blockIdx.x * 64 + threadIdx.x, gstats, slots, count, C, running_mean, running_var, momentum, eps,
+                      save_mean, save_invstd, num_batches_tracked);
+}
+// Several layers in one launch (das_bn_finalize_many): blockIdx.y = layer
+struct BnFinalizeMany {
+  DasBnFinalize l[4];
+};
+__global__ __launch_bounds__(64) void bn_finalize_many_kernel(BnFinalizeMany a) {
+  const DasBnFinalize& f = a.l[blockIdx.y];
+  bn_finalize_channel(blockIdx.x * 64 + threadIdx.x, f.stats, f.stats_slots, f.count, f.C, f.running_mean, f.running_var,
+                      f.momentum, f.eps, f.save_mean, f.save_invstd, f.num_batches_tracked);
 }
 
 // One 16-byte channel vector per thread and iteration. The grid stride is a multiple of the channel-vector
@@ -462,9 +476,30 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
   return DAS_OK;
 }
 
+extern "C" int das_bn_finalize_many(const DasBnFinalize* layers, int n, void* stream) {
+  DAS_PROF(stream);
+  if (!layers || n < 1 || n > 4) return DAS_ERR_ARG;
+  BnFinalizeMany a;
+  int maxc = 0;
+  for (int i = 0; i < 4; ++i) {
+    a.l[i] = layers[i < n ? i : 0];
+    if (i >= n) continue;
+    const DasBnFinalize& f = layers[i];
+    if (!f.stats || !f.save_mean || !f.save_invstd || f.C < 1 || f.count < 1 || f.stats_slots < 0 || f.stats_slots > 64 ||
+        ((f.running_mean == nullptr) != (f.running_var == nullptr)))
+      return DAS_ERR_ARG;
+    if (a.l[i].stats_slots < 1) a.l[i].stats_slots = 1;
+    maxc = std::max(maxc, f.C);
+  }
+  hipLaunchKernelGGL(bn_finalize_many_kernel, dim3((maxc + 63) / 64, n), dim3(64), 0, (hipStream_t)stream, a);
+  DAS_CHECK_LAUNCH();
+  dastune::note_kernel("bn_finalize_kernel");
+  return DAS_OK;
+}
+
 extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLevels* lv, int C, int pix_stride,
                                   int G, const float* gamma, const float* beta, float eps, int relu, float* stats_ws,
-                                  void* stream) {
+                                  int ws_zeroed, void* stream) {
   DAS_PROF(stream);
   if (!x || !y || !gamma || !beta || !stats_ws || !lv_valid(lv) || C % 8 || C % G || pix_stride % 8 || C > 2048)
     return DAS_ERR_ARG;
@@ -472,7 +507,7 @@ extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLe
   if ((C / epv) > GN_NT) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nseg = lv->num_levels * lv->B;
-  if (hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (!ws_zeroed && hipMemsetAsync(stats_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
   int maxhw = 0;
   for (int l = 0; l < lv->num_levels; ++l) maxhw = std::max(maxhw, lv->H[l] * lv->W[l]);
   // enough blocks to fill the chip, at least 64 pixels per block

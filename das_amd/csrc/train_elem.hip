@@ -437,7 +437,7 @@ __global__ void nearest_bwd_kernel(const T* __restrict__ dy, T* __restrict__ db,
 static int groupnorm_backward_impl(const void* dy, const void* y, const void* x, void* dx, int dtype,
                                    const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
                                    const float* gamma, const float* beta, float eps, int relu, float* gsums_ws,
-                                   float* dgamma, float* dbeta, bool accumulate, void* stream) {
+                                   float* dgamma, float* dbeta, bool accumulate, bool ws_zeroed, void* stream) {
   if (!dy || !x || !dx || !fwd_stats || !gamma || !gsums_ws || !dgamma || !dbeta || !lv_valid(lv)) return DAS_ERR_ARG;
   if (C % 8 || C % G || pix_stride % 8 || C > 2048 || (relu && !y && !beta)) return DAS_ERR_ARG;
   const int epv = dtype == DAS_BF16 ? 8 : 4;
@@ -446,7 +446,7 @@ static int groupnorm_backward_impl(const void* dy, const void* y, const void* x,
   const int nseg = lv->num_levels * lv->B;
   // (one fill when the caller laid the three accumulators out back to back: a fill is a ~4 us launch of its own)
   if (accumulate) {   // dgamma / dbeta already hold gradients (the optimizer's flat buffer): only the group sums start at zero
-    if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
+    if (!ws_zeroed && hipMemsetAsync(gsums_ws, 0, sizeof(float) * 2 * nseg * G, s) != hipSuccess) return DAS_ERR_LAUNCH;
   } else if (dgamma == gsums_ws + 2 * nseg * G && dbeta == dgamma + C) {
     if (hipMemsetAsync(gsums_ws, 0, sizeof(float) * (2 * (size_t)nseg * G + 2 * (size_t)C), s) != hipSuccess) return DAS_ERR_LAUNCH;
   } else {
@@ -481,15 +481,15 @@ extern "C" int das_groupnorm_backward(const void* dy, const void* y, const void*
                                       float* dgamma, float* dbeta, void* stream) {
   DAS_PROF(stream);
   return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, beta, eps, relu, gsums_ws,
-                                 dgamma, dbeta, false, stream);
+                                 dgamma, dbeta, false, false, stream);
 }
 extern "C" int das_groupnorm_backward_acc(const void* dy, const void* y, const void* x, void* dx, int dtype,
                                           const DasLevels* lv, int C, int pix_stride, int G, const float* fwd_stats,
                                           const float* gamma, const float* beta, float eps, int relu, float* gsums_ws,
-                                          float* dgamma, float* dbeta, void* stream) {
+                                          float* dgamma, float* dbeta, int ws_zeroed, void* stream) {
   DAS_PROF(stream);
   return groupnorm_backward_impl(dy, y, x, dx, dtype, lv, C, pix_stride, G, fwd_stats, gamma, beta, eps, relu, gsums_ws,
-                                 dgamma, dbeta, true, stream);
+                                 dgamma, dbeta, true, ws_zeroed != 0, stream);
 }
 
 extern "C" int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W,

@@ -688,7 +688,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WgradSched sch_) {
   const long long m_begin = (long long)un.step0 * BKM;
 
   const v4i_t xrs = make_rsrc(p.x, p.xbytes);
-  const v4i_t drs = make_rsrc(p.res, (unsigned)(((long long)(p.M - 1) * p.rps + p.Cout) * 2));
+  // (range up to the end of the last row's last 8-channel vector — it exists: rps >= Cout rounded up to 8 — so that a channel
+  // count that is not a multiple of 8 does not cut the vector holding its last channels out of the last pixel row)
+  const v4i_t drs = make_rsrc(p.res, (unsigned)(((long long)(p.M - 1) * p.rps + (p.Cout + 7) / 8 * 8) * 2));
 
   // per sub-tile 8 DMA instructions (4 rows each); wave w stages instructions (w & 3) * 2 + {0, 1} of the dY and
   // of the X sub-tile (w >> 2)
@@ -829,7 +831,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp_kernel(WgradSched sch_) {
 
 // ------------------------------------------------------------------ column sums (bias gradient)
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, long long rows, int C, int ps, float* __restrict__ out) {
+__global__ void colsum_kernel(const T* __restrict__ x, long long rows, int C, int ps, float* __restrict__ out, int nout) {
+  // (C: the columns walked, a multiple of the vector width; nout <= C: the columns that exist — a layer whose channel
+  // count is not a multiple of 8 lives in rows padded to one, and its bias gradient has no padding)
   constexpr int EPV = Elem<T>::EPV;
   extern __shared__ float part[];   // [PL][C] (common.h: lds_put / lds_fold)
   const int VC = C / EPV;
@@ -848,7 +852,7 @@ __global__ void colsum_kernel(const T* __restrict__ x, long long rows, int C, in
     lds_put<EPV>(part, C, pl, v * EPV, s);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += TPB) atomicAdd(out + i, lds_fold(part, C, PL, i));
+  for (int i = threadIdx.x; i < nout; i += TPB) atomicAdd(out + i, lds_fold(part, C, PL, i));
 }
 
 // ------------------------------------------------------------------ BatchNorm (train) backward
@@ -1151,7 +1155,10 @@ struct HostWgrad {   // one validated op
 
 int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d, HostWgrad& h) {
   if (!x || !dy || !dw || !d) return DAS_ERR_ARG;
-  if (d->Cin % 8 || d->Cout % 8 || d->x_pix_stride % 8 || d->y_pix_stride % 8) return DAS_ERR_ARG;
+  // (Cout need not be a multiple of 8 when dY's rows are padded to one: the loaders take whole 8-channel vectors, the stores
+  // — direct, partial-tile reduce — keep to the rows below Cout)
+  if (d->Cin % 8 || d->Cout < 1 || d->x_pix_stride % 8 || d->y_pix_stride % 8 || d->y_pix_stride < (d->Cout + 7) / 8 * 8)
+    return DAS_ERR_ARG;
   if (d->KH < 1 || d->KW < 1 || d->stride < 1 || d->B < 1 || d->in_up > 1) return DAS_ERR_ARG;
   if (d->dtype != DAS_BF16 && d->dtype != DAS_F32) return DAS_ERR_ARG;
   std::memset(&h.o, 0, sizeof(h.o));   // (the record is part of the schedule cache key: no indeterminate padding)
@@ -1183,7 +1190,7 @@ int wgrad_prepare(const void* x, const void* dy, float* dw, const DasConvDesc* d
   if (d->dtype == DAS_BF16 && pp_mink > 0 && o.K >= pp_mink && d->Cout >= 256) {
     const long long npix = o.nlev > 1 ? M : (long long)d->B * d->H * d->W;
     const long long xb = ((npix - 1) * d->x_pix_stride + d->Cin) * 2;
-    const long long db = ((M - 1) * d->y_pix_stride + d->Cout) * 2;
+    const long long db = ((M - 1) * d->y_pix_stride + (d->Cout + 7) / 8 * 8) * 2;
     if (xb < 0xFFFFFFF0LL && db < 0xFFFFFFE0LL) {
       o.xbytes = (unsigned)xb;
       h.cls = 0;
@@ -1571,17 +1578,18 @@ extern "C" int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, c
   return das_conv2d_wgrad_batch(1, &x, &dy, &dw, d, accumulate, stream);
 }
 
-static int colsum_impl(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, bool accumulate, void* stream) {
-  if (!x || !out || rows <= 0 || C % 8 || pix_stride % 8 || C > 2048) return DAS_ERR_ARG;
+static int colsum_impl(const void* x, int dtype, long long rows, int nout, int pix_stride, float* out, bool accumulate, void* stream) {
+  const int C = (nout + 7) / 8 * 8;   // columns walked (vectors of 8 / 4): the row holds them (pix_stride >= C)
+  if (!x || !out || rows <= 0 || nout < 1 || pix_stride % 8 || pix_stride < C || C > 2048) return DAS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) return DAS_ERR_LAUNCH;
+  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * nout, s) != hipSuccess) return DAS_ERR_LAUNCH;
   const int blocks = (int)std::min<long long>(256, std::max<long long>(1, rows / 64));
   if (dtype == DAS_BF16) {
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(TPB), (TPB / std::min(C / 8, TPB)) * C * sizeof(float), s, (const bf16_t*)x, rows, C,
-                       pix_stride, out);
+                       pix_stride, out, nout);
   } else if (dtype == DAS_F32) {
     hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(TPB), (TPB / std::min(C / 4, TPB)) * C * sizeof(float), s, (const float*)x, rows, C,
-                       pix_stride, out);
+                       pix_stride, out, nout);
   } else {
     return DAS_ERR_ARG;
   }

@@ -132,6 +132,9 @@ def _pad8(v, n, fill=0.0, out=None):
     vd = v.detach()
     if n % 8 == 0 and vd.numel() == n and vd.dtype == torch.float32 and vd.is_contiguous():
         return vd
+    sl = getattr(v, '_das_slot', None)
+    if sl is not None and fill == 0.0 and vd.numel() == n and sl.numel == n and sl.span == (n + 7) // 8 * 8:
+        return sl.padded()     # (the flat optimizer stores a 1-D parameter with its zero padding: nothing to copy)
     if out is not None and out.numel() == (n + 7) // 8 * 8 and out.data_ptr() != vd.data_ptr():
         out[:n].copy_(vd)      # (refresh of a cached padded copy: the padding keeps its fill value)
         return out
@@ -156,8 +159,8 @@ def bias_shift(conv):
     if conv.bias is None:
         return None
     n = conv.bias.numel()
-    if n % 8 == 0:
-        return _pad8(conv.bias, n)      # (used as it is: nothing to cache)
+    if n % 8 == 0 or getattr(conv.bias, '_das_slot', None) is not None:
+        return _pad8(conv.bias, n)      # (used as it is, or with the padding its flat storage carries: nothing to cache)
     return _cache_of(conv).get(('bias',), (conv.bias,), lambda: _pad8(conv.bias, n),
                                refresh=lambda buf: _pad8(conv.bias, n, out=buf))
 
@@ -360,6 +363,31 @@ class _ZeroArena:
 _STATS_ARENA = _ZeroArena()
 
 
+class _KeptZeros:
+    """Zeroed f32 slices that must LIVE (GroupNorm statistics: the backward reads them much later): handed out from a buffer
+    that was filled once; when it is used up a NEW buffer is filled — the slices keep the old one alive. One fill per ~60
+    layers instead of one per layer (each a launch of its own: 14 per training step)."""
+
+    def __init__(self, cap=1 << 18):
+        self.cap, self.buf, self.off = cap, None, 0
+
+    def take(self, n, device):
+        step = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != device or self.off + step > self.buf.numel():
+            self.buf, self.off = torch.zeros(max(self.cap, step), dtype=torch.float32, device=device), 0
+        s = self.buf[self.off:self.off + n]
+        self.off += step
+        return s
+
+
+_KEPT_ZEROS = _KeptZeros()
+ZEROED_GN_WS = True     # GroupNorm statistics workspaces come zeroed from the pools (False: every call fills its own); A/B switch
+
+
+def kept_zeros(n, device):
+    return _KEPT_ZEROS.take(n, device) if ZEROED_GN_WS else None
+
+
 def zeroed_stats(n, device):
     return _STATS_ARENA.take(n, device)[:n]
 
@@ -486,7 +514,8 @@ def group_norm_relu(x, gn, relu=True):
     if ag.grad_mode(_tensor(x), gn.weight):
         g = ag._geom(x)
         return ag._wrap(ag.GroupNormReLUFn.apply(_tensor(x), gn.weight, gn.bias, g, gn.num_groups, gn.eps, relu, gn), g)
-    return ops.groupnorm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=relu)
+    ws = zeroed_stats(ops.groupnorm_stats_size(x, gn.num_groups), _tensor(x).device) if ZEROED_GN_WS else None   # (used by this call's launches only)
+    return ops.groupnorm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=relu, ws=ws)
 
 
 def max_pool(x):

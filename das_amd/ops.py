@@ -384,7 +384,7 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad, out=None, accumulate=False):
         dw = torch.empty(Cout, KH, KW, Cin, dtype=torch.float32, device=xd.device)
     else:
         dw = out
-        assert dw.numel() == Cout * KH * KW * Cin and dw.dtype == torch.float32 and dw.is_contiguous()
+        Cout = _wgrad_rows(dw, Cout, KH, KW, Cin)
     d = _lib.DasConvDesc(dtype=_DT[xd.dtype], out_dtype=_lib.DAS_F32, B=B, H=H, W=W, Cin=Cin, x_pix_stride=_ps(x),
                          Ho=Ho, Wo=Wo, Cout=Cout, y_pix_stride=_ps(dy), KH=KH, KW=KW, stride=stride, pad=pad,
                          num_levels=len(x.sizes) if ragged else 0)
@@ -405,9 +405,20 @@ def conv2d_wgrad(x, dy, KH, KW, stride, pad, out=None, accumulate=False):
     return dw
 
 
-def _wgrad_desc(x, dy, KH, KW, stride, pad):
+def _wgrad_rows(out, width, KH, KW, Cin):
+    """Output channels of a weight gradient written into `out`: the gradient tensor's width, or fewer when that width is the
+    layer's channel count padded to a multiple of 8 (out = the rows that exist; the kernel stores no others)."""
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() % (KH * KW * Cin) == 0
+    cout = out.numel() // (KH * KW * Cin)
+    assert cout <= width < cout + 8 and (cout == width or width % 8 == 0), (cout, width)
+    return cout
+
+
+def _wgrad_desc(x, dy, KH, KW, stride, pad, out=None):
     xd, dyd = _data(x), _data(dy)
     Cin, Cout = xd.shape[-1], dyd.shape[-1]
+    if out is not None:
+        Cout = _wgrad_rows(out, Cout, KH, KW, Cin)
     ragged = isinstance(x, Ragged)
     if ragged:
         B, (H, W) = x.B, x.sizes[0]
@@ -456,8 +467,7 @@ def conv2d_wgrad_batch(items, accumulate=True):
     flops, nby = 0.0, 0.0
     for i, (x, dy, KH, KW, stride, pad, out) in enumerate(items):
         _need_gpu(x, dy, out)
-        d, fl = _wgrad_desc(x, dy, KH, KW, stride, pad)
-        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == d.Cout * KH * KW * d.Cin
+        d, fl = _wgrad_desc(x, dy, KH, KW, stride, pad, out=out)
         descs[i] = d
         xs[i], dys[i], dws[i] = _data(x).data_ptr(), _data(dy).data_ptr(), out.data_ptr()
         flops += fl
@@ -478,7 +488,8 @@ def conv2d_wgrad_batch(items, accumulate=True):
 
 def colsum(x, acc=None):
     """f32[C] column sums over all rows of an NHWC tensor / Ragged (bias gradient).
-    acc: f32[C] the sums are ADDED to instead (the bias's slice of the flat gradient buffer); returns None then."""
+    acc: f32[C'] the sums are ADDED to instead (the bias's slice of the flat gradient buffer); returns None then. C' may be
+    up to 7 less than x's width (a layer whose channel count is not a multiple of 8: the padding columns are not summed)."""
     _need_gpu(x)
     xd = _data(x)
     Cc = xd.shape[-1]
@@ -486,8 +497,9 @@ def colsum(x, acc=None):
     for s in xd.shape[:-1]:
         rows *= s
     if acc is not None:
-        assert acc.dtype == torch.float32 and acc.numel() == Cc and acc.is_contiguous()
-        _lib.check(_lib.load().das_colsum_acc(_ptr(xd), _DT[xd.dtype], rows, Cc, _ps(x), _ptr(acc), _stream()), 'das_colsum_acc')
+        n = acc.numel()
+        assert acc.dtype == torch.float32 and acc.is_contiguous() and n <= Cc < n + 8 and (n == Cc or Cc % 8 == 0), (n, Cc)
+        _lib.check(_lib.load().das_colsum_acc(_ptr(xd), _DT[xd.dtype], rows, n, _ps(x), _ptr(acc), _stream()), 'das_colsum_acc')
         return None
     out = torch.empty(Cc, dtype=torch.float32, device=xd.device)
     _lib.check(_lib.load().das_colsum(_ptr(xd), _DT[xd.dtype], rows, Cc, _ps(x), _ptr(out), _stream()), 'das_colsum')
@@ -772,7 +784,33 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     return y, mean, invstd
 
 
-def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True, dgamma_acc=None, dbeta_acc=None, beta=None):
+def bn_finalize_many(layers):
+    """bn_train_apply(finalize_only=True) of up to four layers in one launch (das_bn_finalize_many). layers: [(stats
+    f32[slots][2C], C, count, running_mean, running_var, momentum, eps, num_batches_tracked)]; count = the rows behind the
+    statistics (all ranks' for SyncBN). Returns [(mean, invstd)]."""
+    n = len(layers)
+    assert 1 <= n <= 4
+    arr = (_lib.DasBnFinalize * n)()
+    out = []
+    for i, (stats, Cc, count, rm, rv, momentum, eps, nbt) in enumerate(layers):
+        _need_gpu(stats)
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() % (2 * Cc) == 0
+        assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda)
+        mi = torch.empty(2, Cc, dtype=torch.float32, device=stats.device)
+        out.append((mi[0], mi[1]))
+        f = arr[i]
+        f.stats, f.stats_slots, f.C, f.count = stats.data_ptr(), stats.numel() // (2 * Cc), Cc, int(count)
+        f.running_mean = rm.data_ptr() if rm is not None else None
+        f.running_var = rv.data_ptr() if rv is not None else None
+        f.momentum, f.eps = momentum, eps
+        f.save_mean, f.save_invstd = mi[0].data_ptr(), mi[1].data_ptr()
+        f.num_batches_tracked = nbt.data_ptr() if nbt is not None else None
+    with _timed('bn_apply_kernel', 0, shape=(int(layers[0][2]), int(layers[0][1]), 0)):
+        _lib.check(_lib.load().das_bn_finalize_many(arr, n, _stream()), 'das_bn_finalize_many')
+    return out
+
+
+def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True, dgamma_acc=None, dbeta_acc=None, beta=None, ws=None):
     """Returns dx (same container as x), dgamma, dbeta. dgamma_acc / dbeta_acc (both): f32[C] slices of the flat gradient
     buffer the parameter gradients are ADDED to instead (dgamma, dbeta come back as None). y=None with relu (needs beta):
     the ReLU mask is recomputed from x, y is not read."""
@@ -787,10 +825,14 @@ def groupnorm_backward(dy, y, x, fwd_stats, gamma, G, eps=1e-5, relu=True, dgamm
     # (the three accumulators back to back: the call zeroes them with one fill)
     ngs = lv.num_levels * lv.B * G * 2
     if dgamma_acc is not None and dbeta_acc is not None:
-        gs = torch.empty(ngs, dtype=torch.float32, device=xd.device)
+        # ws: a ZEROED f32 buffer of at least ngs values for the group sums (a slice of a buffer the caller fills once for many
+        # layers), only read and written by this call's launches
+        assert ws is None or (ws.dtype == torch.float32 and ws.numel() >= ngs and ws.is_contiguous())
+        gs = ws if ws is not None else torch.empty(ngs, dtype=torch.float32, device=xd.device)
         _lib.check(_lib.load().das_groupnorm_backward_acc(_ptr(dyd), _ptr(yd), _ptr(xd), _ptr(_data(dx)), _DT[xd.dtype],
                                                           C.byref(lv), Cc, _ps(x), G, _ptr(fwd_stats), _ptr(gamma), _ptr(beta), eps,
-                                                          int(relu), _ptr(gs), _ptr(dgamma_acc), _ptr(dbeta_acc), _stream()),
+                                                          int(relu), _ptr(gs), _ptr(dgamma_acc), _ptr(dbeta_acc),
+                                                          int(ws is not None), _stream()),
                    'das_groupnorm_backward_acc')
         return dx, None, None
     acc = torch.empty(ngs + 2 * Cc, dtype=torch.float32, device=xd.device)
@@ -1000,16 +1042,29 @@ def upsample_nearest_backward(dy, Hb, Wb):
     return db
 
 
-def groupnorm(x, gamma, beta, G, eps=1e-5, relu=True, out=None, return_stats=False):
-    """In/out NHWC or Ragged (may be channel-slice views with a pixel stride); default in place."""
+def groupnorm_stats_size(x, G):
+    """f32 values of a GroupNorm call's statistics workspace (sum, sum of squares per level, image and group)"""
+    lv = _levels(x)
+    return lv.num_levels * lv.B * G * 2
+
+
+def groupnorm(x, gamma, beta, G, eps=1e-5, relu=True, out=None, return_stats=False, ws=None):
+    """In/out NHWC or Ragged (may be channel-slice views with a pixel stride); default in place.
+    ws: a ZEROED f32 buffer of groupnorm_stats_size values for the statistics (a slice of a buffer the caller fills once for
+    many layers); it is what return_stats hands back, so it must live as long as the backward needs it."""
     _need_gpu(x)
     out = x if out is None else out
     xd, od = _data(x), _data(out)
     lv = _levels(x)
-    ws = torch.empty(lv.num_levels * lv.B * G * 2, dtype=torch.float32, device=xd.device)
+    n = lv.num_levels * lv.B * G * 2
+    zeroed = ws is not None
+    if zeroed:
+        assert ws.dtype == torch.float32 and ws.numel() == n and ws.is_contiguous()
+    else:
+        ws = torch.empty(n, dtype=torch.float32, device=xd.device)
     assert _ps(out) == _ps(x)
     _lib.check(_lib.load().das_groupnorm_nhwc(_ptr(xd), _ptr(od), _DT[xd.dtype], C.byref(lv), xd.shape[-1], _ps(x), G,
-                                              _ptr(gamma), _ptr(beta), eps, int(relu), _ptr(ws), _stream()),
+                                              _ptr(gamma), _ptr(beta), eps, int(relu), _ptr(ws), int(zeroed), _stream()),
                'das_groupnorm_nhwc')
     return (out, ws) if return_stats else out
 

@@ -28,17 +28,28 @@ def _is_bias_param(name, module_of):
     return True
 
 
+# zero padding of odd channel counts inside the flat storage (FlatSGD docstring); switch for A/B runs (tools/dev/ab_launches.py)
+PAD_ODD_CHANNELS = True
+
+
 class _Slot:
     """Where one parameter lives in the flat buffers (attached to the parameter as `_das_slot`)."""
-    __slots__ = ('opt', 'off', 'numel', 'bucket', 'cl_shape', 'grad_cl', 'packable', 'index', 's2_pad')
+    __slots__ = ('opt', 'off', 'numel', 'span', 'o_pad', 'bucket', 'cl_shape', 'grad_cl', 'packable', 'index', 's2_pad')
 
     def fired(self):
         """Tell the optimizer that this parameter's gradient of the current backward is complete."""
         self.opt._fired(self)
 
     def direct(self, cin, cout):
-        """True if a (cout, KH, KW, cin) weight-gradient kernel can add straight into the flat gradient."""
-        return self.cl_shape is not None and self.cl_shape[0] == cout and self.cl_shape[3] == cin
+        """True if a weight-gradient kernel over (cout, cin)-channel operands can add straight into the flat gradient: cout
+        is the gradient tensor's width, i.e. the layer's output channels or their padding to a multiple of 8 (o_pad: the
+        kernel then stores the rows that exist, ops.conv2d_wgrad takes the row count from `out`)."""
+        return self.cl_shape is not None and cout in (self.cl_shape[0], self.o_pad) and self.cl_shape[3] == cin
+
+    def padded(self):
+        """A 1-D parameter with its zero padding to a multiple of 8 elements: f32 view of the flat buffer (what the kernels
+        read per-channel constants from, in vectors of 8)."""
+        return self.opt.flat_p[self.off:self.off + self.span]
 
     def packed(self, dtype, dgrad=False):
         return self.opt._packed_view(self, dtype, dgrad)
@@ -51,6 +62,12 @@ class FlatSGD:
     that is the forward kernels' operand layout and the weight-gradient kernels' output layout, so backward
     adds straight into the flat gradient and one launch per step packs the bf16 / data-gradient copies of
     every layer (`das_pack_conv_weights`).
+    A weight whose output channels are not a multiple of 8 (the head's predictors: 45 / 27 / 2 / 1 channels) is followed by
+    zero rows up to the next multiple, and a 1-D parameter by zeros up to a multiple of 8 elements: parameters, gradients
+    and momentum of the padding are zero and stay zero (zero gradient, weight decay of zero), the parameter itself is a
+    view of the rows that exist — and the padded block IS the operand the kernels want (8-channel vectors), so these
+    layers take the one packing launch and the direct weight-gradient path like every other (before: a pack, a bias pad,
+    a data-gradient pack, a fill and two gradient adds per layer and step).
 
     Data parallel: gradients are all-reduced in param-aligned buckets of >= bucket_mb, launched on a side
     stream DURING backward as soon as a bucket's gradients are complete (hooks count completions; the
@@ -79,20 +96,25 @@ class FlatSGD:
             for n, p in groups[key]:
                 if p.dim() == 4:
                     off = (off + 63) // 64 * 64
-                plan.append((n, p, off))
-                off += p.numel()
+                    O, I, KH, KW = p.shape
+                    span = ((O + 7) // 8 * 8 if (I % 8 == 0 and PAD_ODD_CHANNELS) else O) * I * KH * KW
+                else:
+                    off = (off + 7) // 8 * 8
+                    span = (p.numel() + 7) // 8 * 8 if PAD_ODD_CHANNELS else p.numel()
+                plan.append((n, p, off, span))
+                off += span
             bounds[key] = (start, off)
         total = off
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.slots, self._conv_slots = [], []
-        self._params, self._names = [p for _, p, _ in plan], [n for n, _, _ in plan]
-        for n, p, o in plan:
+        self._params, self._names = [p for _, p, _, _ in plan], [n for n, _, _, _ in plan]
+        for n, p, o, span in plan:
             k = p.numel()
             sl = _Slot()
             sl.opt, sl.off, sl.numel, sl.bucket, sl.cl_shape, sl.grad_cl, sl.packable = self, o, k, 0, None, None, False
-            sl.s2_pad = -1
+            sl.s2_pad, sl.span, sl.o_pad = -1, span, 0
             if p.dim() == 4:
                 O, I, KH, KW = p.shape
                 vp = self.flat_p[o:o + k].view(O, KH, KW, I)
@@ -101,7 +123,8 @@ class FlatSGD:
                 sl.grad_cl = self.flat_g[o:o + k].view(O, KH, KW, I)
                 p.grad = sl.grad_cl.permute(0, 3, 1, 2)
                 sl.cl_shape = (O, KH, KW, I)
-                sl.packable = O % 8 == 0 and I % 8 == 0
+                sl.o_pad = span // (KH * KW * I)
+                sl.packable = I % 8 == 0 and sl.o_pad % 8 == 0    # (output channels: padded by the storage itself)
                 if sl.packable:
                     self._conv_slots.append(sl)
                     mod = module_of.get(n)
@@ -131,7 +154,7 @@ class FlatSGD:
         self.buckets, bstart = [], 0
         for i, sl in enumerate(self.slots):
             sl.bucket = len(self.buckets)
-            end = sl.off + sl.numel
+            end = sl.off + sl.span
             if end - bstart >= n_bucket or i == len(self.slots) - 1:
                 self.buckets.append((bstart, total if i == len(self.slots) - 1 else end))
                 bstart = end
@@ -177,7 +200,8 @@ class FlatSGD:
         tab = np.zeros(len(self._conv_slots), dtype=dt)
         tiles = 0
         for i, sl in enumerate(self._conv_slots):
-            O, KH, KW, I = sl.cl_shape
+            _, KH, KW, I = sl.cl_shape
+            O = sl.o_pad
             tab[i] = (sl.off, O, I, KH, KW, tiles, sl.s2_pad)
             tiles += KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
         self._has_s2 = any(sl.s2_pad >= 0 for sl in self._conv_slots)
@@ -199,7 +223,8 @@ class FlatSGD:
             ops.pack_conv_weights(self.flat_p, self._fwd.get(dtype), self._dgrad[dtype], self._table,
                                   len(self._conv_slots), self._tiles, dgrad_s2_dst=self._dgrad_s2.get(dtype))
             self._packed_epoch[dtype] = PARAM_EPOCH[0]
-        O, KH, KW, I = sl.cl_shape
+        _, KH, KW, I = sl.cl_shape
+        O = sl.o_pad         # (the rows of the stored block: the layer's output channels and their zero padding)
         if dgrad == 's2':
             # the stride-2 data gradient's operands by output parity: {(ph, pw): (I, nth, ntw, O)} (ops.dgrad_s2_weights)
             out, o = {}, sl.off
@@ -211,9 +236,9 @@ class FlatSGD:
                         o += I * nh * nw * O
             return out
         if dgrad:
-            return self._dgrad[dtype][sl.off:sl.off + sl.numel].view(I, KH, KW, O)
+            return self._dgrad[dtype][sl.off:sl.off + sl.span].view(I, KH, KW, O)
         src = self.flat_p if dtype == torch.float32 else self._fwd[dtype]
-        return src[sl.off:sl.off + sl.numel].view(O, KH, KW, I)
+        return src[sl.off:sl.off + sl.span].view(O, KH, KW, I)
 
     # ------------------------------------------------------------------ gradients
     def _param_signature(self):

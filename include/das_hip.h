@@ -256,10 +256,12 @@ int das_groupnorm_backward(const void* dy, const void* y, const void* x, void* d
                            int C, int pix_stride, int G, const float* fwd_stats, const float* gamma, const float* beta,
                            float eps, int relu, float* gsums_ws, float* dgamma, float* dbeta, void* stream);
 /* The same with dgamma / dbeta ACCUMULATED into (parameter-gradient slices of the optimizer's flat buffer); only
- * gsums_ws is zeroed by the call. */
+ * gsums_ws is zeroed by the call — unless ws_zeroed says the caller hands it over zeroed (a slice of a buffer it fills
+ * once for many layers: a fill is a launch of its own, 28 of them per training step before). */
 int das_groupnorm_backward_acc(const void* dy, const void* y, const void* x, void* dx, int dtype, const DasLevels* lv,
                                int C, int pix_stride, int G, const float* fwd_stats, const float* gamma, const float* beta,
-                               float eps, int relu, float* gsums_ws, float* dgamma, float* dbeta, void* stream);
+                               float eps, int relu, float* gsums_ws, float* dgamma, float* dbeta, int ws_zeroed,
+                               void* stream);
 /* Backward of das_maxpool3x3s2 (gradient goes to the first maximum in scan order, as torch does),
  * das_upsample_bilinear_ac and the upsampled operand of das_add_upsample_nearest. */
 int das_maxpool3x3s2_backward(const void* x, const void* dy, void* dx, int dtype, int B, int H, int W, int C,
@@ -369,6 +371,22 @@ int das_bn_train_apply(const void* x, void* y, int dtype, long long count, int C
                        float momentum, float eps, const void* residual, int relu, float* save_mean,
                        float* save_invstd, long long* num_batches_tracked, long long stat_count, int stats_slots,
                        void* relu_bits_out, void* stream);
+/* das_bn_train_apply with y == NULL (finalize only) for up to four layers in ONE launch: the layers whose statistics are
+ * complete at the same point of the forward and whose normalisation is left to one fused consumer (a projection shortcut
+ * and its conv3 under das_bn_dual_apply; the two 1x1 convs of an upsample unit under das_upmerge_forward). Same fold
+ * order and arithmetic per layer as the single call. count = the population behind `stats` (all ranks' rows for SyncBN). */
+typedef struct {
+  const float* stats;
+  int stats_slots, C;
+  long long count;
+  float* running_mean;
+  float* running_var;
+  float momentum, eps;
+  float* save_mean;
+  float* save_invstd;
+  long long* num_batches_tracked;
+} DasBnFinalize;
+int das_bn_finalize_many(const DasBnFinalize* layers, int n, void* stream);
 
 /* Ragged multi-level pixel rows. The DASHead shares its weights across FPN levels
  * (das_head.py:176-178 `multi_apply(self.forward_single, feats, ...)`), so the head ops below take
@@ -387,9 +405,10 @@ int das_dcn3x3_fused(const void* x, const float* om, const void* w, const float*
                      const DasLevels* lv, int C, int Cout, int x_pix_stride, int om_pix_stride, int y_pix_stride, void* stream);
 
 /* GroupNorm (+ReLU) over NHWC rows (torch GroupNorm, das_head.py:54, recursive_update.py:178,244);
- * statistics per (level, image, group). stats workspace: f32[num_levels*B*G*2], zeroed by the call. */
+ * statistics per (level, image, group). stats workspace: f32[num_levels*B*G*2], zeroed by the call unless
+ * ws_zeroed (the caller hands it over zeroed: see das_groupnorm_backward_acc). */
 int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLevels* lv, int C, int pix_stride, int G,
-                       const float* gamma, const float* beta, float eps, int relu, float* stats_ws,
+                       const float* gamma, const float* beta, float eps, int relu, float* stats_ws, int ws_zeroed,
                        void* stream);
 
 /* DCNv2 deformable im2col (mmcv ModulatedDeformConv2dPack.forward -> modulated_deform_conv2d,

@@ -134,6 +134,45 @@ def test_dgrad_epilogue_reduces_bn_backward(case, dtype):
     np.testing.assert_allclose(nchw(draw).numpy(), q(ref, dtype).numpy(), **(tol if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)))
 
 
+@pytest.mark.parametrize('case', [(3, 91, 93, 128, 512, False), (2, 91, 93, 64, 256, False), (2, 91, 93, 256, 1024, False),
+                                  (4, 128, 208, 64, 128, True), (2, 91, 93, 256, 64, True), (16, 32, 52, 256, 1024, True)])
+def test_stream_kernel_mask_bits_pipeline_equals_the_y_mask_path(case):
+    """conv1x1_stream_kernel's mask-as-bits variant requests a half tile's epilogue operands one unit ahead into alternating
+    register sets (counted waits); without a residual the residual's loads are stand-ins. Against the y-mask variant
+    (operands requested and waited for per block) on the same launch: dZ bit-identical, sums equal up to the order of the
+    float atomics — with and without a residual (plain and masked by bits), every wave arrangement (Cout 64 / 128 / 256+),
+    one to seven tiles per workgroup."""
+    from das_amd import ops as o
+    B, H, W, Cin, Cout, with_res = case
+    dtype = torch.bfloat16
+    dy = nhwc(cases.randn(301, B, Cin, H, W), dtype)
+    w = o.pack_weight((cases.randn(302, Cout, Cin, 1, 1) / Cin ** 0.5).to(DEV), dtype)
+    raw = nhwc(cases.randn(303, B, Cout, H, W) * 1.5 + 0.3, dtype)
+    yd = nhwc(torch.relu(cases.randn(304, B, Cout, H, W)), dtype)
+    res = nhwc(cases.randn(305, B, Cout, H, W), dtype) if with_res else None
+    mean, invstd = (cases.randn(306, Cout) * 0.1).to(DEV), (cases.randn(307, Cout).abs() + 0.5).to(DEV)
+    gamma, beta = (cases.randn(308, Cout).abs() + 0.5).to(DEV), (cases.randn(309, Cout) * 0.2).to(DEV)
+    wts = (2 ** torch.arange(8, device=DEV)).to(torch.int32)
+    bits = ((yd.reshape(-1, 8) > 0).to(torch.int32) * wts).sum(1).to(torch.uint8)
+    rows = B * H * W
+    outs = []
+    for bnb in (o.BnBwd(raw, yd, mean, invstd, gamma, beta, True), o.BnBwd(raw, None, mean, invstd, gamma, beta, True, bits=bits)):
+        sums = torch.zeros(4 * 2 * Cout, device=DEV)
+        dz = o.conv2d(dy, w, 1, 1, 1, 0, residual=res, bn_bwd=bnb, stats=sums)
+        assert o.last_kernel() == 'conv1x1_stream_kernel', o.last_kernel()
+        outs.append((dz, sums.view(4, -1).sum(0).cpu().numpy() / rows))
+    assert torch.equal(outs[0][0], outs[1][0])
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-6)
+    assert 0.2 < float((outs[1][0] == 0).float().mean()) < 0.8
+    if with_res:      # the residual masked by its own recorded bits
+        keep = torch.rand(res.numel(), device=DEV, generator=torch.Generator(device=DEV).manual_seed(7)).reshape(res.shape) > 0.4
+        rbits = (keep.reshape(-1, 8).to(torch.int32) * wts).sum(1).to(torch.uint8)
+        bnb = o.BnBwd(raw, None, mean, invstd, gamma, beta, True, bits=bits)
+        a = o.conv2d(dy, w, 1, 1, 1, 0, residual=(res * keep).contiguous(), bn_bwd=bnb, stats=torch.zeros(2 * Cout, device=DEV))
+        b = o.conv2d(dy, w, 1, 1, 1, 0, residual=(res, rbits), bn_bwd=bnb, stats=torch.zeros(2 * Cout, device=DEV))
+        assert torch.equal(a, b)
+
+
 def _mspn_grads(dtype, fused, flat=False, blocks=(2, 2, 2, 2), stages=2):
     import das_amd
     from das_amd import backbones

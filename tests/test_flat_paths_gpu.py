@@ -31,6 +31,34 @@ def test_wgrad_accumulates_into_existing_buffer(dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', [(45, 1, 256, 0), (27, 3, 64, 1), (1, 1, 256, 0), (2, 1, 64, 0), (267, 1, 256, 0)])
+def test_wgrad_and_bias_gradient_of_a_layer_whose_channels_are_not_a_multiple_of_8(dtype, case):
+    """The head's predictors have 45 / 27 / 2 / 1 output channels: their gradient tensors are padded to a multiple of 8
+    columns, the flat optimizer stores the rows that exist. The weight-gradient kernels take the row count from `out` and
+    store no others (the guard value behind the buffer stays), colsum sums the columns that exist; both ADD."""
+    from das_amd import ops as o
+    Cout, k, Cin, pad = case
+    Cp = (Cout + 7) // 8 * 8
+    B, H, W = 2, 24, 20
+    x = nhwc(cases.randn(31, B, Cin, H, W), dtype)
+    dy = nhwc(cases.randn(32, B, Cp, H, W), dtype)       # (the padding columns hold values: they must not leak)
+    ref = o.conv2d_wgrad(x, dy, k, k, 1, pad)            # (Cp, k, k, Cin)
+    buf = torch.full((Cout * k * k * Cin + 64,), 0.25, dtype=torch.float32, device=DEV)
+    out = buf[:Cout * k * k * Cin].view(Cout, k, k, Cin)
+    o.conv2d_wgrad(x, dy, k, k, 1, pad, out=out, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref[:Cout].cpu().numpy() + 0.25, rtol=1e-5, atol=2e-4)
+    assert bool((buf[Cout * k * k * Cin:] == 0.25).all())
+    out2 = torch.full_like(out, 0.5)
+    o.conv2d_wgrad_batch([(x, dy, k, k, 1, pad, out2)])
+    np.testing.assert_allclose(out2.cpu().numpy(), ref[:Cout].cpu().numpy() + 0.5, rtol=1e-5, atol=2e-4)
+    bias = torch.full((Cout + 8,), 2.0, device=DEV)
+    o.colsum(dy, acc=bias[:Cout])
+    want = dy.float().sum((0, 1, 2))[:Cout] + 2.0
+    np.testing.assert_allclose(bias[:Cout].cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-3)
+    assert bool((bias[Cout:] == 2.0).all())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_pack_conv_weights_one_launch(dtype):
     """Flat (O,KH,KW,I) master -> forward cast + flipped/transposed data-gradient weights for a table of tensors."""
     from das_amd import ops as o
@@ -148,6 +176,14 @@ def test_flat_optimizer_gradients_equal_autograd_gradients():
     # running statistics moved identically
     for (n, b), c in zip(plain.named_buffers(), flat.buffers()):
         torch.testing.assert_close(b, c, rtol=1e-5, atol=1e-6)
+    # the layers whose channel counts are not multiples of 8 took the direct paths too, and the zero padding their flat
+    # storage carries received no gradient; an optimizer step leaves it zero
+    odd = [sl for sl in opt.slots if sl.span != sl.numel]
+    assert len(odd) >= 8 and any(sl.cl_shape is not None and sl.packable for sl in odd)
+    opt.step(1e-3)
+    for sl in odd:
+        for buf in (opt.flat_g, opt.flat_p, opt.flat_m):
+            assert float(buf[sl.off + sl.numel:sl.off + sl.span].abs().max()) == 0.0
 
 
 def test_wgrad_side_stream_equals_main_stream():
