@@ -1175,104 +1175,6 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
       }
     }
     int st = 0;
-#ifndef DAS_STREAM_PIPE6
-#define DAS_STREAM_PIPE6 1
-#endif
-    if constexpr (MODE == 6 && PB >= 2 && DAS_STREAM_PIPE6) {
-      // The mask-as-bits variant, software-pipelined over HALF tiles: a tile is two units of PB / 2 pixel blocks, each with
-      // its own register set for the epilogue operands (raw, the residual, their two mask bytes); a unit REQUESTS the next
-      // unit's operands into the other set, multiplies, and waits with a counted vmcnt: loads return in order, so "at
-      // most NL operations outstanding" right after NL newer loads were issued proves this unit's set has landed,
-      // whatever the stores do (the scheme of MODE 2's residual rows). The operands of a unit are in flight for a
-      // whole unit instead of the few hundred cycles of its own MFMAs: the small-M launches (three to seven tiles per
-      // workgroup, nothing else to hide a round trip behind) ran at 3.0-4.1 TB/s against MODE 2's 5.0-5.8.
-      // The load count per unit is constant: without a residual its two loads re-request the raw row / its mask byte
-      // (the same cache lines), and the unit after the last re-requests the last.
-      constexpr int UB = PB / 2, NL = 4 * UB;
-      v4i_t ax[UB], ar[UB], cx[UB], cr[UB];
-      int ab[UB], arb[UB], cb[UB], crb[UB];
-      const unsigned char* bb = p.bnb_bits;
-      auto request = [&](int t, int h0, v4i_t (&sx_)[UB], v4i_t (&sr)[UB], int (&sb)[UB], int (&srb)[UB]) {
-#pragma unroll
-        for (int h = 0; h < UB; ++h) {
-          long long m = (long long)t * TM + wm * (TM / WM) + (h0 + h) * 16 + q;
-          m = m < p.M ? m : p.M - 1;
-          const long long eo = m * p.bnb_ps + (cok ? c8 : 0), ro = m * p.rps + (cok ? c8 : 0);
-          const T* rp = rgb ? rgb + ro : bx + eo;
-          const unsigned char* rbp = rb ? rb + ro / 8 : bb + eo / 8;
-          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sx_[h]) : "v"(bx + eo) : "memory");
-          asm volatile("global_load_ubyte %0, %1, off" : "=v"(sb[h]) : "v"(bb + eo / 8) : "memory");
-          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sr[h]) : "v"(rp) : "memory");
-          asm volatile("global_load_ubyte %0, %1, off" : "=v"(srb[h]) : "v"(rbp) : "memory");
-        }
-      };
-      auto unit = [&](int t, int h0, const char* sx, v4i_t (&ux)[UB], v4i_t (&ur)[UB], int (&ub)[UB], int (&urb)[UB]) {
-#pragma unroll
-        for (int h = 0; h < UB; ++h) {
-          const int row = wm * (TM / WM) + (h0 + h) * 16 + q;
-          f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kb = 0; kb < KB; ++kb) {
-            const int slot = ((kb & 1) * 4 + g4) ^ ((row >> 1) & 7);
-            const uint4 bf = *reinterpret_cast<const uint4*>(sx + (kb >> 1) * SUBB + row * 128 + slot * 16);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[0][kb]),
-                                                           __builtin_bit_cast(bf16x8_t, bf), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[1][kb]),
-                                                           __builtin_bit_cast(bf16x8_t, bf), acc1, 0, 0, 0);
-          }
-          if (h == 0) {   // (the operands name the destination registers: they stay allocated until here)
-#pragma unroll
-            for (int i = 0; i < UB; ++i)
-              asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ux[i]), "+v"(ur[i]), "+v"(ub[i]), "+v"(urb[i]) : "n"(NL) : "memory");
-          }
-          const long long m = (long long)t * TM + row;
-          if (m < p.M && cok) {
-            float v[8], x[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = acc0[j]; v[4 + j] = acc1[j]; }
-            uint4 o = Elem<T>::pack(v);
-            Elem<T>::unpack(o, v);   // the conv result as a tile kernel would have staged it (bf16)
-            if (rgb) {
-              float r[8];
-              Elem<T>::unpack(__builtin_bit_cast(uint4, ur[h]), r);
-              if (rb) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = ((unsigned)urb[h] >> j & 1u) ? r[j] : 0.f;
-              }
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] += r[j];
-            }
-            Elem<T>::unpack(__builtin_bit_cast(uint4, ux[h]), x);
-            float yo[8];
-            Elem<T>::unpack(mask_vec<T>((unsigned)ub[h]), yo);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = yo[j] > 0.f ? v[j] : 0.f;
-            o = Elem<T>::pack(v);
-            Elem<T>::unpack(o, v);   // dZ as stored
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * x[j]; }   // (sum dZ * raw: centred below)
-            *reinterpret_cast<uint4*>(yg + m * p.yps + c8) = o;
-          }
-        }
-      };
-      if (first < ntiles) request(first, 0, ax, ar, ab, arb);
-      for (int t = first; t < ntiles; t += tstride) {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();    // the loader waves saw tile t land
-        asm volatile("" ::: "memory");
-        const char* sx = smem + st * STAGE;
-        request(t, UB, cx, cr, cb, crb);
-        unit(t, 0, sx, ax, ar, ab, arb);
-        request(t + tstride < ntiles ? t + tstride : t, 0, ax, ar, ab, arb);
-        unit(t, UB, sx, cx, cr, cb, crb);
-        st = (st + 1) % NS;
-      }
-      if (first < ntiles) {   // the trailing request: its destination registers stay allocated until it has landed
-#pragma unroll
-        for (int i = 0; i < UB; ++i)
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax[i]), "+v"(ar[i]), "+v"(ab[i]), "+v"(arb[i])::"memory");
-      }
-    } else
     for (int t = first; t < ntiles; t += tstride) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();    // the loader waves saw tile t land

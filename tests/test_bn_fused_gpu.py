@@ -137,9 +137,8 @@ def test_dgrad_epilogue_reduces_bn_backward(case, dtype):
 @pytest.mark.parametrize('case', [(3, 91, 93, 128, 512, False), (2, 91, 93, 64, 256, False), (2, 91, 93, 256, 1024, False),
                                   (4, 128, 208, 64, 128, True), (2, 91, 93, 256, 64, True), (16, 32, 52, 256, 1024, True)])
 def test_stream_kernel_mask_bits_pipeline_equals_the_y_mask_path(case):
-    """conv1x1_stream_kernel's mask-as-bits variant requests a half tile's epilogue operands one unit ahead into alternating
-    register sets (counted waits); without a residual the residual's loads are stand-ins. Against the y-mask variant
-    (operands requested and waited for per block) on the same launch: dZ bit-identical, sums equal up to the order of the
+    """conv1x1_stream_kernel's mask-as-bits variant (MODE 6: all pixel blocks of a tile requested at once) against the
+    y-mask variant (MODE 3: two blocks at a time) on the same launch: dZ bit-identical, sums equal up to the order of the
     float atomics — with and without a residual (plain and masked by bits), every wave arrangement (Cout 64 / 128 / 256+),
     one to seven tiles per workgroup."""
     from das_amd import ops as o
