@@ -165,7 +165,8 @@ int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d,
  * y_pix_stride = pixel stride of dy, ragged levels allowed). accumulate = 0: dw is zeroed by the call;
  * accumulate = 1: the result is added to dw (the optimizer's flat gradient buffer holds conv weights in
  * exactly this layout, so backward adds straight into it — what autograd's AccumulateGrad does in the
- * reference).
+ * reference). Cin % 8 == 0. Cout may be any count as long as y_pix_stride is a multiple of 8 and at least Cout rounded up to
+ * one (a layer with 45 output channels whose gradient tensor has 48 columns): the rows below Cout are stored, no others.
  */
 int das_conv2d_wgrad_nhwc(const void* x, const void* dy, float* dw, const DasConvDesc* d, int accumulate,
                           void* stream);
@@ -185,7 +186,8 @@ int das_conv2d_wgrad_batch(int n, const void* const* xs, const void* const* dys,
  * reduced tiles, longest unit list of a workgroup, reduce groups; out[8] = schedules built by this process so far (a
  * steady training loop stops adding to it: schedules are cached per op list). */
 int das_wgrad_last_plan(long long* out, int n);
-/* out f32[C] (zeroed by the call) = column sums of x (rows, C) — bias gradients. */
+/* out f32[C] (zeroed by the call) = column sums of x (rows, C) — bias gradients. C need not be a multiple of 8 when pix_stride
+ * is one and at least C rounded up to one (the padding columns are not summed). das_colsum_acc: added to out instead. */
 int das_colsum(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream);
 /* The same sums ADDED to out (the optimizer's flat gradient slice of a bias: no temporary, no fill, no separate add). */
 int das_colsum_acc(const void* x, int dtype, long long rows, int C, int pix_stride, float* out, void* stream);
