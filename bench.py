@@ -883,11 +883,19 @@ def main():
     gc.freeze()
     gc.disable()
     sync_all()
+    # (one event behind every timed step: the spread of the steps inside the timed region goes into the line beside their mean)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         res = step()
+        marks[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
+    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    extra['timed_steps_ms'] = dict(min=round(per[0], 3), median=round(per[len(per) // 2], 3), max=round(per[-1], 3),
+                                   note='GPU time between the ends of consecutive timed steps (events on the launch stream); '
+                                        'ms_per_step is the wall clock of the whole region / steps')
     if graphs is not None:     # the per-launch measurement passes below need every launch queued by hand
         model._graphed_trunk = None
     if world > 1:
