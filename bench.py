@@ -425,9 +425,16 @@ def roofline_from_profile(ops, run_step, dtype, ms_per_step=None, reps=PRICED_RE
                 bad.append(f'families {fam_sum:.2f} ms > {PRICED_FIT} x pass step {wall_ms:.2f} ms')
             if ms_per_step is not None and wall_ms > PRICED_PASS_OVER_STEP * ms_per_step:
                 bad.append(f'pass step {wall_ms:.2f} ms > {PRICED_PASS_OVER_STEP} x timed step {ms_per_step:.2f} ms')
-            if not bad or attempts > PRICED_RETRIES:
+            # several ranks: every pass is a sequence of collectives (the steps' gradient all-reduces), so the ranks must agree
+            # on whether another one runs — any rank's failed self-check repeats the pass on all of them
+            again = bool(bad) and attempts <= PRICED_RETRIES
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                flag = torch.tensor([1.0 if again else 0.0], device='cuda')
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                again = bool(flag.item() > 0) and attempts <= PRICED_RETRIES
+            if not again:
                 break
-            problems.append('; '.join(bad))
+            problems.append('; '.join(bad) if bad else 'repeated with the other ranks')
     finally:
         ag.WGRAD_SIDE_STREAM = side_was
     unreliable = bool(bad)
