@@ -899,8 +899,10 @@ def main():
         marks[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
-    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    series = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    per = sorted(series)
     extra['timed_steps_ms'] = dict(min=round(per[0], 3), median=round(per[len(per) // 2], 3), max=round(per[-1], 3),
+                                   in_order=[round(x, 2) for x in series[:64]],
                                    note='GPU time between the ends of consecutive timed steps (events on the launch stream); '
                                         'ms_per_step is the wall clock of the whole region / steps')
     if graphs is not None:     # the per-launch measurement passes below need every launch queued by hand

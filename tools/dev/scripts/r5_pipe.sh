@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a negative result, profiles/r05_negative_results.txt: the DAS_STREAM_PIPE6 code path this compared was removed again)
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 O=gpurun_out/r5
