@@ -288,6 +288,7 @@ OTHER_C = {
     'das_grad_sumsq': ('optimizer (weight packing, clip norm, SGD)', (1, 4)),
     'das_sgd_momentum_step': ('optimizer (weight packing, clip norm, SGD)', (3, 20)),      # p, g, m read; p, m written
     'das_assign_targets': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
+    'das_positive_rows': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
     'das_sigmoid_focal_loss': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
     'das_smooth_l1_loss': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),
     'das_bce_logits_loss': ('losses (targets, focal / L1 / BCE, RealNVP, RLE)', None),

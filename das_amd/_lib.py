@@ -147,7 +147,9 @@ SIGNATURES = {
                                          i32, vp]),
     'das_sigmoid_blend_backward': (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     'das_head_assemble_backward': (i32, [vp, vp, vp, vp, vp, C.POINTER(DasLevels), C.POINTER(DasHeadDesc), vp]),
-    'das_assign_targets': (i32, [C.POINTER(DasLevels), C.POINTER(DasTargetDesc), vp, vp, vp, vp, vp, vp, vp]),
+    'das_assign_targets': (i32, [C.POINTER(DasLevels), C.POINTER(DasTargetDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+    'das_positive_rows': (i32, [vp, i32, vp, vp, C.POINTER(DasLevels), C.POINTER(DasTargetDesc), f32, f32, f32, vp, vp, vp, vp,
+                                vp, vp, vp, vp]),
     'das_sigmoid_focal_loss': (i32, [vp, i32, vp, vp, i64, f32, f32, vp, vp, vp]),
     'das_smooth_l1_loss': (i32, [vp, vp, vp, i64, f32, vp, vp, vp]),
     'das_bce_logits_loss': (i32, [vp, vp, vp, i64, vp, vp, vp]),

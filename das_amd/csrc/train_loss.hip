@@ -33,9 +33,12 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 __global__ void assign_targets_kernel(DasLevels lv, DasTargetDesc d, const float* __restrict__ gt,
                                       const float* __restrict__ centers,
                                       const int* __restrict__ gt_start, int* __restrict__ labels,
-                                      float* __restrict__ targets, float* __restrict__ ctr_t, long long rows) {
+                                      float* __restrict__ targets, float* __restrict__ ctr_t, long long rows,
+                                      float* __restrict__ counts) {
 #pragma clang fp contract(off)
+  __shared__ float sh[TPB / 64];
   const int J = d.J, D = 3 + 4 * J;
+  float n_pos = 0.f, n_3d = 0.f, n_vis = 0.f;   // (counts: positives, positives with a depth annotation, their visible joints)
   for (long long m = (long long)blockIdx.x * TPB + threadIdx.x; m < rows; m += (long long)gridDim.x * TPB) {
     const LvGeom g = lv_geom(lv, m);
     const int s = d.stride[g.l];
@@ -81,6 +84,93 @@ __global__ void assign_targets_kernel(DasLevels lv, DasTargetDesc d, const float
       o[3 + 3 * J + j] = p[3 + 3 * J + j];
     }
     ctr_t[m] = expf(-d.alpha * (sqrtf(dx * dx + dy * dy) / (1.414f * rad)));
+    if (counts && best != 1e8f) {
+      bool any_z = false;
+      float v = 0.f;
+      for (int j = 0; j < J; ++j) { any_z = any_z || p[5 + 3 * j] != 0.f; v += p[3 + 3 * J + j]; }
+      n_pos += 1.f; n_3d += any_z ? 1.f : 0.f; n_vis += v;
+    }
+  }
+  if (counts) {   // (block-uniform)
+    const float a = block_sum(n_pos, sh), b = block_sum(n_3d, sh), c = block_sum(n_vis, sh);
+    if (threadIdx.x == 0 && a != 0.f) { atomicAdd(counts, a); atomicAdd(counts + 1, b); atomicAdd(counts + 2, c); }
+  }
+}
+
+// ------------------------------------------------------------------ the positives' rows of the pose losses
+// What DASHead.loss derives from the ground truth for its positive locations (das_head.py:385-409), for `npos` rows listed in
+// ascending order in `pos`: the pixel-to-joint targets (image offsets in units of the level's stride, depth in units of z_norm),
+// the visibilities, the depth target, the centerness target, 2-D / 3-D kind, and the rank of every positive among the positives
+// of its kind (its block of J rows in the flows' input). Kind, rank and the visibility sum need the rows in order: ONE
+// workgroup walks them in chunks with a running count (a few thousand positives at most).
+__global__ __launch_bounds__(1024) void positives_rank_kernel(const int* __restrict__ pos, int npos, const float* __restrict__ targets,
+                                                              int J, int* __restrict__ is2d, int* __restrict__ slot,
+                                                              float* __restrict__ nvis, float nvis_scale) {
+  __shared__ int scan[1024];
+  __shared__ float fsum[16];
+  __shared__ int base2, base3;
+  const int tid = threadIdx.x, D = 3 + 4 * J;
+  if (tid == 0) { base2 = 0; base3 = 0; }
+  float vis = 0.f;
+  __syncthreads();
+  for (int i0 = 0; i0 < npos; i0 += 1024) {
+    const int i = i0 + tid;
+    int k2 = 0;
+    if (i < npos) {
+      const float* t = targets + (long long)pos[i] * D;
+      bool all0 = true;
+      for (int j = 0; j < J; ++j) { all0 = all0 && t[5 + 3 * j] == 0.f; vis += t[3 + 3 * J + j]; }
+      k2 = all0 ? 1 : 0;
+    }
+    scan[tid] = k2;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan of the 2-D flags of this chunk
+      const int v = tid >= off ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    if (i < npos) {
+      const int r2 = scan[tid];                     // 2-D positives up to and including this one, within the chunk
+      is2d[i] = k2;
+      slot[i] = k2 ? base2 + r2 - 1 : base3 + (tid + 1 - r2) - 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int n = min(1024, npos - i0), c2 = scan[n - 1];
+      base2 += c2; base3 += n - c2;
+    }
+    __syncthreads();
+  }
+  vis = wave_sum(vis);
+  if ((tid & 63) == 0) fsum[tid >> 6] = vis;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += fsum[w];
+    *nvis = t * nvis_scale;
+  }
+}
+__global__ void positives_rows_kernel(const int* __restrict__ pos, int npos, const float* __restrict__ targets,
+                                      const float* __restrict__ ctr_t, DasLevels lv, DasTargetDesc d, float z_norm,
+                                      float depth_factor, float* __restrict__ real, float* __restrict__ vis,
+                                      float* __restrict__ depth_t, float* __restrict__ ctr_pos) {
+#pragma clang fp contract(off)
+  const int J = d.J, D = 3 + 4 * J;
+  const float inv_z = 1.f / z_norm;
+  const long long n = (long long)npos * J;
+  for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < n; e += (long long)gridDim.x * TPB) {
+    const int i = (int)(e / J), j = (int)(e - (long long)i * J);
+    const long long m = pos[i];
+    const float* t = targets + m * D;
+    const float ps = (float)d.stride[lv_geom(lv, m).l];
+    // real = (gt_uvd - [root * stride, 0]) / [stride, stride, z_norm]: the reference's order of operations
+    const float rx = t[0] * ps, ry = t[1] * ps;
+    real[e * 3 + 0] = (t[3 + 3 * j] - rx) / ps;
+    real[e * 3 + 1] = (t[4 + 3 * j] - ry) / ps;
+    real[e * 3 + 2] = (t[5 + 3 * j] - 0.f) * inv_z;   // (torch divides a tensor by a host scalar as a product with its reciprocal)
+    vis[e] = t[3 + 3 * J + j];
+    if (j == 0) { depth_t[i] = t[2] * depth_factor; ctr_pos[i] = ctr_t[m]; }
   }
 }
 
@@ -189,12 +279,29 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 }  // namespace
 
 extern "C" int das_assign_targets(const DasLevels* lv, const DasTargetDesc* d, const float* gt, const float* centers,
-                                  const int* gt_start, int* labels, float* targets, float* centerness, void* stream) {
+                                  const int* gt_start, int* labels, float* targets, float* centerness, float* counts,
+                                  void* stream) {
   DAS_PROF(stream);
   if (!lv_valid(lv) || !d || !gt_start || !labels || !targets || !centerness || d->J < 1) return DAS_ERR_ARG;
   const long long rows = lv_total_rows(*lv);
   hipLaunchKernelGGL(assign_targets_kernel, dim3(grid_for(rows)), dim3(TPB), 0, (hipStream_t)stream, *lv, *d, gt,
-                     centers, gt_start, labels, targets, centerness, rows);
+                     centers, gt_start, labels, targets, centerness, rows, counts);
+  DAS_CHECK_LAUNCH();
+  return DAS_OK;
+}
+
+extern "C" int das_positive_rows(const int* pos, int npos, const float* targets, const float* centerness, const DasLevels* lv,
+                                 const DasTargetDesc* d, float z_norm, float depth_factor, float nvis_scale, float* real,
+                                 float* vis, int* is2d, int* slot, float* depth_t, float* ctr_pos, float* nvis, void* stream) {
+  DAS_PROF(stream);
+  if (!pos || npos < 1 || !targets || !centerness || !lv_valid(lv) || !d || d->J < 1 || !real || !vis || !is2d || !slot ||
+      !depth_t || !ctr_pos || !nvis)
+    return DAS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(positives_rank_kernel, dim3(1), dim3(1024), 0, s, pos, npos, targets, d->J, is2d, slot, nvis, nvis_scale);
+  DAS_CHECK_LAUNCH();
+  hipLaunchKernelGGL(positives_rows_kernel, dim3(grid_for((long long)npos * d->J)), dim3(TPB), 0, s, pos, npos, targets,
+                     centerness, *lv, *d, z_norm, depth_factor, real, vis, depth_t, ctr_pos);
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }

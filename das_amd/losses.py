@@ -156,6 +156,11 @@ def _pack_centers(centers2d, depths, n, device):
     return torch.cat([c, d], 1).contiguous()
 
 
+# the ground-truth half of DASHead.loss through das_assign_targets' counts + das_positive_rows (False: the ATen formulation it
+# replaces, kept as the cross-check of tests/test_loss_gpu.py); switch for A/B runs and tests
+FUSED_TARGETS = True
+
+
 def das_head_targets(head, B, sizes, device, gt_poses_3d, centers2d=None, depths=None):
     """Everything of DASHead.loss (das_head.py:283-478) that depends on the ground truth and the feature-map geometry
     only: target assignment, the positive rows, the 2-D / 3-D split, the RLE targets and weights, and the host-side
@@ -165,6 +170,27 @@ def das_head_targets(head, B, sizes, device, gt_poses_3d, centers2d=None, depths
     J = head.num_joints
     geom = Ragged(torch.empty(sum(B * h * w for h, w in sizes), 0, device=device), B, sizes)
     gt_rows, gt_start = _pack_gt(gt_poses_3d, device)
+    sets = 2 if head.prev_loss else 1
+    if FUSED_TARGETS and torch.device(device).type == 'cuda':
+        # counts out of the assignment kernel itself, the positives' rows from two launches (das_positive_rows): the mask /
+        # sum / gather / concatenate / cumsum formulation below is ~35 launches of 3-6 us at the head of a GPU-bound step
+        # (its own fill: this runs on the detector's side stream next to the backbone — the per-step zero arena belongs to the
+        # main stream's order, and with the host several steps ahead its wrap-around fill may not have RUN yet over there)
+        counts = torch.zeros(3, dtype=torch.float32, device=device)
+        labels, targets, ctr_t = T.assign_targets(geom, head.strides, head.regress_ranges, gt_rows, gt_start, J,
+                                                  head.center_sample_radius, head.centerness_alpha, head.background_label,
+                                                  centers=_pack_centers(centers2d, depths, gt_rows.shape[0], device),
+                                                  counts=counts)
+        prep = dict(B=B, sizes=[tuple(s) for s in sizes], labels=labels)
+        npos, n3d, vis_all = counts.tolist()
+        npos, n3d = int(npos), int(n3d)
+        prep.update(npos=npos, n3d=n3d, nvis_host=vis_all * sets)
+        if npos == 0:
+            return prep
+        pos = torch.nonzero_static(labels == 0, size=npos).reshape(-1)
+        prep.update(pos=pos, **T.positive_rows(geom, head.strides, head.regress_ranges, J, pos, targets, ctr_t, head.z_norm,
+                                               head.depth_factor, float(sets)))
+        return prep
     labels, targets, ctr_t = T.assign_targets(geom, head.strides, head.regress_ranges, gt_rows, gt_start, J,
                                               head.center_sample_radius, head.centerness_alpha, head.background_label,
                                               centers=_pack_centers(centers2d, depths, gt_rows.shape[0], device))

@@ -8,16 +8,41 @@ from . import _lib
 from .ops import Ragged, _levels, _need_gpu, _ptr, _stream
 
 
-def assign_targets(geom_like, strides, regress_ranges, gt_rows, gt_start, J, radius=1.5, alpha=2.5, background=1,
-                   centers=None):
-    """geom_like: a Ragged giving (B, level sizes). gt_rows (sum G, 3+4J) f32, gt_start (B+1,) int32, both on
-    the GPU; centers (sum G, 3) f32 = [centers2d, depths] or None (= gt_rows[:, :3]).
-    Returns labels int32 (rows,), targets f32 (rows, 3+4J), centerness f32 (rows,)."""
-    _need_gpu(gt_rows, gt_start)
-    lv = _levels(geom_like)
+def _target_desc(strides, regress_ranges, J, radius, alpha, background):
     d = _lib.DasTargetDesc(J=J, background=background, radius=radius, alpha=alpha)
     for l, (s, r) in enumerate(zip(strides, regress_ranges)):
         d.stride[l], d.range_lo[l], d.range_hi[l] = int(s), float(r[0]), float(r[1])
+    return d
+
+
+def positive_rows(geom_like, strides, regress_ranges, J, pos, targets, ctr_t, z_norm, depth_factor, nvis_scale):
+    """das_positive_rows: what the pose losses need of the ground truth for the positive rows `pos` (int64 / int32, ascending)
+    of assign_targets' outputs. Returns dict(real (n, J, 3), vis (n, J), is2d int32 (n), slot int32 (n), depth_t (n), ctr_t (n),
+    nvis 0-dim) — das_head.py:385-409."""
+    _need_gpu(pos, targets, ctr_t)
+    n, dev = pos.numel(), targets.device
+    lv = _levels(geom_like)
+    d = _target_desc(strides, regress_ranges, J, 0.0, 0.0, 1)
+    p32 = pos.to(torch.int32)
+    f = torch.empty(n * J * 4 + 2 * n + 1, dtype=torch.float32, device=dev)     # real | vis | depth_t | ctr | nvis in one buffer
+    real, vis = f[:n * J * 3].view(n, J, 3), f[n * J * 3:n * J * 4].view(n, J)
+    depth_t, ctr, nvis = f[n * J * 4:n * J * 4 + n], f[n * J * 4 + n:n * J * 4 + 2 * n], f[n * J * 4 + 2 * n:]
+    ii = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().das_positive_rows(_ptr(p32), n, _ptr(targets), _ptr(ctr_t), C.byref(lv), C.byref(d), float(z_norm),
+                                             float(depth_factor), float(nvis_scale), _ptr(real), _ptr(vis), _ptr(ii[:n]),
+                                             _ptr(ii[n:]), _ptr(depth_t), _ptr(ctr), _ptr(nvis), _stream()), 'das_positive_rows')
+    return dict(real=real, vis=vis, is2d=ii[:n], slot=ii[n:], depth_t=depth_t, ctr_t=ctr, nvis=nvis.reshape(()))
+
+
+def assign_targets(geom_like, strides, regress_ranges, gt_rows, gt_start, J, radius=1.5, alpha=2.5, background=1,
+                   centers=None, counts=None):
+    """geom_like: a Ragged giving (B, level sizes). gt_rows (sum G, 3+4J) f32, gt_start (B+1,) int32, both on
+    the GPU; centers (sum G, 3) f32 = [centers2d, depths] or None (= gt_rows[:, :3]).
+    Returns labels int32 (rows,), targets f32 (rows, 3+4J), centerness f32 (rows,). counts: a ZEROED f32[3] that receives
+    [positives, positives with a depth annotation, sum of the positives' joint visibilities]."""
+    _need_gpu(gt_rows, gt_start)
+    lv = _levels(geom_like)
+    d = _target_desc(strides, regress_ranges, J, radius, alpha, background)
     rows, dev = geom_like.rows, geom_like.device
     labels = torch.empty(rows, dtype=torch.int32, device=dev)
     targets = torch.empty(rows, 3 + 4 * J, dtype=torch.float32, device=dev)
@@ -27,8 +52,10 @@ def assign_targets(geom_like, strides, regress_ranges, gt_rows, gt_start, J, rad
     if centers is not None:
         assert centers.dtype == torch.float32 and centers.is_contiguous() and centers.shape == (gt_rows.shape[0], 3)
         _need_gpu(centers)
+    if counts is not None:
+        assert counts.dtype == torch.float32 and counts.numel() == 3 and counts.is_contiguous()
     _lib.check(_lib.load().das_assign_targets(C.byref(lv), C.byref(d), _ptr(gt_rows), _ptr(centers), _ptr(gt_start), _ptr(labels),
-                                              _ptr(targets), _ptr(ctr), _stream()), 'das_assign_targets')
+                                              _ptr(targets), _ptr(ctr), _ptr(counts), _stream()), 'das_assign_targets')
     return labels, targets, ctr
 
 

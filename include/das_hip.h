@@ -486,8 +486,19 @@ typedef struct {
   float range_lo[5], range_hi[5];
   float radius, alpha;
 } DasTargetDesc;
+/* counts (optional, f32[3], zeroed by the caller): += [positives, positives with a depth annotation (some joint's dz != 0),
+ * sum of the visibilities of the positives' joints] — the host-side branch conditions of DASHead.loss (das_head.py:385-392,
+ * 473-478) without a dozen mask / sum launches. */
 int das_assign_targets(const DasLevels* lv, const DasTargetDesc* d, const float* gt, const float* centers,
-                       const int* gt_start, int* labels, float* targets, float* centerness, void* stream);
+                       const int* gt_start, int* labels, float* targets, float* centerness, float* counts, void* stream);
+/* The positive rows of the pose losses (das_head.py:385-409) from das_assign_targets' outputs: pos = the npos rows with
+ * label 0 in ascending order. real f32 (npos, J, 3) = pixel-to-joint targets (image offsets in units of the level's stride,
+ * depth in units of z_norm), vis f32 (npos, J), is2d int32 (npos) = no joint carries a depth annotation, slot int32 (npos) =
+ * rank of the row among the positives of its kind (its block of J rows in the flows' input), depth_t f32 (npos) = depth
+ * target * depth_factor, ctr_pos f32 (npos) = centerness targets of the rows, nvis f32[1] = sum(vis) * nvis_scale. */
+int das_positive_rows(const int* pos, int npos, const float* targets, const float* centerness, const DasLevels* lv,
+                      const DasTargetDesc* d, float z_norm, float depth_factor, float nvis_scale, float* real, float* vis,
+                      int* is2d, int* slot, float* depth_t, float* ctr_pos, float* nvis, void* stream);
 /* mmdet FocalLoss(use_sigmoid) / mmcv sigmoid_focal_loss for one class (das_head.py:341-344): per-row
  * gradient + sum of the per-row loss (loss_sum zeroed by the call). logits: row i at logits[i*pix_stride].
  * weight (here and in the two losses below): optional f32 per-element factor, mmdet's `weight` argument

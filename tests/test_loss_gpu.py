@@ -146,6 +146,40 @@ def test_assign_targets_full_size_vs_oracle():
     assert npos > 10
 
 
+def test_fused_ground_truth_half_equals_the_aten_formulation():
+    """losses.das_head_targets through das_assign_targets' counts + das_positive_rows (two launches) against the mask / sum /
+    gather / concatenate / cumsum formulation it replaces (das_head.py:385-409), at full size with 2-D-only persons mixed in
+    and more positives than one chunk of the rank kernel: counts, rows, kinds and ranks identical, the float rows bit-equal."""
+    from das_amd import losses
+    J, B = cases.HEAD_CFG['num_joints'], 12
+    rs = np.random.RandomState(11)
+    poses = []
+    for b, n in enumerate((18, 0, 6, 15, 21, 9, 3, 18, 12, 24, 6, 15)):
+        p = cases.make_gt(rs, n, J, 832, 512, spread=70.0)[0]
+        if n:
+            flat = rs.uniform(size=n) < 0.35                    # persons without depth annotation: every dz = 0
+            p[torch.from_numpy(flat), 5:3 + 3 * J:3] = 0.0
+        poses.append(p)
+    head = build_head()
+    head.strides, head.regress_ranges = cases.FULL_STRIDES, ((-1, 80), (80, 160), (160, 320), (320, 1e8))
+    head.center_sample_radius = 2.5
+    out = {}
+    for fused in (False, True):
+        losses.FUSED_TARGETS = fused
+        try:
+            out[fused] = losses.das_head_targets(head, B, cases.FULL_SIZES, torch.device(DEV), [p.to(DEV) for p in poses])
+        finally:
+            losses.FUSED_TARGETS = True
+    a, b = out[False], out[True]
+    assert a['npos'] == b['npos'] > 1024 and a['n3d'] == b['n3d'] and 0 < b['n3d'] < b['npos']
+    assert abs(a['nvis_host'] - b['nvis_host']) <= 1e-5 * abs(a['nvis_host'])
+    for k in ('labels', 'pos', 'is2d', 'slot', 'real', 'vis', 'depth_t', 'ctr_t'):
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, k
+        assert torch.equal(a[k], b[k]), k
+    torch.testing.assert_close(b['nvis'], a['nvis'], rtol=1e-6, atol=0)
+    assert 0 < int(b['is2d'].sum()) < b['npos']
+
+
 def test_dense_loss_kernels_vs_torch():
     import torch.nn.functional as F
     from das_amd import train_ops as T
