@@ -156,6 +156,7 @@ def reset_step_state():
     operands and the 'callback queued' flags are still set; launched now, those stale operands would add into the next
     step's gradient, and with the flags set no later backward would flush or join again."""
     _pending.clear()
+    _held_finalize.clear()
     _flush_queued[0] = False
     _rows_checked[0] = False
     for dev_index, ent in _side.items():
@@ -304,9 +305,21 @@ def _convbn_train_forward(x, conv, bn, gamma, beta, relu, residual, bits=None):
     return y, raw, mean, invstd, world
 
 
-def _conv_stats_forward(x, conv, bn, gamma, beta):
+_held_finalize = []     # finalize jobs waiting for the next _conv_stats_forward call: (bn, stats, count, C, (2, C) output)
+
+
+def flush_held_finalize():
+    if _held_finalize:
+        jobs, _held_finalize[:] = list(_held_finalize), []
+        _finalize_many([j[:4] for j in jobs], outs=[j[4] for j in jobs])
+
+
+def _conv_stats_forward(x, conv, bn, gamma, beta, hold=False):
     """conv (BatchNorm statistics in its epilogue) -> finalize only (mean / invstd published, running buffers advanced): the
-    normalisation is left to a consumer. SyncBN: the statistics are summed over the ranks first. Returns raw, mean, invstd."""
+    normalisation is left to a consumer. SyncBN: the statistics are summed over the ranks first. Returns raw, mean, invstd.
+    hold: the finalize launch is left to the NEXT call of this function, which publishes both layers' statistics in one
+    launch (the two cross-stage skip convs of an upsample unit, computed back to back and consumed together much later);
+    the mean / invstd tensors returned here are filled by then."""
     from .nn import bn_stats_buffer, packed_weight, sync_stats
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     w = packed_weight(conv, x.dtype, cin_pad=x.shape[-1])
@@ -318,6 +331,13 @@ def _conv_stats_forward(x, conv, bn, gamma, beta):
         _check_equal_rows(rows)
         stats = sync_stats(stats, w.shape[0], _all_reduce)
         stat_count = rows * world
+    if FINALIZE_MANY and (hold or _held_finalize):
+        Cc = raw.shape[-1]
+        mi = torch.empty(2, Cc, dtype=torch.float32, device=raw.device)
+        _held_finalize.append((bn, stats, stat_count or raw.numel() // Cc, Cc, mi))
+        if not hold or len(_held_finalize) == 4:
+            flush_held_finalize()
+        return raw, mi[0], mi[1]
     _, mean, invstd = ops.bn_train_apply(raw, stats, gamma, beta, bn.running_mean, bn.running_var,
                                          bn.momentum if bn.momentum is not None else 0.1, bn.eps,
                                          num_batches_tracked=bn.num_batches_tracked, stat_count=stat_count, finalize_only=True)
@@ -352,21 +372,21 @@ def _conv_stats_forward_pair(a, b):
 FINALIZE_MANY = True    # one finalize launch for the layers of a fused consumer (False: one per layer); A/B switch
 
 
-def _finalize_many(items):
+def _finalize_many(items, outs=None):
     """mean / invstd published and running statistics advanced for [(bn, stats, count, C)] in ONE launch (layers whose
     statistics are complete together and whose normalisation one fused consumer does). Returns [(mean, invstd)]."""
     if not FINALIZE_MANY:
         fin = []
-        for it in items:
-            fin += _finalize_many_impl([it])
+        for i, it in enumerate(items):
+            fin += _finalize_many_impl([it], None if outs is None else [outs[i]])
         return fin
-    return _finalize_many_impl(items)
+    return _finalize_many_impl(items, outs)
 
 
-def _finalize_many_impl(items):
+def _finalize_many_impl(items, outs=None):
     fin = ops.bn_finalize_many([(st, Cc, count, bn.running_mean, bn.running_var,
                                  bn.momentum if bn.momentum is not None else 0.1, bn.eps, bn.num_batches_tracked)
-                                for bn, st, count, Cc in items])
+                                for bn, st, count, Cc in items], outs=outs)
     for bn, _, _, _ in items:
         bn.__dict__.pop('_das_cache', None)   # running stats changed under the cache's feet (raw-pointer update)
     return fin
@@ -496,9 +516,9 @@ class ConvStatsFn(Function):
     The gradient that arrives for `raw` is the BatchNorm's complete backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv, bn, skip_through):
+    def forward(ctx, x, weight, conv, bn, skip_through, hold=False):
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        raw, mean, invstd = _conv_stats_forward(x, conv, bn, bn.weight, bn.bias)   # (SyncBN: statistics of all ranks)
+        raw, mean, invstd = _conv_stats_forward(x, conv, bn, bn.weight, bn.bias, hold=hold)   # (SyncBN: statistics of all ranks)
         ctx.save_for_backward(x)
         ctx.cfg = (k, s, p, conv)
         ctx.mark_non_differentiable(mean, invstd)
@@ -511,7 +531,7 @@ class ConvStatsFn(Function):
         (x,) = ctx.saved_tensors
         k, s, p, conv = ctx.cfg
         if draw is None:        # only the handed-through x took part in this backward (autograd.grad over selected outputs)
-            return dskip, None, None, None, None
+            return dskip, None, None, None, None, None
         draw = draw.contiguous()
         dw = _wgrad(x, draw, conv.weight, k, s, p) if ctx.needs_input_grad[1] else None
         dx = None
@@ -524,7 +544,7 @@ class ConvStatsFn(Function):
                 dx = dx[..., :x.shape[-1]]
         elif dskip is not None:
             dx = dskip
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 class BnReluAdd3Fn(Function):
@@ -600,11 +620,15 @@ class UpMergeTrainFn(Function):
         ctx.save_for_backward(x, up_x, raw1, z, out if mask is None else None, mean1, invstd1, mean2, invstd2, g1, g2, mask)
         ctx.mods = (c1, bn1, c2, bn2)
         ctx.skip_through, ctx.world = skip_through, world
+        if skip_through:
+            ctx.set_materialize_grads(False)   # (see BottleneckChainFn: no zero tensor for a handed-through input nobody took)
         return (out, x) if skip_through else out
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
         from .nn import packed_weight_dgrad
+        if dy is None:
+            return (dskip,) + (None,) * 10
         x, up_x, raw1, z, out, mean1, invstd1, mean2, invstd2, g1, g2, mask = ctx.saved_tensors
         c1, bn1, c2, bn2 = ctx.mods
         Cc = raw1.shape[-1]
@@ -665,10 +689,13 @@ class ConvBNTrainSkipFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, conv, bn, relu):
         y = ConvBNTrainFn.forward(ctx, x, weight, gamma, beta, None, conv, bn, relu)
+        ctx.set_materialize_grads(False)       # (see BottleneckChainFn)
         return y, x
 
     @staticmethod
     def backward(ctx, dy, dskip):
+        if dy is None:
+            return dskip, None, None, None, None, None, None
         dx, dw, dgamma, dbeta, _, _, _, _ = ConvBNTrainFn.backward(ctx, dy, dskip)
         return dx, dw, dgamma, dbeta, None, None, None
 
@@ -719,11 +746,17 @@ class BottleneckChainFn(Function):
         ctx.plan, ctx.blocks, ctx.nsaved = plan, blocks, len(saved)
         # skip_through: the layer's input is handed through as a second output (see ConvBNTrainSkipFn): its other
         # consumers take it from there, and their gradient arrives here as `dskip`, added in a data-gradient epilogue
+        if skip_through:
+            # (a handed-through input nobody took — the last stage's units generate no cross-stage skips — must not come
+            # back as a materialised zero tensor: a fill of the whole map and its read as a residual)
+            ctx.set_materialize_grads(False)
         return (x, x_in) if skip_through else x
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
         from .nn import bn_stats_buffer, packed_weight_dgrad, packed_weight_dgrad_s2
+        if dy is None:      # (only the handed-through input took part in the backward)
+            return (dskip, None, None) + (None,) * (len(ctx.saved_tensors) - ctx.nsaved)
         if dskip is not None:
             dskip = dskip.contiguous()
         saved, params = ctx.saved_tensors[:ctx.nsaved], ctx.saved_tensors[ctx.nsaved:]
@@ -1214,25 +1247,41 @@ class SigmoidBlendFn(Function):
 
 
 class HeadAssembleFn(Function):
-    """raw (rows, raw_ps) f32 + the per-level Scale parameters (L,4) -> pose_pred, initial uvd."""
+    """raw (rows, raw_ps) f32 + the per-level Scale parameters (level-major, four per level: 0-dim tensors) -> pose_pred,
+    initial uvd. The scales enter the kernel by value (`desc`); they are inputs here so that autograd knows about them. With
+    the flat optimizer their sixteen gradients are added into the flat buffer by ONE multi-tensor launch (before: a stack of
+    stacks in the forward, a fill, four row copies and sixteen scalar adds in the backward)."""
 
     @staticmethod
-    def forward(ctx, raw, scales, geom, desc, level_ids):
+    def forward(ctx, raw, geom, desc, level_ids, *scale_params):
         pose, uvd = ops.head_assemble(_wrap(raw, geom), desc)
         ctx.save_for_backward(raw)
-        ctx.cfg = (geom, desc, level_ids, scales.shape)
+        ctx.cfg = (geom, desc, level_ids)
+        ctx.scale_params = scale_params
         return _d(pose), _d(uvd)
 
     @staticmethod
     def backward(ctx, d_pose, d_uvd):
         (raw,) = ctx.saved_tensors
-        geom, desc, level_ids, sshape = ctx.cfg
+        geom, desc, level_ids = ctx.cfg
         d_raw, d_scale = ops.head_assemble_backward(_wrap(raw, geom), _wrap(d_pose.contiguous(), geom),
                                                     _wrap(d_uvd.contiguous(), geom), desc)
-        ds = torch.zeros(sshape, dtype=torch.float32, device=raw.device)
+        params = ctx.scale_params
+        grads = [None] * len(params)
         for i, l in enumerate(level_ids):
-            ds[l] = d_scale[i]
-        return d_raw, ds, None, None, None
+            for j in range(4):
+                if 4 * l + j < len(params):
+                    grads[4 * l + j] = d_scale[i][j]
+        accs = [_param_acc(p) for p in params]
+        if params and all(a is not None for a in accs):
+            live = [(a, g) for a, g in zip(accs, grads) if g is not None]
+            torch._foreach_add_([a[1] for a, _ in live], [g.reshape(a[1].shape) for a, g in live])
+            for a in accs:
+                a[0].fired()
+            grads = [None] * len(params)
+        else:
+            grads = [None if g is None else g.reshape(p.shape) for g, p in zip(grads, params)]
+        return (d_raw, None, None, None) + tuple(grads)
 
 
 def grad_mode(*tensors):

@@ -150,7 +150,7 @@ class UpsampleUnit(nn.Module):
             # (train mode: normalised by their consumer, the next stage's add — nn.conv_bn_deferred / skip_add)
             # (the fused add handles ONE statistics span for both layers: a pair that mixes SyncBN and plain BN takes
             # the per-layer path — `partner`)
-            skip1 = nnops.conv_bn_deferred(x, self.out_skip1, partner=self.out_skip2)
+            skip1 = nnops.conv_bn_deferred(x, self.out_skip1, partner=self.out_skip2, hold=True)   # (finalized with skip2's)
             skip2, out = nnops.conv_bn_deferred(out, self.out_skip2, skip_through=True, partner=self.out_skip1)
         if self.ind == self.num_units - 1 and self.gen_cross_conv:
             m = self.cross_conv

@@ -166,13 +166,15 @@ class DAS(nn.Module):
         launch queue in the middle of the step, right before backward has to be queued) happens when it is resolved."""
         log_vars = OrderedDict()
         for name, value in losses.items():
+            # (the mean of a 0-dim tensor is the tensor — what the head's losses are: no reduce launch, no mean backward)
             if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
+                log_vars[name] = value if value.dim() == 0 else value.mean()
             elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
+                log_vars[name] = sum(v if v.dim() == 0 else v.mean() for v in value)
             else:
                 raise TypeError(f'{name} is not a tensor or list of tensors')
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        terms = [v for k, v in log_vars.items() if 'loss' in k]
+        loss = sum(terms[1:], terms[0]) if terms else 0      # (0 + v is v: the same sum without its first add)
         log_vars['loss'] = loss
         # mmdet averages every log var over the ranks and reads it back one by one (a collective and a host
         # sync per entry); same values here from ONE stacked all-reduce and ONE device-to-host copy

@@ -238,7 +238,7 @@ class DeferredBN:
         self.raw, self.mean, self.invstd, self.bn = raw, mean, invstd, bn
 
 
-def conv_bn_deferred(x, module, skip_through=False, partner=None):
+def conv_bn_deferred(x, module, skip_through=False, partner=None, hold=False):
     """module(x) for a ConvModule with BN + ReLU whose only consumer is skip_add: in train mode with autograd a DeferredBN
     (the normalised tensor is never written), otherwise the tensor. skip_through as conv_bn. partner: the ConvModule whose
     output meets this one in skip_add — the fused add's backward sums BOTH layers' reductions over one set of ranks, so a
@@ -249,7 +249,8 @@ def conv_bn_deferred(x, module, skip_through=False, partner=None):
     if (DEFERRED_SKIPS and same_span and module.with_activation and isinstance(bn, nn.modules.batchnorm._BatchNorm)
             and bn.training and conv.bias is None
             and ag.grad_mode(x, conv.weight, bn.weight)):
-        res = ag.ConvStatsFn.apply(x, conv.weight, conv, bn, skip_through)
+        # (hold: this layer's finalize launch waits for the partner's, computed right after: one launch for the two)
+        res = ag.ConvStatsFn.apply(x, conv.weight, conv, bn, skip_through, hold)
         d = DeferredBN(res[0], res[1], res[2], bn)
         return (d, res[3]) if skip_through else d
     return conv_bn(x, conv, bn, relu=module.with_activation, skip_through=skip_through)
@@ -260,6 +261,7 @@ def skip_add(x, s1, s2):
     if isinstance(s1, DeferredBN) or isinstance(s2, DeferredBN):
         from . import autograd as ag
         assert isinstance(s1, DeferredBN) and isinstance(s2, DeferredBN)
+        ag.flush_held_finalize()      # (a held finalize launch whose partner never came: nothing left behind by here)
         assert ag._sync_world(s1.bn) == ag._sync_world(s2.bn), \
             'skip_add: one SyncBN and one plain BatchNorm layer (build both with conv_bn_deferred(..., partner=the other))'
         return ag.BnReluAdd3Fn.apply(x, s1.raw, s1.mean, s1.invstd, s1.bn.weight, s1.bn.bias,

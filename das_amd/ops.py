@@ -784,10 +784,10 @@ def bn_train_apply(x, stats, gamma, beta, running_mean, running_var, momentum=0.
     return y, mean, invstd
 
 
-def bn_finalize_many(layers):
+def bn_finalize_many(layers, outs=None):
     """bn_train_apply(finalize_only=True) of up to four layers in one launch (das_bn_finalize_many). layers: [(stats
     f32[slots][2C], C, count, running_mean, running_var, momentum, eps, num_batches_tracked)]; count = the rows behind the
-    statistics (all ranks' for SyncBN). Returns [(mean, invstd)]."""
+    statistics (all ranks' for SyncBN). Returns [(mean, invstd)]; outs: [(2, C) f32 buffer or None] to publish them into."""
     n = len(layers)
     assert 1 <= n <= 4
     arr = (_lib.DasBnFinalize * n)()
@@ -796,7 +796,8 @@ def bn_finalize_many(layers):
         _need_gpu(stats)
         assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() % (2 * Cc) == 0
         assert nbt is None or (nbt.dtype == torch.int64 and nbt.is_cuda)
-        mi = torch.empty(2, Cc, dtype=torch.float32, device=stats.device)
+        mi = outs[i] if outs is not None and outs[i] is not None else torch.empty(2, Cc, dtype=torch.float32, device=stats.device)
+        assert mi.shape == (2, Cc) and mi.dtype == torch.float32 and mi.is_contiguous()
         out.append((mi[0], mi[1]))
         f = arr[i]
         f.stats, f.stats_slots, f.C, f.count = stats.data_ptr(), stats.numel() // (2 * Cc), Cc, int(count)

@@ -344,8 +344,8 @@ class DASHead(nn.Module):
                              self.depth_factor)
         if train_graph:
             raw = x.like(torch.cat(parts, 1))
-            scales = torch.stack([torch.stack([s.scale for s in lv]) for lv in self.scales])
-            pose_d, uvd_d = ag.HeadAssembleFn.apply(raw.data, scales, ag._geom(raw), desc, tuple(level_ids))
+            pose_d, uvd_d = ag.HeadAssembleFn.apply(raw.data, ag._geom(raw), desc, tuple(level_ids),
+                                                    *[s.scale for lv in self.scales for s in lv])
             pose_pred, uvd0 = x.like(pose_d), x.like(uvd_d)
             ref = self.recursive_update_branch(pose_feat, uvd0)
             zmask = torch.ones(3 * J, dtype=torch.float32, device=ref.device)

@@ -276,10 +276,20 @@ class RLEPoseLossFn(Function):
         stride = {D: -(-count[D] * J // _FLOW_ALIGN) * _FLOW_ALIGN for D in (2, 3)}
         d.stride2, d.stride3 = stride[2], stride[3]
         x, w, logp, z, jobs = {}, {}, {}, {}, {}
+        # (the eight zero-initialised work tensors — flow inputs, weights, log-densities, latent codes for the 2-D and the 3-D
+        # rows — are slices of ONE zero fill: each was a launch of its own)
+        nrow = {D: sets * stride[D] for D in (2, 3)}
+        pool = torch.zeros(sum(nrow[D] * (2 * D + 2) for D in (2, 3)), dtype=torch.float32, device=dev)
+        cut = [0]
+
+        def part(n, *shape):
+            t = pool[cut[0]:cut[0] + n].view(*shape)
+            cut[0] += n
+            return t
         for D in (2, 3):
-            rows = sets * stride[D]
-            x[D] = torch.zeros(rows, D, dtype=torch.float32, device=dev) if rows else None
-            w[D] = torch.zeros(rows, dtype=torch.float32, device=dev) if rows else None
+            rows = nrow[D]
+            x[D] = part(rows * D, rows, D) if rows else None
+            w[D] = part(rows, rows) if rows else None
         lib = _lib.load()
         gt = [meta[k] for k in ('pos', 'real', 'vis', 'is2d', 'slot')]
         _lib.check(lib.das_rle_prepare(_ptr(pose), _ptr(aux), *[_ptr(t) for t in gt], C.byref(d), _ptr(x[2]), _ptr(w[2]),
@@ -296,8 +306,8 @@ class RLEPoseLossFn(Function):
                 arr[q].params, arr[q].dparams, arr[q].dst_table = packed.data_ptr(), None, None
                 arr[q].row_start, arr[q].row_end = r0, r1
             rows = sets * stride[D]
-            logp[D] = torch.zeros(rows, dtype=torch.float32, device=dev)
-            z[D] = torch.zeros(rows, D, dtype=torch.float32, device=dev)
+            logp[D] = part(rows, rows)
+            z[D] = part(rows * D, rows, D)
             c0 = meta['flow_states'][D][0][0]
             _lib.check(lib.das_realnvp_log_prob_multi(_ptr(x[D]), rows, D, arr, sets, len(flows[0].t), c0['bits'],
                                                       _ptr(logp[D]), _ptr(z[D]), _stream()), 'das_realnvp_log_prob_multi')
