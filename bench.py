@@ -895,17 +895,21 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
+    host = [t0]
     for i in range(steps):
         res = step()
         marks[i + 1].record()
+        host.append(time.perf_counter())
     sync_all()
     dt = time.perf_counter() - t0
     series = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     per = sorted(series)
     extra['timed_steps_ms'] = dict(min=round(per[0], 3), median=round(per[len(per) // 2], 3), max=round(per[-1], 3),
                                    in_order=[round(x, 2) for x in series[:64]],
+                                   host_in_order=[round((host[i + 1] - host[i]) * 1e3, 1) for i in range(min(steps, 64))],
                                    note='GPU time between the ends of consecutive timed steps (events on the launch stream); '
-                                        'ms_per_step is the wall clock of the whole region / steps')
+                                        'host_in_order: the time the host took to QUEUE each step (it runs up to three steps '
+                                        'ahead); ms_per_step is the wall clock of the whole region / steps')
     if graphs is not None:     # the per-launch measurement passes below need every launch queued by hand
         model._graphed_trunk = None
     if world > 1:
