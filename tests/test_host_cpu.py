@@ -267,3 +267,34 @@ def test_upsample_adjoint_tables_match_torch_interpolate(H, Ho):
             for dh in (-1, 0, 1) for dw in (-1, 0, 1))
     assert abs(float((w.double()[:, None] * ww.double()[None, :] * z).sum() - up.sum())) < 1e-5 * max(1.0, float(up.abs().sum()))
     assert abs(float((z * G).sum() - (up * up).sum())) < 1e-5 * float((up * up).sum())
+
+
+def test_flat_sgd_pads_odd_channel_counts_inside_its_storage_and_nowhere_else():
+    """FlatSGD stores a conv weight whose output channels are not a multiple of 8 with zero rows up to the next multiple, a
+    1-D parameter with zeros up to a multiple of 8 elements (the padded block is the operand the kernels read): the
+    parameters keep their own shapes and values, state dict and dense momentum see no padding, the padding is zero and
+    the buckets cover it."""
+    import torch.nn as nn
+    from das_amd.optim import FlatSGD
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(16, 45, 1), nn.Conv2d(48, 27, 3, padding=1), nn.Conv2d(3, 8, 3), nn.Conv2d(8, 16, 1, bias=False))
+    want = {k: v.clone() for k, v in net.state_dict().items()}
+    opt = FlatSGD(net, lr=0.1, momentum=0.9, bucket_mb=0)
+    for k, v in net.state_dict().items():
+        assert v.shape == want[k].shape and torch.equal(v, want[k]), k
+    by_name = dict(zip(opt._names, opt.slots))
+    w45, b45, w27, w3, w16 = (by_name[n] for n in ('0.weight', '0.bias', '1.weight', '2.weight', '3.weight'))
+    assert (w45.o_pad, w45.span, w45.numel, w45.packable) == (48, 48 * 16, 45 * 16, True)
+    assert (w27.o_pad, w27.span, w27.packable) == (32, 32 * 9 * 48, True)
+    assert (b45.span, b45.numel) == (48, 45) and b45.padded().numel() == 48
+    assert (w3.o_pad, w3.span, w3.packable) == (8, 8 * 9 * 3, False)        # (3 input channels: the per-layer path, no padding)
+    assert (w16.o_pad, w16.span, w16.packable) == (16, 16 * 8, True)
+    assert w45.direct(16, 48) and w45.direct(16, 45) and not w45.direct(16, 56) and not w45.direct(8, 48)
+    for sl in opt.slots:
+        assert sl.off % 8 == 0
+        for buf in (opt.flat_p, opt.flat_g, opt.flat_m):
+            assert float(buf[sl.off + sl.numel:sl.off + sl.span].abs().sum()) == 0.0
+    ends = sorted(sl.off + sl.span for sl in opt.slots)
+    assert opt.buckets[-1][1] == opt.flat_p.numel() >= ends[-1]
+    dense = opt._dense_momentum()
+    assert {k: tuple(v.shape) for k, v in dense.items()} == {k: tuple(v.shape) for k, v in want.items()}
