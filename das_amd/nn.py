@@ -338,27 +338,36 @@ def conv_bn_stats_only(x, conv, bn):
 
 
 class _ZeroArena:
-    """Zero-filled f32 scratch handed out in slices (per-channel statistics accumulators of the conv
-    epilogue): one memset per ~1M floats instead of one per layer. A slice is only valid for the launches
-    issued right after it is taken (stream order makes the wrap-around memset safe)."""
+    """Zero-filled f32 scratch handed out in slices (per-channel statistics accumulators of the conv epilogues, reduction
+    workspaces): one fill per ~4M floats instead of one per layer. TWO buffers used alternately: when the current one is
+    used up, the OTHER one is filled and taken over — its slices were handed out a whole buffer of takes ago, so every
+    launch that used them precedes the fill in stream order, and the slices of the buffer being left stay intact until the
+    next switch. (Rounds 3-4 had ONE buffer refilled in place: a layer pair that takes its second slice before the first
+    one's consumer is launched — the two convs of an upsample-unit merge, since round 4 — lost the first layer's sums
+    whenever the refill fell between the two takes: mean 0 / variance 0 for that layer in that step, a few times per
+    hundred steps. Found in round 5 by comparing the running variances of two identical runs, tools/dev/rv_probe.py.)
+    All takes and their consumers must be issued on ONE stream (the training stream): the fills are ordered by it."""
 
     def __init__(self, cap=1 << 22):
-        self.cap, self.buf, self.off = cap, None, 0
+        self.cap, self.bufs, self.cur, self.off = cap, None, 0, 0
 
     def take(self, n, device):
         n = (n + 63) // 64 * 64
-        if self.buf is None or self.buf.device != device:
-            self.buf, self.off = torch.zeros(self.cap, dtype=torch.float32, device=device), 0
+        assert n <= self.cap, n
+        if self.bufs is None or self.bufs[0].device != device:
+            self.bufs = [torch.zeros(self.cap, dtype=torch.float32, device=device) for _ in range(2)]
+            self.cur, self.off = 0, 0
         if self.off + n > self.cap:
-            self.buf.zero_()
+            self.cur ^= 1
+            self.bufs[self.cur].zero_()
             self.off = 0
-        s = self.buf[self.off:self.off + n]
+        s = self.bufs[self.cur][self.off:self.off + n]
         self.off += n
         return s
 
     def reset(self):
-        """Zero the whole buffer and start over (the first node of a captured graph: das_amd/graphs.py)."""
-        self.buf.zero_()
+        """Zero the current buffer and start over (the first node of a captured graph: das_amd/graphs.py)."""
+        self.bufs[self.cur].zero_()
         self.off = 0
 
 

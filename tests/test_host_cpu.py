@@ -298,3 +298,26 @@ def test_flat_sgd_pads_odd_channel_counts_inside_its_storage_and_nowhere_else():
     assert opt.buckets[-1][1] == opt.flat_p.numel() >= ends[-1]
     dense = opt._dense_momentum()
     assert {k: tuple(v.shape) for k, v in dense.items()} == {k: tuple(v.shape) for k, v in want.items()}
+
+
+def test_zero_arena_never_refills_a_slice_that_may_still_be_in_use():
+    """nn._ZeroArena hands out zeroed slices of two alternating buffers. A layer pair takes its second slice BEFORE the
+    first one's consumer is launched (the two convs of an upsample-unit merge, a dual apply, a held finalize pair): the take
+    that switches buffers must leave the slices of the buffer it leaves untouched (one buffer refilled in place zeroed the
+    first layer's statistics whenever the refill fell between the two takes — rounds 3-4), and everything it hands out
+    must be zero again however the previous holders left it."""
+    from das_amd.nn import _ZeroArena
+    dev = torch.device('cpu')
+    a = _ZeroArena(cap=1024)
+    first = a.take(960, dev)
+    first.fill_(3.0)                      # (a conv epilogue accumulated its statistics)
+    second = a.take(128, dev)             # does not fit: the other buffer takes over
+    assert float(first.min()) == 3.0, 'the pending slice was refilled under its consumer'
+    assert float(second.abs().max()) == 0.0 and second.data_ptr() != first.data_ptr()
+    second.fill_(5.0)
+    for _ in range(40):                   # many switches later every slice still comes out zeroed
+        s = a.take(200, dev)
+        assert s.numel() == 256 and float(s.abs().max()) == 0.0
+        s.fill_(7.0)
+    a.reset()
+    assert float(a.take(64, dev).abs().max()) == 0.0
