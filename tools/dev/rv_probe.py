@@ -26,11 +26,15 @@ def run(off):
     out = [float(train_iteration(model, opt, data, 2e-3)['log_vars']['loss']) for _ in range(N)]
     names = [n for n, b in model.named_buffers() if n.endswith('running_var')]
     rv = [b.flatten().float().clone() for n, b in model.named_buffers() if n.endswith('running_var')]
-    return out, names, rv
+    pars = {n: p.detach().flatten().float().clone() for n, p in model.named_parameters()}
+    return out, names, rv, pars
 
 
 base = run(())
 for off in [()] + [(k,) for k in sys.argv[2:]]:
-    out, names, rv = run(off)
+    out, names, rv, pars = run(off)
     worst = max(((float((u - v).abs().max() / v.abs().max()), n) for n, u, v in zip(names, rv, base[2])), key=lambda t: t[0])
     print('off=%-16s loss[0] %.3f loss[-1] %.3f  worst running_var difference %.3e at %s' % (','.join(off) or '-', out[0], out[-1], worst[0], worst[1]), flush=True)
+    # parameters: how far two runs drift apart relative to how far the parameter MOVED from its initial value (torch.manual_seed(0) init)
+    pw = sorted(((float((pars[n] - base[3][n]).abs().max() / max(float(base[3][n].abs().max()), 1e-12)), n) for n in pars), reverse=True)[:3]
+    print('      parameters furthest apart (relative to their largest element): ' + '; '.join('%.2e %s' % t for t in pw), flush=True)
