@@ -50,7 +50,7 @@ class DasLevels(C.Structure):
 class DasHeadDesc(C.Structure):
     _fields_ = [('J', i32), ('root_idx', i32), ('raw_ps', i32), ('off_c', i32), ('depth_c', i32), ('uvd_c', i32),
                 ('sigma_c', i32), ('scale', (f32 * 4) * 5), ('level_stride', f32 * 5), ('z_norm', f32),
-                ('depth_factor', f32)]
+                ('depth_factor', f32), ('scale_dev', vp)]
 
 
 class DasTargetDesc(C.Structure):

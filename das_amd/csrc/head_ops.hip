@@ -277,7 +277,8 @@ __global__ void head_assemble_kernel(const float* __restrict__ raw, float* __res
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const int c = (int)(i % D);
     const long long p = i / D;
-    const float* sc = d.scale[level_of(lv, p)];
+    const int lvl = level_of(lv, p);
+    const float* sc = d.scale_dev ? d.scale_dev + 4 * lvl : d.scale[lvl];
     const float* r = raw + p * d.raw_ps;
     float v;
     if (c < 2) {

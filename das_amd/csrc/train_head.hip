@@ -449,7 +449,7 @@ __global__ void head_assemble_bwd_kernel(const float* __restrict__ raw, const fl
     const int c = (int)(i % D);
     const long long p = i / D;
     const int l = level_of(lv, p);
-    const float* sc = d.scale[l];
+    const float* sc = d.scale_dev ? d.scale_dev + 4 * l : d.scale[l];
     const float* r = raw + p * d.raw_ps;
     float* dr = draw + p * d.raw_ps;
     float gsc = 0.f;

@@ -44,6 +44,34 @@ class SyntheticPoseDataset:
 ANNOTATION_KEYS = ('gt_bboxes', 'gt_labels', 'gt_poses_3d', 'gt_labels_3d', 'centers2d', 'depths')
 
 
+def mark_uploaded(tensors):
+    """Tag device tensors with an event recorded NOW on the current stream (right after the copies that filled them): a
+    consumer on another stream waits for THAT (`uploaded_events`) instead of for everything the training stream has queued
+    since — the detector computes the loss's ground-truth half on a side stream and reads three counts back to the host; behind
+    an event recorded at forward time that read waits for the whole previous step, i.e. the host runs in lockstep with the GPU
+    and every host hiccup of a few ms stalls it."""
+    ts = [t for t in tensors if torch.is_tensor(t) and t.is_cuda]
+    if ts:
+        ev = torch.cuda.Event()
+        ev.record()
+        for t in ts:
+            t._das_uploaded = ev
+    return tensors
+
+
+def uploaded_events(*groups):
+    """The distinct upload events of the tensors in `groups` (lists of tensors or None), or None if any tensor carries none."""
+    evs = []
+    for g in groups:
+        for t in (g or ()):
+            ev = getattr(t, '_das_uploaded', None)
+            if ev is None:
+                return None
+            if all(ev is not e for e in evs):
+                evs.append(ev)
+    return evs
+
+
 def pack_to_device(arrays, device):
     """numpy arrays -> device tensors of the same shapes / dtypes with ONE host-to-device copy: the arrays are laid out
     back to back (16-byte aligned) in one byte buffer and the results are views of its device copy."""
@@ -64,7 +92,7 @@ def pack_to_device(arrays, device):
             out.append(torch.empty(a.shape, dtype=dt, device=device))
         else:
             out.append(dev[o:o + a.nbytes].view(dt).view(a.shape))
-    return out
+    return mark_uploaded(out)
 
 
 
@@ -93,6 +121,7 @@ def collate(samples, device=None):
     else:
         for k in keys:
             out[k] = [dev(s[k]) for s in samples]
+        mark_uploaded([t for k in keys for t in out[k]])
     return out
 
 

@@ -112,8 +112,14 @@ class DAS(nn.Module):
         targets = None
         if prepare and img.is_cuda:
             main = torch.cuda.current_stream()
-            ready = torch.cuda.Event()
-            ready.record(main)                  # (the ground truth was put on the device by the main stream)
+            from .datasets import uploaded_events
+            # the ground truth's own upload events (datasets.mark_uploaded) if it carries them: the side stream then waits for
+            # those copies only. Without them: an event recorded now — behind everything the training stream has queued, so
+            # the host's read-back below waits for the previous step to finish (host and GPU in lockstep).
+            ready = uploaded_events(gt_poses_3d, centers2d, depths)
+            if ready is None:
+                ready = [torch.cuda.Event()]
+                ready[0].record(main)
         if hasattr(self.bbox_head, 'prefetch_scales'):
             self.bbox_head.prefetch_scales()    # (a device-to-host copy the head needs: started before the backbone is queued)
         # backbone + neck: two hipGraph replays when the trunk was captured for this batch shape (das_amd/graphs.py)
@@ -124,7 +130,11 @@ class DAS(nn.Module):
             x = self.extract_feat(img)
         if prepare and img.is_cuda:
             side = _side_stream(img.device)
-            side.wait_event(ready)
+            for ev in ready:
+                side.wait_event(ev)
+            for t in list(gt_poses_3d) + list(centers2d or ()) + list(depths or ()):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(side)
             with torch.cuda.stream(side):
                 targets = prepare(hw, img.shape[0], img.device, gt_poses_3d, centers2d, depths)
             main.wait_stream(side)

@@ -1133,10 +1133,17 @@ def sigmoid_blend(off, w, nxt):
     return out
 
 
-def head_desc(J, root_idx, raw_ps, off_c, depth_c, uvd_c, sigma_c, scales, strides, z_norm, depth_factor):
-    """scales: per level [offset, depth, uv, d]; strides: per level head stride."""
+def head_desc(J, root_idx, raw_ps, off_c, depth_c, uvd_c, sigma_c, scales, strides, z_norm, depth_factor, scale_dev=None):
+    """scales: per level [offset, depth, uv, d] as host floats, or None with scale_dev = the same as an f32 (levels, 4) DEVICE
+    tensor (kept alive by the descriptor object: `_scale_dev`); strides: per level head stride."""
     d = _lib.DasHeadDesc(J=J, root_idx=root_idx, raw_ps=raw_ps, off_c=off_c, depth_c=depth_c, uvd_c=uvd_c,
                          sigma_c=sigma_c, z_norm=float(z_norm), depth_factor=float(depth_factor))
+    if scale_dev is not None:
+        _need_gpu(scale_dev)
+        assert scales is None and scale_dev.dtype == torch.float32 and scale_dev.is_contiguous() and scale_dev.shape == (len(strides), 4)
+        d.scale_dev = scale_dev.data_ptr()
+        d._scale_dev = scale_dev
+        scales = ()
     for l, sc in enumerate(scales):
         for k in range(4):
             d.scale[l][k] = float(sc[k])

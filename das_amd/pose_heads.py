@@ -338,10 +338,21 @@ class DASHead(nn.Module):
         pose_feat = predict(pose_feat, self.conv_pose_prevs[0], self.conv_poses[0], L['uvd'], more=True)
         pose_feat = predict(pose_feat, self.conv_pose_prevs[1], self.conv_poses[1], L['sigma'], more=True)
 
-        sc = self._scale_values()
-        desc = ops.head_desc(J, self.root_idx, L['total'], L['off'], L['depth'], L['uvd'], L['sigma'],
-                             [sc[l] for l in level_ids], [self.strides[l] for l in level_ids], self.z_norm,
-                             self.depth_factor)
+        if train_graph and x.data.is_cuda:
+            # training: the kernels read the Scale values from DEVICE memory (one gather launch) — as host floats they cost a
+            # device-to-host copy of parameters the optimizer wrote at the end of the previous step, i.e. the host waited for the
+            # GPU to finish that step before it could queue the head of this one, every step
+            dev_sc = torch.stack([s.scale.detach() for lv in self.scales for s in lv]).float().view(len(self.scales), 4)
+            if tuple(level_ids) != tuple(range(len(self.scales))):
+                dev_sc = dev_sc[list(level_ids)]
+            desc = ops.head_desc(J, self.root_idx, L['total'], L['off'], L['depth'], L['uvd'], L['sigma'], None,
+                                 [self.strides[l] for l in level_ids], self.z_norm, self.depth_factor,
+                                 scale_dev=dev_sc.contiguous())
+        else:
+            sc = self._scale_values()
+            desc = ops.head_desc(J, self.root_idx, L['total'], L['off'], L['depth'], L['uvd'], L['sigma'],
+                                 [sc[l] for l in level_ids], [self.strides[l] for l in level_ids], self.z_norm,
+                                 self.depth_factor)
         if train_graph:
             raw = x.like(torch.cat(parts, 1))
             pose_d, uvd_d = ag.HeadAssembleFn.apply(raw.data, ag._geom(raw), desc, tuple(level_ids),
@@ -375,6 +386,8 @@ class DASHead(nn.Module):
         params = [s.scale for lv in self.scales for s in lv]
         if not params or not params[0].is_cuda:
             return
+        if self.training and torch.is_grad_enabled() and params[0].requires_grad:
+            return      # (the training graph reads the scales from device memory: forward_rows)
         from .nn import _versions
         ver = _versions(*params)
         pend = self.__dict__.get('_scale_prefetch')

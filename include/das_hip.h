@@ -437,12 +437,16 @@ int das_sigmoid_blend(const float* off, const float* w, const float* nxt, float*
  * off@off_c(2), depth@depth_c(1), uvd@uvd_c(3J), sigma@sigma_c(3J).
  * pose_pred: (rows, 3+6J) f32 = [off(2), depth, uvd(3J), sigma(3J)]; uvd_out: (rows,3J) f32 =
  * scaled+pinned initial uvd (input of the recursive-update branch). scale[l] = the level's four
- * `Scale` values (offset, depth, uv, d); level_stride[l] = head stride of level l. */
+ * `Scale` values (offset, depth, uv, d); level_stride[l] = head stride of level l.
+ * scale_dev (optional): the same values as f32[levels][4] in DEVICE memory, read by the kernels instead of scale[][] — a
+ * training step then needs no device-to-host copy of parameters the optimizer has just written (a host synchronisation
+ * with the end of the previous step, every step). */
 typedef struct {
   int J, root_idx, raw_ps, off_c, depth_c, uvd_c, sigma_c;
   float scale[5][4];
   float level_stride[5];
   float z_norm, depth_factor;
+  const float* scale_dev;
 } DasHeadDesc;
 int das_head_assemble(const float* raw, float* pose_pred, float* uvd_out, const DasLevels* lv,
                       const DasHeadDesc* d, void* stream);

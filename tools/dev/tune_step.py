@@ -24,6 +24,20 @@ for _ in range(4):
     train_iteration(model, opt, data, 2e-3)
 
 
+_UP_EV = data['gt_poses_3d'][0]._das_uploaded
+_hiccup = [0.0]
+_head_ft = model.bbox_head.forward_train
+
+
+def _slow_head(*a, **k):
+    if _hiccup[0] > 0:
+        time.sleep(_hiccup[0])
+    return _head_ft(*a, **k)
+
+
+model.bbox_head.forward_train = _slow_head
+
+
 def run(cfg):
     _lib.check(lib.das_tuning_reset(), 'reset')
     wb, fs, ms_ = ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS
@@ -41,6 +55,15 @@ def run(cfg):
             ag.MASK_BITS = bool(int(v))
         elif k == 'DCNF':
             ag.DCN_FUSED = bool(int(v))
+        elif k == 'UPLOADEV':      # 0: the ground truth without its upload events (the detector's side stream then waits for the step before)
+            for key in ('gt_poses_3d', 'centers2d', 'depths'):
+                for t in data[key]:
+                    if int(v):
+                        t._das_uploaded = _UP_EV
+                    elif hasattr(t, '_das_uploaded'):
+                        del t._das_uploaded
+        elif k == 'SLEEP':         # a host hiccup of v ms in every step, right before the head is queued
+            _hiccup[0] = int(v) * 1e-3
         elif k == 'CHAIN':
             dnn.CHAIN_CONSUMERS = bool(int(v))
         elif k == 'DUAL':
@@ -67,6 +90,10 @@ def run(cfg):
     ms = ts[N // 2]
     ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS = wb, fs, ms_
     ag.DCN_FUSED = True
+    _hiccup[0] = 0.0
+    for key in ('gt_poses_3d', 'centers2d', 'depths'):
+        for t in data[key]:
+            t._das_uploaded = _UP_EV
     dnn.CHAIN_CONSUMERS = dnn.UPCONV_AT_LOW_RES = dnn.UPMERGE_FUSED = dnn.DEFERRED_SKIPS = ag.DUAL_APPLY = ag.MASK_BITS = ag.GN_REMASK = ag.RES_BITS = True
     _lib.check(lib.das_tuning_reset(), 'reset')
     return ms
