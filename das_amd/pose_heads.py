@@ -359,8 +359,14 @@ class DASHead(nn.Module):
                                                     *[s.scale for lv in self.scales for s in lv])
             pose_pred, uvd0 = x.like(pose_d), x.like(uvd_d)
             ref = self.recursive_update_branch(pose_feat, uvd0)
-            zmask = torch.ones(3 * J, dtype=torch.float32, device=ref.device)
-            zmask[self.root_idx * 3 + 2] = 0
+            # (the mask is built ONCE per device: `zmask[i] = 0` on a device tensor is a host-to-device copy of a scalar on the
+            # training stream, and the host waits for the stream to reach it — 15 ms per step in lockstep with the GPU)
+            zkey = ('_zmask', str(ref.device), J, self.root_idx)
+            zmask = self.__dict__.get(zkey)
+            if zmask is None:
+                zm = torch.ones(3 * J, dtype=torch.float32)
+                zm[self.root_idx * 3 + 2] = 0
+                zmask = self.__dict__[zkey] = zm.to(ref.device)
             ref = ref.like(ref.data * zmask)  # ref_uvd[:, root z] = 0 (das_head.py:254)
             assert self.training, 'gradients through the eval-mode rescale are not part of the DAS path'
         else:
