@@ -248,6 +248,9 @@ def verify_rows(wait=False):
                                f'type BN')
 
 
+_ROWS_SIGN = {}
+
+
 def _check_equal_rows(rows):
     if _rows_checked[0]:
         return
@@ -255,9 +258,16 @@ def _check_equal_rows(rows):
     import torch.distributed as dist
     from .nn import stats_group
     verify_rows()
-    t = torch.tensor([float(rows), -float(rows)], dtype=torch.float64)
     if dist.get_backend() == 'nccl':
-        t = t.cuda(non_blocking=True)
+        # (built on the device from a cached [1, -1]: a host tensor copied up here is a pageable host-to-device copy on the
+        # training stream — the host would wait for the stream to reach it, every step)
+        dev = torch.device('cuda', torch.cuda.current_device())
+        sign = _ROWS_SIGN.get(dev)
+        if sign is None:
+            sign = _ROWS_SIGN[dev] = torch.tensor([1.0, -1.0], dtype=torch.float64).to(dev)
+        t = sign * float(rows)
+    else:
+        t = torch.tensor([float(rows), -float(rows)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=stats_group())
     if t.is_cuda:
         host = torch.empty(2, dtype=torch.float64, pin_memory=True)
