@@ -64,6 +64,8 @@ def run(cfg):
                         del t._das_uploaded
         elif k == 'SLEEP':         # a host hiccup of v ms in every step, right before the head is queued
             _hiccup[0] = int(v) * 1e-3
+        elif k == 'SIDEPP':
+            ag.SIDE_PP_BLOCKS = int(v)
         elif k == 'CHAIN':
             dnn.CHAIN_CONSUMERS = bool(int(v))
         elif k == 'DUAL':
@@ -90,6 +92,7 @@ def run(cfg):
     ms = ts[N // 2]
     ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS = wb, fs, ms_
     ag.DCN_FUSED = True
+    ag.SIDE_PP_BLOCKS = 128
     _hiccup[0] = 0.0
     for key in ('gt_poses_3d', 'centers2d', 'depths'):
         for t in data[key]:
