@@ -199,6 +199,15 @@ __device__ __forceinline__ LvGeom lv_geom(const DasLevels& lv, long long m) {
   g.plane0 = start + (long long)g.b * hw;
   return g;
 }
+// Minimum pixels per workgroup of the GroupNorm passes. `key` = das_tuning gn.ppb; 0 = automatic: as many as keep at least 448
+// workgroups (1.75 per CU) in the launch, within 256 ... 1024 — 1024 at the training batch (64 level x image segments: -0.5 ms per
+// step against 256, +0.7 with 2048), 256 at the inference batch (32 segments: 1024 there leaves CUs idle, -5 % img/s).
+static inline int gn_ppb_min(long long key, int nseg, int maxhw) {
+  if (key > 0) return (int)key;
+  int ppb = 1024;
+  while (ppb > 256 && (long long)nseg * ((maxhw + ppb - 1) / ppb) < 448) ppb /= 2;
+  return ppb;
+}
 static inline bool lv_valid(const DasLevels* lv) {
   if (!lv || lv->num_levels < 1 || lv->num_levels > 5 || lv->B < 1) return false;
   for (int l = 0; l < lv->num_levels; ++l)

@@ -514,7 +514,7 @@ extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLe
   int chunks = (256 * 4 + lv->B - 1) / lv->B;
   int ppb = (maxhw + chunks - 1) / chunks;
   // (64 pixels per workgroup left the pass launch / latency bound: 42 us for 72 MB; 256: infer +3 %)
-  const int ppb_min = (int)dastune::get(dastune::GN_PPB);   // minimum pixels per workgroup
+  const int ppb_min = gn_ppb_min(dastune::get(dastune::GN_PPB), nseg, maxhw);   // minimum pixels per workgroup
   if (ppb < ppb_min) ppb = ppb_min;
   chunks = (maxhw + ppb - 1) / ppb;
   // LDS of the statistics pass: [pixel lanes][2 x (vectors | channels)] partial sums

@@ -457,7 +457,7 @@ static int groupnorm_backward_impl(const void* dy, const void* y, const void* x,
   int maxhw = 0;
   for (int l = 0; l < lv->num_levels; ++l) maxhw = std::max(maxhw, lv->H[l] * lv->W[l]);
   int chunks = (256 * 4 + lv->B - 1) / lv->B;
-  int ppb = std::max((int)dastune::get(dastune::GN_PPB), (maxhw + chunks - 1) / chunks);   // (see norm.hip)
+  int ppb = std::max(gn_ppb_min(dastune::get(dastune::GN_PPB), nseg, maxhw), (maxhw + chunks - 1) / chunks);   // (see norm.hip)
   chunks = (maxhw + ppb - 1) / ppb;
   DISPATCH_T(dtype, {
     const int vc = C / Elem<T>::EPV;

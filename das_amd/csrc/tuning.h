@@ -15,7 +15,10 @@ enum Key {
   CONV_GLDS4_PP,         // -1 = ping-pong schedule for K >= 256, 0 / 1 force the choice
   CONV_GLDS4_MF,         // conv_glds4_kernel pixel-tile height in 32-row units: 0 = by round count, 8 = 256 rows, 9 = 288 rows
   CONV_STREAM_MINROWS,   // conv1x1_stream_kernel from this many pixel rows up; 0 disables the kernel
-  CONV_STREAM_PERCU,     // ... workgroups per CU of its persistent grid
+  CONV_STREAM_PERCU,     // ... workgroups per CU of its persistent grid. ONE: with two (rounds 2-4) the K <= 128 variants ran 512
+                         // workgroups of which each walked half the tiles — 18-25 % slower per launch on every shape of the step
+                         // (family 12.8 -> 11.4 ms, step -1.45 ms; an A/B that drowned in the step's +-0.5 ms noise until the host
+                         // stopped running in lockstep with the GPU, round 5)
   CONV_TAIL_SPLIT,       // 1: a 256-row-tile launch whose last round of workgroups would be under half full hands the
                          // rows of that round to the 128-row tile kernel (second launch)
   CONV_SPLITK_TARGET,    // tile-kernel launches with at most half this many workgroups (x 2 for the 128-row kernel, two
@@ -32,7 +35,7 @@ enum Key {
   BN_REDUCE_BLOCKS,      // grid / block size of bn_bwd_reduce_kernel
   BN_REDUCE_THREADS,
   BN_VPT,                // 16-byte vectors per thread of the BatchNorm apply passes
-  GN_PPB,                // minimum pixels per workgroup of the GroupNorm statistic passes
+  GN_PPB,                // minimum pixels per workgroup of the GroupNorm passes; 0 = by the launch's size (common.h: gn_ppb_min)
   CONV_C64_MINTILES,     // conv3x3_c64_kernel (3x3, 64 -> 64 channels, 16 x 16-pixel tiles with the input patch and the
                          // whole weight matrix in LDS) from this many tiles up; 0 disables the kernel
   BN_STREAM_MINBYTES,    // BatchNorm apply passes over tensors of at least this many bytes: slot fold as its own launch +

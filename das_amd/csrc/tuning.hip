@@ -18,10 +18,10 @@ struct Entry {
 constexpr Entry kTable[N_KEYS] = {
     {"conv.big_minblocks", 100},  {"conv.big_mink", 0},       {"conv.glds3_pp_mink", 1024},
     {"conv.glds4_minblocks", 128}, {"conv.glds4_pp", -1},      {"conv.glds4_mf", 0},
-    {"conv.stream_minrows", 16384}, {"conv.stream_percu", 2}, {"conv.tail_split", 1},        {"conv.splitk_target", 256},
+    {"conv.stream_minrows", 16384}, {"conv.stream_percu", 1}, {"conv.tail_split", 1},        {"conv.splitk_target", 256},
     {"conv.splitk_minsteps", 12}, {"conv.splitk_kernels", 3},  {"wgrad.pp_mink", 256},  {"wgrad.shapes", 1},
     {"wgrad.bkm", 32},            {"wgrad.blocks", 0},        {"wgrad.pp_blocks", 0},      {"bn.reduce_blocks", 256},     {"bn.reduce_threads", 256},
-    {"bn.vpt", 8},                {"gn.ppb", 256},             {"conv.c64_mintiles", 64},    {"bn.stream_minbytes", 96 << 20},
+    {"bn.vpt", 8},                {"gn.ppb", 0},             {"conv.c64_mintiles", 64},    {"bn.stream_minbytes", 96 << 20},
     {"comm.reserved_cus", 0},  {"elem.upstats_ppb", 0},   {"bn.upmerge_blocks", 512}, {"dcn.fused_minrows", 100000},
     {"conv.balance_rows", 1},
 };
