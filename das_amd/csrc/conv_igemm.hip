@@ -1071,7 +1071,10 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
 #ifndef DAS_STREAM_K64_NS
 #define DAS_STREAM_K64_NS 4
 #endif
-  constexpr int NS = KB == 2 ? DAS_STREAM_K64_NS : 4, AHEAD = NS - 1;
+#ifndef DAS_STREAM_K128_NS
+#define DAS_STREAM_K128_NS 4
+#endif
+  constexpr int NS = KB == 2 ? DAS_STREAM_K64_NS : (KB == 4 ? DAS_STREAM_K128_NS : 4), AHEAD = NS - 1;
   constexpr int IPL = SUBS * 4;                             // DMA instructions per loader wave and tile
   constexpr unsigned OOB = 0xFFFFFFF0u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1392,7 +1395,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
   const int wn = p.Cout >= 256 ? 8 : p.Cout / 32, ncol = p.Cout >= 256 ? p.Cout / 256 : 1;
   const int ntiles = (p.M + 63) / 64;
   const int kb = p.Cin / 32;
-  const size_t sm = (size_t)(p.Cin == 64 ? DAS_STREAM_K64_NS : 4) * ((p.Cin + 63) / 64) * 64 * 128 + 8 * 64 * sizeof(float);   // the stages of 64 pixel rows + the waves' reduced sums
+  const size_t sm = (size_t)(p.Cin == 64 ? DAS_STREAM_K64_NS : (p.Cin == 128 ? DAS_STREAM_K128_NS : 4)) * ((p.Cin + 63) / 64) * 64 * 128 + 8 * 64 * sizeof(float);   // the stages of 64 pixel rows + the waves' reduced sums
   auto go = [&](auto kern) -> bool {
     static int per_cu = 0;   // (one static per template instance: the lambda is instantiated per kernel type)
     if (per_cu == 0) {
