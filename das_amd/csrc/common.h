@@ -199,6 +199,10 @@ __device__ __forceinline__ LvGeom lv_geom(const DasLevels& lv, long long m) {
   g.plane0 = start + (long long)g.b * hw;
   return g;
 }
+// 16-byte vectors per thread of the one-shot BatchNorm passes over large tensors (bn_apply_stream_kernel, bn_bwd_apply_dz_stream_kernel)
+#ifndef DAS_BN_STREAM_VPT
+#define DAS_BN_STREAM_VPT 4
+#endif
 // Minimum pixels per workgroup of the GroupNorm passes. `key` = das_tuning gn.ppb; 0 = automatic: as many as keep at least 448
 // workgroups (1.75 per CU) in the launch, within 256 ... 1024 — 1024 at the training batch (64 level x image segments: -0.5 ms per
 // step against 256, +0.7 with 2048), 256 at the inference batch (32 segments: 1024 there leaves CUs idle, -5 % img/s).

@@ -445,7 +445,7 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
       DAS_CHECK_LAUNCH();
       folded = ws;
     }
-    constexpr int VPT = 4;
+    constexpr int VPT = DAS_BN_STREAM_VPT;
     const int sgrid = (int)((count * vc + TPB * VPT - 1) / (TPB * VPT));
     const size_t ssm = 4 * (size_t)C * sizeof(float);
 #define DAS_BN_STREAM(T)                                                                                              \

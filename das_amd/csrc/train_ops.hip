@@ -1685,7 +1685,7 @@ extern "C" int das_bn_backward_apply(const void* dz, const void* raw, int dtype,
       DAS_CHECK_LAUNCH();
       folded = ws;
     }
-    constexpr int VPT = 4;
+    constexpr int VPT = DAS_BN_STREAM_VPT;
     const int sgrid = (int)((rows * vc + TPB * VPT - 1) / (TPB * VPT));
     const size_t ssm = 4 * (size_t)C * sizeof(float);
 #define DAS_BN_DZS(T)                                                                                                   \

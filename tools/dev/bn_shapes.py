@@ -9,6 +9,9 @@ from das_amd.datasets import SyntheticPoseDataset, collate
 from das_amd.optim import FlatSGD, train_iteration
 from das_amd import autograd as _ag
 _ag.WGRAD_SIDE_STREAM = False
+if os.environ.get('DASLIB'):   # dev: a variant build of the library
+    from das_amd import _lib as _l
+    _l.LIB_PATH = os.path.join(os.path.dirname(_l.LIB_PATH), os.environ['DASLIB'])
 dev = torch.device('cuda', 0)
 model = bench.build_model(dev, num_stages=4, train=True)
 ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=16, seed=0)
