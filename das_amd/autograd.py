@@ -270,6 +270,7 @@ def verify_rows(wait=False):
 
 
 _ROWS_SIGN = {}
+_ROWS_HOST, _ROWS_NEXT = [], [0]
 
 
 def _check_equal_rows(rows):
@@ -291,7 +292,14 @@ def _check_equal_rows(rows):
         t = torch.tensor([float(rows), -float(rows)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=stats_group())
     if t.is_cuda:
-        host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+        # (page-locked landing buffers reused round-robin — at most ROWS_CHECK_LAG + 1 answers are pending: allocating one per
+        # step waits for the device to drain whenever the allocator cannot reuse the previous step's, see detectors.LazyLogVars)
+        if len(_ROWS_HOST) < 8:
+            _ROWS_HOST.append(torch.empty(2, dtype=torch.float64, pin_memory=True))
+            host = _ROWS_HOST[-1]
+        else:
+            host = _ROWS_HOST[_ROWS_NEXT[0] % 8]
+            _ROWS_NEXT[0] += 1
         host.copy_(t, non_blocking=True)
         ev = torch.cuda.Event(blocking=True)
         ev.record()

@@ -30,11 +30,38 @@ class LazyLogVars(Mapping):
     the host only waits for it when a value is READ (mmdet's `_parse_losses` reads every value back right after the
     forward pass — a host synchronisation per step; the logger looks at them every `log_config.interval` steps)."""
 
+    # Page-locked landing buffers, reused round-robin: allocating one (hipHostMalloc) waits for the device to drain — with the host
+    # three steps ahead of the GPU that is a 100 ms stall, and torch's caching host allocator allocates a NEW block whenever the
+    # previous step's has not been released by the GPU yet, i.e. in every one of the first steps (seen as single 135-146 ms steps
+    # in a run with three warm-up steps). A slot is taken again when its previous owner is gone or has been read.
+    _RING, _NEXT = [], [0]
+
+    @classmethod
+    def _landing(cls, vals):
+        n = 8
+        while len(cls._RING) < n:
+            cls._RING.append([None, None])
+        for _ in range(n):
+            slot = cls._RING[cls._NEXT[0] % n]
+            cls._NEXT[0] += 1
+            owner = slot[1]() if slot[1] is not None else None
+            if owner is not None and owner._dict is None:
+                if owner._done is not None and not owner._done.query():
+                    continue                      # (still in flight: leave it alone)
+                owner.resolve()                   # (its copy has landed: read it out, the buffer is free)
+            if slot[0] is None or slot[0].shape != vals.shape or slot[0].dtype != vals.dtype:
+                slot[0] = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
+            return slot
+        return [torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True), None]
+
     def __init__(self, names, vals):
+        import weakref
         self.names = list(names)
         self._dict = None
         if vals.is_cuda:
-            self._host = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
+            slot = self._landing(vals)
+            slot[1] = weakref.ref(self)
+            self._host = slot[0]
             self._host.copy_(vals, non_blocking=True)
             self._done = torch.cuda.Event()
             self._done.record()
