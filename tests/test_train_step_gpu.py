@@ -188,3 +188,20 @@ def test_optimizer_state_with_a_frozen_parameter_matches_torch_layout():
     opt2 = FlatSGD(model2, **kw)
     opt2.load_state_dict(topt.state_dict())
     assert torch.equal(opt2.flat_m, opt.flat_m)
+
+
+def test_lazy_log_vars_landing_buffers_are_reused_without_mixing_steps_up():
+    """detectors.LazyLogVars reuses eight page-locked landing buffers round-robin (a fresh pinned allocation per step drains
+    the device while the host runs ahead): values read late — after their buffer has been handed to a later step — must still be
+    the values of THEIR step (the previous owner is read out before a slot is taken again)."""
+    from das_amd.detectors import LazyLogVars
+    kept = []
+    for i in range(40):
+        vals = torch.tensor([float(i), 2.0 * i, -1.0], device='cuda')
+        kept.append(LazyLogVars(['a', 'b', 'c'], vals))
+        if i % 7 == 3:
+            assert kept[i]['b'] == 2.0 * i          # (some are read at once, most much later)
+    torch.cuda.synchronize()
+    for i, lv in enumerate(kept):
+        assert dict(lv) == {'a': float(i), 'b': 2.0 * i, 'c': -1.0}, i
+    assert len(LazyLogVars._RING) == 8
