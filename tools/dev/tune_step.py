@@ -26,6 +26,21 @@ for _ in range(4):
 
 _UP_EV = data['gt_poses_3d'][0]._das_uploaded
 _hiccup = [0.0]
+_bwd_res = [0]
+_tb = torch.Tensor.backward
+
+
+def _backward(self, *a, **k):
+    if _bwd_res[0]:
+        lib.das_tuning_set(b'comm.reserved_cus', _bwd_res[0])
+    try:
+        return _tb(self, *a, **k)
+    finally:
+        if _bwd_res[0]:
+            lib.das_tuning_set(b'comm.reserved_cus', 0)
+
+
+torch.Tensor.backward = _backward
 _head_ft = model.bbox_head.forward_train
 
 
@@ -64,6 +79,8 @@ def run(cfg):
                         del t._das_uploaded
         elif k == 'SLEEP':         # a host hiccup of v ms in every step, right before the head is queued
             _hiccup[0] = int(v) * 1e-3
+        elif k == 'BWDRES':        # comm.reserved_cus = v during backward only (a CU budget beside the weight gradients' side stream)
+            _bwd_res[0] = int(v)
         elif k == 'SIDEPP':
             ag.SIDE_PP_BLOCKS = int(v)
         elif k == 'CHAIN':
@@ -94,6 +111,7 @@ def run(cfg):
     ag.DCN_FUSED = True
     ag.SIDE_PP_BLOCKS = 128
     _hiccup[0] = 0.0
+    _bwd_res[0] = 0
     for key in ('gt_poses_3d', 'centers2d', 'depths'):
         for t in data[key]:
             t._das_uploaded = _UP_EV
