@@ -327,8 +327,9 @@ def instrument_other_families(ops):
         setattr(lib, name, timed(getattr(lib, name), family, nb))
 
 
-PRICED_REPS = 5            # repetitions of the per-launch pass; per launch index the MINIMUM is priced
-PRICED_FIT = 1.02          # families_ms_sum must fit into the pass's own step time within this factor
+PRICED_REPS = 5            # repetitions of the per-launch pass; per launch index the MEDIAN is priced (the sum of per-launch
+                           # minima understates every single step: it made the self-check easier and fraction_of_roof kinder)
+PRICED_FIT = 1.02          # families_ms_sum must fit into the passes' MEDIAN step time within this factor
 PRICED_PASS_OVER_STEP = 1.15   # ... and the pass's step time must stay within this factor of the timed region's
 PRICED_RETRIES = 3
 
@@ -353,7 +354,7 @@ def _priced_pass(ops, run_step, reps):
 
 
 def _fold_passes(passes):
-    """Per family [flops, seconds (minimum per launch index over the passes), ops, bytes, launches, seconds (median)] of ONE
+    """Per family [flops, seconds (MEDIAN per launch index over the passes), ops, bytes, launches, seconds (minimum)] of ONE
     step. The launch sequence of a step is deterministic; should two passes disagree on it, the families' sums are
     compared instead (aligned = False)."""
     import statistics
@@ -364,11 +365,11 @@ def _fold_passes(passes):
             ts = [p[i][2] for p in passes]
             f = fam.setdefault(ent[0], [0.0, 0.0, 0, 0.0, 0, 0.0])
             f[0] += ent[1]
-            f[1] += min(ts) * 1e-3
+            f[1] += statistics.median(ts) * 1e-3
             f[2] += ent[3]
             f[3] += ent[4]
             f[4] += ent[5]
-            f[5] += statistics.median(ts) * 1e-3
+            f[5] += min(ts) * 1e-3
     else:
         per = []
         for p in passes:
@@ -379,8 +380,8 @@ def _fold_passes(passes):
             per.append(d)
         for k in per[0]:
             have = [d[k] for d in per if k in d]
-            best = min(have, key=lambda f: f[1])
-            fam[k] = best[:5] + [statistics.median(f[1] for f in have)]
+            mid = sorted(have, key=lambda f: f[1])[len(have) // 2]
+            fam[k] = mid[:5] + [min(f[1] for f in have)]
     return fam, aligned
 
 
@@ -388,8 +389,8 @@ def roofline_from_profile(ops, run_step, dtype, ms_per_step=None, reps=PRICED_RE
     """Event pairs recorded INSIDE the library around every launch of the conv families (forward, data gradient, the two
     weight-gradient kernel classes), of the BatchNorm passes and of every other HIP op of the step (OTHER_FAMILIES /
     OTHER_C) — das_prof_*, on the stream each launch goes to, nothing of the interpreter between an event and its launch.
-    `reps` single-step passes; a launch is priced at its MINIMUM over the passes (median reported beside it). The pass
-    checks itself: the families must fit into the pass's own step time (x PRICED_FIT) and that step time must stay within
+    `reps` single-step passes; a launch is priced at its MEDIAN over the passes (minimum reported beside it). The pass
+    checks itself: the families must fit into the passes' median step time (x PRICED_FIT) and that step time must stay within
     PRICED_PASS_OVER_STEP of the timed region's; otherwise the pass is repeated (PRICED_RETRIES times) and, failing
     that, `priced_step.unreliable` is set and the headline comes from roofline_hbm / roofline_mfma.
     Returns (roofline, roofline_mfma, roofline_hbm, roofline_bn, priced):
@@ -419,7 +420,7 @@ def roofline_from_profile(ops, run_step, dtype, ms_per_step=None, reps=PRICED_RE
             if not passes or not passes[0]:
                 return None, None, None, None, None
             fam, aligned = _fold_passes(passes)
-            wall_ms, wall_med = min(walls), statistics.median(walls)
+            wall_ms, wall_min = statistics.median(walls), min(walls)
             fam_sum = sum(f[1] for f in fam.values()) * 1e3
             bad = []
             if fam_sum > PRICED_FIT * wall_ms:
@@ -452,7 +453,7 @@ def roofline_from_profile(ops, run_step, dtype, ms_per_step=None, reps=PRICED_RE
         return dict(bound='mfma' if mfma else 'hbm', kernel=tag, achieved=round(ach, 2 if mfma else 1), peak=pk,
                     unit='TFLOP/s' if mfma else 'GB/s', frac=round(ach / pk, 4), traffic=None, selection=rule,
                     launches_per_step=nl, ops_per_step=nops, avg_launch_us=round(sec / max(nl, 1) * 1e6, 2),
-                    family_ms_per_step=round(sec * 1e3, 3), family_ms_per_step_median=round(v[5] * 1e3, 3),
+                    family_ms_per_step=round(sec * 1e3, 3), family_ms_per_step_min=round(v[5] * 1e3, 3),
                     algorithmic_mb_per_launch=round(by / max(nl, 1) / 1e6, 2),
                     flop_per_byte=round(fl / max(by, 1.0), 1), ridge_flop_per_byte=round(ridge, 1),
                     tflops=round(fl / sec / 1e12, 2), gbs=round(by / sec / 1e9, 1))
@@ -488,25 +489,25 @@ def roofline_from_profile(ops, run_step, dtype, ms_per_step=None, reps=PRICED_RE
                      'are roofline_bn, which may exceed this family')
     roof['all_families'] = {k: dict(tflops=round(x[0] / x[1] / 1e12, 2), gbs=round(x[3] / x[1] / 1e9, 1),
                                     flop_per_byte=round(x[0] / max(x[3], 1.0), 1), ms_per_step=round(x[1] * 1e3, 3),
-                                    ms_per_step_median=round(x[5] * 1e3, 3), launches=x[4], ops=x[2])
+                                    ms_per_step_min=round(x[5] * 1e3, 3), launches=x[4], ops=x[2])
                             for k, x in fam.items()}
     # every millisecond of the step: families + the rest (ATen glue launches, launch gaps, event overhead of this pass)
     fam_ms = {k: x[1] * 1e3 for k, x in fam.items()}
     at_roof = 0.0
     for k, x in fam.items():
         at_roof += max(x[0] / (peak * 1e12), x[3] / (PEAK_HBM_GBS * 1e9)) * 1e3
-    priced = dict(step_ms_this_pass=round(wall_ms, 3), step_ms_this_pass_median=round(wall_med, 3),
+    priced = dict(step_ms_this_pass=round(wall_ms, 3), step_ms_this_pass_min=round(wall_min, 3),
                   reps=reps, attempts=attempts, launch_sequences_aligned=aligned, unreliable=unreliable,
                   checks=dict(families_fit_step=f'families_ms_sum <= {PRICED_FIT} x step_ms_this_pass',
                               pass_vs_timed_step=f'step_ms_this_pass <= {PRICED_PASS_OVER_STEP} x ms_per_step',
                               timed_ms_per_step=None if ms_per_step is None else round(ms_per_step, 3),
                               failures=problems),
                   note='weight gradients on the main stream; one HIP event pair per C entry point, recorded inside the '
-                       'library right around its launches (das_prof_*); each launch priced at its minimum over the '
-                       'repetitions (families_ms_median: the median instead); every family at max(FLOPs / MFMA peak, '
+                       'library right around its launches (das_prof_*); each launch priced at its MEDIAN over the '
+                       'repetitions, step_ms_this_pass = the median pass (families_ms_min: the minima instead); every family at max(FLOPs / MFMA peak, '
                        'algorithmic bytes / HBM peak) gives families_ms_at_roof',
                   families_ms={k: round(v, 3) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])},
-                  families_ms_median={k: round(x[5] * 1e3, 3) for k, x in sorted(fam.items(), key=lambda kv: -kv[1][1])},
+                  families_ms_min={k: round(x[5] * 1e3, 3) for k, x in sorted(fam.items(), key=lambda kv: -kv[1][1])},
                   families_ms_sum=round(sum(fam_ms.values()), 3), families_ms_at_roof=round(at_roof, 3),
                   fraction_of_roof=round(at_roof / max(sum(fam_ms.values()), 1e-9), 4),
                   torch_glue_and_gaps_ms=round(wall_ms - sum(fam_ms.values()), 3))
@@ -886,10 +887,11 @@ def main():
     # generation-2 collection over the autograd graphs of a few steps is a 20-100 ms host pause (seen as single 106 / 191 ms
     # steps among 83 ms ones, tools/dev/first_process_steps.py) — over 20 timed steps one such pause is 1-5 ms per step of
     # noise that has nothing to do with the path measured. Reference counting still frees every step's tensors.
-    import gc
-    gc.collect()
-    gc.freeze()
-    gc.disable()
+    # The SAME policy as the shipped loop (das_amd.optim.GcPark, used by tools/train.py): parked after warm-up, collected at
+    # the loop's quiet points (logging intervals, checkpoints) — none of which fall inside 20 timed steps.
+    from das_amd.optim import GcPark
+    gcp = GcPark(warmup=0)
+    gcp.park()
     sync_all()
     # (one event behind every timed step: the spread of the steps inside the timed region goes into the line beside their mean)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
@@ -927,8 +929,7 @@ def main():
         if r is not None:
             attach_traffic(r, 'train' if train else 'infer', batch)
 
-    gc.enable()
-    gc.unfreeze()
+    gcp.release()
     also = None
     if train and world == 1 and not args.no_also:
         also = also_workloads(args, dev, model, opt, data)

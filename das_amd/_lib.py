@@ -84,6 +84,7 @@ SIGNATURES = {
     'das_tuning_set': (i32, [C.c_char_p, i64]),
     'das_tuning_get': (i32, [C.c_char_p, C.POINTER(i64)]),
     'das_tuning_reset': (i32, []),
+    'das_wgrad_pp_share': (i32, [i32]),
     'das_dev_occupy_cus': (i32, [i32, i32, i32, i32, vp]),
     'das_last_kernel': (C.c_char_p, []),
     'das_conv_last_tile_rows': (i32, []),

@@ -74,13 +74,12 @@ def wgrad_streams():
 
 
 # Grid of conv_wgrad_pp_kernel (one 128 KiB-LDS workgroup per CU) while it runs on the side stream BESIDE the backward's main-stream
-# kernels: 128 workgroups — half the chip — instead of one per CU. A full-chip persistent grid and the main stream's kernels
-# time-slice every CU; on half the chip each the two run side by side: -0.8 / -1.0 ms per step on two boxes (tools/dev/tune_step.py
-# wgrad.pp_blocks = 64 ... 224, interleaved: 96 -0.3, 112 -0.5, 128 -0.8, 144 +0.1, 192 -0.3; measurable only since the host no
-# longer runs in lockstep with the GPU: the step's run-to-run range on a box fell from +-0.5 to +-0.1 ms). Launched on the main
-# stream (WGRAD_SIDE_STREAM off, the per-launch pricing passes of bench.py) the kernel keeps the whole chip. 0 = off. Left alone
-# when the key is set explicitly (set_wgrad_streams, das_tuning_set).
-SIDE_PP_BLOCKS = 128
+# kernels: HALF the usable CUs (device CUs minus comm.reserved_cus, / SIDE_PP_SHARE) instead of one workgroup per CU. A full-chip
+# persistent grid and the main stream's kernels time-slice every CU; on half the chip each the two run side by side: -0.8 / -1.0 ms
+# per step on two boxes (tools/dev/tune_step.py wgrad.pp_blocks = 64 ... 224 of 256, interleaved: 96 -0.3, 112 -0.5, 128 -0.8,
+# 144 +0.1, 192 -0.3). Launched on the main stream (WGRAD_SIDE_STREAM off, the per-launch pricing passes of bench.py) the kernel
+# keeps the whole chip. 1 = off. An explicit wgrad.pp_blocks (set_wgrad_streams, das_tuning_set) wins over the share.
+SIDE_PP_SHARE = 2
 
 
 class _on_side:
@@ -111,21 +110,20 @@ class _on_side:
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         self.ent, self.dev = ent, dev
-        # the ping-pong weight-gradient kernel on HALF the chip while it runs beside the main stream (see SIDE_PP_BLOCKS)
+        # the ping-pong weight-gradient kernel on HALF the usable CUs while it runs beside the main stream (SIDE_PP_SHARE):
+        # a per-thread setting of the library, not a process-global tuning key — other threads' launches never see it
         self.grid = None
-        if SIDE_PP_BLOCKS > 0 and len(ent[0]) == 1:
+        if SIDE_PP_SHARE > 1 and len(ent[0]) == 1:
             from . import _lib
-            import ctypes
-            lib, cur = _lib.load(), ctypes.c_longlong()
-            if lib.das_tuning_get(b'wgrad.pp_blocks', ctypes.byref(cur)) == 0 and cur.value == 0:
-                lib.das_tuning_set(b'wgrad.pp_blocks', SIDE_PP_BLOCKS)
+            lib = _lib.load()
+            if lib.das_wgrad_pp_share(SIDE_PP_SHARE) == 0:
                 self.grid = lib
         return self
 
     def __exit__(self, *exc):
         if self.ctx is not None:
             if self.grid is not None:
-                self.grid.das_tuning_set(b'wgrad.pp_blocks', 0)
+                self.grid.das_wgrad_pp_share(1)
             self.ctx.__exit__(*exc)
             if self.ent[2] is None:
                 _join_side(self.dev.index)

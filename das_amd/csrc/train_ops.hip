@@ -1408,7 +1408,9 @@ int wgrad_launch_class(HostWgrad** ops, int n, int cls, int accumulate, hipStrea
   const long long ucus = dastune::usable_cus();   // (the device's CUs minus comm.reserved_cus)
   if (cls == 0) {
     const long long forced = dastune::get(dastune::WGRAD_PP_BLOCKS);
-    grid = forced > 0 ? forced : ucus;
+    // (0: one workgroup per usable CU, or the calling thread's share of them — das_wgrad_pp_share: the launches a side stream
+    // runs beside the main stream's kernels)
+    grid = forced > 0 ? forced : std::max<long long>(8, ucus / dastune::pp_share_den());
   } else {
     const long long forced = dastune::get(dastune::WGRAD_BLOCKS);
     grid = forced > 0 ? forced : (cls == 1 && bkm == 32 ? 3 : 2) * ucus;

@@ -56,6 +56,9 @@ long long get(Key k);
 // the device's minus comm.reserved_cus (left to the RCCL kernels of an overlapped gradient all-reduce), at least 8.
 int device_cus();
 int usable_cus();
+// The calling thread's share of the chip for conv_wgrad_pp_kernel's grid (das_wgrad_pp_share): grid = usable_cus() / den
+// while wgrad.pp_blocks is 0. Thread-local: a side-stream scope in one thread never changes another thread's launches.
+int pp_share_den();
 // `name` must be a string literal (kept by pointer): the kernel the calling thread's last launcher call picked
 void note_kernel(const char* name);
 // note_kernel calls of the calling thread so far (prof.hip: did the entry point inside this scope pick a kernel?)

@@ -62,9 +62,17 @@ int usable_cus() {
   const long long u = c - (r > 0 ? r : 0);
   return (int)(u < 8 ? 8 : u);
 }
+static thread_local int t_pp_share_den = 1;
+int pp_share_den() { return t_pp_share_den; }
 }  // namespace dastune
 
 using namespace dastune;
+
+extern "C" int das_wgrad_pp_share(int den) {
+  if (den < 1 || den > 16) return DAS_ERR_ARG;
+  dastune::t_pp_share_den = den;
+  return DAS_OK;
+}
 
 extern "C" int das_tuning_set(const char* key, long long value) {
   if (!key) return DAS_ERR_ARG;

@@ -249,7 +249,9 @@ def match_people(gt_poses, pred_poses, o1, trav, threshold=250):
 
     def pick(dist):
         best = dist.argmin(axis=1)
-        ok = dist[np.arange(len(dist)), best] <= threshold
+        # the reference's predicate (`diffs.min() > threshold` -> -1, :556-565): a NaN distance (a frame whose only
+        # "prediction" is the all-zero stand-in: root depth 0) is NOT greater than the threshold and keeps index 0
+        ok = ~(dist[np.arange(len(dist)), best] > threshold)
         return [int(i) if k else -1 for i, k in zip(best, ok)]
     return pick(rel), pick(absolute)
 

@@ -514,7 +514,7 @@ def dcn_v2(x, dcn):
         minrows = ctypes.c_longlong()
         _lib.load().das_tuning_get(b'dcn.fused_minrows', ctypes.byref(minrows))
         rows = _tensor(x).numel() // C
-        if ag.DCN_FUSED or (minrows.value > 0 and rows >= minrows.value):
+        if ag.DCN_FUSED and minrows.value > 0 and rows >= minrows.value:   # (ag.DCN_FUSED: the A/B switch, off = never)
             return ops.dcn3x3_fused(x, om, w, shift)
     col = ops.deform_im2col3x3(x, om)
     return ops.conv2d(col, w, 1, 1, shift=shift)

@@ -511,6 +511,51 @@ def build_optimizer(model, cfg, optimizer_config=None):
                    bias_decay_mult=pw.get('bias_decay_mult', 1.0), max_grad_norm=clip.get('max_norm', 0.0))
 
 
+class GcPark:
+    """The training loop's policy for the interpreter's cyclic garbage collector, shared by tools/train.py and bench.py so
+    that the benchmarked step IS the shipped step. A generation-2 collection over the autograd graphs of a few steps is a
+    20-100 ms host pause (single 106 / 191 ms steps among 83 ms ones: tools/dev/first_process_steps.py). After `warmup`
+    steps — model, optimizer, schedules and workspaces exist and will live for the whole run — everything alive is moved
+    to the permanent generation (gc.freeze) and automatic collection is switched off; reference counting still frees every
+    step's tensors, and the cycles a step does leave behind are collected at the caller's own quiet points
+    (`collect()`: logging intervals, checkpoints, epoch ends), where a pause costs nothing."""
+
+    def __init__(self, warmup=3):
+        self.warmup, self.steps, self.parked = warmup, 0, False
+
+    def step(self):
+        self.steps += 1
+        if not self.parked and self.steps >= self.warmup:
+            self.park()
+
+    def park(self):
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+        self.parked = True
+
+    def collect(self):
+        import gc
+        if self.parked:
+            gc.collect()
+
+    def release(self):
+        import gc
+        if self.parked:
+            gc.enable()
+            gc.unfreeze()
+            self.parked = False
+
+
+def finish_checks():
+    """Everything a training loop must have looked at before it saves weights, evaluates or ends: the SyncBN row-count
+    answers that are still in flight (autograd.verify_rows reads them up to ROWS_CHECK_LAG steps late; a mismatch in the last
+    steps before a checkpoint would otherwise be saved unreported). Cheap: the events have long completed."""
+    from . import autograd
+    autograd.verify_rows(wait=True)
+
+
 MAX_RUN_AHEAD = 3     # steps the host may queue beyond the one the GPU runs (0 = unbounded; see train_iteration)
 
 

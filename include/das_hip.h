@@ -55,6 +55,12 @@ const char* das_target_arch(void);
 int das_tuning_set(const char* key, long long value);
 int das_tuning_get(const char* key, long long* value);
 int das_tuning_reset(void);
+/* The CALLING THREAD's share of the chip for the 256 x 256 ping-pong weight-gradient kernel while key wgrad.pp_blocks is 0:
+ * its grid becomes (device CUs - comm.reserved_cus) / den workgroups (den = 1: the whole chip, the default). Set to 2 around
+ * the weight-gradient launches that run on a side stream beside the main stream's kernels (das_amd.autograd._on_side) and
+ * back to 1 afterwards; thread-local, so another thread's launches (another model or device in the process) never see it.
+ * den outside 1..16: DAS_ERR_ARG. No reference counterpart (torch's autograd engine has no such control). */
+int das_wgrad_pp_share(int den);
 /* Name of the kernel the calling thread's last das_conv2d_nhwc / das_conv2d_wgrad_nhwc call launched
  * ("conv_glds4_kernel<pp>", "conv1x1_stream_kernel", ...): lets a parity test assert WHICH kernel it checked. */
 const char* das_last_kernel(void);

@@ -77,6 +77,16 @@ def test_mupots_helpers_vs_reference(golden_dir):
     np.testing.assert_allclose(back, X, atol=2e-2)       # (world2pixel divides by z + 1e-5)
 
 
+def test_match_people_keeps_index_0_for_nan_distances():
+    """`match` (mupots_3dhp.py:556-565) tests `diffs.min() > threshold`: False for NaN, so the all-zero stand-in of a frame
+    without predictions is matched (index 0), not dropped (-1) — matched-mode PCK counts those persons as misses."""
+    rs = np.random.RandomState(5)
+    gt = [rs.normal(0, 300, (3, 17)) + np.array([[0.0], [0.0], [3000.0]]) for _ in range(3)]
+    with np.errstate(all='ignore'):
+        rel, ab = E.match_people(gt, np.zeros((1, 3, 17)), E.MPII_O1, E.SAFE_TRAVERSAL[1:])
+    assert rel == [0, 0, 0] and ab == [0, 0, 0]
+
+
 def test_mupots_helpers_live_against_the_reference_over_random_frames():
     """Authoring container only: the batched helpers against the reference's one-pair-at-a-time functions imported
     from /root/reference (mupots_3dhp.py:480-566) on 40 random frames, incl. frames whose closest prediction is too far."""
@@ -102,6 +112,14 @@ def test_mupots_helpers_live_against_the_reference_over_random_frames():
         np.testing.assert_allclose(E.procrustes(a.copy(), b.copy()), mup.procrustes(a.copy(), b.copy()), rtol=1e-9, atol=1e-8)
         np.testing.assert_allclose(E.norm_by_bone_length(a.copy(), b.copy(), o1, trav),
                                    mup.norm_by_bone_length(a.copy(), b.copy(), o1, trav), rtol=1e-12)
+    # a frame with no valid prediction: the caller's stand-in is one all-zero pose (root depth 0 -> NaN distances);
+    # the reference's `diffs.min() > threshold` is False for NaN, so every GT person is matched to index 0
+    gt = [rs.normal(0, 300, (3, 17)) + np.array([[0.0], [0.0], [3000.0]]) for _ in range(2)]
+    zero = np.zeros((1, 3, 17))
+    with np.errstate(all='ignore'):
+        ref = mup.match(gt, zero.copy(), o1, trav)
+        got = E.match_people(gt, zero.copy(), o1, trav)
+    assert [int(i) for i in ref[0]] == got[0] == [0, 0] and [int(i) for i in ref[1]] == got[1] == [0, 0]
     # batched alignment == pair by pair
     A, B = rs.normal(0, 100, (5, 3, 17)), rs.normal(0, 100, (5, 3, 17))
     np.testing.assert_allclose(E.procrustes(A, B), np.stack([E.procrustes(x, y) for x, y in zip(A, B)]), rtol=1e-12)

@@ -176,9 +176,70 @@ def test_mupots_three_stage_full_width_eval_f32_maps_and_decode_match_the_oracle
     check_poses_at_the_bar('exp_mupots 3-stage 768x1024', ref, out, spread, 1024, 768)
 
 
+BN_MOMENTUM = 0.1
+
+
+def bn_batch_stats(sd, prefix=''):
+    """{layer: (batch mean, unbiased batch variance)} in f64, recovered from the running statistics of BatchNorm layers that
+    have seen exactly ONE train-mode forward since init (running_mean 0 / running_var 1, momentum 0.1:
+    rm = 0.1 m, rv = 0.9 + 0.1 v — torch BatchNorm2d, mspn_mmpose.py:74-79)."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith('.running_mean'):
+            base = k[:-len('.running_mean')]
+            rv = sd[base + '.running_var']
+            out[prefix + base] = (v.detach().double().cpu() / BN_MOMENTUM,
+                                  (rv.detach().double().cpu() - (1 - BN_MOMENTUM)) / BN_MOMENTUM)
+    return out
+
+
+def bn_stat_errors(got, ref):
+    """Per layer (err_mean, err_var): max over channels of |batch mean - ref| in units of the layer's RMS activation
+    sqrt(mean_c(var + mean^2)), and of |batch var - ref| in units of the layer's mean variance. Scale-free per layer; a layer
+    whose statistics were lost (mean 0 / variance 0: the round-4 arena bug, commit 6237e9b) scores ~1."""
+    assert set(got) == set(ref), sorted(set(got) ^ set(ref))[:8]
+    out = {}
+    for k, (m, v) in ref.items():
+        gm, gv = got[k]
+        scale2 = float((v + m * m).mean())
+        out[k] = (float((gm - m).abs().max()) / max(scale2, 1e-30) ** 0.5, float((gv - v).abs().max()) / max(float(v.mean()), 1e-30))
+    return out
+
+
+def stage_of(layer):
+    """'top', 'stage0' ... 'stage3', 'neck' — the group a BatchNorm layer's bound is stated for."""
+    if layer.startswith('backbone.multi_stage_mspn.'):
+        return 'stage' + layer.split('.')[2]
+    return 'neck' if layer.startswith('neck.') else 'top'
+
+
+def worst_by_stage(errs):
+    w = {}
+    for k, (em, ev) in errs.items():
+        g = stage_of(k)
+        a = w.setdefault(g, [0.0, 0.0, 0])
+        a[0], a[1], a[2] = max(a[0], em), max(a[1], ev), a[2] + 1
+    return w
+
+
+_TRAIN_CASES = {}
+
+
 def train_losses_case(stages):
     """One train-mode forward + the four losses at B = 2 (batch statistics over two frames), full width, 512 x 832:
-    the oracle in f64, the HIP path in f32 and in bf16 on the same weights and frames."""
+    the oracle in f64, the HIP path in f32 and in bf16 on the same weights and frames. Returns the three loss dicts;
+    train_stats_case(stages) the batch statistics of every BatchNorm layer of the same three runs (one run per session)."""
+    if stages not in _TRAIN_CASES:
+        _TRAIN_CASES[stages] = _train_losses_case(stages)
+    return _TRAIN_CASES[stages][:3]
+
+
+def train_stats_case(stages):
+    train_losses_case(stages)
+    return _TRAIN_CASES[stages][3:]
+
+
+def _train_losses_case(stages):
     import bench
     from das_amd.datasets import SyntheticPoseDataset, collate
     from oracle import backbone as ob, head as oh, loss as ol
@@ -196,18 +257,22 @@ def train_losses_case(stages):
         feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img.to(dt), stages, (3, 4, 6, 3), train=True), train=True)
         outs = oh.head_forward(hsd, feats, hcfg, '', True)
         truth = {k: float(v) for k, v in ol.head_loss(hsd, '', *outs, g, hcfg).items()}
+    # (the oracle's train-mode BatchNorm updated bsd / nsd in place: oracle/nn_ops.py batch_norm)
+    st_ref = {**bn_batch_stats(bsd, 'backbone.'), **bn_batch_stats(nsd, 'neck.')}
     data = collate(ss, device=DEV)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     model.to(DEV).train()
     with torch.no_grad():
         l32 = {k: float(v) for k, v in model.train_step(data)['log_vars'].items()}
+    st32 = bn_batch_stats(model.state_dict())
     mb = build(bench.model_cfg(stages, 'bf16'), 0)
     mb.load_state_dict(sd0)
     mb.to(DEV).train()
     with torch.no_grad():
         lbf = {k: float(v) for k, v in mb.train_step(data)['log_vars'].items()}
+    stbf = bn_batch_stats(mb.state_dict())
     print(f'full-width {stages}-stage train losses  oracle f64:', truth, ' hip f32:', l32, ' hip bf16:', lbf)
-    return truth, l32, lbf
+    return truth, l32, lbf, st_ref, st32, stbf
 
 
 def test_one_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
@@ -219,6 +284,81 @@ def test_one_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
     for k, t in truth.items():
         assert abs(l32[k] - t) <= 1e-4 * abs(t), (k, l32[k], t)
         assert abs(lbf[k] - l32[k]) <= 4e-2 * abs(l32[k]), (k, lbf[k], l32[k])
+
+
+# Per-layer BatchNorm statistics after ONE train-mode forward, HIP f32 vs the oracle's f64 (bn_stat_errors: error of the batch
+# mean in units of the layer's RMS activation, of the batch variance in units of the layer's mean variance; worst layer per
+# group). A layer's statistics are per-channel means over 2 x H x W samples: they do not amplify like the losses do, so
+# these are sharp where the 4-stage losses can only be banded. Bounds = ~4x the maxima measured on MI355X
+# (profiles/r06_bn_stats_parity.txt). A layer that lost its statistics (the arena bug of commit 6237e9b) scores ~1.
+BN_STATS_BOUND_1STAGE = dict(top=1e-3, stage0=1e-3, neck=1e-3)
+BN_STATS_BOUND_4STAGE = dict(top=1e-3, stage0=1e-3, stage1=1e-2, stage2=5e-2, stage3=5e-2, neck=5e-2)
+
+
+def check_bn_stats(tag, got, ref, bound):
+    errs = bn_stat_errors(got, ref)
+    worst = worst_by_stage(errs)
+    print(f'{tag}: BatchNorm batch statistics, worst layer per group (err_mean, err_var, layers): ' +
+          ', '.join(f'{g} {w[0]:.2e} {w[1]:.2e} ({w[2]})' for g, w in sorted(worst.items())))
+    bad = [(k, e) for k, e in errs.items() if max(e) > bound[stage_of(k)]]
+    assert not bad, (tag, len(bad), sorted(bad, key=lambda t: -max(t[1]))[:6])
+    return worst
+
+
+def test_one_stage_full_width_every_batchnorm_layers_statistics_f32_vs_oracle():
+    """after ONE train-mode step (B = 2, 512 x 832, f32) EVERY BatchNorm layer's running_mean / running_var
+    against the oracle's (oracle/nn_ops.py batch_norm updates them in place; mspn_mmpose.py:74-79,273-274): 60 backbone
+    + 8 neck layers of the 1-stage net within 1e-3 (layer-relative, see bn_stat_errors)."""
+    st_ref, st32, _ = train_stats_case(1)
+    assert len(st_ref) >= 60
+    check_bn_stats('1-stage f32 vs oracle f64', st32, st_ref, BN_STATS_BOUND_1STAGE)
+
+
+def test_four_stage_full_width_every_batchnorm_layers_statistics_f32_vs_oracle():
+    """The benchmarked 4-stage topology: 264 backbone BatchNorm layers + the neck's. The first stage (and the stem) within
+    1e-3; the later stages see inputs that already differ at the 1e-4 level through the ReLU flips of ~70 layers each
+    (the same effect that makes the LOSSES of this net chaotic at the percent level), so their bound is the measured one
+    per stage — still two orders of magnitude below what a lost or stale statistic produces (~1)."""
+    st_ref, st32, _ = train_stats_case(4)
+    assert len(st_ref) >= 264
+    check_bn_stats('4-stage f32 vs oracle f64', st32, st_ref, BN_STATS_BOUND_4STAGE)
+
+
+def test_batchnorm_statistics_survive_arena_wraps_inside_one_step():
+    """The statistics accumulators come from a zero-filled arena that is refilled when used up (das_amd.nn._ZeroArena). With
+    the arena shrunk so that it wraps every few layers, one 1-stage train-mode forward must give the SAME per-layer statistics
+    as with the default 16 MiB arena (float-atomic order is the only difference: 1e-5). The one-buffer arena of rounds 3-4
+    (commit 6237e9b fixed it) fails this on the layer pairs that hold two slices at once — shown once with the fix reverted
+    in profiles/r06_bn_stats_test_catches_arena_bug.txt (tools/dev/arena_revert_demo.py)."""
+    import bench
+    from das_amd import nn as dnn
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=2, seed=0)
+    data = collate([ds[i] for i in range(2)], device=DEV)
+    model = build(bench.model_cfg(1, 'f32'), 0)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    stats = []
+    keep = dnn._STATS_ARENA
+    try:
+        # (64K floats and up: the largest slice of the step, 8 slots x 2 x 2048 channels, still fits; six sizes move the wrap
+        # points across the layer sequence)
+        for cap in (keep.cap,) + tuple((1 << 16) + 4096 * i for i in range(6)):
+            dnn._STATS_ARENA = type(keep)(cap=cap)
+            m = build(bench.model_cfg(1, 'f32'), 0)
+            m.load_state_dict(sd0)
+            m.to(DEV).train()
+            with torch.no_grad():
+                m.train_step(data)
+            torch.cuda.synchronize()
+            stats.append(bn_batch_stats(m.state_dict()))
+            del m
+    finally:
+        dnn._STATS_ARENA = keep
+    for st in stats[1:]:
+        errs = bn_stat_errors(st, stats[0])
+        worst = max(errs.items(), key=lambda kv: max(kv[1]))
+        print('arena 4M floats vs a small one: worst layer', worst)
+        assert max(worst[1]) < 1e-4, worst
 
 
 def test_four_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
@@ -334,6 +474,7 @@ B16_KERNELS = ('conv_glds4_kernel<pp,288>', 'conv_glds4_kernel<pp>', 'conv_glds3
 # (measured: bf16 0.16 % / 0.08 % / 0.09 % (cls, depth, centerness) and 0.45 % (pose) from f32 — statistics over 16 frames are far
 # less chaotic than over 2; bands ~10x the measured values, a draw of the float atomics included)
 B16_BAND = dict(loss_cls=0.02, loss_depth=0.02, loss_centerness=0.02, loss_pose=0.04, loss=0.04)
+B16_STATS_BOUND = dict(top=0.1, stage0=0.1, stage1=0.1, stage2=0.1, stage3=0.1, neck=0.1)
 
 
 def test_benchmarked_b16_step_bf16_losses_follow_f32_and_dispatch_the_benchmarked_kernels():
@@ -354,6 +495,7 @@ def test_benchmarked_b16_step_bf16_losses_follow_f32_and_dispatch_the_benchmarke
     m32.to(DEV).train()
     with torch.no_grad():
         l32 = {k: float(v) for k, v in m32.train_step(data)['log_vars'].items()}
+    st32 = bn_batch_stats(m32.state_dict())
     del m32
     torch.cuda.empty_cache()
     mb = build(bench.model_cfg(4, 'bf16'), 0)
@@ -372,6 +514,9 @@ def test_benchmarked_b16_step_bf16_losses_follow_f32_and_dispatch_the_benchmarke
     for k, t in l32.items():
         assert np.isfinite(lbf[k]) and abs(lbf[k] - t) <= B16_BAND.get(k, 0.2) * abs(t), (k, lbf[k], t)
     assert all(torch.isfinite(p).all() for p in mb.parameters())
+    # every BatchNorm layer's batch statistics of the bf16 step against the f32 forward's (bf16 rounds every
+    # stored activation to 8 bits: errors of 1e-3 ... 1e-2 of a layer's scale, measured profiles/r06_bn_stats_parity.txt)
+    check_bn_stats('B = 16 4-stage bf16 vs hip f32', bn_batch_stats(mb.state_dict()), st32, B16_STATS_BOUND)
 
 
 def test_four_stage_full_width_eval_f32_maps_and_decode_match_the_oracle():

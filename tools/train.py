@@ -18,7 +18,7 @@ import das_amd  # noqa: E402
 from das_amd.config import parse_cfg_options  # noqa: E402
 from das_amd.datasets import build_dataset, collate, collect_results  # noqa: E402
 from das_amd.loader import PrefetchLoader, ProcessLoader  # noqa: E402
-from das_amd.optim import build_optimizer, step_lr, train_iteration  # noqa: E402
+from das_amd.optim import GcPark, build_optimizer, finish_checks, step_lr, train_iteration  # noqa: E402
 
 
 def parse_args():
@@ -147,6 +147,7 @@ def _train(args, cfg, work_dir, distributed, local_rank, pool):
     want_graphs = bool(cfg.get('hip_graphs', False))
     max_epochs = cfg.get('runner', {}).get('max_epochs', 12)
     log_every = cfg.get('log_config', {}).get('interval', 50)
+    gcp = GcPark()      # cyclic GC parked after warm-up, collected at logging / checkpoint points (as bench.py measures)
     for epoch in range(start_epoch, max_epochs):
         order = torch.randperm(len(dataset), generator=torch.Generator().manual_seed(args.seed + epoch)).tolist()
         # torch DistributedSampler semantics (mmdet's samplers build on it): pad by wrapping around to a multiple of
@@ -167,6 +168,7 @@ def _train(args, cfg, work_dir, distributed, local_rank, pool):
                          warmup_ratio=lrc.get('warmup_ratio', 1.0))
             out = train_iteration(model, opt, data, lr)
             it += 1
+            gcp.step()
             if want_graphs and getattr(model, '_graphed_trunk', None) is None:
                 # `hip_graphs=True` (fixed input size; with several ranks a trunk without SyncBN layers): after the first step — every workspace and
                 # schedule exists — the backbone + neck forward / backward of batches shaped like this one are captured
@@ -185,8 +187,12 @@ def _train(args, cfg, work_dir, distributed, local_rank, pool):
                 lv = ', '.join(f'{k}: {v:.4f}' for k, v in out['log_vars'].items())
                 print(f'Epoch [{epoch + 1}][{b // spg + 1}/{len(order) // spg}] lr: {lr:.3e}, '
                       f'{(time.time() - t0) / (b // spg + 1):.3f} s/it, {lv}', flush=True)
+            if it % log_every == 0:
+                gcp.collect()
             if args.max_iters and it >= args.max_iters:
                 break
+        finish_checks()      # (SyncBN row-count answers still in flight: a mismatch must not reach a checkpoint unreported)
+        gcp.collect()
         if rank == 0:  # CheckpointHook(interval=1): state_dict + meta (tools/train.py:200-210)
             # dense OIHW copies on the host: the live parameters are channels-last views of the optimizer's
             # flat buffer, and a checkpoint must load into the reference (mmcv) as well
@@ -201,6 +207,8 @@ def _train(args, cfg, work_dir, distributed, local_rank, pool):
                 print(f'Epoch(val) [{epoch + 1}] {metrics}', flush=True)
         if args.max_iters and it >= args.max_iters:
             break
+    finish_checks()
+    gcp.release()
     if distributed:
         torch.distributed.destroy_process_group()
 
