@@ -597,9 +597,22 @@ def decode_workload(args, rank, world, dev, quiet=False, batch=None, steps=None,
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        # per-rank wall clock of the timed region, gathered so that the first real multi-GPU line explains itself (a slow
+        # rank, a straggling bucket): value / ms_per_step use the MAX, as the contract says
+        mine = torch.tensor([dt, per[len(per) // 2] * 1e-3], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dts = [float(a[0]) for a in allr]
+        extra['ranks_ms_per_step'] = dict(min=round(min(dts) / steps * 1e3, 3), max=round(max(dts) / steps * 1e3, 3),
+                                          per_rank=[round(x / steps * 1e3, 3) for x in dts],
+                                          per_rank_median_gpu_step=[round(float(a[1]) * 1e3, 3) for a in allr])
+        dt = max(dts)
+    if train and comm is not None:
+        comm.update(grad_comm_dtype=str(opt.grad_comm_dtype).replace('torch.', ''), buckets=len(opt.buckets),
+                    bucket_mb=[round((e - s) * (2 if opt.grad_comm_dtype == torch.bfloat16 else 4) / 2 ** 20, 1)
+                               for s, e in opt.buckets],
+                    end_only_buckets=int(sum(opt._endonly)), overlapped_launches_total=opt.overlapped_launches,
+                    reserved_cus_while_in_flight=opt.comm_reserved_cus)
     if rank != 0:
         return
     kern_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / steps     # events bracket the launch on its stream
@@ -759,6 +772,8 @@ def main():
     ap.add_argument('--norm', default='BN', choices=['BN', 'SyncBN'],
                     help='norm_cfg type of backbone and neck: SyncBN is what the reference ships (exp_panoptic.py:20,28); '
                          'with one rank it is plain BatchNorm arithmetic')
+    ap.add_argument('--grad-comm', default='f32', choices=['f32', 'bf16'],
+                    help='dtype the gradient buckets travel in over RCCL (f32 = the reference\'s DDP; bf16 halves the bytes)')
     ap.add_argument('--no-also', action='store_true',
                     help='skip the short infer / decode measurements appended to the train line (`also`)')
     ap.add_argument('--graph-side-stream', action='store_true', help='A/B: capture the weight gradients on their side streams')
@@ -844,7 +859,7 @@ def main():
     if train:
         from das_amd.optim import FlatSGD, step_lr, train_iteration
         opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0,
-                      max_grad_norm=35.0)
+                      max_grad_norm=35.0, grad_comm_dtype=args.grad_comm)
         it = [0]
 
         def step():
@@ -915,9 +930,22 @@ def main():
     if graphs is not None:     # the per-launch measurement passes below need every launch queued by hand
         model._graphed_trunk = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        # per-rank wall clock of the timed region, gathered so that the first real multi-GPU line explains itself (a slow
+        # rank, a straggling bucket): value / ms_per_step use the MAX, as the contract says
+        mine = torch.tensor([dt, per[len(per) // 2] * 1e-3], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dts = [float(a[0]) for a in allr]
+        extra['ranks_ms_per_step'] = dict(min=round(min(dts) / steps * 1e3, 3), max=round(max(dts) / steps * 1e3, 3),
+                                          per_rank=[round(x / steps * 1e3, 3) for x in dts],
+                                          per_rank_median_gpu_step=[round(float(a[1]) * 1e3, 3) for a in allr])
+        dt = max(dts)
+    if train and comm is not None:
+        comm.update(grad_comm_dtype=str(opt.grad_comm_dtype).replace('torch.', ''), buckets=len(opt.buckets),
+                    bucket_mb=[round((e - s) * (2 if opt.grad_comm_dtype == torch.bfloat16 else 4) / 2 ** 20, 1)
+                               for s, e in opt.buckets],
+                    end_only_buckets=int(sum(opt._endonly)), overlapped_launches_total=opt.overlapped_launches,
+                    reserved_cus_while_in_flight=opt.comm_reserved_cus)
     if train:
         extra['last_losses'] = {k: round(float(v), 4) for k, v in res['log_vars'].items()}
         extra['peak_mem_gb'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
