@@ -218,3 +218,17 @@ static inline bool lv_valid(const DasLevels* lv) {
     if (lv->H[l] < 1 || lv->W[l] < 1) return false;
   return true;
 }
+
+// 16-byte global accesses with a cache-policy switch: nt = non-temporal (`global_load / store ... nt`: streamed data that nobody
+// re-reads soon should not displace what the caches hold for the next kernel)
+typedef unsigned das_v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16(const void* p, bool nt) {
+  const das_v4u_t v = nt ? __builtin_nontemporal_load(reinterpret_cast<const das_v4u_t*>(p)) : *reinterpret_cast<const das_v4u_t*>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st16(void* p, const uint4& u, bool nt) {
+  das_v4u_t v;
+  v.x = u.x; v.y = u.y; v.z = u.z; v.w = u.w;
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<das_v4u_t*>(p));
+  else *reinterpret_cast<das_v4u_t*>(p) = v;
+}

@@ -1,16 +1,21 @@
 // Fused per-image decode: sigmoid scores -> threshold -> per-level top-k -> gather + affine
 // -> stable descending sort -> greedy OKS-NMS (or soft OKS-NMS) -> first nms_post survivors.
 // (das_head.py:690-796 `_get_poses_single`, pose_nms.py:51-126.) One 1024-thread workgroup per
-// image; candidate keys live in LDS (128 KiB). Integer/ordering work is exact:
+// image; candidate keys live in LDS (128 KiB) whenever they fit. Integer/ordering work is exact:
 // key = (score bits << 32) | ~flat_index, so "higher score first, then lower flat index".
 // Thresholding before the per-level top-k is equivalent to the reference's order (top-k first,
 // threshold after concat) because the threshold is applied to the same score.
+// No size limits (round 6; the reference has none, das_head.py:716-723): what is bounded by LDS is the number of
+// locations ABOVE THE THRESHOLD, not the frame — a level of any size whose candidates fit is sorted in LDS as before; a
+// level with more than LDS_KEYS candidates finds its nms_pre-th key by an 8-pass radix select that re-scores the level
+// (no storage); more than SUP_LDS / LDS_KEYS candidates in total (nms_pre <= 0 or huge) keep the suppression flags and
+// the globally sorted keys in the per-image workspace instead of LDS (a bitonic network over global memory: slow, exact).
 #include "common.h"
 #include "prof.h"
 
 namespace {
 constexpr int TPB = 1024;
-constexpr int LDS_KEYS = 16384;  // max locations of one level (128 KiB of u64 keys)
+constexpr int LDS_KEYS = 16384;  // candidate keys that fit in LDS (128 KiB of u64 keys)
 constexpr int SUP_LDS = 4096;    // suppression flags of the candidates, behind the keys in LDS
 // Greedy OKS-NMS, two ways. Up to PAIR_MAX candidates (the usual case: ~150 pass the score threshold) every pair's
 // "iou > thr" is evaluated up front, one thread per pair — the f64 exp chain of a pair is the cost, 15-21 of them, and
@@ -20,8 +25,15 @@ constexpr int SUP_LDS = 4096;    // suppression flags of the candidates, behind 
 // More candidates: the round-by-round form (a matrix of cap^2 would not pay).
 constexpr int PAIR_MAX = 768;
 
+__host__ __device__ inline long long pow2_ceil(long long n) {
+  long long p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+// per image: merged keys [pow2_ceil(cap)] u64 (the power of two: a global-memory bitonic sort pads to it), kx / ky / kz
+// [cap * J] f32, area [cap], centers [cap * 3], soft-NMS scores [cap] f32, suppression flags [cap] u8
 __host__ __device__ inline long long ws_bytes_per_image(int cap, int J) {
-  long long per = (long long)cap * 8 + (long long)cap * J * 4 * 3 + (long long)cap * 4 + (long long)cap * 12 + cap;
+  long long per = pow2_ceil(cap) * 8 + (long long)cap * J * 4 * 3 + (long long)cap * 4 + (long long)cap * 12 + (long long)cap * 4 + cap;
   return (per + 255) / 256 * 256;
 }
 
@@ -73,6 +85,7 @@ __device__ __forceinline__ bool oks_above(const float* kx, const float* ky, cons
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// (keys: LDS or global memory — a generic pointer; P a power of two)
 __device__ void bitonic_sort_desc(unsigned long long* keys, int P) {
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -102,12 +115,15 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   // suppressed [cap] u8, keep [nms_post] int
   char* w = ws + (size_t)b * ws_bytes_per_image(cap, J);
   unsigned long long* mkeys = reinterpret_cast<unsigned long long*>(w);
-  float* kx = reinterpret_cast<float*>(mkeys + cap);
+  float* kx = reinterpret_cast<float*>(mkeys + pow2_ceil(cap));
   float* ky = kx + (size_t)cap * J;
   float* kz = ky + (size_t)cap * J;
   float* area = kz + (size_t)cap * J;
   float* cen = area + cap;
-  unsigned char* sup = reinterpret_cast<unsigned char*>(smem) + (size_t)LDS_KEYS * 8;          // [cap <= SUP_LDS], LDS
+  float* gssc = cen + (size_t)cap * 3;                                                         // soft-NMS scores when cap > SUP_LDS
+  // suppression flags: in LDS behind the keys when the candidate capacity allows, else in the workspace
+  unsigned char* sup = cap <= SUP_LDS ? reinterpret_cast<unsigned char*>(smem) + (size_t)LDS_KEYS * 8
+                                      : reinterpret_cast<unsigned char*>(gssc + cap);
 
   // ---- candidates above the score threshold. Usual case: no level has more of them than nms_pre (a few hundred
   // pass 0.07), so the per-level top-k keeps everything and ONE sweep over all levels' points collects them (their
@@ -143,12 +159,13 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
         if (sc[u] > d.score_thr) {
           const int pos = atomicAdd(&s_n, 1);
           atomicAdd(&s_lv[lv[u]], 1);
-          keys[pos] = ((unsigned long long)__float_as_uint(sc[u]) << 32) | (unsigned)(~(unsigned)(i0 + u * TPB + tid));
+          if (pos < LDS_KEYS)   // (more than fit: counted only — the level loop below re-scores)
+            keys[pos] = ((unsigned long long)__float_as_uint(sc[u]) << 32) | (unsigned)(~(unsigned)(i0 + u * TPB + tid));
         }
       }
     }
     __syncthreads();
-    bool simple = true;
+    bool simple = s_n <= LDS_KEYS;
     for (int l = 0; l < d.num_levels; ++l)
       if (d.nms_pre > 0 && d.H[l] * d.W[l] > d.nms_pre && s_lv[l] > d.nms_pre) simple = false;   // (uniform)
     if (simple) {
@@ -156,32 +173,76 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
       for (int i = tid; i < total; i += TPB) mkeys[i] = keys[i];
       __syncthreads();
     } else {
+      // level by level. n_lv = the level's candidates above the threshold (counted by the sweep). A level that keeps all
+      // of them (no top-k configured for it, or not more than nms_pre) streams its keys straight into the merged list;
+      // a level that must be cut to its nms_pre best sorts its candidates in LDS when they fit, and otherwise finds the
+      // nms_pre-th largest key by a radix select over re-computed scores (keys are distinct, so "key >= the nms_pre-th"
+      // selects exactly nms_pre of them) — no storage proportional to the level.
+      __shared__ int s_hist[256];
+      __shared__ unsigned long long s_prefix;
       int point_base = 0;
       for (int l = 0; l < d.num_levels; ++l) {
         const int npts = d.H[l] * d.W[l];
+        const int n_lv = s_lv[l];
+        const bool cut = d.nms_pre > 0 && npts > d.nms_pre && n_lv > d.nms_pre;
+        const bool in_lds = cut && n_lv <= LDS_KEYS;
+        const float* cls = d.cls[l] + (size_t)b * npts * d.cls_ps[l];
+        const float* ctr = d.ctr[l] + (size_t)b * npts * d.ctr_ps[l];
+        unsigned long long kth = 0ull;   // keep keys >= kth
+        if (cut && !in_lds) {
+          // radix select, most significant byte first: after pass p the top (p + 1) bytes of the nms_pre-th largest key
+          int want = d.nms_pre;          // rank (1-based, descending) of the key looked for among those matching the prefix
+          unsigned long long prefix = 0ull;
+          for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            __syncthreads();
+            for (int i = tid; i < 256; i += TPB) s_hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < npts; i += TPB) {
+              const float sv = sigmoidf_(cls[(size_t)i * d.cls_ps[l]]) * sigmoidf_(ctr[(size_t)i * d.ctr_ps[l]]);
+              if (sv > d.score_thr) {
+                const unsigned long long k = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)(~(unsigned)(point_base + i));
+                if (pass == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&s_hist[(int)((k >> shift) & 0xff)], 1);
+              }
+            }
+            __syncthreads();
+            if (tid == 0) {
+              int acc = 0, bin = 255;
+              for (; bin > 0; --bin) {
+                if (acc + s_hist[bin] >= want) break;
+                acc += s_hist[bin];
+              }
+              s_sel = want - acc;        // rank inside the chosen bin
+              s_prefix = prefix | ((unsigned long long)bin << shift);
+            }
+            __syncthreads();
+            want = s_sel;
+            prefix = s_prefix;
+          }
+          kth = prefix;
+        }
         __syncthreads();
         if (tid == 0) s_n = 0;
         __syncthreads();
-        const float* cls = d.cls[l] + (size_t)b * npts * d.cls_ps[l];
-        const float* ctr = d.ctr[l] + (size_t)b * npts * d.ctr_ps[l];
+        unsigned long long* dst = in_lds ? keys : mkeys + total;
         for (int i = tid; i < npts; i += TPB) {
           const float sv = sigmoidf_(cls[(size_t)i * d.cls_ps[l]]) * sigmoidf_(ctr[(size_t)i * d.ctr_ps[l]]);
           if (sv > d.score_thr) {
-            const int pos = atomicAdd(&s_n, 1);
-            keys[pos] = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)(~(unsigned)(point_base + i));
+            const unsigned long long k = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)(~(unsigned)(point_base + i));
+            if (k >= kth) dst[atomicAdd(&s_n, 1)] = k;
           }
         }
         __syncthreads();
         int n = s_n;
-        if (d.nms_pre > 0 && npts > d.nms_pre && n > d.nms_pre) {
+        if (in_lds) {
           int P = 1;
           while (P < n) P <<= 1;
           for (int i = n + tid; i < P; i += TPB) keys[i] = 0ull;
           __syncthreads();
           bitonic_sort_desc(keys, P);
           n = d.nms_pre;
+          for (int i = tid; i < n; i += TPB) mkeys[total + i] = keys[i];
         }
-        for (int i = tid; i < n; i += TPB) mkeys[total + i] = keys[i];
         total += n;
         point_base += npts;
         __syncthreads();
@@ -204,13 +265,20 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
     __syncthreads();
     if (tid < total) keys[rank] = mine;
     __syncthreads();
-  } else {
+  } else if (total <= LDS_KEYS) {
     int P = 1;
     while (P < total) P <<= 1;
     for (int i = tid; i < P; i += TPB) keys[i] = i < total ? mkeys[i] : 0ull;
     __syncthreads();
     bitonic_sort_desc(keys, P);
+  } else {            // more candidates than LDS holds: the same network over the workspace copy (padded to a power of two)
+    int P = 1;
+    while (P < total) P <<= 1;
+    for (int i = total + tid; i < P; i += TPB) mkeys[i] = 0ull;
+    __syncthreads();
+    bitonic_sort_desc(mkeys, P);
   }
+  const unsigned long long* skeys = total <= LDS_KEYS ? keys : mkeys;   // the candidates in their final order
 
   // ---- gather + affine per candidate (das_head.py:725-743): 32 lanes per candidate, lane j = joint j (a thread per
   // candidate walking its joints pays one memory round trip per joint: 40 us of the launch at J = 21)
@@ -228,7 +296,7 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   if (J <= 32) {
     const int sub = tid & 31;
     for (int c = tid >> 5; c < total; c += TPB / 32) {
-      const unsigned flat = ~(unsigned)(keys[c] & 0xffffffffull);
+      const unsigned flat = ~(unsigned)(skeys[c] & 0xffffffffull);
       int l = 0, base = 0;
       while (l + 1 < d.num_levels && (int)flat >= base + d.H[l] * d.W[l]) { base += d.H[l] * d.W[l]; ++l; }
       const int loc = (int)flat - base, Wl = d.W[l];
@@ -261,7 +329,7 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
     }
   } else {
     for (int c = tid; c < total; c += TPB) {
-      const unsigned flat = ~(unsigned)(keys[c] & 0xffffffffull);
+      const unsigned flat = ~(unsigned)(skeys[c] & 0xffffffffull);
       int l = 0, base = 0;
       while (l + 1 < d.num_levels && (int)flat >= base + d.H[l] * d.W[l]) { base += d.H[l] * d.W[l]; ++l; }
       const int loc = (int)flat - base, Wl = d.W[l];
@@ -296,9 +364,9 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
     // (f32 arithmetic on the f32 oks values, as numpy does with these arrays), until nms_post are taken. The
     // reference re-sorts the remaining scores every round; only their maximum matters for the next round, so a
     // workgroup-wide arg-max replaces the sort (ties: the candidate that came first in the initial order).
-    float* ssc = reinterpret_cast<float*>(smem + (size_t)LDS_KEYS * 8 - (size_t)SUP_LDS * 4);   // [total <= SUP_LDS]
+    float* ssc = cap <= SUP_LDS ? reinterpret_cast<float*>(smem + (size_t)LDS_KEYS * 8 - (size_t)SUP_LDS * 4) : gssc;   // [total]
     __shared__ unsigned long long s_red[TPB / 64];
-    for (int c = tid; c < total; c += TPB) ssc[c] = __uint_as_float((unsigned)(keys[c] >> 32));
+    for (int c = tid; c < total; c += TPB) ssc[c] = __uint_as_float((unsigned)(skeys[c] >> 32));
     __syncthreads();
     const int maxd = total < d.nms_post ? total : d.nms_post;
     int kept = 0;
@@ -406,7 +474,7 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
     const int k = i / (J + 1), j = i % (J + 1);
     const int slot = out_index[(size_t)b * d.nms_post + k];
     if (j == J) {
-      out_scores[(size_t)b * d.nms_post + k] = __uint_as_float((unsigned)(keys[slot] >> 32));
+      out_scores[(size_t)b * d.nms_post + k] = __uint_as_float((unsigned)(skeys[slot] >> 32));
       out_centers[((size_t)b * d.nms_post + k) * 3 + 0] = cen[slot * 3 + 0];
       out_centers[((size_t)b * d.nms_post + k) * 3 + 1] = cen[slot * 3 + 1];
       out_centers[((size_t)b * d.nms_post + k) * 3 + 2] = cen[slot * 3 + 2];
@@ -420,7 +488,7 @@ __global__ __launch_bounds__(TPB) void decode_kernel(DasDecodeDesc d, float* __r
   __syncthreads();
   for (int k = tid; k < K; k += TPB) {
     const int slot = out_index[(size_t)b * d.nms_post + k];
-    out_index[(size_t)b * d.nms_post + k] = (int)~(unsigned)(keys[slot] & 0xffffffffull);
+    out_index[(size_t)b * d.nms_post + k] = (int)~(unsigned)(skeys[slot] & 0xffffffffull);
   }
 }
 }  // namespace
@@ -441,10 +509,13 @@ extern "C" int das_decode(const DasDecodeDesc* d, float* out_scores, float* out_
   DAS_PROF(stream);
   if (!d || !out_scores || !out_poses || !out_centers || !out_index || !out_count || !ws) return DAS_ERR_ARG;
   if (d->B < 1 || d->J < 1 || d->num_levels < 1 || d->num_levels > DAS_MAX_LEVELS || d->nms_post < 1) return DAS_ERR_ARG;
-  for (int l = 0; l < d->num_levels; ++l)
-    if (d->H[l] * d->W[l] > LDS_KEYS || !d->cls[l] || !d->ctr[l] || !d->pose[l]) return DAS_ERR_ARG;
-  const int cap = das_decode_cap(d);
-  if (cap > LDS_KEYS || cap > SUP_LDS) return DAS_ERR_ARG;
+  long long locs = 0;
+  for (int l = 0; l < d->num_levels; ++l) {
+    if (d->H[l] < 1 || d->W[l] < 1 || !d->cls[l] || !d->ctr[l] || !d->pose[l]) return DAS_ERR_ARG;
+    locs += (long long)d->H[l] * d->W[l];
+  }
+  if (locs >= (1ll << 31)) return DAS_ERR_ARG;   // (flat location indices are 32-bit, as the keys store them)
+  const int cap = das_decode_cap(d);             // any size: beyond the LDS capacities the kernel works in the workspace
   const int lds = LDS_KEYS * 8 + SUP_LDS;
   static bool attr = false;
   if (!attr) {

@@ -348,8 +348,9 @@ __global__ __launch_bounds__(TPB) void bn_apply_stream_kernel(const T* __restric
                                                               int relu, float* running_mean, float* running_var,
                                                               float momentum, float* save_mean, float* save_invstd,
                                                               long long* num_batches_tracked,
-                                                              unsigned char* __restrict__ bits) {
+                                                              unsigned char* __restrict__ bits, int ntm) {
   constexpr int EPV = Elem<T>::EPV;
+  const bool nt_x = ntm & 1, nt_r = ntm & 2, nt_y = ntm & 4;   // (das_tuning key bn.nt_fwd)
   const int VC = C / EPV;                 // (host: TPB % VC == 0 — a thread keeps its channels for every vector it takes)
   extern __shared__ float cst[];          // [4][C]: mean, invstd, gamma, beta
   const float nstat = (float)stat_count;
@@ -376,8 +377,8 @@ __global__ __launch_bounds__(TPB) void bn_apply_stream_kernel(const T* __restric
     a[u] = make_uint4(0, 0, 0, 0);
     r[u] = a[u];
     if (i < total) {
-      a[u] = *reinterpret_cast<const uint4*>(x + i * EPV);
-      if (res) r[u] = *reinterpret_cast<const uint4*>(res + i * EPV);
+      a[u] = ld16(x + i * EPV, nt_x);
+      if (res) r[u] = ld16(res + i * EPV, nt_r);
     }
   }
 #pragma unroll
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_stream_kernel(const T* __restric
       for (int j = 0; j < EPV; ++j) f[j] = fmaxf(f[j], 0.f);
     }
     const uint4 packed = Elem<T>::pack(f);
-    *reinterpret_cast<uint4*>(y + i * EPV) = packed;
+    st16(y + i * EPV, packed, nt_y);
     if (bits) bits[i] = (unsigned char)relu_bits<T>(packed);
   }
 }
@@ -451,7 +452,7 @@ extern "C" int das_bn_train_apply(const void* x, void* y, int dtype, long long c
 #define DAS_BN_STREAM(T)                                                                                              \
   hipLaunchKernelGGL((bn_apply_stream_kernel<T, VPT>), dim3(sgrid), dim3(TPB), ssm, s, (const T*)x, (T*)y, count, C,   \
                      folded, nstat, eps, gamma, beta, (const T*)residual, relu, running_mean, running_var, momentum,  \
-                     save_mean, save_invstd, num_batches_tracked, bits)
+                     save_mean, save_invstd, num_batches_tracked, bits, (int)dastune::get(dastune::BN_NT_FWD))
     if (dtype == DAS_BF16) DAS_BN_STREAM(bf16_t); else DAS_BN_STREAM(float);
 #undef DAS_BN_STREAM
     DAS_CHECK_LAUNCH();

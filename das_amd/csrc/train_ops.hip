@@ -1058,8 +1058,9 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_dz_stream_kernel(const T* __
                                                                      const float* __restrict__ gamma,
                                                                      const float* __restrict__ fsumg, long long rows, int C,
                                                                      T* __restrict__ draw, float* __restrict__ dgamma_acc,
-                                                                     float* __restrict__ dbeta_acc, float inv_n) {
+                                                                     float* __restrict__ dbeta_acc, float inv_n, int ntm) {
   constexpr int EPV = Elem<T>::EPV;
+  const bool nt_g = ntm & 1, nt_x = ntm & 2, nt_o = ntm & 4;   // (das_tuning key bn.nt_bwd)
   extern __shared__ float cst[];   // [4][C]: mean, k1, k2, k3
   if (blockIdx.x == 0 && dgamma_acc) {
     for (int c = threadIdx.x; c < C; c += TPB) { dbeta_acc[c] += fsumg[c]; dgamma_acc[c] += fsumg[C + c]; }
@@ -1085,8 +1086,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_dz_stream_kernel(const T* __
     gv[u] = make_uint4(0, 0, 0, 0);
     xv[u] = gv[u];
     if (i < total) {
-      gv[u] = *reinterpret_cast<const uint4*>(dz + i * EPV);
-      xv[u] = *reinterpret_cast<const uint4*>(raw + i * EPV);
+      gv[u] = ld16(dz + i * EPV, nt_g);
+      xv[u] = ld16(raw + i * EPV, nt_x);
     }
   }
 #pragma unroll
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_dz_stream_kernel(const T* __
     Elem<T>::unpack(xv[u], x);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) o[j] = k1[j] * (g[j] - k2[j] - (x[j] - mu[j]) * k3[j]);
-    *reinterpret_cast<uint4*>(draw + i * EPV) = Elem<T>::pack(o);
+    st16(draw + i * EPV, Elem<T>::pack(o), nt_o);
   }
 }
 
@@ -1692,7 +1693,8 @@ extern "C" int das_bn_backward_apply(const void* dz, const void* raw, int dtype,
     const size_t ssm = 4 * (size_t)C * sizeof(float);
 #define DAS_BN_DZS(T)                                                                                                   \
   hipLaunchKernelGGL((bn_bwd_apply_dz_stream_kernel<T, VPT>), dim3(sgrid), dim3(TPB), ssm, s, (const T*)dz, (const T*)raw, \
-                     mean, invstd, gamma, folded, rows, C, (T*)draw, dgamma_acc, dbeta_acc, inv_n)
+                     mean, invstd, gamma, folded, rows, C, (T*)draw, dgamma_acc, dbeta_acc, inv_n,                       \
+                     (int)dastune::get(dastune::BN_NT_BWD))
     if (dtype == DAS_BF16) DAS_BN_DZS(bf16_t); else DAS_BN_DZS(float);
 #undef DAS_BN_DZS
     DAS_CHECK_LAUNCH();

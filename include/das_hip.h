@@ -51,7 +51,9 @@ const char* das_target_arch(void);
  * resident wave of workgroups on the remaining CUs), elem.upstats_ppb (output pixels per workgroup of the resampling
  * kernels, 0 = by size), bn.upmerge_blocks (grid cap of the fused reduce passes of upmerge.hip / skipadd.hip),
  * dcn.fused_minrows (das_amd.nn.dcn_v2: das_dcn3x3_fused in the eval forward from this many pixel rows up; 0 = never),
- * conv.balance_rows (0 off / 1 the 1x1 convs / 2 every conv: see das_conv_last_tile_rows). */
+ * conv.balance_rows (0 off / 1 the 1x1 convs / 2 every conv: see das_conv_last_tile_rows),
+ * bn.nt_fwd / bn.nt_bwd (bit masks: which operands of the one-shot BatchNorm passes over large tensors use non-temporal
+ * loads / stores; see csrc/tuning.h). */
 int das_tuning_set(const char* key, long long value);
 int das_tuning_get(const char* key, long long* value);
 int das_tuning_reset(void);

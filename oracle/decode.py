@@ -32,13 +32,17 @@ def oks_iou(g, d, a_g, a_d):
     return ious
 
 
-def oks_nms(scores, kpts, areas, thr):
-    """scores (n,), kpts (n,3J), areas (n,) numpy float32 -> kept indices, score order."""
+def oks_nms(scores, kpts, areas, thr, limit=None):
+    """scores (n,), kpts (n,3J), areas (n,) numpy float32 -> kept indices, score order.
+    limit: stop after this many kept poses. The reference runs the greedy loop to the end and truncates afterwards
+    (`keep[:nms_post]`, das_head.py:783-788); a kept pose is never un-kept by later rounds, so the first `limit` entries are
+    the same either way — the early stop only keeps the oracle's cost at limit x n instead of kept x n pair evaluations
+    (tens of thousands of candidates at 1080p with nms_pre <= 0)."""
     if len(scores) == 0:
         return np.zeros((0,), dtype=np.int64)
     order = np.argsort(-scores.astype(np.float64), kind='stable')
     keep = []
-    while len(order) > 0:
+    while len(order) > 0 and (limit is None or len(keep) < limit):
         i = order[0]
         keep.append(i)
         ovr = oks_iou(kpts[i], kpts[order[1:]], areas[i], areas[order[1:]])
@@ -105,7 +109,8 @@ def decode_single(cls_scores, pose_preds, centernesses, points, scale_factor, J,
         area = (P[..., :2].max(1)[0] - P[..., :2].min(1)[0]).prod(-1)
         kp = torch.cat([P[..., :2], vis[..., None]], -1).reshape(len(P), -1)
         if test_cfg.get('nms_type', 'hard') == 'hard':
-            keep = oks_nms(nms_scores[:, 0].numpy(), kp.numpy(), area.numpy(), test_cfg.get('nms_thr', 0.9))
+            keep = oks_nms(nms_scores[:, 0].numpy(), kp.numpy(), area.numpy(), test_cfg.get('nms_thr', 0.9),
+                           limit=test_cfg.get('nms_post', 100) if test_cfg.get('oracle_early_stop', False) else None)
             keep = torch.from_numpy(keep[:test_cfg.get('nms_post', 100)])
         else:
             keep = torch.from_numpy(soft_oks_nms(nms_scores[:, 0].numpy(), kp.numpy(), area.numpy(),

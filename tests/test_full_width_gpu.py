@@ -236,7 +236,12 @@ def train_losses_case(stages):
 
 def train_stats_case(stages):
     train_losses_case(stages)
-    return _TRAIN_CASES[stages][3:]
+    return _TRAIN_CASES[stages][3:7]
+
+
+def train_case_objects(stages):
+    train_losses_case(stages)
+    return _TRAIN_CASES[stages][7]
 
 
 def _train_losses_case(stages):
@@ -252,6 +257,7 @@ def _train_losses_case(stages):
     gts = {k: [s[k] for s in ss] for k in ('gt_labels_3d', 'gt_poses_3d', 'centers2d', 'depths')}
     dt = torch.float64
     bsd, nsd, hsd = [{k: (v.to(dt) if v.is_floating_point() else v) for k, v in d.items()} for d in split_sd(model)]
+    bsd0, nsd0 = {k: v.clone() for k, v in bsd.items()}, {k: v.clone() for k, v in nsd.items()}     # (before any running-stat update)
     g = {k: [t.to(dt) if t.is_floating_point() else t for t in v] for k, v in gts.items()}
     with torch.no_grad():
         feats = ob.fpn_forward(nsd, ob.mspn2_forward(bsd, img.to(dt), stages, (3, 4, 6, 3), train=True), train=True)
@@ -264,15 +270,28 @@ def _train_losses_case(stages):
     model.to(DEV).train()
     with torch.no_grad():
         l32 = {k: float(v) for k, v in model.train_step(data)['log_vars'].items()}
-    st32 = bn_batch_stats(model.state_dict())
+    st32_nograd = bn_batch_stats(model.state_dict())
+    # the statistics of the path the BENCHMARK runs: the same forward WITH an autograd graph (the fused train-mode nodes —
+    # upsample-unit merge, deferred skip BatchNorms, layer chains — only exist in grad mode), on fresh running statistics
+    m2 = build(cfg, 0)
+    m2.load_state_dict(sd0)
+    m2.to(DEV).train()
+    out = m2.train_step(data)
+    l32g = {k: float(v) for k, v in out['log_vars'].items()}
+    del out
+    from das_amd.autograd import reset_step_state
+    reset_step_state()           # (no backward follows: drop whatever the forward queued for one)
+    st32 = bn_batch_stats(m2.state_dict())
+    del m2
     mb = build(bench.model_cfg(stages, 'bf16'), 0)
     mb.load_state_dict(sd0)
     mb.to(DEV).train()
     with torch.no_grad():
         lbf = {k: float(v) for k, v in mb.train_step(data)['log_vars'].items()}
     stbf = bn_batch_stats(mb.state_dict())
-    print(f'full-width {stages}-stage train losses  oracle f64:', truth, ' hip f32:', l32, ' hip bf16:', lbf)
-    return truth, l32, lbf, st_ref, st32, stbf
+    print(f'full-width {stages}-stage train losses  oracle f64:', truth, ' hip f32:', l32, ' hip f32 (autograd graph):', l32g,
+          ' hip bf16:', lbf)
+    return truth, l32, lbf, st_ref, st32, stbf, st32_nograd, (model, sd0, img, bsd0, nsd0, data)
 
 
 def test_one_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
@@ -288,19 +307,27 @@ def test_one_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
 
 # Per-layer BatchNorm statistics after ONE train-mode forward, HIP f32 vs the oracle's f64 (bn_stat_errors: error of the batch
 # mean in units of the layer's RMS activation, of the batch variance in units of the layer's mean variance; worst layer per
-# group). A layer's statistics are per-channel means over 2 x H x W samples: they do not amplify like the losses do, so
-# these are sharp where the 4-stage losses can only be banded. Bounds = ~4x the maxima measured on MI355X
-# (profiles/r06_bn_stats_parity.txt). A layer that lost its statistics (the arena bug of commit 6237e9b) scores ~1.
+# group). A layer that lost its statistics (the arena bug of commit 6237e9b) scores ~1. Measured on MI355X
+# (profiles/r06_bn_stats_parity.txt): end to end, 1 stage: 9e-6 / 9e-5 everywhere -> bound 1e-3. 4 stages end to end: the
+# first stage 1e-5 / 5e-5, then x ~70 per stage (7e-4 / 4e-3 in the second, 3e-2 / 0.17 in the third, 7e-2 / 0.75 in the
+# fourth) — with statistics over two frames and random weights the ReLU flips of a stage's ~68 layers amplify the input
+# difference exactly as they do for the losses; the oracle's own f32 evaluation drifts from its f64 one the same way. So
+# the end-to-end test binds the stem and the first two stages, and every LATER stage is checked SHARPLY by teacher
+# forcing: the HIP stage is fed the oracle's own stage inputs (test below), where it lands at 1e-5 ... 1e-4 again.
 BN_STATS_BOUND_1STAGE = dict(top=1e-3, stage0=1e-3, neck=1e-3)
-BN_STATS_BOUND_4STAGE = dict(top=1e-3, stage0=1e-3, stage1=1e-2, stage2=5e-2, stage3=5e-2, neck=5e-2)
+BN_STATS_BOUND_4STAGE_E2E = dict(top=1e-3, stage0=1e-3, stage1=2e-2)       # (stage1: measured 7e-4 / 4e-3)
+BN_STATS_BOUND_FORCED = dict(top=1e-3, stage0=1e-3, stage1=1e-3, stage2=1e-3, stage3=1e-3, neck=1e-3)
 
 
-def check_bn_stats(tag, got, ref, bound):
+def check_bn_stats(tag, got, ref, bound, only=None):
+    if only is not None:
+        got = {k: v for k, v in got.items() if only(k)}
+        ref = {k: v for k, v in ref.items() if only(k)}
     errs = bn_stat_errors(got, ref)
     worst = worst_by_stage(errs)
     print(f'{tag}: BatchNorm batch statistics, worst layer per group (err_mean, err_var, layers): ' +
           ', '.join(f'{g} {w[0]:.2e} {w[1]:.2e} ({w[2]})' for g, w in sorted(worst.items())))
-    bad = [(k, e) for k, e in errs.items() if max(e) > bound[stage_of(k)]]
+    bad = [(k, e) for k, e in errs.items() if stage_of(k) in bound and max(e) > bound[stage_of(k)]]
     assert not bad, (tag, len(bad), sorted(bad, key=lambda t: -max(t[1]))[:6])
     return worst
 
@@ -308,57 +335,139 @@ def check_bn_stats(tag, got, ref, bound):
 def test_one_stage_full_width_every_batchnorm_layers_statistics_f32_vs_oracle():
     """after ONE train-mode step (B = 2, 512 x 832, f32) EVERY BatchNorm layer's running_mean / running_var
     against the oracle's (oracle/nn_ops.py batch_norm updates them in place; mspn_mmpose.py:74-79,273-274): 60 backbone
-    + 8 neck layers of the 1-stage net within 1e-3 (layer-relative, see bn_stat_errors)."""
-    st_ref, st32, _ = train_stats_case(1)
+    + 7 neck layers of the 1-stage net within 1e-3 (layer-relative, see bn_stat_errors) — on the autograd-graph path the
+    benchmark runs AND on the no-grad path the loss tests run."""
+    st_ref, st32, _, st32_nograd = train_stats_case(1)
     assert len(st_ref) >= 60
-    check_bn_stats('1-stage f32 vs oracle f64', st32, st_ref, BN_STATS_BOUND_1STAGE)
+    check_bn_stats('1-stage f32 (autograd graph) vs oracle f64', st32, st_ref, BN_STATS_BOUND_1STAGE)
+    check_bn_stats('1-stage f32 (no_grad) vs oracle f64', st32_nograd, st_ref, BN_STATS_BOUND_1STAGE)
 
 
-def test_four_stage_full_width_every_batchnorm_layers_statistics_f32_vs_oracle():
-    """The benchmarked 4-stage topology: 264 backbone BatchNorm layers + the neck's. The first stage (and the stem) within
-    1e-3; the later stages see inputs that already differ at the 1e-4 level through the ReLU flips of ~70 layers each
-    (the same effect that makes the LOSSES of this net chaotic at the percent level), so their bound is the measured one
-    per stage — still two orders of magnitude below what a lost or stale statistic produces (~1)."""
-    st_ref, st32, _ = train_stats_case(4)
+def test_four_stage_full_width_batchnorm_statistics_end_to_end_f32_vs_oracle():
+    """The benchmarked 4-stage topology end to end: the stem and the first stage within 1e-3, the second within 2e-2; the
+    later stages are printed (chaotic amplification, see the comment above) and bound by the teacher-forced test below."""
+    st_ref, st32, _, st32_nograd = train_stats_case(4)
     assert len(st_ref) >= 264
-    check_bn_stats('4-stage f32 vs oracle f64', st32, st_ref, BN_STATS_BOUND_4STAGE)
+    check_bn_stats('4-stage f32 (autograd graph) vs oracle f64, end to end', st32, st_ref, BN_STATS_BOUND_4STAGE_E2E)
+    check_bn_stats('4-stage f32 (no_grad) vs oracle f64, end to end', st32_nograd, st_ref, BN_STATS_BOUND_4STAGE_E2E)
+
+
+def oracle_stage_io(bsd, nsd, img, stages):
+    """The oracle's train-mode forward stage by stage (oracle/backbone.py mspn2_forward's loop, spelled out): per stage its
+    inputs (x, skip1, skip2); the last stage's outputs; every BatchNorm's batch statistics as a side effect in bsd / nsd."""
+    from oracle import backbone as ob
+    import torch.nn.functional as F
+    ins = []
+    with torch.no_grad():
+        x = ob.conv_bn(bsd, 'top.top.0', img, 2, 3, True, True)
+        x = F.max_pool2d(x, 3, 2, 1)
+        skip1 = skip2 = None
+        outs = None
+        for s in range(stages):
+            ins.append((x, skip1, skip2))
+            sp = f'multi_stage_mspn.{s}'
+            mids = ob.downsample_module(bsd, sp + '.downsample', x, skip1, skip2, (3, 4, 6, 3), True)
+            outs, skip1, skip2, x = ob.upsample_module(bsd, sp + '.upsample', mids, True)
+            if skip1[0] is None:
+                skip1 = skip2 = None
+        feats = outs[::-1]
+        ob.fpn_forward(nsd, feats, train=True)
+    return ins, feats
+
+
+def to_dev_nhwc(t, dtype=torch.float32):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def forced_stage_stats(model, ins, feats, dtype=torch.float32, conv=to_dev_nhwc):
+    """Every stage of `model` (train mode, autograd graph recorded: the benchmarked kernels) fed the GIVEN stage inputs, the
+    neck fed the given backbone outputs (conv: tensor -> NHWC device tensor of dtype); returns the BatchNorm batch
+    statistics this produced."""
+    from das_amd.autograd import reset_step_state
+    bb = model.backbone
+    last = len(bb.multi_stage_mspn) - 1
+    for s, (x, k1, k2) in enumerate(ins):
+        sk1 = [conv(t, dtype) for t in k1] if k1 is not None else None
+        sk2 = [conv(t, dtype) for t in k2] if k2 is not None else None
+        res = bb.multi_stage_mspn[s](conv(x, dtype), sk1, sk2, skip_finest=bb.skip_unused_finest and s == last)
+        del res
+        reset_step_state()
+    res = model.neck([None if f is None else conv(f, dtype).permute(0, 3, 1, 2) for f in feats])
+    del res
+    reset_step_state()
+    torch.cuda.synchronize()
+    return bn_batch_stats(model.state_dict())
+
+
+def test_four_stage_every_batchnorm_layers_statistics_teacher_forced_f32_vs_oracle():
+    """The sharp per-layer check at the benchmarked topology: each of the four stages (and the neck) of the
+    HIP model runs on the ORACLE's inputs of that stage (f64 rounded to f32), so no stage inherits the drift of the one
+    before it — all 264 backbone + 7 neck BatchNorm layers' batch statistics within 1e-3 of the oracle's (measured
+    1e-5 ... 1e-4, profiles/r06_bn_stats_parity.txt). Autograd graph recorded: the fused train-mode kernels of the benchmark."""
+    import bench
+    model0, sd0, img, bsd0, nsd0, _ = train_case_objects(4)
+    bsd, nsd = {k: v.clone() for k, v in bsd0.items()}, {k: v.clone() for k, v in nsd0.items()}
+    ins, feats = oracle_stage_io(bsd, nsd, img.to(torch.float64), 4)
+    st_ref = {**bn_batch_stats(bsd, 'backbone.'), **bn_batch_stats(nsd, 'neck.')}
+    m = build(bench.model_cfg(4, 'f32'), 0)
+    m.load_state_dict(sd0)
+    m.to(DEV).train()
+    got = forced_stage_stats(m, ins, feats)
+    check_bn_stats('4-stage f32 vs oracle f64, every stage on the oracle\'s inputs', got, st_ref, BN_STATS_BOUND_FORCED,
+                   only=lambda k: stage_of(k) != 'top')
 
 
 def test_batchnorm_statistics_survive_arena_wraps_inside_one_step():
-    """The statistics accumulators come from a zero-filled arena that is refilled when used up (das_amd.nn._ZeroArena). With
-    the arena shrunk so that it wraps every few layers, one 1-stage train-mode forward must give the SAME per-layer statistics
-    as with the default 16 MiB arena (float-atomic order is the only difference: 1e-5). The one-buffer arena of rounds 3-4
-    (commit 6237e9b fixed it) fails this on the layer pairs that hold two slices at once — shown once with the fix reverted
-    in profiles/r06_bn_stats_test_catches_arena_bug.txt (tools/dev/arena_revert_demo.py)."""
+    """The statistics accumulators come from a zero-filled arena that is refilled when used up (das_amd.nn._ZeroArena). The
+    sequence of slices one 1-stage train-mode forward takes is recorded, and the forward is then repeated with the arena
+    sized so that the refill falls EXACTLY at take j, for every j the arena size allows (~100 sizes): the per-layer batch
+    statistics must equal the default 16 MiB arena's (float-atomic order is the only difference: 1e-4 on the 8 x 13 level's
+    208 samples per channel, measured; bound 1e-3). The one-buffer arena of rounds 3-4 (commit 6237e9b fixed it) loses a
+    layer's sums whenever the refill falls between the two takes of a layer pair (the two convs of an upsample-unit merge,
+    a projection shortcut and its conv3) — shown once with the fix reverted in
+    profiles/r06_bn_stats_test_catches_arena_bug.txt (tools/dev/arena_revert_demo.py)."""
     import bench
-    from das_amd import nn as dnn
+    from das_amd import autograd as ag, nn as dnn
     from das_amd.datasets import SyntheticPoseDataset, collate
     ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=2, seed=0)
     data = collate([ds[i] for i in range(2)], device=DEV)
-    model = build(bench.model_cfg(1, 'f32'), 0)
-    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-    stats = []
+    m = build(bench.model_cfg(1, 'f32'), 0)
+    m.to(DEV).train()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     keep = dnn._STATS_ARENA
+
+    def forward_stats(arena):
+        dnn._STATS_ARENA = arena
+        m.load_state_dict(sd0)
+        out = m.train_step(data)          # (with the autograd graph: the paths that hold two slices at once)
+        del out
+        ag.reset_step_state()
+        torch.cuda.synchronize()
+        return bn_batch_stats(m.state_dict())
+
+    class Recording(type(keep)):
+        def take(self, n, device):
+            self.sizes.append((n + 63) // 64 * 64)
+            return super().take(n, device)
     try:
-        # (64K floats and up: the largest slice of the step, 8 slots x 2 x 2048 channels, still fits; six sizes move the wrap
-        # points across the layer sequence)
-        for cap in (keep.cap,) + tuple((1 << 16) + 4096 * i for i in range(6)):
-            dnn._STATS_ARENA = type(keep)(cap=cap)
-            m = build(bench.model_cfg(1, 'f32'), 0)
-            m.load_state_dict(sd0)
-            m.to(DEV).train()
-            with torch.no_grad():
-                m.train_step(data)
-            torch.cuda.synchronize()
-            stats.append(bn_batch_stats(m.state_dict()))
-            del m
+        rec = Recording(cap=keep.cap)
+        rec.sizes = []
+        ref = forward_stats(rec)
+        sizes = rec.sizes
+        big = max(sizes)
+        prefix = [sum(sizes[:j]) for j in range(len(sizes))]
+        caps = sorted({p for p in prefix if p >= big})       # arena of exactly prefix[j] floats: take j finds it used up
+        print(f'{len(sizes)} takes per forward (largest {big} floats), {len(caps)} arena sizes that refill at a different take each')
+        assert len(caps) > 40
+        worst_all = 0.0
+        for cap in caps:
+            errs = bn_stat_errors(forward_stats(type(keep)(cap=cap)), ref)
+            worst = max(errs.items(), key=lambda kv: max(kv[1]))
+            worst_all = max(worst_all, max(worst[1]))
+            assert max(worst[1]) < 1e-3, (cap, worst)
+        print('worst layer error over all arena sizes:', worst_all)
     finally:
         dnn._STATS_ARENA = keep
-    for st in stats[1:]:
-        errs = bn_stat_errors(st, stats[0])
-        worst = max(errs.items(), key=lambda kv: max(kv[1]))
-        print('arena 4M floats vs a small one: worst layer', worst)
-        assert max(worst[1]) < 1e-4, worst
 
 
 def test_four_stage_full_width_train_losses_f32_vs_oracle_and_bf16_band():
@@ -474,7 +583,9 @@ B16_KERNELS = ('conv_glds4_kernel<pp,288>', 'conv_glds4_kernel<pp>', 'conv_glds3
 # (measured: bf16 0.16 % / 0.08 % / 0.09 % (cls, depth, centerness) and 0.45 % (pose) from f32 — statistics over 16 frames are far
 # less chaotic than over 2; bands ~10x the measured values, a draw of the float atomics included)
 B16_BAND = dict(loss_cls=0.02, loss_depth=0.02, loss_centerness=0.02, loss_pose=0.04, loss=0.04)
-B16_STATS_BOUND = dict(top=0.1, stage0=0.1, stage1=0.1, stage2=0.1, stage3=0.1, neck=0.1)
+# (per stage on the f32 inputs, bf16 vs f32: measured <= 1.3e-2 of a layer's scale on the means, <= 6.8e-2 of its mean variance on the
+# variances, profiles/r06_bn_stats_parity.txt; bound ~4x that — a lost statistic scores ~1)
+B16_STATS_BOUND = dict(stage0=0.25, stage1=0.25, stage2=0.25, stage3=0.25, neck=0.25)
 
 
 def test_benchmarked_b16_step_bf16_losses_follow_f32_and_dispatch_the_benchmarked_kernels():
@@ -493,8 +604,14 @@ def test_benchmarked_b16_step_bf16_losses_follow_f32_and_dispatch_the_benchmarke
     m32 = build(bench.model_cfg(4, 'f32'), 0)
     sd0 = {k: v.clone() for k, v in m32.state_dict().items()}
     m32.to(DEV).train()
+    # (the f32 forward's own stage inputs are kept: the bf16 stages are checked on THEM below)
+    stage_in, neck_in = [], []
+    hooks = [st.register_forward_pre_hook(lambda m, a: stage_in.append(a[:3])) for st in m32.backbone.multi_stage_mspn]
+    hooks.append(m32.neck.register_forward_pre_hook(lambda m, a: neck_in.append(a[0])))
     with torch.no_grad():
         l32 = {k: float(v) for k, v in m32.train_step(data)['log_vars'].items()}
+    for h in hooks:
+        h.remove()
     st32 = bn_batch_stats(m32.state_dict())
     del m32
     torch.cuda.empty_cache()
@@ -516,7 +633,20 @@ def test_benchmarked_b16_step_bf16_losses_follow_f32_and_dispatch_the_benchmarke
     assert all(torch.isfinite(p).all() for p in mb.parameters())
     # every BatchNorm layer's batch statistics of the bf16 step against the f32 forward's (bf16 rounds every
     # stored activation to 8 bits: errors of 1e-3 ... 1e-2 of a layer's scale, measured profiles/r06_bn_stats_parity.txt)
-    check_bn_stats('B = 16 4-stage bf16 vs hip f32', bn_batch_stats(mb.state_dict()), st32, B16_STATS_BOUND)
+    # bf16 rounds every stored activation to 8 bits, and end to end the difference is amplified stage by stage like every
+    # input difference of this net (measured: 1.4e-2 / 7e-2 in the first stage, 0.4 / 4 in the fourth): printed, and bound in
+    # the first stage only. The check per stage: each bf16 stage on the F32 run's inputs of that stage (teacher forcing).
+    check_bn_stats('B = 16 4-stage bf16 vs hip f32, end to end', bn_batch_stats(mb.state_dict()), st32,
+                   dict(top=1e-2, stage0=0.1))
+    del mb, opt, res
+    torch.cuda.empty_cache()
+    m2 = build(bench.model_cfg(4, 'bf16'), 0)
+    m2.load_state_dict(sd0)
+    m2.to(DEV).train()
+    feats = [None if f is None else f.permute(0, 2, 3, 1) for f in neck_in[0]]
+    got = forced_stage_stats(m2, stage_in, feats, torch.bfloat16, conv=lambda t, dt: t.to(dt))
+    check_bn_stats('B = 16 4-stage bf16 vs hip f32, every stage on the f32 run\'s inputs', got, st32, B16_STATS_BOUND,
+                   only=lambda k: stage_of(k) != 'top')
 
 
 def test_four_stage_full_width_eval_f32_maps_and_decode_match_the_oracle():

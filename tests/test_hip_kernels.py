@@ -528,6 +528,53 @@ def test_decode_mupots_topology():
     _check_decode_vs_oracle(cls, pose, ctr, [(0.8, 0.8)], 21, cases.FULL_STRIDES, cases.FULL_TEST_CFG)
 
 
+HD_SIZES = [(135, 240), (68, 120), (34, 60), (17, 30)]      # 1080 x 1920 input at strides 8 / 16 / 32 / 64: 43 110 locations
+
+
+def _passing_per_level(cls, ctr, thr):
+    return [int(((c.sigmoid() * k.sigmoid()) > thr).flatten(1).sum(1).max()) for c, k in zip(cls, ctr)]
+
+
+@pytest.mark.parametrize('case', ['typical', 'level0_topk_in_lds', 'level0_radix_select', 'keep_all_6k', 'keep_all_over_16k'])
+def test_decode_1080p_beyond_the_former_lds_caps(case):
+    """The reference's `_get_poses_single` (das_head.py:690-796) has no size limit; until round 5 das_decode refused a level
+    of more than 16 384 locations or more than 4096 candidates in total. 1080 x 1920 frames (level 0 =
+    135 x 240 = 32 400 locations), J = 15, kept indices bit-exact against the oracle on every path of the selection:
+      typical              a few hundred candidates (one sweep, everything in LDS)
+      level0_topk_in_lds   level 0 has more candidates than nms_pre = 1000 but fewer than the 16 384 keys LDS holds
+      level0_radix_select  more than 16 384 locations of level 0 pass the threshold: its nms_pre-th key by radix select
+      keep_all_6k          nms_pre = -1 (no per-level cut): ~6000 candidates, suppression flags in the workspace
+      keep_all_over_16k    nms_pre = -1 and more than 16 384 candidates: the global order from a sort over the workspace"""
+    cfg = dict(cases.FULL_TEST_CFG)
+    bias, B = -4.5, 2
+    if case == 'level0_topk_in_lds':
+        bias = -2.6
+    elif case == 'level0_radix_select':
+        bias, B = 1.5, 1
+    elif case == 'keep_all_6k':
+        bias, B, cfg = -3.0, 1, dict(cfg, nms_pre=-1, nms_post=40)
+    elif case == 'keep_all_over_16k':
+        bias, B, cfg = 0.0, 1, dict(cfg, nms_pre=-1, nms_post=20)
+    cls, pose, ctr = cases.full_decode_inputs(seed=31, B=B, sizes=HD_SIZES, bias=bias)
+    n = _passing_per_level(cls, ctr, cfg['score_thr'])
+    print(case, 'candidates above the threshold per level (max over images):', n)
+    if case == 'typical':
+        assert 50 < sum(n) < 1000
+    elif case == 'level0_topk_in_lds':
+        assert 1000 < n[0] <= 16384
+    elif case == 'level0_radix_select':
+        assert n[0] > 16384
+    elif case == 'keep_all_6k':
+        assert 4096 < sum(n) <= 16384
+    else:
+        assert sum(n) > 16384
+    # (oracle_early_stop: the oracle's greedy loop stops at nms_post kept poses — the same prefix as the reference's run to the
+    # end + truncation, oracle/decode.py oks_nms; at these candidate counts the full loop would take minutes to hours)
+    out = _check_decode_vs_oracle(cls, pose, ctr, [(1.5, 1.5)] * B, cases.FULL_J, cases.FULL_STRIDES,
+                                  dict(cfg, oracle_early_stop=True))
+    assert int(out['count'].min()) > 10
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_ragged_multilevel_conv_gn_dcn_match_per_level(dtype):
     """One launch over the rows of all levels == the same op applied level by level."""

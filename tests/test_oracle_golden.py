@@ -254,3 +254,21 @@ def test_dcn_against_scalar_loops():
                             v += wt * xn[0, c, yy, xx]
                     ref[0, :, oy, ox] += wn[:, c, i, j] * v * mn[0, k, oy, ox]
     np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_nms_early_stop_is_the_truncated_full_run():
+    """oracle/decode.py oks_nms(limit=k) — used by the 1080p decode tests, where the greedy loop run to the end would take
+    minutes — returns exactly the first k entries of the full run (the reference's `keep[:nms_post]`, das_head.py:783-788)."""
+    import numpy as np
+    from oracle import decode as od
+    rs = np.random.RandomState(4)
+    n, J = 400, 15
+    kp = rs.normal(0, 40, (n, J, 3)).astype(np.float32)
+    kp[: n // 2] = kp[n // 2:] + rs.normal(0, 3, (n // 2, J, 3)).astype(np.float32)   # near-duplicates: suppression happens
+    kp[..., 2] = 1
+    sc = rs.rand(n).astype(np.float32)
+    area = (kp[..., 0].max(1) - kp[..., 0].min(1)) * (kp[..., 1].max(1) - kp[..., 1].min(1))
+    full = od.oks_nms(sc, kp.reshape(n, -1), area, 0.5)
+    assert len(full) < n
+    for k in (1, 7, 50, len(full), len(full) + 10):
+        np.testing.assert_array_equal(od.oks_nms(sc, kp.reshape(n, -1), area, 0.5, limit=k), full[:k])

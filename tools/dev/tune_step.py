@@ -82,7 +82,7 @@ def run(cfg):
         elif k == 'BWDRES':        # comm.reserved_cus = v during backward only (a CU budget beside the weight gradients' side stream)
             _bwd_res[0] = int(v)
         elif k == 'SIDEPP':
-            ag.SIDE_PP_BLOCKS = int(v)
+            ag.SIDE_PP_SHARE = int(v)
         elif k == 'CHAIN':
             dnn.CHAIN_CONSUMERS = bool(int(v))
         elif k == 'DUAL':
@@ -109,7 +109,7 @@ def run(cfg):
     ms = ts[N // 2]
     ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS = wb, fs, ms_
     ag.DCN_FUSED = True
-    ag.SIDE_PP_BLOCKS = 128
+    ag.SIDE_PP_SHARE = 2
     _hiccup[0] = 0.0
     _bwd_res[0] = 0
     for key in ('gt_poses_3d', 'centers2d', 'depths'):
