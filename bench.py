@@ -685,17 +685,34 @@ def also_workloads(args, dev, model, opt, data):
         ds = SyntheticPoseDataset(num_joints=J, img_shape=(H, W), length=8, seed=0)
         d8 = collate([ds[i] for i in range(8)], device=dev)
         calibrate_scores(m1, d8['img'], d8['img_metas'])
-        for _ in range(3):
-            res = m1(d8['img'], d8['img_metas'], return_loss=False, rescale=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         n = 10
-        for _ in range(n):
-            res = m1(d8['img'], d8['img_metas'], return_loss=False, rescale=True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+
+        def timed_infer():
+            for _ in range(3):
+                r = m1(d8['img'], d8['img_metas'], return_loss=False, rescale=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r = m1(d8['img'], d8['img_metas'], return_loss=False, rescale=True)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, r
+        dt_eager, res = timed_infer()
+        graph_note = 'off'
+        dt = dt_eager
+        if not getattr(args, 'no_infer_graph', False):
+            # the fixed-shape eval forward (backbone + neck + head) as one hipGraph, the decode eager behind it
+            # (das_amd/graphs.py GraphedInference): what a serving loop of fixed-size batches runs
+            try:
+                from das_amd.graphs import enable_inference_graph
+                enable_inference_graph(m1, d8['img'])
+                dt, res = timed_infer()
+                graph_note = 'forward (backbone + neck + head) replayed as one hipGraph, decode eager'
+            except Exception as e:
+                m1._graphed_infer = None
+                graph_note = f'off (capture failed: {type(e).__name__}: {e})'
         out['infer'] = dict(metric='imgs/sec forward+decode', value=round(8 * n / dt, 1), unit='img/s',
                             ms_per_step=round(dt / n * 1e3, 3), steps=n, warmup=3, dtype=args.dtype,
+                            hip_graphs=graph_note, eager_ms_per_step=round(dt_eager / n * 1e3, 3),
                             model_tflops=round(8 * n * FWD_GFLOP[1] / dt / 1e3, 1),
                             poses_per_step=sum(len(r['scores']) for r in res),
                             workload='BASELINE configs[1]: MSPN-50 1-stage + FPN + DASHead J=15, batch 8 x 3x512x832, '
@@ -782,6 +799,8 @@ def main():
                          '38 instead of 62 ms of host time per step, but 1 % LESS throughput than queueing every launch '
                          '(nine A/B pairs on three boxes: 177.2 vs 179.3 img/s) — the GPU, not the host, bounds the step')
     ap.add_argument('--no-graphs', action='store_true', help='(the default; kept for older command lines)')
+    ap.add_argument('--no-infer-graph', action='store_true',
+                    help='A/B: the inference workload launch by launch (default: its forward replayed as one hipGraph)')
     ap.add_argument('--no-wgrad-stream', action='store_true', help='A/B: weight gradients on the main stream')
     ap.add_argument('--wgrad-streams', type=int, default=None, help='A/B: number of weight-gradient side streams')
     ap.add_argument('--wgrad-batch', type=int, default=None, help='A/B: weight gradients per batched launch (1 = off)')
@@ -894,8 +913,22 @@ def main():
         except RuntimeError as e:      # capture refused: the same kernels, queued launch by launch (the line says so)
             model._graphed_trunk = None
             extra['hip_graphs'] = f'off (capture failed: {e})'
+    elif train:
+        extra['hip_graphs'] = 'off (default: every launch queued by hand; --graphs replays the trunk as two hipGraphs)'
+    elif world == 1 and not args.no_infer_graph:
+        # inference, fixed batch shape: the forward as one hipGraph (das_amd/graphs.py GraphedInference), the decode eager
+        res = step()
+        del res
+        try:
+            from das_amd.graphs import enable_inference_graph
+            graphs = enable_inference_graph(model, data['img'])
+            extra['hip_graphs'] = 'forward (backbone + neck + head) replayed as one hipGraph, decode eager'
+        except Exception as e:
+            model._graphed_infer = None
+            graphs = None
+            extra['hip_graphs'] = f'off (capture failed: {type(e).__name__}: {e})'
     else:
-        extra['hip_graphs'] = 'off (default: every launch queued by hand; --graphs replays the trunk as two hipGraphs)' if train else 'off'
+        extra['hip_graphs'] = 'off'
     for _ in range(warmup - (1 if graphs is not None else 0)):
         res = step()
     # The interpreter's cyclic garbage collector is parked for the timed region (and the per-launch passes after it): a
@@ -929,6 +962,7 @@ def main():
                                         'ahead); ms_per_step is the wall clock of the whole region / steps')
     if graphs is not None:     # the per-launch measurement passes below need every launch queued by hand
         model._graphed_trunk = None
+        model._graphed_infer = None
     if world > 1:
         # per-rank wall clock of the timed region, gathered so that the first real multi-GPU line explains itself (a slow
         # rank, a straggling bucket): value / ms_per_step use the MAX, as the contract says

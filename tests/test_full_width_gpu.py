@@ -775,3 +775,51 @@ def test_one_stage_full_width_backward_gradients_vs_oracle_f64():
         print('   %-70s %.3e  %.3e  %.3e' % r)
     for n, e_hip, e_or, spread in report:
         assert e_hip <= max(4 * e_or, 4 * spread, 3e-3), (n, e_hip, e_or, spread)
+
+
+def test_inference_graph_replays_equal_the_eager_forward_and_fall_back_when_anything_changes():
+    """das_amd.graphs.GraphedInference (configs[1]: 1-stage, B = 8, bf16, 512 x 832): the eval forward captured as one hipGraph
+    runs the SAME kernels as the launch-by-launch path — its head maps agree with the eager ones as closely as two eager runs
+    agree with each other (the GroupNorm statistics are summed with float atomics: run-to-run differences of a few bf16 ulp),
+    for the captured batch and for another batch of the same shape, and the decoded poses follow; another shape, training
+    mode or changed parameters run eagerly (and correctly)."""
+    import bench
+    from das_amd.datasets import SyntheticPoseDataset, collate
+    from das_amd.graphs import enable_inference_graph
+    model = bench.build_model(torch.device(DEV), seed=0, dtype='bf16', num_stages=1, train=False)
+    ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=16, seed=0)
+    d0 = collate([ds[i] for i in range(8)], device=DEV)
+    d1 = collate([ds[i] for i in range(8, 16)], device=DEV)
+    bench.calibrate_scores(model, d0['img'], d0['img_metas'])
+
+    def maps_of(d, fn):
+        with torch.no_grad():
+            return [[t.float().clone() for t in group] for group in fn(d['img'])]
+
+    def eager_fn(img):
+        return model.bbox_head(model.extract_feat(img))
+
+    def gap(a, b):     # largest difference over all maps, in units of each map's range
+        return max(float((x - y).abs().max()) / max(float(y.abs().max()), 1e-6) for ga, gb in zip(a, b) for x, y in zip(ga, gb))
+    e0, e0b, e1 = maps_of(d0, eager_fn), maps_of(d0, eager_fn), maps_of(d1, eager_fn)
+    noise = gap(e0b, e0)
+    n_eager = [sum(len(r['scores']) for r in model(d['img'], d['img_metas'], return_loss=False, rescale=True)) for d in (d0, d1)]
+    g = enable_inference_graph(model, d0['img'])
+    assert g.matches(d0['img']) and g.matches(d1['img'])
+    for d, ref, n_ref in ((d0, e0, n_eager[0]), (d1, e1, n_eager[1]), (d0, e0, n_eager[0])):
+        got = maps_of(d, g)
+        err = gap(got, ref)
+        print(f'graph vs eager: {err:.2e} of a map\'s range (two eager runs: {noise:.2e})')
+        assert err <= max(4 * noise, 1e-3), (err, noise)
+        res = model(d['img'], d['img_metas'], return_loss=False, rescale=True)      # (simple_test takes the graph)
+        n = sum(len(r['scores']) for r in res)
+        assert len(res) == 8 and abs(n - n_ref) <= max(2, n_ref // 50), (n, n_ref)
+    assert gap(maps_of(d1, g), e0) > 100 * max(noise, 1e-4)      # (the replay really ran on the new input)
+    small = collate([ds[i] for i in range(4)], device=DEV)
+    assert not g.matches(small['img'])
+    assert len(model(small['img'], small['img_metas'], return_loss=False, rescale=True)) == 4
+    with torch.no_grad():
+        model.bbox_head.conv_cls.bias.add_(1.0)       # a parameter written in place: the captured constants are stale
+    assert not g.matches(d0['img'])
+    res = model(d0['img'], d0['img_metas'], return_loss=False, rescale=True)
+    assert sum(len(r['scores']) for r in res) > n_eager[0]      # (the eager path saw the new bias: more candidates pass)
