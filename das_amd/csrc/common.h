@@ -7,6 +7,7 @@
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 
 #define DAS_CHECK_LAUNCH()                                    \

@@ -180,8 +180,10 @@ __device__ __forceinline__ int tile_row_m(const ConvP& p, int m0, int ml) {
 struct NoCarry {};
 // BITS = false: the ReLU-mask-as-bits operands (ConvP::bnb_bits / res_bits) are compiled out — conv3x3_c64_kernel's epilogue is
 // not overlapped with anything (one workgroup owns the CU), and the step's launches of that kernel never carry bits.
-template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, bool T2D = false, bool BITS = true, typename Acc,
-          typename Carry = NoCarry>
+// MF = 32: the accumulators are 32 x 32 MFMA tiles (conv_glds4_kernel<.., MF = 32>): acc[a][b][r] = channel n0 + wave_n0 + a*32 +
+// 8*(r>>2) + 4*(lane>>5) + (r&3), pixel m0 + wave_m0 + b*32 + (lane&31) — only the staging into the LDS C tile differs.
+template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, bool T2D = false, bool BITS = true, int MF = 16,
+          typename Acc, typename Carry = NoCarry>
 __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* smem, int m0, int n0, Carry&& carry = Carry{}) {
   constexpr bool CARRY = !std::is_same<typename std::decay<Carry>::type, NoCarry>::value;   // (a float[2 * EPVO] otherwise)
   constexpr int TM = TL::TM, TN = TL::TN, NT = TL::NT;
@@ -190,6 +192,35 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m0 = TL::wave_m0(wave), wave_n0 = TL::wave_n0(wave);
   const int ch4 = (lane >> 4) * 4;
+  if constexpr (MF == 32) {
+    static_assert(TN == 4 && TM % 2 == 0, "32 x 32 accumulators: 64 channels x a multiple of 32 pixels per wave");
+#pragma unroll
+    for (int a = 0; a < TN / 2; ++a) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wave_n0 + a * 32 + g * 8 + (lane >> 5) * 4;
+        const int n = n0 + nl;
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.Cout) {
+          if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + n); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
+          if (p.shift) { const float4 t = *reinterpret_cast<const float4*>(p.shift + n); sh[0] = t.x; sh[1] = t.y; sh[2] = t.z; sh[3] = t.w; }
+        }
+#pragma unroll
+        for (int b = 0; b < TM / 2; ++b) {
+          const int ml = wave_m0 + b * 32 + (lane & 31);
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[a][b][g * 4 + j] * sc[j] + sh[j];
+          char* dst = smem + ml * CS + nl * (int)sizeof(OT);
+          if (sizeof(OT) == 2) {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
     const int nl = wave_n0 + a * 16 + ch4;
@@ -212,6 +243,7 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
+  }
   }
   __syncthreads();
   DAS_STAMP(5);

@@ -75,6 +75,9 @@ FORCE = {
                               'conv.glds4_mf': 8, 'conv.stream_minrows': 0},
     'conv_glds4_kernel<pp,288>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.splitk_target': 0,
                                   'conv.glds4_mf': 9, 'conv.stream_minrows': 0},
+    # the same 256 x 256 ping-pong tile on v_mfma_f32_32x32x16_bf16 (round 6)
+    'conv_glds4_kernel<pp,mf32>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.splitk_target': 0,
+                                   'conv.glds4_mf': 8, 'conv.stream_minrows': 0, 'conv.glds4_mfma32': 1},
 }
 
 # B, H, W, Cin, Cout, k, stride, pad
@@ -114,7 +117,7 @@ def test_glds3_forced(kernel, case):
     assert_bf16_exact(nchw(y), conv_ref(x, w, case[6], case[7]))
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>', 'conv_glds4_kernel<pp,mf32>'])
 @pytest.mark.parametrize('case', SHAPES4)
 def test_glds4_forced(kernel, case):
     x, w, y = _run_forced(kernel, case)
@@ -122,7 +125,8 @@ def test_glds4_forced(kernel, case):
     assert_bf16_exact(nchw(y), conv_ref(x, w, case[6], case[7]))
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>',
+                                    'conv_glds4_kernel<pp,mf32>'])
 def test_tile_epilogues_forced(kernel):
     """scale / shift / residual / ReLU, then the BatchNorm statistics of the stored values (in slots)."""
     o = ops()
@@ -147,7 +151,8 @@ def test_tile_epilogues_forced(kernel):
     np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>',
+                                    'conv_glds4_kernel<pp,mf32>'])
 def test_tile_ragged_levels_forced(kernel):
     """The head's mode: four FPN levels in one launch, shared 3x3 weights (das_head.py:176-178)."""
     o = ops()
@@ -165,7 +170,7 @@ def test_tile_ragged_levels_forced(kernel):
         np.testing.assert_allclose(nchw(y.level(l)).numpy(), ref.numpy(), **TOL)
 
 
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>'])
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>', 'conv_glds4_kernel<pp,mf32>'])
 def test_tile_dgrad_forced(kernel):
     """Data gradient of a stride-1 3x3 conv on the tile kernels (flipped weights), with a second gradient of the
     same tensor added in the epilogue."""

@@ -816,7 +816,7 @@ def test_inference_graph_replays_equal_the_eager_forward_and_fall_back_when_anyt
         res = model(d['img'], d['img_metas'], return_loss=False, rescale=True)      # (simple_test takes the graph)
         n = sum(len(r['scores']) for r in res)
         assert len(res) == 8 and abs(n - n_ref) <= max(2, n_ref // 50), (n, n_ref)
-    assert gap(maps_of(d1, g), e0) > 100 * max(noise, 1e-4)      # (the replay really ran on the new input)
+    assert gap(maps_of(d1, g), e0) > 20 * max(noise, 1e-4)      # (the replay really ran on the new input: 0.3 vs 3e-3 measured)
     small = collate([ds[i] for i in range(4)], device=DEV)
     assert not g.matches(small['img'])
     assert len(model(small['img'], small['img_metas'], return_loss=False, rescale=True)) == 4
