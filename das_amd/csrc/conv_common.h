@@ -94,6 +94,15 @@ __device__ __forceinline__ void dma16_buf(unsigned voff, v4i_t rsrc, unsigned ld
                : "memory");
 }
 
+// ... the same with the non-temporal cache policy (streamed operands nobody re-reads soon)
+__device__ __forceinline__ void dma16_buf_nt(unsigned voff, v4i_t rsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(rsrc), "s"(lds_byte_addr)
+               : "memory");
+}
+
 template <typename T>
 __device__ __forceinline__ uint4 relu_vec(uint4 v);
 template <>

@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void stream_stat_flush(float* sred, int lane, int n0,
   }
 }
 template <int KB, int WN, int MODE>   // K = 32 * KB input channels; WN waves across the 32-channel groups, 8 / WN across pixels
-__global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, int ntiles) {
+__global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, int ntiles, int ntm) {   // ntm: das_tuning key conv.stream_nt
   using T = bf16_t;
   constexpr bool STATS = MODE == 0, AFF = MODE == 1 || MODE == 5, RES = MODE == 2 || MODE == 5, BNB = MODE == 3 || MODE == 4 || MODE == 6;
   constexpr int WM = 8 / WN, TM = 64, PB = TM / WM / 16;    // 16-pixel blocks per wave and tile
@@ -1169,7 +1169,8 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
         const long long m = (long long)tile * TM + row;
         const bool ok = m < p.M && sub * 64 + kslot * 8 < K;
         const unsigned off = (unsigned)m * xrow2 + (unsigned)(sub * 64 + kslot * 8) * 2u;
-        dma16_buf(ok ? off : OOB, xrs, lds0 + stage * STAGE + sub * SUBB + rr * 1024);
+        if (ntm & 1) dma16_buf_nt(ok ? off : OOB, xrs, lds0 + stage * STAGE + sub * SUBB + rr * 1024);
+        else dma16_buf(ok ? off : OOB, xrs, lds0 + stage * STAGE + sub * SUBB + rr * 1024);
       }
     };
     const int mine = first < ntiles ? (ntiles - first + tstride - 1) / tstride : 0;   // tiles of this workgroup
@@ -1327,7 +1328,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
             Elem<T>::unpack(o, v);   // dZ as stored
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * x[j]; }   // (sum dZ * raw: centred below)
-            *reinterpret_cast<uint4*>(yg + m * p.yps + c8) = o;
+            st16(yg + m * p.yps + c8, o, ntm & 4);
           }
         }
       }
@@ -1422,7 +1423,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
           }
           if (rg || p.relu) o = Elem<T>::pack(v);
         }
-        *reinterpret_cast<uint4*>(yg + m * p.yps + c8) = o;
+        st16(yg + m * p.yps + c8, o, ntm & 4);
       }
     }
     st = (st + 1) % NS;
@@ -1483,7 +1484,7 @@ inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
     grid = std::min<long long>(grid, (long long)ntiles * ncol);
     grid = std::max<long long>(ncol, grid / ncol * ncol);
     dastune::note_kernel("conv1x1_stream_kernel");
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(640), sm, s, p, ncol, ntiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(640), sm, s, p, ncol, ntiles, (int)dastune::get(dastune::CONV_STREAM_NT));
     return true;
   };
   const bool aff = p.scale || p.shift;

@@ -1,16 +1,20 @@
 """Rounds 4-5: HBM traffic and matrix-core counters of the REAL train step's launches (no proxy mix).
 Inputs: the rocpd databases of three `rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 2 --warmup 1
 --no-cpu-baseline --no-also` passes (FETCH_SIZE; WRITE_SIZE; the MFMA set) — tools/dev/scripts/pmc_r5.sh.
-Outputs under <out>: r05_pmc_step_traffic.md (every kernel variant: dispatches, mean us, fetch / write MB per dispatch, TB/s),
-r05_stream_modes.md (conv1x1_stream_kernel<KB, WN, MODE> only), r05_pmc_mfma_step.md, and the `train` entries of traffic.json
+Outputs under <out>: {RND}_pmc_step_traffic.md (every kernel variant: dispatches, mean us, fetch / write MB per dispatch, TB/s),
+{RND}_stream_modes.md (conv1x1_stream_kernel<KB, WN, MODE> only), {RND}_pmc_mfma_step.md, and the `train` entries of traffic.json
 (bytes per launch of every bench.py family, from the step's own launches).
 usage: pmc_step_tables.py fetch.db write.db mfma.db <out dir>"""
 import json
+import os
 import re
 import sqlite3
 import sys
 
 from pmc_summary import norm
+
+RND = os.environ.get('DAS_ROUND', 'r06')      # file-name prefix of the tables; ROUND_NO in their titles
+ROUND_NO = RND.lstrip('r0') or '0'
 
 
 def per_kernel(db, counter=None):
@@ -55,21 +59,21 @@ def main(fdb, wdb, mdb, out):
         us = dur.get(k, (0, 0.0))[1]
         rows.append((k, n, us, fmb, wmb))
     rows.sort(key=lambda r: -r[1] * r[2])
-    with open(f'{out}/r05_pmc_step_traffic.md', 'w') as f:
-        f.write('# HBM traffic of every kernel of the REAL train step (round 5)\n\n')
+    with open(f'{out}/{RND}_pmc_step_traffic.md', 'w') as f:
+        f.write('# HBM traffic of every kernel of the REAL train step (round ' + ROUND_NO + ')\n\n')
         f.write(f'commands: `{CMD.format("FETCH_SIZE")}` and the same with `WRITE_SIZE` (separate passes, kernel trace only: '
-                'tools/dev/scripts/pmc_r5.sh). The launches are the step\'s own (B = 16, 4-stage MSPN-50 + FPN + head; warm-up, timed and '
+                'tools/dev/scripts/pmc_r*.sh). The launches are the step\'s own (B = 16, 4-stage MSPN-50 + FPN + head; warm-up, timed and '
                 'per-family measurement passes of bench.py: every step issues the same launches), not a proxy mix. FETCH_SIZE is doubled '
                 '(gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md, HBM section); MB = 1e6 bytes; us = mean kernel '
                 'duration in the FETCH pass (kernels run one at a time under --pmc).\n\n')
         f.write('| kernel | dispatches | mean us | fetch MB | write MB | (fetch + write) / time, TB/s |\n|---|---|---|---|---|---|\n')
         for k, n, us, fmb, wmb in rows[:70]:
             f.write(f'| `{k[:100]}` | {n} | {us:.1f} | {fmb:.1f} | {wmb:.1f} | {(fmb + wmb) / max(us, 1e-9):.2f} |\n')
-    with open(f'{out}/r05_stream_modes.md', 'w') as f:
-        f.write('# conv1x1_stream_kernel<KB, WN, MODE> on the step\'s real operands (round 5)\n\n')
+    with open(f'{out}/{RND}_stream_modes.md', 'w') as f:
+        f.write('# conv1x1_stream_kernel<KB, WN, MODE> on the step\'s real operands (round ' + ROUND_NO + ')\n\n')
         f.write('K = 32 KB input channels, WN waves across 32-channel groups; MODE 0 forward + BatchNorm statistics, 2 data gradient + '
                 'second gradient, 3 data gradient + fused BatchNorm-backward sums with the mask from y (+ second gradient), 4 the same with '
-                'the mask recomputed from raw. Same passes as r05_pmc_step_traffic.md.\n\n')
+                f'the mask recomputed from raw. Same passes as {RND}_pmc_step_traffic.md.\n\n')
         f.write('| variant | dispatches | mean us | fetch MB | write MB | TB/s |\n|---|---|---|---|---|---|\n')
         tot = [0, 0.0, 0.0]
         for k, n, us, fmb, wmb in sorted((r for r in rows if r[0].startswith('conv1x1_stream_kernel<')), key=lambda r: r[0]):
@@ -78,8 +82,8 @@ def main(fdb, wdb, mdb, out):
         f.write(f'\nfamily: {tot[0]} dispatches, {tot[2] / max(tot[1], 1e-9):.2f} TB/s of measured HBM traffic\n')
     # matrix-core counters
     mf, mdur = per_kernel(mdb, 'mfma')
-    with open(f'{out}/r05_pmc_mfma_step.md', 'w') as f:
-        f.write('# Matrix-core counters of the REAL train step\'s tile / weight-gradient kernels (round 5)\n\n')
+    with open(f'{out}/{RND}_pmc_mfma_step.md', 'w') as f:
+        f.write('# Matrix-core counters of the REAL train step\'s tile / weight-gradient kernels (round ' + ROUND_NO + ')\n\n')
         f.write(f'command: `{CMD.format("SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE")}`. '
                 'mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128): GUI_ACTIVE is summed over the 8 XCDs (32 CUs x 4 SIMDs each); '
                 'TF from MOPS_BF16 x 512 FLOP / mean duration.\n\n')
@@ -101,7 +105,7 @@ def main(fdb, wdb, mdb, out):
     path = f'{out}/traffic.json'
     doc = json.load(open(path))
     src = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; FETCH_SIZE x 2 as the guide prescribes for '
-           'gfx950) over the REAL train step: `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also` (round 5, tools/dev/scripts/pmc_r5.sh); '
+           'gfx950) over the REAL train step: `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also` (round ' + ROUND_NO + ', tools/dev/scripts/pmc_' + RND.replace('0', '') + '.sh); '
            'per launch of the family, reduce / fold passes counted as launches as bench.py counts them')
     for tag, match in FAMILIES:
         ks = [r for r in rows if match(r[0])]
@@ -112,7 +116,7 @@ def main(fdb, wdb, mdb, out):
         wm = sum(r[1] * r[4] for r in ks) / n
         doc['families'].setdefault(tag, {})['train'] = dict(dispatches=n, fetch_mb=round(fm, 2), write_mb=round(wm, 2),
                                                             hbm_mb_per_launch=round(fm + wm, 2), source=src)
-    doc['note'] = ('HBM bytes per launch behind bench.py roofline*.traffic. train: measured on the step\'s own launches (round 5); '
+    doc['note'] = ('HBM bytes per launch behind bench.py roofline*.traffic. train: measured on the step\'s own launches (round ' + ROUND_NO + '); '
                    'compare with the line\'s algorithmic_mb_per_launch directly. infer: round-2 passes.')
     json.dump(doc, open(path, 'w'), indent=1, sort_keys=True)
     print('wrote tables and', path)

@@ -14,6 +14,7 @@ python3 tools/dev/pricing_repro.py $O/prof_line.json "$db" "(under rocprofv3)" >
 python3 tools/dev/pricing_repro.py $O/plain_line.json "$db" "(plain run; kernel times from the rocprofv3 run)" >> $O/repro.md
 if [ "$1" = "hog" ]; then
   pids=""
+  trap '[ -n "$pids" ] && kill $pids 2>/dev/null' EXIT   # (an outer timeout must not leave the 32 busy loops running on a shared box)
   for i in $(seq 1 32); do python3 -c "while True: pass" & pids="$pids $!"; done
   timeout 900 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also 2>$O/hog.err | tail -1 > $O/hog_line.json
   kill $pids

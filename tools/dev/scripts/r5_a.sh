@@ -22,6 +22,7 @@ PY
 if [ -d r4tree ]; then
   cd r4tree
   pids=""
+  trap '[ -n "$pids" ] && kill $pids 2>/dev/null' EXIT   # (an outer timeout must not leave the 32 busy loops running on a shared box)
   for i in $(seq 1 32); do python3 -c "while True: pass" & pids="$pids $!"; done
   timeout 900 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also 2>../$O/r4_hog.err | tail -1 > ../$O/r4_hog_line.json
   kill $pids
