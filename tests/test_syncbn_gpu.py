@@ -123,3 +123,22 @@ def test_row_count_check_is_looked_at_lazily_and_raises_when_its_answer_says_so(
     assert len(ag._rows_pending) <= ag.ROWS_CHECK_LAG
     ag.verify_rows(wait=True)
     assert not ag._rows_pending
+
+
+def test_a_row_count_mismatch_in_the_last_step_is_reported_before_weights_are_saved():
+    """the row-count answer of a step is read up to ROWS_CHECK_LAG steps later; a mismatch in the LAST steps before a
+    checkpoint / evaluation / the end of the run must still raise — optim.finish_checks() (called by tools/train.py at every
+    epoch end, before the checkpoint is written, and at the end of the run) waits for whatever is still in flight."""
+    from das_amd import autograd as ag
+    from das_amd.optim import finish_checks
+    ag._rows_pending.clear()
+    dev = torch.tensor([26624.0, -13312.0], dtype=torch.float64, device='cuda')     # (a short last batch on one rank)
+    host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+    host.copy_(dev, non_blocking=True)
+    ev = torch.cuda.Event(blocking=True)
+    ev.record()
+    ag._rows_pending.append((host, ev, 26624))
+    with pytest.raises(RuntimeError, match='different numbers of pixel rows'):
+        finish_checks()
+    assert not ag._rows_pending
+    finish_checks()          # nothing pending: a no-op
