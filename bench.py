@@ -597,22 +597,9 @@ def decode_workload(args, rank, world, dev, quiet=False, batch=None, steps=None,
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
-        # per-rank wall clock of the timed region, gathered so that the first real multi-GPU line explains itself (a slow
-        # rank, a straggling bucket): value / ms_per_step use the MAX, as the contract says
-        mine = torch.tensor([dt, per[len(per) // 2] * 1e-3], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        dts = [float(a[0]) for a in allr]
-        extra['ranks_ms_per_step'] = dict(min=round(min(dts) / steps * 1e3, 3), max=round(max(dts) / steps * 1e3, 3),
-                                          per_rank=[round(x / steps * 1e3, 3) for x in dts],
-                                          per_rank_median_gpu_step=[round(float(a[1]) * 1e3, 3) for a in allr])
-        dt = max(dts)
-    if train and comm is not None:
-        comm.update(grad_comm_dtype=str(opt.grad_comm_dtype).replace('torch.', ''), buckets=len(opt.buckets),
-                    bucket_mb=[round((e - s) * (2 if opt.grad_comm_dtype == torch.bfloat16 else 4) / 2 ** 20, 1)
-                               for s, e in opt.buckets],
-                    end_only_buckets=int(sum(opt._endonly)), overlapped_launches_total=opt.overlapped_launches,
-                    reserved_cus_while_in_flight=opt.comm_reserved_cus)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
     if rank != 0:
         return
     kern_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / steps     # events bracket the launch on its stream
