@@ -627,7 +627,13 @@ typedef struct {
                  * das_head.py:784-790): nms_post rounds of "take the best remaining score, multiply every other
                  * remaining score by exp(-oks^2 / nms_thr)"; the scores returned are the original ones */
 } DasDecodeDesc;
-/* candidate capacity per image = sum over levels of min(H*W, nms_pre) */
+/* candidate capacity per image = sum over levels of min(H*W, nms_pre) (H*W for nms_pre <= 0).
+ * No size limits, as in the reference (das_head.py:716-723 cuts a level to nms_pre only when it has more points): any number of
+ * locations per level (what the kernel keeps in LDS are the locations ABOVE score_thr — up to 16 384 per level there, beyond that
+ * the level's nms_pre-th key comes from a radix select over re-computed scores) and any capacity (beyond 4096 candidates the
+ * suppression flags, beyond 16 384 the globally sorted keys live in the workspace). Only the total number of locations must fit
+ * 31 bits (the flat location index). The workspace (das_decode_ws_bytes, device memory, uninitialised) holds per image the merged
+ * keys padded to a power of two, the candidates' joints / areas / centres, soft-NMS scores and suppression flags. */
 int das_decode_cap(const DasDecodeDesc* d);
 long long das_decode_ws_bytes(int B, int cap, int J);
 int das_decode(const DasDecodeDesc* d, float* out_scores, float* out_poses, float* out_centers, int* out_index,
