@@ -27,14 +27,14 @@ def main(line_path, db, label=''):
     rows = c.execute('select name, count(*), sum(end-start) from kernels group by name').fetchall()
     steps = sum(n for name, n, _ in rows if 'assign_targets_kernel' in name)
     out = [f'box {socket.gethostname()} {label}: {line["ms_per_step"]} ms/step timed, pass {pr["step_ms_this_pass"]} ms '
-           f'(median {pr.get("step_ms_this_pass_median")}), families {pr["families_ms_sum"]} ms, unreliable={pr.get("unreliable")}, '
+           f'(median of the passes; min {pr.get("step_ms_this_pass_min")}), families {pr["families_ms_sum"]} ms, unreliable={pr.get("unreliable")}, '
            f'attempts={pr.get("attempts")}, headline {line["roofline"]["kernel"]} frac {line["roofline"]["frac"]}; '
            f'rocprof run: {steps} steps']
-    out.append('| family | event pairs, min (ms/step) | event pairs, median | rocprof kernel time (ms/step) | events / kernels |')
+    out.append('| family | event pairs, median (ms/step) | event pairs, min | rocprof kernel time (ms/step) | events (median) / kernels |')
     out.append('|---|---|---|---|---|')
     for tag, rx in FAMS.items():
         ev = pr['families_ms'].get(tag)
-        med = pr.get('families_ms_median', {}).get(tag)
+        med = pr.get('families_ms_min', {}).get(tag)
         kt = sum(t for name, _, t in rows if re.search(rx, name)) / 1e6 / max(steps, 1)
         if ev is None:
             continue
