@@ -63,6 +63,8 @@ struct ConvP {
   // and stores its raw f32 accumulators to ws[s][M][Cout]; splitk_finish_kernel sums the slabs and runs the epilogue.
   float* ws;
   int ksplit;
+  int* sk_cnt;      // != nullptr: split-K finished INSIDE the tile kernel — one arrival counter per tile (zero between launches): the
+                    // workgroup that draws ticket ksplit - 1 sums the slabs (fixed order) and runs the epilogue itself
   // sub-grid output (DasConvDesc.out_sub): output pixel (b, i, j) is row (b * oH + 2 i + oph) * oW + 2 j + opw of y,
   // of the residual and of the bnb_* tensors
   int osub, oph, opw, oH, oW;

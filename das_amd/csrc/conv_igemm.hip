@@ -197,6 +197,56 @@ __device__ __forceinline__ void splitk_store(const Acc& acc, const ConvP& p, int
       dst[(a * TM + b) * 64] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
 }
 
+// Split-K finished inside the tile kernel (ConvP::sk_cnt; tuning key conv.splitk_inkernel): after its slab is stored a
+// workgroup publishes it and draws a ticket on the tile's arrival counter; the LAST arriver sums all ksplit slabs — its own
+// too, re-read, in slab order: the same fixed summation order as splitk_finish_kernel, whoever arrives last — into `acc`
+// and returns true (the caller runs the epilogue); the others return false. The hand-off is the guide's counter form
+// (cdna guide section 6, guideline 16): plain slab stores -> every wave s_waitcnt vmcnt(0) -> workgroup barrier -> one lane:
+// agent-scope release fence, vmcnt(0) again in asm (the compiler may drop the fence's own wait), relaxed agent-scope ticket
+// -> last arriver: one agent-scope acquire fence (drops this CU's L1), barrier, plain loads. The counter is reset by the last
+// arriver (it was zero when the workspace was allocated), so consecutive launches on the stream find it zero.
+template <int BN, int BMT, typename Acc>
+__device__ __forceinline__ bool splitk_arrive_and_reduce(Acc& acc, const ConvP& p, int tile, char* smem) {
+  constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // every wave's slab stores are out; the LDS stages are dead
+  volatile int* flag = reinterpret_cast<volatile int*>(smem);
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *flag = __hip_atomic_fetch_add(p.sk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int ticket = *flag;
+  if (ticket != p.ksplit - 1) return false;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __hip_atomic_store(p.sk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const float4* src = reinterpret_cast<const float4*>(p.ws) + splitk_slot<BN, BMT>(p, 0, tile);
+  const size_t slab = (size_t)p.nblocks * (Tiling<BN, BMT>::NT / 64) * (TN * TM) * 64;
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const float4 v = src[(a * TM + b) * 64];
+      acc[a][b] = f32x4_t{v.x, v.y, v.z, v.w};
+    }
+  for (int s = 1; s < p.ksplit; ++s) {
+    src += slab;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const float4 v = src[(a * TM + b) * 64];
+        acc[a][b][0] += v.x; acc[a][b][1] += v.y; acc[a][b][2] += v.z; acc[a][b][3] += v.w;
+      }
+  }
+  __syncthreads();   // (the flag word is part of the C tile the epilogue is about to write)
+  return true;
+}
+
 template <typename T, typename OT, int BN, int BMT>
 __global__ __launch_bounds__(2 * BMT, 2) void conv_glds_kernel(ConvP p) {   // (two workgroups per CU: at most 256 registers)
   constexpr int EPV = Elem<T>::EPV;
@@ -660,8 +710,14 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
     nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
   }
   DAS_STAMP(3);
-  if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); DAS_STAMP(4); return; }
-  __syncthreads();  // all LDS reads done before the C tile reuses the buffers
+  if (p.ksplit > 1) {
+    splitk_store<BN, BMT>(acc, p, logical);
+    DAS_STAMP(4);
+    if (!p.sk_cnt) return;                                                    // (splitk_finish_kernel follows)
+    if (!splitk_arrive_and_reduce<BN, BMT>(acc, p, logical, smem)) return;    // not the last split of this tile
+  } else {
+    __syncthreads();  // all LDS reads done before the C tile reuses the buffers
+  }
   conv_epilogue<OT, BN, BMT, Tiling<BN, BMT>, false, BITS>(acc, p, smem, m0, n0);
   DAS_STAMP(4);
 }
@@ -960,11 +1016,20 @@ inline int pick_ksplit(long long nblocks, int nk, int per_cu, int bit, long long
   return ks < 2 ? 1 : (int)ks;
 }
 // Launch a tile kernel split over blockIdx.y, then the finishing kernel on the same tile map.
-template <typename OT, int BN, int BMT, typename Kern>
+// INK: the kernel can finish the sum itself (ConvP::sk_cnt, splitk_arrive_and_reduce) — used when tuning key
+// conv.splitk_inkernel is 1: one launch instead of two.
+template <typename OT, int BN, int BMT, bool INK = false, typename Kern>
 int launch_splitk(Kern kern, ConvP& p, int ks, size_t sm, hipStream_t s) {
   p.ws = dasws::get(dasws::CONV_SPLITK, s, (size_t)ks * p.nblocks * BN * BMT * sizeof(float), (size_t)32 << 20);
   if (!p.ws) return DAS_ERR_LAUNCH;
   p.ksplit = ks;
+  if (INK && dastune::get(dastune::CONV_SPLITK_INKERNEL) == 1) {
+    p.sk_cnt = reinterpret_cast<int*>(dasws::get(dasws::SPLITK_CNT, s, (size_t)p.nblocks * sizeof(int), (size_t)64 << 10));
+    if (!p.sk_cnt) return DAS_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(p.nblocks, ks), dim3(Tiling<BN, BMT>::NT), sm, s, p);
+    DAS_CHECK_LAUNCH();
+    return DAS_OK;
+  }
   static bool fin_attr = false;   // (one per instantiation)
   const size_t sm_fin = epilogue_smem_bytes<OT, BN, BMT>();
   if (!fin_attr) {
@@ -1065,8 +1130,8 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
     if constexpr (BN == 128 && sizeof(OT) == 2) {
       if (ks3 > 1) {
         dastune::note_kernel("conv_glds3_kernel<splitk>");
-        return pp3 ? launch_splitk<OT, 128, 256>(conv_glds3_kernel<T, OT, true>, p, ks3, sm_big, s)
-                   : launch_splitk<OT, 128, 256>(conv_glds3_kernel<T, OT, false>, p, ks3, sm_big, s);
+        return pp3 ? launch_splitk<OT, 128, 256, true>(conv_glds3_kernel<T, OT, true>, p, ks3, sm_big, s)
+                   : launch_splitk<OT, 128, 256, true>(conv_glds3_kernel<T, OT, false>, p, ks3, sm_big, s);
       }
     }
     dastune::note_kernel(pp3 ? "conv_glds3_kernel<pp>" : "conv_glds3_kernel");
@@ -1687,7 +1752,7 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   p.up_sh = d->in_up == 2 ? 1 : 0;
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0; p.m_base = 0; p.mstep = 0;
-  p.ws = nullptr; p.ksplit = 1;
+  p.ws = nullptr; p.ksplit = 1; p.sk_cnt = nullptr;
   p.osub = d->out_sub ? 1 : 0; p.oph = d->out_ph; p.opw = d->out_pw; p.oH = d->out_H; p.oW = d->out_W;
   if (p.osub) {   // sub-grid output: see DasConvDesc
     if (p.nlev > 1 || d->stride != 1 || (unsigned)p.oph > 1u || (unsigned)p.opw > 1u || d->Ho < 1 || d->Wo < 1 ||

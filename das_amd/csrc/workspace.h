@@ -6,7 +6,8 @@
 #include <cstddef>
 
 namespace dasws {
-enum Kind { WGRAD = 0, CONV_SPLITK = 1, BN_FOLD = 2, N_KINDS };
+enum Kind { WGRAD = 0, CONV_SPLITK = 1, BN_FOLD = 2, SPLITK_CNT = 3, N_KINDS };   // SPLITK_CNT: zero-filled when (re)allocated (arrival
+                                                                                  // counters that their kernels leave at zero)
 // nullptr on allocation failure. `min_bytes`: size of the first allocation (avoids regrowth layer by layer).
 float* get(Kind kind, hipStream_t s, size_t bytes, size_t min_bytes);
 }  // namespace dasws

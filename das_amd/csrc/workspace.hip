@@ -35,6 +35,7 @@ float* get(Kind kind, hipStream_t s, size_t bytes, size_t min_bytes) {
     const size_t want = std::max(bytes, min_bytes);
     if (hipMalloc(reinterpret_cast<void**>(&e->buf), want) != hipSuccess) { e->buf = nullptr; return nullptr; }
     e->bytes = want;
+    if (kind == SPLITK_CNT && hipMemsetAsync(e->buf, 0, want, s) != hipSuccess) return nullptr;   // (ordered before the first user on s)
   }
   return e->buf;
 }

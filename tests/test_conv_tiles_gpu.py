@@ -345,6 +345,46 @@ def test_splitk_matches_unsplit(kernel, idx):
     np.testing.assert_allclose(nchw(y2).numpy(), nchw(y1).numpy(), rtol=8e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize('kernel', ['conv_glds3_kernel<pp>', 'conv_glds3_kernel'])
+def test_splitk_finished_inside_the_kernel_is_bitwise_the_two_launch_result(kernel):
+    """Tuning key conv.splitk_inkernel = 1 (round 6): the split-K sum of conv_glds3_kernel is finished by the LAST workgroup to
+    arrive at a tile (agent-scope release / ticket / acquire, csrc/conv_igemm.hip splitk_arrive_and_reduce) instead of by
+    splitk_finish_kernel. The slabs are summed in slab order whoever arrives last, so the result must be BITWISE the two-launch
+    result — for every shape of the split-K set, with residual + ReLU and with BatchNorm statistics, and on every one of 40
+    repetitions while another stream keeps 64 CUs busy in bursts (uneven arrival order; a stale slab or a torn counter shows as
+    a differing element)."""
+    import ctypes
+    from das_amd import _lib
+    o = ops()
+    lib = _lib.load()
+    force, bit, shapes = SPLITK[kernel]
+    side = torch.cuda.Stream()
+    for (B, H, W, Cin, Cout, k, s, p) in shapes:
+        x = cases.randn(221, B, Cin, H, W)
+        w = cases.randn(222, Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+        xd, wd = nhwc(x), o.pack_weight(w.to(DEV), BF)
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        res = nhwc(cases.randn(223, B, Cout, Ho, Wo))
+        split = {**force, 'conv.splitk_target': 512, 'conv.splitk_minsteps': 2, 'conv.splitk_kernels': bit}
+        with o.tuning(**split):
+            y0 = o.conv2d(xd, wd, k, k, s, p, residual=res, relu=True)
+            assert o.last_kernel().endswith('<splitk>'), o.last_kernel()
+            st0 = torch.zeros(2 * Cout, device=DEV)
+            r0 = o.conv2d(xd, wd, k, k, s, p, stats=st0)
+        with o.tuning(**{**split, 'conv.splitk_inkernel': 1}):
+            for rep in range(40):
+                if rep % 4 == 0:     # bursts of foreign work beside the launch: the splits of a tile arrive in a different order
+                    _lib.check(lib.das_dev_occupy_cus(64, 256, 4096, 30 + 7 * rep, ctypes.c_void_p(side.cuda_stream)), 'occupy')
+                y1 = o.conv2d(xd, wd, k, k, s, p, residual=res, relu=True)
+                assert o.last_kernel().endswith('<splitk>'), o.last_kernel()
+                assert torch.equal(y1, y0), (kernel, (B, H, W, Cin, Cout, k, s, p), rep, float((y1.float() - y0.float()).abs().max()))
+            st1 = torch.zeros(2 * Cout, device=DEV)
+            r1 = o.conv2d(xd, wd, k, k, s, p, stats=st1)
+            assert torch.equal(r1, r0)
+            np.testing.assert_allclose(st1.cpu().numpy(), st0.cpu().numpy(), rtol=1e-5, atol=1e-3)   # (float atomics: order)
+    torch.cuda.synchronize()
+
+
 def test_splitk_epilogues_and_default_dispatch():
     """The layer4 3x3 at B=8 takes split-K by default; every epilogue runs in the finishing kernel."""
     o = ops()
