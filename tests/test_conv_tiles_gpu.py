@@ -880,3 +880,42 @@ def test_persistent_grids_follow_the_cu_reserve():
     torch.cuda.synchronize()
     assert 1.8 <= e0.elapsed_time(e1) <= 4.0 and torch.equal(y, out[0][0])
     assert lib.das_dev_occupy_cus(0, 256, 4096, 10, None) == _lib.DAS_ERR_ARG
+
+
+def test_wgrad_pp_share_is_per_thread_and_follows_the_usable_cus():
+    """das_wgrad_pp_share (round 6): the calling thread's share of the usable CUs for the ping-pong weight-gradient
+    grid — what das_amd.autograd._on_side sets around side-stream launches instead of flipping the process-global key
+    wgrad.pp_blocks. Half the usable CUs with share 2 (also under a CU reserve), the whole chip again with share 1, another
+    thread never sees it, an explicit wgrad.pp_blocks wins; the gradient is the same up to the regrouping of f32 partial sums."""
+    import threading
+    from das_amd import _lib
+    o = ops()
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    xg, dyg = nhwc(cases.randn(311, 2, 256, 32, 52)), nhwc(cases.randn(312, 2, 256, 32, 52))
+
+    def grid():
+        dw = o.conv2d_wgrad(xg, dyg, 3, 3, 1, 1)
+        plan = o.last_wgrad_plan()
+        assert plan['cls'] == 0, plan
+        return plan['grid'], dw
+    g1, dw1 = grid()
+    assert g1 == cus
+    assert lib.das_wgrad_pp_share(0) != 0 and lib.das_wgrad_pp_share(17) != 0      # (DAS_ERR_ARG: 1 .. 16)
+    assert lib.das_wgrad_pp_share(2) == 0
+    try:
+        g2, dw2 = grid()
+        assert g2 == cus // 2
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(grid()[0]))
+        t.start()
+        t.join()
+        assert seen == [cus]                      # another thread: the whole chip
+        with o.tuning(**{'comm.reserved_cus': 40}):
+            assert grid()[0] == (cus - 40) // 2
+        with o.tuning(**{'wgrad.pp_blocks': 96}):
+            assert grid()[0] == 96                # the explicit key wins over the share
+    finally:
+        assert lib.das_wgrad_pp_share(1) == 0
+    assert grid()[0] == cus
+    np.testing.assert_allclose(dw2.cpu().numpy(), dw1.cpu().numpy(), rtol=2e-3, atol=2e-3)

@@ -321,3 +321,33 @@ def test_zero_arena_never_refills_a_slice_that_may_still_be_in_use():
         s.fill_(7.0)
     a.reset()
     assert float(a.take(64, dev).abs().max()) == 0.0
+
+
+def test_gc_park_policy_of_the_training_loop():
+    """optim.GcPark (the ONE garbage-collector policy of tools/train.py and bench.py): automatic collection stays on
+    during warm-up, is parked (everything alive frozen) from step `warmup` on, collect() runs a collection at the loop's quiet
+    points, release() restores the interpreter's state."""
+    import gc
+    from das_amd.optim import GcPark
+    assert gc.isenabled()
+    g = GcPark(warmup=3)
+    try:
+        g.step(); g.step()
+        assert gc.isenabled() and not g.parked
+        g.collect()                       # (a no-op before parking)
+        g.step()
+        assert g.parked and not gc.isenabled() and gc.get_freeze_count() > 0
+
+        class Node:
+            pass
+        a, b = Node(), Node()
+        a.other, b.other = b, a           # a reference cycle: only the cyclic collector frees it
+        import weakref
+        w = weakref.ref(a)
+        del a, b
+        assert w() is not None
+        g.collect()
+        assert w() is None
+    finally:
+        g.release()
+    assert gc.isenabled() and gc.get_freeze_count() == 0 and not g.parked
