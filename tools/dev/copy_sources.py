@@ -14,15 +14,28 @@ from das_amd.datasets import SyntheticPoseDataset, collate  # noqa: E402
 from das_amd.optim import FlatSGD, train_iteration  # noqa: E402
 
 dev = torch.device('cuda', 0)
-model = bench.build_model(dev, num_stages=4, train=True)
-ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=16, seed=0)
-data = collate([ds[i] for i in range(16)], device=dev)
-opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=35.0)
+INFER = '--infer' in sys.argv      # the B = 8 1-stage inference step (forward + decode) instead of the train step
+if INFER:
+    model = bench.build_model(dev, num_stages=1, train=False)
+    ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=8, seed=0)
+    data = collate([ds[i] for i in range(8)], device=dev)
+    bench.calibrate_scores(model, data['img'], data['img_metas'])
+
+    def one_step():
+        return model(data['img'], data['img_metas'], return_loss=False, rescale=True)
+else:
+    model = bench.build_model(dev, num_stages=4, train=True)
+    ds = SyntheticPoseDataset(num_joints=bench.J, img_shape=(bench.H, bench.W), length=16, seed=0)
+    data = collate([ds[i] for i in range(16)], device=dev)
+    opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0, max_grad_norm=35.0)
+
+    def one_step():
+        return train_iteration(model, opt, data, 2e-3)
 for _ in range(4):
-    train_iteration(model, opt, data, 2e-3)
+    one_step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    train_iteration(model, opt, data, 2e-3)
+    one_step()
     torch.cuda.synchronize()
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sites = collections.Counter()
@@ -32,7 +45,8 @@ for ev in prof.events():
     if ev.name in names and ev.cpu_parent is not None and ev.cpu_parent.name.startswith('aten::'):
         continue      # (count the outermost aten op only)
     if ev.name in names:
-        frame = next((f for f in ev.stack if ('das_amd' in f or 'bench.py' in f) and 'torch/' not in f), ev.stack[0] if ev.stack else '?')
+        stack = getattr(ev, 'stack', None) or []
+        frame = next((f for f in stack if ('das_amd' in f or 'bench.py' in f) and 'torch/' not in f), stack[0] if stack else '?')
         sites[(ev.name, frame.replace(ROOT + '/', ''))] += 1
 kern = collections.Counter()
 for ev in prof.events():
