@@ -59,3 +59,37 @@ for k, v in kern.most_common():
 print('aten ops by innermost das_amd frame:')
 for (n, f), v in sites.most_common(60):
     print(f'  {v:5d}  {n:18s} {f}')
+
+
+# ---- the same question answered on the Python side (the profiler's stacks are empty on this build): a dispatch mode that
+# records the innermost das_amd / bench frame of every ATen call that launches a copy / fill / cat / elementwise kernel
+import traceback  # noqa: E402
+
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
+
+WATCH = ('copy_', '_to_copy', 'clone', 'cat', 'stack', 'fill_', 'zero_', 'add', 'mul', 'sub', 'div', 'sigmoid', 'contiguous',
+         'ones', 'zeros', 'full', 'empty_like', 'index', 'slice_scatter', 'select_scatter')
+
+
+class Sites(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.sites = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.__name__.split('.')[0]
+        out = func(*args, **(kwargs or {}))
+        if name in WATCH and any(torch.is_tensor(a) and a.is_cuda for a in list(args) + ([out] if torch.is_tensor(out) else [])):
+            fr = [f for f in traceback.extract_stack() if ('das_amd' in f.filename or 'bench.py' in f.filename)
+                  and 'copy_sources' not in f.filename]
+            where = f'{os.path.relpath(fr[-1].filename, ROOT)}:{fr[-1].lineno} {fr[-1].name}' if fr else '?'
+            self.sites[(name, where)] += 1
+        return out
+
+
+with Sites() as rec:
+    one_step()
+    torch.cuda.synchronize()
+print('ATen calls on device tensors in one step, by innermost das_amd / bench frame (dispatch mode):')
+for (n, w), v in rec.sites.most_common(50):
+    print(f'  {v:5d}  {n:14s} {w}')
