@@ -1520,6 +1520,248 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
   }
 }
 
+// ------------------------------------------------------------------ weight-stationary 1x1 convolution for K = 512 / 1024 (round 6)
+// The long-K "reduce" convs (512 -> 128 at 64 x 104, 1024 -> 256 at 32 x 52: forward with statistics, data gradients with the
+// fused BatchNorm backward) run on the tile kernels at 1.4-2.4x their HBM floor: the tile's K loop is bound by LDS-DMA ISSUE
+// (a wave's interval carries 6 DMA instructions of ~150 cycles against 512 cycles of MFMAs), and a third of what it issues is
+// the weight tile every workgroup re-fetches every step. conv1x1_stream_kernel keeps the weights in registers, but 32 channels
+// x K > 256 do not fit beside its ten waves' 168 registers. Here the eight waves of a workgroup (2 per SIMD: 256 registers)
+// split K in two: waves 0-3 ("front", one per 32-channel group of the 128-channel column block) hold the lower half of K,
+// waves 4-7 ("back") the upper half. The pixel operand streams through LDS in tiles of 16 rows x K (32 KiB at K = 1024, four
+// stages, three tiles ahead); the BACK waves issue its DMA — they never store to global memory, so their counted vmcnt does
+// say "tile i has landed" (cf. conv1x1_stream_kernel's loader waves) — and hand their partial sums to the front waves through
+// 8 KiB of LDS; the front waves add their own, run the epilogue (a lane owns eight consecutive channels of one pixel: one
+// 16-byte store) and carry the per-channel sums in registers for the whole launch. ONE workgroup barrier per tile (it says
+// "partial sums of tile i written" and "tile i + 1 landed" at once: two alternating partial-sum sets make that legal).
+// MODE 0: plain output, optional BatchNorm statistics (training forward). MODE 4: data gradient with the fused BatchNorm-
+// backward reduction, ReLU mask recomputed from the pre-norm tensor (ConvP::bnb_raw, no residual: the `bx` launches).
+template <int KB, int MODE>   // K = 32 * KB input channels (KB = 16 / 32)
+__global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol, int ntiles) {
+  using T = bf16_t;
+  constexpr bool BNB = MODE == 4;
+  constexpr int K = KB * 32, KH = KB / 2;                     // K steps of 32 per wave
+  constexpr int PB = KB == 16 ? 2 : 1;                        // 16-pixel blocks per tile: 32-row tiles at K = 512, 16 at K = 1024
+  constexpr int TM = 16 * PB, SUBS = K / 64, SUBB = TM * 128, STAGE = SUBS * SUBB;   // (32 KiB per stage either way)
+  constexpr int NS = 4, AHEAD = NS - 1;
+  constexpr int RPS = TM / 8;                                 // DMA instructions per sub-tile (8 rows x 128 B each)
+  constexpr int IPW = SUBS * RPS / 4;                         // DMA instructions per back wave and tile
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wk = wave >> 2;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);       // the column blocks of a row tile share an XCD (its L2)
+  const int col = logical % ncol, first = logical / ncol, tstride = gridDim.x / ncol;
+  const int n0 = col * 128 + wn * 32;                         // this wave's 32 output channels
+  const int q = lane & 15, g4 = lane >> 4;
+  const int mine = first < ntiles ? (ntiles - first + tstride - 1) / tstride : 0;   // row tiles of this workgroup
+
+  // back waves: the first three pixel tiles are requested BEFORE anything else (the weights' 32 KiB per wave then load beside them)
+  const v4i_t xrs = make_rsrc(p.x, p.xbytes);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned xrow2 = (unsigned)p.xps * 2u;
+  auto issue = [&](int tile, int stage) {
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int ii = wn * IPW + j, sub = ii / RPS, rr = ii % RPS;
+      const int row = rr * 8 + (lane >> 3);
+      const int kslot = (lane & 7) ^ ((row >> 1) & 7);
+      const long long m = (long long)tile * TM + row;
+      const unsigned off = (unsigned)m * xrow2 + (unsigned)(sub * 64 + kslot * 8) * 2u;
+      dma16_buf(m < p.M ? off : OOB, xrs, lds0 + stage * STAGE + sub * SUBB + rr * 1024);
+    }
+  };
+  if (wk == 1) {
+    for (int i = 0; i < AHEAD && i < mine; ++i) issue(first + i * tstride, i);
+  }
+
+  // weights -> MFMA A fragments of this wave's K half (row permutation as in conv1x1_stream_kernel: the accumulator lane
+  // (pixel q, rows g4 * 4 + j) owns channels n0 + g4 * 8 + a * 4 + j)
+  uint4 wf[2][KH];
+  {
+    const T* wg = reinterpret_cast<const T*>(p.w);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ch = n0 + (q >> 2) * 8 + a * 4 + (q & 3);
+#pragma unroll
+      for (int kb = 0; kb < KH; ++kb)
+        wf[a][kb] = ch < p.Cout ? *reinterpret_cast<const uint4*>(wg + (long long)ch * K + (wk * KH + kb) * 32 + g4 * 8)
+                                : make_uint4(0, 0, 0, 0);
+    }
+  }
+  // partial sums of the back waves: two sets used alternately (tile i in set i & 1), so that ONE barrier per tile is enough
+  f32x4_t* xch = reinterpret_cast<f32x4_t*>(smem + NS * STAGE) + (wn * 64 + lane) * (2 * PB);
+  constexpr int XSET = 4 * 64 * 2 * PB;   // f32x4_t per set
+  auto partial = [&](int st, int pb, f32x4_t& acc0, f32x4_t& acc1) {   // this wave's K half of pixel block pb of the tile in stage st
+    const char* sx = smem + st * STAGE;
+    const int row = pb * 16 + q;
+    acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KH; ++kb) {
+      const int kg = wk * KH + kb;
+      const int slot = ((kg & 1) * 4 + g4) ^ ((row >> 1) & 7);
+      const uint4 bf = *reinterpret_cast<const uint4*>(sx + (kg >> 1) * SUBB + row * 128 + slot * 16);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[0][kb]), __builtin_bit_cast(bf16x8_t, bf), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[1][kb]), __builtin_bit_cast(bf16x8_t, bf), acc1, 0, 0, 0);
+    }
+  };
+  if (mine == 0) return;   // (wave-uniform and workgroup-uniform: nobody reaches a barrier)
+
+  // One barrier per tile. Barrier i says two things: "the back waves' partial sums of tile i are in LDS (set i & 1)" and "tile
+  // i + 1 has landed". Stage of tile i + 3 = stage of tile i - 1, read out before barrier i - 1; partial-sum set i & 1 is
+  // written again for tile i + 2, after barrier i + 1, which the front waves only reach after reading set i & 1.
+  if (wk == 1) {   // ---- back waves: the upper K half, the DMA of the pixel tiles
+    // tile 0 landed: at most tiles 1, 2 (and the weight loads, issued after them: waited for by the compiler at first use) fly
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // start: tile 0 is in LDS
+    asm volatile("" ::: "memory");
+    for (int i = 0; i < mine; ++i) {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        f32x4_t a0, a1;
+        partial(i % NS, pb, a0, a1);
+        xch[(i & 1) * XSET + pb * 2] = a0;
+        xch[(i & 1) * XSET + pb * 2 + 1] = a1;
+      }
+      // tile i + 1 landed: the tiles issued after it that may still fly are i + 2 (tile i + 3 goes out below)
+      if (i + 2 < mine) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IPW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();   // barrier i
+      asm volatile("" ::: "memory");
+      if (i + AHEAD < mine) issue(first + (i + AHEAD) * tstride, (i + AHEAD) % NS);   // (into the stage of tile i - 1)
+    }
+    return;
+  }
+
+  // ---- front waves: the lower K half, the sum of the halves, the epilogue
+  const int c8 = n0 + g4 * 8;   // this lane's eight output channels
+  const bool cok = c8 < p.Cout;
+  // this wave's 64 reduced sums: over the start of its OWN partial-sum slots (dead once its loop has ended: the back wave of the
+  // same channel group wrote them for the last time before the last barrier) — at K = 512 the stages and the two sets fill all 160 KiB
+  float* sred = reinterpret_cast<float*>(reinterpret_cast<f32x4_t*>(smem + NS * STAGE) + wn * 64 * (2 * PB));
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  float mu[8], is[8], ga[8], be[8];
+  const T* bx = reinterpret_cast<const T*>(p.bnb_raw);
+  if constexpr (BNB) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = cok ? p.bnb_mean[c8 + j] : 0.f; is[j] = cok ? p.bnb_invstd[c8 + j] : 0.f;
+      ga[j] = cok ? p.bnb_gamma[c8 + j] : 0.f; be[j] = cok ? p.bnb_beta[c8 + j] : 0.f;
+    }
+  }
+  T* yg = reinterpret_cast<T*>(p.y);
+  __builtin_amdgcn_s_barrier();       // start: tile 0 is in LDS
+  asm volatile("" ::: "memory");
+  for (int i = 0; i < mine; ++i) {
+    const int t = first + i * tstride;
+    v4i_t lx[PB];
+    if constexpr (BNB) {              // the pre-norm rows of this lane's pixels: requested now, used after the MFMAs
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        long long mm = (long long)t * TM + pb * 16 + q;
+        mm = mm < p.M ? mm : p.M - 1;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lx[pb]) : "v"(bx + mm * p.bnb_ps + (cok ? c8 : 0)) : "memory");
+      }
+    }
+    f32x4_t acc0[PB], acc1[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) partial(i % NS, pb, acc0[pb], acc1[pb]);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // barrier i: the partial sums of tile i are in set i & 1, tile i + 1 has landed
+    asm volatile("" ::: "memory");
+    if constexpr (BNB) {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[pb])::"memory");   // (also drains the previous tile's stores)
+    }
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const long long m = (long long)t * TM + pb * 16 + q;
+      const f32x4_t b0 = xch[(i & 1) * XSET + pb * 2], b1 = xch[(i & 1) * XSET + pb * 2 + 1];
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = acc0[pb][j] + b0[j]; v[4 + j] = acc1[pb][j] + b1[j]; }
+      uint4 o = Elem<T>::pack(v);
+      if constexpr (BNB) {
+        float x[8];
+        Elem<T>::unpack(o, v);            // the conv result as a tile kernel would have staged it (bf16)
+        Elem<T>::unpack(__builtin_bit_cast(uint4, lx[pb]), x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bn_affine(x[j], mu[j], is[j], ga[j], be[j]) > 0.f ? v[j] : 0.f;
+        o = Elem<T>::pack(v);
+        Elem<T>::unpack(o, v);            // dZ as stored
+        if (m < p.M && cok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * x[j]; }   // (sum dZ * raw: centred below)
+        }
+      } else if (p.stats && m < p.M && cok) {
+        Elem<T>::unpack(o, v);            // the values as stored
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+      }
+      if (m < p.M && cok) *reinterpret_cast<uint4*>(yg + m * p.yps + c8) = o;
+    }
+  }
+  if (p.stats) {
+    // per-channel sums: over the 16 pixels (lanes) of a DPP row, then one atomic instruction per wave (stream_stat_flush)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (BNB) ssq[j] = is[j] * (ssq[j] - mu[j] * ssum[j]);   // sum dZ * xhat
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        float v = w ? ssq[j] : ssum[j];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));
+        if (q == 15) sred[g4 * 16 + j * 2 + w] = v;
+      }
+    }
+    stream_stat_flush(sred, lane, n0, p);
+  }
+}
+
+// Takes the 1x1, stride-1, bf16 -> bf16 convs with K = 512 / 1024 and Cout a multiple of 128 in the two modes the step's
+// long-K layers use (tuning key conv.kstream = 1). Returns false when the shape is not its.
+inline bool try_launch_kstream1x1(const ConvP& p, hipStream_t s) {
+  // bit 0: K = 512 (both modes: 1.05-1.6x the tile kernels, profiles/r06_kstream_ab.md); bit 1: K = 1024 data gradients with the
+  // fused BatchNorm backward (1.07-1.19x); bit 2: K = 1024 forward (0.9x: 16-row tiles and a 256 KiB weight prologue per
+  // workgroup do not pay there). Default 3.
+  const long long mask = dastune::get(dastune::CONV_KSTREAM);
+  if (mask <= 0) return false;
+  const long long min_rows = dastune::get(dastune::CONV_STREAM_MINROWS);
+  if (min_rows <= 0 || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.up_sh != 0 || p.relu_in || p.relu ||
+      p.xbytes == 0 || p.M < min_rows || p.osub || p.scale || p.shift || p.res || p.ksplit > 1)
+    return false;
+  if ((p.Cin != 512 && p.Cin != 1024) || p.Cout % 128 || p.yps % 8 || p.xps % 8) return false;
+  const bool bnb = p.bnb_raw != nullptr;
+  if (bnb && !(p.bnb_relu && !p.bnb_y && !p.bnb_bits && p.stats && p.bnb_ps % 8 == 0)) return false;
+  if (!(mask & (p.Cin == 512 ? 1 : bnb ? 2 : 4))) return false;
+  const int pbk = p.Cin == 512 ? 2 : 1, tm = 16 * pbk;      // pixel blocks / rows per tile (conv1x1_kstream_kernel: PB, TM)
+  const int ncol = p.Cout / 128, ntiles = (p.M + tm - 1) / tm;
+  const size_t sm = (size_t)4 * tm * p.Cin * 2 + 2 * 4 * 64 * 32 * pbk;   // stages + two sets of partial sums (K = 512: exactly 160 KiB)
+  auto go = [&](auto kern) -> bool {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return false;
+      attr = true;
+    }
+    long long grid = std::min<long long>(usable_cus(), (long long)ntiles * ncol);
+    grid = std::max<long long>(ncol, grid / ncol * ncol);
+    dastune::note_kernel("conv1x1_kstream_kernel");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sm, s, p, ncol, ntiles);
+    return true;
+  };
+  if (p.Cin == 512) return bnb ? go(conv1x1_kstream_kernel<16, 4>) : go(conv1x1_kstream_kernel<16, 0>);
+  return bnb ? go(conv1x1_kstream_kernel<32, 4>) : go(conv1x1_kstream_kernel<32, 0>);
+}
+
 // Takes the 1x1, stride-1, bf16 -> bf16 convs with K in {64, 128, 256}, Cout 64 / 128 / a multiple of 256 and enough
 // rows to keep a persistent grid busy. Returns false when the shape is not its.
 inline bool try_launch_stream1x1(const ConvP& p, hipStream_t s) {
@@ -1693,7 +1935,7 @@ bool try_launch_c64(const ConvP& p, hipStream_t s) {
 template <typename T, typename OT>
 int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
   if constexpr (sizeof(T) == 2 && sizeof(OT) == 2) {
-    if (try_launch_stream1x1(p, s)) {
+    if (try_launch_stream1x1(p, s) || try_launch_kstream1x1(p, s)) {
       DAS_CHECK_LAUNCH();
       return DAS_OK;
     }

@@ -35,6 +35,8 @@ CASES = [
     ('conv1x1_stream_kernel', 2, 91, 93, 256, 1024, 1, True),
     ('conv1x1_stream_kernel', 2, 91, 93, 256, 64, 1, False),    # mode 4: recomputed mask (conv3's data gradient, layer1)
     ('conv1x1_stream_kernel', 2, 91, 93, 128, 512, 1, False),   # mode 3 without y: no ReLU on the producing layer
+    ('conv1x1_kstream_kernel', 2, 91, 93, 512, 128, 1, False),  # round 6: the weight-stationary K-split kernel, mode 4 (conv3's
+    ('conv1x1_kstream_kernel', 1, 67, 53, 1024, 256, 1, False),  # data gradient at 64 x 104 / 32 x 52: recomputed mask); M % 16 != 0
     ('conv3x3_c64_kernel', 2, 32, 48, 64, 64, 3, False),        # conv2's data gradient in layer1: recomputed mask
     ('conv3x3_c64_kernel', 1, 16, 64, 64, 64, 3, True),
 ]
@@ -44,6 +46,7 @@ FORCE = {
     'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
     'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
     'conv1x1_stream_kernel': {},
+    'conv1x1_kstream_kernel': {'conv.kstream': 7, 'conv.stream_minrows': 64},
     'conv3x3_c64_kernel': {'conv.c64_mintiles': 1},
 }
 
@@ -53,7 +56,7 @@ FORCE = {
 def test_dgrad_epilogue_reduces_bn_backward(case, dtype):
     from das_amd import ops as o
     kernel, B, H, W, Cin, Cout, k, with_res = case
-    if dtype == torch.float32 and kernel != 'conv_glds_kernel':
+    if dtype == torch.float32 and kernel != 'conv_glds_kernel':   # (incl. conv1x1_kstream_kernel)
         pytest.skip('the 256-row tiles and the persistent kernels are bf16 kernels')
     no_relu = kernel == 'conv1x1_stream_kernel' and Cout == 512
     dy = cases.randn(201, B, Cin, H, W)

@@ -516,6 +516,7 @@ REAL = [
     (4, 128, 208, 128, 128, 3, 1, 1, 'conv_glds3_kernel<pp>'),      # layer2-like 3x3 on a large map (K = 1152: ping-pong)
     (16, 32, 52, 1024, 128, 1, 1, 0, 'conv_glds3_kernel<pp>'),      # 104 tiles, K = 1024
     (2, 128, 208, 256, 64, 1, 1, 0, 'conv1x1_stream_kernel'),
+    (16, 64, 104, 512, 128, 1, 1, 0, 'conv1x1_kstream_kernel'),     # round 6: the K = 512 reduce conv of the 64 x 104 stage (default dispatch)
 ]
 
 
@@ -919,3 +920,37 @@ def test_wgrad_pp_share_is_per_thread_and_follows_the_usable_cus():
         assert lib.das_wgrad_pp_share(1) == 0
     assert grid()[0] == cus
     np.testing.assert_allclose(dw2.cpu().numpy(), dw1.cpu().numpy(), rtol=2e-3, atol=2e-3)
+
+
+# (B, H, W, Cin, Cout): the step's long-K reduce convs and shapes whose rows / channels do not fill the last tile / column block
+KSTREAM = [(2, 64, 104, 512, 128), (2, 32, 52, 1024, 256), (1, 37, 29, 512, 256), (3, 16, 26, 1024, 128), (1, 21, 17, 1024, 384)]
+
+
+@pytest.mark.parametrize('case', KSTREAM)
+def test_kstream_weight_stationary_1x1_forward_and_statistics(case):
+    """conv1x1_kstream_kernel (round 6, tuning key conv.kstream): K = 512 / 1024 split over two wave groups, weights in
+    registers, 16-row pixel tiles. Plain output against F.conv2d (bf16-exact up to the regrouped f32 sum of the two K halves),
+    the BatchNorm statistics against the sums of the kernel's own stored output, and against the tile kernel it replaces."""
+    o = ops()
+    B, H, W, Cin, Cout = case
+    x = cases.randn(401, B, Cin, H, W)
+    w = cases.randn(402, Cout, Cin, 1, 1) / Cin ** 0.5
+    xd, wd = nhwc(x), o.pack_weight(w.to(DEV), BF)
+    with o.tuning(**{'conv.kstream': 0}):
+        y_tile = o.conv2d(xd, wd, 1, 1, 1, 0)
+        assert o.last_kernel() != 'conv1x1_kstream_kernel'
+    with o.tuning(**{'conv.kstream': 7, 'conv.stream_minrows': 64}):
+        stats = torch.zeros(2 * 2 * Cout, device=DEV)      # two slots
+        y = o.conv2d(xd, wd, 1, 1, 1, 0, stats=stats)
+        assert o.last_kernel() == 'conv1x1_kstream_kernel', o.last_kernel()
+        y2 = o.conv2d(xd, wd, 1, 1, 1, 0)
+        assert o.last_kernel() == 'conv1x1_kstream_kernel'
+    assert torch.equal(y, y2)
+    ref = conv_ref(x, w, 1, 0)
+    np.testing.assert_allclose(nchw(y).numpy(), ref.numpy(), **TOL)
+    assert_bf16_exact(nchw(y), ref)
+    np.testing.assert_allclose(nchw(y).numpy(), nchw(y_tile).numpy(), rtol=8e-3, atol=2e-3)
+    yq = nchw(y)
+    n = B * H * W
+    s_ref = torch.cat([yq.sum((0, 2, 3)), (yq ** 2).sum((0, 2, 3))])
+    np.testing.assert_allclose(stats.view(2, -1).sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)

@@ -39,6 +39,7 @@ FAMILIES = (   # bench.py family tag -> matcher on the normalised kernel name
     ('conv_glds_kernel', lambda k: k.startswith('conv_glds_kernel<')),
     ('conv_reg_kernel', lambda k: k.startswith('conv_reg_kernel<')),
     ('conv1x1_stream_kernel', lambda k: k.startswith('conv1x1_stream_kernel<')),
+    ('conv1x1_kstream_kernel', lambda k: k.startswith('conv1x1_kstream_kernel<')),
     ('conv3x3_c64_kernel', lambda k: k.startswith('conv3x3_c64_kernel<')),
     ('conv_wgrad_pp_kernel', lambda k: k == 'conv_wgrad_pp_kernel' or 'AccMap256' in k),
     ('conv_wgrad_kernel<bf16>', lambda k: k.startswith('conv_wgrad_kernel<') or 'AccMap128' in k or k.startswith('conv_wgrad_c64_kernel')
