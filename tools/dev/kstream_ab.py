@@ -11,7 +11,7 @@ from das_amd import _lib, ops  # noqa: E402
 
 lib = _lib.load()
 B = 16
-SHAPES = [(B, 64, 104, 512, 128), (B, 32, 52, 1024, 256), (B, 16, 26, 1024, 256), (B, 64, 104, 512, 256), (B, 32, 52, 1024, 512)]
+SHAPES = [(B, 64, 104, 512, 128), (B, 64, 104, 512, 256), (B, 64, 104, 512, 512), (B, 32, 52, 1024, 256), (B, 32, 52, 1024, 512), (B, 32, 52, 1024, 1024), (B, 128, 208, 512, 128)]
 ROUNDS, INNER = 7, 5
 torch.manual_seed(0)
 print('| shape | mode | tile kernel | us (min) | kstream us (min) | tile / kstream | HBM floor us (6.2 TB/s) |')
