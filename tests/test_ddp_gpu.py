@@ -290,7 +290,7 @@ def test_fused_syncbn_nodes_on_two_ranks_equal_plain_batchnorm_on_the_whole_batc
 # step. Yardstick: two plain runs of this tiny net (48 samples per channel in its deepest BatchNorm layers, statistics
 # and weight gradients summed with float atomics) differ by ~6e-4 of the largest gradient in the FIRST step already
 # (tools/dev/rccl_probe.py); a bucket all-reduced before its gradients were complete, or twice, would be off by O(1).
-def _rccl_worker(rank, world, port, ret):
+def _rccl_worker(rank, world, port, ret, comm_dtype='f32'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     torch.cuda.set_device(0)
     import das_amd
@@ -306,7 +306,8 @@ def _rccl_worker(rank, world, port, ret):
         model.init_weights()
         model.to('cuda').train()
         opt = FlatSGD(model, lr=2e-3, momentum=0.9, weight_decay=1e-4, bias_lr_mult=2.0, bias_decay_mult=0.0,
-                      max_grad_norm=35.0, bucket_mb=1, overlap=True, force_collectives=force)
+                      max_grad_norm=35.0, bucket_mb=1, overlap=True, force_collectives=force,
+                      grad_comm_dtype=comm_dtype if force else 'f32')
         ds = SyntheticPoseDataset(num_joints=15, img_shape=(128, 192), length=4, seed=3, max_persons=3)
         data = collate([ds[i] for i in range(2)], device='cuda')
         losses, g1 = [], None
@@ -479,3 +480,25 @@ def test_syncbn_refuses_ranks_with_different_row_counts():
     port = 35500 + os.getpid() % 1000
     mp.spawn(_rows_worker, args=(2, port, ret), nprocs=2, join=True)
     assert 'different numbers of pixel rows' in ret[0] and 'different numbers of pixel rows' in ret[1], dict(ret)
+
+
+def test_rccl_carries_bf16_gradient_buckets():
+    """FlatSGD(grad_comm_dtype='bf16') over RCCL (one rank: the staging buffer, the conversion on the communication stream, the
+    collective and the conversion back all run; the sum of one rank is its own gradient): the gradient after the collective is
+    the f32 gradient rounded to bf16 — within 2^-8 relative of the plain run's element by element (plus the run-to-run floor of
+    the float atomics) — and the loss of the first step is unchanged."""
+    mp.set_start_method('spawn', force=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 34500 + os.getpid() % 1000
+    mp.spawn(_rccl_worker, args=(1, port, ret, 'bf16'), nprocs=1, join=True)
+    if ret[0][0] == 'skip':
+        pytest.skip('no RCCL process group on this box: ' + ret[0][1])
+    _, g_a, g_b, g, l_a, losses, overlapped, nb, n_end, has_stream = ret[0]
+    assert has_stream and nb > 4 and overlapped > 0
+    assert abs(losses[0] - l_a[0]) <= 1e-4 * abs(l_a[0])
+    floor = (g_a - g_b).abs()
+    err = (g - g_a).abs()
+    bound = g_a.abs() * 2.0 ** -8 + 5 * floor.max() + 1e-12
+    assert bool((err <= bound).all()), (float((err - bound).max()), float(g_a.abs().max()))
+    assert float(err.max()) > 0      # (something WAS rounded: the bf16 path ran)
