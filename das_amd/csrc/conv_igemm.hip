@@ -1730,9 +1730,12 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
 // Takes the 1x1, stride-1, bf16 -> bf16 convs with K = 512 / 1024 and Cout a multiple of 128 in the two modes the step's
 // long-K layers use (tuning key conv.kstream = 1). Returns false when the shape is not its.
 inline bool try_launch_kstream1x1(const ConvP& p, hipStream_t s) {
-  // bit 0: K = 512 (both modes: 1.05-1.6x the tile kernels, profiles/r06_kstream_ab.md); bit 1: K = 1024 data gradients with the
-  // fused BatchNorm backward (1.07-1.19x); bit 2: K = 1024 forward (0.9x: 16-row tiles and a 256 KiB weight prologue per
-  // workgroup do not pay there). Default 3.
+  // Which launches take this kernel: a bit mask. 1 = K 512 data gradients with the fused BatchNorm backward, 2 = the same at
+  // K 1024, 4 = K 512 forward with Cout 128, 8 = K 512 forward with wider outputs, 16 = K 1024 forward. Default 3: with warm
+  // operands (a micro-benchmark that re-reads one tensor: profiles/r06_kstream_ab.md) every K = 512 case wins, but inside the
+  // step, on cold operands, only the fused-BatchNorm-backward launches do (512 -> 128: 54.1 -> 34.6 us, 1024 -> 256: 33.2 ->
+  // 29.8); the forward launches are level (512 -> 128: 39.3 -> 39.9) or lose (512 -> 256: 54.9 -> 60.9, 512 -> 512: 85 -> 113:
+  // four column blocks re-read the pixel tiles) — profiles/r06_train_shapes_kstream_all_k512.txt.
   const long long mask = dastune::get(dastune::CONV_KSTREAM);
   if (mask <= 0) return false;
   const long long min_rows = dastune::get(dastune::CONV_STREAM_MINROWS);
@@ -1742,7 +1745,7 @@ inline bool try_launch_kstream1x1(const ConvP& p, hipStream_t s) {
   if ((p.Cin != 512 && p.Cin != 1024) || p.Cout % 128 || p.yps % 8 || p.xps % 8) return false;
   const bool bnb = p.bnb_raw != nullptr;
   if (bnb && !(p.bnb_relu && !p.bnb_y && !p.bnb_bits && p.stats && p.bnb_ps % 8 == 0)) return false;
-  if (!(mask & (p.Cin == 512 ? 1 : bnb ? 2 : 4))) return false;
+  if (!(mask & (bnb ? (p.Cin == 512 ? 1 : 2) : p.Cin == 512 ? (p.Cout == 128 ? 4 : 8) : 16))) return false;
   const int pbk = p.Cin == 512 ? 2 : 1, tm = 16 * pbk;      // pixel blocks / rows per tile (conv1x1_kstream_kernel: PB, TM)
   const int ncol = p.Cout / 128, ntiles = (p.M + tm - 1) / tm;
   const size_t sm = (size_t)4 * tm * p.Cin * 2 + 2 * 4 * 64 * 32 * pbk;   // stages + two sets of partial sums (K = 512: exactly 160 KiB)

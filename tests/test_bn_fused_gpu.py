@@ -46,7 +46,7 @@ FORCE = {
     'conv_glds4_kernel': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 0, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
     'conv_glds4_kernel<pp>': {'conv.glds4_minblocks': 1, 'conv.glds4_pp': 1, 'conv.stream_minrows': 0, 'conv.splitk_target': 0, 'conv.glds4_mf': 8},
     'conv1x1_stream_kernel': {},
-    'conv1x1_kstream_kernel': {'conv.kstream': 7, 'conv.stream_minrows': 64},
+    'conv1x1_kstream_kernel': {'conv.kstream': 31, 'conv.stream_minrows': 64},
     'conv3x3_c64_kernel': {'conv.c64_mintiles': 1},
 }
 

@@ -34,13 +34,13 @@ for (b, H, W, Cin, Cout) in SHAPES:
                 ops.conv2d(x, w, 1, 1, 1, 0, stats=st, bn_bwd=bnb, out=y)
         names, ts = {}, {0: [], 1: []}
         for arm in (0, 1):
-            lib.das_tuning_set(b'conv.kstream', 7 * arm)
+            lib.das_tuning_set(b'conv.kstream', 31 * arm)
             for _ in range(3):
                 run()
             names[arm] = lib.das_last_kernel().decode()
         for _ in range(ROUNDS):
             for arm in (0, 1):
-                lib.das_tuning_set(b'conv.kstream', 7 * arm)
+                lib.das_tuning_set(b'conv.kstream', 31 * arm)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
