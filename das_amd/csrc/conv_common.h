@@ -73,6 +73,9 @@ struct ConvP {
   int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];
 };
 
+// conv_stem.hip: the 7 x 7 stride-2 stem conv (8 stored input channels -> 64); false when the launch is not its
+bool try_launch_stem7x7(const ConvP& p, hipStream_t s);
+
 // ---- LDS-DMA through a buffer descriptor (inline asm: the compiler must not wait for it, cdna guide 5.7)
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 // Raw buffer descriptor (wave-uniform): base, num_records = bytes, stride 0.

@@ -1942,7 +1942,7 @@ int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
       DAS_CHECK_LAUNCH();
       return DAS_OK;
     }
-    if (try_launch_c64<OT>(p, s)) {
+    if (try_launch_c64<OT>(p, s) || try_launch_stem7x7(p, s)) {
       DAS_CHECK_LAUNCH();
       return DAS_OK;
     }

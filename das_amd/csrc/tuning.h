@@ -59,6 +59,7 @@ enum Key {
                          // residual, bit 2 the output stored non-temporal (streamed tensors of >= bn.stream_minbytes: larger than
                          // what the 256 MiB Infinity Cache keeps for the consumer anyway)
   BN_NT_BWD,             // ... of bn_bwd_apply_dz_stream_kernel: bit 0 dZ, bit 1 the pre-norm tensor, bit 2 the gradient stored
+  CONV_STEM7X7,          // conv_stem7x7_kernel (conv_stem.hip) for the backbone's 7 x 7 stride-2 stem conv instead of conv_reg_kernel: 0 / 1
   N_KEYS
 };
 

@@ -24,6 +24,7 @@ constexpr Entry kTable[N_KEYS] = {
     {"bn.vpt", 8},                {"gn.ppb", 0},             {"conv.c64_mintiles", 64},    {"bn.stream_minbytes", 96 << 20},
     {"comm.reserved_cus", 0},  {"elem.upstats_ppb", 0},   {"bn.upmerge_blocks", 512}, {"dcn.fused_minrows", 100000},
     {"conv.balance_rows", 1},     {"conv.glds4_mfma32", 0},  {"conv.kstream", 3},       {"conv.splitk_inkernel", 0}, {"conv.stream_nt", 0},     {"bn.nt_fwd", 0},          {"bn.nt_bwd", 0},
+    {"conv.stem7x7", 1},
 };
 std::atomic<long long> g_val[N_KEYS];
 std::atomic<bool> g_init{false};

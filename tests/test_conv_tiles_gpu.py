@@ -288,6 +288,71 @@ def test_c64_patch_kernel_data_gradient_and_channel_slices():
     np.testing.assert_allclose(nchw(dx).numpy(), q(q(x.grad) + q(other)).numpy(), **TOL)
 
 
+# ---------------------------------------------------------------- the 7x7 stride-2 stem conv (8 stored channels -> 64)
+@pytest.mark.parametrize('case', [(2, 64, 128), (1, 32, 64), (3, 70, 150), (1, 65, 97), (2, 128, 208), (5, 48, 64)])
+def test_stem7x7_kernel_statistics_affine_borders(case):
+    """conv_stem7x7_kernel (conv_stem.hip: weights in registers, 21 x 72-pixel input windows through LDS-DMA, persistent over
+    8 x 32-pixel output tiles; production: B x 512 x 832 frames, 6656 tiles on 256 workgroups) against torch on the same
+    bf16 operands: the training forward (plain output + BatchNorm statistics in slots) and the eval forward (folded
+    BatchNorm + ReLU); frames whose output is a whole number of tiles and frames whose last tiles hang over the right /
+    bottom border (odd heights and widths too), more tiles than workgroups' first round and a single tile; and the same
+    launch on the generic kernel stores the same values up to accumulation order (reference layer:
+    /root/reference/mmdet3d/models/backbones/mspn_mmpose.py:228-246)."""
+    o = ops()
+    B, H, W = case
+    x = cases.randn(171, B, 3, H, W)
+    w = cases.randn(172, 64, 3, 7, 7) / 12
+    conv = conv_ref(x, w, 2, 3)
+    x8 = torch.zeros(B, H, W, 8, dtype=BF, device=DEV)
+    x8[..., :3] = nhwc(x)
+    w8 = torch.zeros(64, 8, 7, 7)
+    w8[:, :3] = w
+    wd = o.pack_weight(w8.to(DEV), BF)
+    stats = torch.zeros(4, 128, device=DEV)
+    y = o.conv2d(x8, wd, 7, 7, 2, 3, stats=stats.view(-1))
+    assert o.last_kernel() == 'conv_stem7x7_kernel', o.last_kernel()
+    yq = nchw(y)
+    assert yq.shape == conv.shape
+    assert_bf16_exact(yq, conv)
+    n = yq.numel() // 64
+    s_ref = torch.cat([yq.sum((0, 2, 3)), (yq ** 2).sum((0, 2, 3))])
+    np.testing.assert_allclose(stats.sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
+    with o.tuning(**{'conv.stem7x7': 0}):
+        y_gen = o.conv2d(x8, wd, 7, 7, 2, 3)
+        assert o.last_kernel() == 'conv_reg_kernel', o.last_kernel()
+    np.testing.assert_allclose(y.float().cpu().numpy(), y_gen.float().cpu().numpy(), rtol=8e-3, atol=8e-3)
+    scale, shift = cases.randn(173, 64).abs() + 0.5, cases.randn(174, 64)
+    y2 = o.conv2d(x8, wd, 7, 7, 2, 3, scale=scale.to(DEV), shift=shift.to(DEV), relu=True)
+    assert o.last_kernel() == 'conv_stem7x7_kernel', o.last_kernel()
+    aff = conv * scale[None, :, None, None] + shift[None, :, None, None]
+    assert_bf16_exact(nchw(y2), F.relu(aff), frac=0.08)
+    # an output written into a channel slice of a wider tensor (pixel stride 96)
+    wide = torch.full((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 96), 7.0, dtype=BF, device=DEV)
+    o.conv2d(x8, wd, 7, 7, 2, 3, out=wide[..., 16:80])
+    assert o.last_kernel() == 'conv_stem7x7_kernel', o.last_kernel()
+    assert torch.equal(wide[..., 16:80], y) and bool((wide[..., :16] == 7).all()) and bool((wide[..., 80:] == 7).all())
+
+
+def test_stem7x7_kernel_leaves_other_launches_alone():
+    o = ops()
+    x8 = nhwc(cases.randn(175, 1, 8, 64, 64))
+    w7 = o.pack_weight((cases.randn(176, 64, 8, 7, 7) / 20).to(DEV), BF)
+    o.conv2d(x8, w7, 7, 7, 1, 3)                                   # stride 1
+    assert o.last_kernel() != 'conv_stem7x7_kernel'
+    o.conv2d(x8, w7, 7, 7, 2, 3, residual=torch.zeros(1, 32, 32, 64, dtype=BF, device=DEV))   # a residual
+    assert o.last_kernel() != 'conv_stem7x7_kernel'
+    w128 = o.pack_weight((cases.randn(177, 128, 8, 7, 7) / 20).to(DEV), BF)
+    o.conv2d(x8, w128, 7, 7, 2, 3)                                 # 128 output channels
+    assert o.last_kernel() != 'conv_stem7x7_kernel'
+    x16 = nhwc(cases.randn(178, 1, 16, 64, 64))
+    w16 = o.pack_weight((cases.randn(179, 64, 16, 7, 7) / 20).to(DEV), BF)
+    o.conv2d(x16, w16, 7, 7, 2, 3)                                 # 16 input channels
+    assert o.last_kernel() != 'conv_stem7x7_kernel'
+    tiny = nhwc(cases.randn(180, 1, 8, 10, 12))                    # one tile, mostly outside the frame
+    o.conv2d(tiny, w7, 7, 7, 2, 3)
+    assert o.last_kernel() != 'conv_stem7x7_kernel'
+
+
 def test_c64_patch_kernel_leaves_other_shapes_alone():
     o = ops()
     with o.tuning(**C64):
