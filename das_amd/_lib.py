@@ -27,7 +27,7 @@ class DasConvDesc(C.Structure):
                 ('bnb_raw', vp), ('bnb_y', vp), ('bnb_mean', vp), ('bnb_invstd', vp), ('bnb_gamma', vp), ('bnb_beta', vp),
                 ('bnb_relu', i32), ('bnb_pix_stride', i32),
                 ('out_sub', i32), ('out_ph', i32), ('out_pw', i32), ('out_H', i32), ('out_W', i32),
-                ('bnb_mask_bits', vp), ('residual_mask_bits', vp), ('gn_sums', vp), ('gn_groups', i32)]
+                ('bnb_mask_bits', vp), ('residual_mask_bits', vp)]
 
 
 class DasPackEntry(C.Structure):
@@ -192,7 +192,7 @@ def load():
         except AttributeError as e:
             raise DasHipError(f'libdas_hip.so does not export {name}') from e
         fn.restype, fn.argtypes = res, args
-    if lib.das_abi_version() != 5:
+    if lib.das_abi_version() != 4:
         raise DasHipError('libdas_hip.so ABI version mismatch')
     _lib = lib
     return lib

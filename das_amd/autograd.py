@@ -965,14 +965,13 @@ class ConvFn(Function):
     `w_packed`/`shift` are prepared by the caller (fused heads concatenate several nn.Conv2d)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, conv_like, geom, relu, out_dtype, out, skip_through=False, gn_sums=None):
+    def forward(ctx, x, weight, bias, conv_like, geom, relu, out_dtype, out, skip_through=False):
         from .nn import bias_shift, packed_weight
         k, s, p = conv_like.kernel_size[0], conv_like.stride[0], conv_like.padding[0]
         xin = _wrap(x, geom)
         w = packed_weight(conv_like, x.dtype, cin_pad=x.shape[-1])
-        # gn_sums = (zeroed workspace, groups): the GroupNorm layer behind this conv takes its statistics from the epilogue
         y = ops.conv2d(xin, w, k, k, s, p, shift=bias_shift(conv_like), relu=relu, out_dtype=out_dtype,
-                       out=_wrap(out, geom) if out is not None else None, gn_sums=gn_sums)
+                       out=_wrap(out, geom) if out is not None else None)
         yd = _d(y)
         ctx.save_for_backward(x, weight, yd if relu else None)
         ctx.cfg = (k, s, p, relu, geom, conv_like, bias is not None)
@@ -992,7 +991,7 @@ class ConvFn(Function):
         x, weight, y = ctx.saved_tensors
         k, s, p, relu, geom, conv, has_bias = ctx.cfg
         if dy is None:      # this consumer's output took no part in the backward (the root-offset branch): pass dskip on
-            return dskip, None, None, None, None, None, None, None, None, None
+            return dskip, None, None, None, None, None, None, None, None
         if relu:
             dy = dy * (y > 0).to(dy.dtype)  # only the stem-free plain convs with ReLU (none on the DAS path)
         dz = dy if dy.dtype == x.dtype else dy.to(x.dtype)
@@ -1026,7 +1025,7 @@ class ConvFn(Function):
                 ba[0].fired()
             else:
                 db = ops.colsum(dzr)[:weight.shape[0]]
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 # GroupNorm + ReLU backward with the mask recomputed from the input instead of read from the output; switch for A/B runs / tests
@@ -1035,15 +1034,13 @@ GN_REMASK = True
 
 class GroupNormReLUFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, geom, G, eps, relu, gn=None, sums=None):
+    def forward(ctx, x, gamma, beta, geom, G, eps, relu, gn=None):
         ctx.gn = gn      # (the nn.GroupNorm module: its parameters' flat-gradient slices take the gradients directly)
         xin = _wrap(x, geom)
         out = xin.new(x.shape[-1]) if geom is not None else torch.empty_like(x)
         from .nn import kept_zeros
-        # sums: the statistics workspace the producing conv's epilogue already filled (ConvFn's gn_sums; kept like `st`)
         y, st = ops.groupnorm(xin, gamma, beta, G, eps, relu=relu, out=out, return_stats=True,
-                              ws=sums if sums is not None else kept_zeros(ops.groupnorm_stats_size(xin, G), x.device),
-                              have_sums=sums is not None)
+                              ws=kept_zeros(ops.groupnorm_stats_size(xin, G), x.device))
         yd = _d(y)
         # (the ReLU mask is recomputed from x in the backward — no residual enters these layers — so y is not kept)
         ctx.save_for_backward(x, None if GN_REMASK else yd, st, gamma, beta)
@@ -1068,7 +1065,7 @@ class GroupNormReLUFn(Function):
         if direct:
             ga[0].fired()
             ba[0].fired()
-        return _d(dx), dgamma, dbeta, None, None, None, None, None, None
+        return _d(dx), dgamma, dbeta, None, None, None, None, None
 
 
 class MaxPoolFn(Function):

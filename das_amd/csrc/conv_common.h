@@ -71,10 +71,6 @@ struct ConvP {
   // ragged multi-level input (stride 1, "same" padding): rows of level l start at lvStart[l]
   int nlev, B;
   int lvH[MAXLV], lvW[MAXLV], lvStart[MAXLV];
-  // GroupNorm statistics of the output (DasConvDesc.gn_sums): [sum, sum of squares] of the stored values per (level, image,
-  // group) added into gn_sums[(segment * gn_G + group) * 2], segment = level * B + image (das_groupnorm_nhwc's layout)
-  float* gn_sums;
-  int gn_G, gn_cpg;   // groups, channels per group (a multiple of the 16-byte output vector)
 };
 
 // conv_stem.hip: the 7 x 7 stride-2 stem conv (8 stored input channels -> 64); false when the launch is not its
@@ -164,27 +160,9 @@ struct Tiling {
   }
 };
 
-// GroupNorm sums in a conv epilogue (ConvP::gn_sums): a tile's rows lie in a few (level, image) segments; the sums of the
-// first GN_SLOTS of them meet in LDS behind the C tile ([slot][vector][2] floats), later ones go straight to global atomics.
-constexpr int GN_SLOTS = 4;
-// segment of conv output row m and the first row past it
-__device__ __forceinline__ void gn_seg_of(const ConvP& p, int m, int& seg, int& end) {
-  if (p.nlev <= 1) {
-    const int b = m / p.HoWo;
-    seg = b; end = (b + 1) * p.HoWo;
-    return;
-  }
-  int hw = p.lvH[0] * p.lvW[0], start = p.lvStart[0], l = 0;
-#pragma unroll
-  for (int i = 1; i < MAXLV; ++i)
-    if (i < p.nlev && m >= p.lvStart[i]) { hw = p.lvH[i] * p.lvW[i]; start = p.lvStart[i]; l = i; }
-  const int b = (m - start) / hw;
-  seg = l * p.B + b; end = start + (b + 1) * hw;
-}
-
 template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>>
 constexpr size_t epilogue_smem_bytes() {
-  size_t ctile = (size_t)BMT * (BN * sizeof(OT) + 16) + GN_SLOTS * (BN * sizeof(OT) / 16) * 2 * 4;   // C tile + GroupNorm sums
+  size_t ctile = (size_t)BMT * (BN * sizeof(OT) + 16);
   size_t red = 2 * (size_t)(TL::NT / (BN * sizeof(OT) / 16)) * BN * 4;
   return ctile > red ? ctile : red;
 }
@@ -281,19 +259,10 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
     }
   }
   }
-  constexpr int VR = BN * (int)sizeof(OT) / 16;  // 16-B vectors per C row
-  float* gnl = reinterpret_cast<float*>(smem + (size_t)BMT * CS);   // [GN_SLOTS][VR][2] (epilogue_smem_bytes)
-#ifdef DAS_EPI_NOGN   // dev build (make variant VAR=nogn VFLAGS=-DDAS_EPI_NOGN): what does the GroupNorm-sums branch cost the launches that do not use it?
-  constexpr bool gn = false;
-#else
-  const bool gn = !T2D && p.gn_sums != nullptr;
-#endif
-  if (gn) {
-    for (int i = tid; i < GN_SLOTS * VR * 2; i += NT) gnl[i] = 0.f;
-  }
   __syncthreads();
   DAS_STAMP(5);
 
+  constexpr int VR = BN * (int)sizeof(OT) / 16;  // 16-B vectors per C row
   constexpr int RP = NT / VR;                    // rows per pass
   const int vec = tid % VR, r0 = tid / VR;
   const int n = n0 + vec * EPVO;
@@ -302,26 +271,6 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   for (int j = 0; j < EPVO; ++j) {
     if constexpr (CARRY) { ssum[j] = carry[j]; ssq[j] = carry[EPVO + j]; } else { ssum[j] = 0.f; ssq[j] = 0.f; }
   }
-  // GroupNorm sums (ConvP::gn_sums): this thread's vector lies in one group; its rows come in increasing order
-  int gseg = -1, gend = -1, gseg0 = 0;
-  float gs = 0.f, gq = 0.f;
-  if (gn) { int e; gn_seg_of(p, tile_row_m<T2D>(p, m0, 0), gseg0, e); }
-  auto gn_flush = [&]() {
-    if (gseg >= 0) {
-      const int slot = gseg - gseg0;
-      if (slot < GN_SLOTS) {
-        // (an LDS-typed pointer: atomicAdd on the generic one makes hipcc emit an address-space test it then cannot select)
-        auto* l = (__attribute__((address_space(3))) float*)(gnl + (slot * VR + vec) * 2);
-        __builtin_amdgcn_ds_faddf(l, gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
-        __builtin_amdgcn_ds_faddf(l + 1, gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
-      } else {
-        float* dst = p.gn_sums + ((long long)gseg * p.gn_G + n / p.gn_cpg) * 2;
-        atomicAdd(dst, gs);
-        atomicAdd(dst + 1, gq);
-      }
-    }
-    gs = 0.f; gq = 0.f;
-  };
   OT* yg = reinterpret_cast<OT*>(p.y);
   // row of y / residual / bnb tensors that conv output row m goes to
   auto orow = [&](int m) -> long long {
@@ -459,32 +408,6 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
     } else {
       rows_loop(std::integral_constant<int, CH0>{});
     }
-    if (gn) {
-      // GroupNorm sums: a second walk over this thread's rows of the C tile (still in LDS). Inside the loop above, the five
-      // values of the segment bookkeeping made conv_glds4_kernel spill 12-52 registers in EVERY launch; here they only live
-      // in the launches that ask for the sums, after the stores are out.
-#pragma unroll 1
-      for (int it = 0; it < ITERS; ++it) {
-        const int ml = r0 + it * RP;
-        const int m = tile_row_m<T2D>(p, m0, ml);
-        if (m >= p.M) break;
-        if (m >= gend) { gn_flush(); gn_seg_of(p, m, gseg, gend); }
-        float f[EPVO];
-        Elem<OT>::unpack(*reinterpret_cast<const uint4*>(smem + ml * CS + vec * 16), f);
-#pragma unroll
-        for (int j = 0; j < EPVO; ++j) { gs += f[j]; gq += f[j] * f[j]; }
-      }
-      gn_flush();
-    }
-  }
-  if (gn) {   // the tile's sums: LDS -> one atomic per (segment, vector, sum)
-    __syncthreads();
-    for (int i = tid; i < GN_SLOTS * VR * 2; i += NT) {
-      const float v = gnl[i];
-      const int nn = n0 + ((i >> 1) % VR) * EPVO;
-      if (v != 0.f && nn < p.Cout) atomicAdd(p.gn_sums + ((long long)(gseg0 + i / (VR * 2)) * p.gn_G + nn / p.gn_cpg) * 2 + (i & 1), v);
-    }
-    __syncthreads();
   }
   DAS_STAMP(6);
   if constexpr (CARRY) {

@@ -1938,13 +1938,11 @@ bool try_launch_c64(const ConvP& p, hipStream_t s) {
 template <typename T, typename OT>
 int launch_bn(const ConvP& p, bool glds, bool aligned, hipStream_t s) {
   if constexpr (sizeof(T) == 2 && sizeof(OT) == 2) {
-    if (p.gn_sums) {
-      // GroupNorm sums ride in conv_epilogue: the kernels with their own epilogues are not asked
-    } else if (try_launch_stream1x1(p, s) || try_launch_kstream1x1(p, s)) {
+    if (try_launch_stream1x1(p, s) || try_launch_kstream1x1(p, s)) {
       DAS_CHECK_LAUNCH();
       return DAS_OK;
     }
-    if (!p.gn_sums && (try_launch_c64<OT>(p, s) || try_launch_stem7x7(p, s))) {
+    if (try_launch_c64<OT>(p, s) || try_launch_stem7x7(p, s)) {
       DAS_CHECK_LAUNCH();
       return DAS_OK;
     }
@@ -2000,14 +1998,6 @@ extern "C" int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasC
   p.M = (int)M; p.K = d->KH * d->KW * d->Cin; p.HoWo = d->Ho * d->Wo;
   p.ntiles = p.nblocks = 0; p.m_base = 0; p.mstep = 0;
   p.ws = nullptr; p.ksplit = 1; p.sk_cnt = nullptr;
-  p.gn_sums = d->gn_sums; p.gn_G = d->gn_groups; p.gn_cpg = 0;
-  if (p.gn_sums) {   // GroupNorm sums of the output: see DasConvDesc
-    const int epvo = d->out_dtype == DAS_BF16 ? 8 : 4;
-    if (p.gn_G < 1 || d->Cout % p.gn_G || (d->Cout / p.gn_G) % epvo || d->residual || d->relu || d->stats ||
-        d->out_sub || d->bnb_raw)
-      return DAS_ERR_ARG;
-    p.gn_cpg = d->Cout / p.gn_G;
-  }
   p.osub = d->out_sub ? 1 : 0; p.oph = d->out_ph; p.opw = d->out_pw; p.oH = d->out_H; p.oW = d->out_W;
   if (p.osub) {   // sub-grid output: see DasConvDesc
     if (p.nlev > 1 || d->stride != 1 || (unsigned)p.oph > 1u || (unsigned)p.opw > 1u || d->Ho < 1 || d->Wo < 1 ||

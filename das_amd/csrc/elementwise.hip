@@ -428,5 +428,5 @@ extern "C" int das_add3(const void* a, const void* b, const void* c, void* y, in
   return DAS_OK;
 }
 
-extern "C" int das_abi_version(void) { return 5; }
+extern "C" int das_abi_version(void) { return 4; }
 extern "C" const char* das_target_arch(void) { return "gfx950"; }

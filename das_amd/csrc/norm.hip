@@ -525,17 +525,14 @@ extern "C" int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLe
     const void* k = dtype == DAS_BF16 ? (const void*)gn_stats_kernel<bf16_t, GN_NT> : (const void*)gn_stats_kernel<float, GN_NT>;
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DAS_ERR_LAUNCH;
   }
-  const bool have_sums = ws_zeroed == 2;   // (DasConvDesc.gn_sums: the producing conv added them)
   if (dtype == DAS_BF16) {
-    if (!have_sums)
-      hipLaunchKernelGGL((gn_stats_kernel<bf16_t, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), lds, s,
-                         (const bf16_t*)x, *lv, C, pix_stride, G, ppb, stats_ws);
+    hipLaunchKernelGGL((gn_stats_kernel<bf16_t, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), lds, s,
+                       (const bf16_t*)x, *lv, C, pix_stride, G, ppb, stats_ws);
     hipLaunchKernelGGL((gn_apply_kernel<bf16_t, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 0, s, (const bf16_t*)x, (bf16_t*)y,
                        *lv, C, pix_stride, G, ppb, stats_ws, gamma, beta, eps, relu);
   } else if (dtype == DAS_F32) {
-    if (!have_sums)
-      hipLaunchKernelGGL((gn_stats_kernel<float, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), lds, s,
-                         (const float*)x, *lv, C, pix_stride, G, ppb, stats_ws);
+    hipLaunchKernelGGL((gn_stats_kernel<float, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), lds, s,
+                       (const float*)x, *lv, C, pix_stride, G, ppb, stats_ws);
     hipLaunchKernelGGL((gn_apply_kernel<float, GN_NT>), dim3(chunks, nseg), dim3(GN_NT), 0, s, (const float*)x, (float*)y,
                        *lv, C, pix_stride, G, ppb, stats_ws, gamma, beta, eps, relu);
   } else {

@@ -465,22 +465,21 @@ def sync_stats(stats, cout, all_reduce):
 CHAIN_CONSUMERS = True
 
 
-def conv_plain(x, conv, relu=False, out_dtype=None, out=None, skip_through=False, gn_sums=None):
+def conv_plain(x, conv, relu=False, out_dtype=None, out=None, skip_through=False):
     """nn.Conv2d with bias, no norm (the 1x1 predictors). skip_through: returns (y, x) with x routed through the conv's
-    autograd node (autograd.ConvFn) for its other consumers; without a graph, or with CHAIN_CONSUMERS off, x itself.
-    gn_sums = (zeroed workspace, groups): a GroupNorm layer follows; the conv's epilogue adds its statistics (ops.conv2d)."""
+    autograd node (autograd.ConvFn) for its other consumers; without a graph, or with CHAIN_CONSUMERS off, x itself."""
     from . import autograd as ag
     if ag.grad_mode(_tensor(x), conv.weight, conv.bias):
         assert out is None, 'writing into a slice is an inference-only shortcut'
         g = ag._geom(x)
         if skip_through and CHAIN_CONSUMERS and _tensor(x).requires_grad:
-            y, xs = ag.ConvFn.apply(_tensor(x), conv.weight, conv.bias, conv, g, relu, out_dtype, None, True, gn_sums)
+            y, xs = ag.ConvFn.apply(_tensor(x), conv.weight, conv.bias, conv, g, relu, out_dtype, None, True)
             return ag._wrap(y, g), ag._wrap(xs, g)
-        y = ag.ConvFn.apply(_tensor(x), conv.weight, conv.bias, conv, g, relu, out_dtype, None, False, gn_sums)
+        y = ag.ConvFn.apply(_tensor(x), conv.weight, conv.bias, conv, g, relu, out_dtype, None)
         return (ag._wrap(y, g), x) if skip_through else ag._wrap(y, g)
     w = packed_weight(conv, x.dtype, cin_pad=_channels(x))
     k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    y = ops.conv2d(x, w, k, k, s, p, shift=bias_shift(conv), relu=relu, out_dtype=out_dtype, out=out, gn_sums=gn_sums)
+    y = ops.conv2d(x, w, k, k, s, p, shift=bias_shift(conv), relu=relu, out_dtype=out_dtype, out=out)
     return (y, x) if skip_through else y
 
 
@@ -521,36 +520,13 @@ def dcn_v2(x, dcn):
     return ops.conv2d(col, w, 1, 1, shift=shift)
 
 
-def group_norm_relu(x, gn, relu=True, sums=None):
-    """sums: the statistics workspace the conv that produced x already filled (gn_sums_for / conv_plain(gn_sums=...))."""
+def group_norm_relu(x, gn, relu=True):
     from . import autograd as ag
     if ag.grad_mode(_tensor(x), gn.weight):
         g = ag._geom(x)
-        return ag._wrap(ag.GroupNormReLUFn.apply(_tensor(x), gn.weight, gn.bias, g, gn.num_groups, gn.eps, relu, gn, sums), g)
-    if sums is not None:
-        return ops.groupnorm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=relu, ws=sums, have_sums=True)
+        return ag._wrap(ag.GroupNormReLUFn.apply(_tensor(x), gn.weight, gn.bias, g, gn.num_groups, gn.eps, relu, gn), g)
     ws = zeroed_stats(ops.groupnorm_stats_size(x, gn.num_groups), _tensor(x).device) if ZEROED_GN_WS else None   # (used by this call's launches only)
     return ops.groupnorm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, relu=relu, ws=ws)
-
-
-GN_FUSED_STATS = True   # GroupNorm statistics in the producing conv's epilogue (DasConvDesc.gn_sums) instead of a pass over its output; A/B switch
-
-
-def gn_sums_for(x, conv, gn):
-    """The zeroed statistics workspace for `gn` behind the plain conv `conv` applied to x, when the conv's epilogue can fill it
-    (a group a whole number of 16-byte output vectors, stride 1 "same" geometry; the conv's bias is part of the sums); else None."""
-    if not (GN_FUSED_STATS and ZEROED_GN_WS):
-        return None
-    xt = _tensor(x)
-    cout, G = conv.weight.shape[0], gn.num_groups
-    k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-    if cout % G or (cout // G) % (16 // xt.element_size()) or s != 1 or p != k // 2 or not xt.is_cuda:
-        return None
-    from . import autograd as ag
-    n = ops.groupnorm_stats_size(x, G)
-    # (with a graph the sums are what the backward reads as the layer's statistics: kept; without, this call's launches only)
-    ws = kept_zeros(n, xt.device) if ag.grad_mode(xt, conv.weight, gn.weight) else zeroed_stats(n, xt.device)
-    return ws
 
 
 def max_pool(x):
@@ -666,14 +642,12 @@ class ConvModule(nn.Module):
             assert not skip_through
             return conv_bn(x, self.conv, self.norm, relu=relu, residual=residual, relu_in=relu_in)
         assert residual is None and not relu_in
-        sums = gn_sums_for(x, self.conv, self.norm) if self.norm_name == 'gn' and not self.is_dcn else None
-        gn_arg = (sums, self.norm.num_groups) if sums is not None else None
         if skip_through and not self.is_dcn:
-            y, x = conv_plain(x, self.conv, relu=relu and self.norm_name != 'gn', skip_through=True, gn_sums=gn_arg)
-            return (group_norm_relu(y, self.norm, relu=relu, sums=sums) if self.norm_name == 'gn' else y), x
+            y, x = conv_plain(x, self.conv, relu=relu and self.norm_name != 'gn', skip_through=True)
+            return (group_norm_relu(y, self.norm, relu=relu) if self.norm_name == 'gn' else y), x
         if self.norm_name == 'gn':
-            y = dcn_v2(x, self.conv) if self.is_dcn else conv_plain(x, self.conv, gn_sums=gn_arg)
-            y = group_norm_relu(y, self.norm, relu=relu, sums=sums)
+            y = dcn_v2(x, self.conv) if self.is_dcn else conv_plain(x, self.conv)
+            y = group_norm_relu(y, self.norm, relu=relu)
         else:
             y = dcn_v2(x, self.conv) if self.is_dcn else conv_plain(x, self.conv, relu=relu)
         return (y, x) if skip_through else y

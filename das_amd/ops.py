@@ -582,10 +582,8 @@ def bn_train_backward_sync(dy, y, raw, mean, invstd, gamma, relu, want_dres, bet
 
 
 def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None, relu=False, relu_in=False,
-           out_dtype=None, stats=None, out=None, in_up=1, out_hw=None, bn_bwd=None, out_sub=None, gn_sums=None):
+           out_dtype=None, stats=None, out=None, in_up=1, out_hw=None, bn_bwd=None, out_sub=None):
     """x (B,H,W,Cin[view]) or Ragged; w packed (Cout,KH,KW,Cin). Returns y (B,Ho,Wo,Cout) / Ragged.
-    gn_sums = (ws, G): a ZEROED groupnorm_stats_size(out, G) f32 buffer; the epilogue adds the per-(level, image, group)
-    [sum, sum of squares] of the stored output into it (DasConvDesc.gn_sums) — groupnorm(..., ws=ws, have_sums=True) follows.
     in_up / out_hw: data-gradient mode (x zero-upsampled by in_up, explicit output size).
     bn_bwd (BnBwd) + stats: the output (conv + residual) is the gradient wrt a BatchNorm(+ReLU) layer's output; the
     kernel stores dZ = masked gradient and adds [sum dZ | sum dZ * xhat] into stats (slots as for the forward).
@@ -662,11 +660,6 @@ def conv2d(x, w, KH, KW, stride=1, pad=0, scale=None, shift=None, residual=None,
     if ragged:
         for l, (h, w_) in enumerate(x.sizes):
             d.lvl_H[l], d.lvl_W[l] = h, w_
-    if gn_sums is not None:
-        gws, G = gn_sums
-        assert gws.dtype == torch.float32 and gws.is_contiguous() and gws.numel() == (len(x.sizes) if ragged else 1) * B * G * 2
-        _need_gpu(gws)
-        d.gn_sums, d.gn_groups = gws.data_ptr(), G
     if rd is not None:
         assert rd.shape == od.shape and rd.dtype == od.dtype
     if PROFILE is not None:
@@ -1056,25 +1049,23 @@ def groupnorm_stats_size(x, G):
     return lv.num_levels * lv.B * G * 2
 
 
-def groupnorm(x, gamma, beta, G, eps=1e-5, relu=True, out=None, return_stats=False, ws=None, have_sums=False):
+def groupnorm(x, gamma, beta, G, eps=1e-5, relu=True, out=None, return_stats=False, ws=None):
     """In/out NHWC or Ragged (may be channel-slice views with a pixel stride); default in place.
     ws: a ZEROED f32 buffer of groupnorm_stats_size values for the statistics (a slice of a buffer the caller fills once for
-    many layers); it is what return_stats hands back, so it must live as long as the backward needs it.
-    have_sums: ws already holds the sums (conv2d(..., gn_sums=(ws, G)) produced x): the statistics pass is skipped."""
+    many layers); it is what return_stats hands back, so it must live as long as the backward needs it."""
     _need_gpu(x)
     out = x if out is None else out
     xd, od = _data(x), _data(out)
     lv = _levels(x)
     n = lv.num_levels * lv.B * G * 2
     zeroed = ws is not None
-    assert zeroed or not have_sums
     if zeroed:
         assert ws.dtype == torch.float32 and ws.numel() == n and ws.is_contiguous()
     else:
         ws = torch.empty(n, dtype=torch.float32, device=xd.device)
     assert _ps(out) == _ps(x)
     _lib.check(_lib.load().das_groupnorm_nhwc(_ptr(xd), _ptr(od), _DT[xd.dtype], C.byref(lv), xd.shape[-1], _ps(x), G,
-                                              _ptr(gamma), _ptr(beta), eps, int(relu), _ptr(ws), 2 if have_sums else int(zeroed), _stream()),
+                                              _ptr(gamma), _ptr(beta), eps, int(relu), _ptr(ws), int(zeroed), _stream()),
                'das_groupnorm_nhwc')
     return (out, ws) if return_stats else out
 

@@ -163,15 +163,6 @@ typedef struct {
    * output: the identity branch receives dY * (y > 0), and with the bits recorded by the forward that masked tensor never
    * has to be written by the layer's backward (das_bn_train_backward with dres == NULL). */
   const void* residual_mask_bits;
-  /* GroupNorm statistics of the output (round 6; the head's conv + GroupNorm + ReLU modules, das_head.py:54,
-   * anchor_free_mono3d_pose_head.py:97-135): gn_sums != NULL — the [sum, sum of squares] of the STORED values per
-   * (level, image, group) are ADDED into gn_sums f32[num_levels * B * gn_groups * 2] (das_groupnorm_nhwc's stats_ws layout,
-   * segment = level * B + image; zeroed by the caller), in the conv's epilogue instead of a pass over the output;
-   * das_groupnorm_nhwc(..., ws_zeroed = 2) then goes straight to its apply pass. Needs Cout % gn_groups == 0, a group a
-   * whole number of 16-byte output vectors, and none of residual / relu / stats / out_sub / bnb_raw (scale / shift — the
-   * conv's bias — are part of the stored value and of the sums). */
-  float* gn_sums;
-  int gn_groups;
 } DasConvDesc;
 int das_conv2d_nhwc(const void* x, const void* w, void* y, const DasConvDesc* d, void* stream);
 
@@ -428,8 +419,7 @@ int das_dcn3x3_fused(const void* x, const float* om, const void* w, const float*
 
 /* GroupNorm (+ReLU) over NHWC rows (torch GroupNorm, das_head.py:54, recursive_update.py:178,244);
  * statistics per (level, image, group). stats workspace: f32[num_levels*B*G*2], zeroed by the call unless
- * ws_zeroed (1: the caller hands it over zeroed, see das_groupnorm_backward_acc; 2: it already HOLDS the sums — the conv
- * that produced x added them, DasConvDesc.gn_sums — and the statistics pass is skipped). */
+ * ws_zeroed (the caller hands it over zeroed: see das_groupnorm_backward_acc). */
 int das_groupnorm_nhwc(const void* x, void* y, int dtype, const DasLevels* lv, int C, int pix_stride, int G,
                        const float* gamma, const float* beta, float eps, int relu, float* stats_ws, int ws_zeroed,
                        void* stream);

@@ -170,76 +170,6 @@ def test_tile_ragged_levels_forced(kernel):
         np.testing.assert_allclose(nchw(y.level(l)).numpy(), ref.numpy(), **TOL)
 
 
-def _gn_sums_ref(y_levels, G):
-    """[sum, sum of squares] per (level, image, group) of NCHW f32 tensors, in das_groupnorm_nhwc's workspace order."""
-    out = []
-    for t in y_levels:
-        B, Cc, H, W = t.shape
-        g = t.reshape(B, G, Cc // G * H * W).double()
-        out.append(torch.stack([g.sum(-1), (g * g).sum(-1)], -1).reshape(-1))
-    return torch.cat(out).float()
-
-
-@pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>',
-                                    'conv_glds4_kernel<pp,mf32>', None])
-def test_groupnorm_sums_from_the_conv_epilogue(kernel):
-    """DasConvDesc.gn_sums (round 6): the conv that feeds a GroupNorm layer adds the layer's per-(level, image, group) sums in its
-    epilogue (das_head.py:54, anchor_free_mono3d_pose_head.py:97-135: conv 3x3 -> GroupNorm(32) -> ReLU). Five FPN levels in
-    one launch, the small ones far smaller than a tile (one 256-row tile holds all images of three levels: more segments
-    than the four LDS slots, the rest goes to global atomics), every tile kernel forced and the default dispatch; the sums
-    equal those of the STORED output, the output itself is what the launch without gn_sums stores, and
-    groupnorm(have_sums=True) on them equals groupnorm with its own statistics pass."""
-    o = ops()
-    B, Cin, Cout = 3, 64, 256 if (kernel is None or 'glds4' in kernel) else 128
-    G = Cout // 8                       # (32 groups of 8 channels at the head's width)
-    sizes = [(16, 26), (8, 13), (4, 7), (2, 4), (1, 2)]
-    w = cases.randn(130, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
-    xs = [cases.randn(131 + i, B, Cin, h, ww) for i, (h, ww) in enumerate(sizes)]
-    rag = o.Ragged.from_levels([nhwc(t) for t in xs])
-    wd = o.pack_weight(w.to(DEV), BF)
-    n = o.groupnorm_stats_size(rag, G)
-    assert n == len(sizes) * B * G * 2
-    sums = torch.zeros(n, device=DEV)
-    bias = cases.randn(139, Cout).to(DEV)          # (the head's convs carry a bias: part of the stored value and of the sums)
-    with o.tuning(**(FORCE[kernel] if kernel else {})):
-        y = o.conv2d(rag, wd, 3, 3, 1, 1, shift=bias, gn_sums=(sums, G))
-        assert kernel is None or o.last_kernel() == kernel, o.last_kernel()
-        y0 = o.conv2d(rag, wd, 3, 3, 1, 1, shift=bias)
-    assert torch.equal(y.data, y0.data)
-    ref = _gn_sums_ref([nchw(y.level(l)) for l in range(len(sizes))], G)
-    got = sums.cpu()
-    cnt = torch.cat([torch.full((B * G * 2,), float(h * ww * (Cout // G))) for h, ww in sizes])
-    np.testing.assert_allclose((got / cnt).numpy(), (ref / cnt).numpy(), rtol=2e-4, atol=2e-5)
-    gamma, beta = (cases.randn(140, Cout).abs() + 0.5).to(DEV), cases.randn(141, Cout).to(DEV)
-    a = o.groupnorm(y, gamma, beta, G, relu=True, out=y.new(Cout), ws=sums, have_sums=True)
-    b = o.groupnorm(y0, gamma, beta, G, relu=True, out=y0.new(Cout))
-    np.testing.assert_allclose(a.data.float().cpu().numpy(), b.data.float().cpu().numpy(), rtol=8e-3, atol=8e-3)
-
-
-@pytest.mark.parametrize('dtype', [BF, torch.float32])
-def test_groupnorm_sums_plain_tensor_splitk_and_refusals(dtype):
-    """... on a plain (B, H, W, C) tensor (one segment per image; 5 images of 7 x 9 pixels in one tile), with the K loop split
-    (the finish kernel runs the epilogue), in f32; and the launches that cannot carry the sums are refused."""
-    o = ops()
-    B, H, W, Cin, Cout, G = 5, 7, 9, 512, 128, 16
-    x, w = cases.randn(150, B, Cin, H, W), cases.randn(151, Cout, Cin, 3, 3) / (9 * Cin) ** 0.5
-    xd, wd = nhwc(x, dtype), o.pack_weight(w.to(DEV), dtype)
-    for tune in ({}, {'conv.splitk_target': 256, 'conv.splitk_minsteps': 1}, {'conv.splitk_target': 0}):
-        sums = torch.zeros(B * G * 2, device=DEV)
-        with o.tuning(**tune):
-            y = o.conv2d(xd, wd, 3, 3, 1, 1, gn_sums=(sums, G))
-        ref = _gn_sums_ref([nchw(y)], G)
-        cnt = float(H * W * Cout // G)
-        np.testing.assert_allclose(sums.cpu().numpy() / cnt, ref.numpy() / cnt, rtol=2e-4, atol=2e-5)
-    sums = torch.zeros(B * G * 2, device=DEV)
-    with pytest.raises(Exception):
-        o.conv2d(xd, wd, 3, 3, 1, 1, gn_sums=(sums, G), relu=True)
-    with pytest.raises(Exception):
-        o.conv2d(xd, wd, 3, 3, 1, 1, gn_sums=(torch.zeros(B * 48 * 2, device=DEV), 48))     # 128 channels in 48 groups
-    with pytest.raises(Exception):
-        o.conv2d(xd, wd, 3, 3, 1, 1, gn_sums=(torch.zeros(B * 64 * 2, device=DEV), 64))     # two channels per group: not a whole vector
-
-
 @pytest.mark.parametrize('kernel', ['conv_glds3_kernel', 'conv_glds3_kernel<pp>', 'conv_glds4_kernel<pp>', 'conv_glds4_kernel<pp,288>', 'conv_glds4_kernel<pp,mf32>'])
 def test_tile_dgrad_forced(kernel):
     """Data gradient of a stride-1 3x3 conv on the tile kernels (flipped weights), with a second gradient of the

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.das_abi_version() == 5 and lib.das_target_arch() == b'gfx950'
+    assert lib.das_abi_version() == 4 and lib.das_target_arch() == b'gfx950'
 
 
 def test_ops_refuse_cpu_tensors():

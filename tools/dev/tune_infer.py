@@ -1,7 +1,7 @@
 """Dev tool: the B = 8 one-stage INFERENCE step (forward + decode, BASELINE configs[1]) under dispatch variations, ONE
 process: for each `key=value[,key=value...]` argument the tuning is set, 3 warm-up + N timed steps run eagerly, the tuning
 is reset; `-r R` interleaves R rounds of all arms (defaults first in every round) and prints median and range of the
-per-round medians. Special keys: DCNF=<0|1> (das_amd.autograd.DCN_FUSED), GNF=<0|1> (das_amd.nn.GN_FUSED_STATS), GRAPH=1 (replay the forward as one hipGraph).
+per-round medians. Special keys: DCNF=<0|1> (das_amd.autograd.DCN_FUSED), GRAPH=1 (replay the forward as one hipGraph).
 usage: tune_infer.py [-n steps] [-r rounds] cfg1 cfg2 ..."""
 import os
 import statistics
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from das_amd import _lib, autograd as ag, graphs, nn as dnn  # noqa: E402
+from das_amd import _lib, autograd as ag, graphs  # noqa: E402
 from das_amd.datasets import SyntheticPoseDataset, collate  # noqa: E402
 
 args = sys.argv[1:]
@@ -41,8 +41,6 @@ def run(cfg):
         k, v = kv.split('=')
         if k == 'DCNF':
             ag.DCN_FUSED = bool(int(v))
-        elif k == 'GNF':
-            dnn.GN_FUSED_STATS = bool(int(v))
         elif k == 'GRAPH':
             graph = bool(int(v))
         else:
@@ -63,7 +61,6 @@ def run(cfg):
     if graph:
         model._graphed_infer = None
     ag.DCN_FUSED = True
-    dnn.GN_FUSED_STATS = True
     _lib.check(lib.das_tuning_reset(), 'reset')
     return ts[N // 2]
 

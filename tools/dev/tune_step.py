@@ -5,7 +5,7 @@ usage: tune_step.py [-n steps] cfg1 cfg2 ...      special keys: WGRAD_BATCH=<n> 
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-if os.environ.get('DASLIB'):   # dev: a variant build of the library
+if os.environ.get('DASLIB'):   # dev: a variant build of the library (csrc/Makefile: make variant VAR=...)
     from das_amd import _lib as _l0
     _l0.LIB_PATH = os.path.join(os.path.dirname(_l0.LIB_PATH), os.environ['DASLIB'])
 import bench
@@ -73,8 +73,6 @@ def run(cfg):
             ag.MASK_BITS = bool(int(v))
         elif k == 'DCNF':
             ag.DCN_FUSED = bool(int(v))
-        elif k == 'GNF':          # GroupNorm sums in the conv epilogue (das_amd.nn.GN_FUSED_STATS)
-            dnn.GN_FUSED_STATS = bool(int(v))
         elif k == 'UPLOADEV':      # 0: the ground truth without its upload events (the detector's side stream then waits for the step before)
             for key in ('gt_poses_3d', 'centers2d', 'depths'):
                 for t in data[key]:
@@ -114,7 +112,6 @@ def run(cfg):
     ms = ts[N // 2]
     ag.WGRAD_BATCH, dnn._FULL_SLOTS, dnn._MID_SLOTS = wb, fs, ms_
     ag.DCN_FUSED = True
-    dnn.GN_FUSED_STATS = True
     ag.SIDE_PP_SHARE = 2
     _hiccup[0] = 0.0
     _bwd_res[0] = 0
