@@ -196,8 +196,12 @@ struct NoCarry {};
 // not overlapped with anything (one workgroup owns the CU), and the step's launches of that kernel never carry bits.
 // MF = 32: the accumulators are 32 x 32 MFMA tiles (conv_glds4_kernel<.., MF = 32>): acc[a][b][r] = channel n0 + wave_n0 + a*32 +
 // 8*(r>>2) + 4*(lane>>5) + (r&3), pixel m0 + wave_m0 + b*32 + (lane&31) — only the staging into the LDS C tile differs.
+// BNB = false: the fused-BatchNorm-backward operands (ConvP::bnb_*) are compiled out — for the launches without them (forward,
+// plain data gradients) on the kernels that are instantiated both ways: with the code merely branched around, those launches ran
+// 2-7 % slower (profiles/r06_epilogue_bnb_template.md). PLAIN = true (with BNB = false): no residual, no ReLU, no sub-grid output
+// either — the training forward (statistics only) and the plain data gradients.
 template <typename OT, int BN, int BMT = 128, typename TL = Tiling<BN, BMT>, bool T2D = false, bool BITS = true, int MF = 16,
-          typename Acc, typename Carry = NoCarry>
+          bool BNB = true, bool PLAIN = false, typename Acc, typename Carry = NoCarry>
 __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* smem, int m0, int n0, Carry&& carry = Carry{}) {
   constexpr bool CARRY = !std::is_same<typename std::decay<Carry>::type, NoCarry>::value;   // (a float[2 * EPVO] otherwise)
   constexpr int TM = TL::TM, TN = TL::TN, NT = TL::NT;
@@ -274,13 +278,14 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
   OT* yg = reinterpret_cast<OT*>(p.y);
   // row of y / residual / bnb tensors that conv output row m goes to
   auto orow = [&](int m) -> long long {
-    if (!p.osub) return m;
+    if (PLAIN || !p.osub) return m;
     const int b = m / p.HoWo, rem = m - b * p.HoWo;
     const int i = rem / p.Wo, j = rem - i * p.Wo;
     return ((long long)b * p.oH + 2 * i + p.oph) * p.oW + 2 * j + p.opw;
   };
-  const OT* rg = reinterpret_cast<const OT*>(p.res);
-  const OT* bxg = reinterpret_cast<const OT*>(p.bnb_raw);   // fused BatchNorm-backward reduction (see ConvP)
+  const OT* const rg = PLAIN ? nullptr : reinterpret_cast<const OT*>(p.res);
+  const bool relu_ = !PLAIN && p.relu != 0;
+  const OT* const bxg = BNB ? reinterpret_cast<const OT*>(p.bnb_raw) : nullptr;   // fused BatchNorm-backward reduction (see ConvP)
   const OT* byg = reinterpret_cast<const OT*>(p.bnb_y);
 #ifdef DAS_EPI_NOBITS   // dev build (make nobits): what do the dynamic bits branches cost the launches that carry no bits?
   constexpr bool BITS_ = false;
@@ -374,11 +379,11 @@ __device__ __forceinline__ void conv_epilogue(Acc& acc, const ConvP& p, char* sm
 #pragma unroll
           for (int j = 0; j < EPVO; ++j) f[j] += r[j];
         }
-        if (p.relu) {
+        if (relu_) {
 #pragma unroll
           for (int j = 0; j < EPVO; ++j) f[j] = fmaxf(f[j], 0.f);
         }
-        uint4 outv = (rg || p.relu) ? Elem<OT>::pack(f) : raw;
+        uint4 outv = (rg || relu_) ? Elem<OT>::pack(f) : raw;
         if (bxg) {
           float x[EPVO];
           Elem<OT>::unpack(xv[u], x);

@@ -169,6 +169,9 @@ __device__ __forceinline__ void dma16_asm(const void* src, unsigned lds_byte_add
                : "memory");
 }
 
+// The launch carries no residual, ReLU, sub-grid output or fused-BatchNorm-backward operands: conv_epilogue's PLAIN variants
+inline bool epilogue_plain(const ConvP& p) { return !p.res && !p.relu && !p.osub && !p.bnb_raw; }
+
 // ---- split-K (ConvP::ksplit > 1): blockIdx.y = s covers K steps [nk*s/ksplit, nk*(s+1)/ksplit) and stores its raw f32
 // accumulators to slab s of the workspace (float4 = 4 consecutive channels of one pixel); splitk_finish_kernel follows.
 __device__ __forceinline__ void splitk_range(const ConvP& p, int nk, int& kt0, int& kt1) {
@@ -386,7 +389,7 @@ struct TilingC64 {
   static __device__ __forceinline__ int wave_n0(int) { return 0; }
 };
 constexpr int C64_WROW = 1168, C64_WBYTES = 64 * C64_WROW, C64_PATCH = 41 * 1024;   // (324 pixels x 128 B, in 1 KiB DMA units)
-template <typename OT, bool BITS>
+template <typename OT, bool BITS, bool BNB = true, bool PLAIN = false>
 __global__ __launch_bounds__(384) void conv3x3_c64_kernel(ConvP p, int ntiles) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -475,9 +478,9 @@ __global__ __launch_bounds__(384) void conv3x3_c64_kernel(ConvP p, int ntiles) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // B: every wave is done reading the patch
     if (p.stats) {   // (wave-uniform)
-      conv_epilogue<OT, 64, 256, TilingC64, true, BITS>(acc, p, buf, tile, 0, carry);
+      conv_epilogue<OT, 64, 256, TilingC64, true, BITS, 16, BNB, PLAIN>(acc, p, buf, tile, 0, carry);
     } else {
-      conv_epilogue<OT, 64, 256, TilingC64, true, BITS>(acc, p, buf, tile, 0);
+      conv_epilogue<OT, 64, 256, TilingC64, true, BITS, 16, BNB, PLAIN>(acc, p, buf, tile, 0);
     }
   }
   if (p.stats) {
@@ -528,7 +531,7 @@ __global__ __launch_bounds__((BN == 256 ? 512 : 2 * BMT)) void splitk_finish_ker
 // BITS = false: the epilogue without the mask-bits operands (conv_common.h), for the launches that carry none — the epilogue
 // of a one-workgroup-per-CU tile kernel overlaps with nothing, and its dynamic bits branches cost the 256 x 128 kernel 4-8 %
 // of a launch (make nobits / tools/dev/train_shapes.py: conv_glds3<pp> 6.2 -> 5.96 ms, conv_glds3 2.8 -> 2.6 ms per step)
-template <typename T, typename OT, bool PP = false, bool BITS = true>
+template <typename T, typename OT, bool PP = false, bool BITS = true, bool BNB = true, bool PLAIN = false>
 __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   constexpr int BN = 128, BMT = 256, NBUF = 3;
   constexpr int EPV = Elem<T>::EPV;
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   } else {
     __syncthreads();  // all LDS reads done before the C tile reuses the buffers
   }
-  conv_epilogue<OT, BN, BMT, Tiling<BN, BMT>, false, BITS>(acc, p, smem, m0, n0);
+  conv_epilogue<OT, BN, BMT, Tiling<BN, BMT>, false, BITS, 16, BNB, PLAIN>(acc, p, smem, m0, n0);
   DAS_STAMP(4);
 }
 
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
 // v_mfma_f32_32x32x16_bf16 — the same twelve 16-byte fragment reads per K step (a lane reads row l & 31, k-group l >> 5 of
 // each 16-deep half: conflict-free under the same row swizzle), 16 MFMAs of 32 cycles instead of 32 of 16; the matrix pipe's
 // ceiling is 15 % higher for the square shape (2382 vs 2075 TF, cdna guide section 3). Tuning key conv.glds4_mfma32.
-template <typename T, typename OT, bool PP, int BMT = 256, int MF = 16>
+template <typename T, typename OT, bool PP, int BMT = 256, int MF = 16, bool BNB = true, bool PLAIN = false>
 __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
   constexpr int BN = 256, NBUF = 4;
   static_assert(BMT == 256 || BMT == 288, "pixel tile: 256 or 288 rows");
@@ -994,7 +997,7 @@ __global__ __launch_bounds__(512) void conv_glds4_kernel(ConvP p) {
     if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); DAS_STAMP(4); return; }
   }
   __syncthreads();  // all LDS reads done before the C tile reuses the buffers
-  conv_epilogue<OT, BN, BMT, Tiling<BN, BMT>, false, true, MF>(acc, p, smem, m0, n0);
+  conv_epilogue<OT, BN, BMT, Tiling<BN, BMT>, false, BNB, MF, BNB, PLAIN>(acc, p, smem, m0, n0);
   DAS_STAMP(4);
 }
 
@@ -1120,6 +1123,10 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
       (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
       (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
       (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
     }
     attr_set = true;
   }
@@ -1136,13 +1143,18 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
     }
     dastune::note_kernel(pp3 ? "conv_glds3_kernel<pp>" : "conv_glds3_kernel");
     t_last_tile_rows = p.mstep ? p.mstep : 256;
-    const bool bits = p.bnb_bits || p.res_bits;
+    const bool bits = p.bnb_bits || p.res_bits, bnb = p.bnb_raw != nullptr;   // (epilogue variants: conv_epilogue's BITS / BNB / PLAIN)
+    const bool plain = epilogue_plain(p);
     if (pp3) {
       if (bits) hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true, true>), dim3(p.nblocks), dim3(512), sm_big, s, p);
-      else hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      else if (bnb) hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      else if (plain) hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true, false, false, true>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      else hipLaunchKernelGGL((conv_glds3_kernel<T, OT, true, false, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
     } else {
       if (bits) hipLaunchKernelGGL((conv_glds3_kernel<T, OT, false, true>), dim3(p.nblocks), dim3(512), sm_big, s, p);
-      else hipLaunchKernelGGL((conv_glds3_kernel<T, OT, false, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      else if (bnb) hipLaunchKernelGGL((conv_glds3_kernel<T, OT, false, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      else if (plain) hipLaunchKernelGGL((conv_glds3_kernel<T, OT, false, false, false, true>), dim3(p.nblocks), dim3(512), sm_big, s, p);
+      else hipLaunchKernelGGL((conv_glds3_kernel<T, OT, false, false, false>), dim3(p.nblocks), dim3(512), sm_big, s, p);
     }
   } else if (glds) {
     const int ks = BN >= 64 ? pick_ksplit(p.nblocks, nk128, 2, 1, (long long)rows * p.Cout, tail) : 1;
@@ -1843,6 +1855,12 @@ bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
       (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
       (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
       (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true, 288>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4x);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, false, 256, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true, 256, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true, 288, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4x);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, false, 256, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true, 256, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      (void)hipFuncSetAttribute((const void*)conv_glds4_kernel<T, OT, true, 288, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4x);
       attr_set = true;
     }
     if (ks4 > 1) {
@@ -1864,7 +1882,9 @@ bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
       p.nblocks = (int)nb288;
       t_last_tile_rows = 288;
       dastune::note_kernel("conv_glds4_kernel<pp,288>");
-      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 288>), dim3(p.nblocks), dim3(512), sm4x, s, p);
+      if (p.bnb_raw) hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 288>), dim3(p.nblocks), dim3(512), sm4x, s, p);
+      else if (epilogue_plain(p)) hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 288, 16, false, true>), dim3(p.nblocks), dim3(512), sm4x, s, p);
+      else hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 288, 16, false>), dim3(p.nblocks), dim3(512), sm4x, s, p);
       return true;
     }
     int mt = (int)keep;
@@ -1892,9 +1912,13 @@ bool try_launch4(const ConvP& p0, bool glds, bool aligned, hipStream_t s) {
       }
     }
     if (pp) {
-      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 256>), dim3(p.nblocks), dim3(512), sm4, s, p);
+      if (p.bnb_raw) hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 256>), dim3(p.nblocks), dim3(512), sm4, s, p);
+      else if (epilogue_plain(p)) hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 256, 16, false, true>), dim3(p.nblocks), dim3(512), sm4, s, p);
+      else hipLaunchKernelGGL((conv_glds4_kernel<T, OT, true, 256, 16, false>), dim3(p.nblocks), dim3(512), sm4, s, p);
     } else {
-      hipLaunchKernelGGL((conv_glds4_kernel<T, OT, false, 256>), dim3(p.nblocks), dim3(512), sm4, s, p);
+      if (p.bnb_raw) hipLaunchKernelGGL((conv_glds4_kernel<T, OT, false, 256>), dim3(p.nblocks), dim3(512), sm4, s, p);
+      else if (epilogue_plain(p)) hipLaunchKernelGGL((conv_glds4_kernel<T, OT, false, 256, 16, false, true>), dim3(p.nblocks), dim3(512), sm4, s, p);
+      else hipLaunchKernelGGL((conv_glds4_kernel<T, OT, false, 256, 16, false>), dim3(p.nblocks), dim3(512), sm4, s, p);
     }
     return true;
   } else {
@@ -1921,7 +1945,9 @@ bool try_launch_c64(const ConvP& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<OT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_c64_kernel<OT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+        hipFuncSetAttribute((const void*)conv3x3_c64_kernel<OT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_c64_kernel<OT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_c64_kernel<OT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
       return false;
     attr_set = true;
   }
@@ -1929,8 +1955,12 @@ bool try_launch_c64(const ConvP& p, hipStream_t s) {
   dastune::note_kernel("conv3x3_c64_kernel");
   if (p.bnb_bits || p.res_bits) {
     hipLaunchKernelGGL((conv3x3_c64_kernel<OT, true>), dim3(grid), dim3(384), sm, s, p, ntiles);
-  } else {   // (the step's launches: conv2 of a bottleneck never sees a mask as bits)
+  } else if (p.bnb_raw) {   // (the step's launches: conv2 of a bottleneck never sees a mask as bits)
     hipLaunchKernelGGL((conv3x3_c64_kernel<OT, false>), dim3(grid), dim3(384), sm, s, p, ntiles);
+  } else if (epilogue_plain(p)) {
+    hipLaunchKernelGGL((conv3x3_c64_kernel<OT, false, false, true>), dim3(grid), dim3(384), sm, s, p, ntiles);
+  } else {
+    hipLaunchKernelGGL((conv3x3_c64_kernel<OT, false, false>), dim3(grid), dim3(384), sm, s, p, ntiles);
   }
   return true;
 }
