@@ -40,7 +40,7 @@ namespace {
 // =============================================================== generic register-staged kernel
 __device__ __forceinline__ int slot64(int row, int kg) { return row * 64 + ((kg ^ ((-(row >> 2)) & 3)) << 4); }
 
-template <typename T, typename OT, int BN, bool ALIGNED>
+template <typename T, typename OT, int BN, bool ALIGNED, int EPI = 0>   // (EPI: conv_epilogue's variant, as for conv_glds_kernel)
 __global__ __launch_bounds__(256) void conv_reg_kernel(ConvP p) {
   constexpr int EPV = Elem<T>::EPV;
   constexpr int BK = 4 * EPV;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_reg_kernel(ConvP p) {
     if (kt + 1 < nk) stash(buf ^ 1);
     __syncthreads();
   }
-  conv_epilogue<OT, BN>(acc, p, smem, m0, n0);
+  conv_epilogue<OT, BN, 128, Tiling<BN>, false, EPI == 0, 16, EPI == 0, EPI == 2>(acc, p, smem, m0, n0);
 }
 
 // =============================================================== global_load_lds fast path
@@ -250,7 +250,8 @@ __device__ __forceinline__ bool splitk_arrive_and_reduce(Acc& acc, const ConvP& 
   return true;
 }
 
-template <typename T, typename OT, int BN, int BMT>
+// EPI: conv_epilogue's variant — 0 everything decided at run time, 1 no fused-BatchNorm-backward operands, 2 PLAIN (epilogue_plain)
+template <typename T, typename OT, int BN, int BMT, int EPI = 0>
 __global__ __launch_bounds__(2 * BMT, 2) void conv_glds_kernel(ConvP p) {   // (two workgroups per CU: at most 256 registers)
   constexpr int EPV = Elem<T>::EPV;
   constexpr int BK = 8 * EPV;  // 128 bytes of K per row
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(2 * BMT, 2) void conv_glds_kernel(ConvP p) {   // (
     __syncthreads();  // prefetch landed (vmcnt 0) and every wave is done reading `buf`
   }
   if (p.ksplit > 1) { splitk_store<BN, BMT>(acc, p, logical); return; }
-  conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
+  conv_epilogue<OT, BN, BMT, Tiling<BN, BMT>, false, EPI == 0, 16, EPI == 0, EPI == 2>(acc, p, smem, m0, n0);
 }
 
 // =============================================================== 3x3, 64 -> 64 channels, stride 1 (stage-1 bottlenecks)
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(384) void conv3x3_c64_kernel(ConvP p, int ntiles) {
 // Second half of a split-K convolution: same grid and tile map as the tile-kernel launch it follows; every lane sums
 // its accumulator positions over the slabs (fixed order: deterministic) and the shared epilogue does the rest
 // (scale / shift, C tile through LDS, statistics, residual, ReLU, fused BatchNorm-backward sums, 16-byte stores).
-template <typename OT, int BN, int BMT>
+template <typename OT, int BN, int BMT, int EPI = 0>   // (EPI as for conv_glds_kernel)
 __global__ __launch_bounds__((BN == 256 ? 512 : 2 * BMT)) void splitk_finish_kernel(ConvP p) {
   constexpr int TM = Tiling<BN, BMT>::TM, TN = Tiling<BN, BMT>::TN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -520,7 +521,7 @@ __global__ __launch_bounds__((BN == 256 ? 512 : 2 * BMT)) void splitk_finish_ker
         acc[a][b][0] += v.x; acc[a][b][1] += v.y; acc[a][b][2] += v.z; acc[a][b][3] += v.w;
       }
   }
-  conv_epilogue<OT, BN, BMT>(acc, p, smem, m0, n0);
+  conv_epilogue<OT, BN, BMT, Tiling<BN, BMT>, false, EPI == 0, 16, EPI == 0, EPI == 2>(acc, p, smem, m0, n0);
 }
 
 // =============================================================== 3-stage pipeline, 256 x 128 tile, 8 waves
@@ -1037,12 +1038,16 @@ int launch_splitk(Kern kern, ConvP& p, int ks, size_t sm, hipStream_t s) {
   const size_t sm_fin = epilogue_smem_bytes<OT, BN, BMT>();
   if (!fin_attr) {
     (void)hipFuncSetAttribute((const void*)splitk_finish_kernel<OT, BN, BMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_fin);
+    (void)hipFuncSetAttribute((const void*)splitk_finish_kernel<OT, BN, BMT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_fin);
+    (void)hipFuncSetAttribute((const void*)splitk_finish_kernel<OT, BN, BMT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_fin);
     fin_attr = true;
   }
   constexpr int NT = Tiling<BN, BMT>::NT;
   hipLaunchKernelGGL(kern, dim3(p.nblocks, ks), dim3(NT), sm, s, p);
   DAS_CHECK_LAUNCH();
-  hipLaunchKernelGGL((splitk_finish_kernel<OT, BN, BMT>), dim3(p.nblocks), dim3(NT), sm_fin, s, p);
+  if (p.bnb_raw) hipLaunchKernelGGL((splitk_finish_kernel<OT, BN, BMT>), dim3(p.nblocks), dim3(NT), sm_fin, s, p);
+  else if (epilogue_plain(p)) hipLaunchKernelGGL((splitk_finish_kernel<OT, BN, BMT, 2>), dim3(p.nblocks), dim3(NT), sm_fin, s, p);
+  else hipLaunchKernelGGL((splitk_finish_kernel<OT, BN, BMT, 1>), dim3(p.nblocks), dim3(NT), sm_fin, s, p);
   DAS_CHECK_LAUNCH();
   return DAS_OK;
 }
@@ -1117,7 +1122,11 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
     (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
+    (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
+    (void)hipFuncSetAttribute((const void*)conv_reg_kernel<T, OT, BN, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_reg);
     (void)hipFuncSetAttribute((const void*)conv_glds_kernel<T, OT, BN, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_glds);
+    (void)hipFuncSetAttribute((const void*)conv_glds_kernel<T, OT, BN, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_glds);
+    (void)hipFuncSetAttribute((const void*)conv_glds_kernel<T, OT, BN, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_glds);
     if (BN == 128) {
       (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
       (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
@@ -1163,13 +1172,17 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
       return launch_splitk<OT, BN, 128>(conv_glds_kernel<T, OT, BN, 128>, p, ks, sm_glds, s);
     }
     dastune::note_kernel("conv_glds_kernel");
-    hipLaunchKernelGGL((conv_glds_kernel<T, OT, BN, 128>), dim3(p.nblocks), dim3(256), sm_glds, s, p);
+    if (p.bnb_raw) hipLaunchKernelGGL((conv_glds_kernel<T, OT, BN, 128>), dim3(p.nblocks), dim3(256), sm_glds, s, p);
+    else if (epilogue_plain(p)) hipLaunchKernelGGL((conv_glds_kernel<T, OT, BN, 128, 2>), dim3(p.nblocks), dim3(256), sm_glds, s, p);
+    else hipLaunchKernelGGL((conv_glds_kernel<T, OT, BN, 128, 1>), dim3(p.nblocks), dim3(256), sm_glds, s, p);
   } else if (aligned) {
     dastune::note_kernel("conv_reg_kernel");
-    hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, true>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
+    if (epilogue_plain(p)) hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, true, 2>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
+    else hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, true>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
   } else {
     dastune::note_kernel("conv_reg_kernel");
-    hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, false>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
+    if (epilogue_plain(p)) hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, false, 2>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
+    else hipLaunchKernelGGL((conv_reg_kernel<T, OT, BN, false>), dim3(p.nblocks), dim3(256), sm_reg, s, p);
   }
   DAS_CHECK_LAUNCH();
   return DAS_OK;

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(DNT) void dcn3x3_fused_kernel(ConvP p, DcnP d) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing stand-in loads / DMAs: the epilogue reuses the stages
   __builtin_amdgcn_s_barrier();
 #undef DCN_WAIT
-  conv_epilogue<T, DBN, DBM>(acc, p, smem, (int)m0, 0);
+  // (bias only: the PLAIN variant of the epilogue — no residual, ReLU, sub-grid output or fused-BatchNorm-backward code)
+  conv_epilogue<T, DBN, DBM, Tiling<DBN, DBM>, false, false, 16, false, true>(acc, p, smem, (int)m0, 0);
 }
 }  // namespace
 
