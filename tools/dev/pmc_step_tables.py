@@ -31,16 +31,31 @@ def per_kernel(db, counter=None):
     return out, dur
 
 
+def targs(k):
+    """template arguments of a normalised kernel name: 'conv_glds3_kernel<bf16, bf16, true, false>' -> ['bf16', 'bf16', 'true', 'false']"""
+    i = k.find('<')
+    return [a.strip() for a in k[i + 1:k.rfind('>')].split(',')] if i >= 0 else []
+
+
+def _glds3(pp):     # conv_glds3_kernel<T, OT, PP, BITS, BNB, PLAIN>
+    return lambda k: k.startswith('conv_glds3_kernel<') and targs(k)[2] == ('true' if pp else 'false')
+
+
+def _glds4(pp, bmt):     # conv_glds4_kernel<T, OT, PP, BMT, MF, BNB, PLAIN>
+    return lambda k: k.startswith('conv_glds4_kernel<') and targs(k)[2] == ('true' if pp else 'false') and targs(k)[3] == str(bmt)
+
+
 FAMILIES = (   # bench.py family tag -> matcher on the normalised kernel name
-    ('conv_glds4_kernel<pp,288>', lambda k: k.startswith('conv_glds4_kernel<') and k.endswith('true, 288>')),
-    ('conv_glds4_kernel<pp>', lambda k: k.startswith('conv_glds4_kernel<') and k.endswith('true, 256>')),
-    ('conv_glds3_kernel<pp>', lambda k: k.startswith('conv_glds3_kernel<') and k.endswith('true>')),
-    ('conv_glds3_kernel', lambda k: k.startswith('conv_glds3_kernel<') and k.endswith('false>')),
+    ('conv_glds4_kernel<pp,288>', _glds4(True, 288)),
+    ('conv_glds4_kernel<pp>', _glds4(True, 256)),
+    ('conv_glds3_kernel<pp>', _glds3(True)),
+    ('conv_glds3_kernel', _glds3(False)),
     ('conv_glds_kernel', lambda k: k.startswith('conv_glds_kernel<')),
     ('conv_reg_kernel', lambda k: k.startswith('conv_reg_kernel<')),
     ('conv1x1_stream_kernel', lambda k: k.startswith('conv1x1_stream_kernel<')),
     ('conv1x1_kstream_kernel', lambda k: k.startswith('conv1x1_kstream_kernel<')),
     ('conv3x3_c64_kernel', lambda k: k.startswith('conv3x3_c64_kernel<')),
+    ('conv_stem7x7_kernel', lambda k: k.startswith('conv_stem7x7_kernel<')),
     ('conv_wgrad_pp_kernel', lambda k: k == 'conv_wgrad_pp_kernel' or 'AccMap256' in k),
     ('conv_wgrad_kernel<bf16>', lambda k: k.startswith('conv_wgrad_kernel<') or 'AccMap128' in k or k.startswith('conv_wgrad_c64_kernel')
      or k.startswith('wgrad_c64_reduce_kernel')),
