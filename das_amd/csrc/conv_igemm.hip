@@ -1563,7 +1563,7 @@ __global__ __launch_bounds__(640) void conv1x1_stream_kernel(ConvP p, int ncol, 
 template <int KB, int MODE>   // K = 32 * KB input channels (KB = 16 / 32)
 __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol, int ntiles) {
   using T = bf16_t;
-  constexpr bool BNB = MODE == 4;
+  constexpr bool BNB = MODE == 4 || MODE == 6;
   constexpr int K = KB * 32, KH = KB / 2;                     // K steps of 32 per wave
   constexpr int PB = KB == 16 ? 2 : 1;                        // 16-pixel blocks per tile: 32-row tiles at K = 512, 16 at K = 1024
   constexpr int TM = 16 * PB, SUBS = K / 64, SUBB = TM * 128, STAGE = SUBS * SUBB;   // (32 KiB per stage either way)
@@ -1674,7 +1674,11 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   float mu[8], is[8], ga[8], be[8];
   const T* bx = reinterpret_cast<const T*>(p.bnb_raw);
-  if constexpr (BNB) {
+  // MODE 6: the ReLU mask comes as recorded bits, a second gradient of the same tensor may be added (itself masked by bits)
+  const T* rgb = MODE == 6 ? reinterpret_cast<const T*>(p.res) : nullptr;
+  const unsigned char* bb = MODE == 6 ? p.bnb_bits : nullptr;
+  const unsigned char* rb = rgb ? p.res_bits : nullptr;
+  if constexpr (MODE == 4) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       mu[j] = cok ? p.bnb_mean[c8 + j] : 0.f; is[j] = cok ? p.bnb_invstd[c8 + j] : 0.f;
@@ -1686,13 +1690,20 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
   asm volatile("" ::: "memory");
   for (int i = 0; i < mine; ++i) {
     const int t = first + i * tstride;
-    v4i_t lx[PB];
+    v4i_t lx[PB], lr[PB];
+    int lb[PB], lrb[PB];
     if constexpr (BNB) {              // the pre-norm rows of this lane's pixels: requested now, used after the MFMAs
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         long long mm = (long long)t * TM + pb * 16 + q;
         mm = mm < p.M ? mm : p.M - 1;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lx[pb]) : "v"(bx + mm * p.bnb_ps + (cok ? c8 : 0)) : "memory");
+        const long long eo = mm * p.bnb_ps + (cok ? c8 : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lx[pb]) : "v"(bx + eo) : "memory");
+        if constexpr (MODE == 6) {
+          asm volatile("global_load_ubyte %0, %1, off" : "=v"(lb[pb]) : "v"(bb + eo / 8) : "memory");
+          if (rgb) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lr[pb]) : "v"(rgb + mm * p.rps + (cok ? c8 : 0)) : "memory");
+          if (rb) asm volatile("global_load_ubyte %0, %1, off" : "=v"(lrb[pb]) : "v"(rb + (mm * p.rps + (cok ? c8 : 0)) / 8) : "memory");
+        }
       }
     }
     f32x4_t acc0[PB], acc1[PB];
@@ -1701,7 +1712,10 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();     // barrier i: the partial sums of tile i are in set i & 1, tile i + 1 has landed
     asm volatile("" ::: "memory");
-    if constexpr (BNB) {
+    if constexpr (MODE == 6) {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[pb]), "+v"(lr[pb]), "+v"(lb[pb]), "+v"(lrb[pb])::"memory");
+    } else if constexpr (BNB) {
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[pb])::"memory");   // (also drains the previous tile's stores)
     }
@@ -1717,8 +1731,23 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
         float x[8];
         Elem<T>::unpack(o, v);            // the conv result as a tile kernel would have staged it (bf16)
         Elem<T>::unpack(__builtin_bit_cast(uint4, lx[pb]), x);
+        if constexpr (MODE == 6) {
+          if (rgb) {
+            float r[8];
+            Elem<T>::unpack(__builtin_bit_cast(uint4, lr[pb]), r);
+            if (rb) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bn_affine(x[j], mu[j], is[j], ga[j], be[j]) > 0.f ? v[j] : 0.f;
+              for (int j = 0; j < 8; ++j) r[j] = ((unsigned)lrb[pb] >> j & 1u) ? r[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += r[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = ((unsigned)lb[pb] >> j & 1u) ? v[j] : 0.f;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = bn_affine(x[j], mu[j], is[j], ga[j], be[j]) > 0.f ? v[j] : 0.f;
+        }
         o = Elem<T>::pack(v);
         Elem<T>::unpack(o, v);            // dZ as stored
         if (m < p.M && cok) {
@@ -1737,6 +1766,7 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
     // per-channel sums: over the 16 pixels (lanes) of a DPP row, then one atomic instruction per wave (stream_stat_flush)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+      if constexpr (MODE == 6) { mu[j] = cok ? p.bnb_mean[c8 + j] : 0.f; is[j] = cok ? p.bnb_invstd[c8 + j] : 0.f; }
       if constexpr (BNB) ssq[j] = is[j] * (ssq[j] - mu[j] * ssum[j]);   // sum dZ * xhat
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
@@ -1756,7 +1786,8 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
 // long-K layers use (tuning key conv.kstream = 1). Returns false when the shape is not its.
 inline bool try_launch_kstream1x1(const ConvP& p, hipStream_t s) {
   // Which launches take this kernel: a bit mask. 1 = K 512 data gradients with the fused BatchNorm backward, 2 = the same at
-  // K 1024, 4 = K 512 forward with Cout 128, 8 = K 512 forward with wider outputs, 16 = K 1024 forward. Default 3: with warm
+  // K 1024, 4 = K 512 forward with Cout 128, 8 = K 512 forward with wider outputs, 16 = K 1024 forward, 32 / 64 = the mask-bits form of
+  // the data gradients at K = 512 / 1024 (MODE 6; 512 -> 2048 at 16 x 26: -0.17 ms per step). Default 35 = 1 + 2 + 32: with warm
   // operands (a micro-benchmark that re-reads one tensor: profiles/r06_kstream_ab.md) every K = 512 case wins, but inside the
   // step, on cold operands, only the fused-BatchNorm-backward launches do (512 -> 128: 54.1 -> 34.6 us, 1024 -> 256: 33.2 ->
   // 29.8); the forward launches are level (512 -> 128: 39.3 -> 39.9) or lose (512 -> 256: 54.9 -> 60.9, 512 -> 512: 85 -> 113:
@@ -1765,12 +1796,19 @@ inline bool try_launch_kstream1x1(const ConvP& p, hipStream_t s) {
   if (mask <= 0) return false;
   const long long min_rows = dastune::get(dastune::CONV_STREAM_MINROWS);
   if (min_rows <= 0 || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.up_sh != 0 || p.relu_in || p.relu ||
-      p.xbytes == 0 || p.M < min_rows || p.osub || p.scale || p.shift || p.res || p.ksplit > 1)
+      p.xbytes == 0 || p.osub || p.scale || p.shift || p.ksplit > 1)
     return false;
   if ((p.Cin != 512 && p.Cin != 1024) || p.Cout % 128 || p.yps % 8 || p.xps % 8) return false;
   const bool bnb = p.bnb_raw != nullptr;
-  if (bnb && !(p.bnb_relu && !p.bnb_y && !p.bnb_bits && p.stats && p.bnb_ps % 8 == 0)) return false;
-  if (!(mask & (bnb ? (p.Cin == 512 ? 1 : 2) : p.Cin == 512 ? (p.Cout == 128 ? 4 : 8) : 16))) return false;
+  // the mask-bits form (`rbm` launches: small-M, wide expand convs' data gradients): bit 32 / 64 of the mask at K = 512 / 1024
+  const bool bitsm = bnb && p.bnb_relu && !p.bnb_y && p.bnb_bits && p.stats && p.bnb_ps % 8 == 0 && (!p.res || p.rps % 8 == 0);
+  if (bitsm) {
+    if (p.M < 4096 || !(mask & (p.Cin == 512 ? 32 : 64))) return false;
+  } else {
+    if (p.M < min_rows || p.res) return false;
+    if (bnb && !(p.bnb_relu && !p.bnb_y && !p.bnb_bits && p.stats && p.bnb_ps % 8 == 0)) return false;
+    if (!(mask & (bnb ? (p.Cin == 512 ? 1 : 2) : p.Cin == 512 ? (p.Cout == 128 ? 4 : 8) : 16))) return false;
+  }
   const int pbk = p.Cin == 512 ? 2 : 1, tm = 16 * pbk;      // pixel blocks / rows per tile (conv1x1_kstream_kernel: PB, TM)
   const int ncol = p.Cout / 128, ntiles = (p.M + tm - 1) / tm;
   const size_t sm = (size_t)4 * tm * p.Cin * 2 + 2 * 4 * 64 * 32 * pbk;   // stages + two sets of partial sums (K = 512: exactly 160 KiB)
@@ -1786,8 +1824,8 @@ inline bool try_launch_kstream1x1(const ConvP& p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sm, s, p, ncol, ntiles);
     return true;
   };
-  if (p.Cin == 512) return bnb ? go(conv1x1_kstream_kernel<16, 4>) : go(conv1x1_kstream_kernel<16, 0>);
-  return bnb ? go(conv1x1_kstream_kernel<32, 4>) : go(conv1x1_kstream_kernel<32, 0>);
+  if (p.Cin == 512) return bitsm ? go(conv1x1_kstream_kernel<16, 6>) : bnb ? go(conv1x1_kstream_kernel<16, 4>) : go(conv1x1_kstream_kernel<16, 0>);
+  return bitsm ? go(conv1x1_kstream_kernel<32, 6>) : bnb ? go(conv1x1_kstream_kernel<32, 4>) : go(conv1x1_kstream_kernel<32, 0>);
 }
 
 // Takes the 1x1, stride-1, bf16 -> bf16 convs with K in {64, 128, 256}, Cout 64 / 128 / a multiple of 256 and enough

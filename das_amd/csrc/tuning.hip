@@ -23,7 +23,7 @@ constexpr Entry kTable[N_KEYS] = {
     {"wgrad.bkm", 32},            {"wgrad.blocks", 0},        {"wgrad.pp_blocks", 0},      {"bn.reduce_blocks", 256},     {"bn.reduce_threads", 256},
     {"bn.vpt", 8},                {"gn.ppb", 0},             {"conv.c64_mintiles", 64},    {"bn.stream_minbytes", 96 << 20},
     {"comm.reserved_cus", 0},  {"elem.upstats_ppb", 0},   {"bn.upmerge_blocks", 512}, {"dcn.fused_minrows", 100000},
-    {"conv.balance_rows", 1},     {"conv.glds4_mfma32", 0},  {"conv.kstream", 3},       {"conv.splitk_inkernel", 0}, {"conv.stream_nt", 0},     {"bn.nt_fwd", 0},          {"bn.nt_bwd", 0},
+    {"conv.balance_rows", 1},     {"conv.glds4_mfma32", 0},  {"conv.kstream", 35},       {"conv.splitk_inkernel", 0}, {"conv.stream_nt", 0},     {"bn.nt_fwd", 0},          {"bn.nt_bwd", 0},
     {"conv.stem7x7", 1},
 };
 std::atomic<long long> g_val[N_KEYS];

@@ -175,6 +175,47 @@ def test_stream_kernel_mask_bits_pipeline_equals_the_y_mask_path(case):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('case', [(16, 16, 26, 512, 2048, True), (2, 47, 53, 512, 256, True), (3, 40, 41, 1024, 128, False),
+                                  (2, 64, 33, 1024, 384, True)])
+def test_kstream_kernel_mask_bits_mode_equals_the_tile_kernels(case):
+    """conv1x1_kstream_kernel MODE 6 (round 6: the fused BatchNorm backward with the ReLU mask as recorded bits, an optional second
+    gradient, plain or masked by its own bits — the data gradients of the wide expand convs at 16 x 26, `rbm` launches) against
+    the tile kernel on the same launch: the same dZ up to the accumulation order (the K halves are summed by two wave groups),
+    the same sums; M % 32 != 0, one column block and sixteen, K = 512 and 1024."""
+    from das_amd import ops as o
+    B, H, W, Cin, Cout, with_res = case
+    dtype = torch.bfloat16
+    dy = nhwc(cases.randn(401, B, Cin, H, W), dtype)
+    w = o.pack_weight((cases.randn(402, Cout, Cin, 1, 1) / Cin ** 0.5).to(DEV), dtype)
+    raw = nhwc(cases.randn(403, B, Cout, H, W) * 1.5 + 0.3, dtype)
+    yd = nhwc(torch.relu(cases.randn(404, B, Cout, H, W)), dtype)
+    res = nhwc(cases.randn(405, B, Cout, H, W), dtype) if with_res else None
+    mean, invstd = (cases.randn(406, Cout) * 0.1).to(DEV), (cases.randn(407, Cout).abs() + 0.5).to(DEV)
+    gamma, beta = (cases.randn(408, Cout).abs() + 0.5).to(DEV), (cases.randn(409, Cout) * 0.2).to(DEV)
+    wts = (2 ** torch.arange(8, device=DEV)).to(torch.int32)
+    bits = ((yd.reshape(-1, 8) > 0).to(torch.int32) * wts).sum(1).to(torch.uint8)
+    rows = B * H * W
+    bnb = o.BnBwd(raw, None, mean, invstd, gamma, beta, True, bits=bits)
+    resargs = [res]
+    if with_res:
+        keep = torch.rand(res.numel(), device=DEV, generator=torch.Generator(device=DEV).manual_seed(7)).reshape(res.shape) > 0.4
+        resargs.append((res, (keep.reshape(-1, 8).to(torch.int32) * wts).sum(1).to(torch.uint8)))
+    for resarg in resargs:
+        outs = []
+        for tune, kern in (({'conv.kstream': 127}, 'conv1x1_kstream_kernel'), ({'conv.kstream': 0}, None)):
+            sums = torch.zeros(4 * 2 * Cout, device=DEV)
+            with o.tuning(**tune):
+                dz = o.conv2d(dy, w, 1, 1, 1, 0, residual=resarg, bn_bwd=bnb, stats=sums)
+                assert (o.last_kernel() == kern) if kern else (o.last_kernel() != 'conv1x1_kstream_kernel'), o.last_kernel()
+            outs.append((dz.float().cpu(), sums.view(4, -1).sum(0).cpu().numpy() / rows))
+        a, b = outs[0][0], outs[1][0]
+        assert bool(((a == 0) == (b == 0)).all())                    # the same mask
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=8e-3, atol=8e-3)
+        assert float((a != b).float().mean()) < 0.02                 # (bf16 roundings of sums taken in another order)
+        np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=2e-3, atol=2e-4)
+        assert 0.2 < float((a == 0).float().mean()) < 0.8
+
+
 def _mspn_grads(dtype, fused, flat=False, blocks=(2, 2, 2, 2), stages=2):
     import das_amd
     from das_amd import backbones
