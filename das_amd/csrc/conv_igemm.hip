@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
   float mu[8], is[8], ga[8], be[8];
   const T* bx = reinterpret_cast<const T*>(p.bnb_raw);
   // MODE 6: the ReLU mask comes as recorded bits, a second gradient of the same tensor may be added (itself masked by bits)
-  const T* rgb = MODE == 6 ? reinterpret_cast<const T*>(p.res) : nullptr;
+  const T* rgb = (MODE == 6 || MODE == 2) ? reinterpret_cast<const T*>(p.res) : nullptr;   // (MODE 2: y = conv + residual, nothing else)
   const unsigned char* bb = MODE == 6 ? p.bnb_bits : nullptr;
   const unsigned char* rb = rgb ? p.res_bits : nullptr;
   if constexpr (MODE == 4) {
@@ -1692,6 +1692,14 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
     const int t = first + i * tstride;
     v4i_t lx[PB], lr[PB];
     int lb[PB], lrb[PB];
+    if constexpr (MODE == 2) {        // the residual rows of this lane's pixels: requested now, used after the MFMAs
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        long long mm = (long long)t * TM + pb * 16 + q;
+        mm = mm < p.M ? mm : p.M - 1;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lr[pb]) : "v"(rgb + mm * p.rps + (cok ? c8 : 0)) : "memory");
+      }
+    }
     if constexpr (BNB) {              // the pre-norm rows of this lane's pixels: requested now, used after the MFMAs
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
@@ -1715,6 +1723,9 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
     if constexpr (MODE == 6) {
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[pb]), "+v"(lr[pb]), "+v"(lb[pb]), "+v"(lrb[pb])::"memory");
+    } else if constexpr (MODE == 2) {
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lr[pb])::"memory");
     } else if constexpr (BNB) {
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lx[pb])::"memory");   // (also drains the previous tile's stores)
@@ -1754,6 +1765,13 @@ __global__ __launch_bounds__(512) void conv1x1_kstream_kernel(ConvP p, int ncol,
 #pragma unroll
           for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * x[j]; }   // (sum dZ * raw: centred below)
         }
+      } else if constexpr (MODE == 2) {
+        float r[8];
+        Elem<T>::unpack(o, v);            // the conv result as a tile kernel would have staged it (bf16)
+        Elem<T>::unpack(__builtin_bit_cast(uint4, lr[pb]), r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+        o = Elem<T>::pack(v);
       } else if (p.stats && m < p.M && cok) {
         Elem<T>::unpack(o, v);            // the values as stored
 #pragma unroll
@@ -1804,6 +1822,8 @@ inline bool try_launch_kstream1x1(const ConvP& p, hipStream_t s) {
   const bool bitsm = bnb && p.bnb_relu && !p.bnb_y && p.bnb_bits && p.stats && p.bnb_ps % 8 == 0 && (!p.res || p.rps % 8 == 0);
   if (bitsm) {
     if (p.M < 4096 || !(mask & (p.Cin == 512 ? 32 : 64))) return false;
+  } else if (p.res && !bnb) {   // plain output + residual (MODE 2): bit 128 / 256 at K = 512 / 1024
+    if (p.M < min_rows || p.stats || p.rps % 8 || !(mask & (p.Cin == 512 ? 128 : 256))) return false;
   } else {
     if (p.M < min_rows || p.res) return false;
     if (bnb && !(p.bnb_relu && !p.bnb_y && !p.bnb_bits && p.stats && p.bnb_ps % 8 == 0)) return false;
@@ -1824,8 +1844,10 @@ inline bool try_launch_kstream1x1(const ConvP& p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sm, s, p, ncol, ntiles);
     return true;
   };
-  if (p.Cin == 512) return bitsm ? go(conv1x1_kstream_kernel<16, 6>) : bnb ? go(conv1x1_kstream_kernel<16, 4>) : go(conv1x1_kstream_kernel<16, 0>);
-  return bitsm ? go(conv1x1_kstream_kernel<32, 6>) : bnb ? go(conv1x1_kstream_kernel<32, 4>) : go(conv1x1_kstream_kernel<32, 0>);
+  const bool resm = p.res && !bnb;
+  if (p.Cin == 512)
+    return bitsm ? go(conv1x1_kstream_kernel<16, 6>) : resm ? go(conv1x1_kstream_kernel<16, 2>) : bnb ? go(conv1x1_kstream_kernel<16, 4>) : go(conv1x1_kstream_kernel<16, 0>);
+  return bitsm ? go(conv1x1_kstream_kernel<32, 6>) : resm ? go(conv1x1_kstream_kernel<32, 2>) : bnb ? go(conv1x1_kstream_kernel<32, 4>) : go(conv1x1_kstream_kernel<32, 0>);
 }
 
 // Takes the 1x1, stride-1, bf16 -> bf16 convs with K in {64, 128, 256}, Cout 64 / 128 / a multiple of 256 and enough

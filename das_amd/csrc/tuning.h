@@ -52,7 +52,8 @@ enum Key {
   CONV_KSTREAM,          // conv1x1_kstream_kernel (weight-stationary, K split over two wave groups) for the 1x1 convs with
                          // K = 512 / 1024, bit mask: 1 / 2 = K 512 / 1024 data gradients with the fused BatchNorm backward,
                          // 4 / 8 = K 512 forward with Cout 128 / wider, 16 = K 1024 forward, 32 / 64 = K 512 / 1024 data gradients with the
-                         // fused BatchNorm backward and the mask as recorded bits (+ a second gradient); default 35, 0 = never
+                         // fused BatchNorm backward and the mask as recorded bits (+ a second gradient), 128 / 256 = K 512 / 1024 plain output + residual
+                         // (measured level with the tile kernels: off); default 35, 0 = never
   CONV_SPLITK_INKERNEL,  // split-K convs on conv_glds3_kernel finish their sum inside the kernel (last arriver per tile) instead of
                          // in splitk_finish_kernel: 0 / 1
   CONV_STREAM_NT,        // conv1x1_stream_kernel: bit 0 the pixel operand's LDS-DMA non-temporal, bit 2 the output stores

@@ -54,7 +54,7 @@ const char* das_target_arch(void);
  * conv.balance_rows (0 off / 1 the 1x1 convs / 2 every conv: see das_conv_last_tile_rows),
  * conv.kstream (bit mask: which 1x1 convs with K = 512 / 1024 take the weight-stationary conv1x1_kstream_kernel: 1 / 2 = K 512 / 1024
  * data gradients with the fused BatchNorm backward, 4 / 8 = K 512 forward with Cout 128 / wider, 16 = K 1024 forward, 32 / 64 = K 512 / 1024
- * data gradients with the mask as recorded bits and an optional second gradient; default 35), conv.splitk_inkernel, conv.glds4_mfma32, conv.stream_nt,
+ * data gradients with the mask as recorded bits and an optional second gradient, 128 / 256 = K 512 / 1024 plain output + residual; default 35), conv.splitk_inkernel, conv.glds4_mfma32, conv.stream_nt,
  * conv.stem7x7 (1: the 7 x 7 stride-2 stem conv on conv_stem7x7_kernel, 0: on the generic conv_reg_kernel),
  * bn.nt_fwd / bn.nt_bwd (bit masks: which operands of the one-shot BatchNorm passes over large tensors use non-temporal
  * loads / stores; see csrc/tuning.h). */

@@ -1018,3 +1018,10 @@ def test_kstream_weight_stationary_1x1_forward_and_statistics(case):
     n = B * H * W
     s_ref = torch.cat([yq.sum((0, 2, 3)), (yq ** 2).sum((0, 2, 3))])
     np.testing.assert_allclose(stats.view(2, -1).sum(0).cpu().numpy() / n, s_ref.numpy() / n, rtol=1e-3, atol=1e-3)
+    # MODE 2: plain output + a residual (a data gradient with a second gradient of the same tensor)
+    res = cases.randn(403, B, Cout, H, W)
+    with o.tuning(**{'conv.kstream': 511, 'conv.stream_minrows': 64}):
+        yr = o.conv2d(xd, wd, 1, 1, 1, 0, residual=nhwc(res))
+        assert o.last_kernel() == 'conv1x1_kstream_kernel', o.last_kernel()
+    # (the sum of two bf16 values, rounded once: exact given the conv's stored value)
+    assert torch.equal(yr, (y.float() + nhwc(res).float()).to(BF))
