@@ -532,7 +532,8 @@ __global__ __launch_bounds__((BN == 256 ? 512 : 2 * BMT)) void splitk_finish_ker
 // BITS = false: the epilogue without the mask-bits operands (conv_common.h), for the launches that carry none — the epilogue
 // of a one-workgroup-per-CU tile kernel overlaps with nothing, and its dynamic bits branches cost the 256 x 128 kernel 4-8 %
 // of a launch (make nobits / tools/dev/train_shapes.py: conv_glds3<pp> 6.2 -> 5.96 ms, conv_glds3 2.8 -> 2.6 ms per step)
-template <typename T, typename OT, bool PP = false, bool BITS = true, bool BNB = true, bool PLAIN = false>
+// SKONLY: a split-K launch whose sum is finished by splitk_finish_kernel — the epilogue is not compiled in (the partial sums leave in register order)
+template <typename T, typename OT, bool PP = false, bool BITS = true, bool BNB = true, bool PLAIN = false, bool SKONLY = false>
 __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   constexpr int BN = 128, BMT = 256, NBUF = 3;
   constexpr int EPV = Elem<T>::EPV;
@@ -714,6 +715,11 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
     nbuf = nbuf == NBUF - 1 ? 0 : nbuf + 1;
   }
   DAS_STAMP(3);
+  if constexpr (SKONLY) {
+    splitk_store<BN, BMT>(acc, p, logical);
+    DAS_STAMP(4);
+    return;
+  } else {
   if (p.ksplit > 1) {
     splitk_store<BN, BMT>(acc, p, logical);
     DAS_STAMP(4);
@@ -724,6 +730,7 @@ __global__ __launch_bounds__(512) void conv_glds3_kernel(ConvP p) {
   }
   conv_epilogue<OT, BN, BMT, Tiling<BN, BMT>, false, BITS, 16, BNB, PLAIN>(acc, p, smem, m0, n0);
   DAS_STAMP(4);
+  }
 }
 
 // =============================================================== 4-stage pipeline, 256 x 256 tile, 8 waves
@@ -1136,6 +1143,8 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
       (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
       (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
       (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
+      (void)hipFuncSetAttribute((const void*)conv_glds3_kernel<T, OT, true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_big);
     }
     attr_set = true;
   }
@@ -1146,8 +1155,11 @@ int launch(const ConvP& p0, bool glds, bool aligned, hipStream_t s, bool may_spl
     if constexpr (BN == 128 && sizeof(OT) == 2) {
       if (ks3 > 1) {
         dastune::note_kernel("conv_glds3_kernel<splitk>");
-        return pp3 ? launch_splitk<OT, 128, 256, true>(conv_glds3_kernel<T, OT, true>, p, ks3, sm_big, s)
-                   : launch_splitk<OT, 128, 256, true>(conv_glds3_kernel<T, OT, false>, p, ks3, sm_big, s);
+        if (dastune::get(dastune::CONV_SPLITK_INKERNEL) == 1)   // (the last arriver of a tile runs the epilogue itself: the full kernel)
+          return pp3 ? launch_splitk<OT, 128, 256, true>(conv_glds3_kernel<T, OT, true>, p, ks3, sm_big, s)
+                     : launch_splitk<OT, 128, 256, true>(conv_glds3_kernel<T, OT, false>, p, ks3, sm_big, s);
+        return pp3 ? launch_splitk<OT, 128, 256>(conv_glds3_kernel<T, OT, true, false, false, false, true>, p, ks3, sm_big, s)
+                   : launch_splitk<OT, 128, 256>(conv_glds3_kernel<T, OT, false, false, false, false, true>, p, ks3, sm_big, s);
       }
     }
     dastune::note_kernel(pp3 ? "conv_glds3_kernel<pp>" : "conv_glds3_kernel");
